@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run ONCE, in the build container).
+
+What pins what
+--------------
+The reference (ZZY816/COM, /root/reference) has no tests or golden vectors, and
+its sparse-conv arithmetic lives in the un-vendored third-party package ``spconv`` which is not
+installed here.  So the fixtures come from the two independent sources that ARE runnable:
+
+* the reference's own pure-torch hot-path modules, imported file-by-file from /root/reference
+  on CPU: MeanVFE, PillarVFE, PointPillarScatter, HeightCompression, DynamicMeanVFE (the latter with
+  a ``.cuda()`` identity patch and a ``torch_scatter.scatter_mean`` stand-in, because the image has
+  neither a GPU nor torch_scatter);
+* ``torch.nn.functional.conv3d`` (fp64) on the densified grid for the sparse-conv semantics
+  (SubM k3; SparseConv3d k3/s2/p1, k3/s2/p(0,1,1), k(3,1,1)/s(2,1,1)/p0 -- the four geometries of
+  pcdet/models/backbones_3d/spconv_backbone.py:191-232), including the active output set (from the
+  occupancy mask) and dX / dW through autograd.
+
+Nothing from /root/reference is copied: only inputs and outputs (data) are stored.  The CPU
+oracle (oracle/) is then checked against these files by tests/test_oracle_golden.py.
+
+Usage:  python tests/golden/make_golden.py   (needs /root/reference; not needed at test time)
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from com_amd.utils import synth  # noqa: E402  (product-side synthetic generator, numpy only)
+from oracle import oracle as O  # noqa: E402  (only used for the hard voxelizer INPUT of G1/G4)
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def ref_module(subdir, name, pkg):
+    """Import /root/reference/<subdir>/<name>.py under a fake parent package `pkg`."""
+    if pkg not in sys.modules:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, subdir)]
+        sys.modules[pkg] = m
+    return importlib.import_module(f"{pkg}.{name}")
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+manifest = {}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    manifest[name] = {
+        "sha256": sha(*[arrays[k] for k in sorted(arrays)]),
+        "arrays": {k: [str(np.asarray(v).dtype), list(np.asarray(v).shape)] for k, v in arrays.items()},
+        "bytes": os.path.getsize(path),
+    }
+    print(f"{name}: {manifest[name]['bytes']} bytes")
+
+
+# ---------------------------------------------------------------------------------------------
+# G1: config 1 (PointPillars, 4k points, B=1): hard voxels -> PillarVFE -> PointPillarScatter
+def g1():
+    torch.manual_seed(7)
+    pts = synth.synth_cloud(0, n_beams=16, n_azimuth=250)              # 4000 points
+    rng, vs = synth.PILLAR_RANGE, synth.PILLAR_VOXEL
+    voxels, coords, nump = O.voxelize_hard(pts, rng, vs, synth.PILLAR_MAX_POINTS, 32000)
+    coords4 = np.pad(coords, ((0, 0), (1, 0)))                          # batch idx 0
+    pv = ref_module("pcdet/models/backbones_3d/vfe", "pillar_vfe", "refvfe")
+    cfg = Cfg(USE_NORM=True, WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, NUM_FILTERS=[64, 64])
+    vfe = pv.PillarVFE(cfg, num_point_features=5, voxel_size=list(vs), point_cloud_range=np.array(rng))
+    # non-trivial BN statistics, then eval mode (fixed weights)
+    with torch.no_grad():
+        for m in vfe.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    vfe.eval()
+    bd = {"voxels": torch.from_numpy(voxels), "voxel_num_points": torch.from_numpy(nump).float(),
+          "voxel_coords": torch.from_numpy(coords4).float()}
+    with torch.no_grad():
+        bd = vfe(bd)
+    pillar_features = bd["pillar_features"].numpy()
+    sc = ref_module("pcdet/models/backbones_2d/map_to_bev", "pointpillar_scatter", "refbev")
+    grid = O.grid_size(rng, vs)
+    scat = sc.PointPillarScatter(Cfg(NUM_BEV_FEATURES=64), grid_size=[int(g) for g in grid])
+    with torch.no_grad():
+        bd = scat(bd)
+    spatial = bd["spatial_features"].numpy()
+    assert spatial.shape == (1, 64, 468, 468)
+    state = {k.replace(".", "__"): v.numpy() for k, v in vfe.state_dict().items()}
+    # the dense map is 56 MB: keep its hash, its sum and a 64x32x32 crop around the sensor
+    save("g1_pillars", points=pts, voxels=voxels, coords=coords, num_points=nump,
+         pillar_features=pillar_features, spatial_crop=spatial[0, :, 218:250, 218:250].copy(),
+         spatial_sha=np.frombuffer(bytes.fromhex(sha(spatial)), dtype=np.uint8),
+         spatial_nnz=np.array([np.count_nonzero(np.abs(spatial).sum(1))]), **{"w__" + k: v for k, v in state.items()})
+
+
+# ---------------------------------------------------------------------------------------------
+# reduced-grid cloud used by G2/G3/G4: range chosen so the grid is (x,y,z) = (96,96,40)
+SMALL_RANGE = (-4.8, -4.8, -2.0, 4.8, 4.8, 4.0)
+SMALL_VOXEL = (0.1, 0.1, 0.15)
+
+
+def small_points(seed, n, batch):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(batch):
+        ctr = rng.uniform(-3.5, 3.5, (12, 3)) * np.array([1, 1, 0.3])
+        which = rng.integers(0, 12, n)
+        p = ctr[which] + rng.normal(0, 0.35, (n, 3)) * np.array([1, 1, 0.5])
+        p[: n // 20] = rng.uniform(-6, 6, (n // 20, 3))                 # some out of range
+        # exact-boundary probes: points exactly on min / max faces and on voxel faces
+        p[n // 20] = [-4.8, 0.0, 0.0]
+        p[n // 20 + 1] = [4.8, 0.0, 0.0]
+        p[n // 20 + 2] = [0.0, 0.0, 4.0]
+        p[n // 20 + 3] = [0.3, -0.7, -2.0]
+        feat = np.concatenate([p, np.tanh(rng.uniform(0, 2, (n, 1))), rng.uniform(0, 1.5, (n, 1))], 1)
+        out.append(feat.astype(np.float32))
+    return out
+
+
+def g2():
+    frames = small_points(11, 1000, 2)
+    pts_b = np.concatenate([np.pad(p, ((0, 0), (1, 0)), constant_values=float(b))
+                            for b, p in enumerate(frames)], 0).astype(np.float32)
+    # stubs: no GPU, no torch_scatter in this image
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n, src.shape[1]), dtype=src.dtype)
+        out.index_add_(0, index, src)
+        cnt = torch.zeros((n,), dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return out / cnt.clamp(min=1).unsqueeze(1)
+
+    ts.scatter_mean = scatter_mean
+    sys.modules["torch_scatter"] = ts
+    old_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        dm = ref_module("pcdet/models/backbones_3d/vfe", "dynamic_mean_vfe", "refvfe")
+        grid = O.grid_size(SMALL_RANGE, SMALL_VOXEL)
+        vfe = dm.DynamicMeanVFE(Cfg(), 5, list(SMALL_VOXEL), [int(g) for g in grid], list(SMALL_RANGE))
+        bd = vfe({"batch_size": 2, "points": torch.from_numpy(pts_b)})
+    finally:
+        torch.Tensor.cuda = old_cuda
+    save("g2_dynamic", points_b=pts_b, voxel_features=bd["voxel_features"].numpy(),
+         voxel_coords=bd["voxel_coords"].numpy().astype(np.int32),
+         range=np.array(SMALL_RANGE, np.float32), voxel_size=np.array(SMALL_VOXEL, np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+def densify(feat, idx, B, shape):
+    d = torch.zeros((B, feat.shape[1]) + tuple(shape), dtype=torch.float64)
+    d[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = feat
+    return d
+
+
+GEOMS = {
+    "subm_k3": dict(subm=True, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1)),
+    "conv_k3_s2_p1": dict(subm=False, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1)),
+    "conv_k3_s2_p011": dict(subm=False, k=(3, 3, 3), s=(2, 2, 2), p=(0, 1, 1)),
+    "conv_k311_s211_p0": dict(subm=False, k=(3, 1, 1), s=(2, 1, 1), p=(0, 0, 0)),
+}
+
+
+def g3():
+    frames = small_points(23, 700, 2)
+    B = 2
+    shape = (41, 96, 96)
+    per = [O.voxelize_hard(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
+    _, coords, _ = O.collate_voxels(per)
+    idx = torch.from_numpy(coords).long()
+    n = coords.shape[0]
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 8, 16
+    out = {"indices": coords, "spatial_shape": np.array(shape, np.int32)}
+    for tag, rounded in (("f32", False), ("bf16in", True)):
+        x = torch.randn((n, cin), generator=g, dtype=torch.float32)
+        if rounded:
+            x = x.bfloat16().float()
+        out[f"x_{tag}"] = x.numpy()
+        for name, geo in GEOMS.items():
+            k = geo["k"]
+            w = (torch.randn((cout, cin) + k, generator=g, dtype=torch.float32) * 0.2)
+            gy_seed = torch.randn((1,), generator=g)
+            if rounded:
+                w = w.bfloat16().float()
+            xd = densify(x.double(), idx, B, shape).requires_grad_(True)
+            wd = w.double().requires_grad_(True)
+            yd = F.conv3d(xd, wd, stride=geo["s"], padding=geo["p"])
+            occ = densify(torch.ones((n, 1), dtype=torch.float64), idx, B, shape)
+            if geo["subm"]:
+                act = occ[:, 0] > 0
+            else:
+                act = F.conv3d(occ, torch.ones((1, 1) + k, dtype=torch.float64), stride=geo["s"],
+                               padding=geo["p"])[:, 0] > 0.5
+            oidx = act.nonzero()                                          # sorted by (b,z,y,x)
+            y = yd[oidx[:, 0], :, oidx[:, 1], oidx[:, 2], oidx[:, 3]]
+            if geo["subm"]:
+                # keep the INPUT row order for SubM (out rows == in rows)
+                oidx = idx
+                y = yd[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+            gy = torch.randn(y.shape, generator=g, dtype=torch.float32).double()
+            if rounded:
+                gy = gy.float().bfloat16().double()
+            (y * gy).sum().backward()
+            dx = xd.grad[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+            dw = wd.grad                                                   # [cout,cin,kd,kh,kw]
+            # store weights as [K, cin, cout]
+            K = k[0] * k[1] * k[2]
+            w_k = w.reshape(cout, cin, K).permute(2, 1, 0).contiguous().numpy()
+            dw_k = dw.reshape(cout, cin, K).permute(2, 1, 0).contiguous().float().numpy()
+            pre = f"{name}_{tag}_"
+            out[pre + "w"] = w_k
+            out[pre + "out_indices"] = oidx.numpy().astype(np.int32)
+            out[pre + "out_shape"] = np.array(yd.shape[2:], np.int32)
+            out[pre + "y"] = y.detach().float().numpy()
+            out[pre + "gy"] = gy.float().numpy()
+            out[pre + "dx"] = dx.float().numpy()
+            out[pre + "dw"] = dw_k
+            out[pre + "n_pairs"] = np.array([int(round(float(F.conv3d(
+                occ, torch.ones((1, 1) + k, dtype=torch.float64), stride=geo["s"], padding=geo["p"])[
+                    :, 0][act if not geo["subm"] else (occ[:, 0] > 0)].sum())))])
+            del gy_seed
+    save("g3_conv", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def g4():
+    mv = ref_module("pcdet/models/backbones_3d/vfe", "mean_vfe", "refvfe")
+    vfe = mv.MeanVFE(Cfg(), num_point_features=5)
+    frames = small_points(31, 1500, 2)
+    per = [O.voxelize_hard(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
+    voxels, coords, nump = O.collate_voxels(per)
+    bd = vfe({"voxels": torch.from_numpy(voxels), "voxel_num_points": torch.from_numpy(nump).float()})
+    save("g4_meanvfe", points0=frames[0], points1=frames[1], voxels=voxels, coords=coords,
+         num_points=nump, voxel_features=bd["voxel_features"].numpy(),
+         range=np.array(SMALL_RANGE, np.float32), voxel_size=np.array(SMALL_VOXEL, np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+def g5():
+    hc = ref_module("pcdet/models/backbones_2d/map_to_bev", "height_compression", "refbev")
+    rng = np.random.default_rng(3)
+    B, C, D, H, W = 2, 6, 2, 12, 10
+    lin = rng.permutation(B * D * H * W)[:57]
+    idx = np.stack(np.unravel_index(lin, (B, D, H, W)), 1).astype(np.int32)
+    feat = rng.normal(size=(57, C)).astype(np.float32)
+
+    class FakeSp:  # dense() per SURVEY Appendix A.3 (spconv definition)
+        def dense(self):
+            out = torch.zeros((B, D, H, W, C))
+            i = torch.from_numpy(idx).long()
+            out[i[:, 0], i[:, 1], i[:, 2], i[:, 3]] = torch.from_numpy(feat)
+            return out.permute(0, 4, 1, 2, 3).contiguous()
+
+    m = hc.HeightCompression(Cfg(NUM_BEV_FEATURES=C * D))
+    bd = m({"encoded_spconv_tensor": FakeSp(), "encoded_spconv_tensor_stride": 8})
+    save("g5_dense", features=feat, indices=idx, shape=np.array([B, C, D, H, W], np.int32),
+         spatial_features=bd["spatial_features"].numpy())
+
+
+if __name__ == "__main__":
+    g1()
+    g2()
+    g3()
+    g4()
+    g5()
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
