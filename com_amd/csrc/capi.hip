@@ -1,0 +1,24 @@
+// Library info entry points of libpcdops_hip.so.
+#include "common.h"
+
+extern "C" int pcd_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char *pcd_build_arch(void) { return "gfx950"; }
+
+extern "C" const char *pcd_error_string(int code) {
+    switch (code) {
+        case PCD_OK: return "ok";
+        case PCD_ERR_INVALID_ARG: return "invalid argument";
+        case PCD_ERR_UNSUPPORTED: return "unsupported shape / dtype for this build";
+        case PCD_ERR_KEYSPACE: return "batch * D * H * W does not fit the 32-bit coordinate key";
+        case PCD_ERR_WORKSPACE: return "workspace too small";
+        case PCD_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+static thread_local int g_last_hip_error = 0;
+extern "C" void pcd_set_last_hip_error(int code) { g_last_hip_error = code; }
+extern "C" const char *pcd_last_hip_error_string(void) {
+    return hipGetErrorString((hipError_t)g_last_hip_error);
+}

@@ -1,0 +1,409 @@
+// Rulebook construction for sparse 3D convolution on gfx950.
+//
+// Replaces spconv's get_indice_pairs behind spconv.SubMConv3d / spconv.SparseConv3d
+// (pcdet/models/backbones_3d/spconv_backbone.py:12-15); definitions: SURVEY.md Appendix A.4.
+//
+// Two views of every rulebook are produced:
+//   * neighbour tables  nbr[k][row]  (k-major: lanes = consecutive rows -> coalesced) which drive
+//     the output-stationary gather-GEMM kernels (no atomics in the feature path);
+//   * spconv's indice_pairs [K][2][P] + indice_pair_num [K] in canonical order (ascending input row
+//     inside each k), used by the weight-gradient kernel and exported for API parity.
+// Pair compaction is deterministic: per-wave ballot/popcount counts -> row-wise exclusive scan of
+// the small [K][n/64] count matrix -> each wave writes its pairs at (wave offset + lane rank).
+//
+// SubM: coordinate -> row through an open-addressing hash table of packed {key32, row32} 8-byte
+// slots (one CAS to insert, one 8-byte load per probe).
+// Strided conv: active output cells are marked in an occupancy bitmap over the output grid; a
+// popcount prefix over the bitmap words IS the sorted-unique ranking (row id = rank of the linear
+// key), so neither a sort nor a hash table is needed and lookups are 2 loads.
+#include "common.h"
+
+namespace {
+
+struct ConvGeom {
+    int D, H, W;        // input spatial shape
+    int Do, Ho, Wo;     // output spatial shape
+    int kd, kh, kw;
+    int sd, sh, sw;
+    int pd, ph, pw;
+    int dd, dh, dw;
+    int K;
+};
+
+constexpr u64 SLOT_EMPTY = ~0ull;
+
+__device__ __forceinline__ u32 lin_key(int b, int z, int y, int x, int D, int H, int W) {
+    return (((u32)b * D + z) * H + y) * W + x;
+}
+
+__global__ __launch_bounds__(256) void hash_insert_kernel(const int4 *__restrict__ idx, int n, int D,
+                                                          int H, int W, u64 *table, u32 mask) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int4 c = idx[i];
+    u32 key = lin_key(c.x, c.y, c.z, c.w, D, H, W);
+    u64 packed = ((u64)key << 32) | (u32)i;
+    u32 h = hash_u32(key) & mask;
+    for (;;) {
+        u64 prev = atomicCAS(&table[h], SLOT_EMPTY, packed);
+        if (prev == SLOT_EMPTY) break;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int hash_lookup(const u64 *__restrict__ table, u32 mask, u32 key) {
+    u32 h = hash_u32(key) & mask;
+    for (;;) {
+        u64 s = table[h];
+        if (s == SLOT_EMPTY) return -1;
+        if ((u32)(s >> 32) == key) return (int)(u32)s;
+        h = (h + 1) & mask;
+    }
+}
+
+// One thread per output row, loop over the K offsets.  nbr[k][o] = row of (coord_o - c*dil + k*dil).
+// wave_cnt[k][wave] = number of hits of this wave's 64 rows (feeds the pair compaction).
+__global__ __launch_bounds__(256) void subm_probe_kernel(const int4 *__restrict__ idx, int n,
+                                                         ConvGeom G, const u64 *__restrict__ table,
+                                                         u32 mask, int32_t *__restrict__ nbr,
+                                                         int *__restrict__ wave_cnt, int nwaves) {
+    int o = blockIdx.x * 256 + threadIdx.x;
+    bool live = o < n;
+    int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
+    int wave = o >> 6;
+    int k = 0;
+    for (int a = 0; a < G.kd; ++a) {
+        int z = c.y + (a - G.kd / 2) * G.dd;
+        for (int bq = 0; bq < G.kh; ++bq) {
+            int y = c.z + (bq - G.kh / 2) * G.dh;
+            for (int cq = 0; cq < G.kw; ++cq, ++k) {
+                int x = c.w + (cq - G.kw / 2) * G.dw;
+                int r = -1;
+                if (live) {
+                    if (2 * k + 1 == G.K) {
+                        r = o;  // centre offset: the row itself
+                    } else if (z >= 0 && z < G.D && y >= 0 && y < G.H && x >= 0 && x < G.W) {
+                        r = hash_lookup(table, mask, lin_key(c.x, z, y, x, G.D, G.H, G.W));
+                    }
+                    nbr[(size_t)k * n + o] = r;
+                }
+                if (wave_cnt) {
+                    u64 m = __ballot(r >= 0);
+                    if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+                }
+            }
+        }
+    }
+}
+
+// pairs[k] = {(i, tbl[kr][i])} for i ascending, kr = flip ? K-1-k : k  (tbl is an input-stationary
+// view: for SubM the symmetric row of the output-stationary table).
+__global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t *__restrict__ tbl, int n,
+                                                         int K, int flip,
+                                                         const int *__restrict__ wave_off, int nwaves,
+                                                         int32_t *__restrict__ pairs) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int wave = i >> 6;
+    for (int k = 0; k < K; ++k) {
+        int kr = flip ? K - 1 - k : k;
+        int o = (i < n) ? tbl[(size_t)kr * n + i] : -1;
+        int tot;
+        int r = wave_rank(o >= 0, tot);
+        if (o >= 0) {
+            int pos = wave_off[(size_t)kr * nwaves + wave] + r;
+            pairs[((size_t)k * 2 + 0) * n + pos] = i;
+            pairs[((size_t)k * 2 + 1) * n + pos] = o;
+        }
+    }
+}
+
+__global__ void pair_num_kernel(const int *totals, int K, int flip, int32_t *pair_num) {
+    int k = threadIdx.x;
+    if (k < K) pair_num[k] = totals[flip ? K - 1 - k : k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided conv
+__device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int bq, int cq, u32 &key) {
+    int tz = c.y + G.pd - a * G.dd;
+    int ty = c.z + G.ph - bq * G.dh;
+    int tx = c.w + G.pw - cq * G.dw;
+    if (tz < 0 || ty < 0 || tx < 0) return false;
+    int oz = tz / G.sd, oy = ty / G.sh, ox = tx / G.sw;
+    if (oz * G.sd != tz || oy * G.sh != ty || ox * G.sw != tx) return false;
+    if (oz >= G.Do || oy >= G.Ho || ox >= G.Wo) return false;
+    key = lin_key(c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__ idx, int n,
+                                                        ConvGeom G, u32 *bitmap) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int4 c = idx[i];
+    for (int a = 0; a < G.kd; ++a)
+        for (int bq = 0; bq < G.kh; ++bq)
+            for (int cq = 0; cq < G.kw; ++cq) {
+                u32 key;
+                if (!out_cell(G, c, a, bq, cq, key)) continue;
+                u32 bit = 1u << (key & 31);
+                u32 *w = bitmap + (key >> 5);
+                if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+                    atomicOr(w, bit);
+            }
+}
+
+struct PopcWord {
+    const u32 *bitmap;
+    __device__ int operator()(int i) const { return __popc(bitmap[i]); }
+};
+
+__global__ __launch_bounds__(256) void conv_emit_out_kernel(const u32 *__restrict__ bitmap,
+                                                            const int *__restrict__ prefix,
+                                                            int nwords, ConvGeom G, int n_out,
+                                                            int32_t *out_indices) {
+    int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    u32 bits = bitmap[w];
+    int r = prefix[w];
+    while (bits) {
+        int bpos = __ffs(bits) - 1;
+        bits &= bits - 1;
+        u32 key = ((u32)w << 5) + bpos;
+        int x = key % G.Wo;
+        u32 t = key / G.Wo;
+        int y = t % G.Ho;
+        t /= G.Ho;
+        int z = t % G.Do;
+        int b = t / G.Do;
+        if (r < n_out) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(b, z, y, x);
+        ++r;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__ idx, int n,
+                                                        ConvGeom G, const u32 *__restrict__ bitmap,
+                                                        const int *__restrict__ prefix, int n_out,
+                                                        int32_t *__restrict__ nbr_in,
+                                                        int32_t *__restrict__ nbr_out,
+                                                        int *__restrict__ wave_cnt, int nwaves) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    bool live = i < n;
+    int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
+    int wave = i >> 6;
+    int k = 0;
+    for (int a = 0; a < G.kd; ++a)
+        for (int bq = 0; bq < G.kh; ++bq)
+            for (int cq = 0; cq < G.kw; ++cq, ++k) {
+                int o = -1;
+                u32 key;
+                if (live && out_cell(G, c, a, bq, cq, key)) {
+                    u32 w = key >> 5;
+                    o = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
+                    if (o < n_out) nbr_out[(size_t)k * n_out + o] = i; else o = -1;
+                }
+                if (live) nbr_in[(size_t)k * n + i] = o;
+                if (wave_cnt) {
+                    u64 m = __ballot(o >= 0);
+                    if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+                }
+            }
+}
+
+static int make_geom(const int *shape, const int *ks, const int *st, const int *pd, const int *dl,
+                     ConvGeom &G) {
+    for (int d = 0; d < 3; ++d)
+        if (shape[d] <= 0 || ks[d] <= 0 || st[d] <= 0 || pd[d] < 0 || dl[d] <= 0)
+            return PCD_ERR_INVALID_ARG;
+    G.D = shape[0]; G.H = shape[1]; G.W = shape[2];
+    G.kd = ks[0]; G.kh = ks[1]; G.kw = ks[2];
+    G.sd = st[0]; G.sh = st[1]; G.sw = st[2];
+    G.pd = pd[0]; G.ph = pd[1]; G.pw = pd[2];
+    G.dd = dl[0]; G.dh = dl[1]; G.dw = dl[2];
+    G.K = ks[0] * ks[1] * ks[2];
+    int out[3];
+    pcd_conv_out_shape(shape, ks, st, pd, dl, out);
+    G.Do = out[0]; G.Ho = out[1]; G.Wo = out[2];
+    if (G.K > 343) return PCD_ERR_UNSUPPORTED;
+    return PCD_OK;
+}
+
+static u32 table_capacity(int n) {
+    u32 cap = 1024;
+    while (cap < 2u * (u32)(n > 0 ? n : 1)) cap <<= 1;
+    return cap;
+}
+
+struct ConvWs {
+    u32 *bitmap;
+    int *prefix;
+    int *bsums;
+    int *wave_cnt;
+    int *wave_off;
+    int *totals;
+    size_t nwords;
+    int nwaves;
+};
+
+static int conv_ws_layout(void *workspace, size_t bytes, int n, int batch, const ConvGeom &G,
+                          ConvWs &L, size_t *need) {
+    double vol = (double)batch * G.Do * G.Ho * G.Wo;
+    if (vol >= 4294967295.0 || vol <= 0) return PCD_ERR_KEYSPACE;
+    L.nwords = ((size_t)vol + 31) / 32;
+    L.nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    WsCarver ws(workspace, bytes);
+    L.bitmap = ws.take<u32>(L.nwords);
+    L.prefix = ws.take<int>(L.nwords + 1);
+    L.bsums = ws.take<int>(pcd_div_up((int)L.nwords, 256) + 2);
+    L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
+    L.wave_off = ws.take<int>((size_t)G.K * L.nwaves);
+    L.totals = ws.take<int>(G.K);
+    if (need) *need = ws.off;
+    return ws.ok ? PCD_OK : PCD_ERR_WORKSPACE;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int pcd_conv_out_shape(const int *in_shape, const int *ks, const int *st, const int *pd,
+                                  const int *dl, int *out_shape) {
+    if (!in_shape || !ks || !st || !pd || !dl || !out_shape) return PCD_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d) {
+        int num = in_shape[d] + 2 * pd[d] - dl[d] * (ks[d] - 1) - 1;
+        int q = num >= 0 ? num / st[d] : -((-num + st[d] - 1) / st[d]);
+        out_shape[d] = q + 1;
+    }
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol) {
+    if (n < 0 || kvol <= 0) return 0;
+    int nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    return ws_piece(table_capacity(n), sizeof(u64)) + 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) +
+           ws_piece(kvol, sizeof(int));
+}
+
+extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host,
+                                 const int *ksize_host, const int *dil_host, int32_t *nbr,
+                                 int32_t *pairs, int32_t *pair_num, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+    ConvGeom G;
+    int rc = make_geom(shape_host, ksize_host, one, zero, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    if (!(G.kd & 1) || !(G.kh & 1) || !(G.kw & 1)) return PCD_ERR_UNSUPPORTED;  // SubM needs odd kernels
+    if ((double)batch * G.D * G.H * G.W >= 4294967295.0) return PCD_ERR_KEYSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (pair_num) hipMemsetAsync(pair_num, 0, G.K * sizeof(int32_t), st);
+        return PCD_OK;
+    }
+    if (!indices || !nbr) return PCD_ERR_INVALID_ARG;
+    WsCarver ws(workspace, workspace_bytes);
+    u32 tcap = table_capacity(n);
+    int nwaves = pcd_div_up(n, 64);
+    u64 *table = ws.take<u64>(tcap);
+    int *wave_cnt = ws.take<int>((size_t)G.K * nwaves);
+    int *wave_off = ws.take<int>((size_t)G.K * nwaves);
+    int *totals = ws.take<int>(G.K);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    int nb = pcd_div_up(n, 256);
+    hipMemsetAsync(table, 0xFF, (size_t)tcap * sizeof(u64), st);
+    hash_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G.D, G.H, G.W, table, tcap - 1);
+    subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G, table, tcap - 1, nbr,
+                                          pairs ? wave_cnt : nullptr, nwaves);
+    if (pairs) {
+        scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals);
+        hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr, n, G.K, 1, wave_off, nwaves, pairs);
+        pair_num_kernel<<<1, 512, 0, st>>>(totals, G.K, 1, pair_num);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_rulebook_conv_workspace_bytes(int n, int batch, const int *in_shape_host,
+                                                    const int *ksize_host, const int *stride_host,
+                                                    const int *pad_host, const int *dil_host) {
+    ConvGeom G;
+    if (n < 0 || batch <= 0 || !in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
+        return 0;
+    if (make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G) != PCD_OK) return 0;
+    ConvWs L;
+    size_t need = 0;
+    conv_ws_layout(nullptr, 0, n, batch, G, L, &need);
+    return need;
+}
+
+extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
+                                       const int *in_shape_host, const int *ksize_host,
+                                       const int *stride_host, const int *pad_host,
+                                       const int *dil_host, int32_t *n_out_dev, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
+    if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
+        return PCD_ERR_INVALID_ARG;
+    ConvGeom G;
+    int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    if (G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return PCD_ERR_INVALID_ARG;
+    ConvWs L;
+    rc = conv_ws_layout(workspace, workspace_bytes, n, batch, G, L, nullptr);
+    if (rc != PCD_OK) return rc;
+    if (n > 0 && !indices) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(L.bitmap, 0, L.nwords * sizeof(u32), st);
+    if (n > 0)
+        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, G, L.bitmap);
+    PopcWord pw{L.bitmap};
+    rc = scan_exclusive(pw, (int)L.nwords, L.prefix, L.bsums, n_out_dev, st);
+    if (rc != PCD_OK) return rc;
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
+                                      const int *in_shape_host, const int *ksize_host,
+                                      const int *stride_host, const int *pad_host,
+                                      const int *dil_host, int n_out, int32_t *out_indices,
+                                      int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs,
+                                      int32_t *pair_num, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || n_out < 0) return PCD_ERR_INVALID_ARG;
+    if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
+        return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    ConvGeom G;
+    int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    ConvWs L;
+    rc = conv_ws_layout(workspace, workspace_bytes, n, batch, G, L, nullptr);
+    if (rc != PCD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0 || n_out == 0) {
+        if (pair_num) hipMemsetAsync(pair_num, 0, G.K * sizeof(int32_t), st);
+        if (n > 0 && nbr_in) hipMemsetAsync(nbr_in, 0xFF, (size_t)G.K * n * sizeof(int32_t), st);
+        return PCD_OK;
+    }
+    if (!indices || !out_indices || !nbr_in || !nbr_out) return PCD_ERR_INVALID_ARG;
+    conv_emit_out_kernel<<<pcd_div_up((int)L.nwords, 256), 256, 0, st>>>(L.bitmap, L.prefix,
+                                                                        (int)L.nwords, G, n_out,
+                                                                        out_indices);
+    hipMemsetAsync(nbr_out, 0xFF, (size_t)G.K * n_out * sizeof(int32_t), st);
+    int nb = pcd_div_up(n, 256);
+    conv_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G, L.bitmap, L.prefix, n_out,
+                                         nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr, L.nwaves);
+    if (pairs) {
+        scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals);
+        hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr_in, n, G.K, 0, L.wave_off, L.nwaves, pairs);
+        pair_num_kernel<<<1, 512, 0, st>>>(L.totals, G.K, 0, pair_num);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -1,0 +1,420 @@
+// Sparse-convolution arithmetic for gfx950 (replaces spconv's indice_conv fwd / bwd; semantics
+// SURVEY.md A.5; call sites pcdet/models/backbones_3d/spconv_backbone.py:12-17,38-45).
+//
+// Forward and data-gradient: OUTPUT-STATIONARY gather-GEMM.  A wave owns MI*16 output rows and all
+// output channels; the contraction runs over the flattened (kernel offset, input channel) axis in
+// steps of 32 so that one v_mfma_f32_16x16x32_bf16 consumes, per lane, 8 contiguous bf16 (16 B) of
+// ONE gathered feature row: the A/B fragments are filled straight from global memory (L2) with
+// 16-byte loads -- no LDS round trip, no transposition.  Narrow layers pack several offsets into one
+// MFMA step (Cin = 8: 4 offsets / step, Cin = 16: 2).  Operands are swapped (D^T = W^T X^T) so every
+// lane ends with 4 consecutive output channels of one row -> 8/16-byte stores.  Steps whose 16-row
+// tile has no neighbour at all are skipped (wave-uniform ballot test).  No atomics: bit-reproducible.
+// Weights are pre-packed into MFMA fragment order (pcd_pack_weight), one coalesced 1-KiB load per
+// fragment per wave, L2-resident (<= 884 KB per layer).
+//
+// Weight gradient: per kernel offset k a dense  dW_k = X_gathered^T dY_gathered  over the rulebook
+// pairs of k (no wasted MACs).  Each wave stages 32 gathered rows of X and dY in its private LDS
+// slice (16-byte global loads -> ds_write_b128, padded rows), then builds both MFMA operands with the
+// gfx950 transpose read ds_read_b64_tr_b16 (the contraction index = pair index is the slow axis of
+// both row-major tiles).  Waves of a workgroup split the pair range, are reduced through LDS in a
+// fixed order, written to per-split slabs and summed by a second kernel: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+static int log2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+}
+static int pow2_ge8(int c) {
+    int p = 8;
+    while (p < c) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int K, int cin,
+                                                          int cout, int mode, int cshift, int NB,
+                                                          size_t total, unsigned short *out) {
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int j = e & 7;
+    int lane = (e >> 3) & 63;
+    size_t t = e >> 9;
+    int nb = (int)(t % NB);
+    int s = (int)(t / NB);
+    int q = s * 32 + (lane >> 4) * 8 + j;
+    int k = q >> cshift;
+    int c = q & ((1 << cshift) - 1);
+    int col = nb * 16 + (lane & 15);
+    float v = 0.0f;
+    if (k < K) {
+        if (mode == 0) {
+            if (c < cin && col < cout) v = w[((size_t)col * K + k) * cin + c];
+        } else {
+            if (c < cout && col < cin) v = w[((size_t)c * K + k) * cin + col];
+        }
+    }
+    out[e] = f32_to_bf16_bits(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NB, int MI, bool OUT_BF16>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(
+    const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
+    const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
+    int n_out, void *__restrict__ yv, int nsteps) {
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 15;
+    const int g = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * (MI * 16);
+    if (r0 >= n_out) return;
+    const int c_out = NB * 16;
+
+    f32x4 acc[MI][NB];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int rows[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) rows[mi] = r0 + mi * 16 + rl;
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int q0 = s * 32 + g * 8;
+        const int k = q0 >> cshift;
+        const int c0 = q0 & (c_in - 1);
+        const int krow = flip ? (K - 1 - k) : k;
+        uint4 a[MI];
+        bool any = false;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            int i = -1;
+            if (k < K && rows[mi] < n_out) i = nbr[(size_t)krow * nbr_stride + rows[mi]];
+            a[mi] = make_uint4(0, 0, 0, 0);
+            if (i >= 0) {
+                a[mi] = *reinterpret_cast<const uint4 *>(x + (size_t)i * c_in + c0);
+                any = true;
+            }
+        }
+        if (!__any(any)) continue;
+        const uint4 *wps = wp + ((size_t)s * NB) * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bf16x8 b = as_bf16x8(wps[nb * 64]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, as_bf16x8(a[mi]), acc[mi][nb],
+                                                                      0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        int row = rows[mi];
+        if (row >= n_out) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int col = nb * 16 + g * 4;
+            f32x4 v = acc[mi][nb];
+            if (bias) {
+                float4 bv = *reinterpret_cast<const float4 *>(bias + col);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (OUT_BF16) {
+                unsigned short *y = (unsigned short *)yv + (size_t)row * c_out + col;
+                uint2 o;
+                o.x = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(y) = o;
+            } else {
+                float *y = (float *)yv + (size_t)row * c_out + col;
+                *reinterpret_cast<float4 *>(y) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int NB, int MI>
+static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
+                     const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, void *y,
+                     int y_dtype, int nsteps, hipStream_t st) {
+    int rows_per_block = 4 * MI * 16;
+    int grid = pcd_div_up(n_out, rows_per_block);
+    if (y_dtype == PCD_BF16)
+        gather_gemm_kernel<NB, MI, true><<<grid, 256, 0, st>>>(
+            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip,
+            n_out, y, nsteps);
+    else
+        gather_gemm_kernel<NB, MI, false><<<grid, 256, 0, st>>>(
+            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip,
+            n_out, y, nsteps);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+template <int MB, int NBW>
+__global__ __launch_bounds__(256) void wgrad_kernel(
+    const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
+    int cout, const int32_t *__restrict__ pairs, const int32_t *__restrict__ pair_num, int K, int pmax,
+    int pairs_per_wg, int n_cout_chunks, float *__restrict__ slab) {
+    constexpr int CI = MB * 16, CO = NBW * 16;
+    constexpr int XS = CI + 8, YS = CO + 8;  // padded row strides (elements)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    unsigned short *Xs = (unsigned short *)smem + (size_t)wave * 32 * (XS + YS);
+    unsigned short *Ys = Xs + 32 * XS;
+    float *tile = (float *)(smem + (size_t)4 * 32 * (XS + YS) * sizeof(unsigned short));
+
+    const int k = blockIdx.x;
+    const int split = blockIdx.y;
+    const int cic = blockIdx.z / n_cout_chunks;
+    const int coc = blockIdx.z % n_cout_chunks;
+    const int ci0 = cic * CI, co0 = coc * CO;
+    const int P = pair_num[k];
+    const int p_begin = split * pairs_per_wg;
+    int p_end = p_begin + pairs_per_wg;
+    if (p_end > P) p_end = P;
+    const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
+    const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int pr = lane & 31, h = lane >> 5;
+    const int g = lane >> 4, t = lane & 15;
+    for (int p0 = p_begin + wave * 32; p0 < p_end; p0 += 128) {
+        int p = p0 + pr;
+        int i = -1, o = -1;
+        if (p < p_end) {
+            i = pin[p];
+            o = pout[p];
+        }
+        // stage 32 gathered rows of X and dY (this wave's private LDS slice)
+#pragma unroll
+        for (int pc = 0; pc < MB; ++pc) {
+            int c = (pc * 2 + h) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i >= 0 && ci0 + c < cin_pad)
+                v = *reinterpret_cast<const uint4 *>(x + (size_t)i * cin_pad + ci0 + c);
+            *reinterpret_cast<uint4 *>(Xs + pr * XS + c) = v;
+        }
+#pragma unroll
+        for (int pc = 0; pc < NBW; ++pc) {
+            int c = (pc * 2 + h) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o >= 0 && co0 + c < cout)
+                v = *reinterpret_cast<const uint4 *>(dy + (size_t)o * cout + co0 + c);
+            *reinterpret_cast<uint4 *>(Ys + pr * YS + c) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // transpose reads: lane (g,t) supplies the address of 4 bf16 of pair row g*8 + (t>>2)
+        bf16x8 af[MB], bfr[NBW];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const unsigned short *a0 = Xs + (g * 8 + (t >> 2)) * XS + mb * 16 + (t & 3) * 4;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3))) *)(a0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3))) *)(a0 + 4 * XS));
+            s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            af[mb] = __builtin_bit_cast(bf16x8, cat);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const unsigned short *b0 = Ys + (g * 8 + (t >> 2)) * YS + nb * 16 + (t & 3) * 4;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3))) *)(b0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3))) *)(b0 + 4 * YS));
+            s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            bfr[nb] = __builtin_bit_cast(bf16x8, cat);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                acc[mb][nb] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // fixed-order reduction of the 4 waves through LDS: tile[cout_l][cin_l]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int ci = mb * 16 + g * 4 + r;
+                        int co = nb * 16 + t;
+                        float *dst = tile + co * CI + ci;
+                        *dst = (w == 0) ? acc[mb][nb][r] : (*dst + acc[mb][nb][r]);
+                    }
+        }
+        __syncthreads();
+    }
+    // slab[split][cout][K][cin]
+    float *sl = slab + (size_t)split * cout * K * cin;
+    for (int e = threadIdx.x; e < CI * CO; e += 256) {
+        int ci = e % CI, co = e / CI;
+        if (ci0 + ci < cin && co0 + co < cout)
+            sl[((size_t)(co0 + co) * K + k) * cin + ci0 + ci] = tile[co * CI + ci];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int splits,
+                                                           size_t n, float *__restrict__ dw) {
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.0f;
+    for (int q = 0; q < splits; ++q) s += slab[(size_t)q * n + e];
+    dw[e] = s;
+}
+
+static void wgrad_plan(int pmax, int *splits, int *pairs_per_wg) {
+    int s = pcd_div_up(pmax > 0 ? pmax : 1, 4096);
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    int per = pcd_div_up(pmax > 0 ? pmax : 1, s);
+    per = pcd_div_up(per, 128) * 128;
+    *splits = s;
+    *pairs_per_wg = per;
+}
+
+template <int MB, int NBW>
+static int launch_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+                        const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *slab,
+                        hipStream_t st) {
+    constexpr int CI = MB * 16, CO = NBW * 16;
+    int splits, per;
+    wgrad_plan(pmax, &splits, &per);
+    int ncic = pcd_div_up(cin, CI), ncoc = pcd_div_up(cout, CO);
+    size_t lds = (size_t)4 * 32 * (CI + 8 + CO + 8) * 2 + (size_t)CI * CO * 4;
+    dim3 grid(K, splits, ncic * ncoc);
+    wgrad_kernel<MB, NBW><<<grid, 256, lds, st>>>((const unsigned short *)x, cin_pad, cin,
+                                                  (const unsigned short *)dy, cout, pairs, pair_num, K,
+                                                  pmax, per, ncoc, slab);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+static int chunk_blocks(int c) {  // 16-channel blocks per workgroup tile: 1, 2 or 4
+    int b = pcd_div_up(c, 16);
+    return b >= 4 ? 4 : (b >= 2 ? 2 : 1);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" size_t pcd_packed_weight_bytes(int kvol, int cin, int cout, int mode) {
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || (mode != 0 && mode != 1)) return 0;
+    int cc = pow2_ge8(mode == 0 ? cin : cout);
+    int ncol = mode == 0 ? cout : cin;
+    size_t nsteps = ((size_t)kvol * cc + 31) / 32;
+    size_t nb = (ncol + 15) / 16;
+    return nsteps * nb * 64 * 8 * sizeof(unsigned short);
+}
+
+extern "C" int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode,
+                               void *packed, void *stream) {
+    PCD_ENTER();
+    if (!weight || !packed || kvol <= 0 || cin <= 0 || cout <= 0 || (mode != 0 && mode != 1))
+        return PCD_ERR_INVALID_ARG;
+    int cc = pow2_ge8(mode == 0 ? cin : cout);
+    int ncol = mode == 0 ? cout : cin;
+    int nsteps = (kvol * cc + 31) / 32;
+    int NB = (ncol + 15) / 16;
+    size_t total = (size_t)nsteps * NB * 64 * 8;
+    pack_weight_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        weight, kvol, cin, cout, mode, log2_exact(cc), NB, total, (unsigned short *)packed);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w,
+                                           const float *bias, const int32_t *nbr, int nbr_stride,
+                                           int kvol, int flip_k, int n_rows_out, int c_out, void *y,
+                                           int y_dtype, void *stream) {
+    PCD_ENTER();
+    if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
+    if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
+    if (n_rows_out == 0) return PCD_OK;
+    if (!x || !packed_w || !nbr || !y || nbr_stride < n_rows_out) return PCD_ERR_INVALID_ARG;
+    int cshift = log2_exact(c_in);
+    if (cshift < 3 || (c_out % 16) != 0) return PCD_ERR_UNSUPPORTED;
+    int nsteps = (kvol * c_in + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    // two 16-row MFMA tiles per wave once there is enough work to fill the chip
+    bool big = n_rows_out >= 256 * 1024 / 4;
+#define GG(NBv)                                                                                      \
+    return big ? launch_gg<NBv, 2>(x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k,   \
+                                   n_rows_out, y, y_dtype, nsteps, st)                               \
+               : launch_gg<NBv, 1>(x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k,   \
+                                   n_rows_out, y, y_dtype, nsteps, st)
+    switch (c_out / 16) {
+        case 1: GG(1);
+        case 2: GG(2);
+        case 4: GG(4);
+        case 8: GG(8);
+        default: return PCD_ERR_UNSUPPORTED;
+    }
+#undef GG
+}
+
+extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax) {
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0) return 0;
+    int splits, per;
+    wgrad_plan(pmax, &splits, &per);
+    return (size_t)splits * cout * kvol * cin * sizeof(float);
+}
+
+extern "C" int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+                                     const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
+                                     float *dweight, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    PCD_ENTER();
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin) return PCD_ERR_INVALID_ARG;
+    if (!dweight) return PCD_ERR_INVALID_ARG;
+    if ((cin_pad % 8) != 0 || (cout % 8) != 0) return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)cout * kvol * cin;
+    if (pmax == 0) {
+        hipMemsetAsync(dweight, 0, n * sizeof(float), st);
+        return PCD_OK;
+    }
+    if (!x || !dy || !pairs || !pair_num) return PCD_ERR_INVALID_ARG;
+    if (workspace_bytes < pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax) || !workspace)
+        return PCD_ERR_WORKSPACE;
+    float *slab = (float *)workspace;
+    int mb = chunk_blocks(cin), nb = chunk_blocks(cout);
+    int rc = PCD_ERR_UNSUPPORTED;
+#define WG(M, N)                                                                                  \
+    if (mb == M && nb == N)                                                                       \
+        rc = launch_wgrad<M, N>(x, cin_pad, cin, dy, cout, pairs, pair_num, kvol, pmax, slab, st);
+    WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
+#undef WG
+    if (rc != PCD_OK) return rc;
+    int splits, per;
+    wgrad_plan(pmax, &splits, &per);
+    wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(slab, splits, n, dweight);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -1,0 +1,435 @@
+// Point -> voxel scatter for gfx950.
+//
+// Hard voxelisation (reference call site pcdet/datasets/processor/data_processor.py:44-60, algorithm
+// SURVEY.md A.1) is order dependent on the CPU: voxel ids are first-appearance ranks and each voxel
+// keeps its first T points.  The GPU formulation is order free and deterministic:
+//   1. every point hashes its (b,z,y,x) key into an open-addressing table (64-bit keys, CAS) and
+//      pushes its own index through a T-deep "k smallest" cascade of atomicMin's attached to the
+//      slot.  Whatever the interleaving, slot.best[t] ends as the (t+1)-th smallest point index of
+//      the voxel == the reference's t-th kept point; best[0] is the voxel's first point.
+//   2. flag = "I am the first point of my voxel"; an exclusive scan of the flags over the point
+//      buffer (wave ballot/popcount + block scan) gives the first-appearance rank == voxel id.
+//   3. per-frame caps (max_voxels) and the compaction over frames are resolved by a tiny kernel,
+//      then one thread per voxel gathers its <= T points, writes coords / num_points / voxels and
+//      the fused MeanVFE row.
+// Point rows are read with coalesced scalar loads (5 floats/point); index math uses __fsub_rn /
+// __fdiv_rn so no reciprocal or contraction can change floor((p - min) / vsize).
+//
+// Dynamic voxelisation + mean (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72) needs the
+// voxels sorted by key: an occupancy bitmap over the key space + popcount prefix gives every key
+// its rank without sorting.
+#include "common.h"
+
+namespace {
+
+struct VoxGeom {
+    float r0, r1, r2;
+    float v0, v1, v2;
+    int gx, gy, gz;
+};
+
+__device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &G, int &cx, int &cy,
+                                            int &cz) {
+    float fx = floorf(__fdiv_rn(__fsub_rn(p[0], G.r0), G.v0));
+    float fy = floorf(__fdiv_rn(__fsub_rn(p[1], G.r1), G.v1));
+    float fz = floorf(__fdiv_rn(__fsub_rn(p[2], G.r2), G.v2));
+    bool ok = (fx >= 0.0f) && (fx < (float)G.gx) && (fy >= 0.0f) && (fy < (float)G.gy) &&
+              (fz >= 0.0f) && (fz < (float)G.gz);
+    cx = (int)fx;
+    cy = (int)fy;
+    cz = (int)fz;
+    return ok;
+}
+
+__device__ __forceinline__ int frame_of(const int32_t *offs, int batch, int i) {
+    // largest b with offs[b] <= i
+    int lo = 0, hi = batch;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr u64 KEY_EMPTY = ~0ull;
+constexpr u32 IDX_NONE = ~0u;
+
+__global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict__ pts, int n,
+                                                         int stride, int feat_off,
+                                                         const int32_t *__restrict__ offs, int batch,
+                                                         VoxGeom G, int T, u64 *keys, u32 *best,
+                                                         u32 mask, int32_t *pt_slot) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p[0], p[1], p[2]};
+    int cx, cy, cz;
+    if (!voxel_coord(xyz, G, cx, cy, cz)) {
+        pt_slot[i] = -1;
+        return;
+    }
+    int b = frame_of(offs, batch, i);
+    u64 key = (((u64)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+    u32 h = hash_u64(key) & mask;
+    for (;;) {
+        u64 prev = keys[h];
+        if (prev == KEY_EMPTY) prev = atomicCAS(&keys[h], KEY_EMPTY, key);
+        if (prev == KEY_EMPTY || prev == key) break;
+        h = (h + 1) & mask;
+    }
+    pt_slot[i] = (int32_t)h;
+    u32 *slot = best + (size_t)h * T;
+    u32 v = (u32)i;
+    // values only ever decrease: if the last kept index is already smaller we can never enter
+    if (__hip_atomic_load(&slot[T - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) return;
+    for (int t = 0; t < T; ++t) {
+        u32 old = atomicMin(&slot[t], v);
+        if (old == IDX_NONE) break;
+        v = old > v ? old : v;
+    }
+}
+
+struct FirstFlag {
+    const int32_t *pt_slot;
+    const u32 *best;
+    int T;
+    __device__ int operator()(int i) const {
+        int s = pt_slot[i];
+        return (s >= 0 && best[(size_t)s * T] == (u32)i) ? 1 : 0;
+    }
+};
+
+// one block: per-frame counts, caps, output bases
+__global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *rank, int max_voxels,
+                                  int cap, int *frame_rank0, int *frame_base, int32_t *voxel_counts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int b = 0; b < batch; ++b) {
+        int r0 = rank[offs[b]];
+        int r1 = rank[offs[b + 1]];
+        int m = r1 - r0;
+        if (m > max_voxels) m = max_voxels;
+        if (base + m > cap) m = cap - base;
+        frame_rank0[b] = r0;
+        frame_base[b] = base;
+        voxel_counts[b] = m;
+        base += m;
+    }
+    voxel_counts[batch] = base;
+}
+
+__global__ __launch_bounds__(256) void vox_emit_kernel(
+    const float *__restrict__ pts, int n, int stride, int feat_off, int C,
+    const int32_t *__restrict__ offs, int batch, VoxGeom G, int T, const u32 *__restrict__ best,
+    const int32_t *__restrict__ pt_slot, const int *__restrict__ rank, const int *frame_rank0,
+    const int *frame_base, const int32_t *voxel_counts, float *voxels, int32_t *coords,
+    int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int s = pt_slot[i];
+    if (s < 0) return;
+    const u32 *slot = best + (size_t)s * T;
+    if (slot[0] != (u32)i) return;
+    int b = frame_of(offs, batch, i);
+    int vid = rank[i] - frame_rank0[b];
+    if (vid >= voxel_counts[b]) return;  // beyond max_voxels (or capacity)
+    int row = frame_base[b] + vid;
+    const float *p0 = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p0[0], p0[1], p0[2]};
+    int cx, cy, cz;
+    voxel_coord(xyz, G, cx, cy, cz);
+    reinterpret_cast<int4 *>(coords)[row] = make_int4(b, cz, cy, cx);
+    float sum[16];
+    for (int c = 0; c < C; ++c) sum[c] = 0.0f;
+    int np = 0;
+    for (int t = 0; t < T; ++t) {
+        u32 j = slot[t];
+        if (j == IDX_NONE) {
+            if (voxels)
+                for (int c = 0; c < C; ++c) voxels[((size_t)row * T + t) * C + c] = 0.0f;
+            continue;
+        }
+        ++np;
+        const float *p = pts + (size_t)j * stride + feat_off;
+        for (int c = 0; c < C; ++c) {
+            float v = p[c];
+            sum[c] += v;  // same order as voxels.sum(dim=1): t ascending
+            if (voxels) voxels[((size_t)row * T + t) * C + c] = v;
+        }
+    }
+    num_points[row] = np;
+    float norm = np > 0 ? (float)np : 1.0f;
+    if (mean_f32)
+        for (int c = 0; c < C; ++c) mean_f32[(size_t)row * C + c] = __fdiv_rn(sum[c], norm);
+    if (mean_bf16) {
+        for (int c = 0; c < bf16_stride; ++c)
+            mean_bf16[(size_t)row * bf16_stride + c] =
+                c < C ? f32_to_bf16_bits(__fdiv_rn(sum[c], norm)) : (unsigned short)0;
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_vfe_kernel(const float *__restrict__ voxels,
+                                                       const int32_t *__restrict__ nump, int m,
+                                                       int T, int C, float *out) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * C) return;
+    int r = e / C, c = e - r * C;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s += voxels[((size_t)r * T + t) * C + c];
+    float nrm = (float)nump[r];
+    nrm = nrm < 1.0f ? 1.0f : nrm;
+    out[e] = __fdiv_rn(s, nrm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dynamic voxelisation
+__global__ __launch_bounds__(256) void dyn_mark_kernel(const float *__restrict__ pts, int n, int C,
+                                                       VoxGeom G, int batch, u32 *bitmap,
+                                                       u32 *pt_key) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * (C + 1);
+    float xyz[3] = {p[1], p[2], p[3]};
+    int cx, cy, cz;
+    int b = (int)p[0];
+    if (!voxel_coord(xyz, G, cx, cy, cz) || b < 0 || b >= batch) {
+        pt_key[i] = IDX_NONE;
+        return;
+    }
+    // reference key order: b, x, y, z   (dynamic_mean_vfe.py:57-60)
+    u32 key = (((u32)b * G.gx + cx) * G.gy + cy) * G.gz + cz;
+    pt_key[i] = key;
+    u32 bit = 1u << (key & 31);
+    u32 *w = bitmap + (key >> 5);
+    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+}
+
+struct PopcWord {
+    const u32 *bitmap;
+    __device__ int operator()(int i) const { return __popc(bitmap[i]); }
+};
+
+__global__ __launch_bounds__(256) void dyn_emit_coords_kernel(const u32 *__restrict__ bitmap,
+                                                              const int *__restrict__ prefix,
+                                                              int nwords, VoxGeom G, int cap,
+                                                              int32_t *coords) {
+    int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    u32 bits = bitmap[w];
+    int r = prefix[w];
+    while (bits) {
+        int bpos = __ffs(bits) - 1;
+        bits &= bits - 1;
+        u32 key = ((u32)w << 5) + bpos;
+        int cz = key % G.gz;
+        u32 t = key / G.gz;
+        int cy = t % G.gy;
+        t /= G.gy;
+        int cx = t % G.gx;
+        int b = t / G.gx;
+        if (r < cap) reinterpret_cast<int4 *>(coords)[r] = make_int4(b, cz, cy, cx);
+        ++r;
+    }
+}
+
+__global__ __launch_bounds__(256) void dyn_accum_kernel(const float *__restrict__ pts, int n, int C,
+                                                        const u32 *__restrict__ pt_key,
+                                                        const u32 *__restrict__ bitmap,
+                                                        const int *__restrict__ prefix, int cap,
+                                                        float *sums, int *cnt) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32 key = pt_key[i];
+    if (key == IDX_NONE) return;
+    u32 w = key >> 5;
+    int r = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
+    if (r >= cap) return;
+    const float *p = pts + (size_t)i * (C + 1) + 1;
+    for (int c = 0; c < C; ++c) atomicAdd(&sums[(size_t)r * C + c], p[c]);
+    atomicAdd(&cnt[r], 1);
+}
+
+__global__ __launch_bounds__(256) void dyn_finalize_kernel(float *feat, const int *cnt,
+                                                           const int *num_voxels, int cap, int C) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    int m = *num_voxels;
+    if (m > cap) m = cap;
+    if (e >= m * C) return;
+    int r = e / C;
+    feat[e] = __fdiv_rn(feat[e], (float)cnt[r]);
+}
+
+static VoxGeom make_geom(const float *range, const float *vs) {
+    VoxGeom G;
+    G.r0 = range[0]; G.r1 = range[1]; G.r2 = range[2];
+    G.v0 = vs[0]; G.v1 = vs[1]; G.v2 = vs[2];
+    int g[3];
+    for (int j = 0; j < 3; ++j) {
+        double d = ((double)range[j + 3] - (double)range[j]) / (double)vs[j];
+        g[j] = (int)llround(d);  // data_processor.py:127-128
+    }
+    G.gx = g[0]; G.gy = g[1]; G.gz = g[2];
+    return G;
+}
+
+static u32 table_capacity(int n) {
+    u32 cap = 1024;
+    while (cap < 2u * (u32)(n > 0 ? n : 1)) cap <<= 1;
+    return cap;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points, int batch) {
+    if (n_points < 0 || max_points <= 0 || batch <= 0) return 0;
+    u32 cap = table_capacity(n_points);
+    size_t b = 0;
+    b += ws_piece(cap, sizeof(u64));                       // keys
+    b += ws_piece((size_t)cap * max_points, sizeof(u32));  // best
+    b += ws_piece(n_points + 1, sizeof(int32_t));          // pt_slot
+    b += ws_piece(n_points + 1, sizeof(int));              // rank
+    b += ws_piece(pcd_div_up(n_points, 256) + 2, sizeof(int));
+    b += ws_piece(batch + 1, sizeof(int)) * 2;
+    return b;
+}
+
+extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_stride,
+                                 int feat_offset, int num_features, const int32_t *frame_offsets,
+                                 int batch, const float *range_host, const float *vsize_host,
+                                 int max_points, int max_voxels, int cap, float *voxels,
+                                 int32_t *coords, int32_t *num_points, float *mean_f32,
+                                 void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
+        !frame_offsets || !range_host || !vsize_host || !coords || !num_points || !voxel_counts)
+        return PCD_ERR_INVALID_ARG;
+    if (n_points > 0 && !points) return PCD_ERR_INVALID_ARG;
+    if (num_features < 3 || num_features > 16 || point_stride < feat_offset + num_features)
+        return PCD_ERR_UNSUPPORTED;
+    if (mean_bf16 && mean_bf16_stride < num_features) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    if ((double)batch * G.gx * G.gy * G.gz >= 1.8e19) return PCD_ERR_KEYSPACE;
+    if (workspace_bytes < pcd_voxelize_hard_workspace_bytes(n_points, max_points, batch))
+        return PCD_ERR_WORKSPACE;
+    WsCarver ws(workspace, workspace_bytes);
+    u32 tcap = table_capacity(n_points);
+    u64 *keys = ws.take<u64>(tcap);
+    u32 *best = ws.take<u32>((size_t)tcap * max_points);
+    int32_t *pt_slot = ws.take<int32_t>(n_points + 1);
+    int *rank = ws.take<int>(n_points + 1);
+    int *bsums = ws.take<int>(pcd_div_up(n_points, 256) + 2);
+    int *frame_rank0 = ws.take<int>(batch + 1);
+    int *frame_base = ws.take<int>(batch + 1);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    // keys and best are adjacent pieces: one memset to 0xFF covers both sentinels
+    hipMemsetAsync(keys, 0xFF, (size_t)((char *)pt_slot - (char *)keys), st);
+    int nb = pcd_div_up(n_points, 256);
+    if (n_points > 0) {
+        vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
+                                              frame_offsets, batch, G, max_points, keys, best,
+                                              tcap - 1, pt_slot);
+        PCD_RETURN_IF_LAUNCH_FAILED();
+    }
+    FirstFlag ff{pt_slot, best, max_points};
+    int rc = scan_exclusive(ff, n_points, rank, bsums, nullptr, st);
+    if (rc != PCD_OK) return rc;
+    vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
+                                        frame_base, voxel_counts);
+    if (n_points > 0) {
+        vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
+                                            num_features, frame_offsets, batch, G, max_points, best,
+                                            pt_slot, rank, frame_rank0, frame_base, voxel_counts,
+                                            voxels, coords, num_points, mean_f32,
+                                            (unsigned short *)mean_bf16, mean_bf16_stride);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
+                            int num_features, float *out, void *stream) {
+    PCD_ENTER();
+    if (m < 0 || max_points <= 0 || num_features <= 0) return PCD_ERR_INVALID_ARG;
+    if (m == 0) return PCD_OK;
+    if (!voxels || !num_points || !out) return PCD_ERR_INVALID_ARG;
+    mean_vfe_kernel<<<pcd_div_up(m * num_features, 256), 256, 0, (hipStream_t)stream>>>(
+        voxels, num_points, m, max_points, num_features, out);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int dyn_words(int batch, const VoxGeom &G, size_t *nwords) {
+    double vol = (double)batch * G.gx * G.gy * G.gz;
+    if (vol >= 4294967295.0) return PCD_ERR_KEYSPACE;
+    *nwords = ((size_t)vol + 31) / 32;
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_voxelize_dynamic_workspace_bytes(int n_points, int num_features, int batch,
+                                                       const float *range_host,
+                                                       const float *vsize_host) {
+    if (n_points < 0 || batch <= 0 || !range_host || !vsize_host) return 0;
+    (void)num_features;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    size_t nw;
+    if (dyn_words(batch, G, &nw) != PCD_OK) return 0;
+    size_t b = 0;
+    b += ws_piece(nw, sizeof(u32));
+    b += ws_piece(nw + 1, sizeof(int));
+    b += ws_piece(pcd_div_up((int)nw, 256) + 2, sizeof(int));
+    b += ws_piece(n_points + 1, sizeof(u32));
+    b += ws_piece(n_points + 1, sizeof(int));
+    return b;
+}
+
+extern "C" int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, int num_features,
+                                         int batch, const float *range_host,
+                                         const float *vsize_host, int cap, float *features,
+                                         int32_t *coords, int32_t *counts, int32_t *num_voxels,
+                                         void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n_points < 0 || batch <= 0 || cap < 0 || !range_host || !vsize_host || !num_voxels)
+        return PCD_ERR_INVALID_ARG;
+    if (num_features < 3 || num_features > 16) return PCD_ERR_UNSUPPORTED;
+    if (n_points > 0 && (!points_b || !features || !coords)) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    size_t nw;
+    int rc = dyn_words(batch, G, &nw);
+    if (rc != PCD_OK) return rc;
+    WsCarver ws(workspace, workspace_bytes);
+    u32 *bitmap = ws.take<u32>(nw);
+    int *prefix = ws.take<int>(nw + 1);
+    int *bsums = ws.take<int>(pcd_div_up((int)nw, 256) + 2);
+    u32 *pt_key = ws.take<u32>(n_points + 1);
+    int *cnt_ws = ws.take<int>(n_points + 1);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    int *cnt = counts ? counts : cnt_ws;
+    int rows = cap < n_points ? cap : n_points;
+    hipMemsetAsync(bitmap, 0, nw * sizeof(u32), st);
+    if (rows > 0) {
+        hipMemsetAsync(features, 0, (size_t)rows * num_features * sizeof(float), st);
+        hipMemsetAsync(cnt, 0, (size_t)rows * sizeof(int), st);
+    }
+    int nb = pcd_div_up(n_points, 256);
+    if (n_points > 0)
+        dyn_mark_kernel<<<nb, 256, 0, st>>>(points_b, n_points, num_features, G, batch, bitmap,
+                                            pt_key);
+    PopcWord pw{bitmap};
+    rc = scan_exclusive(pw, (int)nw, prefix, bsums, num_voxels, st);
+    if (rc != PCD_OK) return rc;
+    if (n_points > 0) {
+        dyn_emit_coords_kernel<<<pcd_div_up((int)nw, 256), 256, 0, st>>>(bitmap, prefix, (int)nw, G,
+                                                                        cap, coords);
+        dyn_accum_kernel<<<nb, 256, 0, st>>>(points_b, n_points, num_features, pt_key, bitmap,
+                                             prefix, cap, features, cnt);
+        dyn_finalize_kernel<<<pcd_div_up(rows * num_features, 256), 256, 0, st>>>(
+            features, cnt, num_voxels, cap, num_features);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -1,0 +1,43 @@
+"""HeightCompression / PointPillarScatter (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-26,
+pointpillar_scatter.py:14-37) on the single-pass HIP BEV scatter."""
+import torch.nn as nn
+
+from ..spconv import functional as Fsp
+
+
+def _cfg_get(cfg, name):
+    return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+class HeightCompression(nn.Module):
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_bev_features = _cfg_get(model_cfg, 'NUM_BEV_FEATURES')
+
+    def forward(self, batch_dict):
+        sp = batch_dict['encoded_spconv_tensor']
+        # dense() + view(N, C*D, H, W) in one kernel; channel index = c*D + z (height_compression.py:22-23)
+        spatial_features = Fsp.bev_dense(sp.features, sp.indices, sp.batch_size, sp.spatial_shape)
+        batch_dict['spatial_features'] = spatial_features
+        batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
+        return batch_dict
+
+
+class PointPillarScatter(nn.Module):
+    def __init__(self, model_cfg, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_bev_features = _cfg_get(model_cfg, 'NUM_BEV_FEATURES')
+        self.nx, self.ny, self.nz = [int(v) for v in grid_size]
+        assert self.nz == 1
+
+    def forward(self, batch_dict, **kwargs):
+        pillar_features, coords = batch_dict['pillar_features'], batch_dict['voxel_coords']
+        # the reference syncs on coords[:, 0].max().item() (pointpillar_scatter.py:17); batch_size is
+        # already in batch_dict, so no host sync is needed
+        batch_size = batch_dict['batch_size'] if 'batch_size' in batch_dict \
+            else int(coords[:, 0].max().int().item()) + 1
+        out = Fsp.bev_dense(pillar_features, coords.int().contiguous(), batch_size, [self.nz, self.ny, self.nx])
+        batch_dict['spatial_features'] = out
+        return batch_dict

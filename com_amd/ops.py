@@ -1,0 +1,282 @@
+"""Functional host layer over the C ABI (``include/pcd_ops.h``): torch tensors in, torch tensors out.
+
+Every function here calls the HIP library; nothing is computed in Python/torch except buffer
+allocation, the one host read-back of a data-dependent row count, and trivial views.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+PCD_F32, PCD_BF16 = L.PCD_F32, L.PCD_BF16
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return PCD_F32
+    if t.dtype == torch.bfloat16:
+        return PCD_BF16
+    raise L.PcdError(f"unsupported feature dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.PcdError("hot-path ops need HIP device tensors (there is no CPU fallback)")
+
+
+def pow2_ge8(c):
+    p = 8
+    while p < c:
+        p <<= 1
+    return p
+
+
+def grid_size(point_cloud_range, voxel_size):
+    """pcdet/datasets/processor/data_processor.py:127-128"""
+    return [int(round((point_cloud_range[j + 3] - point_cloud_range[j]) / voxel_size[j])) for j in range(3)]
+
+
+# ---------------------------------------------------------------------------------------------
+def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
+                  feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0):
+    """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
+    rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
+    voxel_features, voxel_features_bf16, counts (host list per frame))."""
+    _require_cuda(points)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    dev = points.device
+    n, stride = points.shape
+    C = num_features if num_features is not None else stride - feat_offset
+    if torch.is_tensor(frame_offsets):
+        offs = frame_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    else:
+        offs = torch.tensor(list(frame_offsets), dtype=torch.int32, device=dev)
+    batch = offs.numel() - 1
+    cap = max(1, min(n, batch * max_voxels))
+    lib = L.lib()
+    ws = _ws(lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch), dev)
+    voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, C), dtype=torch.float32, device=dev) if want_mean else None
+    mean16 = (torch.empty((cap, mean_bf16_stride), dtype=torch.bfloat16, device=dev)
+              if mean_bf16_stride else None)
+    counts = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    L.check(lib.pcd_voxelize_hard(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
+                                  L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
+                                  max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
+                                  L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
+                                  L.stream_ptr()), "pcd_voxelize_hard")
+    host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
+    m = host_counts[-1]
+    return dict(voxels=voxels[:m] if want_voxels else None, coords=coords[:m], num_points=nump[:m],
+                voxel_features=mean[:m] if want_mean else None,
+                voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1])
+
+
+def mean_vfe(voxels, num_points):
+    """pcdet/models/backbones_3d/vfe/mean_vfe.py:25-29 on materialised voxels."""
+    _require_cuda(voxels, num_points)
+    voxels = voxels.contiguous().float()
+    nump = num_points.contiguous().to(torch.int32)
+    m, T, C = voxels.shape
+    out = torch.empty((m, C), dtype=torch.float32, device=voxels.device)
+    L.check(L.lib().pcd_mean_vfe(L.ptr(voxels), L.ptr(nump), m, T, C, L.ptr(out), L.stream_ptr()),
+            "pcd_mean_vfe")
+    return out
+
+
+def voxelize_dynamic_mean(points_b, batch_size, point_cloud_range, voxel_size):
+    """pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72: (features [M,C], coords [M,4], counts)."""
+    _require_cuda(points_b)
+    points_b = points_b.contiguous().float()
+    n, c1 = points_b.shape
+    C = c1 - 1
+    dev = points_b.device
+    lib = L.lib()
+    rng, vs = L.host_f32(point_cloud_range), L.host_f32(voxel_size)
+    wsb = lib.pcd_voxelize_dynamic_workspace_bytes(n, C, batch_size, rng, vs)
+    if wsb == 0:
+        raise L.PcdError("pcd_voxelize_dynamic: key space too large for 32-bit keys")
+    ws = _ws(wsb, dev)
+    cap = max(n, 1)
+    feat = torch.empty((cap, C), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.empty((cap,), dtype=torch.int32, device=dev)
+    nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+    L.check(lib.pcd_voxelize_dynamic_mean(L.ptr(points_b), n, C, batch_size, rng, vs, cap, L.ptr(feat),
+                                          L.ptr(coords), L.ptr(cnt), L.ptr(nv), L.ptr(ws), ws.numel(),
+                                          L.stream_ptr()), "pcd_voxelize_dynamic_mean")
+    m = int(nv.item())
+    return feat[:m], coords[:m], cnt[:m]
+
+
+# ---------------------------------------------------------------------------------------------
+class Rulebook:
+    """Device-resident rulebook of one indice_key (what spconv keeps in SparseConvTensor.indice_dict).
+
+    nbr_out [K, n_out]: input row feeding output row o via offset k (or -1)
+    nbr_in  [K, n_in] : output row fed by input row i via offset k (or -1); for SubM it is the k-flipped
+                        view of nbr_out and is not stored (``subm`` flag)
+    pairs [K, 2, n_in], pair_num [K]: spconv's indice_pairs / indice_pair_num, canonical order.
+    """
+
+    def __init__(self, subm, kvol, n_in, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape,
+                 ksize, stride, padding, dilation):
+        self.subm, self.kvol, self.n_in, self.n_out = subm, kvol, n_in, n_out
+        self.nbr_out, self.nbr_in, self.pairs, self.pair_num = nbr_out, nbr_in, pairs, pair_num
+        self.out_indices, self.out_shape = out_indices, list(out_shape)
+        self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+
+    def inverse(self):
+        """Rulebook of SparseInverseConv3d sharing this indice_key."""
+        assert not self.subm
+        pairs = self.pairs.flip(1).contiguous() if self.pairs is not None else None
+        return Rulebook(False, self.kvol, self.n_out, self.n_in, self.nbr_in, self.nbr_out, pairs,
+                        self.pair_num, None, None, self.ksize, self.stride, self.padding, self.dilation)
+
+
+def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
+    out = L.host_i32([0, 0, 0])
+    L.check(L.lib().pcd_conv_out_shape(L.host_i32(_triple(spatial_shape)), L.host_i32(_triple(ksize)),
+                                       L.host_i32(_triple(stride)), L.host_i32(_triple(padding)),
+                                       L.host_i32(_triple(dilation)), out), "pcd_conv_out_shape")
+    return [int(v) for v in out]
+
+
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True):
+    _require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
+    dev = indices.device
+    n = indices.shape[0]
+    ks, dl, shp = _triple(ksize), _triple(dilation), _triple(spatial_shape)
+    K = ks[0] * ks[1] * ks[2]
+    lib = L.lib()
+    ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
+    nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
+    pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
+    pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
+    L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                                  L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), L.ptr(ws),
+                                  ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
+    return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
+                    [k // 2 for k in ks], dl)
+
+
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True):
+    _require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
+    dev = indices.device
+    n = indices.shape[0]
+    ks, st, pd, dl, shp = (_triple(ksize), _triple(stride), _triple(padding), _triple(dilation),
+                           _triple(spatial_shape))
+    K = ks[0] * ks[1] * ks[2]
+    lib = L.lib()
+    args = (L.host_i32(shp), L.host_i32(ks), L.host_i32(st), L.host_i32(pd), L.host_i32(dl))
+    out_shape = conv_out_shape(shp, ks, st, pd, dl)
+    wsb = lib.pcd_rulebook_conv_workspace_bytes(n, batch_size, *args)
+    if wsb == 0:
+        raise L.PcdError("pcd_rulebook_conv: bad geometry or key space too large")
+    ws = _ws(wsb, dev)
+    n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+    L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(ws),
+                                        ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+    n_out = int(n_out_dev.item())          # host sync: data-dependent number of output rows
+    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((K, n), dtype=torch.int32, device=dev)
+    nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+    pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
+    pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
+    L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
+                                       L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
+                                       L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_fill")
+    return Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
+                    pd, dl)
+
+
+# ---------------------------------------------------------------------------------------------
+def pack_weight(weight, mode):
+    """weight [Cout, kd, kh, kw, Cin] f32 (spconv 2.x layout) -> bf16 MFMA-fragment order."""
+    _require_cuda(weight)
+    w = weight.detach().contiguous().float()
+    cout, cin = w.shape[0], w.shape[-1]
+    K = w.numel() // (cout * cin)
+    lib = L.lib()
+    nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
+    packed = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    L.check(lib.pcd_pack_weight(L.ptr(w), K, cin, cout, mode, L.ptr(packed), L.stream_ptr()),
+            "pcd_pack_weight")
+    return packed
+
+
+def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype):
+    """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]  (output-stationary; forward and dgrad)."""
+    _require_cuda(x, packed_w, nbr)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
+    y = torch.empty((n_rows_out, c_out), dtype=out_dtype, device=x.device)
+    L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr),
+                                                nbr.shape[1], kvol, int(flip_k), n_rows_out, c_out,
+                                                L.ptr(y), _dtype_code(y), L.stream_ptr()),
+            "pcd_sparse_conv_gather_gemm")
+    return y
+
+
+def wgrad(x, cin, dy, pairs, pair_num, kvol):
+    """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]."""
+    _require_cuda(x, dy, pairs, pair_num)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    assert x.is_contiguous() and dy.is_contiguous() and pairs.is_contiguous()
+    cout = dy.shape[1]
+    pmax = pairs.shape[2]
+    lib = L.lib()
+    ws = _ws(lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax), x.device)
+    dw = torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
+    L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
+                                      L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
+                                      L.stream_ptr()), "pcd_sparse_conv_wgrad")
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+def bev_scatter(features, indices, batch_size, spatial_shape, channels=None):
+    """dense() + view(N, C*D, H, W): height_compression.py:20-25; D == 1 is PointPillarScatter."""
+    _require_cuda(features, indices)
+    assert features.is_contiguous() and indices.dtype == torch.int32 and indices.is_contiguous()
+    D, H, W = _triple(spatial_shape)
+    n, cs = features.shape
+    C = channels if channels is not None else cs
+    lib = L.lib()
+    out = torch.empty((batch_size, C * D, H, W), dtype=features.dtype, device=features.device)
+    ws = _ws(lib.pcd_bev_workspace_bytes(batch_size, D, H, W), features.device)
+    L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, batch_size,
+                                D, H, W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "pcd_bev_scatter")
+    return out
+
+
+def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None):
+    _require_cuda(dout, indices)
+    dout = dout.contiguous()
+    D, H, W = _triple(spatial_shape)
+    n = indices.shape[0]
+    cs = c_stride if c_stride is not None else channels
+    if cs != channels:
+        df = torch.zeros((n, cs), dtype=dout.dtype, device=dout.device)
+    else:
+        df = torch.empty((n, cs), dtype=dout.dtype, device=dout.device)
+    L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n, batch_size,
+                                   D, H, W, L.ptr(df), L.stream_ptr()), "pcd_bev_gather")
+    return df

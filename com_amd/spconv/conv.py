@@ -1,0 +1,125 @@
+"""SubMConv3d / SparseConv3d / SparseInverseConv3d with spconv's constructor signatures
+(used at pcdet/models/backbones_3d/spconv_backbone.py:12-17,38-45,78,90-114,192-229).
+
+Parameter ``weight`` keeps spconv-2.x layout [Cout, kd, kh, kw, Cin] (the layout the reference's
+checkpoint loader expects, pcdet/models/detectors/detector3d_template.py:341-348), ``bias`` [Cout].
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import ops
+from . import functional as Fsp
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, subm=False, output_padding=0, transposed=False, inverse=False,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        assert ndim == 3, "only 3D sparse convolution is on the hot path"
+        assert groups == 1
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.dilation = _triple(dilation)
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self._packed = None
+        self._packed_version = None
+
+    def reset_parameters(self):
+        # spconv 2.x default init: kaiming_uniform_(a=sqrt(5)), bias ~ U(+-1/sqrt(fan_in))  
+        kvol = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        fan_in = self.in_channels * kvol
+        gain = init.calculate_gain("leaky_relu", math.sqrt(5))
+        bound = gain * math.sqrt(3.0 / fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                b = 1.0 / math.sqrt(fan_in)
+                self.bias.uniform_(-b, b)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, subm={self.subm}, inverse={self.inverse}, key={self.indice_key}")
+
+    def _packed_fwd(self):
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        if self._packed is None or self._packed_version != key:
+            self._packed = ops.pack_weight(self.weight, 0)
+            self._packed_version = key
+        return self._packed
+
+    def _rulebook(self, x):
+        """Look up / build the rulebook; returns (rulebook, out_indices, out_spatial_shape)."""
+        cached = x.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert cached is not None and self.indice_key is not None, \
+                "SparseInverseConv3d needs the rulebook of the SparseConv3d with the same indice_key"
+            fwd_rb, in_indices, in_shape = cached
+            return fwd_rb.inverse(), in_indices, in_shape
+        if cached is not None and self.subm:
+            rb, _, _ = cached
+            return rb, x.indices, x.spatial_shape
+        if self.subm:
+            rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+            out_idx, out_shape = x.indices, x.spatial_shape
+        else:
+            rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
+                                   self.padding, self.dilation)
+            out_idx, out_shape = rb.out_indices, rb.out_shape
+        if self.indice_key is not None:
+            # spconv stores (.., indice_pairs, indice_pair_num, spatial_shape) by key; for inverse convs
+            # we also remember the INPUT side
+            x.indice_dict[self.indice_key] = (rb, x.indices, list(x.spatial_shape))
+        return rb, out_idx, out_shape
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        rb, out_idx, out_shape = self._rulebook(input)
+        feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd())
+        out = SparseConvTensor(feats, out_idx, out_shape, input.batch_size, input.grid, input.voxel_num,
+                               input.indice_dict, input.benchmark)
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         True, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True, algo=None,
+                 fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)

@@ -1,0 +1,63 @@
+"""SparseConvTensor -- the container spconv hands between layers (constructed at
+pcdet/models/backbones_3d/spconv_backbone.py:141-146,254-259)."""
+import torch
+
+from .. import ops
+from . import functional as Fsp
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
+                 indice_dict=None, benchmark=False):
+        """features [N, C]; indices [N, 4] int32 (batch, z, y, x); spatial_shape [D, H, W]."""
+        self._features = features
+        if indices.dtype != torch.int32:
+            indices = indices.int()
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = indice_dict if indice_dict is not None else {}
+        self.grid = grid
+        self.voxel_num = voxel_num
+        self.benchmark = benchmark
+
+    # spconv 2.x forbids assignment and offers replace_feature (pcdet/utils/spconv_utils.py:28-34);
+    # spconv 1.x assigns.  Both spellings work here.
+    @property
+    def features(self):
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._features = value
+
+    def replace_feature(self, feature):
+        new = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid,
+                               self.voxel_num, self.indice_dict, self.benchmark)
+        return new
+
+    @property
+    def spatial_size(self):
+        n = 1
+        for s in self.spatial_shape:
+            n *= s
+        return n
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key, None)
+
+    def dense(self, channels_first=True):
+        """[B, C, D, H, W] (channels_first) or [B, D, H, W, C]; differentiable (backward = gather)."""
+        D, H, W = self.spatial_shape
+        flat = Fsp.bev_dense(self._features, self.indices, self.batch_size, self.spatial_shape)
+        C = self._features.shape[1]
+        out = flat.view(self.batch_size, C, D, H, W)
+        if not channels_first:
+            out = out.permute(0, 2, 3, 4, 1).contiguous()
+        return out
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / (self.spatial_size * self.batch_size)

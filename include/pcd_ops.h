@@ -1,0 +1,192 @@
+/*
+ * pcd_ops.h -- C ABI of libpcdops_hip.so: the MI355X (gfx950) implementation of the sparse-voxel
+ * hot path the reference (ZZY816/COM, an OpenPCDet fork) inherits from `spconv` + a few torch modules.
+ *
+ * Conventions (the reference's own binder convention is
+ * pcdet/ops/pointnet2/pointnet2_stack/src/ball_query.cpp:29-45: caller-allocated outputs, int return,
+ * raw pointers, contiguous int32 / float32 tensors):
+ *   - every function returns 0 on success or a negative PCD_ERR_* code (never exit()s);
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; host arrays are read
+ *     before the function returns;
+ *   - the caller owns every buffer (outputs, workspaces); the library never allocates or frees
+ *     device memory and keeps no pointer after returning; all work is enqueued on `stream`
+ *     (a hipStream_t, may be NULL for the default stream) and NOT synchronised;
+ *   - functions are re-entrant: no global state;
+ *   - index tensors are int32, coordinates are (batch, z, y, x) rows of 4 int32.
+ *
+ * Feature element types: PCD_BF16 (MFMA path, fp32 accumulate) for sparse-conv features,
+ * PCD_F32 for point / voxel payloads.  A feature row has `c_pad` elements, c_pad % 8 == 0,
+ * padding channels must be zero.
+ */
+#ifndef PCD_OPS_H_
+#define PCD_OPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCD_OK 0
+#define PCD_ERR_INVALID_ARG (-1)  /* NULL pointer, negative size, bad enum                       */
+#define PCD_ERR_UNSUPPORTED (-2)  /* shape / dtype combination this build has no kernel for      */
+#define PCD_ERR_KEYSPACE (-3)     /* batch * D * H * W does not fit the 32-bit coordinate key    */
+#define PCD_ERR_WORKSPACE (-4)    /* workspace too small                                         */
+#define PCD_ERR_LAUNCH (-5)       /* hipGetLastError() != hipSuccess after a launch              */
+
+#define PCD_F32 0
+#define PCD_BF16 1
+
+/* ---- library info -------------------------------------------------------------------------- */
+int pcd_version(void);                    /* 10000*major + 100*minor + patch */
+const char *pcd_error_string(int code);
+const char *pcd_build_arch(void);         /* "gfx950" */
+/* text of the HIP runtime error behind the calling thread's last PCD_ERR_LAUNCH */
+const char *pcd_last_hip_error_string(void);
+void pcd_set_last_hip_error(int code);    /* internal use */
+
+/* ============================================================================================
+ * (a1) hard voxelisation -- replaces spconv.utils.VoxelGeneratorV2.generate /
+ *      Point2VoxelCPU3d.point_to_voxel as called from
+ *      pcdet/datasets/processor/data_processor.py:44-60 (+ the batch collation of
+ *      pcdet/datasets/dataset.py:252-259), and optionally fuses MeanVFE
+ *      (pcdet/models/backbones_3d/vfe/mean_vfe.py:25-29).
+ *
+ * points: rows of `point_stride` floats; the C features copied into voxels start at column
+ * `feat_offset` and begin with x, y, z (feat_offset = 1 for collated (b,x,y,z,..) rows).
+ * Frame b owns point rows [frame_offsets[b], frame_offsets[b+1]).
+ * Semantics per frame = reference: point order, coordinate floor((p-min)/vsize) in IEEE f32,
+ * voxel ids in first-appearance order, at most max_voxels voxels, first max_points points kept.
+ * Output rows are compacted over frames: frame b starts at sum_{b'<b} M_b'.
+ *   voxels      [cap][max_points][C] f32, zero padded (may be NULL)
+ *   coords      [cap][4] i32 (b, z, y, x)
+ *   num_points  [cap] i32
+ *   mean_f32    [cap][C] f32 = sum / max(num,1)  (may be NULL)
+ *   mean_bf16   [cap][mean_bf16_stride] bf16, zero padded channels (may be NULL)
+ *   voxel_counts[batch+1] i32: M_b per frame, last = total rows written
+ * cap = capacity in rows of the outputs (>= min(n_points, batch*max_voxels) is always enough).
+ * ============================================================================================ */
+size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points, int batch);
+int pcd_voxelize_hard(const float *points, int n_points, int point_stride, int feat_offset,
+                      int num_features, const int32_t *frame_offsets, int batch,
+                      const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
+                      int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
+                      int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
+                      int32_t *voxel_counts, void *workspace, size_t workspace_bytes, void *stream);
+
+/* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
+int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
+                 int num_features, float *out, void *stream);
+
+/* ============================================================================================
+ * (a5) dynamic voxelisation + mean -- replaces torch.unique + torch_scatter.scatter_mean in
+ *      pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72.
+ * points_b rows = (batch_idx, x, y, z, f3, ...) with 1 + C floats.  Output sorted by the
+ * reference key b*XYZ + cx*YZ + cy*Z + cz; coords (b, z, y, x); no caps.
+ *   features [cap][C] f32, coords [cap][4], counts [cap] (may be NULL), num_voxels [1] i32.
+ * ============================================================================================ */
+size_t pcd_voxelize_dynamic_workspace_bytes(int n_points, int num_features, int batch,
+                                            const float *range_host, const float *vsize_host);
+int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, int num_features, int batch,
+                              const float *range_host, const float *vsize_host, int cap,
+                              float *features, int32_t *coords, int32_t *counts,
+                              int32_t *num_voxels, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
+/* ============================================================================================
+ * (a8) SubMConv3d rulebook -- replaces spconv's get_indice_pairs(subm=True) behind
+ *      spconv.SubMConv3d (pcdet/models/backbones_3d/spconv_backbone.py:12,38-45).
+ * indices [n][4].  K = kd*kh*kw, offsets enumerated k = (kd*KH+kh)*KW+kw,
+ * in_pos = out_pos - (ksize/2)*dil + k_idx*dil.
+ *   nbr      [K][n] i32: nbr[k][o] = input row feeding output row o through offset k, or -1.
+ *            (SubM symmetry: the input-stationary view is nbr_in[k] = nbr[K-1-k].)
+ *   pairs    [K][2][n] i32 (may be NULL): spconv's indice_pairs, canonical order = ascending input
+ *            row within each k, -1 padded.
+ *   pair_num [K] i32 (required iff pairs != NULL)
+ * ============================================================================================ */
+size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol);
+int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host /*[3]*/,
+                      const int *ksize_host, const int *dil_host, int32_t *nbr, int32_t *pairs,
+                      int32_t *pair_num, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
+ * (a9) SparseConv3d (strided) rulebook -- replaces get_indice_pairs(subm=False) behind
+ *      spconv.SparseConv3d (spconv_backbone.py:14-15,205-229).  Two phases because the number of
+ *      output rows is data dependent:
+ *   phase 1 `_count`: marks the active output cells, ranks them (sorted by linear key
+ *           ((b*D+z)*H+y)*W+x) and writes n_out to n_out_dev[0]; state lives in `workspace`.
+ *   phase 2 `_fill` : (after the caller read n_out and allocated) emits
+ *           out_indices [n_out][4], nbr_in [K][n] (output row fed by input i, or -1),
+ *           nbr_out [K][n_out] (input row feeding output o, or -1),
+ *           pairs [K][2][n] + pair_num [K] (may be NULL/NULL).
+ *   The same `workspace` (untouched in between) must be passed to both phases.
+ * out_shape_host [3] receives floor((in + 2p - d(k-1) - 1)/s) + 1.
+ * ============================================================================================ */
+size_t pcd_rulebook_conv_workspace_bytes(int n, int batch, const int *in_shape_host,
+                                         const int *ksize_host, const int *stride_host,
+                                         const int *pad_host, const int *dil_host);
+int pcd_conv_out_shape(const int *in_shape_host, const int *ksize_host, const int *stride_host,
+                       const int *pad_host, const int *dil_host, int *out_shape_host);
+int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                            const int *ksize_host, const int *stride_host, const int *pad_host,
+                            const int *dil_host, int32_t *n_out_dev, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                           const int *ksize_host, const int *stride_host, const int *pad_host,
+                           const int *dil_host, int n_out, int32_t *out_indices, int32_t *nbr_in,
+                           int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
+ * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
+ *
+ * Weights: the module parameter keeps spconv-2.x layout  weight [Cout][K][Cin] f32
+ * (pcdet/models/detectors/detector3d_template.py:341-348).  pcd_pack_weight converts it to the
+ * bf16 MFMA-fragment order the kernels read (call after every weight update):
+ *   mode 0 (forward):  contraction over (k, cin),  outputs cout
+ *   mode 1 (dgrad):    contraction over (k, cout), outputs cin
+ * packed size in bytes = pcd_packed_weight_bytes(K, c_contract_pad, c_out_pad_to_16).
+ * ============================================================================================ */
+size_t pcd_packed_weight_bytes(int kvol, int cin, int cout, int mode);
+int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode, void *packed,
+                    void *stream);
+
+/* y[o] = bias + sum_k x[nbr[k'][o]] @ W[k],  k' = flip_k ? K-1-k : k.
+ * Output-stationary gather-GEMM (no atomics, deterministic).  Used for
+ *   forward : x = features [n_in][cin_pad] bf16, nbr = nbr_out [K][n_out], packed mode 0;
+ *   dgrad   : x = dY [n_out][cout_pad], nbr = nbr_in [K][n_in] (SubM: nbr with flip_k = 1),
+ *             packed mode 1.
+ * c_in = contraction channels (row stride of x, % 8 == 0), c_out = output channels (% 16 == 0),
+ * nbr_stride = row stride (elements) of the nbr table.  y dtype PCD_BF16 or PCD_F32; bias f32 or NULL. */
+int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w, const float *bias,
+                                const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
+                                int n_rows_out, int c_out, void *y, int y_dtype, void *stream);
+
+/* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout),
+ * dbias[cout] = sum_o dY[o][cout] (may be NULL).  Deterministic: partial slabs in `workspace`
+ * are reduced in a fixed order. */
+size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax);
+int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+                          const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
+                          float *dweight, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
+ * (a13/a14) BEV scatter -- replaces SparseConvTensor.dense() + the view in
+ * pcdet/models/backbones_2d/map_to_bev/height_compression.py:20-25 and the per-batch loop of
+ * pointpillar_scatter.py:17-37 (D == 1).   out [B][C*D][H][W], channel index c*D + z, every
+ * element written (zeros included; no separate memset).  dtype: PCD_F32 or PCD_BF16 for both
+ * features [n][c_stride] and out.  `gather` is the backward: dfeat[r][c] = dout[b][c*D+z][y][x].
+ * workspace: pcd_bev_workspace_bytes(B, D, H, W) (a dense int32 row map).
+ * ============================================================================================ */
+size_t pcd_bev_workspace_bytes(int batch, int d, int h, int w);
+int pcd_bev_scatter(const void *features, int c, int c_stride, int dtype, const int32_t *indices,
+                    int n, int batch, int d, int h, int w, void *out, void *workspace,
+                    size_t workspace_bytes, void *stream);
+int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
+                   int batch, int d, int h, int w, void *dfeatures, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCD_OPS_H_ */
