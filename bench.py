@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- training frames/sec of the sparse-voxel hot path on N MI355X (one process per GPU).
+
+One "step" = one pass of the hot path over one batch of B synthetic Waymo-shaped frames per GPU
+(SURVEY.md section 8d): hard voxelisation (+ fused MeanVFE) of the HBM-resident point buffer ->
+VoxelResBackBone8x forward (9 rulebook builds, 21 sparse convs, BN/ReLU/residual) -> HeightCompression
+BEV scatter -> loss -> backward (dgrad + wgrad of every conv, BEV gather) -> DDP gradient all-reduce
+(N > 1, RCCL over xGMI) -> grad-norm clip (centerpoint.yaml:96) -> Adam step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel,
+timed live with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port
+on a bounded stratified sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from com_amd import hotpath, ops  # noqa: E402
+from com_amd.utils import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU (centerpoint.yaml:78)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
+    return ap.parse_args()
+
+
+class HotPath(torch.nn.Module):
+    """vfe -> backbone_3d -> map_to_bev of CenterPoint-VoxelNet (tools/cfgs/waymo_models/centerpoint.yaml:9-17)."""
+
+    def __init__(self):
+        super().__init__()
+        grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+        self.vfe = hotpath.MeanVFE({}, 5)
+        self.backbone_3d = hotpath.VoxelResBackBone8x({}, 5, grid)
+        self.map_to_bev_module = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256})
+
+    def forward(self, voxel_features, voxel_coords, batch_size):
+        bd = {"voxel_features": voxel_features, "voxel_coords": voxel_coords, "batch_size": batch_size}
+        bd = self.map_to_bev_module(self.backbone_3d(self.vfe(bd)))
+        return bd["spatial_features"], bd
+
+
+def measure_roofline(model, out, dev):
+    """Filled in after the first rocprofv3 profile names the dominant kernel."""
+    return None
+
+
+def measure_cpu_baseline():
+    """CPU baseline ("port"): the C oracle (oracle/pcd_oracle.c, spconv's native gather-GEMM-scatter
+    algorithm, fp32, scalar C compiled -O3 -march=native) on ONE host core, timed on a bounded stratified
+    sample of ONE synthetic frame: voxelisation, every rulebook geometry once, every distinct conv layer
+    type fwd+bwd once (x its multiplicity in VoxelResBackBone8x, spconv_backbone.py:191-232), BN+ReLU via
+    torch-CPU (1 thread), BEV dense.  Reported as the per-frame total -> frames/s."""
+    from oracle import oracle as O          # cpu_baseline leg only
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(0)
+    t_total = {}
+
+    def timed(name, mult, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        t_total[name] = t_total.get(name, 0.0) + mult * (time.perf_counter() - t0)
+        return r
+
+    pts = synth.synth_cloud(0)
+    v, c, n = timed("voxelize", 1, lambda: O.voxelize_hard(pts, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000))
+    timed("mean_vfe", 1, lambda: O.mean_vfe(v, n))
+    idx = np.pad(c, ((0, 0), (1, 0))).astype(np.int32)
+    shape = (41, 1504, 1504)
+    # (level channels, strided-conv geometry leading OUT of the level)
+    levels = [(16, dict(k=3, s=2, p=1), 32), (32, dict(k=3, s=2, p=1), 64), (64, dict(k=3, s=2, p=(0, 1, 1)), 128),
+              (128, dict(k=(3, 1, 1), s=(2, 1, 1), p=0), 128)]
+
+    def conv_fb(rb, cin, cout, mult, name):
+        x = rng.normal(size=(rb["n_in"], cin)).astype(np.float32)
+        w = (rng.normal(size=(rb["K"], cin, cout)) * 0.1).astype(np.float32)
+        y = timed(name, mult, lambda: O.conv_fwd(x, w, None, rb))
+        timed(name, mult, lambda: O.conv_bwd(x, w, y, rb))
+
+    def bn_relu(nrows, ch, mult):
+        x = torch.randn(nrows, ch, requires_grad=True)
+        bn = torch.nn.BatchNorm1d(ch, eps=1e-3, momentum=0.01)
+        def f():
+            y = torch.relu(bn(x)); y.sum().backward()
+        timed("bn_relu", mult, f)
+
+    first = True
+    for cl, geo, cnext in levels:
+        rb = timed("rulebook", 2 if first else 1, lambda: O.rulebook_subm(idx, shape))   # subm1 + res1 at level 1
+        if first:
+            conv_fb(rb, 5, 16, 1, "conv")            # conv_input
+            first = False
+        conv_fb(rb, cl, cl, 4, "conv")               # 2 SparseBasicBlocks = 4 SubM convs
+        bn_relu(rb["n_out"], cl, 5)
+        rc = timed("rulebook", 1, lambda: O.rulebook_conv(idx, shape, geo["k"], geo["s"], geo["p"]))
+        conv_fb(rc, cl, cnext, 1, "conv")
+        idx, shape = rc["out_indices"], tuple(int(s) for s in rc["out_shape"])
+    bn_relu(idx.shape[0], 128, 1)
+    feat = rng.normal(size=(idx.shape[0], 128)).astype(np.float32)
+    timed("bev", 2, lambda: O.dense_bev(feat, idx, 1, shape))
+    per_frame = sum(t_total.values())
+    return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "1 synthetic 160k-pt frame, fp32 C oracle (spconv native gather-GEMM-scatter): voxelize + "
+                      "9 rulebooks + each distinct VoxelResBackBone8x conv type fwd+bwd once x multiplicity + "
+                      "BN/ReLU (torch-CPU, 1 thread) + BEV dense; "
+                      + ", ".join(f"{k} {v:.2f}s" for k, v in t_total.items())}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+    assert world == args.gpus or world == 1
+
+    B = args.batch
+    torch.manual_seed(666 + rank)                            # cf. tools/train.py:86-87
+    # frames sharded by rank (DistributedSampler striding, pcdet/datasets/__init__.py:65-72); two batches
+    # alternate so consecutive steps do not see identical clouds
+    batches = []
+    for j in range(2):
+        first = (j * world + rank) * B
+        frames = [synth.synth_cloud(first + b) for b in range(B)]
+        pts, offs = hotpath.collate_points(frames, dev)      # resident in HBM before the timed region
+        offs_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
+        batches.append((pts, offs_dev))
+
+    model = HotPath().to(dev)
+    model.train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+
+    def step(i, record=None):
+        pts, offs = batches[i % 2]
+        ev = record
+        bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
+        if ev is not None: ev("voxelize")
+        bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
+                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True)
+        if ev is not None: ev("forward")
+        sf, out = net(bd["voxel_features"], bd["voxel_coords"], B)
+        loss = sf.float().square().mean()
+        if ev is not None: ev("backward")
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if ev is not None: ev("optimizer")
+        torch.nn.utils.clip_grad_norm_(params, 10.0)         # centerpoint.yaml:96 GRAD_NORM_CLIP
+        opt.step()
+        if ev is not None: ev("end")
+        return bd, out
+
+    for i in range(args.warmup):
+        step(i)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        bd, out = step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    fps = world * B * args.steps / elapsed
+
+    if args.stage_times and rank == 0:
+        marks = []
+
+        def rec(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e, time.perf_counter()))
+
+        step(0, rec)
+        torch.cuda.synchronize()
+        for (n0, e0, h0), (n1, e1, h1) in zip(marks[:-1], marks[1:]):
+            print(f"[stage] {n0:10s} gpu {e0.elapsed_time(e1):8.3f} ms   host {1e3 * (h1 - h0):8.3f} ms", file=sys.stderr)
+
+    result = {
+        "metric": "training frames/sec, CenterPoint-VoxelNet Waymo 160k-pt clouds, 1/2/4/8 MI355X",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "CenterPoint-VoxelNet hot path (hard voxelize+MeanVFE -> VoxelResBackBone8x fwd+bwd -> "
+                               "HeightCompression fwd+bwd -> grad all-reduce -> clip -> Adam), Waymo-shaped 160k-pt "
+                               "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
+                   "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
+                   "voxels_per_frame": int(sum(bd["voxel_counts"]) / B), "parallelism": f"dp{world}"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = measure_roofline(model, out, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = measure_cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,10 @@ def lib():
     """Load the HIP library; raise if it has not been built (no fallback path exists)."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime (libamdhip64); it must be loaded FIRST so that this library's
+        # NEEDED entry binds to the same runtime instance (two runtimes in one process do not share devices,
+        # streams or allocations).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise PcdError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

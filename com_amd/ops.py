@@ -138,7 +138,8 @@ class Rulebook:
                  ksize, stride, padding, dilation):
         self.subm, self.kvol, self.n_in, self.n_out = subm, kvol, n_in, n_out
         self.nbr_out, self.nbr_in, self.pairs, self.pair_num = nbr_out, nbr_in, pairs, pair_num
-        self.out_indices, self.out_shape = out_indices, list(out_shape)
+        self.out_indices = out_indices
+        self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
 
     def inverse(self):
