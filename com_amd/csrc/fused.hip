@@ -1,0 +1,386 @@
+// Fused sparse epilogues for gfx950: BatchNorm1d (+ residual add) (+ ReLU) over a [n][c] feature matrix
+// (nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU between every sparse conv and the residual add of
+// SparseBasicBlock: pcdet/models/backbones_3d/spconv_backbone.py:21-25,50-66,73).
+//
+// All HBM-bound streaming kernels: 16-byte loads/stores, a lane always owns the same 16-byte channel piece
+// (grid strides are multiples of the pieces per row) so per-channel parameters stay in registers.
+//   forward (training): pass 1  per-block partial (sum, sum of squares) -> workspace;
+//                       finalize mean / invstd (+ running-stat update) in one small block (fixed order);
+//                       pass 2  y = relu(x * scale + shift + residual).
+//   backward:           pass 1  dbeta = sum dz, dgamma = sum dz * xhat, dz = dy * (y > 0);
+//                       pass 2  dx = gamma * invstd * (dz - dbeta/n - xhat * dgamma/n), dresidual = dz.
+// Deterministic (no atomics): partials are reduced in a fixed order.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 512;
+
+template <typename T>
+struct Piece;  // 16-byte piece of a row
+template <>
+struct Piece<float> {
+    static constexpr int N = 4;
+    __device__ static void load(const float *p, float (&v)[4]) {
+        float4 r = *reinterpret_cast<const float4 *>(p);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+    __device__ static void store(float *p, const float (&v)[4]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct Piece<unsigned short> {
+    static constexpr int N = 8;
+    __device__ static void load(const unsigned short *p, float (&v)[8]) {
+        uint4 r = *reinterpret_cast<const uint4 *>(p);
+        u32 w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = __uint_as_float(w[j] << 16);
+            v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+    __device__ static void store(unsigned short *p, const float (&v)[8]) {
+        u32 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// block-level reduction of per-thread piece accumulators -> partial[blockIdx][which][c]
+template <int N, int NACC>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c, int pcs,
+                                                   float *partial /*[gridDim.x][NACC][c]*/, float *lds) {
+    // lds: [256][NACC*N]
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int j = 0; j < N; ++j) lds[threadIdx.x * (NACC * N) + a * N + j] = acc[a][j];
+    __syncthreads();
+    for (int item = threadIdx.x; item < NACC * c; item += 256) {
+        int a = item / c, ch = item - a * c;
+        int piece = ch / N, j = ch - piece * N;
+        float s = 0.0f;
+        for (int t = piece; t < 256; t += pcs) s += lds[t * (NACC * N) + a * N + j];
+        partial[((size_t)blockIdx.x * NACC + a) * c + ch] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, int n, int c,
+                                                       float *__restrict__ partial) {
+    constexpr int N = Piece<T>::N;
+    __shared__ float lds[256 * 2 * N];
+    const int pcs = c / N;
+    const size_t total = (size_t)n * pcs;
+    float acc[2][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float v[N];
+        Piece<T>::load(x + e * N, v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            acc[0][j] += v[j];
+            acc[1][j] += v[j] * v[j];
+        }
+    }
+    block_reduce_store<N, 2>(acc, c, pcs, partial, lds);
+}
+
+// Reduce the per-block partials of 64 channels per workgroup: 16 waves split the block axis (coalesced
+// over channels), then a fixed-order LDS reduction.  partial layout [nblocks][2][c].
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int ch,
+                                                double &s, double &ss, double *lds /*[2][16][64]*/) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (ch < c)
+        for (int blk = w; blk < nblocks; blk += 16) {
+            a += (double)partial[((size_t)blk * 2 + 0) * c + ch];
+            b += (double)partial[((size_t)blk * 2 + 1) * c + ch];
+        }
+    lds[(0 * 16 + w) * 64 + lane] = a;
+    lds[(1 * 16 + w) * 64 + lane] = b;
+    __syncthreads();
+    s = 0.0;
+    ss = 0.0;
+    if (w == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            s += lds[(0 * 16 + q) * 64 + lane];
+            ss += lds[(1 * 16 + q) * 64 + lane];
+        }
+    }
+}
+
+// grid = ceil(c/64), block = 1024: mean / invstd / running stats; scale/shift for the apply pass
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float *__restrict__ partial, int nblocks, int n, int c, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, float momentum, float *running_mean, float *running_var,
+    float *save_mean, float *save_invstd, float *scale, float *shift) {
+    __shared__ double lds[2 * 16 * 64];
+    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, ss;
+    reduce_partials(partial, nblocks, c, ch, s, ss, lds);
+    if (threadIdx.x >= 64 || ch >= c) return;
+    double mean = n > 0 ? s / n : 0.0;
+    double var = n > 0 ? ss / n - mean * mean : 0.0;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = invstd;
+    if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mean;
+    if (running_var) {
+        double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+    float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+    scale[ch] = g * invstd;
+    shift[ch] = b - (float)mean * g * invstd;
+}
+
+__global__ void bn_eval_coeff_kernel(int c, const float *gamma, const float *beta, const float *rm,
+                                     const float *rv, float eps, float *scale, float *shift) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float invstd = 1.0f / sqrtf(rv[ch] + eps);
+    float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+    scale[ch] = g * invstd;
+    shift[ch] = b - rm[ch] * g * invstd;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, const T *__restrict__ res,
+                                                       int n, int c, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, int relu,
+                                                       T *__restrict__ y) {
+    constexpr int N = Piece<T>::N;
+    const int pcs = c / N;
+    const size_t total = (size_t)n * pcs;
+    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
+    float sc[N], sh[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sc[j] = scale[piece * N + j];
+        sh[j] = shift[piece * N + j];
+    }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float v[N], r[N];
+        Piece<T>::load(x + e * N, v);
+        if (res) Piece<T>::load(res + e * N, r);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float o = v[j] * sc[j] + sh[j];
+            if (res) o += r[j];
+            if (relu) o = o > 0.0f ? o : 0.0f;
+            v[j] = o;
+        }
+        Piece<T>::store(y + e * N, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                                                            const T *__restrict__ y, int n, int c,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, int relu,
+                                                            float *__restrict__ partial) {
+    constexpr int N = Piece<T>::N;
+    __shared__ float lds[256 * 2 * N];
+    const int pcs = c / N;
+    const size_t total = (size_t)n * pcs;
+    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
+    float mu[N], is[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        mu[j] = mean[piece * N + j];
+        is[j] = invstd[piece * N + j];
+    }
+    float acc[2][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float g[N], xv[N], yv[N];
+        Piece<T>::load(dy + e * N, g);
+        Piece<T>::load(x + e * N, xv);
+        if (relu) Piece<T>::load(y + e * N, yv);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float dz = (relu && !(yv[j] > 0.0f)) ? 0.0f : g[j];
+            acc[0][j] += dz;
+            acc[1][j] += dz * (xv[j] - mu[j]) * is[j];
+        }
+    }
+    block_reduce_store<N, 2>(acc, c, pcs, partial, lds);
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial,
+                                                               int nblocks, int c, float *dgamma,
+                                                               float *dbeta) {
+    __shared__ double lds[2 * 16 * 64];
+    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, ss;
+    reduce_partials(partial, nblocks, c, ch, s, ss, lds);
+    if (threadIdx.x >= 64 || ch >= c) return;
+    dbeta[ch] = (float)s;
+    dgamma[ch] = (float)ss;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                                                           const T *__restrict__ y, int n, int c,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ dgamma,
+                                                           const float *__restrict__ dbeta, int relu,
+                                                           int training, T *__restrict__ dx,
+                                                           T *__restrict__ dres) {
+    constexpr int N = Piece<T>::N;
+    const int pcs = c / N;
+    const size_t total = (size_t)n * pcs;
+    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
+    float mu[N], is[N], gm[N], k1[N], k2[N];
+    const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        int ch = piece * N + j;
+        mu[j] = mean[ch];
+        is[j] = invstd[ch];
+        gm[j] = (gamma ? gamma[ch] : 1.0f) * is[j];
+        k1[j] = training ? dbeta[ch] * inv_n : 0.0f;
+        k2[j] = training ? dgamma[ch] * inv_n : 0.0f;
+    }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float g[N], xv[N], yv[N], o[N];
+        Piece<T>::load(dy + e * N, g);
+        Piece<T>::load(x + e * N, xv);
+        if (relu) Piece<T>::load(y + e * N, yv);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float dz = (relu && !(yv[j] > 0.0f)) ? 0.0f : g[j];
+            g[j] = dz;
+            float xhat = (xv[j] - mu[j]) * is[j];
+            o[j] = gm[j] * (dz - k1[j] - xhat * k2[j]);
+        }
+        Piece<T>::store(dx + e * N, o);
+        if (dres) Piece<T>::store(dres + e * N, g);
+    }
+}
+
+static int grid_for(size_t pieces, int pcs) {
+    size_t blocks = (pieces + 1023) / 1024;  // >= 4 pieces per thread
+    if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    // total threads must be a multiple of the pieces per row (pcs | 256 always holds)
+    (void)pcs;
+    return (int)blocks;
+}
+
+static bool shape_ok(int c, int dtype) {
+    int N = dtype == PCD_F32 ? 4 : 8;
+    if (c % N) return false;
+    int pcs = c / N;
+    return pcs >= 1 && pcs <= 256 && (256 % pcs) == 0 && c <= 1024;
+}
+
+struct BnWs {
+    float *partial, *scale, *shift;
+};
+static bool bn_ws(void *ws, size_t bytes, int c, BnWs &L) {
+    WsCarver w(ws, bytes);
+    L.partial = w.take<float>((size_t)MAX_BLOCKS * 2 * c);
+    L.scale = w.take<float>(c);
+    L.shift = w.take<float>(c);
+    return w.ok;
+}
+
+}  // namespace
+
+extern "C" size_t pcd_bn_workspace_bytes(int c) {
+    if (c <= 0) return 0;
+    return ws_piece((size_t)MAX_BLOCKS * 2 * c, sizeof(float)) + 2 * ws_piece(c, sizeof(float));
+}
+
+extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
+                              const float *gamma, const float *beta, float eps, float momentum,
+                              int training, float *running_mean, float *running_var, int relu, void *y,
+                              float *save_mean, float *save_invstd, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
+    if (!training && (!running_mean || !running_var)) return PCD_ERR_INVALID_ARG;
+    if (training && (!save_mean || !save_invstd)) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (!x || !y)) return PCD_ERR_INVALID_ARG;
+    BnWs L;
+    if (!bn_ws(workspace, workspace_bytes, c, L)) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = dtype == PCD_F32 ? 4 : 8;
+    const int pcs = c / N;
+    int grid = grid_for((size_t)n * pcs, pcs);
+    if (training) {
+        if (dtype == PCD_F32)
+            bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
+        else
+            bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
+        bn_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, n, c, gamma, beta, eps,
+                                                               momentum, running_mean, running_var,
+                                                               save_mean, save_invstd, L.scale, L.shift);
+    } else {
+        bn_eval_coeff_kernel<<<pcd_div_up(c, 128), 128, 0, st>>>(c, gamma, beta, running_mean, running_var,
+                                                                 eps, L.scale, L.shift);
+    }
+    if (n > 0) {
+        if (dtype == PCD_F32)
+            bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float *)x, (const float *)residual, n, c,
+                                                         L.scale, L.shift, relu, (float *)y);
+        else
+            bn_apply_kernel<unsigned short><<<grid, 256, 0, st>>>(
+                (const unsigned short *)x, (const unsigned short *)residual, n, c, L.scale, L.shift, relu,
+                (unsigned short *)y);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
+                               const float *gamma, const float *save_mean, const float *save_invstd,
+                               int relu, int training, void *dx, void *dresidual, float *dgamma,
+                               float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
+    if (!save_mean || !save_invstd || !dgamma || !dbeta) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (!dy || !x || !dx || (relu && !y))) return PCD_ERR_INVALID_ARG;
+    BnWs L;
+    if (!bn_ws(workspace, workspace_bytes, c, L)) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = dtype == PCD_F32 ? 4 : 8;
+    const int pcs = c / N;
+    int grid = grid_for((size_t)n * pcs, pcs);
+    if (dtype == PCD_F32) {
+        bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
+                                                          (const float *)y, n, c, save_mean, save_invstd,
+                                                          relu, L.partial);
+        bn_bwd_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        if (n > 0)
+            bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>(
+                (const float *)dy, (const float *)x, (const float *)y, n, c, gamma, save_mean, save_invstd,
+                dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
+    } else {
+        typedef unsigned short B;
+        bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
+                                                      save_mean, save_invstd, relu, L.partial);
+        bn_bwd_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        if (n > 0)
+            bn_bwd_apply_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
+                                                         gamma, save_mean, save_invstd, dgamma, dbeta, relu,
+                                                         training, (B *)dx, (B *)dresidual);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -8,6 +8,7 @@ from torch import nn
 
 from .. import spconv
 from ..spconv import SparseConvTensor
+from ..spconv import functional as Fsp
 
 
 def replace_feature(out, new_features):
@@ -50,16 +51,15 @@ class SparseBasicBlock(spconv.SparseModule):
         self.stride = stride
 
     def forward(self, x):
+        # same dataflow as spconv_backbone.py:50-66; bn -> relu and bn -> (+identity) -> relu each run as
+        # one fused stats pass + one fused apply pass (com_amd/csrc/fused.hip)
         identity = x
         out = self.conv1(x)
-        out = replace_feature(out, self.bn1(out.features))
-        out = replace_feature(out, self.relu(out.features))
+        out = replace_feature(out, Fsp.batch_norm_act(self.bn1, out.features, None, True))
         out = self.conv2(out)
-        out = replace_feature(out, self.bn2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
-        out = replace_feature(out, out.features + identity.features)
-        out = replace_feature(out, self.relu(out.features))
+        out = replace_feature(out, Fsp.batch_norm_act(self.bn2, out.features, identity.features, True))
         return out
 
 
@@ -75,7 +75,19 @@ class _BackboneBase(nn.Module):
         return SparseConvTensor(features=feats, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
                                 batch_size=batch_size)
 
+    def _bump_bn_counters(self):
+        """num_batches_tracked += 1 for every BatchNorm1d in ONE multi-tensor launch instead of 21."""
+        if not hasattr(self, "_bn_list"):
+            self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
+            for m in self._bn_list:
+                m._defer_nbt = True
+        if self.training:
+            counters = [m.num_batches_tracked for m in self._bn_list if m.num_batches_tracked is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)
+
     def _run(self, batch_dict):
+        self._bump_bn_counters()
         x = self.conv_input(self._input_tensor(batch_dict))
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

@@ -281,3 +281,41 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
     L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n, batch_size,
                                    D, H, W, L.ptr(df), L.stream_ptr()), "pcd_bev_gather")
     return df
+
+
+# ---------------------------------------------------------------------------------------------
+def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu):
+    """Fused BatchNorm1d (+residual) (+ReLU) over [n, c] (spconv_backbone.py:21-25,50-66).
+    Returns (y, save_mean, save_invstd)."""
+    _require_cuda(x)
+    assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
+    n, c = x.shape
+    dev = x.device
+    lib = L.lib()
+    y = torch.empty_like(x)
+    save_mean = torch.empty((c,), dtype=torch.float32, device=dev)
+    save_invstd = torch.empty((c,), dtype=torch.float32, device=dev)
+    ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
+    L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
+                               float(eps), float(momentum), int(training), L.ptr(running_mean),
+                               L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
+                               L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_forward")
+    return y, save_mean, save_invstd
+
+
+def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres):
+    _require_cuda(dy, x)
+    dy = dy.contiguous()
+    n, c = x.shape
+    dev = x.device
+    lib = L.lib()
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
+    L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma),
+                                L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
+                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(),
+                                L.stream_ptr()), "pcd_bn_backward")
+    return dx, dres, dgamma, dbeta

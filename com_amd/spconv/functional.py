@@ -94,3 +94,63 @@ def bev_dense(features, indices, batch_size, spatial_shape):
 
 def sparse_conv(features, weight, bias, rb, packed_fwd):
     return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd)
+
+
+class FusedBNFunction(Function):
+    """nn.BatchNorm1d (+ residual add) (+ nn.ReLU) on `.features` in two streaming passes
+    (spconv_backbone.py:21-25,50-66); parameters / buffers stay in the caller's nn.BatchNorm1d."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu):
+        xc = x.detach().contiguous()
+        rc = residual.detach().contiguous() if residual is not None else None
+        if rc is not None and rc.dtype != xc.dtype:
+            rc = rc.to(xc.dtype)
+        training = bn.training or bn.running_mean is None
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        g = gamma.detach().float() if gamma is not None else None
+        b = beta.detach().float() if beta is not None else None
+        y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
+                                                   bn.running_var, relu)
+        if not training:
+            save_mean = bn.running_mean
+            save_invstd = torch.rsqrt(bn.running_var + bn.eps)
+        ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
+        ctx.save_for_backward(xc, y, g, save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, g, save_mean, save_invstd = ctx.saved_tensors
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
+                                                  ctx.has_res and ctx.needs_input_grad[3])
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                dres, None, None)
+
+
+def _fusable(bn, x):
+    import torch.nn as nn
+    if not isinstance(bn, nn.BatchNorm1d) or not x.is_cuda or x.dim() != 2:
+        return False
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    c = x.shape[1]
+    piece = 4 if x.dtype == torch.float32 else 8
+    if c % piece or c > 1024:
+        return False
+    pcs = c // piece
+    return (256 % pcs) == 0 and (bn.running_mean is not None or bn.training)
+
+
+def batch_norm_act(bn, x, residual=None, relu=True):
+    """y = relu?(bn(x) + residual?) through the fused HIP kernels when the shape allows, else torch."""
+    if _fusable(bn, x):
+        if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_defer_nbt", False):
+            bn.num_batches_tracked.add_(1)
+        return FusedBNFunction.apply(x, bn.weight, bn.bias, residual, bn, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y

@@ -55,14 +55,27 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        from . import functional as Fsp
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 input = module(input)
-            else:
-                if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
-                        input = input.replace_feature(module(input.features))
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] == 0:
+                    continue
+                if isinstance(module, nn.BatchNorm1d) and Fsp._fusable(module, input.features):
+                    # BatchNorm1d (+ the ReLU that follows it) in one fused pass pair; the modules, their
+                    # parameters and state-dict entries are untouched
+                    relu = i < len(mods) and type(mods[i]) is nn.ReLU
+                    input = input.replace_feature(Fsp.batch_norm_act(module, input.features, None, relu))
+                    if relu:
+                        i += 1
                 else:
-                    input = module(input)
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
         return input

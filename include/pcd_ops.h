@@ -186,6 +186,28 @@ int pcd_bev_scatter(const void *features, int c, int c_stride, int dtype, const 
 int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
                    int batch, int d, int h, int w, void *dfeatures, void *stream);
 
+/* ============================================================================================
+ * (a11) fused sparse epilogue -- replaces the nn.BatchNorm1d(eps=1e-3, momentum=0.01) -> (+ residual)
+ * -> nn.ReLU chains that SparseSequential / SparseBasicBlock apply to `.features` between convs
+ * (pcdet/models/backbones_3d/spconv_backbone.py:21-25,50-66,73).
+ *   forward : y = relu?( (x - mean) * invstd * gamma + beta + residual? ),  x/y/residual [n][c] of `dtype`;
+ *             training != 0: batch statistics (biased var for normalisation, unbiased for running_var,
+ *             running = (1-momentum)*running + momentum*batch), saved to save_mean / save_invstd [c];
+ *             training == 0: running statistics.
+ *   backward: dz = relu ? dy * (y > 0) : dy; dresidual = dz (may be NULL); dgamma, dbeta [c];
+ *             dx = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n)   (training) or gamma*invstd*dz (eval).
+ * c % 8 == 0 (bf16) / c % 4 == 0 (f32), c/piece a power of two <= 256.  Deterministic (no atomics).
+ * ============================================================================================ */
+size_t pcd_bn_workspace_bytes(int c);
+int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c, const float *gamma,
+                   const float *beta, float eps, float momentum, int training, float *running_mean,
+                   float *running_var, int relu, void *y, float *save_mean, float *save_invstd,
+                   void *workspace, size_t workspace_bytes, void *stream);
+int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
+                    const float *gamma, const float *save_mean, const float *save_invstd, int relu,
+                    int training, void *dx, void *dresidual, float *dgamma, float *dbeta, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
