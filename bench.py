@@ -61,9 +61,54 @@ class HotPath(torch.nn.Module):
         return bd["spatial_features"], bd
 
 
-def measure_roofline(model, out, dev):
-    """Filled in after the first rocprofv3 profile names the dominant kernel."""
-    return None
+def measure_roofline(step_fn):
+    """Roofline of the dominant HIP kernel of the step, measured LIVE: one extra training step runs with
+    HIP events (on the launch stream) around every sparse-conv kernel launch (com_amd.ops.PROFILE); launches
+    are grouped by kernel instantiation (the name rocprofv3 reports), the group with the largest total time
+    is the dominant kernel.  achieved = sum of ALGORITHMIC flops (2*P*Cin*Cout) or bytes (SURVEY.md 8d:
+    (N_in*Cin + N_out*Cout)*2 + 8*P + K*Cin*Cout*e) of its launches / sum of their durations.  The bound is
+    "mfma" when the group's arithmetic intensity is above the ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B)."""
+    ops.PROFILE = []
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+        recs = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    groups = {}
+    for key, e0, e1, meta in recs:
+        name = key.split(" ")[0] + (" " + key.split(" ")[1] if key.startswith("wgrad") else "")
+        g = groups.setdefault(name, dict(ms=0.0, bytes=0, flops=0, launches=0, members={}))
+        ms = e0.elapsed_time(e1)
+        g["ms"] += ms
+        g["bytes"] += meta["bytes"]
+        g["flops"] += meta["flops"]
+        g["launches"] += 1
+        m = g["members"].setdefault(key, [0, 0.0])
+        m[0] += 1
+        m[1] += ms
+    if not groups:
+        return None
+    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    secs = g["ms"] * 1e-3
+    ai = g["flops"] / max(g["bytes"], 1)
+    tf = g["flops"] / secs / 1e12
+    gbs = g["bytes"] / secs / 1e9
+    mfma_bound = ai > MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = {"bound": "mfma" if mfma_bound else "hbm",
+           "achieved": round(tf if mfma_bound else gbs, 2),
+           "peak": MFMA_BF16_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+           "unit": "TFLOP/s" if mfma_bound else "GB/s",
+           "frac": round((tf / MFMA_BF16_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
+           "traffic": None,
+           "kernel": name, "launches_per_step": g["launches"],
+           "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+           "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
+           "algorithmic_flops_per_launch": int(g["flops"] / g["launches"]),
+           "arithmetic_intensity_flop_per_byte": round(ai, 1),
+           "other_frac": {"hbm": round(gbs / HBM_PEAK_GBS, 4), "mfma": round(tf / MFMA_BF16_PEAK_TF, 4)},
+           "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
+    return out
 
 
 def measure_cpu_baseline():
@@ -201,7 +246,7 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     fps = world * B * args.steps / elapsed
 
-    if args.stage_times and rank == 0:
+    if args.stage_times:
         marks = []
 
         def rec(name):
@@ -211,7 +256,7 @@ def main():
 
         step(0, rec)
         torch.cuda.synchronize()
-        for (n0, e0, h0), (n1, e1, h1) in zip(marks[:-1], marks[1:]):
+        for (n0, e0, h0), (n1, e1, h1) in zip(marks[:-1], marks[1:]) if rank == 0 else []:
             print(f"[stage] {n0:10s} gpu {e0.elapsed_time(e1):8.3f} ms   host {1e3 * (h1 - h0):8.3f} ms", file=sys.stderr)
 
     result = {
@@ -226,8 +271,10 @@ def main():
                    "voxels_per_frame": int(sum(bd["voxel_counts"]) / B), "parallelism": f"dp{world}"},
     }
 
-    if rank == 0 and not args.no_roofline:
-        result["roofline"] = measure_roofline(model, out, dev)
+    if not args.no_roofline:
+        roof = measure_roofline(lambda: step(0))     # every rank runs the extra step (collectives inside)
+        if rank == 0:
+            result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
     if rank == 0:

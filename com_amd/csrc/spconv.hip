@@ -18,6 +18,8 @@
 // gfx950 transpose read ds_read_b64_tr_b16 (the contraction index = pair index is the slow axis of
 // both row-major tiles).  Waves of a workgroup split the pair range, are reduced through LDS in a
 // fixed order, written to per-split slabs and summed by a second kernel: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -64,18 +66,54 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NB, int MI, bool OUT_BF16>
+// Output-stationary gather-GEMM.  Workgroup = 4 waves x (MI*16) output rows, all NB*16 output channels.
+//   * the workgroup's rulebook tile nbr[K][ROWS] is staged in LDS once (coalesced k-major reads);
+//   * packed weights are shared by the 4 waves through LDS: narrow layers keep the whole packed weight
+//     resident (no barrier in the main loop); wide layers stream it through a double-buffered stage of
+//     SG contraction steps, filled global -> registers -> LDS one stage ahead (one barrier per stage, the
+//     stage is long enough to cover the L2 latency).  Fragments come back with conflict-free linear
+//     ds_read_b128; with MI = 2 each fragment feeds two MFMAs (LDS read rate <= half of peak);
+//   * gathered feature rows go straight from L2 into MFMA operand registers, issued one GROUP of G
+//     contraction steps ahead of their use (register double buffer);
+//   * a contraction step whose 16-row tile has no neighbour at all is skipped (wave-uniform ballot).
+template <int NB, int MI, int G, int SG, bool OUT_BF16>   // SG == 0: weights resident in LDS
 __global__ __launch_bounds__(256) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
     int n_out, void *__restrict__ yv, int nsteps) {
+    constexpr int ROWS = 4 * MI * 16;
+    constexpr bool STAGED = SG > 0;
+    constexpr int VEC = STAGED ? SG * NB * 64 : 1;         // uint4 per stage
+    constexpr int WPT = STAGED ? VEC / 256 : 1;            // uint4 per thread per stage
+    static_assert(!STAGED || (SG % G == 0 && VEC % 256 == 0), "stage / group mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t wtotal = (size_t)nsteps * NB * 64;  // uint4 in the packed weight
+    uint4 *wbuf = (uint4 *)smem;                     // staged: [2][VEC]; resident: [wtotal]
+    int *nbr_s = (int *)(smem + (STAGED ? (size_t)2 * VEC : wtotal) * sizeof(uint4));  // [K][ROWS]
+
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;
     const int g = lane >> 4;
-    const int r0 = (blockIdx.x * 4 + wave) * (MI * 16);
-    if (r0 >= n_out) return;
-    const int c_out = NB * 16;
+    const int r0wg = blockIdx.x * ROWS;
+    constexpr int c_out = NB * 16;
+
+    for (int idx = threadIdx.x; idx < K * ROWS; idx += 256) {
+        int k = idx / ROWS, r = idx - k * ROWS;
+        int row = r0wg + r;
+        int krow = flip ? (K - 1 - k) : k;
+        nbr_s[idx] = row < n_out ? nbr[(size_t)krow * nbr_stride + row] : -1;
+    }
+    if (STAGED) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            size_t e = (size_t)j * 256 + threadIdx.x;
+            wbuf[e] = e < wtotal ? wp[e] : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        for (size_t e = threadIdx.x; e < wtotal; e += 256) wbuf[e] = wp[e];
+    }
+    __syncthreads();
 
     f32x4 acc[MI][NB];
 #pragma unroll
@@ -83,42 +121,77 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int rows[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) rows[mi] = r0 + mi * 16 + rl;
+    const int tile_row = wave * (MI * 16) + rl;
+    uint4 a_cur[G][MI], a_next[G][MI];
+    bool v_cur[G], v_next[G];
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int q0 = s * 32 + g * 8;
-        const int k = q0 >> cshift;
-        const int c0 = q0 & (c_in - 1);
-        const int krow = flip ? (K - 1 - k) : k;
-        uint4 a[MI];
-        bool any = false;
+    auto gather_group = [&](int s0, uint4(&a)[G][MI], bool(&valid)[G]) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            int i = -1;
-            if (k < K && rows[mi] < n_out) i = nbr[(size_t)krow * nbr_stride + rows[mi]];
-            a[mi] = make_uint4(0, 0, 0, 0);
-            if (i >= 0) {
-                a[mi] = *reinterpret_cast<const uint4 *>(x + (size_t)i * c_in + c0);
-                any = true;
+        for (int gg = 0; gg < G; ++gg) {
+            const int q0 = (s0 + gg) * 32 + g * 8;
+            const int k = q0 >> cshift;
+            const int c0 = q0 & (c_in - 1);
+            valid[gg] = false;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int i = (k < K) ? nbr_s[k * ROWS + tile_row + mi * 16] : -1;
+                a[gg][mi] = make_uint4(0, 0, 0, 0);
+                if (i >= 0) {
+                    a[gg][mi] = *reinterpret_cast<const uint4 *>(x + (size_t)i * c_in + c0);
+                    valid[gg] = true;
+                }
             }
         }
-        if (!__any(any)) continue;
-        const uint4 *wps = wp + ((size_t)s * NB) * 64 + lane;
+    };
+
+    gather_group(0, a_cur, v_cur);
+    const int ngroups = (nsteps + G - 1) / G;
+    int cur = 0;
+    uint4 wreg[WPT];
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int s0 = grp * G;
+        if (STAGED && (s0 % SG) == 0) {
+            const size_t base = (size_t)(s0 / SG + 1) * VEC;  // next stage
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            bf16x8 b = as_bf16x8(wps[nb * 64]);
+            for (int j = 0; j < WPT; ++j) {
+                size_t e = base + (size_t)j * 256 + threadIdx.x;
+                wreg[j] = e < wtotal ? wp[e] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (grp + 1 < ngroups) gather_group(s0 + G, a_next, v_next);
+        const uint4 *wcur = STAGED ? wbuf + (size_t)cur * VEC + (size_t)(s0 % (STAGED ? SG : 1)) * NB * 64
+                                   : wbuf + (size_t)s0 * NB * 64;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, as_bf16x8(a[mi]), acc[mi][nb],
-                                                                      0, 0, 0);
+        for (int gg = 0; gg < G; ++gg) {
+            if (s0 + gg < nsteps && __any(v_cur[gg])) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    bf16x8 b = as_bf16x8(wcur[(gg * NB + nb) * 64 + lane]);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, as_bf16x8(a_cur[gg][mi]),
+                                                                              acc[mi][nb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a_cur[gg][mi] = a_next[gg][mi];
+            v_cur[gg] = v_next[gg];
+        }
+        if (STAGED && ((s0 + G) % SG) == 0) {
+            uint4 *wnext = wbuf + (size_t)(cur ^ 1) * VEC;
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) wnext[(size_t)j * 256 + threadIdx.x] = wreg[j];
+            __syncthreads();
+            cur ^= 1;
         }
     }
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        int row = rows[mi];
+        int row = r0wg + tile_row + mi * 16;
         if (row >= n_out) continue;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -142,20 +215,29 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
     }
 }
 
-template <int NB, int MI>
+template <int NB, int MI, int G, int SG>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, void *y,
                      int y_dtype, int nsteps, hipStream_t st) {
-    int rows_per_block = 4 * MI * 16;
-    int grid = pcd_div_up(n_out, rows_per_block);
+    constexpr int ROWS = 4 * MI * 16;
+    int grid = pcd_div_up(n_out, ROWS);
+    size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
+    size_t lds = wbytes + (size_t)K * ROWS * sizeof(int);
+    if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
+    auto kb = gather_gemm_kernel<NB, MI, G, SG, true>;
+    auto kf = gather_gemm_kernel<NB, MI, G, SG, false>;
+    if (lds > 64 * 1024) {
+        // above the default dynamic-LDS limit: raise it for this kernel (idempotent, host-side attribute)
+        if (hipFuncSetAttribute((const void *)(y_dtype == PCD_BF16 ? kb : kf),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PCD_ERR_LAUNCH;
+    }
     if (y_dtype == PCD_BF16)
-        gather_gemm_kernel<NB, MI, true><<<grid, 256, 0, st>>>(
-            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip,
-            n_out, y, nsteps);
+        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
+                                   nbr_stride, K, flip, n_out, y, nsteps);
     else
-        gather_gemm_kernel<NB, MI, false><<<grid, 256, 0, st>>>(
-            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip,
-            n_out, y, nsteps);
+        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
+                                   nbr_stride, K, flip, n_out, y, nsteps);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -174,7 +256,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     const int lane = threadIdx.x & 63;
     unsigned short *Xs = (unsigned short *)smem + (size_t)wave * 32 * (XS + YS);
     unsigned short *Ys = Xs + 32 * XS;
-    float *tile = (float *)(smem + (size_t)4 * 32 * (XS + YS) * sizeof(unsigned short));
+    float *tile = (float *)smem;  // reduction tile aliases the staging area (used after the main loop)
 
     const int k = blockIdx.x;
     const int split = blockIdx.y;
@@ -196,30 +278,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 
     const int pr = lane & 31, h = lane >> 5;
     const int g = lane >> 4, t = lane & 15;
-    for (int p0 = p_begin + wave * 32; p0 < p_end; p0 += 128) {
+    // software pipeline: the gathers of the NEXT 32 pairs are in flight while the current 32 are
+    // transposed out of LDS and multiplied
+    // (rows one step ahead, pair indices two steps ahead, so no dependent-load latency is exposed)
+    uint4 xr[MB], yr[NBW];
+    int i_n = -1, o_n = -1;
+    auto load_idx = [&](int p0) {
         int p = p0 + pr;
-        int i = -1, o = -1;
+        i_n = -1;
+        o_n = -1;
         if (p < p_end) {
-            i = pin[p];
-            o = pout[p];
+            i_n = pin[p];
+            o_n = pout[p];
         }
-        // stage 32 gathered rows of X and dY (this wave's private LDS slice)
+    };
+    auto load_rows = [&](int i, int o) {
 #pragma unroll
         for (int pc = 0; pc < MB; ++pc) {
             int c = (pc * 2 + h) * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            xr[pc] = make_uint4(0, 0, 0, 0);
             if (i >= 0 && ci0 + c < cin_pad)
-                v = *reinterpret_cast<const uint4 *>(x + (size_t)i * cin_pad + ci0 + c);
-            *reinterpret_cast<uint4 *>(Xs + pr * XS + c) = v;
+                xr[pc] = *reinterpret_cast<const uint4 *>(x + (size_t)i * cin_pad + ci0 + c);
         }
 #pragma unroll
         for (int pc = 0; pc < NBW; ++pc) {
             int c = (pc * 2 + h) * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            yr[pc] = make_uint4(0, 0, 0, 0);
             if (o >= 0 && co0 + c < cout)
-                v = *reinterpret_cast<const uint4 *>(dy + (size_t)o * cout + co0 + c);
-            *reinterpret_cast<uint4 *>(Ys + pr * YS + c) = v;
+                yr[pc] = *reinterpret_cast<const uint4 *>(dy + (size_t)o * cout + co0 + c);
         }
+    };
+    const int p_first = p_begin + wave * 32;
+    load_idx(p_first);
+    load_rows(i_n, o_n);
+    load_idx(p_first + 128);
+    for (int p0 = p_first; p0 < p_end; p0 += 128) {
+        // stage the 32 gathered rows of X and dY (this wave's private LDS slice)
+#pragma unroll
+        for (int pc = 0; pc < MB; ++pc)
+            *reinterpret_cast<uint4 *>(Xs + pr * XS + (pc * 2 + h) * 8) = xr[pc];
+#pragma unroll
+        for (int pc = 0; pc < NBW; ++pc)
+            *reinterpret_cast<uint4 *>(Ys + pr * YS + (pc * 2 + h) * 8) = yr[pc];
+        load_rows(i_n, o_n);
+        load_idx(p0 + 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // transpose reads: lane (g,t) supplies the address of 4 bf16 of pair row g*8 + (t>>2)
@@ -255,6 +357,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     }
 
     // fixed-order reduction of the 4 waves through LDS: tile[cout_l][cin_l]
+    __syncthreads();
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -307,7 +410,8 @@ static int launch_wgrad(const void *x, int cin_pad, int cin, const void *dy, int
     int splits, per;
     wgrad_plan(pmax, &splits, &per);
     int ncic = pcd_div_up(cin, CI), ncoc = pcd_div_up(cout, CO);
-    size_t lds = (size_t)4 * 32 * (CI + 8 + CO + 8) * 2 + (size_t)CI * CO * 4;
+    size_t lds_stage = (size_t)4 * 32 * (CI + 8 + CO + 8) * 2, lds_tile = (size_t)CI * CO * 4;
+    size_t lds = lds_stage > lds_tile ? lds_stage : lds_tile;
     dim3 grid(K, splits, ncic * ncoc);
     wgrad_kernel<MB, NBW><<<grid, 256, lds, st>>>((const unsigned short *)x, cin_pad, cin,
                                                   (const unsigned short *)dy, cout, pairs, pair_num, K,
@@ -362,21 +466,28 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *
     if (cshift < 3 || (c_out % 16) != 0) return PCD_ERR_UNSUPPORTED;
     int nsteps = (kvol * c_in + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    // two 16-row MFMA tiles per wave once there is enough work to fill the chip
-    bool big = n_rows_out >= 256 * 1024 / 4;
-#define GG(NBv)                                                                                      \
-    return big ? launch_gg<NBv, 2>(x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k,   \
-                                   n_rows_out, y, y_dtype, nsteps, st)                               \
-               : launch_gg<NBv, 1>(x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k,   \
-                                   n_rows_out, y, y_dtype, nsteps, st)
+    // Launch configuration per output width (NB = c_out/16):  <NB, MI, G (gather look-ahead), SG (stage)>
+    //   packed weight <= 32 KB  -> resident in LDS, no barrier in the main loop (narrow / early layers)
+    //   else                    -> double-buffered stages of SG steps
+    const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
+    const bool resident = wbytes <= 32 * 1024;
+    const bool small = n_rows_out < 32 * 1024;  // few rows: 64-row workgroups fill the chip better
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, y, y_dtype, nsteps, st
     switch (c_out / 16) {
-        case 1: GG(1);
-        case 2: GG(2);
-        case 4: GG(4);
-        case 8: GG(8);
-        default: return PCD_ERR_UNSUPPORTED;
+        case 1:
+            return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 16>(GG_ARGS);
+        case 2:
+            return resident ? launch_gg<2, 2, 4, 0>(GG_ARGS) : launch_gg<2, 2, 4, 8>(GG_ARGS);
+        case 4:
+            if (resident) return launch_gg<4, 2, 2, 0>(GG_ARGS);
+            return small ? launch_gg<4, 1, 4, 8>(GG_ARGS) : launch_gg<4, 2, 4, 8>(GG_ARGS);
+        case 8:
+            if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
+            return small ? launch_gg<8, 1, 4, 4>(GG_ARGS) : launch_gg<8, 2, 2, 4>(GG_ARGS);
+        default:
+            return PCD_ERR_UNSUPPORTED;
     }
-#undef GG
+#undef GG_ARGS
 }
 
 extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax) {
@@ -392,12 +503,11 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const 
                                      void *stream) {
     PCD_ENTER();
     if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin) return PCD_ERR_INVALID_ARG;
-    if (!dweight) return PCD_ERR_INVALID_ARG;
     if ((cin_pad % 8) != 0 || (cout % 8) != 0) return PCD_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)cout * kvol * cin;
     if (pmax == 0) {
-        hipMemsetAsync(dweight, 0, n * sizeof(float), st);
+        if (dweight) hipMemsetAsync(dweight, 0, n * sizeof(float), st);
         return PCD_OK;
     }
     if (!x || !dy || !pairs || !pair_num) return PCD_ERR_INVALID_ARG;
@@ -411,10 +521,20 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const 
         rc = launch_wgrad<M, N>(x, cin_pad, cin, dy, cout, pairs, pair_num, kvol, pmax, slab, st);
     WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
 #undef WG
-    if (rc != PCD_OK) return rc;
+    return rc;
+}
+
+extern "C" int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
+                                            const void *workspace, void *stream) {
+    PCD_ENTER();
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || !dweight) return PCD_ERR_INVALID_ARG;
+    size_t n = (size_t)cout * kvol * cin;
+    if (pmax == 0) return PCD_OK;  // pcd_sparse_conv_wgrad already zeroed dweight
+    if (!workspace) return PCD_ERR_WORKSPACE;
     int splits, per;
     wgrad_plan(pmax, &splits, &per);
-    wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(slab, splits, n, dweight);
+    wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const float *)workspace, splits, n, dweight);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -11,6 +11,30 @@ from . import _lib as L
 
 PCD_F32, PCD_BF16 = L.PCD_F32, L.PCD_BF16
 
+# ---------------------------------------------------------------------------------------------
+# Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  When
+# `PROFILE` is a list, every instrumented call appends (kernel key, start event, end event, meta) where
+# meta carries the ALGORITHMIC bytes / flops of the launch (SURVEY.md section 8d formulas).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, key, meta_fn):
+        self.key, self.meta_fn = key, meta_fn
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.key, self.e0, self.e1, self.meta_fn()))
+        return False
+
 
 def _triple(v):
     if isinstance(v, (list, tuple)):
@@ -228,10 +252,19 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     _require_cuda(x, packed_w, nbr)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
     y = torch.empty((n_rows_out, c_out), dtype=out_dtype, device=x.device)
-    L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr),
-                                                nbr.shape[1], kvol, int(flip_k), n_rows_out, c_out,
-                                                L.ptr(y), _dtype_code(y), L.stream_ptr()),
-            "pcd_sparse_conv_gather_gemm")
+
+    def meta():
+        pairs = int((nbr >= 0).sum().item())
+        e = 2
+        return dict(bytes=(x.shape[0] * x.shape[1] + n_rows_out * c_out) * e + 8 * pairs
+                    + kvol * x.shape[1] * c_out * e, flops=2 * pairs * x.shape[1] * c_out,
+                    rows=n_rows_out, pairs=pairs)
+
+    with _Timed(f"gather_gemm_kernel<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
+        L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[1], L.ptr(packed_w), L.ptr(bias),
+                                                    L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
+                                                    c_out, L.ptr(y), _dtype_code(y), L.stream_ptr()),
+                "pcd_sparse_conv_gather_gemm")
     return y
 
 
@@ -245,9 +278,24 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol):
     lib = L.lib()
     ws = _ws(lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax), x.device)
     dw = torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
-    L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
-                                      L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
-                                      L.stream_ptr()), "pcd_sparse_conv_wgrad")
+
+    def meta():
+        npairs = int(pair_num.sum().item())
+        e = 2
+        return dict(bytes=(x.shape[0] * x.shape[1] + dy.shape[0] * cout) * e + 8 * npairs
+                    + kvol * cin * cout * 4, flops=2 * npairs * x.shape[1] * cout, rows=dy.shape[0],
+                    pairs=npairs)
+
+    def blocks(c):
+        b = (c + 15) // 16
+        return 4 if b >= 4 else (2 if b >= 2 else 1)
+
+    with _Timed(f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}> {x.shape[1]}x{cout} K={kvol}", meta):
+        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
+                                          L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
+                                          L.stream_ptr()), "pcd_sparse_conv_wgrad")
+    L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
+            "pcd_sparse_conv_wgrad_reduce")
     return dw
 
 

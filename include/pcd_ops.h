@@ -163,13 +163,16 @@ int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w, c
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, int c_out, void *y, int y_dtype, void *stream);
 
-/* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout),
- * dbias[cout] = sum_o dY[o][cout] (may be NULL).  Deterministic: partial slabs in `workspace`
- * are reduced in a fixed order. */
+/* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
+ * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
+ * pcd_sparse_conv_wgrad_reduce sums them in a fixed order into dweight (deterministic, no atomics).
+ * `dweight` of the first call is only used when pmax == 0 (it is zeroed); it may be NULL otherwise. */
 size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax);
 int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
                           const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                           float *dweight, void *workspace, size_t workspace_bytes, void *stream);
+int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
+                                 const void *workspace, void *stream);
 
 /* ============================================================================================
  * (a13/a14) BEV scatter -- replaces SparseConvTensor.dense() + the view in
