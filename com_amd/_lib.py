@@ -43,7 +43,7 @@ PROTOTYPES = {
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_bev_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_bev_scatter": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

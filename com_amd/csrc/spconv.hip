@@ -95,7 +95,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;
     const int g = lane >> 4;
-    const int r0wg = blockIdx.x * ROWS;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed only): give each
+    // XCD a CONTIGUOUS run of row tiles so its private L2 holds 1/8 of the feature matrix (+ halo) instead
+    // of every XCD streaming all of it.  gridDim.x is a multiple of 8; surplus tiles exit.
+    const int tiles_per_xcd = gridDim.x >> 3;
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    const int r0wg = tile * ROWS;
+    if (r0wg >= n_out) return;
     constexpr int c_out = NB * 16;
 
     for (int idx = threadIdx.x; idx < K * ROWS; idx += 256) {
@@ -220,7 +226,7 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, void *y,
                      int y_dtype, int nsteps, hipStream_t st) {
     constexpr int ROWS = 4 * MI * 16;
-    int grid = pcd_div_up(n_out, ROWS);
+    int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
     size_t lds = wbytes + (size_t)K * ROWS * sizeof(int);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
@@ -248,7 +254,7 @@ template <int MB, int NBW>
 __global__ __launch_bounds__(256) void wgrad_kernel(
     const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
     int cout, const int32_t *__restrict__ pairs, const int32_t *__restrict__ pair_num, int K, int pmax,
-    int pairs_per_wg, int n_cout_chunks, float *__restrict__ slab) {
+    int rows_per_split, int n_splits, int n_chunks, int n_cout_chunks, float *__restrict__ slab) {
     constexpr int CI = MB * 16, CO = NBW * 16;
     constexpr int XS = CI + 8, YS = CO + 8;  // padded row strides (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,17 +264,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     unsigned short *Ys = Xs + 32 * XS;
     float *tile = (float *)smem;  // reduction tile aliases the staging area (used after the main loop)
 
-    const int k = blockIdx.x;
-    const int split = blockIdx.y;
-    const int cic = blockIdx.z / n_cout_chunks;
-    const int coc = blockIdx.z % n_cout_chunks;
+    // 1-D grid of (split, k, chunk) items, contiguous runs per XCD (block b -> XCD b % 8): all offsets and
+    // channel chunks of one ROW RANGE run on one XCD, whose L2 then holds that range of X and dY.
+    const int items = K * n_splits * n_chunks;
+    const int per_xcd = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    const int split = item / (K * n_chunks);
+    const int rem = item - split * (K * n_chunks);
+    const int k = rem / n_chunks;
+    const int chunk = rem - k * n_chunks;
+    const int cic = chunk / n_cout_chunks;
+    const int coc = chunk % n_cout_chunks;
     const int ci0 = cic * CI, co0 = coc * CO;
     const int P = pair_num[k];
-    const int p_begin = split * pairs_per_wg;
-    int p_end = p_begin + pairs_per_wg;
-    if (p_end > P) p_end = P;
     const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
     const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+    // pairs of offset k are ascending in input row: this split owns input rows [row_lo, row_hi)
+    const int row_lo = split * rows_per_split, row_hi = row_lo + rows_per_split;
+    auto lower_bound = [&](int row) {
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (pin[mid] < row) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int p_begin = lower_bound(row_lo);
+    const int p_end = lower_bound(row_hi);
 
     f32x4 acc[MB][NBW];
 #pragma unroll
@@ -392,30 +415,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     dw[e] = s;
 }
 
-static void wgrad_plan(int pmax, int *splits, int *pairs_per_wg) {
+// splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
+static void wgrad_plan(int pmax, int *splits, int *rows_per_split) {
     int s = pcd_div_up(pmax > 0 ? pmax : 1, 4096);
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     int per = pcd_div_up(pmax > 0 ? pmax : 1, s);
-    per = pcd_div_up(per, 128) * 128;
     *splits = s;
-    *pairs_per_wg = per;
+    *rows_per_split = per;
 }
 
 template <int MB, int NBW>
-static int launch_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int cout,
                         const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *slab,
                         hipStream_t st) {
     constexpr int CI = MB * 16, CO = NBW * 16;
     int splits, per;
     wgrad_plan(pmax, &splits, &per);
+    per = pcd_div_up(n_x > 0 ? n_x : 1, splits);  // the splits partition the rows of X (pairs[k][0] values)
     int ncic = pcd_div_up(cin, CI), ncoc = pcd_div_up(cout, CO);
     size_t lds_stage = (size_t)4 * 32 * (CI + 8 + CO + 8) * 2, lds_tile = (size_t)CI * CO * 4;
     size_t lds = lds_stage > lds_tile ? lds_stage : lds_tile;
-    dim3 grid(K, splits, ncic * ncoc);
+    int items = K * splits * ncic * ncoc;
+    int grid = pcd_div_up(items, 8) * 8;
     wgrad_kernel<MB, NBW><<<grid, 256, lds, st>>>((const unsigned short *)x, cin_pad, cin,
                                                   (const unsigned short *)dy, cout, pairs, pair_num, K,
-                                                  pmax, per, ncoc, slab);
+                                                  pmax, per, splits, ncic * ncoc, ncoc, slab);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -497,12 +522,12 @@ extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int c
     return (size_t)splits * cout * kvol * cin * sizeof(float);
 }
 
-extern "C" int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int cout,
                                      const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                                      float *dweight, void *workspace, size_t workspace_bytes,
                                      void *stream) {
     PCD_ENTER();
-    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin) return PCD_ERR_INVALID_ARG;
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin || n_x < 0) return PCD_ERR_INVALID_ARG;
     if ((cin_pad % 8) != 0 || (cout % 8) != 0) return PCD_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)cout * kvol * cin;
@@ -518,7 +543,7 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const 
     int rc = PCD_ERR_UNSUPPORTED;
 #define WG(M, N)                                                                                  \
     if (mb == M && nb == N)                                                                       \
-        rc = launch_wgrad<M, N>(x, cin_pad, cin, dy, cout, pairs, pair_num, kvol, pmax, slab, st);
+        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, cout, pairs, pair_num, kvol, pmax, slab, st);
     WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
 #undef WG
     return rc;

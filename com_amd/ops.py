@@ -169,7 +169,14 @@ class Rulebook:
     def inverse(self):
         """Rulebook of SparseInverseConv3d sharing this indice_key."""
         assert not self.subm
-        pairs = self.pairs.flip(1).contiguous() if self.pairs is not None else None
+        pairs = None
+        if self.pairs is not None:
+            # swap roles, then restore the canonical order (ascending NEW input row inside each k; the
+            # weight-gradient kernel binary-searches it)
+            sw = self.pairs.flip(1)
+            key = torch.where(sw[:, 0, :] < 0, torch.full_like(sw[:, 0, :], 2 ** 31 - 1), sw[:, 0, :])
+            order = torch.argsort(key, dim=1, stable=True)
+            pairs = torch.gather(sw, 2, order.unsqueeze(1).expand(-1, 2, -1)).contiguous()
         return Rulebook(False, self.kvol, self.n_out, self.n_in, self.nbr_in, self.nbr_out, pairs,
                         self.pair_num, None, None, self.ksize, self.stride, self.padding, self.dilation)
 
@@ -291,7 +298,7 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol):
         return 4 if b >= 4 else (2 if b >= 2 else 1)
 
     with _Timed(f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}> {x.shape[1]}x{cout} K={kvol}", meta):
-        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
+        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
                                           L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
                                           L.stream_ptr()), "pcd_sparse_conv_wgrad")
     L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),

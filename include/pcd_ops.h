@@ -166,9 +166,11 @@ int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w, c
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
  * pcd_sparse_conv_wgrad_reduce sums them in a fixed order into dweight (deterministic, no atomics).
- * `dweight` of the first call is only used when pmax == 0 (it is zeroed); it may be NULL otherwise. */
+ * `dweight` of the first call is only used when pmax == 0 (it is zeroed); it may be NULL otherwise.
+ * pairs[k][0] (rows of x, n_x_rows of them) must be ascending inside each k (canonical order): the
+ * kernel partitions the work by ranges of x rows and binary-searches the pair list. */
 size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax);
-int pcd_sparse_conv_wgrad(const void *x, int cin_pad, int cin, const void *dy, int cout,
+int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, const void *dy, int cout,
                           const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                           float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
