@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int MAX_BLOCKS = 512;
+constexpr int MAX_BLOCKS = 128;
 
 template <typename T>
 struct Piece;  // 16-byte piece of a row
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
 }
 
 static int grid_for(size_t pieces, int pcs) {
-    size_t blocks = (pieces + 1023) / 1024;  // >= 4 pieces per thread
+    size_t blocks = (pieces + 2047) / 2048;  // >= 8 pieces per thread
     if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     // total threads must be a multiple of the pieces per row (pcs | 256 always holds)
@@ -343,6 +343,36 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
                 (const unsigned short *)x, (const unsigned short *)residual, n, c, L.scale, L.shift, relu,
                 (unsigned short *)y);
     }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+__global__ __launch_bounds__(1024) void col_sum_finalize_kernel(const float *__restrict__ partial, int nblocks,
+                                                                int c, float *out) {
+    __shared__ double lds[2 * 16 * 64];
+    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, ss;
+    reduce_partials(partial, nblocks, c, ch, s, ss, lds);
+    if (threadIdx.x >= 64 || ch >= c) return;
+    out[ch] = (float)s;
+}
+
+extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || c <= 0 || !out || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
+    if (n > 0 && !x) return PCD_ERR_INVALID_ARG;
+    BnWs L;
+    if (!bn_ws(workspace, workspace_bytes, c, L)) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = dtype == PCD_F32 ? 4 : 8;
+    int grid = grid_for((size_t)n * (c / N), c / N);
+    if (dtype == PCD_F32)
+        bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
+    else
+        bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
+    col_sum_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

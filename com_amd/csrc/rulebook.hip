@@ -285,7 +285,7 @@ extern "C" size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol) {
 
 extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host,
                                  const int *ksize_host, const int *dil_host, int32_t *nbr,
-                                 int32_t *pairs, int32_t *pair_num, void *workspace,
+                                 int32_t *pairs, int32_t *pair_num, int pad_pairs, void *workspace,
                                  size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
@@ -317,7 +317,7 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
                                           pairs ? wave_cnt : nullptr, nwaves);
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals);
-        hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        if (pad_pairs) hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
         pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr, n, G.K, 1, wave_off, nwaves, pairs);
         pair_num_kernel<<<1, 512, 0, st>>>(totals, G.K, 1, pair_num);
     }
@@ -371,8 +371,8 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                       const int *stride_host, const int *pad_host,
                                       const int *dil_host, int n_out, int32_t *out_indices,
                                       int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs,
-                                      int32_t *pair_num, void *workspace, size_t workspace_bytes,
-                                      void *stream) {
+                                      int32_t *pair_num, int pad_pairs, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || n_out < 0) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
@@ -400,7 +400,7 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                          nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr, L.nwaves);
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals);
-        hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        if (pad_pairs) hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
         pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr_in, n, G.K, 0, L.wave_off, L.nwaves, pairs);
         pair_num_kernel<<<1, 512, 0, st>>>(L.totals, G.K, 0, pair_num);
     }

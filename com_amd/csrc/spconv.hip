@@ -25,6 +25,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -80,7 +81,7 @@ template <int NB, int MI, int G, int SG, bool OUT_BF16>   // SG == 0: weights re
 __global__ __launch_bounds__(256) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
-    int n_out, void *__restrict__ yv, int nsteps) {
+    int n_out, void *__restrict__ yv, int nsteps, unsigned x_bytes) {
     constexpr int ROWS = 4 * MI * 16;
     constexpr bool STAGED = SG > 0;
     constexpr int VEC = STAGED ? SG * NB * 64 : 1;         // uint4 per stage
@@ -128,71 +129,74 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
         for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tile_row = wave * (MI * 16) + rl;
-    uint4 a_cur[G][MI], a_next[G][MI];
-    bool v_cur[G], v_next[G];
+    // Feature rows are fetched with raw buffer loads: a missing neighbour (index -1) becomes an offset beyond
+    // num_records, which the hardware answers with zeros WITHOUT a memory access, a branch or an exec-mask
+    // dance, and the address is one 32-bit shift-add instead of a 64-bit multiply-add.
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const int row_shift = cshift + 1;  // log2(bytes per feature row)
+    u32x4 a0[G][MI], a1[G][MI];
+    bool v0[G], v1[G];
 
-    auto gather_group = [&](int s0, uint4(&a)[G][MI], bool(&valid)[G]) {
+    auto gather_group = [&](int s0, u32x4(&a)[G][MI], bool(&valid)[G]) {
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
             const int q0 = (s0 + gg) * 32 + g * 8;
             const int k = q0 >> cshift;
-            const int c0 = q0 & (c_in - 1);
+            const unsigned c0b = (unsigned)(q0 & (c_in - 1)) * 2u;
             valid[gg] = false;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 int i = (k < K) ? nbr_s[k * ROWS + tile_row + mi * 16] : -1;
-                a[gg][mi] = make_uint4(0, 0, 0, 0);
-                if (i >= 0) {
-                    a[gg][mi] = *reinterpret_cast<const uint4 *>(x + (size_t)i * c_in + c0);
-                    valid[gg] = true;
-                }
+                a[gg][mi] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((unsigned)i << row_shift) + c0b, 0, 0);
+                valid[gg] |= (i >= 0);
             }
         }
     };
 
-    gather_group(0, a_cur, v_cur);
     const int ngroups = (nsteps + G - 1) / G;
     int cur = 0;
     uint4 wreg[WPT];
-    for (int grp = 0; grp < ngroups; ++grp) {
+    // one group of G contraction steps: prefetch the next stage's weights / the next group's rows, multiply
+    auto body = [&](int grp, u32x4(&ac)[G][MI], bool(&vc)[G], u32x4(&an)[G][MI], bool(&vn)[G]) {
         const int s0 = grp * G;
-        if (STAGED && (s0 % SG) == 0) {
-            const size_t base = (size_t)(s0 / SG + 1) * VEC;  // next stage
+        if (STAGED && (s0 % (STAGED ? SG : 1)) == 0) {
+            const size_t base = (size_t)(s0 / (STAGED ? SG : 1) + 1) * VEC;  // next stage
 #pragma unroll
             for (int j = 0; j < WPT; ++j) {
                 size_t e = base + (size_t)j * 256 + threadIdx.x;
                 wreg[j] = e < wtotal ? wp[e] : make_uint4(0, 0, 0, 0);
             }
         }
-        if (grp + 1 < ngroups) gather_group(s0 + G, a_next, v_next);
+        if (grp + 1 < ngroups) gather_group(s0 + G, an, vn);
         const uint4 *wcur = STAGED ? wbuf + (size_t)cur * VEC + (size_t)(s0 % (STAGED ? SG : 1)) * NB * 64
                                    : wbuf + (size_t)s0 * NB * 64;
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
-            if (s0 + gg < nsteps && __any(v_cur[gg])) {
+            if (s0 + gg < nsteps && __any(vc[gg])) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     bf16x8 b = as_bf16x8(wcur[(gg * NB + nb) * 64 + lane]);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, as_bf16x8(a_cur[gg][mi]),
-                                                                              acc[mi][nb], 0, 0, 0);
+                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            b, __builtin_bit_cast(bf16x8, ac[gg][mi]), acc[mi][nb], 0, 0, 0);
                 }
             }
         }
-#pragma unroll
-        for (int gg = 0; gg < G; ++gg) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a_cur[gg][mi] = a_next[gg][mi];
-            v_cur[gg] = v_next[gg];
-        }
-        if (STAGED && ((s0 + G) % SG) == 0) {
+        if (STAGED && ((s0 + G) % (STAGED ? SG : 1)) == 0) {
             uint4 *wnext = wbuf + (size_t)(cur ^ 1) * VEC;
 #pragma unroll
             for (int j = 0; j < WPT; ++j) wnext[(size_t)j * 256 + threadIdx.x] = wreg[j];
             __syncthreads();
             cur ^= 1;
         }
+    };
+
+    gather_group(0, a0, v0);
+    for (int grp = 0; grp < ngroups; grp += 2) {  // ping-pong the two register sets (no copies)
+        body(grp, a0, v0, a1, v1);
+        if (grp + 1 < ngroups) body(grp + 1, a1, v1, a0, v0);
     }
 
 #pragma unroll
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
 template <int NB, int MI, int G, int SG>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, void *y,
-                     int y_dtype, int nsteps, hipStream_t st) {
+                     int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
@@ -240,23 +244,32 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
     }
     if (y_dtype == PCD_BF16)
         kb<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, y, nsteps);
+                                   nbr_stride, K, flip, n_out, y, nsteps, x_bytes);
     else
         kf<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, y, nsteps);
+                                   nbr_stride, K, flip, n_out, y, nsteps, x_bytes);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient
+template <int C>
+struct WgradStride {  // elements; C/16 even -> pad by 16 elements (8 dwords)
+    static constexpr int value = ((C / 16) % 2 == 0) ? C + 16 : C;
+};
+
 template <int MB, int NBW>
 __global__ __launch_bounds__(256) void wgrad_kernel(
     const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
     int cout, const int32_t *__restrict__ pairs, const int32_t *__restrict__ pair_num, int K, int pmax,
-    int rows_per_split, int n_splits, int n_chunks, int n_cout_chunks, float *__restrict__ slab) {
+    int rows_per_split, int n_splits, int n_chunks, int n_cout_chunks, float *__restrict__ slab,
+    unsigned x_bytes, unsigned dy_bytes) {
     constexpr int CI = MB * 16, CO = NBW * 16;
-    constexpr int XS = CI + 8, YS = CO + 8;  // padded row strides (elements)
+    // LDS row strides (elements).  In dwords the stride is 8 * odd, so that (i) the 8 consecutive pair rows a
+    // 32-lane half touches in one ds_read_b64_tr_b16 start on 8 distinct 8-dword windows of the 64 banks and
+    // (ii) 4 consecutive rows x 32 B written by 8 consecutive lanes (ds_write_b128) cover 32 distinct banks.
+    constexpr int XS = WgradStride<CI>::value, YS = WgradStride<CO>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -299,12 +312,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int pr = lane & 31, h = lane >> 5;
+    const int pr = lane >> 1, h = lane & 1;  // staging: lane -> (pair row, 16-byte piece parity)
     const int g = lane >> 4, t = lane & 15;
+    // contraction index k = g*8 + j of the MFMA  <->  staged pair row (j < 4 ? 4g + j : 16 + 4g + j - 4):
+    // any bijection works as long as X and dY use the same one; this one keeps each transpose read on 8
+    // consecutive LDS rows
+    const int trow = 4 * g + (t >> 2);
     // software pipeline: the gathers of the NEXT 32 pairs are in flight while the current 32 are
     // transposed out of LDS and multiplied
     // (rows one step ahead, pair indices two steps ahead, so no dependent-load latency is exposed)
-    uint4 xr[MB], yr[NBW];
+    u32x4 xr[MB], yr[NBW];
     int i_n = -1, o_n = -1;
     auto load_idx = [&](int p0) {
         int p = p0 + pr;
@@ -315,20 +332,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
             o_n = pout[p];
         }
     };
+    // gathered rows come through raw buffer loads: index -1 (beyond the pair range) or a channel piece beyond
+    // the row -> offset past num_records -> hardware returns zeros, no branch, no memory access
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)dy_bytes, 0x00020000);
+    const unsigned x_row_bytes = (unsigned)cin_pad * 2u, y_row_bytes = (unsigned)cout * 2u;
     auto load_rows = [&](int i, int o) {
 #pragma unroll
         for (int pc = 0; pc < MB; ++pc) {
-            int c = (pc * 2 + h) * 8;
-            xr[pc] = make_uint4(0, 0, 0, 0);
-            if (i >= 0 && ci0 + c < cin_pad)
-                xr[pc] = *reinterpret_cast<const uint4 *>(x + (size_t)i * cin_pad + ci0 + c);
+            int c = ci0 + (pc * 2 + h) * 8;
+            unsigned off = (c < cin_pad) ? (unsigned)i * x_row_bytes + (unsigned)c * 2u : 0xFFFFFFF0u;
+            xr[pc] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
         }
 #pragma unroll
         for (int pc = 0; pc < NBW; ++pc) {
-            int c = (pc * 2 + h) * 8;
-            yr[pc] = make_uint4(0, 0, 0, 0);
-            if (o >= 0 && co0 + c < cout)
-                yr[pc] = *reinterpret_cast<const uint4 *>(dy + (size_t)o * cout + co0 + c);
+            int c = co0 + (pc * 2 + h) * 8;
+            unsigned off = (c < cout) ? (unsigned)o * y_row_bytes + (unsigned)c * 2u : 0xFFFFFFF0u;
+            yr[pc] = __builtin_amdgcn_raw_buffer_load_b128(yrs, off, 0, 0);
         }
     };
     const int p_first = p_begin + wave * 32;
@@ -339,10 +359,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
         // stage the 32 gathered rows of X and dY (this wave's private LDS slice)
 #pragma unroll
         for (int pc = 0; pc < MB; ++pc)
-            *reinterpret_cast<uint4 *>(Xs + pr * XS + (pc * 2 + h) * 8) = xr[pc];
+            *reinterpret_cast<u32x4 *>(Xs + pr * XS + (pc * 2 + h) * 8) = xr[pc];
 #pragma unroll
         for (int pc = 0; pc < NBW; ++pc)
-            *reinterpret_cast<uint4 *>(Ys + pr * YS + (pc * 2 + h) * 8) = yr[pc];
+            *reinterpret_cast<u32x4 *>(Ys + pr * YS + (pc * 2 + h) * 8) = yr[pc];
         load_rows(i_n, o_n);
         load_idx(p0 + 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -351,21 +371,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
         bf16x8 af[MB], bfr[NBW];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            const unsigned short *a0 = Xs + (g * 8 + (t >> 2)) * XS + mb * 16 + (t & 3) * 4;
+            const unsigned short *a0 = Xs + trow * XS + mb * 16 + (t & 3) * 4;
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (s16x4 __attribute__((address_space(3))) *)(a0));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3))) *)(a0 + 4 * XS));
+                (s16x4 __attribute__((address_space(3))) *)(a0 + 16 * XS));
             s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             af[mb] = __builtin_bit_cast(bf16x8, cat);
         }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const unsigned short *b0 = Ys + (g * 8 + (t >> 2)) * YS + nb * 16 + (t & 3) * 4;
+            const unsigned short *b0 = Ys + trow * YS + nb * 16 + (t & 3) * 4;
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (s16x4 __attribute__((address_space(3))) *)(b0));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3))) *)(b0 + 4 * YS));
+                (s16x4 __attribute__((address_space(3))) *)(b0 + 16 * YS));
             s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             bfr[nb] = __builtin_bit_cast(bf16x8, cat);
         }
@@ -426,7 +446,7 @@ static void wgrad_plan(int pmax, int *splits, int *rows_per_split) {
 }
 
 template <int MB, int NBW>
-static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int cout,
+static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int n_dy, int cout,
                         const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *slab,
                         hipStream_t st) {
     constexpr int CI = MB * 16, CO = NBW * 16;
@@ -434,13 +454,16 @@ static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void
     wgrad_plan(pmax, &splits, &per);
     per = pcd_div_up(n_x > 0 ? n_x : 1, splits);  // the splits partition the rows of X (pairs[k][0] values)
     int ncic = pcd_div_up(cin, CI), ncoc = pcd_div_up(cout, CO);
-    size_t lds_stage = (size_t)4 * 32 * (CI + 8 + CO + 8) * 2, lds_tile = (size_t)CI * CO * 4;
+    size_t lds_stage = (size_t)4 * 32 * (WgradStride<CI>::value + WgradStride<CO>::value) * 2;
+    size_t lds_tile = (size_t)CI * CO * 4;
     size_t lds = lds_stage > lds_tile ? lds_stage : lds_tile;
     int items = K * splits * ncic * ncoc;
     int grid = pcd_div_up(items, 8) * 8;
     wgrad_kernel<MB, NBW><<<grid, 256, lds, st>>>((const unsigned short *)x, cin_pad, cin,
                                                   (const unsigned short *)dy, cout, pairs, pair_num, K,
-                                                  pmax, per, splits, ncic * ncoc, ncoc, slab);
+                                                  pmax, per, splits, ncic * ncoc, ncoc, slab,
+                                                  (unsigned)((size_t)n_x * cin_pad * 2),
+                                                  (unsigned)((size_t)n_dy * cout * 2));
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -478,7 +501,7 @@ extern "C" int pcd_pack_weight(const float *weight, int kvol, int cin, int cout,
     return PCD_OK;
 }
 
-extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w,
+extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w,
                                            const float *bias, const int32_t *nbr, int nbr_stride,
                                            int kvol, int flip_k, int n_rows_out, int c_out, void *y,
                                            int y_dtype, void *stream) {
@@ -489,6 +512,8 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *
     if (!x || !packed_w || !nbr || !y || nbr_stride < n_rows_out) return PCD_ERR_INVALID_ARG;
     int cshift = log2_exact(c_in);
     if (cshift < 3 || (c_out % 16) != 0) return PCD_ERR_UNSUPPORTED;
+    if (n_rows_in < 0 || (double)n_rows_in * c_in * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
+    const unsigned x_bytes = (unsigned)((size_t)n_rows_in * c_in * 2);
     int nsteps = (kvol * c_in + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     // Launch configuration per output width (NB = c_out/16):  <NB, MI, G (gather look-ahead), SG (stage)>
@@ -497,7 +522,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
     const bool resident = wbytes <= 32 * 1024;
     const bool small = n_rows_out < 32 * 1024;  // few rows: 64-row workgroups fill the chip better
-#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, y, y_dtype, nsteps, st
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, y, y_dtype, nsteps, x_bytes, st
     switch (c_out / 16) {
         case 1:
             return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 16>(GG_ARGS);
@@ -508,7 +533,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *
             return small ? launch_gg<4, 1, 4, 8>(GG_ARGS) : launch_gg<4, 2, 4, 8>(GG_ARGS);
         case 8:
             if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
-            return small ? launch_gg<8, 1, 4, 4>(GG_ARGS) : launch_gg<8, 2, 2, 4>(GG_ARGS);
+            return small ? launch_gg<8, 1, 4, 4>(GG_ARGS) : launch_gg<8, 2, 4, 4>(GG_ARGS);
         default:
             return PCD_ERR_UNSUPPORTED;
     }
@@ -522,12 +547,16 @@ extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int c
     return (size_t)splits * cout * kvol * cin * sizeof(float);
 }
 
-extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int cout,
+extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int n_dy,
+                                     int cout,
                                      const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                                      float *dweight, void *workspace, size_t workspace_bytes,
                                      void *stream) {
     PCD_ENTER();
-    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin || n_x < 0) return PCD_ERR_INVALID_ARG;
+    if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin || n_x < 0 || n_dy < 0)
+        return PCD_ERR_INVALID_ARG;
+    if ((double)n_x * cin_pad * 2 >= 4294966000.0 || (double)n_dy * cout * 2 >= 4294966000.0)
+        return PCD_ERR_UNSUPPORTED;
     if ((cin_pad % 8) != 0 || (cout % 8) != 0) return PCD_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)cout * kvol * cin;
@@ -543,7 +572,7 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int ci
     int rc = PCD_ERR_UNSUPPORTED;
 #define WG(M, N)                                                                                  \
     if (mb == M && nb == N)                                                                       \
-        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, cout, pairs, pair_num, kvol, pmax, slab, st);
+        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, slab, st);
     WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
 #undef WG
     return rc;

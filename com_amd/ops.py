@@ -174,7 +174,8 @@ class Rulebook:
             # swap roles, then restore the canonical order (ascending NEW input row inside each k; the
             # weight-gradient kernel binary-searches it)
             sw = self.pairs.flip(1)
-            key = torch.where(sw[:, 0, :] < 0, torch.full_like(sw[:, 0, :], 2 ** 31 - 1), sw[:, 0, :])
+            valid = torch.arange(sw.shape[2], device=sw.device).unsqueeze(0) < self.pair_num.unsqueeze(1)
+            key = torch.where(valid, sw[:, 0, :], torch.full_like(sw[:, 0, :], 2 ** 31 - 1))
             order = torch.argsort(key, dim=1, stable=True)
             pairs = torch.gather(sw, 2, order.unsqueeze(1).expand(-1, 2, -1)).contiguous()
         return Rulebook(False, self.kvol, self.n_out, self.n_in, self.nbr_in, self.nbr_out, pairs,
@@ -189,7 +190,7 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
     return [int(v) for v in out]
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True):
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False):
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -202,13 +203,14 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
     L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
-                                  L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), L.ptr(ws),
-                                  ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
+                                  L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
+                                  L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
     return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
                     [k // 2 for k in ks], dl)
 
 
-def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True):
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
+                  pad_pairs=False):
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -234,7 +236,8 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
     L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
                                        L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
-                                       L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_fill")
+                                       int(pad_pairs), L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "pcd_rulebook_conv_fill")
     return Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
                     pd, dl)
 
@@ -268,7 +271,7 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
                     rows=n_rows_out, pairs=pairs)
 
     with _Timed(f"gather_gemm_kernel<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
-        L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[1], L.ptr(packed_w), L.ptr(bias),
+        L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
                                                     c_out, L.ptr(y), _dtype_code(y), L.stream_ptr()),
                 "pcd_sparse_conv_gather_gemm")
@@ -298,7 +301,8 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol):
         return 4 if b >= 4 else (2 if b >= 2 else 1)
 
     with _Timed(f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}> {x.shape[1]}x{cout} K={kvol}", meta):
-        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), cout, L.ptr(pairs),
+        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), dy.shape[0], cout,
+                                          L.ptr(pairs),
                                           L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
                                           L.stream_ptr()), "pcd_sparse_conv_wgrad")
     L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
@@ -374,3 +378,16 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
                                 L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(),
                                 L.stream_ptr()), "pcd_bn_backward")
     return dx, dres, dgamma, dbeta
+
+
+def col_sum(x):
+    """out[c] = sum_rows x[:, c] in fp32 (bias gradient), deterministic two-stage reduction."""
+    _require_cuda(x)
+    x = x.contiguous()
+    n, c = x.shape
+    lib = L.lib()
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.pcd_bn_workspace_bytes(c), x.device)
+    L.check(lib.pcd_col_sum(L.ptr(x), _dtype_code(x), n, c, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "pcd_col_sum")
+    return out

@@ -83,7 +83,17 @@ class SparseConvolution(SparseModule):
             rb, _, _ = cached
             return rb, x.indices, x.spatial_shape
         if self.subm:
-            rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+            # a SubM rulebook depends only on (indices, kernel, dilation): layers with different indice_keys on
+            # the same tensor (conv_input 'subm1' and conv1 'res1' of VoxelResBackBone8x) share one build
+            gkey = ("__subm__", x.indices.data_ptr(), x.indices.shape[0], tuple(self.kernel_size),
+                    tuple(self.dilation))
+            hit = x.indice_dict.get(gkey, None)
+            if hit is not None and hit[1] is x.indices:
+                rb = hit[0]
+            else:
+                rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
+                                       self.dilation)
+                x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,

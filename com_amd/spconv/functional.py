@@ -61,7 +61,7 @@ class SparseConvFunction(Function):
             dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol)      # [Cout, K, Cin] f32
             dw = dwk.view(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
+            db = ops.col_sum(dy16)
         return dx, dw, db, None, None
 
 

@@ -104,11 +104,14 @@ int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, int num_featu
  *   pairs    [K][2][n] i32 (may be NULL): spconv's indice_pairs, canonical order = ascending input
  *            row within each k, -1 padded.
  *   pair_num [K] i32 (required iff pairs != NULL)
+ *   pad_pairs != 0: entries of pairs beyond pair_num[k] are set to -1 (spconv's padding; costs a memset
+ *            of the whole table -- the compute kernels never read them)
  * ============================================================================================ */
 size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol);
 int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host /*[3]*/,
                       const int *ksize_host, const int *dil_host, int32_t *nbr, int32_t *pairs,
-                      int32_t *pair_num, void *workspace, size_t workspace_bytes, void *stream);
+                      int32_t *pair_num, int pad_pairs, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* ============================================================================================
  * (a9) SparseConv3d (strided) rulebook -- replaces get_indice_pairs(subm=False) behind
@@ -135,8 +138,8 @@ int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch, const int 
 int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
                            const int *ksize_host, const int *stride_host, const int *pad_host,
                            const int *dil_host, int n_out, int32_t *out_indices, int32_t *nbr_in,
-                           int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
@@ -157,9 +160,10 @@ int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode, 
  *   forward : x = features [n_in][cin_pad] bf16, nbr = nbr_out [K][n_out], packed mode 0;
  *   dgrad   : x = dY [n_out][cout_pad], nbr = nbr_in [K][n_in] (SubM: nbr with flip_k = 1),
  *             packed mode 1.
- * c_in = contraction channels (row stride of x, % 8 == 0), c_out = output channels (% 16 == 0),
+ * n_rows_in = rows of x (bounds of the gathers), c_in = contraction channels (row stride of x, a power
+ * of two >= 8), c_out = output channels (% 16 == 0),
  * nbr_stride = row stride (elements) of the nbr table.  y dtype PCD_BF16 or PCD_F32; bias f32 or NULL. */
-int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w, const float *bias,
+int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, int c_out, void *y, int y_dtype, void *stream);
 
@@ -170,7 +174,7 @@ int pcd_sparse_conv_gather_gemm(const void *x, int c_in, const void *packed_w, c
  * pairs[k][0] (rows of x, n_x_rows of them) must be ascending inside each k (canonical order): the
  * kernel partitions the work by ranges of x rows and binary-searches the pair list. */
 size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax);
-int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, const void *dy, int cout,
+int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, const void *dy, int n_dy_rows, int cout,
                           const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                           float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
@@ -204,6 +208,9 @@ int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32
  * c % 8 == 0 (bf16) / c % 4 == 0 (f32), c/piece a power of two <= 256.  Deterministic (no atomics).
  * ============================================================================================ */
 size_t pcd_bn_workspace_bytes(int c);
+/* out[c] = sum over the n rows of x [n][c] (bias gradient); workspace = pcd_bn_workspace_bytes(c). */
+int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, void *workspace,
+                size_t workspace_bytes, void *stream);
 int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c, const float *gamma,
                    const float *beta, float eps, float momentum, int training, float *running_mean,
                    float *running_var, int relu, void *y, float *save_mean, float *save_invstd,

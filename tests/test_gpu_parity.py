@@ -119,7 +119,7 @@ GEOMS = {
 
 def _check_subm(idx_np, batch, shape):
     rb_o = O.rulebook_subm(idx_np, shape)
-    rb = _ops().rulebook_subm(torch.from_numpy(idx_np).to(DEV), batch, list(shape))
+    rb = _ops().rulebook_subm(torch.from_numpy(idx_np).to(DEV), batch, list(shape), pad_pairs=True)
     np.testing.assert_array_equal(_cpu(rb.nbr_out), rb_o["nbr_out"])
     np.testing.assert_array_equal(_cpu(rb.pair_num), rb_o["pair_num"])
     np.testing.assert_array_equal(_cpu(rb.pairs), rb_o["pairs"])
@@ -128,7 +128,8 @@ def _check_subm(idx_np, batch, shape):
 
 def _check_conv(idx_np, batch, shape, geo):
     rb_o = O.rulebook_conv(idx_np, shape, geo["k"], geo["s"], geo["p"])
-    rb = _ops().rulebook_conv(torch.from_numpy(idx_np).to(DEV), batch, list(shape), geo["k"], geo["s"], geo["p"])
+    rb = _ops().rulebook_conv(torch.from_numpy(idx_np).to(DEV), batch, list(shape), geo["k"], geo["s"], geo["p"],
+                              pad_pairs=True)
     assert rb.n_out == rb_o["n_out"] and rb.out_shape == list(rb_o["out_shape"])
     np.testing.assert_array_equal(_cpu(rb.out_indices), rb_o["out_indices"])
     np.testing.assert_array_equal(_cpu(rb.nbr_out), rb_o["nbr_out"])
