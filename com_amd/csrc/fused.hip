@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int MAX_BLOCKS = 128;
+constexpr int MAX_BLOCKS = 512;       // blocks of the reduction passes (= rows of the partial buffer)
+constexpr int MAX_APPLY_BLOCKS = 2048; // blocks of the streaming apply passes
 
 template <typename T>
 struct Piece;  // 16-byte piece of a row
@@ -91,41 +92,62 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, 
     block_reduce_store<N, 2>(acc, c, pcs, partial, lds);
 }
 
-// Reduce the per-block partials of 64 channels per workgroup: 16 waves split the block axis (coalesced
-// over channels), then a fixed-order LDS reduction.  partial layout [nblocks][2][c].
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int ch,
-                                                double &s, double &ss, double *lds /*[2][16][64]*/) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// Reduce the per-block partials [nblocks][2][c] with ONE 1024-thread workgroup: thread -> (slice, channel),
+// 1024/cp slices split the block axis (cp = c rounded up to a power of two, coalesced over channels), then a
+// fixed-order LDS reduction over the slices.  Requires c <= 1024.
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblocks, int c, int &ch,
+                                                double &s, double &ss, double *lds /*[2][1024]*/) {
+    int cp = 1;
+    while (cp < c) cp <<= 1;
+    const int slices = 1024 / cp;
+    const int slice = threadIdx.x / cp;
+    ch = threadIdx.x - slice * cp;
     double a = 0.0, b = 0.0;
-    if (ch < c)
-        for (int blk = w; blk < nblocks; blk += 16) {
+    if (ch < c) {
+        // 8 independent loads in flight per thread (the rows were just written: L2 hits, latency bound)
+        int blk = slice;
+        for (; blk + 7 * slices < nblocks; blk += 8 * slices) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = partial[((size_t)(blk + u * slices) * 2 + 0) * c + ch];
+                vb[u] = partial[((size_t)(blk + u * slices) * 2 + 1) * c + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += (double)va[u];
+                b += (double)vb[u];
+            }
+        }
+        for (; blk < nblocks; blk += slices) {
             a += (double)partial[((size_t)blk * 2 + 0) * c + ch];
             b += (double)partial[((size_t)blk * 2 + 1) * c + ch];
         }
-    lds[(0 * 16 + w) * 64 + lane] = a;
-    lds[(1 * 16 + w) * 64 + lane] = b;
+    }
+    lds[threadIdx.x] = a;
+    lds[1024 + threadIdx.x] = b;
     __syncthreads();
     s = 0.0;
     ss = 0.0;
-    if (w == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            s += lds[(0 * 16 + q) * 64 + lane];
-            ss += lds[(1 * 16 + q) * 64 + lane];
+    if (slice == 0) {
+        for (int q = 0; q < slices; ++q) {
+            s += lds[q * cp + ch];
+            ss += lds[1024 + q * cp + ch];
         }
     }
+    if (slice != 0) ch = c;  // only slice 0 carries the result
 }
 
-// grid = ceil(c/64), block = 1024: mean / invstd / running stats; scale/shift for the apply pass
+// grid = 1, block = 1024: mean / invstd / running stats; scale/shift for the apply pass
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ partial, int nblocks, int n, int c, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float momentum, float *running_mean, float *running_var,
     float *save_mean, float *save_invstd, float *scale, float *shift) {
-    __shared__ double lds[2 * 16 * 64];
-    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double lds[2 * 1024];
+    int ch;
     double s, ss;
     reduce_partials(partial, nblocks, c, ch, s, ss, lds);
-    if (threadIdx.x >= 64 || ch >= c) return;
+    if (ch >= c) return;
     double mean = n > 0 ? s / n : 0.0;
     double var = n > 0 ? ss / n - mean * mean : 0.0;
     if (var < 0.0) var = 0.0;
@@ -220,11 +242,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial,
                                                                int nblocks, int c, float *dgamma,
                                                                float *dbeta) {
-    __shared__ double lds[2 * 16 * 64];
-    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double lds[2 * 1024];
+    int ch;
     double s, ss;
     reduce_partials(partial, nblocks, c, ch, s, ss, lds);
-    if (threadIdx.x >= 64 || ch >= c) return;
+    if (ch >= c) return;
     dbeta[ch] = (float)s;
     dgamma[ch] = (float)ss;
 }
@@ -271,9 +293,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
-static int grid_for(size_t pieces, int pcs) {
-    size_t blocks = (pieces + 2047) / 2048;  // >= 8 pieces per thread
-    if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+static int grid_for(size_t pieces, int pcs, int max_blocks = MAX_BLOCKS) {
+    size_t blocks = (pieces + 1023) / 1024;  // >= 4 pieces per thread
+    if (blocks > (size_t)max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     // total threads must be a multiple of the pieces per row (pcs | 256 always holds)
     (void)pcs;
@@ -322,12 +344,13 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     const int N = dtype == PCD_F32 ? 4 : 8;
     const int pcs = c / N;
     int grid = grid_for((size_t)n * pcs, pcs);
+    int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (training) {
         if (dtype == PCD_F32)
             bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
         else
             bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
-        bn_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, n, c, gamma, beta, eps,
+        bn_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, n, c, gamma, beta, eps,
                                                                momentum, running_mean, running_var,
                                                                save_mean, save_invstd, L.scale, L.shift);
     } else {
@@ -336,10 +359,10 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     }
     if (n > 0) {
         if (dtype == PCD_F32)
-            bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float *)x, (const float *)residual, n, c,
+            bn_apply_kernel<float><<<agrid, 256, 0, st>>>((const float *)x, (const float *)residual, n, c,
                                                          L.scale, L.shift, relu, (float *)y);
         else
-            bn_apply_kernel<unsigned short><<<grid, 256, 0, st>>>(
+            bn_apply_kernel<unsigned short><<<agrid, 256, 0, st>>>(
                 (const unsigned short *)x, (const unsigned short *)residual, n, c, L.scale, L.shift, relu,
                 (unsigned short *)y);
     }
@@ -349,11 +372,11 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
 
 __global__ __launch_bounds__(1024) void col_sum_finalize_kernel(const float *__restrict__ partial, int nblocks,
                                                                 int c, float *out) {
-    __shared__ double lds[2 * 16 * 64];
-    int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ double lds[2 * 1024];
+    int ch;
     double s, ss;
     reduce_partials(partial, nblocks, c, ch, s, ss, lds);
-    if (threadIdx.x >= 64 || ch >= c) return;
+    if (ch >= c) return;
     out[ch] = (float)s;
 }
 
@@ -372,7 +395,7 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, v
         bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
     else
         bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
-    col_sum_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, out);
+    col_sum_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -392,22 +415,23 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     const int N = dtype == PCD_F32 ? 4 : 8;
     const int pcs = c / N;
     int grid = grid_for((size_t)n * pcs, pcs);
+    int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (dtype == PCD_F32) {
         bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, c, save_mean, save_invstd,
                                                           relu, L.partial);
-        bn_bwd_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
-            bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>(
+            bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, c, gamma, save_mean, save_invstd,
                 dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
     } else {
         typedef unsigned short B;
         bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
                                                       save_mean, save_invstd, relu, L.partial);
-        bn_bwd_finalize_kernel<<<pcd_div_up(c, 64), 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
-            bn_bwd_apply_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
+            bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
                                                          gamma, save_mean, save_invstd, dgamma, dbeta, relu,
                                                          training, (B *)dx, (B *)dresidual);
     }
