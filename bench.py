@@ -218,7 +218,7 @@ def main():
         sf, out = net(bd["voxel_features"], bd["voxel_coords"], B)
         # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense
         # gradient, one read of the map forward and one write backward)
-        loss = torch.dot(sf.reshape(-1), loss_w)
+        loss = torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)   # (rocBLAS dot is not capturable)
         if ev is not None: ev("backward")
         opt.zero_grad(set_to_none=True)
         loss.backward()

@@ -33,26 +33,26 @@ PROTOTYPES = {
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_subm_workspace_bytes": (_sz, [_i, _i]),
-    "pcd_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcd_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_workspace_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
-                                    _sz, _vp]),
+                                    _vp, _sz, _vp]),
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_bev_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "pcd_bev_scatter": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "pcd_bev_gather": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pcd_bev_scatter": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_bev_gather": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_bn_workspace_bytes": (_sz, [_i]),
-    "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
-                            _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                              _vp]),
 }
 

@@ -15,10 +15,11 @@ __device__ __host__ static inline size_t pcd_align_up_dev(size_t x) { return (x 
 
 namespace {
 
-__global__ __launch_bounds__(256) void bev_map_kernel(const int4 *__restrict__ idx, int n, int B,
-                                                      int D, int H, int W, int *__restrict__ map) {
+__global__ __launch_bounds__(256) void bev_map_kernel(const int4 *__restrict__ idx, int n,
+                                                      const int32_t *n_dev, int B, int D, int H, int W,
+                                                      int *__restrict__ map) {
     int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
+    if (r >= eff_rows(n_dev, n)) return;
     int4 c = idx[r];
     if (c.x < 0 || c.x >= B || c.y < 0 || c.y >= D || c.z < 0 || c.z >= H || c.w < 0 || c.w >= W) return;
     map[(((size_t)c.x * D + c.y) * H + c.z) * W + c.w] = r;
@@ -67,10 +68,12 @@ __global__ __launch_bounds__(256) void bev_scatter_kernel(const T *__restrict__ 
 
 template <typename T>
 __global__ __launch_bounds__(256) void bev_gather_kernel(const T *__restrict__ dout, int C, int c_stride,
-                                                         const int4 *__restrict__ idx, int n, int D,
-                                                         int H, int W, T *__restrict__ dfeat) {
+                                                         const int4 *__restrict__ idx, int n_cap,
+                                                         const int32_t *n_dev, int D, int H, int W,
+                                                         T *__restrict__ dfeat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *tile = (T *)smem;  // [64][C+pad]
+    const int n = eff_rows(n_dev, n_cap);
     const int LD = C + (int)(4 / sizeof(T));
     const int r0 = blockIdx.x * 64;
     const int rl = threadIdx.x & 63;
@@ -100,11 +103,12 @@ extern "C" size_t pcd_bev_workspace_bytes(int batch, int d, int h, int w) {
 
 template <typename T>
 static int bev_scatter_t(const void *features, int c, int c_stride, const int32_t *indices, int n,
-                         int batch, int d, int h, int w, void *out, int *map, hipStream_t st) {
+                         const int32_t *n_dev, int batch, int d, int h, int w, void *out, int *map,
+                         hipStream_t st) {
     size_t cells = (size_t)batch * d * h * w;
-    hipMemsetAsync(map, 0xFF, cells * sizeof(int), st);
+    pcd_fill(map, 0xFF, cells * sizeof(int), st);
     if (n > 0)
-        bev_map_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, batch, d, h, w, map);
+        bev_map_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, batch, d, h, w, map);
     int XT = w <= 192 ? w : 128;
     // keep the LDS tile under the 64 KB default dynamic-LDS limit
     while ((size_t)c * (XT + 2) * sizeof(T) > 60 * 1024 && XT > 32) XT /= 2;
@@ -118,8 +122,9 @@ static int bev_scatter_t(const void *features, int c, int c_stride, const int32_
 }
 
 extern "C" int pcd_bev_scatter(const void *features, int c, int c_stride, int dtype,
-                               const int32_t *indices, int n, int batch, int d, int h, int w,
-                               void *out, void *workspace, size_t workspace_bytes, void *stream) {
+                               const int32_t *indices, int n, const int32_t *n_dev, int batch, int d,
+                               int h, int w, void *out, void *workspace, size_t workspace_bytes,
+                               void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || c_stride < c || batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !out)
         return PCD_ERR_INVALID_ARG;
@@ -129,19 +134,20 @@ extern "C" int pcd_bev_scatter(const void *features, int c, int c_stride, int dt
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PCD_F32) {
         if (c_stride % 4) return PCD_ERR_UNSUPPORTED;
-        return bev_scatter_t<float>(features, c, c_stride, indices, n, batch, d, h, w, out,
+        return bev_scatter_t<float>(features, c, c_stride, indices, n, n_dev, batch, d, h, w, out,
                                     (int *)workspace, st);
     }
     if (dtype == PCD_BF16) {
         if (c_stride % 8) return PCD_ERR_UNSUPPORTED;
-        return bev_scatter_t<unsigned short>(features, c, c_stride, indices, n, batch, d, h, w, out,
+        return bev_scatter_t<unsigned short>(features, c, c_stride, indices, n, n_dev, batch, d, h, w, out,
                                              (int *)workspace, st);
     }
     return PCD_ERR_INVALID_ARG;
 }
 
 extern "C" int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32_t *indices,
-                              int n, int batch, int d, int h, int w, void *dfeatures, void *stream) {
+                              int n, const int32_t *n_dev, int batch, int d, int h, int w, void *dfeatures,
+                              void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || c_stride < c || batch <= 0 || d <= 0 || h <= 0 || w <= 0)
         return PCD_ERR_INVALID_ARG;
@@ -152,12 +158,12 @@ extern "C" int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, 
     if (dtype == PCD_F32) {
         size_t lds = (size_t)64 * (c + 1) * sizeof(float);
         bev_gather_kernel<float><<<grid, 256, lds, st>>>((const float *)dout, c, c_stride,
-                                                         (const int4 *)indices, n, d, h, w,
+                                                         (const int4 *)indices, n, n_dev, d, h, w,
                                                          (float *)dfeatures);
     } else if (dtype == PCD_BF16) {
         size_t lds = (size_t)64 * (c + 2) * sizeof(unsigned short);
         bev_gather_kernel<unsigned short><<<grid, 256, lds, st>>>(
-            (const unsigned short *)dout, c, c_stride, (const int4 *)indices, n, d, h, w,
+            (const unsigned short *)dout, c, c_stride, (const int4 *)indices, n, n_dev, d, h, w,
             (unsigned short *)dfeatures);
     } else {
         return PCD_ERR_INVALID_ARG;

@@ -66,6 +66,15 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Row count of a launch: `n_cap` is the host-side capacity (grid size, strides); when `n_dev` is non-NULL the
+// real count lives in device memory (so the caller never has to read it back -> hipGraph capturable) and is
+// clamped to the capacity.
+__device__ __forceinline__ int eff_rows(const int32_t *n_dev, int n_cap) {
+    if (!n_dev) return n_cap;
+    int v = *n_dev;
+    return v < n_cap ? (v < 0 ? 0 : v) : n_cap;
+}
+
 // exclusive prefix of a 0/1 predicate inside a wave + wave total (ballot / popcount)
 __device__ __forceinline__ int wave_rank(bool pred, int &total) {
     u64 m = __ballot(pred);
@@ -117,6 +126,28 @@ __device__ __forceinline__ u32 hash_u64(u64 k) {
     k *= 0xff51afd7ed558ccdull;
     k ^= k >> 33;
     return (u32)k ^ (u32)(k >> 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fill kernel used instead of hipMemsetAsync: memset nodes recorded during stream capture were observed not
+// to be re-executed reliably on hipGraph replay (ROCm 7.2: hash tables stayed dirty -> probe loops never
+// ended on the 3rd replay); a plain kernel node always replays.  `p` must be 16-byte aligned, bytes % 4 == 0.
+static __global__ __launch_bounds__(256) void pcd_fill_kernel(uint4 *p, u32 word, size_t n16, size_t tail_words) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const uint4 v = make_uint4(word, word, word, word);
+    for (size_t e = i; e < n16; e += stride) p[e] = v;
+    if (i < tail_words) reinterpret_cast<u32 *>(p + n16)[i] = word;
+}
+static inline void pcd_fill(void *p, int byte_value, size_t bytes, hipStream_t st) {
+    if (bytes == 0 || p == nullptr) return;
+    u32 b = (u32)(byte_value & 0xFF);
+    u32 word = b | (b << 8) | (b << 16) | (b << 24);
+    size_t n16 = bytes / 16, tail = (bytes % 16) / 4;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    pcd_fill_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint4 *)p, word, n16, tail);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,8 +204,8 @@ static inline int scan_exclusive(F f, int n, int *out, int *block_sums, int *tot
     int nb = pcd_div_up(n, 256);
     if (n <= 0) {
         // out[0] = 0, total = 0
-        hipMemsetAsync(out, 0, sizeof(int), st);
-        if (total_out) hipMemsetAsync(total_out, 0, sizeof(int), st);
+        pcd_fill(out, 0, sizeof(int), st);
+        if (total_out) pcd_fill(total_out, 0, sizeof(int), st);
         return PCD_OK;
     }
     scan_reduce_kernel<F><<<nb, 256, 0, st>>>(f, n, block_sums);

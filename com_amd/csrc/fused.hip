@@ -71,12 +71,13 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, int n, int c,
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, int n_cap,
+                                                       const int32_t *n_dev, int c,
                                                        float *__restrict__ partial) {
     constexpr int N = Piece<T>::N;
     __shared__ float lds[256 * 2 * N];
     const int pcs = c / N;
-    const size_t total = (size_t)n * pcs;
+    const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     float acc[2][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
@@ -140,10 +141,12 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
 
 // grid = 1, block = 1024: mean / invstd / running stats; scale/shift for the apply pass
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
-    const float *__restrict__ partial, int nblocks, int n, int c, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float eps, float momentum, float *running_mean, float *running_var,
-    float *save_mean, float *save_invstd, float *scale, float *shift) {
+    const float *__restrict__ partial, int nblocks, int n_cap, const int32_t *n_dev, int c,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+    float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *scale,
+    float *shift) {
     __shared__ double lds[2 * 1024];
+    const int n = eff_rows(n_dev, n_cap);
     int ch;
     double s, ss;
     reduce_partials(partial, nblocks, c, ch, s, ss, lds);
@@ -176,12 +179,13 @@ __global__ void bn_eval_coeff_kernel(int c, const float *gamma, const float *bet
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, const T *__restrict__ res,
-                                                       int n, int c, const float *__restrict__ scale,
+                                                       int n_cap, const int32_t *n_dev, int c,
+                                                       const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int relu,
                                                        T *__restrict__ y) {
     constexpr int N = Piece<T>::N;
     const int pcs = c / N;
-    const size_t total = (size_t)n * pcs;
+    const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
 #pragma unroll
@@ -206,14 +210,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ dy, const T *__restrict__ x,
-                                                            const T *__restrict__ y, int n, int c,
+                                                            const T *__restrict__ y, int n_cap,
+                                                            const int32_t *n_dev, int c,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, int relu,
                                                             float *__restrict__ partial) {
     constexpr int N = Piece<T>::N;
     __shared__ float lds[256 * 2 * N];
     const int pcs = c / N;
-    const size_t total = (size_t)n * pcs;
+    const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
     float mu[N], is[N];
 #pragma unroll
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ x,
-                                                           const T *__restrict__ y, int n, int c,
+                                                           const T *__restrict__ y, int n_cap,
+                                                           const int32_t *n_dev, int c,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ invstd,
@@ -263,6 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            T *__restrict__ dres) {
     constexpr int N = Piece<T>::N;
     const int pcs = c / N;
+    const int n = eff_rows(n_dev, n_cap);
     const size_t total = (size_t)n * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
     float mu[N], is[N], gm[N], k1[N], k2[N];
@@ -293,12 +300,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
+// Reduction passes ALWAYS use MAX_BLOCKS workgroups: which elements a (block, thread) accumulates then depends
+// only on the real row count (host n or *n_dev) and never on the capacity the buffers were allocated with, so
+// eager and static-shape (hipGraph) execution produce bit-identical statistics.
 static int grid_for(size_t pieces, int pcs, int max_blocks = MAX_BLOCKS) {
-    size_t blocks = (pieces + 1023) / 1024;  // >= 4 pieces per thread
+    (void)pcs;
+    if (max_blocks == MAX_BLOCKS) return MAX_BLOCKS;
+    size_t blocks = (pieces + 1023) / 1024;  // streaming apply passes: >= 4 pieces per thread
     if (blocks > (size_t)max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    // total threads must be a multiple of the pieces per row (pcs | 256 always holds)
-    (void)pcs;
     return (int)blocks;
 }
 
@@ -330,7 +340,7 @@ extern "C" size_t pcd_bn_workspace_bytes(int c) {
 extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
                               const float *gamma, const float *beta, float eps, float momentum,
                               int training, float *running_mean, float *running_var, int relu, void *y,
-                              float *save_mean, float *save_invstd, void *workspace,
+                              float *save_mean, float *save_invstd, const int32_t *n_dev, void *workspace,
                               size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
@@ -347,10 +357,11 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (training) {
         if (dtype == PCD_F32)
-            bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
+            bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, n_dev, c, L.partial);
         else
-            bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
-        bn_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, n, c, gamma, beta, eps,
+            bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, n_dev, c,
+                                                                  L.partial);
+        bn_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, n, n_dev, c, gamma, beta, eps,
                                                                momentum, running_mean, running_var,
                                                                save_mean, save_invstd, L.scale, L.shift);
     } else {
@@ -359,11 +370,11 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     }
     if (n > 0) {
         if (dtype == PCD_F32)
-            bn_apply_kernel<float><<<agrid, 256, 0, st>>>((const float *)x, (const float *)residual, n, c,
+            bn_apply_kernel<float><<<agrid, 256, 0, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
                                                          L.scale, L.shift, relu, (float *)y);
         else
             bn_apply_kernel<unsigned short><<<agrid, 256, 0, st>>>(
-                (const unsigned short *)x, (const unsigned short *)residual, n, c, L.scale, L.shift, relu,
+                (const unsigned short *)x, (const unsigned short *)residual, n, n_dev, c, L.scale, L.shift, relu,
                 (unsigned short *)y);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(1024) void col_sum_finalize_kernel(const float *__r
     out[ch] = (float)s;
 }
 
-extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, void *workspace,
-                           size_t workspace_bytes, void *stream) {
+extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, const int32_t *n_dev,
+                           void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || !out || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
@@ -392,9 +403,9 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, v
     const int N = dtype == PCD_F32 ? 4 : 8;
     int grid = grid_for((size_t)n * (c / N), c / N);
     if (dtype == PCD_F32)
-        bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, c, L.partial);
+        bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, n_dev, c, L.partial);
     else
-        bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, c, L.partial);
+        bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, n_dev, c, L.partial);
     col_sum_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -403,7 +414,8 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, v
 extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
                                const float *gamma, const float *save_mean, const float *save_invstd,
                                int relu, int training, void *dx, void *dresidual, float *dgamma,
-                               float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
+                               float *dbeta, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                               void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
@@ -418,20 +430,20 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (dtype == PCD_F32) {
         bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
-                                                          (const float *)y, n, c, save_mean, save_invstd,
-                                                          relu, L.partial);
+                                                          (const float *)y, n, n_dev, c, save_mean,
+                                                          save_invstd, relu, L.partial);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
-                (const float *)dy, (const float *)x, (const float *)y, n, c, gamma, save_mean, save_invstd,
-                dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
+                (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, save_mean,
+                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
     } else {
         typedef unsigned short B;
-        bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
+        bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                       save_mean, save_invstd, relu, L.partial);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
-            bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, c,
+            bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                          gamma, save_mean, save_invstd, dgamma, dbeta, relu,
                                                          training, (B *)dx, (B *)dresidual);
     }

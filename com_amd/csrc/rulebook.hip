@@ -36,10 +36,11 @@ __device__ __forceinline__ u32 lin_key(int b, int z, int y, int x, int D, int H,
     return (((u32)b * D + z) * H + y) * W + x;
 }
 
-__global__ __launch_bounds__(256) void hash_insert_kernel(const int4 *__restrict__ idx, int n, int D,
-                                                          int H, int W, u64 *table, u32 mask) {
+__global__ __launch_bounds__(256) void hash_insert_kernel(const int4 *__restrict__ idx, int n,
+                                                          const int32_t *n_dev, int D, int H, int W,
+                                                          u64 *table, u32 mask) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= eff_rows(n_dev, n)) return;
     int4 c = idx[i];
     u32 key = lin_key(c.x, c.y, c.z, c.w, D, H, W);
     u64 packed = ((u64)key << 32) | (u32)i;
@@ -64,11 +65,12 @@ __device__ __forceinline__ int hash_lookup(const u64 *__restrict__ table, u32 ma
 // One thread per output row, loop over the K offsets.  nbr[k][o] = row of (coord_o - c*dil + k*dil).
 // wave_cnt[k][wave] = number of hits of this wave's 64 rows (feeds the pair compaction).
 __global__ __launch_bounds__(256) void subm_probe_kernel(const int4 *__restrict__ idx, int n,
-                                                         ConvGeom G, const u64 *__restrict__ table,
+                                                         const int32_t *n_dev, ConvGeom G,
+                                                         const u64 *__restrict__ table,
                                                          u32 mask, int32_t *__restrict__ nbr,
                                                          int *__restrict__ wave_cnt, int nwaves) {
     int o = blockIdx.x * 256 + threadIdx.x;
-    bool live = o < n;
+    bool live = o < eff_rows(n_dev, n);
     int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
     int wave = o >> 6;
     int k = 0;
@@ -99,14 +101,15 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4 *__restrict_
 // pairs[k] = {(i, tbl[kr][i])} for i ascending, kr = flip ? K-1-k : k  (tbl is an input-stationary
 // view: for SubM the symmetric row of the output-stationary table).
 __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t *__restrict__ tbl, int n,
-                                                         int K, int flip,
+                                                         const int32_t *n_dev, int K, int flip,
                                                          const int *__restrict__ wave_off, int nwaves,
                                                          int32_t *__restrict__ pairs) {
     int i = blockIdx.x * 256 + threadIdx.x;
     int wave = i >> 6;
+    const int nn = eff_rows(n_dev, n);
     for (int k = 0; k < K; ++k) {
         int kr = flip ? K - 1 - k : k;
-        int o = (i < n) ? tbl[(size_t)kr * n + i] : -1;
+        int o = (i < nn) ? tbl[(size_t)kr * n + i] : -1;
         int tot;
         int r = wave_rank(o >= 0, tot);
         if (o >= 0) {
@@ -137,9 +140,9 @@ __device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int b
 }
 
 __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__ idx, int n,
-                                                        ConvGeom G, u32 *bitmap) {
+                                                        const int32_t *n_dev, ConvGeom G, u32 *bitmap) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= eff_rows(n_dev, n)) return;
     int4 c = idx[i];
     for (int a = 0; a < G.kd; ++a)
         for (int bq = 0; bq < G.kh; ++bq)
@@ -182,13 +185,14 @@ __global__ __launch_bounds__(256) void conv_emit_out_kernel(const u32 *__restric
 }
 
 __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__ idx, int n,
-                                                        ConvGeom G, const u32 *__restrict__ bitmap,
+                                                        const int32_t *n_dev, ConvGeom G,
+                                                        const u32 *__restrict__ bitmap,
                                                         const int *__restrict__ prefix, int n_out,
                                                         int32_t *__restrict__ nbr_in,
                                                         int32_t *__restrict__ nbr_out,
                                                         int *__restrict__ wave_cnt, int nwaves) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    bool live = i < n;
+    bool live = i < eff_rows(n_dev, n);
     int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
     int wave = i >> 6;
     int k = 0;
@@ -285,8 +289,9 @@ extern "C" size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol) {
 
 extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host,
                                  const int *ksize_host, const int *dil_host, int32_t *nbr,
-                                 int32_t *pairs, int32_t *pair_num, int pad_pairs, void *workspace,
-                                 size_t workspace_bytes, void *stream) {
+                                 int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                                 const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
     if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
@@ -298,7 +303,7 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
     if ((double)batch * G.D * G.H * G.W >= 4294967295.0) return PCD_ERR_KEYSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        if (pair_num) hipMemsetAsync(pair_num, 0, G.K * sizeof(int32_t), st);
+        if (pair_num) pcd_fill(pair_num, 0, G.K * sizeof(int32_t), st);
         return PCD_OK;
     }
     if (!indices || !nbr) return PCD_ERR_INVALID_ARG;
@@ -311,14 +316,14 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
     int *totals = ws.take<int>(G.K);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n, 256);
-    hipMemsetAsync(table, 0xFF, (size_t)tcap * sizeof(u64), st);
-    hash_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G.D, G.H, G.W, table, tcap - 1);
-    subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G, table, tcap - 1, nbr,
+    pcd_fill(table, 0xFF, (size_t)tcap * sizeof(u64), st);
+    hash_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G.D, G.H, G.W, table, tcap - 1);
+    subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, table, tcap - 1, nbr,
                                           pairs ? wave_cnt : nullptr, nwaves);
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals);
-        if (pad_pairs) hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
-        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr, n, G.K, 1, wave_off, nwaves, pairs);
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr, n, n_dev, G.K, 1, wave_off, nwaves, pairs);
         pair_num_kernel<<<1, 512, 0, st>>>(totals, G.K, 1, pair_num);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
@@ -341,8 +346,8 @@ extern "C" size_t pcd_rulebook_conv_workspace_bytes(int n, int batch, const int 
 extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
                                        const int *in_shape_host, const int *ksize_host,
                                        const int *stride_host, const int *pad_host,
-                                       const int *dil_host, int32_t *n_out_dev, void *workspace,
-                                       size_t workspace_bytes, void *stream) {
+                                       const int *dil_host, int32_t *n_out_dev, const int32_t *n_dev,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
@@ -356,9 +361,9 @@ extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
     if (rc != PCD_OK) return rc;
     if (n > 0 && !indices) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(L.bitmap, 0, L.nwords * sizeof(u32), st);
+    pcd_fill(L.bitmap, 0, L.nwords * sizeof(u32), st);
     if (n > 0)
-        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, G, L.bitmap);
+        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap);
     PopcWord pw{L.bitmap};
     rc = scan_exclusive(pw, (int)L.nwords, L.prefix, L.bsums, n_out_dev, st);
     if (rc != PCD_OK) return rc;
@@ -371,8 +376,8 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                       const int *stride_host, const int *pad_host,
                                       const int *dil_host, int n_out, int32_t *out_indices,
                                       int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs,
-                                      int32_t *pair_num, int pad_pairs, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
+                                      int32_t *pair_num, int pad_pairs, const int32_t *n_dev,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || n_out < 0) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
@@ -386,22 +391,22 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
     if (rc != PCD_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0 || n_out == 0) {
-        if (pair_num) hipMemsetAsync(pair_num, 0, G.K * sizeof(int32_t), st);
-        if (n > 0 && nbr_in) hipMemsetAsync(nbr_in, 0xFF, (size_t)G.K * n * sizeof(int32_t), st);
+        if (pair_num) pcd_fill(pair_num, 0, G.K * sizeof(int32_t), st);
+        if (n > 0 && nbr_in) pcd_fill(nbr_in, 0xFF, (size_t)G.K * n * sizeof(int32_t), st);
         return PCD_OK;
     }
     if (!indices || !out_indices || !nbr_in || !nbr_out) return PCD_ERR_INVALID_ARG;
     conv_emit_out_kernel<<<pcd_div_up((int)L.nwords, 256), 256, 0, st>>>(L.bitmap, L.prefix,
                                                                         (int)L.nwords, G, n_out,
                                                                         out_indices);
-    hipMemsetAsync(nbr_out, 0xFF, (size_t)G.K * n_out * sizeof(int32_t), st);
+    pcd_fill(nbr_out, 0xFF, (size_t)G.K * n_out * sizeof(int32_t), st);
     int nb = pcd_div_up(n, 256);
-    conv_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, G, L.bitmap, L.prefix, n_out,
+    conv_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix, n_out,
                                          nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr, L.nwaves);
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals);
-        if (pad_pairs) hipMemsetAsync(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
-        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr_in, n, G.K, 0, L.wave_off, L.nwaves, pairs);
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr_in, n, n_dev, G.K, 0, L.wave_off, L.nwaves, pairs);
         pair_num_kernel<<<1, 512, 0, st>>>(L.totals, G.K, 0, pair_num);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();

@@ -81,9 +81,11 @@ template <int NB, int MI, int G, int SG, bool OUT_BF16>   // SG == 0: weights re
 __global__ __launch_bounds__(256) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
-    int n_out, void *__restrict__ yv, int nsteps, unsigned x_bytes) {
+    int n_out_cap, const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, int nsteps,
+    unsigned x_bytes) {
     constexpr int ROWS = 4 * MI * 16;
     constexpr bool STAGED = SG > 0;
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
     constexpr int VEC = STAGED ? SG * NB * 64 : 1;         // uint4 per stage
     constexpr int WPT = STAGED ? VEC / 256 : 1;            // uint4 per thread per stage
     static_assert(!STAGED || (SG % G == 0 && VEC % 256 == 0), "stage / group mismatch");
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
 
 template <int NB, int MI, int G, int SG>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
-                     const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, void *y,
-                     int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st) {
+                     const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, const int32_t *n_out_dev,
+                     void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
@@ -237,17 +239,23 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
     auto kb = gather_gemm_kernel<NB, MI, G, SG, true>;
     auto kf = gather_gemm_kernel<NB, MI, G, SG, false>;
     if (lds > 64 * 1024) {
-        // above the default dynamic-LDS limit: raise it for this kernel (idempotent, host-side attribute)
-        if (hipFuncSetAttribute((const void *)(y_dtype == PCD_BF16 ? kb : kf),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return PCD_ERR_LAUNCH;
+        // above the default dynamic-LDS limit: raise it for this kernel (host-side attribute, set once per
+        // instantiation -- benign race: the call is idempotent)
+        static size_t raised[2] = {0, 0};
+        const int which = y_dtype == PCD_BF16 ? 0 : 1;
+        if (raised[which] < lds) {
+            if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return PCD_ERR_LAUNCH;
+            raised[which] = lds;
+        }
     }
     if (y_dtype == PCD_BF16)
         kb<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, y, nsteps, x_bytes);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes);
     else
         kf<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, y, nsteps, x_bytes);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -503,8 +511,9 @@ extern "C" int pcd_pack_weight(const float *weight, int kvol, int cin, int cout,
 
 extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w,
                                            const float *bias, const int32_t *nbr, int nbr_stride,
-                                           int kvol, int flip_k, int n_rows_out, int c_out, void *y,
-                                           int y_dtype, void *stream) {
+                                           int kvol, int flip_k, int n_rows_out,
+                                           const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype,
+                                           void *stream) {
     PCD_ENTER();
     if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
     if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
@@ -522,7 +531,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
     const bool resident = wbytes <= 32 * 1024;
     const bool small = n_rows_out < 32 * 1024;  // few rows: 64-row workgroups fill the chip better
-#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, y, y_dtype, nsteps, x_bytes, st
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st
     switch (c_out / 16) {
         case 1:
             return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 16>(GG_ARGS);
@@ -561,7 +570,7 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int ci
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)cout * kvol * cin;
     if (pmax == 0) {
-        if (dweight) hipMemsetAsync(dweight, 0, n * sizeof(float), st);
+        if (dweight) pcd_fill(dweight, 0, n * sizeof(float), st);
         return PCD_OK;
     }
     if (!x || !dy || !pairs || !pair_num) return PCD_ERR_INVALID_ARG;

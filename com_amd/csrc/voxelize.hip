@@ -325,7 +325,7 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
     int *frame_base = ws.take<int>(batch + 1);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     // keys and best are adjacent pieces: one memset to 0xFF covers both sentinels
-    hipMemsetAsync(keys, 0xFF, (size_t)((char *)pt_slot - (char *)keys), st);
+    pcd_fill(keys, 0xFF, (size_t)((char *)pt_slot - (char *)keys), st);
     int nb = pcd_div_up(n_points, 256);
     if (n_points > 0) {
         vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
@@ -410,10 +410,10 @@ extern "C" int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, in
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int *cnt = counts ? counts : cnt_ws;
     int rows = cap < n_points ? cap : n_points;
-    hipMemsetAsync(bitmap, 0, nw * sizeof(u32), st);
+    pcd_fill(bitmap, 0, nw * sizeof(u32), st);
     if (rows > 0) {
-        hipMemsetAsync(features, 0, (size_t)rows * num_features * sizeof(float), st);
-        hipMemsetAsync(cnt, 0, (size_t)rows * sizeof(int), st);
+        pcd_fill(features, 0, (size_t)rows * num_features * sizeof(float), st);
+        pcd_fill(cnt, 0, (size_t)rows * sizeof(int), st);
     }
     int nb = pcd_div_up(n_points, 256);
     if (n_points > 0)

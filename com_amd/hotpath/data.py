@@ -36,19 +36,24 @@ def collate_points(frames, device="cuda"):
 
 
 def transform_points_to_voxels(batch_dict, point_cloud_range, voxel_size, max_points_per_voxel,
-                               max_voxels, fuse_mean=True, keep_voxels=False):
+                               max_voxels, fuse_mean=True, keep_voxels=False, bf16_features=False):
     """Batched GPU form of data_processor.py:125-153 + collate: consumes batch_dict['points']
     ([sum N, 1+C] with batch index) and batch_dict['frame_offsets'], produces 'voxel_coords' [M,4],
     'voxel_num_points', and either 'voxels' (reference layout) or the fused MeanVFE 'voxel_features'."""
     pts = batch_dict['points']
     res = ops.voxelize_hard(pts, batch_dict['frame_offsets'], point_cloud_range, voxel_size,
                             max_points_per_voxel, max_voxels, feat_offset=1, num_features=pts.shape[1] - 1,
-                            want_voxels=keep_voxels or not fuse_mean, want_mean=fuse_mean)
+                            want_voxels=keep_voxels or not fuse_mean, want_mean=fuse_mean and not bf16_features,
+                            mean_bf16_stride=ops.pow2_ge8(pts.shape[1] - 1) if (fuse_mean and bf16_features) else 0)
     batch_dict['voxel_coords'] = res['coords']
     batch_dict['voxel_num_points'] = res['num_points']
     if res['voxels'] is not None:
         batch_dict['voxels'] = res['voxels']
     if fuse_mean:
-        batch_dict['voxel_features'] = res['voxel_features']
+        # bf16_features: the MeanVFE row is emitted directly as the zero-padded bf16 [M, 8] operand of the
+        # first sparse conv (no cast / pad kernels in between)
+        batch_dict['voxel_features'] = res['voxel_features_bf16'] if bf16_features else res['voxel_features']
     batch_dict['voxel_counts'] = res['counts']
+    if res.get('num_rows', None) is not None:
+        batch_dict['voxel_num_rows'] = res['num_rows']
     return batch_dict

@@ -18,7 +18,7 @@ class HeightCompression(nn.Module):
     def forward(self, batch_dict):
         sp = batch_dict['encoded_spconv_tensor']
         # dense() + view(N, C*D, H, W) in one kernel; channel index = c*D + z (height_compression.py:22-23)
-        spatial_features = Fsp.bev_dense(sp.features, sp.indices, sp.batch_size, sp.spatial_shape)
+        spatial_features = Fsp.bev_dense(sp.features, sp.indices, sp.batch_size, sp.spatial_shape, sp.num_rows)
         batch_dict['spatial_features'] = spatial_features
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict

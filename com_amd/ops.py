@@ -61,6 +61,46 @@ def _require_cuda(*tensors):
             raise L.PcdError("hot-path ops need HIP device tensors (there is no CPU fallback)")
 
 
+# ---------------------------------------------------------------------------------------------
+class StaticPlan:
+    """Capacities for "static shape" execution (hipGraph capture of a whole training step).
+
+    The data-dependent row counts of the path (voxels per batch, output rows of every strided conv) are
+    OBSERVED during a few eager steps; afterwards (`active = True`) every buffer is allocated at
+    capacity = observed maximum x margin, the real counts stay in device memory (`n_dev` arguments of the
+    C ABI) and nothing is read back to the host, so the whole step can be captured in one hipGraph.
+    `check()` (one sync, outside the timed region) verifies that no count exceeded its capacity."""
+
+    def __init__(self, margin=1.25, round_to=1024):
+        self.margin, self.round_to = margin, round_to
+        self.caps = {}
+        self.active = False
+        self.recorded = []          # (key, n_dev tensor, capacity) of the captured step
+
+    def observe(self, key, n):
+        self.caps[key] = max(self.caps.get(key, 0), int(n))
+
+    def cap(self, key):
+        if key not in self.caps:
+            raise L.PcdError(f"static plan has no observation for {key!r}: run eager warm-up steps first")
+        c = int(self.caps[key] * self.margin) + 1
+        return (c + self.round_to - 1) // self.round_to * self.round_to
+
+    def record(self, key, n_dev, cap):
+        self.recorded.append((key, n_dev, cap))
+
+    def check(self):
+        """Raise if any device-side count of the last replay exceeded its capacity."""
+        for key, n_dev, cap in self.recorded:
+            n = int(n_dev.reshape(-1)[-1].item())
+            if n > cap:
+                raise L.PcdError(f"static capacity overflow for {key!r}: {n} rows > capacity {cap}")
+        return True
+
+
+PLAN = None  # set by the caller (bench.py / tests) to enable observation / static execution
+
+
 def pow2_ge8(c):
     p = 8
     while p < c:
@@ -90,6 +130,9 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         offs = torch.tensor(list(frame_offsets), dtype=torch.int32, device=dev)
     batch = offs.numel() - 1
     cap = max(1, min(n, batch * max_voxels))
+    static = PLAN is not None and PLAN.active
+    if static:
+        cap = min(cap, PLAN.cap("voxels"))
     lib = L.lib()
     ws = _ws(lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch), dev)
     voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
@@ -104,9 +147,17 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
                                   max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
                                   L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
                                   L.stream_ptr()), "pcd_voxelize_hard")
+    if static:
+        # no read-back: outputs stay at capacity, the row count stays on the device
+        num_rows = counts[batch:batch + 1]
+        PLAN.record("voxels", num_rows, cap)
+        return dict(voxels=voxels, coords=coords, num_points=nump, voxel_features=mean,
+                    voxel_features_bf16=mean16, counts=counts, num_rows=num_rows)
     host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
     m = host_counts[-1]
-    return dict(voxels=voxels[:m] if want_voxels else None, coords=coords[:m], num_points=nump[:m],
+    if PLAN is not None:
+        PLAN.observe("voxels", m)
+    return dict(num_rows=None,voxels=voxels[:m] if want_voxels else None, coords=coords[:m], num_points=nump[:m],
                 voxel_features=mean[:m] if want_mean else None,
                 voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1])
 
@@ -159,8 +210,10 @@ class Rulebook:
     """
 
     def __init__(self, subm, kvol, n_in, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape,
-                 ksize, stride, padding, dilation):
+                 ksize, stride, padding, dilation, n_in_dev=None, n_out_dev=None):
         self.subm, self.kvol, self.n_in, self.n_out = subm, kvol, n_in, n_out
+        # device-side row counts (static-shape mode): n_in / n_out are then capacities
+        self.n_in_dev, self.n_out_dev = n_in_dev, n_out_dev
         self.nbr_out, self.nbr_in, self.pairs, self.pair_num = nbr_out, nbr_in, pairs, pair_num
         self.out_indices = out_indices
         self.out_shape = list(out_shape) if out_shape is not None else None
@@ -179,7 +232,8 @@ class Rulebook:
             order = torch.argsort(key, dim=1, stable=True)
             pairs = torch.gather(sw, 2, order.unsqueeze(1).expand(-1, 2, -1)).contiguous()
         return Rulebook(False, self.kvol, self.n_out, self.n_in, self.nbr_in, self.nbr_out, pairs,
-                        self.pair_num, None, None, self.ksize, self.stride, self.padding, self.dilation)
+                        self.pair_num, None, None, self.ksize, self.stride, self.padding, self.dilation,
+                        n_in_dev=self.n_out_dev, n_out_dev=self.n_in_dev)
 
 
 def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
@@ -190,7 +244,8 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
     return [int(v) for v in out]
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False):
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False,
+                  n_dev=None):
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -204,13 +259,13 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
     L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
                                   L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
-                                  L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
+                                  L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
     return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
-                    [k // 2 for k in ks], dl)
+                    [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
 
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
-                  pad_pairs=False):
+                  pad_pairs=False, n_dev=None, plan_key=None):
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -226,9 +281,16 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
         raise L.PcdError("pcd_rulebook_conv: bad geometry or key space too large")
     ws = _ws(wsb, dev)
     n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-    L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(ws),
-                                        ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
-    n_out = int(n_out_dev.item())          # host sync: data-dependent number of output rows
+    L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
+                                        L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+    static = PLAN is not None and PLAN.active
+    if static:
+        n_out = PLAN.cap(plan_key)         # capacity; the real count stays in n_out_dev (no host sync)
+        PLAN.record(plan_key, n_out_dev, n_out)
+    else:
+        n_out = int(n_out_dev.item())      # host sync: data-dependent number of output rows
+        if PLAN is not None and plan_key is not None:
+            PLAN.observe(plan_key, n_out)
     out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
     nbr_in = torch.empty((K, n), dtype=torch.int32, device=dev)
     nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
@@ -236,10 +298,10 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
     L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
                                        L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
-                                       int(pad_pairs), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                       int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "pcd_rulebook_conv_fill")
     return Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
-                    pd, dl)
+                    pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -257,7 +319,7 @@ def pack_weight(weight, mode):
     return packed
 
 
-def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype):
+def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None):
     """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]  (output-stationary; forward and dgrad)."""
     _require_cuda(x, packed_w, nbr)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
@@ -273,7 +335,8 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     with _Timed(f"gather_gemm_kernel<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
         L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
-                                                    c_out, L.ptr(y), _dtype_code(y), L.stream_ptr()),
+                                                    L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),
+                                                    L.stream_ptr()),
                 "pcd_sparse_conv_gather_gemm")
     return y
 
@@ -311,7 +374,7 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol):
 
 
 # ---------------------------------------------------------------------------------------------
-def bev_scatter(features, indices, batch_size, spatial_shape, channels=None):
+def bev_scatter(features, indices, batch_size, spatial_shape, channels=None, n_dev=None):
     """dense() + view(N, C*D, H, W): height_compression.py:20-25; D == 1 is PointPillarScatter."""
     _require_cuda(features, indices)
     assert features.is_contiguous() and indices.dtype == torch.int32 and indices.is_contiguous()
@@ -321,13 +384,13 @@ def bev_scatter(features, indices, batch_size, spatial_shape, channels=None):
     lib = L.lib()
     out = torch.empty((batch_size, C * D, H, W), dtype=features.dtype, device=features.device)
     ws = _ws(lib.pcd_bev_workspace_bytes(batch_size, D, H, W), features.device)
-    L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, batch_size,
-                                D, H, W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
+    L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, L.ptr(n_dev),
+                                batch_size, D, H, W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "pcd_bev_scatter")
     return out
 
 
-def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None):
+def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None, n_dev=None):
     _require_cuda(dout, indices)
     dout = dout.contiguous()
     D, H, W = _triple(spatial_shape)
@@ -337,13 +400,14 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
         df = torch.zeros((n, cs), dtype=dout.dtype, device=dout.device)
     else:
         df = torch.empty((n, cs), dtype=dout.dtype, device=dout.device)
-    L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n, batch_size,
-                                   D, H, W, L.ptr(df), L.stream_ptr()), "pcd_bev_gather")
+    L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n,
+                                   L.ptr(n_dev), batch_size, D, H, W, L.ptr(df), L.stream_ptr()),
+            "pcd_bev_gather")
     return df
 
 
 # ---------------------------------------------------------------------------------------------
-def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu):
+def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu, n_dev=None):
     """Fused BatchNorm1d (+residual) (+ReLU) over [n, c] (spconv_backbone.py:21-25,50-66).
     Returns (y, save_mean, save_invstd)."""
     _require_cuda(x)
@@ -358,11 +422,11 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
     L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
                                float(eps), float(momentum), int(training), L.ptr(running_mean),
                                L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
-                               L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_forward")
+                               L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_forward")
     return y, save_mean, save_invstd
 
 
-def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres):
+def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None):
     _require_cuda(dy, x)
     dy = dy.contiguous()
     n, c = x.shape
@@ -375,12 +439,12 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
     L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma),
                                 L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
-                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(),
+                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev), L.ptr(ws), ws.numel(),
                                 L.stream_ptr()), "pcd_bn_backward")
     return dx, dres, dgamma, dbeta
 
 
-def col_sum(x):
+def col_sum(x, n_dev=None):
     """out[c] = sum_rows x[:, c] in fp32 (bias gradient), deterministic two-stage reduction."""
     _require_cuda(x)
     x = x.contiguous()
@@ -388,6 +452,6 @@ def col_sum(x):
     lib = L.lib()
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), x.device)
-    L.check(lib.pcd_col_sum(L.ptr(x), _dtype_code(x), n, c, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
-            "pcd_col_sum")
+    L.check(lib.pcd_col_sum(L.ptr(x), _dtype_code(x), n, c, L.ptr(out), L.ptr(n_dev), L.ptr(ws), ws.numel(),
+                            L.stream_ptr()), "pcd_col_sum")
     return out

@@ -92,12 +92,13 @@ class SparseConvolution(SparseModule):
                 rb = hit[0]
             else:
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
-                                       self.dilation)
+                                       self.dilation, n_dev=x.num_rows)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
-                                   self.padding, self.dilation)
+                                   self.padding, self.dilation, n_dev=x.num_rows,
+                                   plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)))
             out_idx, out_shape = rb.out_indices, rb.out_shape
         if self.indice_key is not None:
             # spconv stores (.., indice_pairs, indice_pair_num, spatial_shape) by key; for inverse convs
@@ -110,7 +111,7 @@ class SparseConvolution(SparseModule):
         rb, out_idx, out_shape = self._rulebook(input)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd())
         out = SparseConvTensor(feats, out_idx, out_shape, input.batch_size, input.grid, input.voxel_num,
-                               input.indice_dict, input.benchmark)
+                               input.indice_dict, input.benchmark, rb.n_out_dev)
         return out
 
 

@@ -26,14 +26,16 @@ class SparseConvFunction(Function):
     @staticmethod
     def forward(ctx, features, weight, bias, rb, packed_fwd):
         cout, cin = weight.shape[0], weight.shape[-1]
-        assert features.shape[1] == cin, (features.shape, weight.shape)
         cin_pad = ops.pow2_ge8(cin)
+        assert features.shape[1] in (cin, cin_pad), (features.shape, weight.shape)
         x = _to_bf16_padded(features.detach(), cin_pad)
         out_dtype = features.dtype if features.dtype in (torch.float32, torch.bfloat16) else torch.float32
         b = bias.detach().float().contiguous() if bias is not None else None
-        y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype)
+        y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
+                            n_dev=rb.n_out_dev)
         ctx.rb = rb
         ctx.cin, ctx.cout, ctx.cin_pad = cin, cout, cin_pad
+        ctx.in_cols = features.shape[1]
         ctx.has_bias = bias is not None
         ctx.in_dtype = features.dtype
         ctx.save_for_backward(x, weight)
@@ -52,16 +54,16 @@ class SparseConvFunction(Function):
             packed_d = ops.pack_weight(weight, 1)
             if rb.subm:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev)
             else:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype)
-            dx = dxp if ctx.cin_pad == ctx.cin else dxp[:, :ctx.cin].contiguous()
+                                      ctx.in_dtype, n_dev=rb.n_in_dev)
+            dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
         if ctx.needs_input_grad[1]:
             dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol)      # [Cout, K, Cin] f32
             dw = dwk.view(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.col_sum(dy16)
+            db = ops.col_sum(dy16, n_dev=rb.n_out_dev)
         return dx, dw, db, None, None
 
 
@@ -69,7 +71,7 @@ class BevDenseFunction(Function):
     """SparseConvTensor.dense() fused with the [B, C*D, H, W] view; backward = gather."""
 
     @staticmethod
-    def forward(ctx, features, indices, batch_size, spatial_shape):
+    def forward(ctx, features, indices, batch_size, spatial_shape, n_dev=None):
         f = features.detach().contiguous()
         if f.dtype not in (torch.float32, torch.bfloat16):
             f = f.float()
@@ -77,19 +79,19 @@ class BevDenseFunction(Function):
         c = f.shape[1]
         if pad:
             f = torch.nn.functional.pad(f, (0, pad))
-        out = ops.bev_scatter(f, indices, batch_size, spatial_shape, channels=c)
-        ctx.meta = (indices, batch_size, list(spatial_shape), c)
+        out = ops.bev_scatter(f, indices, batch_size, spatial_shape, channels=c, n_dev=n_dev)
+        ctx.meta = (indices, batch_size, list(spatial_shape), c, n_dev)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        indices, batch_size, spatial_shape, c = ctx.meta
-        df = ops.bev_gather(dout, indices, batch_size, spatial_shape, c)
-        return df, None, None, None
+        indices, batch_size, spatial_shape, c, n_dev = ctx.meta
+        df = ops.bev_gather(dout, indices, batch_size, spatial_shape, c, n_dev=n_dev)
+        return df, None, None, None, None
 
 
-def bev_dense(features, indices, batch_size, spatial_shape):
-    return BevDenseFunction.apply(features, indices, batch_size, spatial_shape)
+def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None):
+    return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev)
 
 
 def sparse_conv(features, weight, bias, rb, packed_fwd):
@@ -101,7 +103,7 @@ class FusedBNFunction(Function):
     (spconv_backbone.py:21-25,50-66); parameters / buffers stay in the caller's nn.BatchNorm1d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, n_dev=None):
         xc = x.detach().contiguous()
         rc = residual.detach().contiguous() if residual is not None else None
         if rc is not None and rc.dtype != xc.dtype:
@@ -111,11 +113,12 @@ class FusedBNFunction(Function):
         g = gamma.detach().float() if gamma is not None else None
         b = beta.detach().float() if beta is not None else None
         y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
-                                                   bn.running_var, relu)
+                                                   bn.running_var, relu, n_dev=n_dev)
         if not training:
             save_mean = bn.running_mean
             save_invstd = torch.rsqrt(bn.running_var + bn.eps)
         ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
+        ctx.n_dev = n_dev
         ctx.save_for_backward(xc, y, g, save_mean, save_invstd)
         return y
 
@@ -125,9 +128,9 @@ class FusedBNFunction(Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
-                                                  ctx.has_res and ctx.needs_input_grad[3])
+                                                  ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                dres, None, None)
+                dres, None, None, None)
 
 
 def _fusable(bn, x):
@@ -144,12 +147,14 @@ def _fusable(bn, x):
     return (256 % pcs) == 0 and (bn.running_mean is not None or bn.training)
 
 
-def batch_norm_act(bn, x, residual=None, relu=True):
+def batch_norm_act(bn, x, residual=None, relu=True, n_dev=None):
     """y = relu?(bn(x) + residual?) through the fused HIP kernels when the shape allows, else torch."""
     if _fusable(bn, x):
         if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_defer_nbt", False):
             bn.num_batches_tracked.add_(1)
-        return FusedBNFunction.apply(x, bn.weight, bn.bias, residual, bn, relu)
+        return FusedBNFunction.apply(x, bn.weight, bn.bias, residual, bn, relu, n_dev)
+    if n_dev is not None:
+        raise RuntimeError("static-shape mode needs the fused BatchNorm path (unsupported channel count / dtype)")
     y = bn(x)
     if residual is not None:
         y = y + residual

@@ -71,7 +71,8 @@ class SparseSequential(SparseModule):
                     # BatchNorm1d (+ the ReLU that follows it) in one fused pass pair; the modules, their
                     # parameters and state-dict entries are untouched
                     relu = i < len(mods) and type(mods[i]) is nn.ReLU
-                    input = input.replace_feature(Fsp.batch_norm_act(module, input.features, None, relu))
+                    input = input.replace_feature(Fsp.batch_norm_act(module, input.features, None, relu,
+                                                                     input.num_rows))
                     if relu:
                         i += 1
                 else:

@@ -14,6 +14,11 @@
  *   - functions are re-entrant: no global state;
  *   - index tensors are int32, coordinates are (batch, z, y, x) rows of 4 int32.
  *
+ * Device-side row counts: wherever a function takes a row count `n` together with a `const int32_t *n_dev`
+ * argument, `n` is the CAPACITY (buffer strides, grid size) and, when n_dev != NULL, the kernels process
+ * min(*n_dev, n) rows.  A caller can therefore chain the whole path (voxelise -> rulebooks -> convs -> BEV)
+ * without ever reading a data-dependent size back to the host, i.e. inside one captured hipGraph.
+ *
  * Feature element types: PCD_BF16 (MFMA path, fp32 accumulate) for sparse-conv features,
  * PCD_F32 for point / voxel payloads.  A feature row has `c_pad` elements, c_pad % 8 == 0,
  * padding channels must be zero.
@@ -110,8 +115,8 @@ int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, int num_featu
 size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol);
 int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host /*[3]*/,
                       const int *ksize_host, const int *dil_host, int32_t *nbr, int32_t *pairs,
-                      int32_t *pair_num, int pad_pairs, void *workspace, size_t workspace_bytes,
-                      void *stream);
+                      int32_t *pair_num, int pad_pairs, const int32_t *n_dev, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (a9) SparseConv3d (strided) rulebook -- replaces get_indice_pairs(subm=False) behind
@@ -133,13 +138,13 @@ int pcd_conv_out_shape(const int *in_shape_host, const int *ksize_host, const in
                        const int *pad_host, const int *dil_host, int *out_shape_host);
 int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch, const int *in_shape_host,
                             const int *ksize_host, const int *stride_host, const int *pad_host,
-                            const int *dil_host, int32_t *n_out_dev, void *workspace,
+                            const int *dil_host, int32_t *n_out_dev, const int32_t *n_dev, void *workspace,
                             size_t workspace_bytes, void *stream);
 int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
                            const int *ksize_host, const int *stride_host, const int *pad_host,
                            const int *dil_host, int n_out, int32_t *out_indices, int32_t *nbr_in,
                            int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
@@ -165,7 +170,8 @@ int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode, 
  * nbr_stride = row stride (elements) of the nbr table.  y dtype PCD_BF16 or PCD_F32; bias f32 or NULL. */
 int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
-                                int n_rows_out, int c_out, void *y, int y_dtype, void *stream);
+                                int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
+                                int y_dtype, void *stream);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
@@ -190,10 +196,10 @@ int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *d
  * ============================================================================================ */
 size_t pcd_bev_workspace_bytes(int batch, int d, int h, int w);
 int pcd_bev_scatter(const void *features, int c, int c_stride, int dtype, const int32_t *indices,
-                    int n, int batch, int d, int h, int w, void *out, void *workspace,
-                    size_t workspace_bytes, void *stream);
+                    int n, const int32_t *n_dev, int batch, int d, int h, int w, void *out,
+                    void *workspace, size_t workspace_bytes, void *stream);
 int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
-                   int batch, int d, int h, int w, void *dfeatures, void *stream);
+                   const int32_t *n_dev, int batch, int d, int h, int w, void *dfeatures, void *stream);
 
 /* ============================================================================================
  * (a11) fused sparse epilogue -- replaces the nn.BatchNorm1d(eps=1e-3, momentum=0.01) -> (+ residual)
@@ -209,16 +215,16 @@ int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32
  * ============================================================================================ */
 size_t pcd_bn_workspace_bytes(int c);
 /* out[c] = sum over the n rows of x [n][c] (bias gradient); workspace = pcd_bn_workspace_bytes(c). */
-int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, void *workspace,
+int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, const int32_t *n_dev, void *workspace,
                 size_t workspace_bytes, void *stream);
 int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c, const float *gamma,
                    const float *beta, float eps, float momentum, int training, float *running_mean,
                    float *running_var, int relu, void *y, float *save_mean, float *save_invstd,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
                     const float *gamma, const float *save_mean, const float *save_invstd, int relu,
-                    int training, void *dx, void *dresidual, float *dgamma, float *dbeta, void *workspace,
-                    size_t workspace_bytes, void *stream);
+                    int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                    const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
