@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: replay the captured step (default); eager: one launch per kernel from Python")
     return ap.parse_args()
 
 
@@ -59,6 +61,18 @@ class HotPath(torch.nn.Module):
         bd = {"voxel_features": voxel_features, "voxel_coords": voxel_coords, "batch_size": batch_size}
         bd = self.map_to_bev_module(self.backbone_3d(self.vfe(bd)))
         return bd["spatial_features"], bd
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_pmc_traffic.json) -- PMC counters cannot be read from
+    inside the timed process, so this is the offline measurement of the same command; None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        return k[kernel]["hbm_bytes_per_launch_corrected"] if kernel in k else None
+    except Exception:
+        return None
 
 
 def measure_roofline(step_fn):
@@ -100,7 +114,7 @@ def measure_roofline(step_fn):
            "peak": MFMA_BF16_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
            "unit": "TFLOP/s" if mfma_bound else "GB/s",
            "frac": round((tf / MFMA_BF16_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
-           "traffic": None,
+           "traffic": _pmc_traffic(name),
            "kernel": name, "launches_per_step": g["launches"],
            "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
            "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
@@ -197,39 +211,52 @@ def main():
         offs_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
         batches.append((pts, offs_dev))
 
+    from com_amd import dist as cdist
     model = HotPath().to(dev)
     model.train()
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    if world > 1:                                            # what DDP does at construction (tools/train.py:165-166)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
-
+    # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
+    bucket = cdist.FlatGradBucket(params)
+    opt = torch.optim.Adam(params, lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True, capturable=True)
     loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
+    last = {}
 
-    def step(i, record=None):
-        pts, offs = batches[i % 2]
-        ev = record
+    def fwd_bwd(pts, offs, ev=None):
+        """voxelise -> MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into bucket)"""
         bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
         if ev is not None: ev("voxelize")
         bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
-                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True)
+                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True)
         if ev is not None: ev("forward")
-        sf, out = net(bd["voxel_features"], bd["voxel_coords"], B)
+        bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B}
+        if "voxel_num_rows" in bd:
+            bd2["voxel_num_rows"] = bd["voxel_num_rows"]
+        sf = model.map_to_bev_module(model.backbone_3d(model.vfe(bd2)))["spatial_features"]
         # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense
-        # gradient, one read of the map forward and one write backward)
-        loss = torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)   # (rocBLAS dot is not capturable)
+        # gradient; rocBLAS dot is not graph-capturable, hence mul + sum)
+        loss = torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)
         if ev is not None: ev("backward")
-        opt.zero_grad(set_to_none=True)
+        bucket.zero()
         loss.backward()
-        if ev is not None: ev("optimizer")
+        if not (ops.PLAN is not None and ops.PLAN.active):
+            last["voxels"] = sum(bd["voxel_counts"])
+        return None
+
+    def opt_step():
         torch.nn.utils.clip_grad_norm_(params, 10.0)         # centerpoint.yaml:96 GRAD_NORM_CLIP
         opt.step()
-        if ev is not None: ev("end")
-        return bd, out
 
-    for i in range(args.warmup):
-        step(i)
+    def eager_step(i, ev=None):
+        pts, offs = batches[i % 2]
+        fwd_bwd(pts, offs, ev)
+        if ev is not None: ev("allreduce")
+        bucket.all_reduce_mean()                             # RCCL over xGMI (no-op at N = 1)
+        if ev is not None: ev("optimizer")
+        opt_step()
+        if ev is not None: ev("end")
 
     def sync():
         torch.cuda.synchronize()
@@ -237,18 +264,55 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    use_graph = args.mode == "graph"
+    plan = ops.StaticPlan()
+    ops.PLAN = plan
+    for i in range(max(args.warmup, 2)):                     # eager: also observes the data-dependent row counts
+        eager_step(i)
+    if use_graph:
+        # the whole step becomes two hipGraphs (forward+backward | clip+Adam) with the gradient all-reduce in
+        # between; row counts stay on the device, buffers are sized from the observed counts x 1.25
+        plan.active = True
+        s_pts, s_offs = batches[0][0].clone(), batches[0][1].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd(s_pts, s_offs)
+                opt_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        plan.recorded.clear()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            fwd_bwd(s_pts, s_offs)
+        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+            opt_step()
+
+        def run_step(i):
+            pts, offs = batches[i % 2]
+            s_pts.copy_(pts, non_blocking=True)              # device -> device: the batch is already in HBM
+            s_offs.copy_(offs, non_blocking=True)
+            g_fb.replay()
+            bucket.all_reduce_mean()
+            g_opt.replay()
+        for i in range(2):
+            run_step(i)
+    else:
+        run_step = eager_step
+
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        bd, out = step(i)
+        run_step(i)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     fps = world * B * args.steps / elapsed
+    if use_graph:
+        plan.check()                                         # no device-side count exceeded its capacity
+        plan.active = False                                  # the instrumented steps below run eagerly
 
     if args.stage_times:
         marks = []
@@ -258,7 +322,7 @@ def main():
             e.record()
             marks.append((name, e, time.perf_counter()))
 
-        step(0, rec)
+        eager_step(0, rec)
         torch.cuda.synchronize()
         for (n0, e0, h0), (n1, e1, h1) in zip(marks[:-1], marks[1:]) if rank == 0 else []:
             print(f"[stage] {n0:10s} gpu {e0.elapsed_time(e1):8.3f} ms   host {1e3 * (h1 - h0):8.3f} ms", file=sys.stderr)
@@ -272,11 +336,13 @@ def main():
                                "HeightCompression fwd+bwd -> grad all-reduce -> clip -> Adam), Waymo-shaped 160k-pt "
                                "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
-                   "voxels_per_frame": int(sum(bd["voxel_counts"]) / B), "parallelism": f"dp{world}"},
+                   "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
+                   "execution": "hipGraph replay (fwd+bwd | all-reduce | clip+Adam), device-side row counts"
+                                if use_graph else "eager launches"},
     }
 
     if not args.no_roofline:
-        roof = measure_roofline(lambda: step(0))     # every rank runs the extra step (collectives inside)
+        roof = measure_roofline(lambda: eager_step(0))   # every rank runs the extra step (collectives inside)
         if rank == 0:
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
