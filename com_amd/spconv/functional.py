@@ -6,6 +6,38 @@ from torch.autograd import Function
 from .. import ops
 
 
+OVERLAP_WGRAD = True
+# Opt-in (training loops that own their gradient buffers, e.g. bench.py with com_amd.dist.FlatGradBucket):
+# the weight / bias gradients are computed AND accumulated into the pre-allocated `.grad` on the side stream
+# and autograd gets None for them, so the whole wgrad chain runs as a second pipeline beside the
+# dgrad/BatchNorm chain.  The caller must call join_deferred_wgrad() after loss.backward().
+DEFERRED_WGRAD = False
+_SIDE = {}
+
+
+def join_deferred_wgrad():
+    """Make the current stream wait for every side-stream weight-gradient kernel issued so far."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.type, cur.device.index)
+    if key in _SIDE:
+        cur.wait_stream(_SIDE[key])
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _to_bf16_padded(x, c_pad):
     """[N, C] (f32 or bf16) -> contiguous bf16 [N, c_pad], zero padded channels."""
     if x.dtype != torch.bfloat16:
@@ -37,6 +69,8 @@ class SparseConvFunction(Function):
         ctx.cin, ctx.cout, ctx.cin_pad = cin, cout, cin_pad
         ctx.in_cols = features.shape[1]
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
+        ctx.weight_param = weight if isinstance(weight, torch.nn.Parameter) else None
         ctx.in_dtype = features.dtype
         ctx.save_for_backward(x, weight)
         return y
@@ -47,6 +81,36 @@ class SparseConvFunction(Function):
         rb = ctx.rb
         dy16 = _to_bf16_padded(dy, ctx.cout)
         dx = dw = db = None
+        # dgrad and wgrad only share their inputs: at B = 4 neither fills the chip (1-4 waves per SIMD), so the
+        # weight gradient (+ bias column sum) runs on a second HIP stream concurrently with the data gradient
+        # and is joined before returning (fork/join is captured as such in hipGraph mode).
+        side = None
+        cur = torch.cuda.current_stream()
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if OVERLAP_WGRAD and want_w and ctx.needs_input_grad[0]:
+            side = _side_stream(dy16.device)
+            side.wait_stream(cur)
+        bias_p = ctx.bias_param
+        weight_p = ctx.weight_param
+        deferred = (DEFERRED_WGRAD and side is not None and weight_p is not None and weight_p.grad is not None
+                    and (not ctx.has_bias or (bias_p is not None and bias_p.grad is not None)))
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            if ctx.needs_input_grad[1]:
+                dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol)      # [Cout, K, Cin] f32
+                dw = dwk.view(weight.shape).to(weight.dtype)
+                if deferred:
+                    weight_p.grad.add_(dw)
+                    dw = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = ops.col_sum(dy16, n_dev=rb.n_out_dev)
+                if deferred:
+                    bias_p.grad.add_(db)
+                    db = None
+        if deferred:
+            # the side stream still reads these after this node returns: keep the allocator from recycling them
+            x.record_stream(side)
+            dy16.record_stream(side)
+            side = None                              # no join here: join_deferred_wgrad() after backward
         if ctx.needs_input_grad[0]:
             if ctx.cin_pad % 16 != 0:
                 raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
@@ -59,11 +123,11 @@ class SparseConvFunction(Function):
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev)
             dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
-        if ctx.needs_input_grad[1]:
-            dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol)      # [Cout, K, Cin] f32
-            dw = dwk.view(weight.shape).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.col_sum(dy16, n_dev=rb.n_out_dev)
+        if side is not None:
+            cur.wait_stream(side)                    # join: dW / dbias are consumed on the current stream
+            for t in (dw, db):
+                if t is not None:
+                    t.record_stream(cur)
         return dx, dw, db, None, None
 
 
