@@ -87,9 +87,35 @@ class _BackboneBase(nn.Module):
             if counters:
                 torch._foreach_add_(counters, 1)
 
+    prefetch_rulebooks = True
+
+    def _prefetch_rulebooks(self, x0):
+        """All 9 rulebooks depend only on the voxel coordinates, not on features: build the whole chain up front
+        on a second HIP stream so the (latency-bound, LDS-free) hash / bitmap kernels run beside the feature
+        kernels; every conv waits on the event of its own rulebook.  Captured as fork/join in hipGraph mode."""
+        if not (self.prefetch_rulebooks and x0.features.is_cuda):
+            return
+        if not hasattr(self, "_conv_list"):
+            self._conv_list = [m for m in self.modules() if isinstance(m, spconv.conv.SparseConvolution)]
+        cur = torch.cuda.current_stream()
+        side = Fsp._side_stream(x0.features.device, "rulebook")
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            t = x0
+            for conv in self._conv_list:
+                rb, out_idx, out_shape = conv._rulebook(t)
+                if getattr(rb, "ready_event", None) is None:
+                    rb.ready_event = torch.cuda.Event()
+                    rb.ready_event.record(side)
+                if not conv.subm:
+                    t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
+                                         num_rows=rb.n_out_dev)
+
     def _run(self, batch_dict):
         self._bump_bn_counters()
-        x = self.conv_input(self._input_tensor(batch_dict))
+        x0 = self._input_tensor(batch_dict)
+        self._prefetch_rulebooks(x0)
+        x = self.conv_input(x0)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
         x_conv3 = self.conv3(x_conv2)

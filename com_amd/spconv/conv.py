@@ -82,6 +82,9 @@ class SparseConvolution(SparseModule):
         if cached is not None and self.subm:
             rb, _, _ = cached
             return rb, x.indices, x.spatial_shape
+        if cached is not None and not self.subm and cached[1] is x.indices and cached[0].out_indices is not None:
+            rb = cached[0]                          # pre-built for exactly this input (rulebook prefetch)
+            return rb, rb.out_indices, rb.out_shape
         if self.subm:
             # a SubM rulebook depends only on (indices, kernel, dilation): layers with different indice_keys on
             # the same tensor (conv_input 'subm1' and conv1 'res1' of VoxelResBackBone8x) share one build
@@ -109,6 +112,9 @@ class SparseConvolution(SparseModule):
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
         rb, out_idx, out_shape = self._rulebook(input)
+        ev = getattr(rb, "ready_event", None)
+        if ev is not None:                          # built on the prefetch stream: order this stream after it
+            torch.cuda.current_stream().wait_event(ev)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd())
         out = SparseConvTensor(feats, out_idx, out_shape, input.batch_size, input.grid, input.voxel_num,
                                input.indice_dict, input.benchmark, rb.n_out_dev)

@@ -31,8 +31,8 @@ class _NullCtx:
         return False
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, role="wgrad"):
+    key = (device.type, device.index) if role == "wgrad" else (device.type, device.index, role)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
