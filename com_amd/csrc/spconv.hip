@@ -20,6 +20,8 @@
 // fixed order, written to per-split slabs and summed by a second kernel: deterministic, no atomics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -68,33 +70,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 
 // ---------------------------------------------------------------------------------------------
 // Output-stationary gather-GEMM.  Workgroup = 4 waves x (MI*16) output rows, all NB*16 output channels.
-//   * the workgroup's rulebook tile nbr[K][ROWS] is staged in LDS once (coalesced k-major reads);
+//   * the workgroup's rulebook tile nbr[K][ROWS] is staged in LDS once (coalesced k-major reads) plus one
+//     row of -1 that padded contraction steps read;
 //   * packed weights are shared by the 4 waves through LDS: narrow layers keep the whole packed weight
 //     resident (no barrier in the main loop); wide layers stream it through a double-buffered stage of
-//     SG contraction steps, filled global -> registers -> LDS one stage ahead (one barrier per stage, the
-//     stage is long enough to cover the L2 latency).  Fragments come back with conflict-free linear
-//     ds_read_b128; with MI = 2 each fragment feeds two MFMAs (LDS read rate <= half of peak);
+//     SG contraction steps, filled global -> registers -> LDS one stage ahead (one barrier per stage).
+//     Fragments come back with conflict-free linear ds_read_b128; with MI = 2 each feeds two MFMAs;
 //   * gathered feature rows go straight from L2 into MFMA operand registers, issued one GROUP of G
-//     contraction steps ahead of their use (register double buffer);
+//     contraction steps ahead of their use (two register sets, ping-pong, no copies);
 //   * a contraction step whose 16-row tile has no neighbour at all is skipped (wave-uniform ballot).
-template <int NB, int MI, int G, int SG, bool OUT_BF16>   // SG == 0: weights resident in LDS
-__global__ __launch_bounds__(256) void gather_gemm_kernel(
+// EVERY load in the main loop is an unconditional raw buffer load (out-of-range -> zeros, no memory access):
+// with conditional loads hipcc cannot count how many younger loads follow an operand's load and falls back to
+// s_waitcnt vmcnt(~0) at the first MFMA of each group, which waits for the loads issued for the NEXT group and
+// exposes the full L2 latency every G steps (seen in the ISA of the previous version).
+// WN = 2: 8 waves per workgroup, waves 4-7 take the upper half of the output channels of the same rows.
+template <int NB, int MI, int G, int SG, bool OUT_BF16, int WN = 1>   // SG == 0: weights resident in LDS
+__global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
     int n_out_cap, const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, int nsteps,
-    unsigned x_bytes) {
+    unsigned x_bytes, int dbg) {
     constexpr int ROWS = 4 * MI * 16;
+    constexpr int THREADS = 256 * WN;
+    constexpr int NBW = NB / WN;                           // 16-channel blocks per wave
+    static_assert(NB % WN == 0, "channel split");
     constexpr bool STAGED = SG > 0;
-    const int n_out = eff_rows(n_out_dev, n_out_cap);
+    constexpr int GPS = STAGED ? SG / G : 1;               // gather groups per weight stage: 1 or 2
+    static_assert(!STAGED || (SG == G || SG == 2 * G), "a stage is one or two gather groups");
     constexpr int VEC = STAGED ? SG * NB * 64 : 1;         // uint4 per stage
-    constexpr int WPT = STAGED ? VEC / 256 : 1;            // uint4 per thread per stage
-    static_assert(!STAGED || (SG % G == 0 && VEC % 256 == 0), "stage / group mismatch");
+    constexpr int WPT = STAGED ? VEC / THREADS : 1;        // uint4 per thread per stage
+    static_assert(!STAGED || VEC % THREADS == 0, "stage size");
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t wtotal = (size_t)nsteps * NB * 64;  // uint4 in the packed weight
-    uint4 *wbuf = (uint4 *)smem;                     // staged: [2][VEC]; resident: [wtotal]
-    int *nbr_s = (int *)(smem + (STAGED ? (size_t)2 * VEC : wtotal) * sizeof(uint4));  // [K][ROWS]
+    const unsigned wtotal = (unsigned)nsteps * NB * 64;  // uint4 in the packed weight
+    uint4 *wbuf = (uint4 *)smem;                         // staged: [2][VEC]; resident: [wtotal]
+    int *nbr_s = (int *)(smem + (STAGED ? (size_t)2 * VEC : (size_t)wtotal) * sizeof(uint4));  // [K+1][ROWS]
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = (threadIdx.x >> 6) & 3;               // row-tile index inside the workgroup
+    const int wn = threadIdx.x >> 8;                       // channel half (0 when WN == 1)
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15;
     const int g = lane >> 4;
@@ -107,28 +120,59 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
     if (r0wg >= n_out) return;
     constexpr int c_out = NB * 16;
 
-    for (int idx = threadIdx.x; idx < K * ROWS; idx += 256) {
-        int k = idx / ROWS, r = idx - k * ROWS;
-        int row = r0wg + r;
-        int krow = flip ? (K - 1 - k) : k;
-        nbr_s[idx] = row < n_out ? nbr[(size_t)krow * nbr_stride + row] : -1;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)(wtotal * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+    // rulebook tile -> LDS, 4 independent loads in flight per thread
+    {
+        const int total = K * ROWS;
+        for (int base = threadIdx.x; base < total + ROWS; base += 4 * THREADS) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                const int k = idx / ROWS, r = idx - k * ROWS;
+                const int row = r0wg + r;
+                const int krow = flip ? (K - 1 - k) : k;
+                const unsigned off = (idx < total && row < n_out)
+                                         ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u
+                                         : 0xFFFFFFF0u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
+                if (!(idx < total && row < n_out)) v[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                if (idx < total + ROWS) nbr_s[idx] = v[u];  // row K of the tile = -1 (padded steps)
+            }
+        }
     }
     if (STAGED) {
+        u32x4 w0[WPT];
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            size_t e = (size_t)j * 256 + threadIdx.x;
-            wbuf[e] = e < wtotal ? wp[e] : make_uint4(0, 0, 0, 0);
-        }
+        for (int j = 0; j < WPT; ++j)
+            w0[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(j * THREADS + threadIdx.x) * 16u, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) reinterpret_cast<u32x4 *>(wbuf)[j * THREADS + threadIdx.x] = w0[j];
     } else {
-        for (size_t e = threadIdx.x; e < wtotal; e += 256) wbuf[e] = wp[e];
+        for (unsigned e = threadIdx.x; e < wtotal; e += 4 * THREADS) {
+            u32x4 w0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                w0[u] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (e + u * THREADS) * 16u, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u * THREADS < wtotal) reinterpret_cast<u32x4 *>(wbuf)[e + u * THREADS] = w0[u];
+        }
     }
     __syncthreads();
 
-    f32x4 acc[MI][NB];
+    f32x4 acc[MI][NBW];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tile_row = wave * (MI * 16) + rl;
     // Feature rows are fetched with raw buffer loads: a missing neighbour (index -1) becomes an offset beyond
@@ -144,41 +188,44 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
             const int q0 = (s0 + gg) * 32 + g * 8;
-            const int k = q0 >> cshift;
+            int k = q0 >> cshift;
+            k = k < K ? k : K;                                  // padded steps read the -1 row
             const unsigned c0b = (unsigned)(q0 & (c_in - 1)) * 2u;
             valid[gg] = false;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                int i = (k < K) ? nbr_s[k * ROWS + tile_row + mi * 16] : -1;
+                int i = nbr_s[k * ROWS + tile_row + mi * 16];
+                if (dbg & 1) i = (i >= 0) ? (tile_row & 63) : i;  // ablation: gathers hit a few hot rows
                 a[gg][mi] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((unsigned)i << row_shift) + c0b, 0, 0);
                 valid[gg] |= (i >= 0);
             }
         }
     };
 
-    const int ngroups = (nsteps + G - 1) / G;
+    u32x4 wreg[WPT];
     int cur = 0;
-    uint4 wreg[WPT];
-    // one group of G contraction steps: prefetch the next stage's weights / the next group's rows, multiply
-    auto body = [&](int grp, u32x4(&ac)[G][MI], bool(&vc)[G], u32x4(&an)[G][MI], bool(&vn)[G]) {
+    // one group of G contraction steps.  FIRST / LAST: position of the group inside its weight stage
+    // (compile time), so the stage prefetch / publish code is straight-line.
+    auto body = [&](int grp, auto first_tag, auto last_tag, u32x4(&ac)[G][MI], bool(&vc)[G], u32x4(&an)[G][MI],
+                    bool(&vn)[G]) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
         const int s0 = grp * G;
-        if (STAGED && (s0 % (STAGED ? SG : 1)) == 0) {
-            const size_t base = (size_t)(s0 / (STAGED ? SG : 1) + 1) * VEC;  // next stage
+        if (STAGED && FIRST && !(dbg & 2)) {
+            const unsigned base = (unsigned)(s0 / (STAGED ? SG : 1) + 1) * VEC;  // next stage (OOB -> zeros)
 #pragma unroll
-            for (int j = 0; j < WPT; ++j) {
-                size_t e = base + (size_t)j * 256 + threadIdx.x;
-                wreg[j] = e < wtotal ? wp[e] : make_uint4(0, 0, 0, 0);
-            }
+            for (int j = 0; j < WPT; ++j)
+                wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, (base + (unsigned)(j * THREADS) + threadIdx.x) * 16u, 0, 0);
         }
-        if (grp + 1 < ngroups) gather_group(s0 + G, an, vn);
-        const uint4 *wcur = STAGED ? wbuf + (size_t)cur * VEC + (size_t)(s0 % (STAGED ? SG : 1)) * NB * 64
+        gather_group(s0 + G, an, vn);  // beyond the last step: index -1 everywhere -> no memory traffic
+        const uint4 *wcur = STAGED ? wbuf + (size_t)cur * VEC + (size_t)(FIRST ? 0 : G) * NB * 64
                                    : wbuf + (size_t)s0 * NB * 64;
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
-            if (s0 + gg < nsteps && __any(vc[gg])) {
+            if (__any(vc[gg]) && !(dbg & 4)) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    bf16x8 b = as_bf16x8(wcur[(gg * NB + nb) * 64 + lane]);
+                for (int nb = 0; nb < NBW; ++nb) {
+                    bf16x8 b = as_bf16x8(wcur[(gg * NB + wn * NBW + nb) * 64 + lane]);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -186,19 +233,28 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
                 }
             }
         }
-        if (STAGED && ((s0 + G) % (STAGED ? SG : 1)) == 0) {
-            uint4 *wnext = wbuf + (size_t)(cur ^ 1) * VEC;
+        if (STAGED && LAST) {
+            u32x4 *wnext = reinterpret_cast<u32x4 *>(wbuf) + (size_t)(cur ^ 1) * VEC;
 #pragma unroll
-            for (int j = 0; j < WPT; ++j) wnext[(size_t)j * 256 + threadIdx.x] = wreg[j];
+            for (int j = 0; j < WPT; ++j) wnext[j * THREADS + threadIdx.x] = wreg[j];
             __syncthreads();
             cur ^= 1;
         }
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
 
     gather_group(0, a0, v0);
-    for (int grp = 0; grp < ngroups; grp += 2) {  // ping-pong the two register sets (no copies)
-        body(grp, a0, v0, a1, v1);
-        if (grp + 1 < ngroups) body(grp + 1, a1, v1, a0, v0);
+    const int ngroups = (nsteps + G - 1) / G;
+    const int npairs = (dbg & 8) ? 0 : (ngroups + 1) / 2;  // groups are processed in ping-pong pairs
+    for (int pr = 0; pr < npairs; ++pr) {
+        if (GPS == 2) {  // one stage = this pair
+            body(2 * pr, T_{}, F_{}, a0, v0, a1, v1);
+            body(2 * pr + 1, F_{}, T_{}, a1, v1, a0, v0);
+        } else {         // every group is a stage (or the weights are resident)
+            body(2 * pr, T_{}, T_{}, a0, v0, a1, v1);
+            body(2 * pr + 1, T_{}, T_{}, a1, v1, a0, v0);
+        }
     }
 
 #pragma unroll
@@ -206,8 +262,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
         int row = r0wg + tile_row + mi * 16;
         if (row >= n_out) continue;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            int col = nb * 16 + g * 4;
+        for (int nb = 0; nb < NBW; ++nb) {
+            int col = (wn * NBW + nb) * 16 + g * 4;
             f32x4 v = acc[mi][nb];
             if (bias) {
                 float4 bv = *reinterpret_cast<const float4 *>(bias + col);
@@ -227,17 +283,18 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(
     }
 }
 
-template <int NB, int MI, int G, int SG>
+template <int NB, int MI, int G, int SG, int WN = 1>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, const int32_t *n_out_dev,
                      void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
-    size_t lds = wbytes + (size_t)K * ROWS * sizeof(int);
+    size_t lds = wbytes + (size_t)(K + 1) * ROWS * sizeof(int);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
-    auto kb = gather_gemm_kernel<NB, MI, G, SG, true>;
-    auto kf = gather_gemm_kernel<NB, MI, G, SG, false>;
+    static const int dbg = getenv("PCD_GG_DBG") ? atoi(getenv("PCD_GG_DBG")) : 0;  // ablation switches
+    auto kb = gather_gemm_kernel<NB, MI, G, SG, true, WN>;
+    auto kf = gather_gemm_kernel<NB, MI, G, SG, false, WN>;
     if (lds > 64 * 1024) {
         // above the default dynamic-LDS limit: raise it for this kernel (host-side attribute, set once per
         // instantiation -- benign race: the call is idempotent)
@@ -251,11 +308,11 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
         }
     }
     if (y_dtype == PCD_BF16)
-        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes);
+        kb<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg);
     else
-        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes);
+        kf<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -534,7 +591,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st
     switch (c_out / 16) {
         case 1:
-            return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 16>(GG_ARGS);
+            return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 8>(GG_ARGS);
         case 2:
             return resident ? launch_gg<2, 2, 4, 0>(GG_ARGS) : launch_gg<2, 2, 4, 8>(GG_ARGS);
         case 4:
@@ -542,6 +599,14 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
             return small ? launch_gg<4, 1, 4, 8>(GG_ARGS) : launch_gg<4, 2, 4, 8>(GG_ARGS);
         case 8:
             if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
+            if (const char *e = getenv("PCD_GG8")) {  // experiment switch
+                if (e[0] == '4') return launch_gg<8, 4, 2, 4>(GG_ARGS);
+                if (e[0] == 'a') return launch_gg<8, 2, 4, 4, 2>(GG_ARGS);
+                if (e[0] == 'b') return launch_gg<8, 2, 2, 4, 2>(GG_ARGS);
+                if (e[0] == 'c') return launch_gg<8, 4, 2, 4, 2>(GG_ARGS);
+                if (e[0] == '1') return launch_gg<8, 1, 4, 4>(GG_ARGS);
+                if (e[0] == '2') return launch_gg<8, 2, 4, 4>(GG_ARGS);
+            }
             return small ? launch_gg<8, 1, 4, 4>(GG_ARGS) : launch_gg<8, 2, 4, 4>(GG_ARGS);
         default:
             return PCD_ERR_UNSUPPORTED;
