@@ -275,32 +275,41 @@ def main():
     if use_graph:
         # the whole step becomes two hipGraphs (forward+backward | clip+Adam) with the gradient all-reduce in
         # between; row counts stay on the device, buffers are sized from the observed counts x 1.25
-        plan.active = True
-        s_pts, s_offs = batches[0][0].clone(), batches[0][1].clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
+        try:
+            plan.active = True
+            s_pts, s_offs = batches[0][0].clone(), batches[0][1].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fwd_bwd(s_pts, s_offs)
+                    opt_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            plan.recorded.clear()
+            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb):
                 fwd_bwd(s_pts, s_offs)
+            with torch.cuda.graph(g_opt, pool=g_fb.pool()):
                 opt_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        plan.recorded.clear()
-        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb):
-            fwd_bwd(s_pts, s_offs)
-        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
-            opt_step()
 
-        def run_step(i):
-            pts, offs = batches[i % 2]
-            s_pts.copy_(pts, non_blocking=True)              # device -> device: the batch is already in HBM
-            s_offs.copy_(offs, non_blocking=True)
-            g_fb.replay()
-            bucket.all_reduce_mean()
-            g_opt.replay()
-        for i in range(2):
-            run_step(i)
+            def run_step(i):
+                pts, offs = batches[i % 2]
+                s_pts.copy_(pts, non_blocking=True)          # device -> device: the batch is already in HBM
+                s_offs.copy_(offs, non_blocking=True)
+                g_fb.replay()
+                bucket.all_reduce_mean()
+                g_opt.replay()
+            for i in range(2):
+                run_step(i)
+            torch.cuda.synchronize()
+            plan.check()
+        except Exception as exc:                             # never lose the measurement: fall back to eager
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            use_graph = False
+            plan.active = False
+            torch.cuda.synchronize()
+            run_step = eager_step
     else:
         run_step = eager_step
 
