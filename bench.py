@@ -214,6 +214,7 @@ def main():
     from com_amd import dist as cdist
     from com_amd.spconv import functional as Fsp
     # (Fsp.DEFERRED_WGRAD -- a fully asynchronous wgrad pipeline -- measured slower here: 516 vs 542 frames/s)
+    Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
     model = HotPath().to(dev)
     model.train()
     if world > 1:                                            # what DDP does at construction (tools/train.py:165-166)

@@ -101,6 +101,8 @@ class _BackboneBase(nn.Module):
         side = Fsp._side_stream(x0.features.device, "rulebook")
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            for conv in self._conv_list:                       # weight packs (fwd + dgrad) off the critical path
+                conv.prepack(dgrad=self.training)
             t = x0
             for conv in self._conv_list:
                 rb, out_idx, out_shape = conv._rulebook(t)

@@ -305,15 +305,17 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 
 
 # ---------------------------------------------------------------------------------------------
-def pack_weight(weight, mode):
-    """weight [Cout, kd, kh, kw, Cin] f32 (spconv 2.x layout) -> bf16 MFMA-fragment order."""
+def pack_weight(weight, mode, out=None):
+    """weight [Cout, kd, kh, kw, Cin] f32 (spconv 2.x layout) -> bf16 MFMA-fragment order (into `out` if it is a
+    persistent buffer of the right size)."""
     _require_cuda(weight)
     w = weight.detach().contiguous().float()
     cout, cin = w.shape[0], w.shape[-1]
     K = w.numel() // (cout * cin)
     lib = L.lib()
     nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
-    packed = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    packed = out if (out is not None and out.numel() == nbytes // 2 and out.device == w.device) else \
+        torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
     L.check(lib.pcd_pack_weight(L.ptr(w), K, cin, cout, mode, L.ptr(packed), L.stream_ptr()),
             "pcd_pack_weight")
     return packed
@@ -341,8 +343,14 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     return y
 
 
-def wgrad(x, cin, dy, pairs, pair_num, kvol):
-    """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]."""
+def _usable_out(out, numel):
+    return (out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == numel
+            and out.is_cuda)
+
+
+def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None):
+    """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
+    (e.g. the parameter's .grad) when given."""
     _require_cuda(x, dy, pairs, pair_num)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     assert x.is_contiguous() and dy.is_contiguous() and pairs.is_contiguous()
@@ -350,7 +358,8 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol):
     pmax = pairs.shape[2]
     lib = L.lib()
     ws = _ws(lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax), x.device)
-    dw = torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
+    dw = out if _usable_out(out, cout * kvol * cin) else \
+        torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
 
     def meta():
         npairs = int(pair_num.sum().item())
@@ -426,7 +435,8 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
     return y, save_mean, save_invstd
 
 
-def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None):
+def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None,
+                dgamma_out=None, dbeta_out=None):
     _require_cuda(dy, x)
     dy = dy.contiguous()
     n, c = x.shape
@@ -434,8 +444,8 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     lib = L.lib()
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
-    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    dgamma = dgamma_out if _usable_out(dgamma_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
+    dbeta = dbeta_out if _usable_out(dbeta_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
     L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma),
                                 L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
@@ -444,13 +454,14 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     return dx, dres, dgamma, dbeta
 
 
-def col_sum(x, n_dev=None):
+def col_sum(x, n_dev=None, out=None):
     """out[c] = sum_rows x[:, c] in fp32 (bias gradient), deterministic two-stage reduction."""
     _require_cuda(x)
     x = x.contiguous()
     n, c = x.shape
     lib = L.lib()
-    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    if not _usable_out(out, c):
+        out = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), x.device)
     L.check(lib.pcd_col_sum(L.ptr(x), _dtype_code(x), n, c, L.ptr(out), L.ptr(n_dev), L.ptr(ws), ws.numel(),
                             L.stream_ptr()), "pcd_col_sum")

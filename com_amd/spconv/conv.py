@@ -47,6 +47,8 @@ class SparseConvolution(SparseModule):
         self.reset_parameters()
         self._packed = None
         self._packed_version = None
+        self._packed_d = None
+        self._packed_d_version = None
 
     def reset_parameters(self):
         # spconv 2.x default init: kaiming_uniform_(a=sqrt(5)), bias ~ U(+-1/sqrt(fan_in))  
@@ -67,9 +69,23 @@ class SparseConvolution(SparseModule):
     def _packed_fwd(self):
         key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
         if self._packed is None or self._packed_version != key:
-            self._packed = ops.pack_weight(self.weight, 0)
+            self._packed = ops.pack_weight(self.weight, 0, out=self._packed)
             self._packed_version = key
         return self._packed
+
+    def _packed_dgrad(self):
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        if self._packed_d is None or self._packed_d_version != key:
+            self._packed_d = ops.pack_weight(self.weight, 1, out=self._packed_d)
+            self._packed_d_version = key
+        return self._packed_d
+
+    def prepack(self, dgrad=True):
+        """Pack the weights for forward (and dgrad) now -- e.g. on a side stream at the start of a step, so the
+        ~40 small pack kernels of a backbone leave the critical path; later calls hit the cache."""
+        self._packed_fwd()
+        if dgrad and self.in_channels >= 16:
+            self._packed_dgrad()
 
     def _rulebook(self, x):
         """Look up / build the rulebook; returns (rulebook, out_indices, out_spatial_shape)."""
@@ -115,7 +131,7 @@ class SparseConvolution(SparseModule):
         ev = getattr(rb, "ready_event", None)
         if ev is not None:                          # built on the prefetch stream: order this stream after it
             torch.cuda.current_stream().wait_event(ev)
-        feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd())
+        feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad)
         out = SparseConvTensor(feats, out_idx, out_shape, input.batch_size, input.grid, input.voxel_num,
                                input.indice_dict, input.benchmark, rb.n_out_dev)
         return out

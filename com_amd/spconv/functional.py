@@ -12,6 +12,11 @@ OVERLAP_WGRAD = True
 # and autograd gets None for them, so the whole wgrad chain runs as a second pipeline beside the
 # dgrad/BatchNorm chain.  The caller must call join_deferred_wgrad() after loss.backward().
 DEFERRED_WGRAD = False
+# Opt-in for training loops whose parameters each receive exactly ONE gradient contribution per step and own
+# pre-allocated fp32 `.grad` buffers (bench.py: views of one flat bucket): the kernels then write dW / dbias /
+# dgamma / dbeta straight into `.grad` and autograd gets None for them -- no temporary, no AccumulateGrad add
+# kernel per parameter (79 tiny launches per step on the critical path of VoxelResBackBone8x).
+DIRECT_GRAD = False
 _SIDE = {}
 
 
@@ -56,7 +61,7 @@ class SparseConvFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, packed_fwd):
+    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None):
         cout, cin = weight.shape[0], weight.shape[-1]
         cin_pad = ops.pow2_ge8(cin)
         assert features.shape[1] in (cin, cin_pad), (features.shape, weight.shape)
@@ -66,6 +71,7 @@ class SparseConvFunction(Function):
         y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
                             n_dev=rb.n_out_dev)
         ctx.rb = rb
+        ctx.packed_dgrad = packed_dgrad          # callable returning the (cached) dgrad pack of the module
         ctx.cin, ctx.cout, ctx.cin_pad = cin, cout, cin_pad
         ctx.in_cols = features.shape[1]
         ctx.has_bias = bias is not None
@@ -94,16 +100,23 @@ class SparseConvFunction(Function):
         weight_p = ctx.weight_param
         deferred = (DEFERRED_WGRAD and side is not None and weight_p is not None and weight_p.grad is not None
                     and (not ctx.has_bias or (bias_p is not None and bias_p.grad is not None)))
+        direct_w = DIRECT_GRAD and weight_p is not None and weight_p.grad is not None \
+            and weight_p.grad.dtype == torch.float32 and weight_p.grad.is_contiguous()
+        direct_b = DIRECT_GRAD and bias_p is not None and bias_p.grad is not None \
+            and bias_p.grad.dtype == torch.float32 and bias_p.grad.is_contiguous()
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if ctx.needs_input_grad[1]:
-                dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol)      # [Cout, K, Cin] f32
-                dw = dwk.view(weight.shape).to(weight.dtype)
-                if deferred:
+                dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol,
+                                out=weight_p.grad if direct_w else None)                 # [Cout, K, Cin] f32
+                dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
+                if deferred and dw is not None:
                     weight_p.grad.add_(dw)
                     dw = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = ops.col_sum(dy16, n_dev=rb.n_out_dev)
-                if deferred:
+                db = ops.col_sum(dy16, n_dev=rb.n_out_dev, out=bias_p.grad if direct_b else None)
+                if direct_b:
+                    db = None
+                elif deferred:
                     bias_p.grad.add_(db)
                     db = None
         if deferred:
@@ -115,7 +128,7 @@ class SparseConvFunction(Function):
             if ctx.cin_pad % 16 != 0:
                 raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
                                    "requires an input gradient)")
-            packed_d = ops.pack_weight(weight, 1)
+            packed_d = ctx.packed_dgrad() if ctx.packed_dgrad is not None else ops.pack_weight(weight, 1)
             if rb.subm:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev)
@@ -128,7 +141,7 @@ class SparseConvFunction(Function):
             for t in (dw, db):
                 if t is not None:
                     t.record_stream(cur)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class BevDenseFunction(Function):
@@ -158,8 +171,8 @@ def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None):
     return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev)
 
 
-def sparse_conv(features, weight, bias, rb, packed_fwd):
-    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd)
+def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None):
+    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad)
 
 
 class FusedBNFunction(Function):
@@ -183,6 +196,7 @@ class FusedBNFunction(Function):
             save_invstd = torch.rsqrt(bn.running_var + bn.eps)
         ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
         ctx.n_dev = n_dev
+        ctx.bn = bn
         ctx.save_for_backward(xc, y, g, save_mean, save_invstd)
         return y
 
@@ -191,8 +205,17 @@ class FusedBNFunction(Function):
         x, y, g, save_mean, save_invstd = ctx.saved_tensors
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
+        bn = ctx.bn
+        gw = bn.weight.grad if (DIRECT_GRAD and bn.weight is not None and ctx.needs_input_grad[1]) else None
+        gb = bn.bias.grad if (DIRECT_GRAD and bn.bias is not None and ctx.needs_input_grad[2]) else None
+        direct = gw is not None and gb is not None and ops._usable_out(gw, x.shape[1]) \
+            and ops._usable_out(gb, x.shape[1])
         dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
-                                                  ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev)
+                                                  ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev,
+                                                  dgamma_out=gw if direct else None,
+                                                  dbeta_out=gb if direct else None)
+        if direct:
+            dgamma = dbeta = None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 dres, None, None, None)
 
