@@ -60,82 +60,70 @@ class DynamicMeanVFE(VFETemplate):
 
 
 class PFNLayer(nn.Module):
-    """pillar_vfe.py:8-49"""
+    """One PointNet stage of the pillar encoder (pillar_vfe.py:8-49): per-point Linear (+BatchNorm1d eps 1e-3,
+    momentum 0.01) + ReLU, max over the points of a pillar; non-final stages append the pillar maximum to every
+    point.  Sub-module names (`linear`, `norm`) match the reference state dict."""
 
     def __init__(self, in_channels, out_channels, use_norm=True, last_layer=False):
         super().__init__()
-        self.last_vfe = last_layer
-        self.use_norm = use_norm
-        if not self.last_vfe:
-            out_channels = out_channels // 2
-        if self.use_norm:
-            self.linear = nn.Linear(in_channels, out_channels, bias=False)
-            self.norm = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)
-        else:
-            self.linear = nn.Linear(in_channels, out_channels, bias=True)
-        self.part = 50000
+        self.last_vfe, self.use_norm = last_layer, use_norm
+        width = out_channels if last_layer else out_channels // 2
+        self.linear = nn.Linear(in_channels, width, bias=not use_norm)
+        if use_norm:
+            self.norm = nn.BatchNorm1d(width, eps=1e-3, momentum=0.01)
 
     def forward(self, inputs):
-        x = self.linear(inputs)
-        x = self.norm(x.permute(0, 2, 1)).permute(0, 2, 1) if self.use_norm else x
-        x = F.relu(x)
-        x_max = torch.max(x, dim=1, keepdim=True)[0]
-        if self.last_vfe:
-            return x_max
-        x_repeat = x_max.repeat(1, inputs.shape[1], 1)
-        return torch.cat([x, x_repeat], dim=2)
+        m, t, _ = inputs.shape
+        h = self.linear(inputs)
+        if self.use_norm:                       # BatchNorm over all (pillar, point) rows, channel last
+            h = self.norm(h.reshape(m * t, -1)).reshape(m, t, -1)
+        h = F.relu(h)
+        pooled = h.amax(dim=1, keepdim=True)
+        return pooled if self.last_vfe else torch.cat((h, pooled.expand(-1, t, -1)), dim=2)
 
 
 class PillarVFE(VFETemplate):
-    """pillar_vfe.py:52-123 (decoration + PointNet).  Plain library math (Linear/BN) stays in torch."""
+    """Pillar feature encoder (pillar_vfe.py:52-123): decorate the <= T points of each pillar with their offset
+    to the pillar mean (`f_cluster`) and to the pillar centre (`f_center`), zero the padding slots, run the PFN
+    stack.  Linear / BatchNorm are plain library math and stay in torch."""
 
     def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range, **kwargs):
         super().__init__(model_cfg=model_cfg)
         self.use_norm = _cfg_get(model_cfg, 'USE_NORM')
         self.with_distance = _cfg_get(model_cfg, 'WITH_DISTANCE')
         self.use_absolute_xyz = _cfg_get(model_cfg, 'USE_ABSLOTE_XYZ')
-        num_point_features += 6 if self.use_absolute_xyz else 3
-        if self.with_distance:
-            num_point_features += 1
         self.num_filters = list(_cfg_get(model_cfg, 'NUM_FILTERS'))
-        assert len(self.num_filters) > 0
-        num_filters = [num_point_features] + self.num_filters
-        layers = []
-        for i in range(len(num_filters) - 1):
-            layers.append(PFNLayer(num_filters[i], num_filters[i + 1], self.use_norm,
-                                   last_layer=(i >= len(num_filters) - 2)))
-        self.pfn_layers = nn.ModuleList(layers)
-        self.voxel_x, self.voxel_y, self.voxel_z = voxel_size[0], voxel_size[1], voxel_size[2]
-        self.x_offset = self.voxel_x / 2 + point_cloud_range[0]
-        self.y_offset = self.voxel_y / 2 + point_cloud_range[1]
-        self.z_offset = self.voxel_z / 2 + point_cloud_range[2]
+        assert self.num_filters
+        width_in = num_point_features + (6 if self.use_absolute_xyz else 3) + (1 if self.with_distance else 0)
+        widths = [width_in] + self.num_filters
+        self.pfn_layers = nn.ModuleList(
+            PFNLayer(widths[i], widths[i + 1], self.use_norm, last_layer=(i == len(widths) - 2))
+            for i in range(len(widths) - 1))
+        # pillar centre of voxel index c along an axis = c * size + (size / 2 + range_min)
+        self.voxel_x, self.voxel_y, self.voxel_z = (float(v) for v in voxel_size[:3])
+        self.x_offset = self.voxel_x / 2 + float(point_cloud_range[0])
+        self.y_offset = self.voxel_y / 2 + float(point_cloud_range[1])
+        self.z_offset = self.voxel_z / 2 + float(point_cloud_range[2])
 
     def get_output_feature_dim(self):
         return self.num_filters[-1]
 
-    @staticmethod
-    def get_paddings_indicator(actual_num, max_num, axis=0):
-        actual_num = torch.unsqueeze(actual_num, axis + 1)
-        shape = [1] * len(actual_num.shape)
-        shape[axis + 1] = -1
-        max_num = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(shape)
-        return actual_num.int() > max_num
-
     def forward(self, batch_dict, **kwargs):
-        vf, nump, coords = batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords']
-        points_mean = vf[:, :, :3].sum(dim=1, keepdim=True) / nump.type_as(vf).view(-1, 1, 1)
-        f_cluster = vf[:, :, :3] - points_mean
-        f_center = torch.zeros_like(vf[:, :, :3])
-        f_center[:, :, 0] = vf[:, :, 0] - (coords[:, 3].to(vf.dtype).unsqueeze(1) * self.voxel_x + self.x_offset)
-        f_center[:, :, 1] = vf[:, :, 1] - (coords[:, 2].to(vf.dtype).unsqueeze(1) * self.voxel_y + self.y_offset)
-        f_center[:, :, 2] = vf[:, :, 2] - (coords[:, 1].to(vf.dtype).unsqueeze(1) * self.voxel_z + self.z_offset)
-        features = [vf, f_cluster, f_center] if self.use_absolute_xyz else [vf[..., 3:], f_cluster, f_center]
+        pts = batch_dict['voxels']                                  # [M, T, C], zero padded
+        count = batch_dict['voxel_num_points'].to(pts.dtype)        # [M]   (not clamped: pillar_vfe.py:97)
+        coords = batch_dict['voxel_coords'].to(pts.dtype)           # [M, 4] (b, z, y, x)
+        xyz = pts[..., :3]
+        mean = xyz.sum(dim=1, keepdim=True) / count.view(-1, 1, 1)
+        size = pts.new_tensor([self.voxel_x, self.voxel_y, self.voxel_z])
+        origin = pts.new_tensor([self.x_offset, self.y_offset, self.z_offset])
+        centre = coords[:, [3, 2, 1]] * size + origin               # (x, y, z) centre of each pillar
+        parts = [pts if self.use_absolute_xyz else pts[..., 3:], xyz - mean, xyz - centre.unsqueeze(1)]
         if self.with_distance:
-            features.append(torch.norm(vf[:, :, :3], 2, 2, keepdim=True))
-        features = torch.cat(features, dim=-1)
-        mask = self.get_paddings_indicator(nump, features.shape[1], axis=0)
-        features = features * torch.unsqueeze(mask, -1).type_as(vf)
-        for pfn in self.pfn_layers:
-            features = pfn(features)
-        batch_dict['pillar_features'] = features.squeeze(1) if features.dim() == 3 else features
+            parts.append(xyz.norm(dim=2, keepdim=True))
+        feats = torch.cat(parts, dim=-1)
+        slot = torch.arange(pts.shape[1], device=pts.device).view(1, -1)
+        feats = feats * (slot < batch_dict['voxel_num_points'].view(-1, 1)).unsqueeze(-1).to(pts.dtype)
+        for layer in self.pfn_layers:
+            feats = layer(feats)
+        batch_dict['pillar_features'] = feats.squeeze(1)
         return batch_dict
