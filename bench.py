@@ -214,6 +214,7 @@ def main():
     from com_amd import dist as cdist
     from com_amd.spconv import functional as Fsp
     # (Fsp.DEFERRED_WGRAD -- a fully asynchronous wgrad pipeline -- measured slower here: 516 vs 542 frames/s)
+    Fsp.DEFERRED_WGRAD = bool(int(os.environ.get('PCD_DEFERRED', '0')))
     Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
     model = HotPath().to(dev)
     model.train()

@@ -585,29 +585,27 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
     // Launch configuration per output width (NB = c_out/16):  <NB, MI, G (gather look-ahead), SG (stage)>
     //   packed weight <= 32 KB  -> resident in LDS, no barrier in the main loop (narrow / early layers)
     //   else                    -> double-buffered stages of SG steps
+    // Narrow layers (NB 1/2, 300k+ rows): short look-ahead, many waves per SIMD.
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
     const bool resident = wbytes <= 32 * 1024;
-    const bool small = n_rows_out < 32 * 1024;  // few rows: 64-row workgroups fill the chip better
+    // Wide layers are latency bound, so occupancy wins over look-ahead (G = 1, one-step stages) and the
+    // rows per wave (MI x 16) shrink with the row count to keep >= ~3 workgroups per CU in flight
+    // (measured on gfx950, 128 ch / 42k rows: MI 1/2/4 = 61/68/77 us; 64 ch / 115k rows: 60/55/53 us).
+    const int mi = n_rows_out >= 96 * 1024 ? 4 : n_rows_out >= 48 * 1024 ? 2 : 1;
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st
     switch (c_out / 16) {
         case 1:
-            return resident ? launch_gg<1, 2, 4, 0>(GG_ARGS) : launch_gg<1, 2, 4, 8>(GG_ARGS);
+            return resident ? launch_gg<1, 1, 2, 0>(GG_ARGS) : launch_gg<1, 1, 2, 4>(GG_ARGS);
         case 2:
-            return resident ? launch_gg<2, 2, 4, 0>(GG_ARGS) : launch_gg<2, 2, 4, 8>(GG_ARGS);
+            return resident ? launch_gg<2, 2, 1, 0>(GG_ARGS) : launch_gg<2, 2, 1, 2>(GG_ARGS);
         case 4:
             if (resident) return launch_gg<4, 2, 2, 0>(GG_ARGS);
-            return small ? launch_gg<4, 1, 4, 8>(GG_ARGS) : launch_gg<4, 2, 4, 8>(GG_ARGS);
+            return mi == 4 ? launch_gg<4, 4, 1, 1>(GG_ARGS)
+                           : mi == 2 ? launch_gg<4, 2, 1, 1>(GG_ARGS) : launch_gg<4, 1, 1, 1>(GG_ARGS);
         case 8:
             if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
-            if (const char *e = getenv("PCD_GG8")) {  // experiment switch
-                if (e[0] == '4') return launch_gg<8, 4, 2, 4>(GG_ARGS);
-                if (e[0] == 'a') return launch_gg<8, 2, 4, 4, 2>(GG_ARGS);
-                if (e[0] == 'b') return launch_gg<8, 2, 2, 4, 2>(GG_ARGS);
-                if (e[0] == 'c') return launch_gg<8, 4, 2, 4, 2>(GG_ARGS);
-                if (e[0] == '1') return launch_gg<8, 1, 4, 4>(GG_ARGS);
-                if (e[0] == '2') return launch_gg<8, 2, 4, 4>(GG_ARGS);
-            }
-            return small ? launch_gg<8, 1, 4, 4>(GG_ARGS) : launch_gg<8, 2, 4, 4>(GG_ARGS);
+            return mi == 4 ? launch_gg<8, 4, 1, 1>(GG_ARGS)
+                           : mi == 2 ? launch_gg<8, 2, 1, 1>(GG_ARGS) : launch_gg<8, 1, 1, 1>(GG_ARGS);
         default:
             return PCD_ERR_UNSUPPORTED;
     }

@@ -1,4 +1,4 @@
-"""Experiment: level-4 SubM 128->128 forward kernel variants (PCD_GG8 env)."""
+"""Experiment: level-3/4 SubM 64->64 / 128->128 forward kernel variants (PCD_GG48 env, argv[1] = channels)."""
 import sys, os, torch
 sys.path.insert(0, '.')
 from com_amd import ops, hotpath
@@ -8,11 +8,12 @@ frames = [synth.synth_cloud(f) for f in range(4)]
 pts, offs = hotpath.collate_points(frames, dev)
 res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5, want_voxels=False)
 idx, shape = res['coords'], [41, 1504, 1504]
-for geo in ((3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1))):
+CH = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+for geo in ((3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)))[:3 if CH == 128 else 2]:
     rb = ops.rulebook_conv(idx, 4, shape, geo[0], geo[1], geo[2]); idx, shape = rb.out_indices, rb.out_shape
 n = idx.shape[0]
 rb = ops.rulebook_subm(idx, 4, shape)
-x = torch.randn(n, 128, device=dev).bfloat16(); w = torch.randn(128, 27, 128, device=dev) * 0.05
+x = torch.randn(n, CH, device=dev).bfloat16(); w = torch.randn(CH, 27, CH, device=dev) * 0.05
 pw = ops.pack_weight(w, 0)
 def t(fn, reps=20):
     for _ in range(3): fn()
@@ -22,5 +23,5 @@ def t(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 pairs = int(rb.pair_num.sum())
-us = t(lambda: ops.gather_gemm(x, pw, None, rb.nbr_out, 27, False, n, 128, torch.bfloat16))
-print(os.environ.get('PCD_GG8', 'default'), f"rows {n} pairs {pairs}: {us:.1f} us -> {2*pairs*128*128/us*1e-6:.0f} TFLOP/s algorithmic", flush=True)
+us = t(lambda: ops.gather_gemm(x, pw, None, rb.nbr_out, 27, False, n, CH, torch.bfloat16))
+print(os.environ.get('PCD_GG48', 'default'), CH, f"rows {n} pairs {pairs}: {us:.1f} us -> {2*pairs*CH*CH/us*1e-6:.0f} TFLOP/s algorithmic", flush=True)
