@@ -64,6 +64,33 @@ class SparseBasicBlock(spconv.SparseModule):
         return out
 
 
+class _RulebookPrefetcher:
+    def __init__(self, units, x0, side):
+        self.units, self.t, self.side, self.next = units, x0, side, 0
+
+    def advance(self):
+        if self.next >= len(self.units):
+            return
+        unit = self.units[self.next]
+        self.next += 1
+        with torch.cuda.stream(self.side):
+            t = self.t
+            built = []
+            for conv in unit:
+                rb, out_idx, out_shape = conv._rulebook(t)
+                if getattr(rb, "ready_event", None) is None:
+                    built.append(rb)
+                if not conv.subm:
+                    t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
+                                         num_rows=rb.n_out_dev)
+            self.t = t
+            if built:
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                for rb in built:
+                    rb.ready_event = ev
+
+
 class _BackboneBase(nn.Module):
     feature_dtype = torch.bfloat16
 
@@ -88,30 +115,38 @@ class _BackboneBase(nn.Module):
                 torch._foreach_add_(counters, 1)
 
     prefetch_rulebooks = True
+    prefetch_depth = 2          # rulebook units issued before the first conv; each unit's first consumer issues one more
 
     def _prefetch_rulebooks(self, x0):
-        """All 9 rulebooks depend only on the voxel coordinates, not on features: build the whole chain up front
-        on a second HIP stream so the (latency-bound, LDS-free) hash / bitmap kernels run beside the feature
-        kernels; every conv waits on the event of its own rulebook.  Captured as fork/join in hipGraph mode."""
+        """All 9 rulebooks depend only on the voxel coordinates, not on features: they are built on a second HIP
+        stream, one UNIT (a strided conv's rulebook + the SubM rulebook of the level it opens) ahead of the
+        feature kernels, so the latency-bound, LDS-free hash / bitmap kernels run beside the gather-GEMMs.  The
+        first conv that consumes a unit waits on the unit's event and then issues the next unit.  The weight
+        packs (forward + dgrad) go to a third stream.  Captured as fork/join in hipGraph mode."""
         if not (self.prefetch_rulebooks and x0.features.is_cuda):
             return
         if not hasattr(self, "_conv_list"):
             self._conv_list = [m for m in self.modules() if isinstance(m, spconv.conv.SparseConvolution)]
-        cur = torch.cuda.current_stream()
-        side = Fsp._side_stream(x0.features.device, "rulebook")
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for conv in self._conv_list:                       # weight packs (fwd + dgrad) off the critical path
-                conv.prepack(dgrad=self.training)
-            t = x0
+            units = [[]]
             for conv in self._conv_list:
-                rb, out_idx, out_shape = conv._rulebook(t)
-                if getattr(rb, "ready_event", None) is None:
-                    rb.ready_event = torch.cuda.Event()
-                    rb.ready_event.record(side)
-                if not conv.subm:
-                    t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
-                                         num_rows=rb.n_out_dev)
+                if not conv.subm and units[-1]:
+                    units.append([])
+                units[-1].append(conv)
+            self._rb_units = units
+        cur = torch.cuda.current_stream()
+        dev = x0.features.device
+        side = Fsp._side_stream(dev, "rulebook")
+        side.wait_stream(cur)
+        pf = _RulebookPrefetcher(self._rb_units, x0, side)
+        x0.indice_dict["__prefetcher__"] = pf
+        for _ in range(max(1, int(self.prefetch_depth))):
+            pf.advance()
+        pack_side = Fsp._side_stream(dev)                      # the wgrad stream is idle during the forward
+        pack_side.wait_stream(cur)
+        with torch.cuda.stream(pack_side):
+            for conv in self._conv_list:
+                conv.prepack(dgrad=self.training)
+        cur.wait_stream(pack_side)
 
     def _run(self, batch_dict):
         self._bump_bn_counters()
@@ -123,6 +158,8 @@ class _BackboneBase(nn.Module):
         x_conv3 = self.conv3(x_conv2)
         x_conv4 = self.conv4(x_conv3)
         out = self.conv_out(x_conv4)
+        if "__prefetcher__" in x0.indice_dict:                 # every unit was consumed; join the stream anyway
+            torch.cuda.current_stream().wait_stream(x0.indice_dict.pop("__prefetcher__").side)
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {
             'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3, 'x_conv4': x_conv4}})

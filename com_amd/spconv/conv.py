@@ -49,6 +49,7 @@ class SparseConvolution(SparseModule):
         self._packed_version = None
         self._packed_d = None
         self._packed_d_version = None
+        self._fresh_f = self._fresh_d = False
 
     def reset_parameters(self):
         # spconv 2.x default init: kaiming_uniform_(a=sqrt(5)), bias ~ U(+-1/sqrt(fan_in))  
@@ -66,26 +67,44 @@ class SparseConvolution(SparseModule):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
                 f"padding={self.padding}, subm={self.subm}, inverse={self.inverse}, key={self.indice_key}")
 
+    # Packed (MFMA fragment order) copies of the weight.  `weight._version` is NOT a reliable change marker:
+    # fused optimizers (torch.optim.Adam(fused=True), torch._fused_adam_) update parameters without bumping
+    # it.  So in training mode a pack is used exactly once: prepack() (start of the step) or the forward packs
+    # it, the forward / backward consumes it; in eval mode the pack is cached per (version, pointer) and
+    # train()/eval() switches drop the cache.
+    def _key(self):
+        return (self.weight._version, self.weight.data_ptr(), self.weight.device)
+
     def _packed_fwd(self):
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
-        if self._packed is None or self._packed_version != key:
+        if self._packed is None or self._packed_version != self._key() or (self.training and not self._fresh_f):
             self._packed = ops.pack_weight(self.weight, 0, out=self._packed)
-            self._packed_version = key
+            self._packed_version = self._key()
+        self._fresh_f = False
         return self._packed
 
     def _packed_dgrad(self):
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
-        if self._packed_d is None or self._packed_d_version != key:
+        if self._packed_d is None or self._packed_d_version != self._key() or (self.training and not self._fresh_d):
             self._packed_d = ops.pack_weight(self.weight, 1, out=self._packed_d)
-            self._packed_d_version = key
+            self._packed_d_version = self._key()
+        self._fresh_d = False
         return self._packed_d
 
     def prepack(self, dgrad=True):
         """Pack the weights for forward (and dgrad) now -- e.g. on a side stream at the start of a step, so the
-        ~40 small pack kernels of a backbone leave the critical path; later calls hit the cache."""
+        ~40 small pack kernels of a backbone leave the critical path; the next forward / backward consumes
+        these packs instead of packing again."""
+        self._fresh_f = False
         self._packed_fwd()
+        self._fresh_f = True
         if dgrad and self.in_channels >= 16:
+            self._fresh_d = False
             self._packed_dgrad()
+            self._fresh_d = True
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self._packed_version = self._packed_d_version = None
+        return super().train(mode)
 
     def _rulebook(self, x):
         """Look up / build the rulebook; returns (rulebook, out_indices, out_spatial_shape)."""
@@ -128,12 +147,20 @@ class SparseConvolution(SparseModule):
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
         rb, out_idx, out_shape = self._rulebook(input)
+        cur = torch.cuda.current_stream()
         ev = getattr(rb, "ready_event", None)
-        if ev is not None:                          # built on the prefetch stream: order this stream after it
-            torch.cuda.current_stream().wait_event(ev)
+        first_use = False
+        if ev is not None and getattr(rb, "joined_stream", None) != cur.cuda_stream:
+            cur.wait_event(ev)                      # built on the prefetch stream: order this stream after it ONCE
+            rb.joined_stream = cur.cuda_stream
+            first_use = True
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad)
         out = SparseConvTensor(feats, out_idx, out_shape, input.batch_size, input.grid, input.voxel_num,
                                input.indice_dict, input.benchmark, rb.n_out_dev)
+        if first_use:                               # first consumer of a prefetched unit: start the next unit
+            pf = input.indice_dict.get("__prefetcher__", None)
+            if pf is not None:
+                pf.advance()
         return out
 
 

@@ -7,25 +7,26 @@ from .. import ops
 
 
 OVERLAP_WGRAD = True
-# Opt-in (training loops that own their gradient buffers, e.g. bench.py with com_amd.dist.FlatGradBucket):
-# the weight / bias gradients are computed AND accumulated into the pre-allocated `.grad` on the side stream
-# and autograd gets None for them, so the whole wgrad chain runs as a second pipeline beside the
-# dgrad/BatchNorm chain.  The caller must call join_deferred_wgrad() after loss.backward().
-DEFERRED_WGRAD = False
+# Opt-in, needs DIRECT_GRAD: the join of layer i's weight-gradient kernels is postponed until WGRAD_JOIN_LAG
+# later conv backward nodes have been issued (the side stream is in order, so only the LAST event matters),
+# so the current stream never idles while wgrad(+reduce) of a layer outlasts its dgrad.  The inputs of the
+# pending kernels are kept alive by reference until their join.  The training loop must call
+# join_deferred_wgrad() after loss.backward() and before it reads any `.grad`.
+WGRAD_JOIN_LAG = 0
 # Opt-in for training loops whose parameters each receive exactly ONE gradient contribution per step and own
 # pre-allocated fp32 `.grad` buffers (bench.py: views of one flat bucket): the kernels then write dW / dbias /
 # dgamma / dbeta straight into `.grad` and autograd gets None for them -- no temporary, no AccumulateGrad add
 # kernel per parameter (79 tiny launches per step on the critical path of VoxelResBackBone8x).
 DIRECT_GRAD = False
 _SIDE = {}
+_PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not yet joined
 
 
 def join_deferred_wgrad():
     """Make the current stream wait for every side-stream weight-gradient kernel issued so far."""
-    cur = torch.cuda.current_stream()
-    key = (cur.device.type, cur.device.index)
-    if key in _SIDE:
-        cur.wait_stream(_SIDE[key])
+    if _PENDING:
+        torch.cuda.current_stream().wait_event(_PENDING[-1][0])
+        _PENDING.clear()
 
 
 class _NullCtx:
@@ -98,32 +99,27 @@ class SparseConvFunction(Function):
             side.wait_stream(cur)
         bias_p = ctx.bias_param
         weight_p = ctx.weight_param
-        deferred = (DEFERRED_WGRAD and side is not None and weight_p is not None and weight_p.grad is not None
-                    and (not ctx.has_bias or (bias_p is not None and bias_p.grad is not None)))
         direct_w = DIRECT_GRAD and weight_p is not None and weight_p.grad is not None \
             and weight_p.grad.dtype == torch.float32 and weight_p.grad.is_contiguous()
         direct_b = DIRECT_GRAD and bias_p is not None and bias_p.grad is not None \
             and bias_p.grad.dtype == torch.float32 and bias_p.grad.is_contiguous()
+        deferred = (WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not ctx.needs_input_grad[1])
+                    and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if ctx.needs_input_grad[1]:
                 dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol,
                                 out=weight_p.grad if direct_w else None)                 # [Cout, K, Cin] f32
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
-                if deferred and dw is not None:
-                    weight_p.grad.add_(dw)
-                    dw = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = ops.col_sum(dy16, n_dev=rb.n_out_dev, out=bias_p.grad if direct_b else None)
                 if direct_b:
                     db = None
-                elif deferred:
-                    bias_p.grad.add_(db)
-                    db = None
+            if deferred:
+                ev = torch.cuda.Event()
+                ev.record(side)
         if deferred:
-            # the side stream still reads these after this node returns: keep the allocator from recycling them
-            x.record_stream(side)
-            dy16.record_stream(side)
-            side = None                              # no join here: join_deferred_wgrad() after backward
+            _PENDING.append((ev, x, dy16))           # inputs stay alive until the lagged join below
+            side = None
         if ctx.needs_input_grad[0]:
             if ctx.cin_pad % 16 != 0:
                 raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
@@ -136,6 +132,9 @@ class SparseConvFunction(Function):
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev)
             dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
+        if deferred and len(_PENDING) > WGRAD_JOIN_LAG:
+            cur.wait_event(_PENDING[-1 - WGRAD_JOIN_LAG][0])
+            del _PENDING[:len(_PENDING) - WGRAD_JOIN_LAG]
         if side is not None:
             cur.wait_stream(side)                    # join: dW / dbias are consumed on the current stream
             for t in (dw, db):

@@ -34,3 +34,9 @@ big = sorted(gaps, reverse=True)[:8]
 for g, at in big:
     prev = max((r for r in step if r[ci['end']] <= at + 1), key=lambda r: r[ci['end']])
     print(f"   gap {g * 1e-3:.1f} us after {prev[ci[name]][:60]}")
+if len(sys.argv) > 2:  # dump the step's kernel sequence: queue, start offset (us), duration (us), short name
+    import re
+    with open(sys.argv[2], "w") as f:
+        for r in step:
+            nm = re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r[ci[name]])[:70]
+            f.write(f"{r[ci[qcol]] if qcol else 0} {1e-3 * (r[ci['start']] - t0):9.1f} {1e-3 * (r[ci['end']] - r[ci['start']]):8.1f} {nm}\n")
