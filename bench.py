@@ -223,8 +223,25 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
     bucket = cdist.FlatGradBucket(params)
-    opt = torch.optim.Adam(params, lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True, capturable=True)
+    # ... and so do the parameters: one fused Adam launch for the whole model, clipping = norm + scale of one tensor
+    flat_param = bucket.flatten_parameters()
+    opt = torch.optim.Adam([flat_param], lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True,
+                           capturable=True)
     loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
+
+    class ProjectionLoss(torch.autograd.Function):
+        """Stand-in for the dense head: loss = <spatial_features, fixed random tensor> (fp32 sum); its gradient
+        is that tensor times the upstream scalar -- one elementwise kernel, no autograd temporaries."""
+
+        @staticmethod
+        def forward(ctx, sf):
+            ctx.shape = sf.shape
+            return torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)
+
+        @staticmethod
+        def backward(ctx, g):
+            return (loss_w * g.to(loss_w.dtype)).view(ctx.shape)
+
     last = {}
 
     def fwd_bwd(pts, offs, ev=None):
@@ -240,7 +257,7 @@ def main():
         sf = model.map_to_bev_module(model.backbone_3d(model.vfe(bd2)))["spatial_features"]
         # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense
         # gradient; rocBLAS dot is not graph-capturable, hence mul + sum)
-        loss = torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)
+        loss = ProjectionLoss.apply(sf)
         if ev is not None: ev("backward")
         bucket.zero()
         loss.backward()
@@ -250,7 +267,7 @@ def main():
         return None
 
     def opt_step():
-        torch.nn.utils.clip_grad_norm_(params, 10.0)         # centerpoint.yaml:96 GRAD_NORM_CLIP
+        bucket.clip_grad_norm_(10.0)                         # centerpoint.yaml:96 GRAD_NORM_CLIP
         opt.step()
 
     def eager_step(i, ev=None):

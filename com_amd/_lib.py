@@ -41,6 +41,7 @@ PROTOTYPES = {
                                     _vp, _sz, _vp]),
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -52,8 +53,8 @@ PROTOTYPES = {
     "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
                             _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
-                             _vp]),
+    "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _sz, _vp]),
 }
 
 _lib = None

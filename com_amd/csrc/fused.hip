@@ -208,10 +208,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     }
 }
 
+// ReLU mask: from the saved output y when it is given; with y == nullptr (no residual was added in the forward)
+// from the sign of x * scale + shift recomputed exactly as bn_apply_kernel computed it.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ dy, const T *__restrict__ x,
                                                             const T *__restrict__ y, int n_cap,
                                                             const int32_t *n_dev, int c,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, int relu,
                                                             float *__restrict__ partial) {
@@ -220,12 +224,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
-    float mu[N], is[N];
+    float mu[N], is[N], sc[N], sh[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        mu[j] = mean[piece * N + j];
-        is[j] = invstd[piece * N + j];
+        const int ch = piece * N + j;
+        mu[j] = mean[ch];
+        is[j] = invstd[ch];
+        const float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+        sc[j] = g * is[j];
+        sh[j] = b - mu[j] * g * is[j];
     }
+    const bool mask_from_x = relu && y == nullptr;
     float acc[2][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
@@ -233,10 +242,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
         float g[N], xv[N], yv[N];
         Piece<T>::load(dy + e * N, g);
         Piece<T>::load(x + e * N, xv);
-        if (relu) Piece<T>::load(y + e * N, yv);
+        if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float dz = (relu && !(yv[j] > 0.0f)) ? 0.0f : g[j];
+            const float t = mask_from_x ? xv[j] * sc[j] + sh[j] : yv[j];
+            const float dz = (relu && !(t > 0.0f)) ? 0.0f : g[j];
             acc[0][j] += dz;
             acc[1][j] += dz * (xv[j] - mu[j]) * is[j];
         }
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const T *__restrict__ y, int n_cap,
                                                            const int32_t *n_dev, int c,
                                                            const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ invstd,
                                                            const float *__restrict__ dgamma,
@@ -272,14 +283,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     const int n = eff_rows(n_dev, n_cap);
     const size_t total = (size_t)n * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
-    float mu[N], is[N], gm[N], k1[N], k2[N];
+    float mu[N], is[N], gm[N], sh[N], k1[N], k2[N];
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
+    const bool mask_from_x = relu && y == nullptr;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         int ch = piece * N + j;
         mu[j] = mean[ch];
         is[j] = invstd[ch];
         gm[j] = (gamma ? gamma[ch] : 1.0f) * is[j];
+        sh[j] = (beta ? beta[ch] : 0.0f) - mu[j] * (gamma ? gamma[ch] : 1.0f) * is[j];
         k1[j] = training ? dbeta[ch] * inv_n : 0.0f;
         k2[j] = training ? dgamma[ch] * inv_n : 0.0f;
     }
@@ -287,10 +300,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         float g[N], xv[N], yv[N], o[N];
         Piece<T>::load(dy + e * N, g);
         Piece<T>::load(x + e * N, xv);
-        if (relu) Piece<T>::load(y + e * N, yv);
+        if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float dz = (relu && !(yv[j] > 0.0f)) ? 0.0f : g[j];
+            const float t = mask_from_x ? xv[j] * gm[j] + sh[j] : yv[j];
+            float dz = (relu && !(t > 0.0f)) ? 0.0f : g[j];
             g[j] = dz;
             float xhat = (xv[j] - mu[j]) * is[j];
             o[j] = gm[j] * (dz - k1[j] - xhat * k2[j]);
@@ -412,7 +426,8 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, c
 }
 
 extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
-                               const float *gamma, const float *save_mean, const float *save_invstd,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd,
                                int relu, int training, void *dx, void *dresidual, float *dgamma,
                                float *dbeta, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
                                void *stream) {
@@ -420,7 +435,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
     if (!save_mean || !save_invstd || !dgamma || !dbeta) return PCD_ERR_INVALID_ARG;
-    if (n > 0 && (!dy || !x || !dx || (relu && !y))) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (!dy || !x || !dx)) return PCD_ERR_INVALID_ARG;
     BnWs L;
     if (!bn_ws(workspace, workspace_bytes, c, L)) return PCD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -430,22 +445,22 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (dtype == PCD_F32) {
         bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
-                                                          (const float *)y, n, n_dev, c, save_mean,
+                                                          (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                                                           save_invstd, relu, L.partial);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
-                (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, save_mean,
+                (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                 save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
     } else {
         typedef unsigned short B;
         bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
-                                                      save_mean, save_invstd, relu, L.partial);
+                                                      gamma, beta, save_mean, save_invstd, relu, L.partial);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
-                                                         gamma, save_mean, save_invstd, dgamma, dbeta, relu,
-                                                         training, (B *)dx, (B *)dresidual);
+                                                         gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                                                         relu, training, (B *)dx, (B *)dresidual);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

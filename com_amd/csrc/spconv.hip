@@ -43,11 +43,8 @@ static int pow2_ge8(int c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int K, int cin,
-                                                          int cout, int mode, int cshift, int NB,
-                                                          size_t total, unsigned short *out) {
-    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+__device__ __forceinline__ void pack_one(const float *__restrict__ w, int K, int cin, int cout, int mode,
+                                         int cshift, int NB, size_t e, unsigned short *out) {
     int j = e & 7;
     int lane = (e >> 3) & 63;
     size_t t = e >> 9;
@@ -66,6 +63,38 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         }
     }
     out[e] = f32_to_bf16_bits(v);
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int K, int cin,
+                                                          int cout, int mode, int cshift, int NB,
+                                                          size_t total, unsigned short *out) {
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    pack_one(w, K, cin, cout, mode, cshift, NB, e, out);
+}
+
+// One launch for a whole list of weights.  table[i] = {weight ptr, packed ptr, kvol, cin, cout, mode,
+// first block of entry i, 0}; every entry owns whole 256-thread blocks, found by a binary search over the
+// first-block column.
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long long *__restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long *row = table + (size_t)lo * 8;
+    const float *w = (const float *)row[0];
+    unsigned short *out = (unsigned short *)row[1];
+    const int K = (int)row[2], cin = (int)row[3], cout = (int)row[4], mode = (int)row[5];
+    int cc = 8;
+    while (cc < (mode == 0 ? cin : cout)) cc <<= 1;
+    int cshift = 0;
+    while ((1 << cshift) < cc) ++cshift;
+    const int NB = ((mode == 0 ? cout : cin) + 15) / 16;
+    const size_t total = (size_t)((K * cc + 31) / 32) * NB * 512;
+    const size_t e = ((size_t)blockIdx.x - (size_t)row[6]) * 256 + threadIdx.x;
+    if (e >= total) return;
+    pack_one(w, K, cin, cout, mode, cshift, NB, e, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -601,6 +630,15 @@ extern "C" int pcd_pack_weight(const float *weight, int kvol, int cin, int cout,
     size_t total = (size_t)nsteps * NB * 64 * 8;
     pack_weight_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         weight, kvol, cin, cout, mode, log2_exact(cc), NB, total, (unsigned short *)packed);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || total_blocks < 0 || (n > 0 && !table)) return PCD_ERR_INVALID_ARG;
+    if (n == 0 || total_blocks == 0) return PCD_OK;
+    pack_weights_batched_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const long long *)table, n);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -42,6 +42,28 @@ class FlatGradBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
+    def flatten_parameters(self):
+        """Also move the parameters themselves into ONE flat fp32 buffer (each `p.data` becomes a view of it) and
+        return it as a single nn.Parameter whose `.grad` is the flat gradient buffer: the optimizer then updates
+        the whole model with one fused kernel and gradient clipping is a norm + scale of one tensor."""
+        flat = torch.empty_like(self.flat)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view_as(p)
+                off += n
+        self.flat_param = torch.nn.Parameter(flat, requires_grad=True)
+        self.flat_param.grad = self.flat
+        return self.flat_param
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ semantics on the flat buffer (L2 norm, coefficient clamped to 1)."""
+        norm = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
+
     def zero(self):
         self.flat.zero_()
 

@@ -144,9 +144,31 @@ class _BackboneBase(nn.Module):
         pack_side = Fsp._side_stream(dev)                      # the wgrad stream is idle during the forward
         pack_side.wait_stream(cur)
         with torch.cuda.stream(pack_side):
+            self._pack_all()
+        cur.wait_stream(pack_side)
+
+    def _pack_all(self):
+        """All forward (+ dgrad) weight packs of the backbone in one launch."""
+        from .. import ops
+        todo = []
+        for conv in self._conv_list:
+            todo.append((conv, 0))
+            if self.training and conv.in_channels >= 16:
+                todo.append((conv, 1))
+        wm = [(c.weight.detach(), m) for c, m in todo]
+        if not all(w.dtype == torch.float32 and w.is_contiguous() for w, _ in wm):
             for conv in self._conv_list:
                 conv.prepack(dgrad=self.training)
-        cur.wait_stream(pack_side)
+            return
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or not plan.valid_for(wm):
+            plan = self._pack_plan = ops.PackPlan(wm)
+        packed = plan.run()
+        got = {}
+        for (conv, mode), buf in zip(todo, packed):
+            got.setdefault(conv, [None, None])[mode] = buf
+        for conv, (f, d) in got.items():
+            conv.adopt_packs(f, d)
 
     def _run(self, batch_dict):
         self._bump_bn_counters()

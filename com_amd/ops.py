@@ -321,6 +321,40 @@ def pack_weight(weight, mode, out=None):
     return packed
 
 
+class PackPlan:
+    """Re-pack a fixed list of (weight, mode) pairs with ONE kernel launch per call (pcd_pack_weights_batched).
+    The packed buffers and the device-side descriptor table are allocated once; `valid_for` tells whether the
+    weights still live at the addresses the table was built with."""
+
+    def __init__(self, weights_modes):
+        lib = L.lib()
+        self.keys = tuple((w.data_ptr(), m) for w, m in weights_modes)
+        self.packed = []
+        rows, first = [], 0
+        for w, mode in weights_modes:
+            _require_cuda(w)
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            cout, cin = w.shape[0], w.shape[-1]
+            K = w.numel() // (cout * cin)
+            nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
+            buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+            self.packed.append(buf)
+            rows.append([w.data_ptr(), buf.data_ptr(), K, cin, cout, mode, first, 0])
+            first += (nbytes // 2 + 255) // 256
+        self.total_blocks = first
+        self.n = len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(weights_modes[0][0].device) if rows else None
+
+    def valid_for(self, weights_modes):
+        return self.keys == tuple((w.data_ptr(), m) for w, m in weights_modes)
+
+    def run(self):
+        if self.n:
+            L.check(L.lib().pcd_pack_weights_batched(L.ptr(self.table), self.n, self.total_blocks, L.stream_ptr()),
+                    "pcd_pack_weights_batched")
+        return self.packed
+
+
 def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None):
     """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]  (output-stationary; forward and dgrad)."""
     _require_cuda(x, packed_w, nbr)
@@ -436,8 +470,12 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
 
 
 def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None,
-                dgamma_out=None, dbeta_out=None):
+                dgamma_out=None, dbeta_out=None, beta=None):
+    """y may be None (relu, forward without residual, training): the ReLU mask is recomputed from x and the
+    affine parameters (`beta` required then) instead of being read from the saved output."""
     _require_cuda(dy, x)
+    if relu and y is None and (beta is None or not training):
+        raise ValueError("bn_backward: y=None needs beta and training statistics")
     dy = dy.contiguous()
     n, c = x.shape
     dev = x.device
@@ -447,7 +485,7 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     dgamma = dgamma_out if _usable_out(dgamma_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
     dbeta = dbeta_out if _usable_out(dbeta_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
-    L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma),
+    L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
                                 L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
                                 L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev), L.ptr(ws), ws.numel(),
                                 L.stream_ptr()), "pcd_bn_backward")

@@ -101,6 +101,12 @@ class SparseConvolution(SparseModule):
             self._packed_dgrad()
             self._fresh_d = True
 
+    def adopt_packs(self, fwd, dgrad=None):
+        """Take freshly packed copies made elsewhere (ops.PackPlan: one launch for a whole backbone)."""
+        self._packed, self._packed_version, self._fresh_f = fwd, self._key(), True
+        if dgrad is not None:
+            self._packed_d, self._packed_d_version, self._fresh_d = dgrad, self._key(), True
+
     def train(self, mode=True):
         if mode != self.training:
             self._packed_version = self._packed_d_version = None

@@ -196,12 +196,14 @@ class FusedBNFunction(Function):
         ctx.relu, ctx.training, ctx.has_res = relu, training, residual is not None
         ctx.n_dev = n_dev
         ctx.bn = bn
-        ctx.save_for_backward(xc, y, g, save_mean, save_invstd)
+        # without a residual the ReLU mask is recomputed from x in the backward (one [n][c] read less per pass)
+        ctx.mask_from_x = bool(relu and residual is None and training and b is not None)
+        ctx.save_for_backward(xc, None if ctx.mask_from_x else y, g, b, save_mean, save_invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, g, save_mean, save_invstd = ctx.saved_tensors
+        x, y, g, b, save_mean, save_invstd = ctx.saved_tensors
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         bn = ctx.bn
@@ -212,7 +214,8 @@ class FusedBNFunction(Function):
         dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
                                                   ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev,
                                                   dgamma_out=gw if direct else None,
-                                                  dbeta_out=gb if direct else None)
+                                                  dbeta_out=gb if direct else None,
+                                                  beta=b if ctx.mask_from_x else None)
         if direct:
             dgamma = dbeta = None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,

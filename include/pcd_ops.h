@@ -159,6 +159,12 @@ int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *
 size_t pcd_packed_weight_bytes(int kvol, int cin, int cout, int mode);
 int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode, void *packed,
                     void *stream);
+/* The same conversion for a whole list of weights in ONE launch (a backbone re-packs ~40 small weights after
+ * every optimizer step).  `table` is DEVICE memory, int64 [n][8], row i =
+ *   { weight pointer, packed pointer, kvol, cin, cout, mode, first_block_i, 0 },
+ * first_block_0 = 0, first_block_{i+1} = first_block_i + ceil(pcd_packed_weight_bytes(..)/2 / 256);
+ * total_blocks = first_block_n.  The table can be built once and reused while the pointers stay valid. */
+int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 
 /* y[o] = bias + sum_k x[nbr[k'][o]] @ W[k],  k' = flip_k ? K-1-k : k.
  * Output-stationary gather-GEMM (no atomics, deterministic).  Used for
@@ -211,6 +217,9 @@ int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32
  *             training == 0: running statistics.
  *   backward: dz = relu ? dy * (y > 0) : dy; dresidual = dz (may be NULL); dgamma, dbeta [c];
  *             dx = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n)   (training) or gamma*invstd*dz (eval).
+ *             y may be NULL when relu != 0 and the forward had NO residual: the mask is then recomputed from
+ *             x, gamma, beta (required in that case), save_mean, save_invstd exactly as the forward computed
+ *             it, which saves one [n][c] read in each of the two backward passes.
  * c % 8 == 0 (bf16) / c % 4 == 0 (f32), c/piece a power of two <= 256.  Deterministic (no atomics).
  * ============================================================================================ */
 size_t pcd_bn_workspace_bytes(int c);
@@ -222,8 +231,8 @@ int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
                    float *running_var, int relu, void *y, float *save_mean, float *save_invstd,
                    const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
-                    const float *gamma, const float *save_mean, const float *save_invstd, int relu,
-                    int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                    const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                    int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

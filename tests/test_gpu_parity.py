@@ -322,6 +322,28 @@ def test_sparse_conv_module_autograd_and_inverse(golden):
 
 
 @pytest.mark.gpu
+def test_pack_weights_batched_matches_single():
+    """pcd_pack_weights_batched (one launch for a list of weights) == pcd_pack_weight per weight, bit for bit."""
+    ops = _ops()
+    torch.manual_seed(3)
+    shapes = [(16, 27, 5), (16, 27, 16), (32, 27, 16), (64, 27, 64), (128, 3, 128), (24, 27, 40)]
+    wm = []
+    for cout, k, cin in shapes:
+        w = torch.randn(cout, k, cin, device=DEV)
+        wm.append((w, 0))
+        if cin >= 16:
+            wm.append((w, 1))
+    plan = ops.PackPlan(wm)
+    assert plan.valid_for(wm)
+    for _ in range(2):                                         # second run: table and buffers are reused
+        got = plan.run()
+        for (w, mode), buf in zip(wm, got):
+            assert torch.equal(buf.view(torch.int16), ops.pack_weight(w, mode).view(torch.int16))
+        for w, _ in wm:
+            w.mul_(1.5)
+
+
+@pytest.mark.gpu
 def test_weight_pack_follows_fused_optimizer_updates(golden):
     """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping `weight._version`; the packed
     (MFMA-order) weight copies must still follow every update in training mode, and a train()->eval()
