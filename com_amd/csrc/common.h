@@ -215,25 +215,42 @@ static inline int scan_exclusive(F f, int n, int *out, int *block_sums, int *tot
     return PCD_OK;
 }
 
-// Row-wise exclusive scan of a small count matrix cnt[rows][cols] (one block per row), totals[row].
+// Row-wise exclusive scan of a count matrix cnt[rows][cols] (one block per row, 8 consecutive elements per
+// thread and iteration so that 8 loads are in flight), totals[row]; optionally also
+// totals_out[flip ? rows - 1 - row : row] (spconv's indice_pair_num order).
 static __global__ __launch_bounds__(256) void scan_rows_kernel(const int *cnt, int *off, int cols,
-                                                        int *totals) {
+                                                        int *totals, int *totals_out = nullptr,
+                                                        int flip = 0) {
     __shared__ int lds[4];
     __shared__ int carry_s;
     const int *c = cnt + (size_t)blockIdx.x * cols;
     int *o = off + (size_t)blockIdx.x * cols;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < cols; base += 256) {
-        int i = base + threadIdx.x;
-        int v = (i < cols) ? c[i] : 0;
+    for (int base = 0; base < cols; base += 2048) {
+        const int i0 = base + threadIdx.x * 8;
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (i0 + j < cols) ? c[i0 + j] : 0;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int t = v[j];
+            v[j] = sum;
+            sum += t;
+        }
         int total;
-        int ex = block_exclusive_scan(v, lds, total);
+        int ex = block_exclusive_scan(sum, lds, total);
         int carry = carry_s;
-        if (i < cols) o[i] = carry + ex;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j < cols) o[i0 + j] = carry + ex + v[j];
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && totals) totals[blockIdx.x] = carry_s;
+    if (threadIdx.x == 0) {
+        if (totals) totals[blockIdx.x] = carry_s;
+        if (totals_out) totals_out[flip ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x] = carry_s;
+    }
 }

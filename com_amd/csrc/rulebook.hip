@@ -98,8 +98,53 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4 *__restrict_
     }
 }
 
+// SubM rulebook of a level whose rows ARE the bitmap ranks of the strided conv that created it (row id = rank of
+// the linear key): a neighbour lookup is one bitmap word + one prefix word, both shared by the x-neighbours and
+// by the neighbouring rows of the (key-sorted) wave -- no hash table is built or probed.
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__ idx, int n,
+                                                        const int32_t *n_dev, ConvGeom G,
+                                                        const u32 *__restrict__ bitmap,
+                                                        const int *__restrict__ prefix,
+                                                        int32_t *__restrict__ nbr, int *__restrict__ wave_cnt,
+                                                        int nwaves) {
+    constexpr int K = KD * KH * KW;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const bool live = o < eff_rows(n_dev, n);
+    const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
+    const int wave = o >> 6;
+    u32 bits[K];
+    int pre[K];
+    int sh[K];  // bit position, or -1: outside the grid / dead lane
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int a = k / (KH * KW), bq = (k / KW) % KH, cq = k % KW;
+        const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh, x = c.w + (cq - KW / 2) * G.dw;
+        const bool inb = live && z >= 0 && z < G.D && y >= 0 && y < G.H && x >= 0 && x < G.W;
+        const u32 key = inb ? lin_key(c.x, z, y, x, G.D, G.H, G.W) : 0u;
+        sh[k] = inb ? (int)(key & 31) : -1;
+        bits[k] = bitmap[key >> 5];   // unconditional (word 0 for dead lanes): independent loads in flight
+        pre[k] = prefix[key >> 5];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int r = -1;
+        if (sh[k] >= 0 && ((bits[k] >> sh[k]) & 1u)) {
+            r = pre[k] + __popc(bits[k] & ((1u << sh[k]) - 1u));
+            if (r >= n) r = -1;  // beyond the row capacity: that row does not exist
+        }
+        if (2 * k + 1 == K && live) r = o;
+        if (live) nbr[(size_t)k * n + o] = r;
+        if (wave_cnt) {
+            u64 m = __ballot(r >= 0);
+            if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+        }
+    }
+}
+
 // pairs[k] = {(i, tbl[kr][i])} for i ascending, kr = flip ? K-1-k : k  (tbl is an input-stationary
 // view: for SubM the symmetric row of the output-stationary table).
+template <int KT>   // KT > 0: compile-time K (unrolled: all table loads of a thread in flight); 0: runtime K
 __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t *__restrict__ tbl, int n,
                                                          const int32_t *n_dev, int K, int flip,
                                                          const int *__restrict__ wave_off, int nwaves,
@@ -107,6 +152,26 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t *__restri
     int i = blockIdx.x * 256 + threadIdx.x;
     int wave = i >> 6;
     const int nn = eff_rows(n_dev, n);
+    if (KT > 0) {
+        int o[KT > 0 ? KT : 1];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            int kr = flip ? KT - 1 - k : k;
+            o[k] = (i < nn) ? tbl[(size_t)kr * n + i] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            int kr = flip ? KT - 1 - k : k;
+            int tot;
+            int r = wave_rank(o[k] >= 0, tot);
+            if (o[k] >= 0) {
+                int pos = wave_off[(size_t)kr * nwaves + wave] + r;
+                pairs[((size_t)k * 2 + 0) * n + pos] = i;
+                pairs[((size_t)k * 2 + 1) * n + pos] = o[k];
+            }
+        }
+        return;
+    }
     for (int k = 0; k < K; ++k) {
         int kr = flip ? K - 1 - k : k;
         int o = (i < nn) ? tbl[(size_t)kr * n + i] : -1;
@@ -120,9 +185,13 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t *__restri
     }
 }
 
-__global__ void pair_num_kernel(const int *totals, int K, int flip, int32_t *pair_num) {
-    int k = threadIdx.x;
-    if (k < K) pair_num[k] = totals[flip ? K - 1 - k : k];
+static void launch_pairs_fill(const int32_t *tbl, int n, const int32_t *n_dev, int K, int flip,
+                              const int *wave_off, int nwaves, int32_t *pairs, hipStream_t st) {
+    int nb = pcd_div_up(n, 256);
+    if (K == 27)
+        pairs_fill_kernel<27><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_off, nwaves, pairs);
+    else
+        pairs_fill_kernel<0><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_off, nwaves, pairs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -132,28 +201,66 @@ __device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int b
     int ty = c.z + G.ph - bq * G.dh;
     int tx = c.w + G.pw - cq * G.dw;
     if (tz < 0 || ty < 0 || tx < 0) return false;
-    int oz = tz / G.sd, oy = ty / G.sh, ox = tx / G.sw;
+    int oz = G.sd == 2 ? (tz >> 1) : (G.sd == 1 ? tz : tz / G.sd);
+    int oy = G.sh == 2 ? (ty >> 1) : (G.sh == 1 ? ty : ty / G.sh);
+    int ox = G.sw == 2 ? (tx >> 1) : (G.sw == 1 ? tx : tx / G.sw);
     if (oz * G.sd != tz || oy * G.sh != ty || ox * G.sw != tx) return false;
     if (oz >= G.Do || oy >= G.Ho || ox >= G.Wo) return false;
     key = lin_key(c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
     return true;
 }
 
+// t / s for t >= 0 with the strides that occur (1, 2) as shifts
+__device__ __forceinline__ int div_stride(int t, int s) { return s == 1 ? t : (s == 2 ? (t >> 1) : t / s); }
+
+// Output coordinate along one axis reached from input coordinate c through kernel index k, or -1.
+__device__ __forceinline__ int axis_out(int c, int p, int d, int s, int k, int n_out) {
+    int t = c + p - k * d;
+    if (t < 0) return -1;
+    int o = div_stride(t, s);
+    return (o * s == t && o < n_out) ? o : -1;
+}
+
 __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__ idx, int n,
-                                                        const int32_t *n_dev, ConvGeom G, u32 *bitmap) {
+                                                        const int32_t *n_dev, ConvGeom G,
+                                                        unsigned char *__restrict__ bytemap) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= eff_rows(n_dev, n)) return;
     int4 c = idx[i];
-    for (int a = 0; a < G.kd; ++a)
-        for (int bq = 0; bq < G.kh; ++bq)
+    // validity is tested once per axis level (kd + nz*kh + nz*ny*kw tests instead of 3*K)
+    for (int a = 0; a < G.kd; ++a) {
+        const int oz = axis_out(c.y, G.pd, G.dd, G.sd, a, G.Do);
+        if (oz < 0) continue;
+        for (int bq = 0; bq < G.kh; ++bq) {
+            const int oy = axis_out(c.z, G.ph, G.dh, G.sh, bq, G.Ho);
+            if (oy < 0) continue;
             for (int cq = 0; cq < G.kw; ++cq) {
-                u32 key;
-                if (!out_cell(G, c, a, bq, cq, key)) continue;
-                u32 bit = 1u << (key & 31);
-                u32 *w = bitmap + (key >> 5);
-                if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
-                    atomicOr(w, bit);
+                const int ox = axis_out(c.w, G.pw, G.dw, G.sw, cq, G.Wo);
+                if (ox < 0) continue;
+                // one BYTE per output cell: plain stores of the same value need no atomics (about 8 inputs mark
+                // each cell; the 32-bit-word bitmap this replaced cost one memory-side atomic per mark)
+                bytemap[lin_key(c.x, oz, oy, ox, G.Do, G.Ho, G.Wo)] = 1;
             }
+        }
+    }
+}
+
+// bytemap (32 cells = 32 bytes per thread, two 16-byte loads) -> occupancy bitmap words
+__global__ __launch_bounds__(256) void conv_pack_kernel(const uint4 *__restrict__ bytemap, size_t nwords,
+                                                        u32 *__restrict__ bitmap) {
+    size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    uint4 lo = bytemap[2 * w], hi = bytemap[2 * w + 1];
+    const u32 v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32 bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // bytes are 0 / 1: gather bit 0 of each byte into 4 consecutive bits
+        u32 t = v[j] & 0x01010101u;
+        t = (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
+        bits |= t << (4 * j);
+    }
+    bitmap[w] = bits;
 }
 
 struct PopcWord {
@@ -239,6 +346,7 @@ static u32 table_capacity(int n) {
 }
 
 struct ConvWs {
+    unsigned char *bytemap;
     u32 *bitmap;
     int *prefix;
     int *bsums;
@@ -258,6 +366,7 @@ static int conv_ws_layout(void *workspace, size_t bytes, int n, int batch, const
     WsCarver ws(workspace, bytes);
     L.bitmap = ws.take<u32>(L.nwords);
     L.prefix = ws.take<int>(L.nwords + 1);
+    L.bytemap = ws.take<unsigned char>(L.nwords * 32);
     L.bsums = ws.take<int>(pcd_div_up((int)L.nwords, 256) + 2);
     L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
     L.wave_off = ws.take<int>((size_t)G.K * L.nwaves);
@@ -321,12 +430,74 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
     subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, table, tcap - 1, nbr,
                                           pairs ? wave_cnt : nullptr, nwaves);
     if (pairs) {
-        scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals);
+        scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
-        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr, n, n_dev, G.K, 1, wave_off, nwaves, pairs);
-        pair_num_kernel<<<1, 512, 0, st>>>(totals, G.K, 1, pair_num);
+        launch_pairs_fill(nbr, n, n_dev, G.K, 1, wave_off, nwaves, pairs, st);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_rulebook_subm_ranked_workspace_bytes(int n, int kvol) {
+    if (n < 0 || kvol <= 0) return 0;
+    int nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    return 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) + ws_piece(kvol, sizeof(int));
+}
+
+extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
+                                        const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                                        const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                                        int pad_pairs, const int32_t *n_dev, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+    ConvGeom G;
+    int rc = make_geom(shape_host, ksize_host, one, zero, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    if (G.kd != 3 || G.kh != 3 || G.kw != 3) return PCD_ERR_UNSUPPORTED;  // use pcd_rulebook_subm
+    if ((double)batch * G.D * G.H * G.W >= 4294967295.0) return PCD_ERR_KEYSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (pair_num) pcd_fill(pair_num, 0, G.K * sizeof(int32_t), st);
+        return PCD_OK;
+    }
+    if (!indices || !nbr || !bitmap || !prefix) return PCD_ERR_INVALID_ARG;
+    WsCarver ws(workspace, workspace_bytes);
+    int nwaves = pcd_div_up(n, 64);
+    int *wave_cnt = ws.take<int>((size_t)G.K * nwaves);
+    int *wave_off = ws.take<int>((size_t)G.K * nwaves);
+    int *totals = ws.take<int>(G.K);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    int nb = pcd_div_up(n, 256);
+    subm_rank_kernel<3, 3, 3><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
+                                                 pairs ? wave_cnt : nullptr, nwaves);
+    if (pairs) {
+        scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        launch_pairs_fill(nbr, n, n_dev, G.K, 1, wave_off, nwaves, pairs, st);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                                             const int *stride_host, const int *pad_host, const int *dil_host,
+                                             size_t *bitmap_offset, size_t *prefix_offset, size_t *nwords) {
+    ConvGeom G;
+    if (n < 0 || batch <= 0 || !in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host ||
+        !bitmap_offset || !prefix_offset || !nwords)
+        return PCD_ERR_INVALID_ARG;
+    int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    ConvWs L;
+    size_t need = 0;
+    conv_ws_layout(nullptr, 0, n, batch, G, L, &need);
+    // conv_ws_layout takes the bitmap first, then the prefix array (each piece 256-byte aligned)
+    *bitmap_offset = 0;
+    *prefix_offset = ws_piece(L.nwords, sizeof(u32));
+    *nwords = L.nwords;
     return PCD_OK;
 }
 
@@ -361,9 +532,11 @@ extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
     if (rc != PCD_OK) return rc;
     if (n > 0 && !indices) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    pcd_fill(L.bitmap, 0, L.nwords * sizeof(u32), st);
+    pcd_fill(L.bytemap, 0, L.nwords * 32, st);
     if (n > 0)
-        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap);
+        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap);
+    conv_pack_kernel<<<(unsigned)((L.nwords + 255) / 256), 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords,
+                                                                        L.bitmap);
     PopcWord pw{L.bitmap};
     rc = scan_exclusive(pw, (int)L.nwords, L.prefix, L.bsums, n_out_dev, st);
     if (rc != PCD_OK) return rc;
@@ -404,10 +577,9 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
     conv_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix, n_out,
                                          nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr, L.nwaves);
     if (pairs) {
-        scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals);
+        scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals, pair_num, 0);
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
-        pairs_fill_kernel<<<nb, 256, 0, st>>>(nbr_in, n, n_dev, G.K, 0, L.wave_off, L.nwaves, pairs);
-        pair_num_kernel<<<1, 512, 0, st>>>(L.totals, G.K, 0, pair_num);
+        launch_pairs_fill(nbr_in, n, n_dev, G.K, 0, L.wave_off, L.nwaves, pairs, st);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

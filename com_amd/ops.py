@@ -218,6 +218,7 @@ class Rulebook:
         self.out_indices = out_indices
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+        self.rank = None          # RankMap of the output level (strided builds only)
 
     def inverse(self):
         """Rulebook of SparseInverseConv3d sharing this indice_key."""
@@ -244,8 +245,22 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
     return [int(v) for v in out]
 
 
+class RankMap:
+    """Coordinate -> row map of the level a strided rulebook build produced: occupancy bitmap of the output grid
+    + exclusive popcount prefix (row id = rank of the linear key).  Views into the build's workspace, which this
+    object keeps alive.  `indices` is the out_indices tensor the ranks refer to."""
+
+    def __init__(self, ws, bitmap, prefix, indices, shape):
+        self.ws, self.bitmap, self.prefix, self.indices, self.shape = ws, bitmap, prefix, indices, list(shape)
+
+    def matches(self, indices, shape, ks):
+        return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
+
+
 def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False,
-                  n_dev=None):
+                  n_dev=None, rank=None):
+    """`rank`: the RankMap of the strided build whose out_indices these `indices` are -- the rulebook is then
+    derived from the bitmap ranks (no hash table); results are identical."""
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -253,13 +268,20 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     ks, dl, shp = _triple(ksize), _triple(dilation), _triple(spatial_shape)
     K = ks[0] * ks[1] * ks[2]
     lib = L.lib()
-    ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
     nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
     pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
-    L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
-                                  L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
-                                  L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
+    if rank is not None and rank.matches(indices, shp, ks):
+        ws = _ws(lib.pcd_rulebook_subm_ranked_workspace_bytes(n, K), dev)
+        L.check(lib.pcd_rulebook_subm_ranked(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                                             L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
+                                             L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
+                                             L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
+    else:
+        ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
+        L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                                      L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
+                                      L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
     return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
                     [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
 
@@ -300,8 +322,17 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
                                        L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
                                        int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "pcd_rulebook_conv_fill")
-    return Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
-                    pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
+    rb = Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
+                  pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
+    # the build's bitmap + prefix stay valid as long as `ws` lives: a SubM conv on out_indices can rank with them
+    import ctypes
+    boff, poff, nwords = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    L.check(lib.pcd_rulebook_conv_rank_layout(n, batch_size, *args, ctypes.byref(boff), ctypes.byref(poff),
+                                              ctypes.byref(nwords)), "pcd_rulebook_conv_rank_layout")
+    nw = int(nwords.value)
+    rb.rank = RankMap(ws, ws[boff.value:boff.value + 4 * nw].view(torch.int32),
+                      ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape)
+    return rb
 
 
 # ---------------------------------------------------------------------------------------------

@@ -135,8 +135,10 @@ class SparseConvolution(SparseModule):
             if hit is not None and hit[1] is x.indices:
                 rb = hit[0]
             else:
+                # rows created by a strided conv of this chain are its bitmap ranks: no hash table needed
+                rank = x.indice_dict.get(("__rank__", x.indices.data_ptr()), None)
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
-                                       self.dilation, n_dev=x.num_rows)
+                                       self.dilation, n_dev=x.num_rows, rank=rank)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:
@@ -144,6 +146,8 @@ class SparseConvolution(SparseModule):
                                    self.padding, self.dilation, n_dev=x.num_rows,
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)))
             out_idx, out_shape = rb.out_indices, rb.out_shape
+            if rb.rank is not None:
+                x.indice_dict[("__rank__", out_idx.data_ptr())] = rb.rank
         if self.indice_key is not None:
             # spconv stores (.., indice_pairs, indice_pair_num, spatial_shape) by key; for inverse convs
             # we also remember the INPUT side

@@ -146,6 +146,25 @@ int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *
                            int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The rank structure the strided build leaves in its workspace is exactly a coordinate -> row map of the OUTPUT
+ * level (row id = rank of the linear key): the SubM rulebook of that level (the 'subm2..4' keys that follow
+ * every strided conv of spconv_backbone.py:205-229) can use it instead of building and probing a hash table.
+ *   pcd_rulebook_conv_rank_layout: byte offsets of the occupancy bitmap (u32 [nwords]) and of its exclusive
+ *       popcount prefix (i32 [nwords]) inside a workspace of pcd_rulebook_conv_workspace_bytes(same arguments);
+ *       valid after pcd_rulebook_conv_count, for as long as the caller keeps that workspace untouched.
+ *   pcd_rulebook_subm_ranked: same outputs (bit for bit) as pcd_rulebook_subm for indices == the out_indices of
+ *       that strided build, shape_host == its output shape; 3x3x3 kernels only (PCD_ERR_UNSUPPORTED otherwise).
+ *       Ranks >= n (rows dropped by a static capacity) count as missing neighbours. */
+int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                                  const int *stride_host, const int *pad_host, const int *dil_host,
+                                  size_t *bitmap_offset, size_t *prefix_offset, size_t *nwords);
+size_t pcd_rulebook_subm_ranked_workspace_bytes(int n, int kvol);
+int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
+                             const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                             const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                             int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* ============================================================================================
  * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
  *

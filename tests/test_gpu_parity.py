@@ -160,6 +160,14 @@ def test_rulebooks_waymo_chain_bit_exact():
         _check_subm(idx, 1, shape)
         rb, rb_o = _check_conv(idx, 1, shape, geo)
         assert rb.out_shape == es                                  # spconv_backbone.py:89-112 shape comments
+        if es[0] >= 3:
+            # SubM rulebook of the new level derived from the strided build's bitmap ranks (no hash table)
+            rb_r = _ops().rulebook_subm(rb.out_indices, 1, es, pad_pairs=True, rank=rb.rank)
+            rb_so = O.rulebook_subm(rb_o["out_indices"], tuple(es))
+            assert rb.rank.matches(rb.out_indices, es, [3, 3, 3])
+            np.testing.assert_array_equal(_cpu(rb_r.nbr_out), rb_so["nbr_out"])
+            np.testing.assert_array_equal(_cpu(rb_r.pair_num), rb_so["pair_num"])
+            np.testing.assert_array_equal(_cpu(rb_r.pairs), rb_so["pairs"])
         idx, shape = rb_o["out_indices"], tuple(es)
 
 

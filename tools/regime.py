@@ -1,0 +1,56 @@
+"""Bandwidth-regime measurements asked for by SURVEY.md section 8(d): the rulebook builds (and the whole
+forward+backward step) at B = 4 (reference batch) and B = 32 frames per GPU, with the algorithmic bytes of
+section 8(d) (rulebook: 16*N_in + 8*P, + 16*N_out for strided convs) over the measured time vs 8 TB/s.
+Usage: python tools/regime.py [B ...]   -> one JSON line per batch size."""
+import json, sys, time, torch
+sys.path.insert(0, '.')
+from com_amd import ops, hotpath
+from com_amd.utils import synth
+dev = 'cuda'
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        out = fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = fn()
+    e1.record(); torch.cuda.synchronize()
+    return out, e0.elapsed_time(e1) / reps * 1e-3
+
+
+for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
+    frames = [synth.synth_cloud(f) for f in range(B)]
+    pts, offs = hotpath.collate_points(frames, dev)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
+                            num_features=5, want_voxels=False)
+    idx, shape = res['coords'], [41, 1504, 1504]
+    rows = []
+    tot_bytes = tot_t = 0.0
+    rank = None
+    geos = [None, (3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)]
+    for lvl, geo in enumerate(geos):
+        if geo is not None:
+            n_in = idx.shape[0]
+            rbc, t = timed(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2]))
+            P = int(rbc.pair_num.sum())
+            by = 16 * n_in + 8 * P + 16 * rbc.out_indices.shape[0]
+            rows.append(dict(kind="strided", level=lvl + 1, n_in=n_in, n_out=int(rbc.out_indices.shape[0]), pairs=P,
+                             us=round(t * 1e6, 1), alg_MB=round(by / 1e6, 1), GBps=round(by / t / 1e9, 1)))
+            tot_bytes += by; tot_t += t
+            idx, shape, rank = rbc.out_indices, rbc.out_shape, rbc.rank
+        if lvl < 4:
+            n = idx.shape[0]
+            rb, t = timed(lambda: ops.rulebook_subm(idx, B, shape, rank=rank))
+            P = int(rb.pair_num.sum())
+            by = 16 * n + 8 * P
+            rows.append(dict(kind="subm" + ("_ranked" if rank is not None else "_hash"), level=lvl + 1, n_in=n, pairs=P, us=round(t * 1e6, 1),
+                             alg_MB=round(by / 1e6, 1), GBps=round(by / t / 1e9, 1)))
+            tot_bytes += by; tot_t += t
+    print(json.dumps(dict(frames=B, rulebook_chain_us=round(tot_t * 1e6, 1), alg_MB=round(tot_bytes / 1e6, 1),
+                          achieved_GBps=round(tot_bytes / tot_t / 1e9, 1), frac_of_8TBps=round(tot_bytes / tot_t / 8e12, 4),
+                          builds=rows)), flush=True)
+    del frames, pts, res, idx
+    torch.cuda.empty_cache()
