@@ -244,17 +244,21 @@ def main():
 
     last = {}
 
-    def fwd_bwd(pts, offs, ev=None):
-        """voxelise -> MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into bucket)"""
+    def voxelize(pts, offs):
+        """hard voxelisation + fused MeanVFE of one batch (what the reference's DataLoader workers do on the CPU)"""
         bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
-        if ev is not None: ev("voxelize")
         bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
                                                 synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True)
-        if ev is not None: ev("forward")
         bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B}
         if "voxel_num_rows" in bd:
             bd2["voxel_num_rows"] = bd["voxel_num_rows"]
-        sf = model.map_to_bev_module(model.backbone_3d(model.vfe(bd2)))["spatial_features"]
+        if not (ops.PLAN is not None and ops.PLAN.active):
+            last["voxels"] = sum(bd["voxel_counts"])
+        return bd2
+
+    def train_from_voxels(bd2, ev=None):
+        """MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into the bucket)"""
+        sf = model.map_to_bev_module(model.backbone_3d(model.vfe(dict(bd2))))["spatial_features"]
         # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense
         # gradient; rocBLAS dot is not graph-capturable, hence mul + sum)
         loss = ProjectionLoss.apply(sf)
@@ -262,8 +266,12 @@ def main():
         bucket.zero()
         loss.backward()
         Fsp.join_deferred_wgrad()                            # side-stream wgrad pipeline -> back to this stream
-        if not (ops.PLAN is not None and ops.PLAN.active):
-            last["voxels"] = sum(bd["voxel_counts"])
+
+    def fwd_bwd(pts, offs, ev=None):
+        if ev is not None: ev("voxelize")
+        bd2 = voxelize(pts, offs)
+        if ev is not None: ev("forward")
+        train_from_voxels(bd2, ev)
         return None
 
     def opt_step():
@@ -305,23 +313,40 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             plan.recorded.clear()
-            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            if os.environ.get('PCD_GRAPH_DOT'):                  # debugging aid: dump the captured DAG
-                g_fb.enable_debug_mode()
+            # three graphs: voxelisation | forward+backward | clip+Adam.  The voxelisation of batch i+1 is
+            # replayed on a second stream as soon as forward+backward of batch i has finished, i.e. beside the
+            # gradient all-reduce and the optimizer of step i (the reference voxelises in DataLoader workers,
+            # asynchronously to the training step); it owns its memory pool because it runs concurrently with
+            # the optimizer graph.  Every timed step still contains exactly one voxelisation.
+            g_vox, g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_vox):
+                vox_out = voxelize(s_pts, s_offs)
             with torch.cuda.graph(g_fb):
-                fwd_bwd(s_pts, s_offs)
+                train_from_voxels(vox_out)
             with torch.cuda.graph(g_opt, pool=g_fb.pool()):
                 opt_step()
-            if os.environ.get('PCD_GRAPH_DOT'):
-                g_fb.debug_dump(os.environ['PCD_GRAPH_DOT'])
+            vox_stream = torch.cuda.Stream()
+            ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
+
+            def prefetch_voxels(i):
+                pts, offs = batches[i % 2]
+                with torch.cuda.stream(vox_stream):
+                    vox_stream.wait_event(ev_fb)             # the previous forward+backward still reads vox_out
+                    s_pts.copy_(pts, non_blocking=True)      # device -> device: the batch is already in HBM
+                    s_offs.copy_(offs, non_blocking=True)
+                    g_vox.replay()
+                    ev_vox.record(vox_stream)
 
             def run_step(i):
-                pts, offs = batches[i % 2]
-                s_pts.copy_(pts, non_blocking=True)          # device -> device: the batch is already in HBM
-                s_offs.copy_(offs, non_blocking=True)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev_vox)                       # voxels of batch i
                 g_fb.replay()
+                ev_fb.record(cur)
+                prefetch_voxels(i + 1)
                 bucket.all_reduce_mean()
                 g_opt.replay()
+            ev_fb.record(torch.cuda.current_stream())
+            prefetch_voxels(0)
             for i in range(2):
                 run_step(i)
             torch.cuda.synchronize()
@@ -375,7 +400,7 @@ def main():
                                "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
                    "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
-                   "execution": "hipGraph replay (fwd+bwd | all-reduce | clip+Adam), device-side row counts"
+                   "execution": "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd | all-reduce | clip+Adam), device-side row counts"
                                 if use_graph else "eager launches"},
     }
 
