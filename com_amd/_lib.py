@@ -46,7 +46,7 @@ PROTOTYPES = {
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
-    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),

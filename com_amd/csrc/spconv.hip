@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
     int n_out_cap, const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, int nsteps,
-    unsigned x_bytes, int dbg) {
+    unsigned x_bytes, int dbg, const void *__restrict__ addend) {
     constexpr int ROWS = 4 * MI * 16;
     constexpr int THREADS = 256 * WN;
     constexpr int NBW = NB / WN;                           // 16-channel blocks per wave
@@ -299,12 +299,23 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             }
             if (OUT_BF16) {
+                if (addend) {  // y = conv + addend (e.g. the residual branch's gradient), rounded once
+                    uint2 ad = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + (size_t)row * c_out + col);
+                    v[0] += __uint_as_float(ad.x << 16);
+                    v[1] += __uint_as_float(ad.x & 0xffff0000u);
+                    v[2] += __uint_as_float(ad.y << 16);
+                    v[3] += __uint_as_float(ad.y & 0xffff0000u);
+                }
                 unsigned short *y = (unsigned short *)yv + (size_t)row * c_out + col;
                 uint2 o;
                 o.x = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
                 o.y = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
                 *reinterpret_cast<uint2 *>(y) = o;
             } else {
+                if (addend) {
+                    float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + (size_t)row * c_out + col);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
                 float *y = (float *)yv + (size_t)row * c_out + col;
                 *reinterpret_cast<float4 *>(y) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
 template <int NB, int MI, int G, int SG, int WN = 1>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, const int32_t *n_out_dev,
-                     void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st) {
+                     void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
@@ -338,10 +349,10 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
     }
     if (y_dtype == PCD_BF16)
         kb<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend);
     else
         kf<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -647,7 +658,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
                                            const float *bias, const int32_t *nbr, int nbr_stride,
                                            int kvol, int flip_k, int n_rows_out,
                                            const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype,
-                                           void *stream) {
+                                           const void *addend, void *stream) {
     PCD_ENTER();
     if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
     if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
@@ -669,7 +680,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
     // rows per wave (MI x 16) shrink with the row count to keep >= ~3 workgroups per CU in flight
     // (measured on gfx950, 128 ch / 42k rows: MI 1/2/4 = 61/68/77 us; 64 ch / 115k rows: 60/55/53 us).
     const int mi = n_rows_out >= 96 * 1024 ? 4 : n_rows_out >= 48 * 1024 ? 2 : 1;
-#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend
     switch (c_out / 16) {
         case 1:
             return resident ? launch_gg<1, 1, 2, 0>(GG_ARGS) : launch_gg<1, 1, 2, 4>(GG_ARGS);

@@ -35,6 +35,7 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
 class SparseBasicBlock(spconv.SparseModule):
     """spconv_backbone.py:30-66 (both convs have bias=True: `bias = norm_fn is not None`)."""
     expansion = 1
+    fuse_identity_grad = True      # identity-branch gradient added inside conv1's dgrad kernel
 
     def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
         super().__init__()
@@ -53,13 +54,17 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         # same dataflow as spconv_backbone.py:50-66; bn -> relu and bn -> (+identity) -> relu each run as
         # one fused stats pass + one fused apply pass (com_amd/csrc/fused.hip)
-        identity = x
-        out = self.conv1(x)
+        # the identity branch leaves conv1 as a second output, so its gradient is added in conv1's dgrad epilogue
+        fuse_identity = (self.fuse_identity_grad and self.downsample is None and x.features.is_cuda
+                         and torch.is_grad_enabled())
+        if fuse_identity:
+            out, identity_features = self.conv1(x, passthrough=True)
+        else:
+            out = self.conv1(x)
+            identity_features = (self.downsample(x) if self.downsample is not None else x).features
         out = replace_feature(out, Fsp.batch_norm_act(self.bn1, out.features, None, True, out.num_rows))
         out = self.conv2(out)
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        out = replace_feature(out, Fsp.batch_norm_act(self.bn2, out.features, identity.features, True,
+        out = replace_feature(out, Fsp.batch_norm_act(self.bn2, out.features, identity_features, True,
                                                       out.num_rows))
         return out
 

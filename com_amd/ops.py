@@ -386,11 +386,13 @@ class PackPlan:
         return self.packed
 
 
-def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None):
-    """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]  (output-stationary; forward and dgrad)."""
+def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None, addend=None):
+    """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o])  (output-stationary; forward and dgrad)."""
     _require_cuda(x, packed_w, nbr)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
     y = torch.empty((n_rows_out, c_out), dtype=out_dtype, device=x.device)
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == y.dtype and addend.is_contiguous() and addend.is_cuda
 
     def meta():
         pairs = int((nbr >= 0).sum().item())
@@ -403,7 +405,7 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
         L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
                                                     L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),
-                                                    L.stream_ptr()),
+                                                    L.ptr(addend), L.stream_ptr()),
                 "pcd_sparse_conv_gather_gemm")
     return y
 

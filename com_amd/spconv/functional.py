@@ -62,7 +62,10 @@ class SparseConvFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None):
+    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+        """passthrough=True also returns `features` itself as a second output (the identity branch of a residual
+        block): backward then receives the gradients of BOTH branches in one call and adds the identity gradient
+        inside the dgrad kernel's epilogue instead of through a separate elementwise kernel."""
         cout, cin = weight.shape[0], weight.shape[-1]
         cin_pad = ops.pow2_ge8(cin)
         assert features.shape[1] in (cin, cin_pad), (features.shape, weight.shape)
@@ -79,13 +82,18 @@ class SparseConvFunction(Function):
         ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.weight_param = weight if isinstance(weight, torch.nn.Parameter) else None
         ctx.in_dtype = features.dtype
+        ctx.passthrough = passthrough
         ctx.save_for_backward(x, weight)
+        if passthrough:
+            return y, features.view_as(features)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_ident=None):
         x, weight = ctx.saved_tensors
         rb = ctx.rb
+        if dy is None:                               # only the identity branch received a gradient
+            return (d_ident, None, None, None, None, None, None)
         dy16 = _to_bf16_padded(dy, ctx.cout)
         dx = dw = db = None
         # dgrad and wgrad only share their inputs: at B = 4 neither fills the chip (1-4 waves per SIMD), so the
@@ -125,13 +133,18 @@ class SparseConvFunction(Function):
                 raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
                                    "requires an input gradient)")
             packed_d = ctx.packed_dgrad() if ctx.packed_dgrad is not None else ops.pack_weight(weight, 1)
+            add = None
+            if d_ident is not None and ctx.cin_pad == ctx.in_cols and d_ident.dtype == ctx.in_dtype:
+                add = d_ident.contiguous()           # fused: dx = dgrad + identity-branch gradient
             if rb.subm:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
             else:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
             dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
+            if d_ident is not None and add is None:
+                dx = dx + d_ident.to(dx.dtype)
         if deferred and len(_PENDING) > WGRAD_JOIN_LAG:
             cur.wait_event(_PENDING[-1 - WGRAD_JOIN_LAG][0])
             del _PENDING[:len(_PENDING) - WGRAD_JOIN_LAG]
@@ -140,7 +153,9 @@ class SparseConvFunction(Function):
             for t in (dw, db):
                 if t is not None:
                     t.record_stream(cur)
-        return dx, dw, db, None, None, None
+        if dx is None and d_ident is not None:
+            dx = d_ident
+        return dx, dw, db, None, None, None, None
 
 
 class BevDenseFunction(Function):
@@ -170,8 +185,8 @@ def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None):
     return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev)
 
 
-def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None):
-    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad)
+def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
 
 
 class FusedBNFunction(Function):

@@ -192,11 +192,14 @@ int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *s
  *             packed mode 1.
  * n_rows_in = rows of x (bounds of the gathers), c_in = contraction channels (row stride of x, a power
  * of two >= 8), c_out = output channels (% 16 == 0),
- * nbr_stride = row stride (elements) of the nbr table.  y dtype PCD_BF16 or PCD_F32; bias f32 or NULL. */
+ * nbr_stride = row stride (elements) of the nbr table.  y dtype PCD_BF16 or PCD_F32; bias f32 or NULL.
+ * addend (NULL or [n_rows_out][c_out] of y's dtype) is added before the single rounding of y: the gradient of the
+ * residual branch in the dgrad of a SparseBasicBlock's first conv (spconv_backbone.py:56-63) -- replaces the
+ * elementwise add autograd would launch. */
 int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
-                                int y_dtype, void *stream);
+                                int y_dtype, const void *addend, void *stream);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
