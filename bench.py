@@ -274,8 +274,11 @@ def main():
         train_from_voxels(bd2, ev)
         return None
 
+    clip_div = torch.ones((), dtype=torch.float32, device=dev)
+    opt.grad_scale = clip_div        # fused Adam divides the gradients by this inside its kernel
+
     def opt_step():
-        bucket.clip_grad_norm_(10.0)                         # centerpoint.yaml:96 GRAD_NORM_CLIP
+        bucket.clip_divisor_(10.0, clip_div)                 # centerpoint.yaml:96 GRAD_NORM_CLIP (norm + clamp only)
         opt.step()
 
     def eager_step(i, ev=None):

@@ -60,9 +60,28 @@ __global__ __launch_bounds__(256) void bev_scatter_kernel(const T *__restrict__ 
         }
     }
     __syncthreads();
-    for (int item = threadIdx.x; item < C * xt; item += 256) {
-        int c = item / xt, x = item - c * xt;
-        out[((((size_t)b * C + c) * D + z) * H + y) * W + x0 + x] = tile[(size_t)c * LD + x];
+    // write every channel's W-contiguous line: 8-byte stores (4 bf16 / 2 f32 per thread) where the line allows it
+    constexpr int Q = 8 / sizeof(T);
+    if ((W % Q) == 0 && (x0 % Q) == 0) {
+        const int nq = xt / Q;
+        for (int item = threadIdx.x; item < C * nq; item += 256) {
+            const int c = item / nq, x = (item - c * nq) * Q;
+            T v[Q];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) v[j] = tile[(size_t)c * LD + x + j];
+            uint2 o;
+            __builtin_memcpy(&o, v, 8);
+            *reinterpret_cast<uint2 *>(out + ((((size_t)b * C + c) * D + z) * H + y) * W + x0 + x) = o;
+        }
+        for (int item = threadIdx.x; item < C * (xt - nq * Q); item += 256) {   // ragged tail of the line
+            const int c = item / (xt - nq * Q), x = nq * Q + item % (xt - nq * Q);
+            out[((((size_t)b * C + c) * D + z) * H + y) * W + x0 + x] = tile[(size_t)c * LD + x];
+        }
+    } else {
+        for (int item = threadIdx.x; item < C * xt; item += 256) {
+            int c = item / xt, x = item - c * xt;
+            out[((((size_t)b * C + c) * D + z) * H + y) * W + x0 + x] = tile[(size_t)c * LD + x];
+        }
     }
 }
 

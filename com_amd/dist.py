@@ -64,6 +64,14 @@ class FlatGradBucket:
         self.flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
         return norm
 
+    def clip_divisor_(self, max_norm, out):
+        """out <- max((||g|| + 1e-6) / max_norm, 1): the number the gradients must be DIVIDED by to implement
+        clip_grad_norm_.  Handing it to a fused optimizer as `grad_scale` (torch.optim.Adam(fused=True) divides the
+        gradients by it inside its kernel) saves the separate scaling pass over the whole buffer."""
+        norm = torch.linalg.vector_norm(self.flat)
+        out.copy_(torch.clamp((norm + 1e-6) / max_norm, min=1.0))
+        return out
+
     def zero(self):
         self.flat.zero_()
 
