@@ -98,6 +98,171 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4 *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Level-1 SubM rulebook (rows in first-appearance order, no spatial order to exploit) through a hash of 4x4x4
+// BLOCKS instead of a hash of cells: a 16-byte slot {block key + 1, base, 64-bit occupancy mask} per non-empty
+// block and one row list (rows of a block contiguous, ordered by cell bit).  A row's 26 neighbours live in at most
+// 8 blocks, one of them its own (slot remembered from the insert): (1.5^3 - 1) = 2.4 probes per row on average
+// instead of 26, and the table is ~N/6 slots of 16 bytes (L2-sized at B = 4) instead of 2N slots of 8 bytes.
+struct Blk {
+    u32 key1;   // block key + 1; 0 = empty
+    int base;   // first entry of this block in the row list
+    u64 mask;   // bit (z&3)<<4 | (y&3)<<2 | (x&3)
+};
+static_assert(sizeof(Blk) == 16, "slot");
+
+__device__ __forceinline__ u32 blk_key(int b, int bz, int by, int bx, int Dz, int Hy, int Wx) {
+    return (((u32)b * Dz + bz) * Hy + by) * Wx + bx;
+}
+
+__global__ __launch_bounds__(256) void blk_insert_kernel(const int4 *__restrict__ idx, int n,
+                                                         const int32_t *n_dev, int Dz, int Hy, int Wx, Blk *table,
+                                                         u32 mask, int32_t *__restrict__ rowslot) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= eff_rows(n_dev, n)) return;
+    int4 c = idx[i];
+    const u32 key1 = blk_key(c.x, c.y >> 2, c.z >> 2, c.w >> 2, Dz, Hy, Wx) + 1u;
+    u32 h = hash_u32(key1) & mask;
+    for (;;) {
+        u32 prev = table[h].key1;
+        if (prev == 0u) prev = atomicCAS(&table[h].key1, 0u, key1);
+        if (prev == 0u || prev == key1) break;
+        h = (h + 1) & mask;
+    }
+    atomicOr((unsigned long long *)&table[h].mask, 1ull << (((c.y & 3) << 4) | ((c.z & 3) << 2) | (c.w & 3)));
+    rowslot[i] = (int)h;
+}
+
+// base of every non-empty block in the row list: popcount prefix inside a 4096-slot chunk (4 slots per thread,
+// wave scan, LDS scan of the 16 wave totals) and ONE atomicAdd per chunk -- same-address atomics cost ~6 ns each,
+// one per wave took longer than the probes.  The order of the blocks in the list is irrelevant: only lookups
+// through `base` ever read it.
+__global__ __launch_bounds__(1024) void blk_base_kernel(Blk *table, u32 cap, int *total) {
+    __shared__ int wsum[16];
+    __shared__ int chunk_base;
+    const u32 s0 = (blockIdx.x * 1024u + threadIdx.x) * 4u;
+    int cnt[4];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 sidx = s0 + j;
+        cnt[j] = (sidx < cap && table[sidx].key1 != 0u) ? __popcll(table[sidx].mask) : 0;
+        mine += cnt[j];
+    }
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d);
+        if (lane_id() >= d) inc += t;
+    }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int q = 0; q < 16; ++q) {
+            int t = wsum[q];
+            wsum[q] = run;
+            run += t;
+        }
+        chunk_base = run > 0 ? atomicAdd(total, run) : 0;
+    }
+    __syncthreads();
+    int base = chunk_base + wsum[w] + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (cnt[j] > 0) table[s0 + j].base = base;
+        base += cnt[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void blk_fill_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                       const Blk *__restrict__ table,
+                                                       const int32_t *__restrict__ rowslot,
+                                                       int32_t *__restrict__ rowlist) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= eff_rows(n_dev, n)) return;
+    int4 c = idx[i];
+    const uint4 raw = *reinterpret_cast<const uint4 *>(&table[rowslot[i]]);
+    const u64 m = ((u64)raw.w << 32) | raw.z;
+    const int bit = ((c.y & 3) << 4) | ((c.z & 3) << 2) | (c.w & 3);
+    rowlist[(int)raw.y + __popcll(m & ((1ull << bit) - 1ull))] = i;
+}
+
+__global__ __launch_bounds__(256) void blk_probe_kernel(const int4 *__restrict__ idx, int n,
+                                                        const int32_t *n_dev, ConvGeom G, int Dz, int Hy, int Wx,
+                                                        const Blk *__restrict__ table, u32 mask,
+                                                        const int32_t *__restrict__ rowslot,
+                                                        const int32_t *__restrict__ rowlist,
+                                                        int32_t *__restrict__ nbr, int *__restrict__ wave_cnt,
+                                                        int nwaves) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const bool live = o < eff_rows(n_dev, n);
+    const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
+    const int wave = o >> 6;
+    const int bz = c.y >> 2, by = c.z >> 2, bx = c.w >> 2;
+    const int cz = c.y & 3, cy = c.z & 3, cx = c.w & 3;
+    // per axis: side 0 = own block coordinate, side 1 = the neighbouring block a +-1 step can reach (if any)
+    const int oz = cz == 0 ? bz - 1 : (cz == 3 ? bz + 1 : -1);
+    const int oy = cy == 0 ? by - 1 : (cy == 3 ? by + 1 : -1);
+    const int ox = cx == 0 ? bx - 1 : (cx == 3 ? bx + 1 : -1);
+    const bool hz = oz >= 0 && oz < Dz, hy = oy >= 0 && oy < Hy, hx = ox >= 0 && ox < Wx;
+    u64 bm[8];
+    int bb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        bm[q] = 0ull;
+        bb[q] = 0;
+    }
+    if (live) {
+        const uint4 own = *reinterpret_cast<const uint4 *>(&table[rowslot[o]]);
+        bm[0] = ((u64)own.w << 32) | own.z;
+        bb[0] = (int)own.y;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const bool sz = q & 4, sy = q & 2, sx = q & 1;
+            if ((sz && !hz) || (sy && !hy) || (sx && !hx)) continue;
+            const u32 key1 = blk_key(c.x, sz ? oz : bz, sy ? oy : by, sx ? ox : bx, Dz, Hy, Wx) + 1u;
+            u32 h = hash_u32(key1) & mask;
+            for (;;) {
+                const uint4 sl = *reinterpret_cast<const uint4 *>(&table[h]);
+                if (sl.x == 0u) break;
+                if (sl.x == key1) {
+                    bm[q] = ((u64)sl.w << 32) | sl.z;
+                    bb[q] = (int)sl.y;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        int r = -1;
+        if (live) {
+            const int z = cz + dz * G.dd, y = cy + dy * G.dh, x = cx + dx * G.dw;  // dilation 1 only (checked on host)
+            const bool sz = z < 0 || z > 3, sy = y < 0 || y > 3, sx = x < 0 || x > 3;
+            const int q = (sz ? 4 : 0) | (sy ? 2 : 0) | (sx ? 1 : 0);
+            u64 m = bm[0];
+            int base = bb[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) {
+                m = q == t ? bm[t] : m;
+                base = q == t ? bb[t] : base;
+            }
+            const int bit = ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
+            if ((m >> bit) & 1ull) r = rowlist[base + __popcll(m & ((1ull << bit) - 1ull))];
+            if (k == 13) r = o;
+            nbr[(size_t)k * n + o] = r;
+        }
+        if (wave_cnt) {
+            u64 mm = __ballot(r >= 0);
+            if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(mm);
+        }
+    }
+}
+
 // SubM rulebook of a level whose rows ARE the bitmap ranks of the strided conv that created it (row id = rank of
 // the linear key): a neighbour lookup is one bitmap word + one prefix word, both shared by the x-neighbours and
 // by the neighbouring rows of the (key-sorted) wave -- no hash table is built or probed.
@@ -392,8 +557,9 @@ extern "C" int pcd_conv_out_shape(const int *in_shape, const int *ks, const int 
 extern "C" size_t pcd_rulebook_subm_workspace_bytes(int n, int kvol) {
     if (n < 0 || kvol <= 0) return 0;
     int nwaves = pcd_div_up(n > 0 ? n : 1, 64);
-    return ws_piece(table_capacity(n), sizeof(u64)) + 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) +
-           ws_piece(kvol, sizeof(int));
+    return ws_piece(2 * (size_t)table_capacity(n), sizeof(u64)) + 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) +
+           ws_piece(kvol, sizeof(int)) + 2 * ws_piece((size_t)(n > 0 ? n : 1), sizeof(int32_t)) +
+           ws_piece(1, sizeof(int));
 }
 
 extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape_host,
@@ -419,16 +585,35 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
     WsCarver ws(workspace, workspace_bytes);
     u32 tcap = table_capacity(n);
     int nwaves = pcd_div_up(n, 64);
-    u64 *table = ws.take<u64>(tcap);
+    u64 *table = ws.take<u64>(2 * (size_t)tcap);  // cell hash: tcap x 8 B; block hash: up to tcap x 16 B
     int *wave_cnt = ws.take<int>((size_t)G.K * nwaves);
     int *wave_off = ws.take<int>((size_t)G.K * nwaves);
     int *totals = ws.take<int>(G.K);
+    int32_t *rowslot = ws.take<int32_t>(n);
+    int32_t *rowlist = ws.take<int32_t>(n);
+    int *blk_total = ws.take<int>(1);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n, 256);
-    pcd_fill(table, 0xFF, (size_t)tcap * sizeof(u64), st);
-    hash_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G.D, G.H, G.W, table, tcap - 1);
-    subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, table, tcap - 1, nbr,
-                                          pairs ? wave_cnt : nullptr, nwaves);
+    const bool blocks = G.kd == 3 && G.kh == 3 && G.kw == 3 && G.dd == 1 && G.dh == 1 && G.dw == 1;
+    if (blocks) {
+        // at most n non-empty blocks (typically n/6): tcap / 2 >= n slots, strictly more unless n is a power of
+        // two -- a probe for a missing block needs at least one empty slot to terminate
+        const u32 bcap = (tcap / 2 > (u32)n) ? tcap / 2 : tcap;
+        const int Dz = (G.D + 3) / 4, Hy = (G.H + 3) / 4, Wx = (G.W + 3) / 4;
+        Blk *bt = (Blk *)table;
+        pcd_fill(bt, 0, (size_t)bcap * sizeof(Blk), st);
+        pcd_fill(blk_total, 0, sizeof(int), st);
+        blk_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, Dz, Hy, Wx, bt, bcap - 1, rowslot);
+        blk_base_kernel<<<pcd_div_up((int)bcap, 4096), 1024, 0, st>>>(bt, bcap, blk_total);
+        blk_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, bt, rowslot, rowlist);
+        blk_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, Dz, Hy, Wx, bt, bcap - 1, rowslot,
+                                             rowlist, nbr, pairs ? wave_cnt : nullptr, nwaves);
+    } else {
+        pcd_fill(table, 0xFF, (size_t)tcap * sizeof(u64), st);
+        hash_insert_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G.D, G.H, G.W, table, tcap - 1);
+        subm_probe_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, table, tcap - 1, nbr,
+                                              pairs ? wave_cnt : nullptr, nwaves);
+    }
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
