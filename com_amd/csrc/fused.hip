@@ -51,6 +51,35 @@ struct Piece<unsigned short> {
     }
 };
 
+// A thread's N per-channel parameters.  16-byte loads when the arrays allow it (`vec`, decided on the host from the
+// pointer alignment): with one 4-byte load per channel the prologue of a streaming kernel was up to 48 wave-wide
+// load instructions (~32 clk each in the CU's single texture-address unit) -- a third of the kernel's run time.
+template <int N>
+__device__ __forceinline__ void load_params(const float *__restrict__ p, int ch0, bool vec, float (&v)[N]) {
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            float4 t = *reinterpret_cast<const float4 *>(p + ch0 + j);
+            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = p[ch0 + j];
+    }
+}
+template <int N>
+__device__ __forceinline__ void fill_params(float val, float (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = val;
+}
+static bool aligned16(const void *a, const void *b = nullptr, const void *c = nullptr, const void *d = nullptr,
+                      const void *e = nullptr, const void *f = nullptr) {
+    const void *ps[6] = {a, b, c, d, e, f};
+    for (const void *q : ps)
+        if (q && ((uintptr_t)q & 15u)) return false;
+    return true;
+}
+
 // block-level reduction of per-thread piece accumulators -> partial[blockIdx][which][c]
 template <int N, int NACC>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c, int pcs,
@@ -182,17 +211,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
                                                        int n_cap, const int32_t *n_dev, int c,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int relu,
-                                                       T *__restrict__ y) {
+                                                       T *__restrict__ y, int vec) {
     constexpr int N = Piece<T>::N;
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        sc[j] = scale[piece * N + j];
-        sh[j] = shift[piece * N + j];
-    }
+    load_params<N>(scale, piece * N, vec, sc);
+    load_params<N>(shift, piece * N, vec, sh);
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float v[N], r[N];
         Piece<T>::load(x + e * N, v);
@@ -218,21 +244,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
                                                             const float *__restrict__ beta,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, int relu,
-                                                            float *__restrict__ partial) {
+                                                            float *__restrict__ partial, int vec) {
     constexpr int N = Piece<T>::N;
     __shared__ float lds[256 * 2 * N];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
-    float mu[N], is[N], sc[N], sh[N];
+    float mu[N], is[N], sc[N], sh[N], gmv[N], btv[N];
+    load_params<N>(mean, piece * N, vec, mu);
+    load_params<N>(invstd, piece * N, vec, is);
+    if (gamma) load_params<N>(gamma, piece * N, vec, gmv); else fill_params<N>(1.0f, gmv);
+    if (beta) load_params<N>(beta, piece * N, vec, btv); else fill_params<N>(0.0f, btv);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const int ch = piece * N + j;
-        mu[j] = mean[ch];
-        is[j] = invstd[ch];
-        const float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
-        sc[j] = g * is[j];
-        sh[j] = b - mu[j] * g * is[j];
+        sc[j] = gmv[j] * is[j];
+        sh[j] = btv[j] - mu[j] * gmv[j] * is[j];
     }
     const bool mask_from_x = relu && y == nullptr;
     float acc[2][N];
@@ -277,24 +303,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const float *__restrict__ dgamma,
                                                            const float *__restrict__ dbeta, int relu,
                                                            int training, T *__restrict__ dx,
-                                                           T *__restrict__ dres) {
+                                                           T *__restrict__ dres, int vec) {
     constexpr int N = Piece<T>::N;
     const int pcs = c / N;
     const int n = eff_rows(n_dev, n_cap);
     const size_t total = (size_t)n * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
-    float mu[N], is[N], gm[N], sh[N], k1[N], k2[N];
+    float mu[N], is[N], gm[N], sh[N], k1[N], k2[N], gmv[N], btv[N];
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
     const bool mask_from_x = relu && y == nullptr;
+    load_params<N>(mean, piece * N, vec, mu);
+    load_params<N>(invstd, piece * N, vec, is);
+    if (gamma) load_params<N>(gamma, piece * N, vec, gmv); else fill_params<N>(1.0f, gmv);
+    if (beta) load_params<N>(beta, piece * N, vec, btv); else fill_params<N>(0.0f, btv);
+    if (training) {
+        load_params<N>(dbeta, piece * N, vec, k1);
+        load_params<N>(dgamma, piece * N, vec, k2);
+    } else {
+        fill_params<N>(0.0f, k1);
+        fill_params<N>(0.0f, k2);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        int ch = piece * N + j;
-        mu[j] = mean[ch];
-        is[j] = invstd[ch];
-        gm[j] = (gamma ? gamma[ch] : 1.0f) * is[j];
-        sh[j] = (beta ? beta[ch] : 0.0f) - mu[j] * (gamma ? gamma[ch] : 1.0f) * is[j];
-        k1[j] = training ? dbeta[ch] * inv_n : 0.0f;
-        k2[j] = training ? dgamma[ch] * inv_n : 0.0f;
+        gm[j] = gmv[j] * is[j];
+        sh[j] = btv[j] - mu[j] * gmv[j] * is[j];
+        k1[j] *= inv_n;
+        k2[j] *= inv_n;
     }
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float g[N], xv[N], yv[N], o[N];
@@ -385,11 +419,11 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     if (n > 0) {
         if (dtype == PCD_F32)
             bn_apply_kernel<float><<<agrid, 256, 0, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
-                                                         L.scale, L.shift, relu, (float *)y);
+                                                         L.scale, L.shift, relu, (float *)y, 1);
         else
             bn_apply_kernel<unsigned short><<<agrid, 256, 0, st>>>(
                 (const unsigned short *)x, (const unsigned short *)residual, n, n_dev, c, L.scale, L.shift, relu,
-                (unsigned short *)y);
+                (unsigned short *)y, 1);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -443,24 +477,25 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     const int pcs = c / N;
     int grid = grid_for((size_t)n * pcs, pcs);
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
+    const int vec = aligned16(gamma, beta, save_mean, save_invstd, dgamma, dbeta) ? 1 : 0;
     if (dtype == PCD_F32) {
         bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                                                          save_invstd, relu, L.partial);
+                                                          save_invstd, relu, L.partial, vec);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual);
+                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec);
     } else {
         typedef unsigned short B;
         bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
-                                                      gamma, beta, save_mean, save_invstd, relu, L.partial);
+                                                      gamma, beta, save_mean, save_invstd, relu, L.partial, vec);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                          gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                                         relu, training, (B *)dx, (B *)dresidual);
+                                                         relu, training, (B *)dx, (B *)dresidual, vec);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
