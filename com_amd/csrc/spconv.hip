@@ -153,8 +153,40 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
         __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)(wtotal * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
-    // rulebook tile -> LDS, 4 independent loads in flight per thread
-    {
+    // rulebook tile -> LDS.  With a row stride that is a multiple of 4 (always in static-shape mode, where the
+    // capacities are rounded) a lane fetches 4 consecutive rows of one offset with ONE 16-byte load: 4x fewer
+    // load instructions in a prologue that is pure latency (27 dword loads per thread otherwise).
+    if ((nbr_stride & 3) == 0) {
+        constexpr int QR = ROWS / 4;                       // 16-byte pieces per offset
+        const int total = K * QR;
+        for (int base = threadIdx.x; base < total; base += 4 * THREADS) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                const int k = idx / QR, r = (idx - k * QR) * 4;
+                const int krow = flip ? (K - 1 - k) : k;
+                const unsigned off = idx < total ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)(r0wg + r)) * 4u
+                                                 : 0xFFFFFFF0u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(nrsrc, off, 0, 0);   // beyond the table: zeros
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                if (idx < total) {
+                    const int k = idx / QR, r = (idx - k * QR) * 4;
+                    int4 w = make_int4((int)v[u][0], (int)v[u][1], (int)v[u][2], (int)v[u][3]);
+                    const int row = r0wg + r;       // rows at / beyond n_out have no neighbours
+                    if (row + 0 >= n_out) w.x = -1;
+                    if (row + 1 >= n_out) w.y = -1;
+                    if (row + 2 >= n_out) w.z = -1;
+                    if (row + 3 >= n_out) w.w = -1;
+                    *reinterpret_cast<int4 *>(nbr_s + k * ROWS + r) = w;
+                }
+            }
+        }
+        for (int r = threadIdx.x; r < ROWS; r += THREADS) nbr_s[K * ROWS + r] = -1;   // row K: padded steps
+    } else {
         const int total = K * ROWS;
         for (int base = threadIdx.x; base < total + ROWS; base += 4 * THREADS) {
             int v[4];
@@ -540,10 +572,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     }
     // slab[split][cout][K][cin]
     float *sl = slab + (size_t)split * cout * K * cin;
-    for (int e = threadIdx.x; e < CI * CO; e += 256) {
-        int ci = e % CI, co = e / CI;
-        if (ci0 + ci < cin && co0 + co < cout)
-            sl[((size_t)(co0 + co) * K + k) * cin + ci0 + ci] = tile[co * CI + ci];
+    if ((cin & 3) == 0) {   // 16-byte stores: consecutive cin are contiguous in the slab and in the tile
+        for (int e = threadIdx.x; e < CI * CO / 4; e += 256) {
+            int ci = (e % (CI / 4)) * 4, co = e / (CI / 4);
+            if (ci0 + ci < cin && co0 + co < cout)
+                *reinterpret_cast<float4 *>(sl + ((size_t)(co0 + co) * K + k) * cin + ci0 + ci) =
+                    *reinterpret_cast<const float4 *>(tile + co * CI + ci);
+        }
+    } else {
+        for (int e = threadIdx.x; e < CI * CO; e += 256) {
+            int ci = e % CI, co = e / CI;
+            if (ci0 + ci < cin && co0 + co < cout)
+                sl[((size_t)(co0 + co) * K + k) * cin + ci0 + ci] = tile[co * CI + ci];
+        }
     }
 }
 
@@ -551,31 +592,58 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 // (q = g, g + 8, ...) with independent loads in flight, then the 8 partial sums are added in group order.
 // (One thread per element looping over up to 64 splits left a 16-channel layer with 27 workgroups of 64
 // dependent-latency iterations: 20+ us for a 1.7 MB reduction.)
+template <int V>   // V = 4: four consecutive elements per thread (16-byte loads), n % 4 == 0;  V = 1: scalar
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int splits,
                                                            size_t n, float *__restrict__ dw) {
-    __shared__ float part[8][32];
+    __shared__ float part[8][32][V];
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const size_t e = (size_t)blockIdx.x * 32 + el;
-    float s = 0.0f;
+    const size_t e = ((size_t)blockIdx.x * 32 + el) * V;
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = 0.0f;
+    auto ld = [&](int q, float (&v)[V]) {
+        if (V == 4) {
+            float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)q * n + e);
+            v[0] = t.x; v[1 % V] = t.y; v[2 % V] = t.z; v[3 % V] = t.w;
+        } else {
+            v[0] = slab[(size_t)q * n + e];
+        }
+    };
     if (e < n) {
         int q = g;
         for (; q + 24 < splits; q += 32) {
-            float a0 = slab[(size_t)q * n + e], a1 = slab[(size_t)(q + 8) * n + e];
-            float a2 = slab[(size_t)(q + 16) * n + e], a3 = slab[(size_t)(q + 24) * n + e];
-            s += a0;
-            s += a1;
-            s += a2;
-            s += a3;
+            float a0[V], a1[V], a2[V], a3[V];
+            ld(q, a0); ld(q + 8, a1); ld(q + 16, a2); ld(q + 24, a3);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s[j] += a0[j];
+                s[j] += a1[j];
+                s[j] += a2[j];
+                s[j] += a3[j];
+            }
         }
-        for (; q < splits; q += 8) s += slab[(size_t)q * n + e];
+        for (; q < splits; q += 8) {
+            float a0[V];
+            ld(q, a0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += a0[j];
+        }
     }
-    part[g][el] = s;
+#pragma unroll
+    for (int j = 0; j < V; ++j) part[g][el][j] = s[j];
     __syncthreads();
     if (g == 0 && e < n) {
-        float r = part[0][el];
+        float r[V];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) r += part[j][el];
-        dw[e] = r;
+        for (int j = 0; j < V; ++j) {
+            r[j] = part[0][el][j];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) r[j] += part[t][el][j];
+        }
+        if (V == 4)
+            *reinterpret_cast<float4 *>(dw + e) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
+        else
+            dw[e] = r[0];
     }
 }
 
@@ -747,8 +815,12 @@ extern "C" int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pma
     if (!workspace) return PCD_ERR_WORKSPACE;
     int splits, per;
     wgrad_plan(pmax, &splits, &per);
-    wgrad_reduce_kernel<<<(unsigned)((n + 31) / 32), 256, 0, (hipStream_t)stream>>>(
-        (const float *)workspace, splits, n, dweight);
+    if ((n & 3) == 0 && (((uintptr_t)dweight | (uintptr_t)workspace) & 15u) == 0)
+        wgrad_reduce_kernel<4><<<(unsigned)((n / 4 + 31) / 32), 256, 0, (hipStream_t)stream>>>(
+            (const float *)workspace, splits, n, dweight);
+    else
+        wgrad_reduce_kernel<1><<<(unsigned)((n + 31) / 32), 256, 0, (hipStream_t)stream>>>(
+            (const float *)workspace, splits, n, dweight);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
