@@ -541,6 +541,38 @@ def test_fused_batchnorm_relu_vs_torch_fp32(c, dtype, res):
         torch.testing.assert_close(ye.float(), bn_ref(x32), rtol=tol, atol=tol)
 
 
+def test_fused_batchnorm_unaligned_parameter_views():
+    """The BatchNorm kernels read per-channel parameters with 16-byte loads when the arrays are 16-byte aligned;
+    parameters that live at odd offsets of a flat buffer (4-byte aligned only) must take the scalar path and give
+    the same numbers."""
+    ops = _ops()
+    torch.manual_seed(9)
+    n, c = 5003, 32
+    x = torch.randn(n, c, device=DEV).bfloat16()
+    dy = torch.randn(n, c, device=DEV).bfloat16()
+    flat = torch.rand(4 * c + 8, device=DEV) + 0.5
+    outs = {}
+    for shift in (0, 1):                                      # 0: aligned views, 1: views shifted by one float
+        gv = flat[shift:shift + c]
+        bv = flat[2 * c + shift:2 * c + shift + c]
+        # same VALUES in both runs: copy the aligned values into the shifted views
+        if shift:
+            gv.copy_(outs["g"]); bv.copy_(outs["b"])
+        else:
+            outs["g"], outs["b"] = gv.clone(), bv.clone()
+        assert (gv.data_ptr() % 16 == 0) == (shift == 0)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        y, sm, si = ops.bn_forward(x, None, gv, bv, 1e-3, 0.01, True, rm, rv, True)
+        dgo = torch.empty(c + 1, device=DEV)[shift:shift + c]
+        dbo = torch.empty(c + 1, device=DEV)[shift:shift + c]
+        dx, _, dgam, dbet = ops.bn_backward(dy, x, None, gv, sm, si, True, True, False, beta=bv,
+                                            dgamma_out=dgo if dgo.is_contiguous() else None,
+                                            dbeta_out=dbo if dbo.is_contiguous() else None)
+        outs[shift] = (y.clone(), dx.clone(), dgam.clone(), dbet.clone())
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+
+
 def test_backbone_end_to_end_shapes_and_determinism():
     """VoxelResBackBone8x + HeightCompression on two 20k-pt frames: output contract of
     spconv_backbone.py:271-291 and bit-reproducibility of forward + backward (no atomics anywhere)."""
