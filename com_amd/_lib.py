@@ -35,6 +35,10 @@ PROTOTYPES = {
     "pcd_rulebook_subm_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_workspace_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_rulebook_conv_classes_workspace_bytes": (_sz, [_i]),
+    "pcd_rulebook_conv_classes": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_sparse_conv_dgrad_classes": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
+                                           _i, _vp, _vp]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,

@@ -686,6 +686,128 @@ extern "C" int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_sha
     return PCD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parity classes of the INPUT rows of a strided conv.  Input coordinate c reaches an output cell through kernel
+// index k only if (c + p - k*d) is a multiple of the stride, so the residues ((c + p) mod s) of the three axes pick
+// the 1..8 offsets (of 27 for k = 3, s = 2) a row can use at all.  The data gradient of a strided conv run over
+// rows in their natural order executes all K offsets for every tile although 66 % of the (tile, offset) steps are
+// empty; grouped by residue class every tile runs only its class's offsets.
+//   perm   [vcap] : virtual row -> input row, -1 = padding; class segments start at multiples of `tile`
+//   vstart [ncls + 1] (device): first virtual row of every class, vstart[ncls] = end
+// The order inside a class is the input-row order (stable), so results do not depend on scheduling.
+constexpr int CLS_MAX = 8;
+
+__device__ __forceinline__ int row_class(int4 c, int pd, int ph, int pw, int sd, int sh, int sw) {
+    return (((c.y + pd) % sd) * sh + ((c.z + ph) % sh)) * sw + ((c.w + pw) % sw);
+}
+
+__global__ __launch_bounds__(256) void cls_count_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                        ConvGeom G, int ncls, int *__restrict__ blk_cnt) {
+    __shared__ int cnt[CLS_MAX];
+    if (threadIdx.x < CLS_MAX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int cls = -1;
+    if (i < eff_rows(n_dev, n)) cls = row_class(idx[i], G.pd, G.ph, G.pw, G.sd, G.sh, G.sw);
+    for (int q = 0; q < ncls; ++q) {
+        u64 m = __ballot(cls == q);
+        if (lane_id() == 0 && m) atomicAdd(&cnt[q], __popcll(m));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncls) blk_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// one block, one WAVE per class: blk_cnt[cls][blk] -> virtual row of the block's first row of that class
+// (exclusive prefix inside the class + the tile-aligned class start)
+__global__ __launch_bounds__(64 * CLS_MAX) void cls_offsets_kernel(int *blk_cnt, int nblk, int ncls, int tile,
+                                                                   int *vstart) {
+    __shared__ int tot[CLS_MAX];
+    __shared__ int start[CLS_MAX + 1];
+    const int q = threadIdx.x >> 6;
+    int *row = blk_cnt + (size_t)q * nblk;
+    if (q < ncls) {
+        int carry = 0;
+        for (int base = 0; base < nblk; base += 64) {
+            const int i = base + lane_id();
+            const int v = (i < nblk) ? row[i] : 0;
+            const int inc = wave_inclusive_scan(v);
+            if (i < nblk) row[i] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (lane_id() == 0) tot[q] = carry;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int vb = 0;
+        for (int c = 0; c < ncls; ++c) {
+            start[c] = vb;
+            vstart[c] = vb;
+            vb = (vb + tot[c] + tile - 1) / tile * tile;
+        }
+        vstart[ncls] = vb;
+    }
+    __syncthreads();
+    if (q < ncls) {
+        const int st = start[q];
+        for (int i = lane_id(); i < nblk; i += 64) row[i] += st;
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_fill_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                       ConvGeom G, int ncls, const int *__restrict__ blk_off,
+                                                       int32_t *__restrict__ perm) {
+    __shared__ int wcnt[4][CLS_MAX];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int cls = -1;
+    if (i < eff_rows(n_dev, n)) cls = row_class(idx[i], G.pd, G.ph, G.pw, G.sd, G.sh, G.sw);
+    const int w = threadIdx.x >> 6;
+    const u64 lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+    int rank = 0;
+    for (int q = 0; q < ncls; ++q) {
+        u64 m = __ballot(cls == q);
+        if (cls == q) rank = __popcll(m & lt);
+        if (lane_id() == 0) wcnt[w][q] = __popcll(m);
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        int before = 0;
+        for (int ww = 0; ww < w; ++ww) before += wcnt[ww][cls];
+        perm[blk_off[(size_t)cls * gridDim.x + blockIdx.x] + before + rank] = i;
+    }
+}
+
+extern "C" size_t pcd_rulebook_conv_classes_workspace_bytes(int n) {
+    if (n < 0) return 0;
+    return ws_piece((size_t)CLS_MAX * pcd_div_up(n > 0 ? n : 1, 256), sizeof(int));
+}
+
+extern "C" int pcd_rulebook_conv_classes(const int32_t *indices, int n, const int *stride_host, const int *pad_host,
+                                         int tile, int32_t *perm, int vcap, int32_t *vstart_dev,
+                                         const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+    PCD_ENTER();
+    if (n < 0 || !stride_host || !pad_host || tile <= 0 || !perm || !vstart_dev) return PCD_ERR_INVALID_ARG;
+    ConvGeom G = {};
+    G.sd = stride_host[0]; G.sh = stride_host[1]; G.sw = stride_host[2];
+    G.pd = pad_host[0]; G.ph = pad_host[1]; G.pw = pad_host[2];
+    if (G.sd <= 0 || G.sh <= 0 || G.sw <= 0 || G.pd < 0 || G.ph < 0 || G.pw < 0) return PCD_ERR_INVALID_ARG;
+    const int ncls = G.sd * G.sh * G.sw;
+    if (ncls > CLS_MAX) return PCD_ERR_UNSUPPORTED;
+    if (vcap < (n + tile - 1) / tile * tile + ncls * tile) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && !indices) return PCD_ERR_INVALID_ARG;
+    const int nblk = pcd_div_up(n > 0 ? n : 1, 256);
+    WsCarver ws(workspace, workspace_bytes);
+    int *blk_cnt = ws.take<int>((size_t)CLS_MAX * nblk);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    pcd_fill(perm, 0xFF, (size_t)vcap * sizeof(int32_t), st);
+    cls_count_kernel<<<nblk, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, ncls, blk_cnt);
+    cls_offsets_kernel<<<1, 64 * CLS_MAX, 0, st>>>(blk_cnt, nblk, ncls, tile, vstart_dev);
+    cls_fill_kernel<<<nblk, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, ncls, blk_cnt, perm);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
 extern "C" size_t pcd_rulebook_conv_workspace_bytes(int n, int batch, const int *in_shape_host,
                                                     const int *ksize_host, const int *stride_host,
                                                     const int *pad_host, const int *dil_host) {

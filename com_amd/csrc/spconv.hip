@@ -390,6 +390,186 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
+// rows all share the residues ((c + p) mod s) of the three axes, hence the same 1..8 usable offsets (of 27 for
+// k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
+// two thirds of its (tile, offset) steps are empty.  Same arithmetic in the same order (skipped steps add exact
+// zeros), so the result is bit-identical to the generic kernel's.
+struct ClsTable {
+    int ncls;
+    int nk[8];
+    int k[8][8];   // usable kernel offsets of class c, ascending
+};
+
+template <int NB, int MI, bool OUT_BF16>
+__global__ __launch_bounds__(256) void gather_gemm_cls_kernel(
+    const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
+    const int32_t *__restrict__ nbr, int nbr_stride, int K, const int32_t *__restrict__ perm,
+    const int32_t *__restrict__ vstart, ClsTable T, void *__restrict__ yv, int nsteps_total, unsigned x_bytes,
+    const void *__restrict__ addend) {
+    constexpr int ROWS = 4 * MI * 16;
+    constexpr int VEC = NB * 64;                           // uint4 per weight stage (one contraction step)
+    constexpr int WPT = (VEC + 255) / 256;
+    constexpr int c_out = NB * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *wbuf = (uint4 *)smem;                           // [2][VEC]
+    int *row_s = (int *)(smem + (size_t)2 * VEC * sizeof(uint4));   // [ROWS] real row of every tile row, or -1
+    int *nbr_s = row_s + ROWS;                             // [8 + 1][ROWS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    const int tiles_per_xcd = gridDim.x >> 3;
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    const int v0 = tile * ROWS;
+    if (v0 >= vstart[T.ncls]) return;
+    int cls_v = 0;
+    for (int q = 1; q < T.ncls; ++q)
+        if (vstart[q] <= v0) cls_v = q;
+    // the class is uniform over the workgroup: keep it in an SGPR so that the by-value table is read with scalar
+    // loads (a divergent index would make the compiler copy the whole struct to scratch memory per thread)
+    const int cls = __builtin_amdgcn_readfirstlane(cls_v);
+    const int nk = T.nk[cls];
+    int *kk_s = nbr_s + 9 * ROWS;                          // [8] usable offsets of this class
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk_s[j] = T.k[cls][j];
+    }
+    const int spk_shift = cshift - 5;                      // log2(contraction steps per offset)
+    const int S = nk << spk_shift;
+    const unsigned wtotal = (unsigned)nsteps_total * VEC;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)(wtotal * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    auto real_step = [&](int s) {                          // contraction step s of this class -> step of the pack
+        const int j = s >> spk_shift;
+        return j < nk ? (kk_s[j] << spk_shift) + (s & ((1 << spk_shift) - 1)) : nsteps_total;
+    };
+    for (int r = threadIdx.x; r < ROWS; r += 256) row_s[r] = perm[v0 + r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < (nk + 1) * ROWS; e += 256) {
+        const int j = e / ROWS, r = e - j * ROWS;
+        const int i = row_s[r];
+        nbr_s[e] = (j < nk && i >= 0) ? nbr[(size_t)kk_s[j] * nbr_stride + i] : -1;
+    }
+    u32x4 wreg[WPT];
+    auto load_w = [&](int s) {
+        const unsigned base = (unsigned)real_step(s) * VEC;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const unsigned e = (unsigned)(j * 256) + threadIdx.x;
+            wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, e < (unsigned)VEC ? (base + e) * 16u : 0xFFFFFFF0u, 0, 0);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const unsigned e = (unsigned)(j * 256) + threadIdx.x;
+            if (e < (unsigned)VEC) reinterpret_cast<u32x4 *>(wbuf)[buf * VEC + e] = wreg[j];
+        }
+    };
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+
+    f32x4 acc[MI][NB];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tile_row = wave * (MI * 16) + rl;
+    const int row_shift = cshift + 1;
+    auto gather = [&](int s, u32x4(&a)[MI], bool &valid) {
+        const int j = min(s >> spk_shift, nk);             // beyond the class's offsets: the all -1 row
+        const unsigned c0b = (unsigned)(((s & ((1 << spk_shift) - 1)) * 32 + g * 8) * 2);
+        valid = false;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int i = nbr_s[j * ROWS + tile_row + mi * 16];
+            a[mi] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((unsigned)i << row_shift) + c0b, 0, 0);
+            valid |= (i >= 0);
+        }
+    };
+    auto compute = [&](int cur, const u32x4(&a)[MI], bool valid) {
+        if (__any(valid)) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bf16x8 b = as_bf16x8(wbuf[cur * VEC + nb * 64 + lane]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, __builtin_bit_cast(bf16x8, a[mi]),
+                                                                          acc[mi][nb], 0, 0, 0);
+            }
+        }
+    };
+    u32x4 a0[MI], a1[MI];
+    bool v0v, v1v;
+    gather(0, a0, v0v);
+    for (int s = 0; s < S; s += 2) {
+        load_w(s + 1);
+        gather(s + 1, a1, v1v);
+        compute(0, a0, v0v);
+        store_w(1);
+        __syncthreads();
+        load_w(s + 2);
+        gather(s + 2, a0, v0v);
+        compute(1, a1, v1v);                                // step S (odd S): all -1 -> skipped
+        store_w(0);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_s[tile_row + mi * 16];
+        if (row < 0) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 16 + g * 4;
+            f32x4 v = acc[mi][nb];
+            if (OUT_BF16) {
+                if (addend) {
+                    uint2 ad = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + (size_t)row * c_out + col);
+                    v[0] += __uint_as_float(ad.x << 16);
+                    v[1] += __uint_as_float(ad.x & 0xffff0000u);
+                    v[2] += __uint_as_float(ad.y << 16);
+                    v[3] += __uint_as_float(ad.y & 0xffff0000u);
+                }
+                unsigned short *y = (unsigned short *)yv + (size_t)row * c_out + col;
+                uint2 o;
+                o.x = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
+                o.y = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(y) = o;
+            } else {
+                if (addend) {
+                    float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + (size_t)row * c_out + col);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+                float *y = (float *)yv + (size_t)row * c_out + col;
+                *reinterpret_cast<float4 *>(y) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int NB, int MI>
+static int launch_gg_cls(const void *x, int c_in, int cshift, const void *wp, const int32_t *nbr, int nbr_stride,
+                         int K, const int32_t *perm, const int32_t *vstart, const ClsTable &T, int vcap, void *y,
+                         int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend) {
+    constexpr int ROWS = 4 * MI * 16;
+    int grid = pcd_div_up(pcd_div_up(vcap, ROWS), 8) * 8;
+    size_t lds = (size_t)2 * NB * 64 * sizeof(uint4) + (size_t)(1 + 9) * ROWS * sizeof(int) + 8 * sizeof(int);
+    if (y_dtype == PCD_BF16)
+        gather_gemm_cls_kernel<NB, MI, true><<<grid, 256, lds, st>>>(
+            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
+            nsteps, x_bytes, addend);
+    else
+        gather_gemm_cls_kernel<NB, MI, false><<<grid, 256, lds, st>>>(
+            (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
+            nsteps, x_bytes, addend);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient
 template <int C>
 struct WgradStride {  // elements; C/16 even -> pad by 16 elements (8 dwords)
@@ -766,6 +946,62 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
             return PCD_ERR_UNSUPPORTED;
     }
 #undef GG_ARGS
+}
+
+extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const void *packed_w,
+                                             const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
+                                             const int *stride_host, const int *pad_host, const int *dil_host,
+                                             const int32_t *perm, const int32_t *vstart_dev, int vcap,
+                                             int n_rows_in, int c_in, void *dx, int dx_dtype, const void *addend,
+                                             void *stream) {
+    PCD_ENTER();
+    if (!ksize_host || !stride_host || !pad_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (n_rows_in < 0 || vcap < 0 || c_dy <= 0 || c_in <= 0) return PCD_ERR_INVALID_ARG;
+    if (dx_dtype != PCD_BF16 && dx_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
+    if (n_rows_in == 0 || vcap == 0) return PCD_OK;
+    if (!dy || !packed_w || !nbr_in || !perm || !vstart_dev || !dx || nbr_stride < n_rows_in)
+        return PCD_ERR_INVALID_ARG;
+    const int cshift = log2_exact(c_dy);
+    if (cshift < 5 || (c_in % 16) != 0) return PCD_ERR_UNSUPPORTED;   // a contraction step must stay inside one offset
+    if (n_dy_rows < 0 || (double)n_dy_rows * c_dy * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
+    const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
+    ClsTable T = {};
+    T.ncls = stride_host[0] * stride_host[1] * stride_host[2];
+    if (T.ncls > 8 || T.ncls <= 0) return PCD_ERR_UNSUPPORTED;
+    for (int rz = 0; rz < stride_host[0]; ++rz)
+        for (int ry = 0; ry < stride_host[1]; ++ry)
+            for (int rx = 0; rx < stride_host[2]; ++rx) {
+                const int cls = (rz * stride_host[1] + ry) * stride_host[2] + rx;
+                int cnt = 0;
+                for (int kz = 0; kz < ksize_host[0]; ++kz)
+                    for (int ky = 0; ky < ksize_host[1]; ++ky)
+                        for (int kx = 0; kx < ksize_host[2]; ++kx) {
+                            auto ok = [](int r, int k, int d, int st_) { return (((r - k * d) % st_) + st_) % st_ == 0; };
+                            if (ok(rz, kz, dil_host[0], stride_host[0]) && ok(ry, ky, dil_host[1], stride_host[1]) &&
+                                ok(rx, kx, dil_host[2], stride_host[2])) {
+                                if (cnt >= 8) return PCD_ERR_UNSUPPORTED;
+                                T.k[cls][cnt++] = (kz * ksize_host[1] + ky) * ksize_host[2] + kx;
+                            }
+                        }
+                T.nk[cls] = cnt;
+            }
+    const unsigned x_bytes = (unsigned)((size_t)n_dy_rows * c_dy * 2);
+    const int nsteps = (K * c_dy + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    // a class tile runs only 1..8 of the K offsets: little work per workgroup, so small tiles (more workgroups in
+    // flight) hide its prologue better than the generic kernel's row-count rule
+    const int mi = n_rows_in >= 64 * 1024 ? 2 : 1;   // (measured: 1 / 2 / 4 within 10 % of each other)
+#define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend
+#define CLS_MI(NBV) (mi == 4 ? launch_gg_cls<NBV, 4>(CLS_ARGS) : mi == 2 ? launch_gg_cls<NBV, 2>(CLS_ARGS) : launch_gg_cls<NBV, 1>(CLS_ARGS))
+    switch (c_in / 16) {
+        case 1: return CLS_MI(1);
+        case 2: return CLS_MI(2);
+        case 4: return CLS_MI(4);
+        case 8: return CLS_MI(8);
+        default: return PCD_ERR_UNSUPPORTED;
+    }
+#undef CLS_MI
+#undef CLS_ARGS
 }
 
 extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax) {

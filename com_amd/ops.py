@@ -219,6 +219,7 @@ class Rulebook:
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.rank = None          # RankMap of the output level (strided builds only)
+        self.classes = None       # (perm, vstart, vcap): input rows grouped by stride-parity class (strided, training)
 
     def inverse(self):
         """Rulebook of SparseInverseConv3d sharing this indice_key."""
@@ -332,7 +333,38 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     nw = int(nwords.value)
     rb.rank = RankMap(ws, ws[boff.value:boff.value + 4 * nw].view(torch.int32),
                       ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape)
+    if want_pairs and st[0] * st[1] * st[2] <= 8:
+        # training: input rows grouped by stride-parity class for the data gradient (dgrad_classes)
+        ncls = st[0] * st[1] * st[2]
+        vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
+        perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
+        vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
+        cws = _ws(lib.pcd_rulebook_conv_classes_workspace_bytes(n), dev)
+        L.check(lib.pcd_rulebook_conv_classes(L.ptr(indices), n, L.host_i32(st), L.host_i32(pd), CLS_TILE, L.ptr(perm),
+                                              vcap, L.ptr(vstart), L.ptr(n_dev), L.ptr(cws), cws.numel(),
+                                              L.stream_ptr()), "pcd_rulebook_conv_classes")
+        rb.classes = (perm, vstart, vcap)
     return rb
+
+
+CLS_TILE = 256
+
+
+def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None):
+    """Data gradient of the strided conv `rb` over its parity-class row groups: dx [n_in, c_in].
+    Same result as gather_gemm(dy, packed_w, None, rb.nbr_in, ...), running only the offsets each class can use."""
+    _require_cuda(dy, packed_w)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and rb.classes is not None
+    perm, vstart, vcap = rb.classes
+    dx = torch.empty((rb.n_in, c_in), dtype=out_dtype, device=dy.device)
+    if addend is not None:
+        assert addend.shape == dx.shape and addend.dtype == dx.dtype and addend.is_contiguous()
+    L.check(L.lib().pcd_sparse_conv_dgrad_classes(
+        L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(rb.nbr_in), rb.nbr_in.shape[1],
+        L.host_i32(rb.ksize), L.host_i32(rb.stride), L.host_i32(rb.padding), L.host_i32(rb.dilation), L.ptr(perm),
+        L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), L.stream_ptr()),
+        "pcd_sparse_conv_dgrad_classes")
+    return dx
 
 
 # ---------------------------------------------------------------------------------------------

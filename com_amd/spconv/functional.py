@@ -18,6 +18,7 @@ WGRAD_JOIN_LAG = 0
 # dgamma / dbeta straight into `.grad` and autograd gets None for them -- no temporary, no AccumulateGrad add
 # kernel per parameter (79 tiny launches per step on the critical path of VoxelResBackBone8x).
 DIRECT_GRAD = False
+USE_DGRAD_CLASSES = True      # strided-conv data gradient over parity-class row groups (ops.dgrad_classes)
 _SIDE = {}
 _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not yet joined
 
@@ -139,6 +140,10 @@ class SparseConvFunction(Function):
             if rb.subm:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
+            elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
+                    and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
+                # strided conv: rows grouped by parity class run only the 1..8 offsets they can use
+                dxp = ops.dgrad_classes(dy16, packed_d, rb, ctx.cin_pad, ctx.in_dtype, addend=add)
             else:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)

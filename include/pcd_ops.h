@@ -165,6 +165,24 @@ int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int
                              int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* Parity classes of the input rows of a strided conv, for its data gradient: input coordinate c reaches an output
+ * cell through kernel index k only if (c + p - k*d) is a multiple of the stride, so the residues ((c + p) mod s) of
+ * the three axes select the 1..8 offsets (of 27 for k = 3, s = 2) a row can use at all.
+ *   perm   [vcap] i32 : virtual row -> input row (stable inside a class), -1 = padding; every class starts at a
+ *                       multiple of `tile`; vcap >= round_up(n, tile) + (sd*sh*sw) * tile
+ *   vstart [sd*sh*sw + 1] i32 on the DEVICE: first virtual row of every class, last entry = end.
+ * pcd_sparse_conv_dgrad_classes then runs, per class, only that class's offsets (bit-identical to
+ * pcd_sparse_conv_gather_gemm on nbr_in; c_dy >= 32, a power of two; tile must be 256). */
+size_t pcd_rulebook_conv_classes_workspace_bytes(int n);
+int pcd_rulebook_conv_classes(const int32_t *indices, int n, const int *stride_host, const int *pad_host, int tile,
+                              int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const void *packed_w,
+                                  const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
+                                  const int *stride_host, const int *pad_host, const int *dil_host,
+                                  const int32_t *perm, const int32_t *vstart_dev, int vcap, int n_rows_in, int c_in,
+                                  void *dx, int dx_dtype, const void *addend, void *stream);
+
 /* ============================================================================================
  * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
  *
