@@ -110,7 +110,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, 
     float acc[2][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    // 4 pieces in flight per thread: with 2 workgroups per CU a thread's 4-5 pieces otherwise cost one full memory
+    // latency EACH (the same accumulation order as the plain loop, so results do not change)
+    const size_t S = (size_t)gridDim.x * 256;
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; e + 3 * S < total; e += 4 * S) {
+        float v[4][N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Piece<T>::load(x + (e + u * S) * N, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                acc[0][j] += v[u][j];
+                acc[1][j] += v[u][j] * v[u][j];
+            }
+    }
+    for (; e < total; e += S) {
         float v[N];
         Piece<T>::load(x + e * N, v);
 #pragma unroll
@@ -264,11 +280,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
     float acc[2][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        float g[N], xv[N], yv[N];
-        Piece<T>::load(dy + e * N, g);
-        Piece<T>::load(x + e * N, xv);
-        if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
+    auto accumulate = [&](const float (&g)[N], const float (&xv)[N], const float (&yv)[N]) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float t = mask_from_x ? xv[j] * sc[j] + sh[j] : yv[j];
@@ -276,6 +288,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
             acc[0][j] += dz;
             acc[1][j] += dz * (xv[j] - mu[j]) * is[j];
         }
+    };
+    // two rows of loads (4-6 x 16 bytes) in flight per thread, same accumulation order as the plain loop
+    const size_t S = (size_t)gridDim.x * 256;
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; e + S < total; e += 2 * S) {
+        float g[2][N], xv[2][N], yv[2][N];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Piece<T>::load(dy + (e + u * S) * N, g[u]);
+            Piece<T>::load(x + (e + u * S) * N, xv[u]);
+            if (relu && !mask_from_x) Piece<T>::load(y + (e + u * S) * N, yv[u]);
+        }
+        accumulate(g[0], xv[0], yv[0]);
+        accumulate(g[1], xv[1], yv[1]);
+    }
+    for (; e < total; e += S) {
+        float g[N], xv[N], yv[N];
+        Piece<T>::load(dy + e * N, g);
+        Piece<T>::load(x + e * N, xv);
+        if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
+        accumulate(g, xv, yv);
     }
     block_reduce_store<N, 2>(acc, c, pcs, partial, lds);
 }
