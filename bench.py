@@ -316,40 +316,65 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             plan.recorded.clear()
-            # three graphs: voxelisation | forward+backward | clip+Adam.  The voxelisation of batch i+1 is
+            # N > 1: three graphs, voxelisation | forward+backward | clip+Adam.  The voxelisation of batch i+1 is
             # replayed on a second stream as soon as forward+backward of batch i has finished, i.e. beside the
             # gradient all-reduce and the optimizer of step i (the reference voxelises in DataLoader workers,
             # asynchronously to the training step); it owns its memory pool because it runs concurrently with
             # the optimizer graph.  Every timed step still contains exactly one voxelisation.
-            g_vox, g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_vox):
-                vox_out = voxelize(s_pts, s_offs)
-            with torch.cuda.graph(g_fb):
-                train_from_voxels(vox_out)
-            with torch.cuda.graph(g_opt, pool=g_fb.pool()):
-                opt_step()
             vox_stream = torch.cuda.Stream()
-            ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
+            if world == 1:
+                # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
+                # voxelisation of the next batch (a forked branch that ends by copying its outputs into the
+                # buffers the next replay reads first).  Two graph boundaries per step less than the N > 1 form.
+                vox_out = voxelize(s_pts, s_offs)
+                torch.cuda.synchronize()
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all):
+                    cur = torch.cuda.current_stream()
+                    train_from_voxels(vox_out)
+                    vox_stream.wait_stream(cur)
+                    with torch.cuda.stream(vox_stream):
+                        vox_next = voxelize(s_pts, s_offs)
+                        for key, dst in vox_out.items():
+                            if torch.is_tensor(dst):
+                                dst.copy_(vox_next[key])
+                    opt_step()
+                    cur.wait_stream(vox_stream)
 
-            def prefetch_voxels(i):
-                pts, offs = batches[i % 2]
-                with torch.cuda.stream(vox_stream):
-                    vox_stream.wait_event(ev_fb)             # the previous forward+backward still reads vox_out
-                    s_pts.copy_(pts, non_blocking=True)      # device -> device: the batch is already in HBM
+                def run_step(i):
+                    pts, offs = batches[(i + 1) % 2]             # the batch this replay voxelises for the next one
+                    s_pts.copy_(pts, non_blocking=True)          # device -> device: the batch is already in HBM
                     s_offs.copy_(offs, non_blocking=True)
-                    g_vox.replay()
-                    ev_vox.record(vox_stream)
+                    g_all.replay()
+            else:
+                g_vox, g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_vox):
+                    vox_out = voxelize(s_pts, s_offs)
+                with torch.cuda.graph(g_fb):
+                    train_from_voxels(vox_out)
+                with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+                    opt_step()
+                ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
 
-            def run_step(i):
-                cur = torch.cuda.current_stream()
-                cur.wait_event(ev_vox)                       # voxels of batch i
-                g_fb.replay()
-                ev_fb.record(cur)
-                prefetch_voxels(i + 1)
-                bucket.all_reduce_mean()
-                g_opt.replay()
-            ev_fb.record(torch.cuda.current_stream())
-            prefetch_voxels(0)
+                def prefetch_voxels(i):
+                    pts, offs = batches[i % 2]
+                    with torch.cuda.stream(vox_stream):
+                        vox_stream.wait_event(ev_fb)         # the previous forward+backward still reads vox_out
+                        s_pts.copy_(pts, non_blocking=True)  # device -> device: the batch is already in HBM
+                        s_offs.copy_(offs, non_blocking=True)
+                        g_vox.replay()
+                        ev_vox.record(vox_stream)
+
+                def run_step(i):
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev_vox)                   # voxels of batch i
+                    g_fb.replay()
+                    ev_fb.record(cur)
+                    prefetch_voxels(i + 1)
+                    bucket.all_reduce_mean()
+                    g_opt.replay()
+                ev_fb.record(torch.cuda.current_stream())
+                prefetch_voxels(0)
             for i in range(2):
                 run_step(i)
             torch.cuda.synchronize()
@@ -403,7 +428,7 @@ def main():
                                "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
                    "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
-                   "execution": "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd | all-reduce | clip+Adam), device-side row counts"
+                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if world == 1 else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd | all-reduce | clip+Adam)") + ", device-side row counts"
                                 if use_graph else "eager launches"},
     }
 
