@@ -102,10 +102,40 @@ class SparseConvFunction(Function):
         # and is joined before returning (fork/join is captured as such in hipGraph mode).
         side = None
         cur = torch.cuda.current_stream()
+        # The data gradient is issued FIRST and the weight gradient forks from an event recorded before it: in a
+        # captured graph the first successor of a node stays on its hardware queue, and the main chain
+        # (BatchNorm backward -> dgrad -> BatchNorm backward ...) should be the one that never changes queues --
+        # a cross-queue dependency costs several microseconds, a same-queue one ~1.5.
+        ready = None
+        if OVERLAP_WGRAD and ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or
+                                                         (ctx.has_bias and ctx.needs_input_grad[2])):
+            ready = torch.cuda.Event()
+            ready.record(cur)
+        if ctx.needs_input_grad[0]:
+            if ctx.cin_pad % 16 != 0:
+                raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
+                                   "requires an input gradient)")
+            packed_d = ctx.packed_dgrad() if ctx.packed_dgrad is not None else ops.pack_weight(weight, 1)
+            add = None
+            if d_ident is not None and ctx.cin_pad == ctx.in_cols and d_ident.dtype == ctx.in_dtype:
+                add = d_ident.contiguous()           # fused: dx = dgrad + identity-branch gradient
+            if rb.subm:
+                dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
+            elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
+                    and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
+                # strided conv: rows grouped by parity class run only the 1..8 offsets they can use
+                dxp = ops.dgrad_classes(dy16, packed_d, rb, ctx.cin_pad, ctx.in_dtype, addend=add)
+            else:
+                dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
+            dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
+            if d_ident is not None and add is None:
+                dx = dx + d_ident.to(dx.dtype)
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if OVERLAP_WGRAD and want_w and ctx.needs_input_grad[0]:
             side = _side_stream(dy16.device)
-            side.wait_stream(cur)
+            side.wait_event(ready)                   # dy16 is complete (recorded BEFORE the dgrad was issued)
         bias_p = ctx.bias_param
         weight_p = ctx.weight_param
         direct_w = DIRECT_GRAD and weight_p is not None and weight_p.grad is not None \
@@ -129,27 +159,6 @@ class SparseConvFunction(Function):
         if deferred:
             _PENDING.append((ev, x, dy16))           # inputs stay alive until the lagged join below
             side = None
-        if ctx.needs_input_grad[0]:
-            if ctx.cin_pad % 16 != 0:
-                raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
-                                   "requires an input gradient)")
-            packed_d = ctx.packed_dgrad() if ctx.packed_dgrad is not None else ops.pack_weight(weight, 1)
-            add = None
-            if d_ident is not None and ctx.cin_pad == ctx.in_cols and d_ident.dtype == ctx.in_dtype:
-                add = d_ident.contiguous()           # fused: dx = dgrad + identity-branch gradient
-            if rb.subm:
-                dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
-            elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
-                    and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
-                # strided conv: rows grouped by parity class run only the 1..8 offsets they can use
-                dxp = ops.dgrad_classes(dy16, packed_d, rb, ctx.cin_pad, ctx.in_dtype, addend=add)
-            else:
-                dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
-            dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
-            if d_ident is not None and add is None:
-                dx = dx + d_ident.to(dx.dtype)
         if deferred and len(_PENDING) > WGRAD_JOIN_LAG:
             cur.wait_event(_PENDING[-1 - WGRAD_JOIN_LAG][0])
             del _PENDING[:len(_PENDING) - WGRAD_JOIN_LAG]
