@@ -244,12 +244,14 @@ def main():
 
     last = {}
 
-    def voxelize(pts, offs):
+    def voxelize(pts, offs, out=None):
         """hard voxelisation + fused MeanVFE of one batch (what the reference's DataLoader workers do on the CPU)"""
         bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
         bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
-                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True)
-        bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B}
+                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True,
+                                                out=out["_result"] if out is not None else None)
+        bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B,
+               "_result": bd["voxelize_result"]}
         if "voxel_num_rows" in bd:
             bd2["voxel_num_rows"] = bd["voxel_num_rows"]
         if not (ops.PLAN is not None and ops.PLAN.active):
@@ -324,8 +326,8 @@ def main():
             vox_stream = torch.cuda.Stream()
             if world == 1:
                 # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
-                # voxelisation of the next batch (a forked branch that ends by copying its outputs into the
-                # buffers the next replay reads first).  Two graph boundaries per step less than the N > 1 form.
+                # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
+                # first).  Two graph boundaries per step less than the N > 1 form.
                 vox_out = voxelize(s_pts, s_offs)
                 torch.cuda.synchronize()
                 g_all = torch.cuda.CUDAGraph()
@@ -334,10 +336,8 @@ def main():
                     train_from_voxels(vox_out)
                     vox_stream.wait_stream(cur)
                     with torch.cuda.stream(vox_stream):
-                        vox_next = voxelize(s_pts, s_offs)
-                        for key, dst in vox_out.items():
-                            if torch.is_tensor(dst):
-                                dst.copy_(vox_next[key])
+                        vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
+                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
                     opt_step()
                     cur.wait_stream(vox_stream)
 

@@ -115,10 +115,12 @@ def grid_size(point_cloud_range, voxel_size):
 
 # ---------------------------------------------------------------------------------------------
 def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
-                  feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0):
+                  feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None):
     """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
     rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
-    voxel_features, voxel_features_bf16, counts (host list per frame))."""
+    voxel_features, voxel_features_bf16, counts (host list per frame)).
+    `out` (static-shape mode): the dict a previous call returned -- its tensors are written again instead of
+    allocating new ones (a prefetched voxelisation then lands in the buffers the consumer already holds)."""
     _require_cuda(points)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
     dev = points.device
@@ -135,13 +137,20 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         cap = min(cap, PLAN.cap("voxels"))
     lib = L.lib()
     ws = _ws(lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch), dev)
-    voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
-    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
-    mean = torch.empty((cap, C), dtype=torch.float32, device=dev) if want_mean else None
-    mean16 = (torch.empty((cap, mean_bf16_stride), dtype=torch.bfloat16, device=dev)
-              if mean_bf16_stride else None)
-    counts = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    def buf(key, shape, dtype, want=True):
+        if not want:
+            return None
+        t = out.get(key) if (out is not None and static) else None
+        if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == dev:
+            return t
+        return torch.empty(shape, dtype=dtype, device=dev)
+
+    voxels = buf("voxels", (cap, max_points, C), torch.float32, want_voxels)
+    coords = buf("coords", (cap, 4), torch.int32)
+    nump = buf("num_points", (cap,), torch.int32)
+    mean = buf("voxel_features", (cap, C), torch.float32, want_mean)
+    mean16 = buf("voxel_features_bf16", (cap, mean_bf16_stride), torch.bfloat16, bool(mean_bf16_stride))
+    counts = buf("counts", (batch + 1,), torch.int32)
     L.check(lib.pcd_voxelize_hard(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
                                   L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
                                   max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
