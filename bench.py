@@ -324,7 +324,7 @@ def main():
             # asynchronously to the training step); it owns its memory pool because it runs concurrently with
             # the optimizer graph.  Every timed step still contains exactly one voxelisation.
             vox_stream = torch.cuda.Stream()
-            if world == 1:
+            if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH'):   # (the switch exercises the N > 1 form on one GPU)
                 # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
                 # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
                 # first).  Two graph boundaries per step less than the N > 1 form.
