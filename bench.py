@@ -280,14 +280,15 @@ def main():
     opt.grad_scale = clip_div        # fused Adam divides the gradients by this inside its kernel
 
     def opt_step():
-        bucket.clip_divisor_(10.0, clip_div)                 # centerpoint.yaml:96 GRAD_NORM_CLIP (norm + clamp only)
+        # mean over the ranks + centerpoint.yaml:96 GRAD_NORM_CLIP, both folded into Adam's grad_scale
+        bucket.clip_divisor_(10.0, clip_div, pre_divisor=float(world))
         opt.step()
 
     def eager_step(i, ev=None):
         pts, offs = batches[i % 2]
         fwd_bwd(pts, offs, ev)
         if ev is not None: ev("allreduce")
-        bucket.all_reduce_mean()                             # RCCL over xGMI (no-op at N = 1)
+        bucket.all_reduce_sum()                              # RCCL over xGMI (no-op at N = 1)
         if ev is not None: ev("optimizer")
         opt_step()
         if ev is not None: ev("end")
@@ -371,7 +372,7 @@ def main():
                     g_fb.replay()
                     ev_fb.record(cur)
                     prefetch_voxels(i + 1)
-                    bucket.all_reduce_mean()
+                    bucket.all_reduce_sum()
                     g_opt.replay()
                 ev_fb.record(torch.cuda.current_stream())
                 prefetch_voxels(0)

@@ -64,13 +64,20 @@ class FlatGradBucket:
         self.flat.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
         return norm
 
-    def clip_divisor_(self, max_norm, out):
-        """out <- max((||g|| + 1e-6) / max_norm, 1): the number the gradients must be DIVIDED by to implement
-        clip_grad_norm_.  Handing it to a fused optimizer as `grad_scale` (torch.optim.Adam(fused=True) divides the
-        gradients by it inside its kernel) saves the separate scaling pass over the whole buffer."""
-        norm = torch.linalg.vector_norm(self.flat)
-        out.copy_(torch.clamp((norm + 1e-6) / max_norm, min=1.0))
+    def clip_divisor_(self, max_norm, out, pre_divisor=1.0):
+        """out <- pre_divisor * max((||g / pre_divisor|| + 1e-6) / max_norm, 1): the number the gradients must be
+        DIVIDED by to implement (averaging over `pre_divisor` ranks +) clip_grad_norm_.  Handing it to a fused
+        optimizer as `grad_scale` (torch.optim.Adam(fused=True) divides the gradients by it inside its kernel)
+        saves the separate scaling passes over the whole buffer (mean after all_reduce_sum, clip coefficient)."""
+        norm = torch.linalg.vector_norm(self.flat) / pre_divisor
+        out.copy_(torch.clamp((norm + 1e-6) / max_norm, min=1.0) * pre_divisor)
         return out
+
+    def all_reduce_sum(self):
+        """Gradient SUM over the ranks (one collective); pair with clip_divisor_(..., pre_divisor=world_size)."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        return self.flat
 
     def zero(self):
         self.flat.zero_()

@@ -40,6 +40,13 @@ def _worker(rank, world, port, q):
     expect = sum(range(1, world + 1)) / world
     ok_bucket = all(torch.allclose(p.grad, torch.full_like(p, expect * (i + 1))) for i, p in enumerate(bucket.params))
     n_flat = bucket.flat.numel()
+    # sum-reduce + divisor form (what bench.py uses: the mean and the clip coefficient go into Adam's grad_scale)
+    for i, p in enumerate(bucket.params):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    bucket.all_reduce_sum()
+    div = bucket.clip_divisor_(1e9, torch.ones(()), pre_divisor=float(world))     # no clipping: divisor = world
+    ok_bucket = ok_bucket and abs(float(div) - world) < 1e-6 and all(
+        torch.allclose(p.grad / div, torch.full_like(p, expect * (i + 1))) for i, p in enumerate(bucket.params))
 
     # DDP's own reducer over the same parameters: grads of sum(p * (rank+1)) are averaged over ranks
     for p in model.parameters():
