@@ -75,13 +75,8 @@ def _pmc_traffic(kernel):
         return None
 
 
-def measure_roofline(step_fn):
-    """Roofline of the dominant HIP kernel of the step, measured LIVE: one extra training step runs with
-    HIP events (on the launch stream) around every sparse-conv kernel launch (com_amd.ops.PROFILE); launches
-    are grouped by kernel instantiation (the name rocprofv3 reports), the group with the largest total time
-    is the dominant kernel.  achieved = sum of ALGORITHMIC flops (2*P*Cin*Cout) or bytes (SURVEY.md 8d:
-    (N_in*Cin + N_out*Cout)*2 + 8*P + K*Cin*Cout*e) of its launches / sum of their durations.  The bound is
-    "mfma" when the group's arithmetic intensity is above the ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B)."""
+def _profiled_groups(step_fn):
+    """One extra step with HIP events around every sparse-conv kernel launch -> per-kernel-group totals."""
     ops.PROFILE = []
     try:
         step_fn()
@@ -92,15 +87,22 @@ def measure_roofline(step_fn):
     groups = {}
     for key, e0, e1, meta in recs:
         name = key.split(" ")[0] + (" " + key.split(" ")[1] if key.startswith("wgrad") else "")
-        g = groups.setdefault(name, dict(ms=0.0, bytes=0, flops=0, launches=0, members={}))
-        ms = e0.elapsed_time(e1)
-        g["ms"] += ms
+        g = groups.setdefault(name, dict(ms=0.0, bytes=0, flops=0, launches=0))
+        g["ms"] += e0.elapsed_time(e1)
         g["bytes"] += meta["bytes"]
         g["flops"] += meta["flops"]
         g["launches"] += 1
-        m = g["members"].setdefault(key, [0, 0.0])
-        m[0] += 1
-        m[1] += ms
+    return groups
+
+
+def measure_roofline(step_fn):
+    """Roofline of the dominant HIP kernel of the step, measured LIVE: one extra training step runs with
+    HIP events (on the launch stream) around every sparse-conv kernel launch (com_amd.ops.PROFILE); launches
+    are grouped by kernel instantiation (the name rocprofv3 reports), the group with the largest total time
+    is the dominant kernel.  achieved = sum of ALGORITHMIC flops (2*P*Cin*Cout) or bytes (SURVEY.md 8d:
+    (N_in*Cin + N_out*Cout)*2 + 8*P + K*Cin*Cout*e) of its launches / sum of their durations.  The bound is
+    "mfma" when the group's arithmetic intensity is above the ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B)."""
+    groups = _profiled_groups(step_fn)
     if not groups:
         return None
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
@@ -122,6 +124,21 @@ def measure_roofline(step_fn):
            "arithmetic_intensity_flop_per_byte": round(ai, 1),
            "other_frac": {"hbm": round(gbs / HBM_PEAK_GBS, 4), "mfma": round(tf / MFMA_BF16_PEAK_TF, 4)},
            "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
+    # the same kernel WITHOUT a concurrent weight-gradient kernel on the second stream (in the step the data
+    # gradient and the weight gradient of a layer overlap and stretch each other; this is the kernel by itself)
+    from com_amd.spconv import functional as Fsp
+    keep = Fsp.OVERLAP_WGRAD
+    Fsp.OVERLAP_WGRAD = False
+    try:
+        alone = _profiled_groups(step_fn).get(name)
+    finally:
+        Fsp.OVERLAP_WGRAD = keep
+    if alone and alone["ms"] > 0:
+        tf_a = alone["flops"] / (alone["ms"] * 1e-3) / 1e12
+        gb_a = alone["bytes"] / (alone["ms"] * 1e-3) / 1e9
+        out["isolated"] = {"avg_launch_us": round(1e3 * alone["ms"] / alone["launches"], 2),
+                           "achieved": round(tf_a if mfma_bound else gb_a, 2),
+                           "frac": round((tf_a / MFMA_BF16_PEAK_TF) if mfma_bound else (gb_a / HBM_PEAK_GBS), 4)}
     return out
 
 

@@ -368,11 +368,17 @@ def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None):
     dx = torch.empty((rb.n_in, c_in), dtype=out_dtype, device=dy.device)
     if addend is not None:
         assert addend.shape == dx.shape and addend.dtype == dx.dtype and addend.is_contiguous()
-    L.check(L.lib().pcd_sparse_conv_dgrad_classes(
-        L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(rb.nbr_in), rb.nbr_in.shape[1],
-        L.host_i32(rb.ksize), L.host_i32(rb.stride), L.host_i32(rb.padding), L.host_i32(rb.dilation), L.ptr(perm),
-        L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), L.stream_ptr()),
-        "pcd_sparse_conv_dgrad_classes")
+    def meta():
+        pairs = int((rb.nbr_in >= 0).sum().item())
+        return dict(bytes=(dy.shape[0] * dy.shape[1] + rb.n_in * c_in) * 2 + 8 * pairs + rb.kvol * dy.shape[1] * c_in * 2,
+                    flops=2 * pairs * dy.shape[1] * c_in, rows=rb.n_in, pairs=pairs)
+
+    with _Timed(f"gather_gemm_cls_kernel<NB={c_in // 16}> {dy.shape[1]}->{c_in} K={rb.kvol}", meta):
+        L.check(L.lib().pcd_sparse_conv_dgrad_classes(
+            L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(rb.nbr_in), rb.nbr_in.shape[1],
+            L.host_i32(rb.ksize), L.host_i32(rb.stride), L.host_i32(rb.padding), L.host_i32(rb.dilation), L.ptr(perm),
+            L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), L.stream_ptr()),
+            "pcd_sparse_conv_dgrad_classes")
     return dx
 
 
