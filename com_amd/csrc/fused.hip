@@ -80,10 +80,34 @@ static bool aligned16(const void *a, const void *b = nullptr, const void *c = nu
     return true;
 }
 
-// block-level reduction of per-thread piece accumulators -> partial[blockIdx][which][c]
+// block-level reduction of per-thread piece accumulators -> partial[blockIdx][which][c].
+// pcs <= 64: the lanes of a wave that own the same piece (lane % pcs) are summed with a shuffle butterfly, then
+// the 4 waves through 4 * NACC * c floats of LDS (4 KB at c = 128) -- the previous form staged all 256 threads
+// (16 KB), which kept these blocks from being scheduled beside the weight-gradient workgroups that fill the LDS.
+// Fixed summation tree -> deterministic.  `lds` is dynamic shared memory of bn_reduce_lds_bytes(c, N) bytes.
 template <int N, int NACC>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c, int pcs,
                                                    float *partial /*[gridDim.x][NACC][c]*/, float *lds) {
+    if (pcs <= 64) {
+        for (int off = pcs; off < 64; off <<= 1) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc[a][j] += __shfl_xor(acc[a][j], off);
+        }
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l < pcs) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int j = 0; j < N; ++j) lds[(w * NACC + a) * c + l * N + j] = acc[a][j];
+        }
+        __syncthreads();
+        for (int item = threadIdx.x; item < NACC * c; item += 256)
+            partial[(size_t)blockIdx.x * NACC * c + item] =
+                ((lds[item] + lds[NACC * c + item]) + lds[2 * NACC * c + item]) + lds[3 * NACC * c + item];
+        return;
+    }
     // lds: [256][NACC*N]
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -98,13 +122,16 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c,
         partial[((size_t)blockIdx.x * NACC + a) * c + ch] = s;
     }
 }
+static size_t bn_reduce_lds_bytes(int c, int N) {
+    return (c / N <= 64 ? (size_t)4 * 2 * c : (size_t)256 * 2 * N) * sizeof(float);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, int n_cap,
                                                        const int32_t *n_dev, int c,
                                                        float *__restrict__ partial) {
     constexpr int N = Piece<T>::N;
-    __shared__ float lds[256 * 2 * N];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     float acc[2][N];
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
                                                             const float *__restrict__ invstd, int relu,
                                                             float *__restrict__ partial, int vec) {
     constexpr int N = Piece<T>::N;
-    __shared__ float lds[256 * 2 * N];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
@@ -438,9 +465,9 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     if (training) {
         if (dtype == PCD_F32)
-            bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, n_dev, c, L.partial);
+            bn_stats_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
         else
-            bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, n_dev, c,
+            bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c,
                                                                   L.partial);
         bn_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, n, n_dev, c, gamma, beta, eps,
                                                                momentum, running_mean, running_var,
@@ -484,9 +511,9 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, c
     const int N = dtype == PCD_F32 ? 4 : 8;
     int grid = grid_for((size_t)n * (c / N), c / N);
     if (dtype == PCD_F32)
-        bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float *)x, n, n_dev, c, L.partial);
+        bn_stats_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
     else
-        bn_stats_kernel<unsigned short><<<grid, 256, 0, st>>>((const unsigned short *)x, n, n_dev, c, L.partial);
+        bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c, L.partial);
     col_sum_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -512,7 +539,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     const int vec = aligned16(gamma, beta, save_mean, save_invstd, dgamma, dbeta) ? 1 : 0;
     if (dtype == PCD_F32) {
-        bn_bwd_reduce_kernel<float><<<grid, 256, 0, st>>>((const float *)dy, (const float *)x,
+        bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                                                           save_invstd, relu, L.partial, vec);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
@@ -522,7 +549,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
                 save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec);
     } else {
         typedef unsigned short B;
-        bn_bwd_reduce_kernel<B><<<grid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
+        bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                       gamma, beta, save_mean, save_invstd, relu, L.partial, vec);
         bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
         if (n > 0)
