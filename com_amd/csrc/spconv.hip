@@ -645,7 +645,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int pr = lane >> 1, h = lane & 1;  // staging: lane -> (pair row, 16-byte piece parity)
+    // staging: one load instruction fetches WHOLE chunk rows -- lane -> (row, 16-byte piece) with all 2*MB pieces of
+    // a row in adjacent lanes (8 rows x 128 B per instruction at 64 channels).  The vector L1 works per 128-byte
+    // line touched: 32 rows x 32 B per instruction (the previous mapping) cost 4x the line accesses of 8 full rows.
+    constexpr int LPX = 2 * MB, LPY = 2 * NBW;           // lanes (pieces) per row
+    constexpr int RPX = 64 / LPX, RPY = 64 / LPY;         // rows per load instruction
+    const int xrow = lane / LPX, xpc = lane % LPX;
+    const int yrow = lane / LPY, ypc = lane % LPY;
     const int g = lane >> 4, t = lane & 15;
     // contraction index k = g*8 + j of the MFMA  <->  staged pair row (j < 4 ? 4g + j : 16 + 4g + j - 4):
     // any bijection works as long as X and dY use the same one; this one keeps each transpose read on 8
@@ -655,48 +661,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     // transposed out of LDS and multiplied
     // (rows one step ahead, pair indices two steps ahead, so no dependent-load latency is exposed)
     u32x4 xr[MB], yr[NBW];
-    int i_n = -1, o_n = -1;
+    int idx_n = -1;   // lanes 0-31: input row of pair p0 + lane; lanes 32-63: output row of pair p0 + lane - 32
     auto load_idx = [&](int p0) {
-        int p = p0 + pr;
-        i_n = -1;
-        o_n = -1;
-        if (p < p_end) {
-            i_n = pin[p];
-            o_n = pout[p];
-        }
+        const int p = p0 + (lane & 31);
+        idx_n = -1;
+        if (p < p_end) idx_n = (lane < 32) ? pin[p] : pout[p];
     };
     // gathered rows come through raw buffer loads: index -1 (beyond the pair range) or a channel piece beyond
     // the row -> offset past num_records -> hardware returns zeros, no branch, no memory access
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)dy_bytes, 0x00020000);
     const unsigned x_row_bytes = (unsigned)cin_pad * 2u, y_row_bytes = (unsigned)cout * 2u;
-    auto load_rows = [&](int i, int o) {
+    auto load_rows = [&](int idx) {
 #pragma unroll
-        for (int pc = 0; pc < MB; ++pc) {
-            int c = ci0 + (pc * 2 + h) * 8;
+        for (int j = 0; j < MB; ++j) {
+            const int i = __shfl(idx, j * RPX + xrow);
+            const int c = ci0 + xpc * 8;
             unsigned off = (c < cin_pad) ? (unsigned)i * x_row_bytes + (unsigned)c * 2u : 0xFFFFFFF0u;
-            xr[pc] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
         }
 #pragma unroll
-        for (int pc = 0; pc < NBW; ++pc) {
-            int c = co0 + (pc * 2 + h) * 8;
+        for (int j = 0; j < NBW; ++j) {
+            const int o = __shfl(idx, 32 + j * RPY + yrow);
+            const int c = co0 + ypc * 8;
             unsigned off = (c < cout) ? (unsigned)o * y_row_bytes + (unsigned)c * 2u : 0xFFFFFFF0u;
-            yr[pc] = __builtin_amdgcn_raw_buffer_load_b128(yrs, off, 0, 0);
+            yr[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, off, 0, 0);
         }
     };
     const int p_first = p_begin + wave * 32;
     load_idx(p_first);
-    load_rows(i_n, o_n);
+    load_rows(idx_n);
     load_idx(p_first + 128);
     for (int p0 = p_first; p0 < p_end; p0 += 128) {
         // stage the 32 gathered rows of X and dY (this wave's private LDS slice)
 #pragma unroll
-        for (int pc = 0; pc < MB; ++pc)
-            *reinterpret_cast<u32x4 *>(Xs + pr * XS + (pc * 2 + h) * 8) = xr[pc];
+        for (int j = 0; j < MB; ++j)
+            *reinterpret_cast<u32x4 *>(Xs + (j * RPX + xrow) * XS + xpc * 8) = xr[j];
 #pragma unroll
-        for (int pc = 0; pc < NBW; ++pc)
-            *reinterpret_cast<u32x4 *>(Ys + pr * YS + (pc * 2 + h) * 8) = yr[pc];
-        load_rows(i_n, o_n);
+        for (int j = 0; j < NBW; ++j)
+            *reinterpret_cast<u32x4 *>(Ys + (j * RPY + yrow) * YS + ypc * 8) = yr[j];
+        load_rows(idx_n);
         load_idx(p0 + 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
