@@ -210,10 +210,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("PCD_DIST_ONE_GPU"):                   # validation of the multi-rank control flow on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        backend = os.environ.get("PCD_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm (gloo only for that validation)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus or world == 1
 
     B = args.batch
