@@ -243,10 +243,11 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
     bucket = cdist.FlatGradBucket(params)
-    # ... and so do the parameters: one fused Adam launch for the whole model, clipping = norm + scale of one tensor
+    # ... and so do the parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step;
+    # torch.optim.Adam semantics, lr / betas / weight decay of adam_onecycle at its start, centerpoint.yaml:90-96)
     flat_param = bucket.flatten_parameters()
-    opt = torch.optim.Adam([flat_param], lr=3e-3 * 0.1, betas=(0.9, 0.99), weight_decay=0.01, fused=True,
-                           capturable=True)
+    opt = cdist.FlatAdam(bucket, lr=3e-3 * 0.1, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0,
+                         world=world)
     loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
 
     class ProjectionLoss(torch.autograd.Function):
@@ -296,13 +297,8 @@ def main():
         train_from_voxels(bd2, ev)
         return None
 
-    clip_div = torch.ones((), dtype=torch.float32, device=dev)
-    opt.grad_scale = clip_div        # fused Adam divides the gradients by this inside its kernel
-
     def opt_step():
-        # mean over the ranks + centerpoint.yaml:96 GRAD_NORM_CLIP, both folded into Adam's grad_scale
-        bucket.clip_divisor_(10.0, clip_div, pre_divisor=float(world))
-        opt.step()
+        opt.step()       # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 3 launches
 
     def eager_step(i, ev=None):
         pts, offs = batches[i % 2]

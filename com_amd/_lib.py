@@ -61,6 +61,10 @@ PROTOTYPES = {
     "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
                             _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_adam_flat_workspace_bytes": (_sz, []),
+    "pcd_adam_flat_step": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _sz,
+                                _vp]),
     "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _sz, _vp]),
 }

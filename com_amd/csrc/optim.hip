@@ -1,0 +1,105 @@
+// Gradient clipping + Adam over ONE flat fp32 parameter buffer, in two launches (the exchange / update end of the
+// data-parallel step: tools/train.py:165-166 wraps the model in DDP, tools/train_utils/train_utils.py:93-96 clips
+// the gradient norm and steps the optimizer).  torch's route is clip_grad_norm_ (norm + five scalar kernels + a
+// scaling pass) and a multi-tensor Adam kernel: ~200 us on the tail of every step for a 2.7 M-parameter backbone;
+// here: one pass for the squared norm, one pass that derives the clip coefficient from the 256 partials and
+// applies torch.optim.Adam's update (L2 weight decay, bias correction) -- same formula, fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int NORM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float4 *__restrict__ g, size_t n4,
+                                                             const float *__restrict__ tail, int ntail,
+                                                             double *__restrict__ partial) {
+    __shared__ double lds[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)NORM_BLOCKS * 256) {
+        float4 v = g[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) s += (double)tail[threadIdx.x] * tail[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// step_dev[0] holds the number of updates done so far (a device float, as torch keeps it for capturable
+// optimizers, so the step can be replayed from a hipGraph); the kernel uses step + 1 and a one-thread kernel
+// launched after it stores the increment (every block of this kernel must read the old value).
+__global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                        float4 *__restrict__ m, float4 *__restrict__ v, size_t n4,
+                                                        const double *__restrict__ norm_partial, float max_norm,
+                                                        float pre_divisor, const float *__restrict__ step_dev,
+                                                        float lr, float beta1, float beta2, float eps, float wd,
+                                                        float *__restrict__ norm_out) {
+    __shared__ double total_s;
+    if (threadIdx.x < 64) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < NORM_BLOCKS; i += 64) s += norm_partial[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (threadIdx.x == 0) total_s = s;
+    }
+    __syncthreads();
+    const float norm = (float)(sqrt(total_s) / (double)pre_divisor);          // norm of the rank-mean gradient
+    const float coef = fminf(max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f, 1.0f);
+    const float gscale = coef / pre_divisor;                                  // g_used = g_sum * gscale
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+    const float step = step_dev[0] + 1.0f;
+    const float bc1 = 1.0f - powf(beta1, step);
+    const float bc2 = 1.0f - powf(beta2, step);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w},
+              V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = G[j] * gscale + wd * P[j];
+            M[j] = M[j] + (gr - M[j]) * (1.0f - beta1);
+            V[j] = beta2 * V[j] + (1.0f - beta2) * gr * gr;
+            float denom = sqrtf(V[j]) / bc2_sqrt + eps;
+            P[j] = P[j] - step_size * (M[j] / denom);
+        }
+        p[i] = make_float4(P[0], P[1], P[2], P[3]);
+        m[i] = make_float4(M[0], M[1], M[2], M[3]);
+        v[i] = make_float4(V[0], V[1], V[2], V[3]);
+    }
+}
+
+__global__ void step_inc_kernel(float *step_dev) { step_dev[0] += 1.0f; }
+
+}  // namespace
+
+extern "C" size_t pcd_adam_flat_workspace_bytes(void) { return ws_piece(NORM_BLOCKS, sizeof(double)); }
+
+extern "C" int pcd_adam_flat_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float max_norm, float pre_divisor, float *step_dev, float *norm_out,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || pre_divisor <= 0.0f) return PCD_ERR_INVALID_ARG;
+    if ((n & 3) != 0) return PCD_ERR_UNSUPPORTED;   // the flat buffer is padded to a multiple of 4 by its owner
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) != 0)
+        return PCD_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < pcd_adam_flat_workspace_bytes()) return PCD_ERR_WORKSPACE;
+    if (n == 0) return PCD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    const size_t n4 = n / 4;
+    sumsq_partials_kernel<<<NORM_BLOCKS, 256, 0, st>>>((const float4 *)grad, n4, nullptr, 0, partial);
+    int blocks = (int)((n4 + 1023) / 1024);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    adam_flat_kernel<<<blocks, 256, 0, st>>>((float4 *)param, (const float4 *)grad, (float4 *)exp_avg,
+                                             (float4 *)exp_avg_sq, n4, partial, max_norm, pre_divisor, step_dev, lr,
+                                             beta1, beta2, eps, weight_decay, norm_out);
+    step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -36,7 +36,8 @@ class FlatGradBucket:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.numel = n
+        self.flat = torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=dev)   # padded for 16-byte kernels
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -87,6 +88,34 @@ class FlatGradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         return self.flat
+
+
+class FlatAdam:
+    """torch.optim.Adam (L2 weight decay, bias correction) + clip_grad_norm_ on the flat buffers of a
+    FlatGradBucket with flattened parameters, through pcd_adam_flat_step: two passes over the buffers in three
+    launches instead of torch's norm + scalar kernels + scaling pass + multi-tensor Adam.  `step()` expects
+    bucket.flat to hold the SUM of the ranks' gradients (all_reduce_sum) and divides by `world` itself."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0, world=1):
+        assert getattr(bucket, "flat_param", None) is not None, "call bucket.flatten_parameters() first"
+        from . import _lib as L
+        self.L, self.bucket = L, bucket
+        self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.max_norm, self.world = float(max_norm), float(world)
+        p = bucket.flat_param.data
+        self.exp_avg = torch.zeros_like(p)
+        self.exp_avg_sq = torch.zeros_like(p)
+        self.step_dev = torch.zeros((1,), dtype=torch.float32, device=p.device)
+        self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=p.device)
+        self.ws = torch.empty((max(int(L.lib().pcd_adam_flat_workspace_bytes()), 256),), dtype=torch.uint8, device=p.device)
+
+    def step(self):
+        L, b = self.L, self.bucket
+        p = b.flat_param.data
+        L.check(L.lib().pcd_adam_flat_step(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                           p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                           self.max_norm, self.world, L.ptr(self.step_dev), L.ptr(self.grad_norm),
+                                           L.ptr(self.ws), self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step")
 
 
 def max_over_ranks(value, device="cpu"):

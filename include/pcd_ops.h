@@ -275,6 +275,20 @@ int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int
                     int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ============================================================================================
+ * (a15) update end of the data-parallel step: gradient-norm clipping + Adam on ONE flat fp32 buffer
+ * (tools/train.py:165-166 DDP, tools/train_utils/train_utils.py:93-96 clip_grad_norm_ + optimizer.step();
+ * torch.optim.Adam semantics: L2 weight decay added to the gradient, bias-corrected moments).
+ *   grad holds the SUM of the ranks' gradients, pre_divisor = world size (1 on a single GPU): the update uses
+ *   g = grad / pre_divisor * min(1, max_norm / (||grad / pre_divisor|| + 1e-6))   (max_norm <= 0: no clipping).
+ *   step_dev[0] (device float) = number of updates done so far; incremented by the call.  norm_out (may be NULL)
+ *   receives the gradient norm.  n % 4 == 0, buffers 16-byte aligned.  Two passes over the buffers, 3 launches.
+ * ============================================================================================ */
+size_t pcd_adam_flat_workspace_bytes(void);
+int pcd_adam_flat_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
+                       float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

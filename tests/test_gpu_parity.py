@@ -408,6 +408,38 @@ def test_strided_dgrad_by_parity_class_equals_generic():
 
 
 @pytest.mark.gpu
+def test_flat_adam_matches_torch_adam_with_clipping():
+    """pcd_adam_flat_step == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(weight_decay, betas) on the same
+    parameters over several steps (including the rank-sum / world-size form), fp32, to 1e-6 relative."""
+    from com_amd import dist as cdist
+    torch.manual_seed(21)
+    shapes = [(16, 27, 5), (16,), (32, 27, 16), (32,), (7, 4)]
+    for world, max_norm in ((1, 10.0), (4, 0.5), (1, 0.0)):
+        ref = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+        opt = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.99), weight_decay=0.01)
+        bucket = cdist.FlatGradBucket(mine)
+        bucket.flatten_parameters()
+        fa = cdist.FlatAdam(bucket, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=max_norm,
+                            world=world)
+        for step in range(4):
+            grads = [torch.randn(*sh, device=DEV) * (3.0 if step % 2 else 0.05) for sh in shapes]
+            for p, g in zip(ref, grads):
+                p.grad = g.clone()
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(ref, max_norm)
+            opt.step()
+            for p, g in zip(mine, grads):
+                p.grad.copy_(g * world)                       # what all_reduce_sum leaves in the bucket
+            fa.step()
+            if max_norm > 0:
+                expect = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+                torch.testing.assert_close(fa.grad_norm[0], expect, rtol=1e-5, atol=1e-6)
+        assert float(fa.step_dev[0]) == 4.0
+        for p, q in zip(ref, mine):
+            torch.testing.assert_close(q.detach(), p.detach(), rtol=2e-6, atol=2e-7)
+
+
 def test_pack_weights_batched_matches_single():
     """pcd_pack_weights_batched (one launch for a list of weights) == pcd_pack_weight per weight, bit for bit."""
     ops = _ops()
