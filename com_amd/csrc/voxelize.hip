@@ -89,14 +89,24 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict
     }
 }
 
+// "point i is the first point of its voxel": one random read of the candidate table per point.  The flag is
+// evaluated ONCE, by the reduce pass of the scan, which leaves it in `flag` (the scan's output array, overwritten
+// in place by the down pass); the down pass and the emit kernel read it back coalesced.
 struct FirstFlag {
     const int32_t *pt_slot;
     const u32 *best;
     int T;
+    int *flag;
     __device__ int operator()(int i) const {
         int s = pt_slot[i];
-        return (s >= 0 && best[(size_t)s * T] == (u32)i) ? 1 : 0;
+        int v = (s >= 0 && best[(size_t)s * T] == (u32)i) ? 1 : 0;
+        flag[i] = v;
+        return v;
     }
+};
+struct StoredFlag {
+    const int *flag;
+    __device__ int operator()(int i) const { return flag[i]; }
 };
 
 // one block: per-frame counts, caps, output bases
@@ -126,12 +136,11 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int s = pt_slot[i];
-    if (s < 0) return;
-    const u32 *slot = best + (size_t)s * T;
-    if (slot[0] != (u32)i) return;
+    const int rk = rank[i];
+    if (rank[i + 1] == rk) return;                 // not the first point of a voxel (exclusive ranks: no step)
+    const u32 *slot = best + (size_t)pt_slot[i] * T;
     int b = frame_of(offs, batch, i);
-    int vid = rank[i] - frame_rank0[b];
+    int vid = rk - frame_rank0[b];
     if (vid >= voxel_counts[b]) return;  // beyond max_voxels (or capacity)
     int row = frame_base[b] + vid;
     const float *p0 = pts + (size_t)i * stride + feat_off;
@@ -336,9 +345,18 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
                                               tcap - 1, pt_slot);
         PCD_RETURN_IF_LAUNCH_FAILED();
     }
-    FirstFlag ff{pt_slot, best, max_points};
-    int rc = scan_exclusive(ff, n_points, rank, bsums, nullptr, st);
-    if (rc != PCD_OK) return rc;
+    int rc = PCD_OK;
+    if (n_points > 0) {
+        FirstFlag ff{pt_slot, best, max_points, rank};
+        StoredFlag sf{rank};
+        scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
+        scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+        scan_down_kernel<StoredFlag><<<nb, 256, 0, st>>>(sf, n_points, bsums, rank);   // in place
+        PCD_RETURN_IF_LAUNCH_FAILED();
+    } else {
+        rc = scan_exclusive(StoredFlag{rank}, 0, rank, bsums, nullptr, st);
+        if (rc != PCD_OK) return rc;
+    }
     vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
                                         frame_base, voxel_counts);
     if (n_points > 0) {
