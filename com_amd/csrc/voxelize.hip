@@ -54,35 +54,67 @@ __device__ __forceinline__ int frame_of(const int32_t *offs, int batch, int i) {
 constexpr u64 KEY_EMPTY = ~0ull;
 constexpr u32 IDX_NONE = ~0u;
 
+// LiDAR sweeps arrive in range-image order, so neighbouring points mostly fall into the same voxel.  Lanes of a
+// wave that hold the same voxel as the lane before them form a RUN: only the run's first lane probes the key
+// table; the others take its slot, and start the candidate cascade at their rank within the run.
+//
+// Candidate cascade (per voxel T words, all-ones = none): a value visits slot t with atomicMin, stays if the slot
+// was empty, otherwise carries max(old, v) to slot t + 1.  The values visiting slot t + 1 are exactly those that
+// visited slot t minus the minimum that stays, so slot t ends up holding the (t+1)-th smallest index -- for any
+// arrival order, and also when a value starts at a slot j <= (number of smaller indices of the same voxel), which
+// the rank within a run guarantees.  Members of rank >= T can never be kept and skip the table altogether.
 __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict__ pts, int n,
                                                          int stride, int feat_off,
                                                          const int32_t *__restrict__ offs, int batch,
-                                                         VoxGeom G, int T, u64 *keys, u32 *best,
+                                                         VoxGeom G, int T, int L, u64 *keys, u32 *best,
                                                          u32 mask, int32_t *pt_slot) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    u64 key = KEY_EMPTY;
+    if (i < n) {
+        const float *p = pts + (size_t)i * stride + feat_off;
+        float xyz[3] = {p[0], p[1], p[2]};
+        int cx, cy, cz;
+        if (voxel_coord(xyz, G, cx, cy, cz)) {
+            int b = frame_of(offs, batch, i);
+            key = (((u64)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+        }
+    }
+    const bool valid = key != KEY_EMPTY;
+    u64 prev_key = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev_key != key;
+    const u64 heads = __ballot(head);
+    const int head_lane = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+    const int run_rank = lane - head_lane;
+
+    u32 h = 0;
+    u32 last = IDX_NONE;
+    if (head && valid) {
+        h = hash_u64(key) & mask;
+        for (;;) {
+            u64 *kp = keys + (size_t)h * (L / 2);      // key and candidates of a slot share one 32-byte record
+            u64 prev = *kp;
+            // same sector as the key, so it comes back with it: the last kept candidate.  Values only ever
+            // decrease -- a stale read can only be too large, never cause a wrong early exit below.
+            last = __hip_atomic_load(best + (size_t)h * L + (T - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == key) break;
+            if (prev == KEY_EMPTY) prev = atomicCAS(kp, KEY_EMPTY, key);
+            if (prev == KEY_EMPTY || prev == key) break;
+            h = (h + 1) & mask;
+        }
+    }
+    h = __shfl(h, head_lane);
     if (i >= n) return;
-    const float *p = pts + (size_t)i * stride + feat_off;
-    float xyz[3] = {p[0], p[1], p[2]};
-    int cx, cy, cz;
-    if (!voxel_coord(xyz, G, cx, cy, cz)) {
+    if (!valid) {
         pt_slot[i] = -1;
         return;
     }
-    int b = frame_of(offs, batch, i);
-    u64 key = (((u64)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
-    u32 h = hash_u64(key) & mask;
-    for (;;) {
-        u64 prev = keys[h];
-        if (prev == KEY_EMPTY) prev = atomicCAS(&keys[h], KEY_EMPTY, key);
-        if (prev == KEY_EMPTY || prev == key) break;
-        h = (h + 1) & mask;
-    }
     pt_slot[i] = (int32_t)h;
-    u32 *slot = best + (size_t)h * T;
     u32 v = (u32)i;
-    // values only ever decrease: if the last kept index is already smaller we can never enter
-    if (__hip_atomic_load(&slot[T - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) return;
-    for (int t = 0; t < T; ++t) {
+    // T smaller indices are already kept (or precede us in the run): we can never enter
+    if (run_rank >= T || last < v) return;
+    u32 *slot = best + (size_t)h * L;
+    for (int t = run_rank; t < T; ++t) {
         u32 old = atomicMin(&slot[t], v);
         if (old == IDX_NONE) break;
         v = old > v ? old : v;
@@ -95,11 +127,11 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict
 struct FirstFlag {
     const int32_t *pt_slot;
     const u32 *best;
-    int T;
+    int L;   // slot stride in 32-bit words
     int *flag;
     __device__ int operator()(int i) const {
         int s = pt_slot[i];
-        int v = (s >= 0 && best[(size_t)s * T] == (u32)i) ? 1 : 0;
+        int v = (s >= 0 && best[(size_t)s * L] == (u32)i) ? 1 : 0;
         flag[i] = v;
         return v;
     }
@@ -130,7 +162,7 @@ __global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *ran
 
 __global__ __launch_bounds__(256) void vox_emit_kernel(
     const float *__restrict__ pts, int n, int stride, int feat_off, int C,
-    const int32_t *__restrict__ offs, int batch, VoxGeom G, int T, const u32 *__restrict__ best,
+    const int32_t *__restrict__ offs, int batch, VoxGeom G, int T, int L, const u32 *__restrict__ best,
     const int32_t *__restrict__ pt_slot, const int *__restrict__ rank, const int *frame_rank0,
     const int *frame_base, const int32_t *voxel_counts, float *voxels, int32_t *coords,
     int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride) {
@@ -138,7 +170,7 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     if (i >= n) return;
     const int rk = rank[i];
     if (rank[i + 1] == rk) return;                 // not the first point of a voxel (exclusive ranks: no step)
-    const u32 *slot = best + (size_t)pt_slot[i] * T;
+    const u32 *slot = best + (size_t)pt_slot[i] * L;
     int b = frame_of(offs, batch, i);
     int vid = rk - frame_rank0[b];
     if (vid >= voxel_counts[b]) return;  // beyond max_voxels (or capacity)
@@ -283,6 +315,9 @@ static VoxGeom make_geom(const float *range, const float *vs) {
 
 // power of two >= 1.5 x points: at most one voxel per point, so the load factor is <= 2/3 in the worst case and
 // ~1/3 on LiDAR frames (about two points per voxel); every halving keeps more of the key / candidate tables in L2
+// 32-bit words per hash record: 64-bit key + T candidate indices, padded to an even count (8-byte aligned keys)
+static int slot_words(int max_points) { return (2 + max_points + 1) & ~1; }
+
 static u32 table_capacity(int n) {
     u32 cap = 1024;
     const u32 need = (u32)(n > 0 ? n : 1);
@@ -297,8 +332,7 @@ extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points
     if (n_points < 0 || max_points <= 0 || batch <= 0) return 0;
     u32 cap = table_capacity(n_points);
     size_t b = 0;
-    b += ws_piece(cap, sizeof(u64));                       // keys
-    b += ws_piece((size_t)cap * max_points, sizeof(u32));  // best
+    b += ws_piece((size_t)cap * slot_words(max_points), sizeof(u32));   // {key u64, best u32[T]} records
     b += ws_piece(n_points + 1, sizeof(int32_t));          // pt_slot
     b += ws_piece(n_points + 1, sizeof(int));              // rank
     b += ws_piece(pcd_div_up(n_points, 256) + 2, sizeof(int));
@@ -328,26 +362,28 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
         return PCD_ERR_WORKSPACE;
     WsCarver ws(workspace, workspace_bytes);
     u32 tcap = table_capacity(n_points);
-    u64 *keys = ws.take<u64>(tcap);
-    u32 *best = ws.take<u32>((size_t)tcap * max_points);
+    const int L = slot_words(max_points);
+    u32 *tab = ws.take<u32>((size_t)tcap * L);
+    u64 *keys = (u64 *)tab;     // record h: key at word h*L, candidates at words h*L + 2 ..
+    u32 *best = tab + 2;
     int32_t *pt_slot = ws.take<int32_t>(n_points + 1);
     int *rank = ws.take<int>(n_points + 1);
     int *bsums = ws.take<int>(pcd_div_up(n_points, 256) + 2);
     int *frame_rank0 = ws.take<int>(batch + 1);
     int *frame_base = ws.take<int>(batch + 1);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
-    // keys and best are adjacent pieces: one memset to 0xFF covers both sentinels
-    pcd_fill(keys, 0xFF, (size_t)((char *)pt_slot - (char *)keys), st);
+    // one memset to 0xFF sets both sentinels (empty key, no candidate)
+    pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
     int nb = pcd_div_up(n_points, 256);
     if (n_points > 0) {
         vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
-                                              frame_offsets, batch, G, max_points, keys, best,
+                                              frame_offsets, batch, G, max_points, L, keys, best,
                                               tcap - 1, pt_slot);
         PCD_RETURN_IF_LAUNCH_FAILED();
     }
     int rc = PCD_OK;
     if (n_points > 0) {
-        FirstFlag ff{pt_slot, best, max_points, rank};
+        FirstFlag ff{pt_slot, best, L, rank};
         StoredFlag sf{rank};
         scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
         scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
@@ -361,7 +397,7 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
                                         frame_base, voxel_counts);
     if (n_points > 0) {
         vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
-                                            num_features, frame_offsets, batch, G, max_points, best,
+                                            num_features, frame_offsets, batch, G, max_points, L, best,
                                             pt_slot, rank, frame_rank0, frame_base, voxel_counts,
                                             voxels, coords, num_points, mean_f32,
                                             (unsigned short *)mean_bf16, mean_bf16_stride);
