@@ -38,7 +38,9 @@ PROTOTYPES = {
     "pcd_rulebook_conv_classes_workspace_bytes": (_sz, [_i]),
     "pcd_rulebook_conv_classes": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_dgrad_classes": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
-                                           _i, _vp, _vp]),
+                                           _i, _vp, _vp, _vp]),
+    "pcd_sparse_conv_dgrad_classes_tiles": (_i, [_i, _i]),
+    "pcd_sparse_conv_gather_gemm_tiles": (_i, [_i, _i, _i, _i, _i]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
@@ -50,7 +52,8 @@ PROTOTYPES = {
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
-    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
+                                         _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
@@ -60,13 +63,13 @@ PROTOTYPES = {
     "pcd_bn_workspace_bytes": (_sz, [_i]),
     "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
-                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                            _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcd_adam_flat_workspace_bytes": (_sz, []),
     "pcd_adam_flat_step": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _sz,
                                 _vp]),
     "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _sz, _vp]),
+                             _i, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -74,6 +77,13 @@ _lib = None
 
 class PcdError(RuntimeError):
     pass
+
+
+class PcdBnReduce(ctypes.Structure):
+    """include/pcd_ops.h: struct PcdBnReduce (conv-epilogue reductions for the BatchNorm beside the conv)."""
+    _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p),
+                ("partial_rows", ctypes.c_int)]
 
 
 def build(force=False):

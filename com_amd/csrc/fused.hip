@@ -448,8 +448,9 @@ extern "C" size_t pcd_bn_workspace_bytes(int c) {
 extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
                               const float *gamma, const float *beta, float eps, float momentum,
                               int training, float *running_mean, float *running_var, int relu, void *y,
-                              float *save_mean, float *save_invstd, const int32_t *n_dev, void *workspace,
-                              size_t workspace_bytes, void *stream) {
+                              float *save_mean, float *save_invstd, const int32_t *n_dev,
+                              const float *ext_partial, int ext_rows, void *workspace, size_t workspace_bytes,
+                              void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
@@ -463,13 +464,16 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     const int pcs = c / N;
     int grid = grid_for((size_t)n * pcs, pcs);
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
+    if (ext_partial && ext_rows < 0) return PCD_ERR_INVALID_ARG;
     if (training) {
-        if (dtype == PCD_F32)
+        if (ext_partial)   // the conv epilogue already took the sums (PcdBnReduce mode 1)
+            ;
+        else if (dtype == PCD_F32)
             bn_stats_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
         else
             bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c,
                                                                   L.partial);
-        bn_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, n, n_dev, c, gamma, beta, eps,
+        bn_finalize_kernel<<<1, 1024, 0, st>>>(ext_partial ? ext_partial : L.partial, ext_partial ? ext_rows : grid, n, n_dev, c, gamma, beta, eps,
                                                                momentum, running_mean, running_var,
                                                                save_mean, save_invstd, L.scale, L.shift);
     } else {
@@ -523,8 +527,8 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
                                const float *gamma, const float *beta, const float *save_mean,
                                const float *save_invstd,
                                int relu, int training, void *dx, void *dresidual, float *dgamma,
-                               float *dbeta, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+                               float *dbeta, const int32_t *n_dev, const float *ext_partial, int ext_rows,
+                               void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
@@ -538,20 +542,25 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     int grid = grid_for((size_t)n * pcs, pcs);
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     const int vec = aligned16(gamma, beta, save_mean, save_invstd, dgamma, dbeta) ? 1 : 0;
+    if (ext_partial && ext_rows < 0) return PCD_ERR_INVALID_ARG;
+    const float *part = ext_partial ? ext_partial : L.partial;     // PcdBnReduce mode 2: sums taken by the dgrad
+    const int prow = ext_partial ? ext_rows : grid;
     if (dtype == PCD_F32) {
-        bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
+        if (!ext_partial)
+            bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                                                           save_invstd, relu, L.partial, vec);
-        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                 save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec);
     } else {
         typedef unsigned short B;
-        bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
+        if (!ext_partial)
+            bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                       gamma, beta, save_mean, save_invstd, relu, L.partial, vec);
-        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, dgamma, dbeta);
+        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
         if (n > 0)
             bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                          gamma, beta, save_mean, save_invstd, dgamma, dbeta,

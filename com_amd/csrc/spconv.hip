@@ -42,6 +42,9 @@ static int pow2_ge8(int c) {
     return p;
 }
 
+// blocks interleaved in the packed channel order (see the epilogue of the gather-GEMM kernels)
+__host__ __device__ constexpr int gg_quad(int nb) { return nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1); }
+
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_one(const float *__restrict__ w, int K, int cin, int cout, int mode,
                                          int cshift, int NB, size_t e, unsigned short *out) {
@@ -53,7 +56,8 @@ __device__ __forceinline__ void pack_one(const float *__restrict__ w, int K, int
     int q = s * 32 + (lane >> 4) * 8 + j;
     int k = q >> cshift;
     int c = q & ((1 << cshift) - 1);
-    int col = nb * 16 + (lane & 15);
+    const int Q = gg_quad(NB), m = lane & 15;   // interleaved channel order, see gg_quad
+    int col = (nb / Q) * 16 * Q + (m >> 2) * 4 * Q + (nb % Q) * 4 + (m & 3);
     float v = 0.0f;
     if (k < K) {
         if (mode == 0) {
@@ -98,6 +102,195 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long lo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Optional per-channel reductions of the output tile in the gather-GEMM epilogue (mode 0 = off).  The values are
+// in registers anyway; a separate kernel would read them back from memory:
+//   mode 1  forward: sum / sum of squares of the ROUNDED outputs = the batch statistics of the BatchNorm that
+//           follows the conv (replaces its statistics pass);
+//   mode 2  data gradient: the output is dy of the BatchNorm (+ReLU) that produced this conv's input; accumulates
+//           sum(dz) and sum(dz * xhat), dz = dy where y > 0 (ReLU), xhat = (x - mean) * invstd (replaces the
+//           reduction pass of the BatchNorm backward; the second
+//           sum is centred per lane: (sum dz*x - mean * sum dz) * invstd over the lane's <= 4 rows).
+// One row of partial[gridDim.x][2][c_out] per workgroup (zeros from workgroups without rows); fixed summation
+// tree (mi, DPP row, waves) -> deterministic.
+struct BnRed {
+    int mode;
+    int relu;
+    const unsigned short *x;      // mode 2: input of the BatchNorm, [rows][c_out] bf16
+    const unsigned short *y;      // mode 2, relu: BatchNorm(+residual)+ReLU output (the conv's own input features)
+    const float *mean, *invstd;
+    float *partial;
+};
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in all of them
+__device__ __forceinline__ float row16_sum(float v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true);  // row_mirror
+    v += __builtin_bit_cast(float, t);
+    return v;
+}
+
+__device__ __forceinline__ void bnred_zero_row(const BnRed &bn, int tile, int c_out) {
+    for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) bn.partial[(size_t)tile * 2 * c_out + e] = 0.0f;
+}
+
+// Channel order inside the packed weights.  The MFMA leaves lane (g, rl) with rows m = 4g..4g+3 of every 16-channel
+// block nb; with the natural order (channel = 16 nb + m) a lane owns 4 consecutive channels per block = 8-byte
+// accesses, 32 bytes per output row and instruction.  The packs instead interleave Q = 4 (2, 1) blocks:
+//     channel(nb, m) = (nb / Q) * 16Q + (m / 4) * 4Q + (nb % Q) * 4 + (m % 4),   Q = gg_quad(blocks)
+// so a lane owns 4Q CONSECUTIVE channels of its row across the Q blocks: 16-byte accesses, and the 4 lanes of a
+// row cover 16Q channels = one full 128-byte line at Q = 4 (the vector L1 works per line touched).
+
+// Epilogue of both gather-GEMM kernels: lane (g, rl) of a wave holds, for every mi, the output channels described
+// above of row rows[mi] (-1: no row).  (+bias) (+addend), one rounding, 8/16-byte stores, optional BnRed
+// reductions (`red`: 4 * 2 * c_out floats of LDS not used by the main loop).
+template <int MI, int NBW, bool OUT_BF16>
+__device__ __forceinline__ void gg_epilogue(const f32x4 (&acc)[MI][NBW], const int (&rows)[MI], int c_out, int col0,
+                                            int g, int rl, int wave, int tile, const float *__restrict__ bias,
+                                            const void *__restrict__ addend, void *__restrict__ yv, const BnRed &bn,
+                                            float *red) {
+    constexpr int Q = gg_quad(NBW);
+    constexpr int U = Q >= 2 ? 2 : 1;        // blocks per access unit: 8 channels = 16 bytes of bf16 (4 at Q = 1)
+    constexpr int CH = 4 * U;
+    const bool has_bias = bias != nullptr;
+    auto ld_f = [](const float *p, float (&v)[CH]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + 4 * u);
+            v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
+        }
+    };
+    auto ld_h = [](const unsigned short *p, float (&v)[CH]) {     // CH bf16 -> float
+        u32 w[2 * U];
+        if (U == 2) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(p);
+            w[0] = t.x; w[1] = t.y; w[2 % (2 * U)] = t.z; w[3 % (2 * U)] = t.w;
+        } else {
+            const uint2 t = *reinterpret_cast<const uint2 *>(p);
+            w[0] = t.x; w[1] = t.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * U; ++j) {
+            v[2 * j] = __uint_as_float(w[j] << 16);
+            v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    };
+#pragma unroll
+    for (int qd = 0; qd < NBW / Q; ++qd)
+#pragma unroll
+        for (int un = 0; un < Q / U; ++un) {
+            const int nb0 = qd * Q + un * U;                              // first of the unit's U blocks
+            const int col = col0 + qd * 16 * Q + g * 4 * Q + un * CH;     // first of the lane's CH channels
+            float bs[CH], bq[CH], bv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) bs[j] = bq[j] = bv[j] = 0.0f;
+            if (has_bias) ld_f(bias + col, bv);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = rows[mi];
+                if (row < 0) continue;
+                float v[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[j] = acc[mi][nb0 + j / 4][j % 4];
+                if (has_bias) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) v[j] += bv[j];
+                }
+                const size_t at = (size_t)row * c_out + col;
+                if (OUT_BF16) {
+                    if (addend) {  // y = conv + addend (e.g. the residual branch's gradient), rounded once
+                        float ad[CH];
+                        ld_h((const unsigned short *)addend + at, ad);
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) v[j] += ad[j];
+                    }
+                    u32 o[2 * U];
+#pragma unroll
+                    for (int j = 0; j < 2 * U; ++j)
+                        o[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+                    unsigned short *y = (unsigned short *)yv + at;
+                    if (U == 2)
+                        *reinterpret_cast<uint4 *>(y) = make_uint4(o[0], o[1], o[2 % (2 * U)], o[3 % (2 * U)]);
+                    else
+                        *reinterpret_cast<uint2 *>(y) = make_uint2(o[0], o[1]);
+                    if (bn.mode) {
+                        float d[CH];
+#pragma unroll
+                        for (int j = 0; j < 2 * U; ++j) {
+                            d[2 * j] = __uint_as_float(o[j] << 16);
+                            d[2 * j + 1] = __uint_as_float(o[j] & 0xffff0000u);
+                        }
+                        if (bn.mode == 1) {
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) {
+                                bs[j] += d[j];
+                                bq[j] += d[j] * d[j];
+                            }
+                        } else {
+                            float xv[CH], tv[CH];
+                            ld_h(bn.x + at, xv);
+                            if (bn.relu) ld_h(bn.y + at, tv);
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) {
+                                const float dz = (bn.relu && !(tv[j] > 0.0f)) ? 0.0f : d[j];
+                                bs[j] += dz;
+                                bq[j] += dz * xv[j];     // centred below: sum dz*(x - mean) = sum dz*x - mean * sum dz
+                            }
+                        }
+                    }
+                } else {
+                    float *y = (float *)yv + at;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float4 o = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+                        if (addend) {
+                            const float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + at + 4 * u);
+                            o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                        }
+                        *reinterpret_cast<float4 *>(y + 4 * u) = o;
+                    }
+                }
+            }
+            if (OUT_BF16 && bn.mode) {
+                if (bn.mode == 2) {
+                    // the lane's <= MI rows: (sum dz*x - mean*sum dz) * invstd = sum dz*xhat; mean and invstd are
+                    // only needed here, not across the row loop (registers)
+                    float mu[CH], is[CH];
+                    ld_f(bn.mean + col, mu);
+                    ld_f(bn.invstd + col, is);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) bq[j] = (bq[j] - mu[j] * bs[j]) * is[j];
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    bs[j] = row16_sum(bs[j]);
+                    bq[j] = row16_sum(bq[j]);
+                }
+                if (rl == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        *reinterpret_cast<float4 *>(red + (wave * 2 + 0) * c_out + col + 4 * u) =
+                            make_float4(bs[4 * u], bs[4 * u + 1], bs[4 * u + 2], bs[4 * u + 3]);
+                        *reinterpret_cast<float4 *>(red + (wave * 2 + 1) * c_out + col + 4 * u) =
+                            make_float4(bq[4 * u], bq[4 * u + 1], bq[4 * u + 2], bq[4 * u + 3]);
+                    }
+                }
+            }
+        }
+    if (OUT_BF16 && bn.mode) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x)
+            bn.partial[(size_t)tile * 2 * c_out + e] =
+                ((red[e] + red[2 * c_out + e]) + red[4 * c_out + e]) + red[6 * c_out + e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Output-stationary gather-GEMM.  Workgroup = 4 waves x (MI*16) output rows, all NB*16 output channels.
 //   * the workgroup's rulebook tile nbr[K][ROWS] is staged in LDS once (coalesced k-major reads) plus one
 //     row of -1 that padded contraction steps read;
@@ -113,16 +306,25 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long lo
 // s_waitcnt vmcnt(~0) at the first MFMA of each group, which waits for the loads issued for the NEXT group and
 // exposes the full L2 latency every G steps (seen in the ISA of the previous version).
 // WN = 2: 8 waves per workgroup, waves 4-7 take the upper half of the output channels of the same rows.
+// Waves per SIMD the main loop's registers allow (accumulators + two gather register sets + ~24): the epilogue
+// (BnRed) must not push the allocation past that -- these kernels live on occupancy.
+constexpr int gg_waves(int nbw, int mi, int g) {
+    const int est = mi * nbw * 4 + 2 * g * mi * 4 + 32 + (mi == 1 ? 16 : (mi == 2 && g == 1 ? 8 : 0));
+    const int w = 512 / est;
+    return w > 7 ? 7 : (w < 1 ? 1 : w);   // (LDS limits the narrow kernels to <= 7 waves per SIMD anyway)
+}
+
 template <int NB, int MI, int G, int SG, bool OUT_BF16, int WN = 1>   // SG == 0: weights resident in LDS
-__global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
+__global__ __launch_bounds__(256 * WN, gg_waves(NB / WN, MI, G)) void gather_gemm_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const float *__restrict__ bias, const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip,
     int n_out_cap, const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, int nsteps,
-    unsigned x_bytes, int dbg, const void *__restrict__ addend) {
+    unsigned x_bytes, int dbg, const void *__restrict__ addend, BnRed bn) {
     constexpr int ROWS = 4 * MI * 16;
     constexpr int THREADS = 256 * WN;
     constexpr int NBW = NB / WN;                           // 16-channel blocks per wave
     static_assert(NB % WN == 0, "channel split");
+    static_assert(WN == 1 || gg_quad(NB) == gg_quad(NB / WN), "interleave groups must not straddle the channel split");
     constexpr bool STAGED = SG > 0;
     constexpr int GPS = STAGED ? SG / G : 1;               // gather groups per weight stage: 1 or 2
     static_assert(!STAGED || (SG == G || SG == 2 * G), "a stage is one or two gather groups");
@@ -134,6 +336,7 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
     const unsigned wtotal = (unsigned)nsteps * NB * 64;  // uint4 in the packed weight
     uint4 *wbuf = (uint4 *)smem;                         // staged: [2][VEC]; resident: [wtotal]
     int *nbr_s = (int *)(smem + (STAGED ? (size_t)2 * VEC : (size_t)wtotal) * sizeof(uint4));  // [K+1][ROWS]
+    float *red_s = (float *)(nbr_s + (K + 1) * ROWS);      // [4][2][c_out], only with bn.mode
 
     const int wave = (threadIdx.x >> 6) & 3;               // row-tile index inside the workgroup
     const int wn = threadIdx.x >> 8;                       // channel half (0 when WN == 1)
@@ -146,8 +349,11 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
     const int tiles_per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     const int r0wg = tile * ROWS;
-    if (r0wg >= n_out) return;
     constexpr int c_out = NB * 16;
+    if (r0wg >= n_out) {
+        if (bn.mode) bnred_zero_row(bn, tile, c_out);
+        return;
+    }
 
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)(wtotal * 16u), 0x00020000);
@@ -318,51 +524,59 @@ __global__ __launch_bounds__(256 * WN) void gather_gemm_kernel(
         }
     }
 
+    int rows[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        int row = r0wg + tile_row + mi * 16;
-        if (row >= n_out) continue;
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            int col = (wn * NBW + nb) * 16 + g * 4;
-            f32x4 v = acc[mi][nb];
-            if (bias) {
-                float4 bv = *reinterpret_cast<const float4 *>(bias + col);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (OUT_BF16) {
-                if (addend) {  // y = conv + addend (e.g. the residual branch's gradient), rounded once
-                    uint2 ad = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + (size_t)row * c_out + col);
-                    v[0] += __uint_as_float(ad.x << 16);
-                    v[1] += __uint_as_float(ad.x & 0xffff0000u);
-                    v[2] += __uint_as_float(ad.y << 16);
-                    v[3] += __uint_as_float(ad.y & 0xffff0000u);
-                }
-                unsigned short *y = (unsigned short *)yv + (size_t)row * c_out + col;
-                uint2 o;
-                o.x = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(y) = o;
-            } else {
-                if (addend) {
-                    float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + (size_t)row * c_out + col);
-                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                }
-                float *y = (float *)yv + (size_t)row * c_out + col;
-                *reinterpret_cast<float4 *>(y) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
+        const int row = r0wg + tile_row + mi * 16;
+        rows[mi] = row < n_out ? row : -1;
     }
+    BnRed bne = bn;
+    if (WN != 1) bne.mode = 0;   // the reductions assume 4 waves x all channels (every launch configuration in use)
+    gg_epilogue<MI, NBW, OUT_BF16>(acc, rows, c_out, wn * NBW * 16, g, rl, wave, tile, bias, addend, yv, bne, red_s);
+}
+
+// host: PcdBnReduce (C ABI) -> kernel argument; `grid` partial rows will be written
+static int make_bnred(const PcdBnReduce *r, int y_dtype, int c_out, int grid, BnRed *out) {
+    BnRed b = {};
+    *out = b;
+    if (!r || r->mode == 0) return PCD_OK;
+    if (r->mode != 1 && r->mode != 2) return PCD_ERR_INVALID_ARG;
+    if (y_dtype != PCD_BF16) return PCD_ERR_UNSUPPORTED;
+    if (!r->partial || r->partial_rows < grid) return PCD_ERR_INVALID_ARG;
+    if (r->mode == 2) {
+        if (!r->x || !r->mean || !r->invstd) return PCD_ERR_INVALID_ARG;
+        if (r->relu && !r->y) return PCD_ERR_INVALID_ARG;
+        if (((uintptr_t)r->mean | (uintptr_t)r->invstd) & 15u)
+            return PCD_ERR_UNSUPPORTED;   // the epilogue reads 4 channels per 16-byte load
+    }
+    (void)c_out;
+    b.mode = r->mode;
+    b.relu = r->relu;
+    b.x = (const unsigned short *)r->x;
+    b.y = (const unsigned short *)r->y;
+    b.mean = r->mean;
+    b.invstd = r->invstd;
+    b.partial = r->partial;
+    *out = b;
+    return PCD_OK;
 }
 
 template <int NB, int MI, int G, int SG, int WN = 1>
 static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const float *bias,
                      const int32_t *nbr, int nbr_stride, int K, int flip, int n_out, const int32_t *n_out_dev,
-                     void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend) {
+                     void *y, int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend,
+                     const PcdBnReduce *bnr, int *tiles_only) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
+    if (bn.mode && WN != 1) return PCD_ERR_UNSUPPORTED;
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
-    size_t lds = wbytes + (size_t)(K + 1) * ROWS * sizeof(int);
+    size_t lds = wbytes + (size_t)(K + 1) * ROWS * sizeof(int) + (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
     static const int dbg = getenv("PCD_GG_DBG") ? atoi(getenv("PCD_GG_DBG")) : 0;  // ablation switches
     auto kb = gather_gemm_kernel<NB, MI, G, SG, true, WN>;
@@ -381,10 +595,10 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
     }
     if (y_dtype == PCD_BF16)
         kb<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend, bn);
     else
         kf<<<grid, 256 * WN, lds, st>>>((const unsigned short *)x, c_in, cshift, (const uint4 *)wp, bias, nbr,
-                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend);
+                                   nbr_stride, K, flip, n_out, n_out_dev, y, nsteps, x_bytes, dbg, addend, bn);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -402,11 +616,11 @@ struct ClsTable {
 };
 
 template <int NB, int MI, bool OUT_BF16>
-__global__ __launch_bounds__(256) void gather_gemm_cls_kernel(
+__global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const int32_t *__restrict__ nbr, int nbr_stride, int K, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ vstart, ClsTable T, void *__restrict__ yv, int nsteps_total, unsigned x_bytes,
-    const void *__restrict__ addend) {
+    const void *__restrict__ addend, BnRed bn) {
     constexpr int ROWS = 4 * MI * 16;
     constexpr int VEC = NB * 64;                           // uint4 per weight stage (one contraction step)
     constexpr int WPT = (VEC + 255) / 256;
@@ -420,7 +634,10 @@ __global__ __launch_bounds__(256) void gather_gemm_cls_kernel(
     const int tiles_per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     const int v0 = tile * ROWS;
-    if (v0 >= vstart[T.ncls]) return;
+    if (v0 >= vstart[T.ncls]) {
+        if (bn.mode) bnred_zero_row(bn, tile, c_out);
+        return;
+    }
     int cls_v = 0;
     for (int q = 1; q < T.ncls; ++q)
         if (vstart[q] <= v0) cls_v = q;
@@ -429,6 +646,7 @@ __global__ __launch_bounds__(256) void gather_gemm_cls_kernel(
     const int cls = __builtin_amdgcn_readfirstlane(cls_v);
     const int nk = T.nk[cls];
     int *kk_s = nbr_s + 9 * ROWS;                          // [8] usable offsets of this class
+    float *red_s = (float *)(kk_s + 8);                    // [4][2][c_out], only with bn.mode
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) kk_s[j] = T.k[cls][j];
@@ -517,54 +735,35 @@ __global__ __launch_bounds__(256) void gather_gemm_cls_kernel(
         __syncthreads();
     }
 
+    int rows[MI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = row_s[tile_row + mi * 16];
-        if (row < 0) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = nb * 16 + g * 4;
-            f32x4 v = acc[mi][nb];
-            if (OUT_BF16) {
-                if (addend) {
-                    uint2 ad = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + (size_t)row * c_out + col);
-                    v[0] += __uint_as_float(ad.x << 16);
-                    v[1] += __uint_as_float(ad.x & 0xffff0000u);
-                    v[2] += __uint_as_float(ad.y << 16);
-                    v[3] += __uint_as_float(ad.y & 0xffff0000u);
-                }
-                unsigned short *y = (unsigned short *)yv + (size_t)row * c_out + col;
-                uint2 o;
-                o.x = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
-                o.y = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(y) = o;
-            } else {
-                if (addend) {
-                    float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + (size_t)row * c_out + col);
-                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                }
-                float *y = (float *)yv + (size_t)row * c_out + col;
-                *reinterpret_cast<float4 *>(y) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
+    for (int mi = 0; mi < MI; ++mi) rows[mi] = row_s[tile_row + mi * 16];
+    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g, rl, wave, tile, nullptr, addend, yv, bn, red_s);
 }
 
 template <int NB, int MI>
 static int launch_gg_cls(const void *x, int c_in, int cshift, const void *wp, const int32_t *nbr, int nbr_stride,
                          int K, const int32_t *perm, const int32_t *vstart, const ClsTable &T, int vcap, void *y,
-                         int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend) {
+                         int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend,
+                         const PcdBnReduce *bnr, int *tiles_only) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(vcap, ROWS), 8) * 8;
-    size_t lds = (size_t)2 * NB * 64 * sizeof(uint4) + (size_t)(1 + 9) * ROWS * sizeof(int) + 8 * sizeof(int);
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
+    size_t lds = (size_t)2 * NB * 64 * sizeof(uint4) + (size_t)(1 + 9) * ROWS * sizeof(int) + 8 * sizeof(int) +
+                 (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
     if (y_dtype == PCD_BF16)
         gather_gemm_cls_kernel<NB, MI, true><<<grid, 256, lds, st>>>(
             (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
-            nsteps, x_bytes, addend);
+            nsteps, x_bytes, addend, bn);
     else
         gather_gemm_cls_kernel<NB, MI, false><<<grid, 256, lds, st>>>(
             (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
-            nsteps, x_bytes, addend);
+            nsteps, x_bytes, addend, bn);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -909,16 +1108,17 @@ extern "C" int pcd_pack_weights_batched(const void *table, int n, int total_bloc
     return PCD_OK;
 }
 
-extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w,
-                                           const float *bias, const int32_t *nbr, int nbr_stride,
-                                           int kvol, int flip_k, int n_rows_out,
-                                           const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype,
-                                           const void *addend, void *stream) {
-    PCD_ENTER();
+static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
+                       const int32_t *nbr, int nbr_stride, int kvol, int flip_k, int n_rows_out,
+                       const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype, const void *addend,
+                       const PcdBnReduce *bnr, int *tiles_only, void *stream) {
     if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
     if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
-    if (n_rows_out == 0) return PCD_OK;
-    if (!x || !packed_w || !nbr || !y || nbr_stride < n_rows_out) return PCD_ERR_INVALID_ARG;
+    if (n_rows_out == 0) {
+        if (tiles_only) *tiles_only = 0;
+        return PCD_OK;
+    }
+    if (!tiles_only && (!x || !packed_w || !nbr || !y || nbr_stride < n_rows_out)) return PCD_ERR_INVALID_ARG;
     int cshift = log2_exact(c_in);
     if (cshift < 3 || (c_out % 16) != 0) return PCD_ERR_UNSUPPORTED;
     if (n_rows_in < 0 || (double)n_rows_in * c_in * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
@@ -935,7 +1135,7 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
     // rows per wave (MI x 16) shrink with the row count to keep >= ~3 workgroups per CU in flight
     // (measured on gfx950, 128 ch / 42k rows: MI 1/2/4 = 61/68/77 us; 64 ch / 115k rows: 60/55/53 us).
     const int mi = n_rows_out >= 96 * 1024 ? 4 : n_rows_out >= 48 * 1024 ? 2 : 1;
-#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
         case 1:
             return resident ? launch_gg<1, 1, 2, 0>(GG_ARGS) : launch_gg<1, 1, 2, 4>(GG_ARGS);
@@ -955,12 +1155,39 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
 #undef GG_ARGS
 }
 
+extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w,
+                                           const float *bias, const int32_t *nbr, int nbr_stride,
+                                           int kvol, int flip_k, int n_rows_out,
+                                           const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype,
+                                           const void *addend, const PcdBnReduce *bn_reduce, void *stream) {
+    PCD_ENTER();
+    return gg_dispatch(x, n_rows_in, c_in, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev,
+                       c_out, y, y_dtype, addend, bn_reduce, nullptr, stream);
+}
+
+extern "C" int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out) {
+    int tiles = 0;
+    int rc = gg_dispatch(nullptr, n_rows_in, c_in, nullptr, nullptr, nullptr, 0, kvol, 0, n_rows_out, nullptr, c_out,
+                         nullptr, PCD_BF16, nullptr, nullptr, &tiles, nullptr);
+    return rc == PCD_OK ? tiles : rc;
+}
+
+// a class tile runs only 1..8 of the K offsets: little work per workgroup, so small tiles (more workgroups in
+// flight) hide its prologue better than the generic kernel's row-count rule (measured: 1 / 2 / 4 within 10 %)
+static int cls_mi(int n_rows_in) { return n_rows_in >= 64 * 1024 ? 2 : 1; }
+
+extern "C" int pcd_sparse_conv_dgrad_classes_tiles(int vcap, int n_rows_in) {
+    if (vcap < 0 || n_rows_in < 0) return PCD_ERR_INVALID_ARG;
+    if (vcap == 0 || n_rows_in == 0) return 0;
+    return pcd_div_up(pcd_div_up(vcap, 64 * cls_mi(n_rows_in)), 8) * 8;
+}
+
 extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const void *packed_w,
                                              const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
                                              const int *stride_host, const int *pad_host, const int *dil_host,
                                              const int32_t *perm, const int32_t *vstart_dev, int vcap,
                                              int n_rows_in, int c_in, void *dx, int dx_dtype, const void *addend,
-                                             void *stream) {
+                                             const PcdBnReduce *bn_reduce, void *stream) {
     PCD_ENTER();
     if (!ksize_host || !stride_host || !pad_host || !dil_host) return PCD_ERR_INVALID_ARG;
     if (n_rows_in < 0 || vcap < 0 || c_dy <= 0 || c_in <= 0) return PCD_ERR_INVALID_ARG;
@@ -997,8 +1224,9 @@ extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int 
     hipStream_t st = (hipStream_t)stream;
     // a class tile runs only 1..8 of the K offsets: little work per workgroup, so small tiles (more workgroups in
     // flight) hide its prologue better than the generic kernel's row-count rule
-    const int mi = n_rows_in >= 64 * 1024 ? 2 : 1;   // (measured: 1 / 2 / 4 within 10 % of each other)
-#define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend
+    const int mi = cls_mi(n_rows_in);
+    int *tiles_only = nullptr;
+#define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend, bn_reduce, tiles_only
 #define CLS_MI(NBV) (mi == 4 ? launch_gg_cls<NBV, 4>(CLS_ARGS) : mi == 2 ? launch_gg_cls<NBV, 2>(CLS_ARGS) : launch_gg_cls<NBV, 1>(CLS_ARGS))
     switch (c_in / 16) {
         case 1: return CLS_MI(1);

@@ -359,7 +359,49 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 CLS_TILE = 256
 
 
-def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None):
+class BnReduce:
+    """Per-channel sums a conv kernel takes over its OUTPUT tile for the BatchNorm beside it (C ABI: PcdBnReduce).
+    mode 1: forward statistics (sum y, sum y^2); mode 2: the two BatchNorm-backward reductions, the conv output
+    being dy of the BatchNorm described by (x = its input, y = its output (needed when relu), mean, invstd).
+    After the launch `partial` [rows, 2, c] / `rows` hold the result for ops.bn_forward / ops.bn_backward."""
+
+    def __init__(self, mode, relu=False, x=None, y=None, mean=None, invstd=None):
+        self.mode, self.relu = mode, bool(relu)
+        self.x, self.y, self.mean, self.invstd = x, y, mean, invstd
+        self.partial, self.rows = None, 0
+
+    def usable(self, c_out, out_dtype):
+        if out_dtype != torch.bfloat16:
+            return False
+        if self.mode == 2:
+            if self.x is None or self.x.dtype != torch.bfloat16 or self.x.shape[1] != c_out:
+                return False
+            if self.relu and (self.y is None or self.y.dtype != torch.bfloat16 or self.y.shape != self.x.shape):
+                return False
+            for t in (self.mean, self.invstd):
+                if t is None or t.dtype != torch.float32 or t.data_ptr() % 16:
+                    return False
+        return True
+
+    def _struct(self, tiles, c_out, device):
+        self.partial = torch.empty((max(tiles, 1), 2, c_out), dtype=torch.float32, device=device)
+        self.rows = tiles
+        return L.PcdBnReduce(self.mode, int(self.relu), L.ptr(self.x), L.ptr(self.y), L.ptr(self.mean),
+                             L.ptr(self.invstd), L.ptr(self.partial), tiles)
+
+
+def _tiles(v, what):
+    if v < 0:
+        L.check(v, what)
+    return v
+
+
+def _byref(struct):
+    import ctypes
+    return ctypes.cast(ctypes.pointer(struct), ctypes.c_void_p) if struct is not None else None
+
+
+def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None, bn_reduce=None):
     """Data gradient of the strided conv `rb` over its parity-class row groups: dx [n_in, c_in].
     Same result as gather_gemm(dy, packed_w, None, rb.nbr_in, ...), running only the offsets each class can use."""
     _require_cuda(dy, packed_w)
@@ -373,11 +415,16 @@ def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None):
         return dict(bytes=(dy.shape[0] * dy.shape[1] + rb.n_in * c_in) * 2 + 8 * pairs + rb.kvol * dy.shape[1] * c_in * 2,
                     flops=2 * pairs * dy.shape[1] * c_in, rows=rb.n_in, pairs=pairs)
 
+    bnr = None
+    if bn_reduce is not None:
+        tiles = L.lib().pcd_sparse_conv_dgrad_classes_tiles(vcap, rb.n_in)
+        bnr = bn_reduce._struct(_tiles(tiles, "pcd_sparse_conv_dgrad_classes_tiles"), c_in, dy.device)
     with _Timed(f"gather_gemm_cls_kernel<NB={c_in // 16}> {dy.shape[1]}->{c_in} K={rb.kvol}", meta):
         L.check(L.lib().pcd_sparse_conv_dgrad_classes(
             L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(rb.nbr_in), rb.nbr_in.shape[1],
             L.host_i32(rb.ksize), L.host_i32(rb.stride), L.host_i32(rb.padding), L.host_i32(rb.dilation), L.ptr(perm),
-            L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), L.stream_ptr()),
+            L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), _byref(bnr),
+            L.stream_ptr()),
             "pcd_sparse_conv_dgrad_classes")
     return dx
 
@@ -433,7 +480,8 @@ class PackPlan:
         return self.packed
 
 
-def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None, addend=None):
+def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None, addend=None,
+                bn_reduce=None):
     """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o])  (output-stationary; forward and dgrad)."""
     _require_cuda(x, packed_w, nbr)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
@@ -448,11 +496,15 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
                     + kvol * x.shape[1] * c_out * e, flops=2 * pairs * x.shape[1] * c_out,
                     rows=n_rows_out, pairs=pairs)
 
+    bnr = None
+    if bn_reduce is not None:
+        tiles = L.lib().pcd_sparse_conv_gather_gemm_tiles(x.shape[0], x.shape[1], kvol, n_rows_out, c_out)
+        bnr = bn_reduce._struct(_tiles(tiles, "pcd_sparse_conv_gather_gemm_tiles"), c_out, x.device)
     with _Timed(f"gather_gemm_kernel<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
         L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
                                                     L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),
-                                                    L.ptr(addend), L.stream_ptr()),
+                                                    L.ptr(addend), _byref(bnr), L.stream_ptr()),
                 "pcd_sparse_conv_gather_gemm")
     return y
 
@@ -530,8 +582,10 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
 
 
 # ---------------------------------------------------------------------------------------------
-def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu, n_dev=None):
+def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu, n_dev=None,
+               partials=None):
     """Fused BatchNorm1d (+residual) (+ReLU) over [n, c] (spconv_backbone.py:21-25,50-66).
+    `partials` = (tensor [rows, 2, c], rows): column sums the producing conv already took (BnReduce mode 1).
     Returns (y, save_mean, save_invstd)."""
     _require_cuda(x)
     assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
@@ -545,12 +599,14 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
     L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
                                float(eps), float(momentum), int(training), L.ptr(running_mean),
                                L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
-                               L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_forward")
+                               L.ptr(n_dev), L.ptr(partials[0]) if partials else None,
+                               partials[1] if partials else 0, L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "pcd_bn_forward")
     return y, save_mean, save_invstd
 
 
 def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None,
-                dgamma_out=None, dbeta_out=None, beta=None):
+                dgamma_out=None, dbeta_out=None, beta=None, partials=None):
     """y may be None (relu, forward without residual, training): the ReLU mask is recomputed from x and the
     affine parameters (`beta` required then) instead of being read from the saved output."""
     _require_cuda(dy, x)
@@ -567,8 +623,9 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
     L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
                                 L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
-                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev), L.ptr(ws), ws.numel(),
-                                L.stream_ptr()), "pcd_bn_backward")
+                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
+                                L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
+                                L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
     return dx, dres, dgamma, dbeta
 
 

@@ -19,6 +19,12 @@ WGRAD_JOIN_LAG = 0
 # kernel per parameter (79 tiny launches per step on the critical path of VoxelResBackBone8x).
 DIRECT_GRAD = False
 USE_DGRAD_CLASSES = True      # strided-conv data gradient over parity-class row groups (ops.dgrad_classes)
+# The conv kernels take the per-channel sums of the BatchNorm beside them in their epilogue (ops.BnReduce): the
+# forward conv the batch statistics of the BatchNorm that follows it, the data-gradient kernel the two reductions
+# of the BatchNorm whose output was the conv's input.  Each replaces one streaming pass + launch per BatchNorm.
+# The hand-over goes through attributes on the tensors (`_pcd_stats` on a conv output, `_pcd_bn_link` on a
+# BatchNorm output) and is only used when the consumer sees exactly that tensor.
+FUSE_BN_REDUCTIONS = True
 _SIDE = {}
 _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not yet joined
 
@@ -73,8 +79,19 @@ class SparseConvFunction(Function):
         x = _to_bf16_padded(features.detach(), cin_pad)
         out_dtype = features.dtype if features.dtype in (torch.float32, torch.bfloat16) else torch.float32
         b = bias.detach().float().contiguous() if bias is not None else None
+        stats = None
+        if FUSE_BN_REDUCTIONS and out_dtype == torch.bfloat16 and cout % 16 == 0 and ctx.needs_input_grad[1]:
+            stats = ops.BnReduce(1)              # training: a BatchNorm follows every conv of the backbones
         y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
-                            n_dev=rb.n_out_dev)
+                            n_dev=rb.n_out_dev, bn_reduce=stats)
+        if stats is not None:
+            y._pcd_stats = stats
+        # the input is the output of a fused BatchNorm: its backward reductions can ride on our data gradient
+        link = getattr(features, "_pcd_bn_link", None) if FUSE_BN_REDUCTIONS else None
+        if link is not None and not (features.dtype == torch.bfloat16 and x.data_ptr() == features.data_ptr()
+                                     and x.shape == features.shape):
+            link = None
+        ctx.bn_link = link
         ctx.rb = rb
         ctx.packed_dgrad = packed_dgrad          # callable returning the (cached) dgrad pack of the module
         ctx.cin, ctx.cout, ctx.cin_pad = cin, cout, cin_pad
@@ -119,16 +136,25 @@ class SparseConvFunction(Function):
             add = None
             if d_ident is not None and ctx.cin_pad == ctx.in_cols and d_ident.dtype == ctx.in_dtype:
                 add = d_ident.contiguous()           # fused: dx = dgrad + identity-branch gradient
+            link, red = ctx.bn_link, None
+            if link is not None and (d_ident is None or add is not None):
+                # the ReLU mask comes from the BatchNorm's output, which is this conv's saved input x
+                red = ops.BnReduce(2, link.relu, x=link.x, y=x if link.relu else None, mean=link.mean,
+                                   invstd=link.invstd)
+                if not red.usable(ctx.cin_pad, ctx.in_dtype):
+                    red = None
             if rb.subm:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red)
             elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
                     and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
                 # strided conv: rows grouped by parity class run only the 1..8 offsets they can use
-                dxp = ops.dgrad_classes(dy16, packed_d, rb, ctx.cin_pad, ctx.in_dtype, addend=add)
+                dxp = ops.dgrad_classes(dy16, packed_d, rb, ctx.cin_pad, ctx.in_dtype, addend=add, bn_reduce=red)
             else:
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_in, rb.kvol, False, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red)
+            if red is not None:
+                link.result = (dxp, red.partial, red.rows)   # dxp stays referenced: its address cannot be reused
             dx = dxp if ctx.cin_pad == ctx.in_cols else dxp[:, :ctx.in_cols].contiguous()
             if d_ident is not None and add is None:
                 dx = dx + d_ident.to(dx.dtype)
@@ -203,6 +229,16 @@ def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passt
     return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
 
 
+class _BnLink:
+    """What the data-gradient kernel of the NEXT conv needs to take this BatchNorm's backward reductions
+    (attached to the BatchNorm output as `_pcd_bn_link`; holds no reference to that output)."""
+    __slots__ = ("relu", "x", "mean", "invstd", "result")
+
+    def __init__(self, relu, x, mean, invstd):
+        self.relu, self.x, self.mean, self.invstd = relu, x, mean, invstd
+        self.result = None     # (dx tensor, partial [rows, 2, c], rows) left by the data-gradient kernel
+
+
 class FusedBNFunction(Function):
     """nn.BatchNorm1d (+ residual add) (+ nn.ReLU) on `.features` in two streaming passes
     (spconv_backbone.py:21-25,50-66); parameters / buffers stay in the caller's nn.BatchNorm1d."""
@@ -217,8 +253,13 @@ class FusedBNFunction(Function):
         momentum = bn.momentum if bn.momentum is not None else 0.1
         g = gamma.detach().float() if gamma is not None else None
         b = beta.detach().float() if beta is not None else None
+        partials = None
+        st = getattr(x, "_pcd_stats", None) if (FUSE_BN_REDUCTIONS and training) else None
+        if st is not None and st.partial is not None and xc.data_ptr() == x.data_ptr() \
+                and xc.dtype == torch.bfloat16 and st.partial.shape[2] == xc.shape[1]:
+            partials = (st.partial, st.rows)         # the conv that produced x already summed its columns
         y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
-                                                   bn.running_var, relu, n_dev=n_dev)
+                                                   bn.running_var, relu, n_dev=n_dev, partials=partials)
         if not training:
             save_mean = bn.running_mean
             save_invstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -228,6 +269,10 @@ class FusedBNFunction(Function):
         # without a residual the ReLU mask is recomputed from x in the backward (one [n][c] read less per pass)
         ctx.mask_from_x = bool(relu and residual is None and training and b is not None)
         ctx.save_for_backward(xc, None if ctx.mask_from_x else y, g, b, save_mean, save_invstd)
+        ctx.link = None
+        if FUSE_BN_REDUCTIONS and training and xc.dtype == torch.bfloat16:
+            ctx.link = _BnLink(bool(relu), xc, save_mean, save_invstd)
+            y._pcd_bn_link = ctx.link
         return y
 
     @staticmethod
@@ -240,11 +285,19 @@ class FusedBNFunction(Function):
         gb = bn.bias.grad if (DIRECT_GRAD and bn.bias is not None and ctx.needs_input_grad[2]) else None
         direct = gw is not None and gb is not None and ops._usable_out(gw, x.shape[1]) \
             and ops._usable_out(gb, x.shape[1])
+        partials = None
+        link = ctx.link
+        if link is not None and link.result is not None:
+            rdx, part, rows = link.result
+            link.result = None
+            if rdx.data_ptr() == dy.data_ptr() and rdx.shape == dy.shape and dy.dtype == x.dtype \
+                    and dy.is_contiguous():
+                partials = (part, rows)              # dy IS the tensor whose kernel took the reductions
         dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
                                                   ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev,
                                                   dgamma_out=gw if direct else None,
                                                   dbeta_out=gb if direct else None,
-                                                  beta=b if ctx.mask_from_x else None)
+                                                  beta=b if ctx.mask_from_x else None, partials=partials)
         if direct:
             dgamma = dbeta = None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,

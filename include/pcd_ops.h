@@ -165,6 +165,28 @@ int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int
                              int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* Optional per-channel reductions of the OUTPUT tile in the epilogue of pcd_sparse_conv_gather_gemm /
+ * pcd_sparse_conv_dgrad_classes (bf16 outputs only; NULL or mode 0 = off).  The BatchNorm1d that follows every conv of
+ * the reference backbones (spconv_backbone.py:21-25,50-66) needs these sums; taking them while the values are still in
+ * registers replaces one streaming pass per BatchNorm and direction:
+ *   mode 1 (forward)       partial[t] = { sum y, sum y^2 } of the rounded outputs  -> pcd_bn_forward(ext_partial)
+ *   mode 2 (data gradient) the output is dy of the BatchNorm(+ReLU) whose output was the conv's input:
+ *                          partial[t] = { sum dz, sum dz*xhat }, dz = relu ? dy*(y > 0) : dy, xhat = (x-mean)*invstd;
+ *                          y = that BatchNorm's output = the conv's own input features (required when relu)
+ *                                                                               -> pcd_bn_backward(ext_partial)
+ * One row [2][c_out] per workgroup tile t; partial_rows must be >= pcd_sparse_conv_gather_gemm_tiles(..) /
+ * pcd_sparse_conv_dgrad_classes_tiles(..), which is also the row count to hand to the BatchNorm call.
+ * mean / invstd must be 16-byte aligned.  Fixed summation order (deterministic). */
+typedef struct PcdBnReduce {
+    int mode;
+    int relu;
+    const void *x;            /* mode 2: BatchNorm input  [rows][c_out] bf16 */
+    const void *y;            /* mode 2: BatchNorm output [rows][c_out] bf16 (NULL when relu == 0) */
+    const float *mean, *invstd;
+    float *partial;           /* out: [partial_rows][2][c_out] f32 */
+    int partial_rows;
+} PcdBnReduce;
+
 /* Parity classes of the input rows of a strided conv, for its data gradient: input coordinate c reaches an output
  * cell through kernel index k only if (c + p - k*d) is a multiple of the stride, so the residues ((c + p) mod s) of
  * the three axes select the 1..8 offsets (of 27 for k = 3, s = 2) a row can use at all.
@@ -181,7 +203,9 @@ int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const
                                   const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
                                   const int *stride_host, const int *pad_host, const int *dil_host,
                                   const int32_t *perm, const int32_t *vstart_dev, int vcap, int n_rows_in, int c_in,
-                                  void *dx, int dx_dtype, const void *addend, void *stream);
+                                  void *dx, int dx_dtype, const void *addend, const PcdBnReduce *bn_reduce,
+                                  void *stream);
+int pcd_sparse_conv_dgrad_classes_tiles(int vcap, int n_rows_in);
 
 /* ============================================================================================
  * (a8-a10) sparse convolution arithmetic -- replaces spconv's indice_conv fwd/bwd.
@@ -217,7 +241,9 @@ int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *s
 int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
-                                int y_dtype, const void *addend, void *stream);
+                                int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
+/* number of workgroup tiles (= partial rows of bn_reduce) of that launch; < 0: error code */
+int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
@@ -260,6 +286,8 @@ int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32
  *             y may be NULL when relu != 0 and the forward had NO residual: the mask is then recomputed from
  *             x, gamma, beta (required in that case), save_mean, save_invstd exactly as the forward computed
  *             it, which saves one [n][c] read in each of the two backward passes.
+ * ext_partial (NULL = compute here): [ext_rows][2][c] sums already taken by a conv epilogue (PcdBnReduce); the
+ *             statistics / reduction pass is then skipped.
  * c % 8 == 0 (bf16) / c % 4 == 0 (f32), c/piece a power of two <= 256.  Deterministic (no atomics).
  * ============================================================================================ */
 size_t pcd_bn_workspace_bytes(int c);
@@ -269,11 +297,13 @@ int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, const int32_
 int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c, const float *gamma,
                    const float *beta, float eps, float momentum, int training, float *running_mean,
                    float *running_var, int relu, void *y, float *save_mean, float *save_invstd,
-                   const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+                   const int32_t *n_dev, const float *ext_partial, int ext_rows, void *workspace,
+                   size_t workspace_bytes, void *stream);
 int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
                     const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
                     int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                    const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+                    const int32_t *n_dev, const float *ext_partial, int ext_rows, void *workspace,
+                    size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (a15) update end of the data-parallel step: gradient-norm clipping + Adam on ONE flat fp32 buffer

@@ -429,6 +429,118 @@ def test_strided_dgrad_by_parity_class_equals_generic():
 
 
 @pytest.mark.gpu
+def test_conv_epilogue_takes_batchnorm_reductions():
+    """PcdBnReduce: the sums a conv kernel takes over its output tile equal what the BatchNorm kernels compute from
+    the stored tensor -- forward statistics (mode 1) and the two backward reductions (mode 2: mask from y,
+    no ReLU), for every output width and both data-gradient kernels; handing them to
+    pcd_bn_forward / pcd_bn_backward reproduces the unfused results (fp32 sums to 1e-5 of their scale, bf16
+    outputs within one rounding on a handful of elements)."""
+    ops = _ops()
+    torch.manual_seed(5)
+    frames = [synth.synth_cloud(0, 32, 1250)]
+    pts, offs = __import__("com_amd.hotpath", fromlist=["x"]).collate_points(frames, DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
+                            num_features=5, want_voxels=False)
+    idx, shape = res["coords"], [41, 1504, 1504]
+    n = idx.shape[0]
+    rb = ops.rulebook_subm(idx, 1, shape)
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-4, what
+
+    for c in (16, 32, 64, 128):
+        x = torch.randn(n, c, device=DEV).bfloat16()
+        w = torch.randn(c, 27, c, device=DEV) * 0.05
+        bias = torch.randn(c, device=DEV)
+        # forward statistics
+        st = ops.BnReduce(1)
+        y = ops.gather_gemm(x, ops.pack_weight(w, 0), bias, rb.nbr_out, 27, False, n, c, torch.bfloat16, bn_reduce=st)
+        y_plain = ops.gather_gemm(x, ops.pack_weight(w, 0), bias, rb.nbr_out, 27, False, n, c, torch.bfloat16)
+        assert torch.equal(y.view(torch.int16), y_plain.view(torch.int16))
+        assert st.partial.shape == (st.rows, 2, c)
+        close(st.partial[:, 0].double().sum(0), y.double().sum(0), ("sum", c))
+        close(st.partial[:, 1].double().sum(0), (y.double() ** 2).sum(0), ("sumsq", c))
+        gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.3
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        o1, m1, i1 = ops.bn_forward(y, None, gamma, beta, 1e-3, 0.01, True, rm.clone(), rv.clone(), True)
+        o2, m2, i2 = ops.bn_forward(y, None, gamma, beta, 1e-3, 0.01, True, rm.clone(), rv.clone(), True,
+                                    partials=(st.partial, st.rows))
+        close(m2, m1, "mean"), close(i2, i1, "invstd")
+        assert float((o1.float() - o2.float()).abs().max()) <= 0.02 * float(o1.float().abs().max())
+        # backward reductions: y / o1 / m1 / i1 describe a BatchNorm(+ReLU) whose output feeds the next conv
+        pd = ops.pack_weight(w, 1)
+        dyn = torch.randn(n, c, device=DEV).bfloat16()
+        add = torch.randn(n, c, device=DEV).bfloat16()
+        for relu, ysrc in ((True, o1), (False, None)):
+            red = ops.BnReduce(2, relu, x=y, y=ysrc, mean=m1, invstd=i1)
+            assert red.usable(c, torch.bfloat16)
+            dx = ops.gather_gemm(dyn, pd, None, rb.nbr_out, 27, True, n, c, torch.bfloat16, addend=add, bn_reduce=red)
+            dx_plain = ops.gather_gemm(dyn, pd, None, rb.nbr_out, 27, True, n, c, torch.bfloat16, addend=add)
+            assert torch.equal(dx.view(torch.int16), dx_plain.view(torch.int16))
+            a = ops.bn_backward(dx, y, ysrc, gamma, m1, i1, relu, True, False, beta=beta)
+            b = ops.bn_backward(dx, y, ysrc, gamma, m1, i1, relu, True, False, beta=beta,
+                                partials=(red.partial, red.rows))
+            close(b[3], a[3], ("dbeta", c, relu)), close(b[2], a[2], ("dgamma", c, relu))
+            assert float((a[0].float() - b[0].float()).abs().max()) <= 0.02 * float(a[0].float().abs().max())
+    # the class kernel of a strided conv's data gradient
+    rbc = ops.rulebook_conv(idx, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    for cin, cout in ((16, 32), (64, 64)):
+        xin = torch.randn(n, cin, device=DEV).bfloat16()               # BatchNorm input at the conv's input level
+        mean, invstd = torch.randn(cin, device=DEV) * 0.1, torch.rand(cin, device=DEV) + 0.5
+        gamma, beta = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.3
+        w = torch.randn(cout, 27, cin, device=DEV) * 0.05
+        dyn = torch.randn(rbc.n_out, cout, device=DEV).bfloat16()
+        yout = torch.relu(torch.randn(n, cin, device=DEV)).bfloat16()   # that BatchNorm's (ReLU) output
+        red = ops.BnReduce(2, True, x=xin, y=yout, mean=mean, invstd=invstd)
+        dx = ops.dgrad_classes(dyn, ops.pack_weight(w, 1), rbc, cin, torch.bfloat16, bn_reduce=red)
+        a = ops.bn_backward(dx, xin, yout, gamma, mean, invstd, True, True, False)
+        b = ops.bn_backward(dx, xin, yout, gamma, mean, invstd, True, True, False,
+                            partials=(red.partial, red.rows))
+        close(b[3], a[3], ("cls dbeta", cin)), close(b[2], a[2], ("cls dgamma", cin))
+
+
+@pytest.mark.gpu
+def test_backbone_with_fused_reductions_matches_unfused():
+    """VoxelResBackBone8x forward + backward with the BatchNorm reductions taken inside the conv kernels
+    (functional.FUSE_BN_REDUCTIONS) vs the separate reduction kernels: same loss and parameter gradients up to the
+    bf16 rounding noise the different fp32 summation order can flip."""
+    from com_amd import hotpath, ops
+    from com_amd.spconv import functional as F
+    frames = [synth.synth_cloud(f, 16, 1250) for f in range(2)]
+    pts, offs = hotpath.collate_points(frames, DEV)
+    grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+    torch.manual_seed(3)
+    net = hotpath.VoxelResBackBone8x({}, 5, grid).to(DEV)
+    bev = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256})
+
+    def run(flag):
+        old = F.FUSE_BN_REDUCTIONS
+        F.FUSE_BN_REDUCTIONS = flag
+        try:
+            bd = {"points": pts, "frame_offsets": offs, "batch_size": 2}
+            bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000)
+            bd = bev(net(bd))
+            net.zero_grad()
+            loss = bd["spatial_features"].float().square().mean()
+            loss.backward()
+            F.join_deferred_wgrad()
+            return float(loss), [p.grad.clone() for p in net.parameters()]
+        finally:
+            F.FUSE_BN_REDUCTIONS = old
+
+    for m in net.modules():                       # same running statistics for both runs
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.momentum = 0.0
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0 - l1) <= 2e-3 * abs(l0)
+    num = sum(float((a - b).double().square().sum()) for a, b in zip(g0, g1))
+    den = sum(float(a.double().square().sum()) for a in g0)
+    assert num <= (3e-2 ** 2) * den, (num / den) ** 0.5
+
+
+@pytest.mark.gpu
 def test_flat_adam_matches_torch_adam_with_clipping():
     """pcd_adam_flat_step == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(weight_decay, betas) on the same
     parameters over several steps (including the rank-sum / world-size form), fp32, to 1e-6 relative."""
