@@ -211,6 +211,63 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
     if (slice != 0) ch = c;  // only slice 0 carries the result
 }
 
+// Two-stage finalisation of the partial sums (used instead of the single-workgroup kernels above when the apply
+// pass follows): MID_ROWS workgroups each sum an interleaved subset of the partial rows in double (coalesced over
+// the 2c columns, fixed order) -> mid[MID_ROWS][2c]; every workgroup of the apply kernel then adds the MID_ROWS
+// rows itself (16 loads per column, L2 hits) instead of waiting for one workgroup to chew through up to 5000 rows
+// (conv tiles deliver one partial row each): 10-12 us -> ~3 us + a 1 us prologue.
+constexpr int MID_ROWS = 16;
+
+__global__ __launch_bounds__(256) void bn_mid_kernel(const float *__restrict__ partial, int nblocks, int c,
+                                                     double *__restrict__ mid) {
+    __shared__ double lds[256];
+    const int cols = 2 * c;
+    int cp = 1;
+    while (cp < cols && cp < 256) cp <<= 1;
+    const int slices = 256 / cp;                       // cols > 256: one slice, columns looped
+    const int slice = threadIdx.x / cp;
+    for (int col0 = 0; col0 < cols; col0 += cp) {
+        const int col = col0 + (threadIdx.x - slice * cp);
+        double a = 0.0;
+        if (col < cols) {
+            int blk = blockIdx.x + MID_ROWS * slice;
+            const int step = MID_ROWS * slices;
+            for (; blk + 3 * step < nblocks; blk += 4 * step) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = partial[(size_t)(blk + u * step) * cols + col];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += (double)v[u];
+            }
+            for (; blk < nblocks; blk += step) a += (double)partial[(size_t)blk * cols + col];
+        }
+        lds[threadIdx.x] = a;
+        __syncthreads();
+        if (slice == 0 && col < cols) {
+            double s = 0.0;
+            for (int q = 0; q < slices; ++q) s += lds[q * cp + (threadIdx.x)];
+            mid[(size_t)blockIdx.x * cols + col] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// tot[0..2c) = column totals of mid (every workgroup of an apply kernel; ends with a barrier)
+__device__ __forceinline__ void mid_totals(const double *__restrict__ mid, int c, double *tot) {
+    const int cols = 2 * c;
+    for (int t = threadIdx.x; t < cols; t += blockDim.x) {
+        double v[MID_ROWS];
+#pragma unroll
+        for (int r = 0; r < MID_ROWS; ++r) v[r] = mid[(size_t)r * cols + t];
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < MID_ROWS; ++r) s += v[r];
+        tot[t] = s;
+    }
+    __syncthreads();
+}
+static size_t bn_mid_lds_bytes(int c) { return (size_t)2 * c * sizeof(double) + (size_t)2 * c * sizeof(float); }
+
 // grid = 1, block = 1024: mean / invstd / running stats; scale/shift for the apply pass
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ partial, int nblocks, int n_cap, const int32_t *n_dev, int c,
@@ -249,19 +306,62 @@ __global__ void bn_eval_coeff_kernel(int c, const float *gamma, const float *bet
     shift[ch] = b - rm[ch] * g * invstd;
 }
 
+// training-mode finalisation done inside bn_apply_kernel (mid == nullptr: scale / shift come from memory)
+struct BnFin {
+    const double *mid;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var, *save_mean, *save_invstd;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, const T *__restrict__ res,
                                                        int n_cap, const int32_t *n_dev, int c,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int relu,
-                                                       T *__restrict__ y, int vec) {
+                                                       T *__restrict__ y, int vec, BnFin fin) {
     constexpr int N = Piece<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
-    load_params<N>(scale, piece * N, vec, sc);
-    load_params<N>(shift, piece * N, vec, sh);
+    if (fin.mid) {
+        // training: finish the batch statistics here (see bn_mid_kernel); workgroup 0 also publishes them
+        double *tot = (double *)dyn_lds;
+        float *sc_s = (float *)(tot + 2 * c), *sh_s = sc_s + c;
+        mid_totals(fin.mid, c, tot);
+        const int n = eff_rows(n_dev, n_cap);
+        for (int ch = threadIdx.x; ch < c; ch += 256) {
+            const double s = tot[ch], ss = tot[c + ch];
+            double mean = n > 0 ? s / n : 0.0;
+            double var = n > 0 ? ss / n - mean * mean : 0.0;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+            const float g = fin.gamma ? fin.gamma[ch] : 1.0f, b = fin.beta ? fin.beta[ch] : 0.0f;
+            sc_s[ch] = g * invstd;
+            sh_s[ch] = b - (float)mean * g * invstd;
+            if (blockIdx.x == 0) {
+                fin.save_mean[ch] = (float)mean;
+                fin.save_invstd[ch] = invstd;
+                if (fin.running_mean)
+                    fin.running_mean[ch] = (1.0f - fin.momentum) * fin.running_mean[ch] + fin.momentum * (float)mean;
+                if (fin.running_var) {
+                    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+                    fin.running_var[ch] = (1.0f - fin.momentum) * fin.running_var[ch] + fin.momentum * (float)unbiased;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            sc[j] = sc_s[piece * N + j];
+            sh[j] = sh_s[piece * N + j];
+        }
+    } else {
+        load_params<N>(scale, piece * N, vec, sc);
+        load_params<N>(shift, piece * N, vec, sh);
+    }
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float v[N], r[N];
         Piece<T>::load(x + e * N, v);
@@ -360,11 +460,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const float *__restrict__ beta,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ invstd,
-                                                           const float *__restrict__ dgamma,
-                                                           const float *__restrict__ dbeta, int relu,
+                                                           float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, int relu,
                                                            int training, T *__restrict__ dx,
-                                                           T *__restrict__ dres, int vec) {
+                                                           T *__restrict__ dres, int vec, const double *mid) {
     constexpr int N = Piece<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
     const int n = eff_rows(n_dev, n_cap);
     const size_t total = (size_t)n * pcs;
@@ -376,7 +477,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     load_params<N>(invstd, piece * N, vec, is);
     if (gamma) load_params<N>(gamma, piece * N, vec, gmv); else fill_params<N>(1.0f, gmv);
     if (beta) load_params<N>(beta, piece * N, vec, btv); else fill_params<N>(0.0f, btv);
-    if (training) {
+    if (training && mid) {
+        // finish the two reductions here (see bn_mid_kernel); workgroup 0 publishes dgamma / dbeta
+        double *tot = (double *)dyn_lds;
+        float *fs = (float *)(tot + 2 * c);
+        mid_totals(mid, c, tot);
+        for (int t = threadIdx.x; t < 2 * c; t += 256) {
+            const float v = (float)tot[t];
+            fs[t] = v;
+            if (blockIdx.x == 0) (t < c ? dbeta[t] : dgamma[t - c]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            k1[j] = fs[piece * N + j];
+            k2[j] = fs[c + piece * N + j];
+        }
+    } else if (training) {
         load_params<N>(dbeta, piece * N, vec, k1);
         load_params<N>(dgamma, piece * N, vec, k2);
     } else {
@@ -429,12 +546,14 @@ static bool shape_ok(int c, int dtype) {
 
 struct BnWs {
     float *partial, *scale, *shift;
+    double *mid;
 };
 static bool bn_ws(void *ws, size_t bytes, int c, BnWs &L) {
     WsCarver w(ws, bytes);
     L.partial = w.take<float>((size_t)MAX_BLOCKS * 2 * c);
     L.scale = w.take<float>(c);
     L.shift = w.take<float>(c);
+    L.mid = w.take<double>((size_t)MID_ROWS * 2 * c);
     return w.ok;
 }
 
@@ -442,7 +561,8 @@ static bool bn_ws(void *ws, size_t bytes, int c, BnWs &L) {
 
 extern "C" size_t pcd_bn_workspace_bytes(int c) {
     if (c <= 0) return 0;
-    return ws_piece((size_t)MAX_BLOCKS * 2 * c, sizeof(float)) + 2 * ws_piece(c, sizeof(float));
+    return ws_piece((size_t)MAX_BLOCKS * 2 * c, sizeof(float)) + 2 * ws_piece(c, sizeof(float)) +
+           ws_piece((size_t)MID_ROWS * 2 * c, sizeof(double));
 }
 
 extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
@@ -473,21 +593,38 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
         else
             bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c,
                                                                   L.partial);
-        bn_finalize_kernel<<<1, 1024, 0, st>>>(ext_partial ? ext_partial : L.partial, ext_partial ? ext_rows : grid, n, n_dev, c, gamma, beta, eps,
-                                                               momentum, running_mean, running_var,
-                                                               save_mean, save_invstd, L.scale, L.shift);
+        const float *part = ext_partial ? ext_partial : L.partial;
+        const int prow = ext_partial ? ext_rows : grid;
+        if (n > 0)   // two-stage: the apply kernel finishes the statistics itself
+            bn_mid_kernel<<<MID_ROWS, 256, 0, st>>>(part, prow, c, L.mid);
+        else
+            bn_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, n, n_dev, c, gamma, beta, eps, momentum, running_mean,
+                                                   running_var, save_mean, save_invstd, L.scale, L.shift);
     } else {
         bn_eval_coeff_kernel<<<pcd_div_up(c, 128), 128, 0, st>>>(c, gamma, beta, running_mean, running_var,
                                                                  eps, L.scale, L.shift);
     }
     if (n > 0) {
+        BnFin fin = {};
+        if (training) {
+            fin.mid = L.mid;
+            fin.gamma = gamma;
+            fin.beta = beta;
+            fin.eps = eps;
+            fin.momentum = momentum;
+            fin.running_mean = running_mean;
+            fin.running_var = running_var;
+            fin.save_mean = save_mean;
+            fin.save_invstd = save_invstd;
+        }
+        const size_t lds = training ? bn_mid_lds_bytes(c) : 0;
         if (dtype == PCD_F32)
-            bn_apply_kernel<float><<<agrid, 256, 0, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
-                                                         L.scale, L.shift, relu, (float *)y, 1);
+            bn_apply_kernel<float><<<agrid, 256, lds, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
+                                                           L.scale, L.shift, relu, (float *)y, 1, fin);
         else
-            bn_apply_kernel<unsigned short><<<agrid, 256, 0, st>>>(
+            bn_apply_kernel<unsigned short><<<agrid, 256, lds, st>>>(
                 (const unsigned short *)x, (const unsigned short *)residual, n, n_dev, c, L.scale, L.shift, relu,
-                (unsigned short *)y, 1);
+                (unsigned short *)y, 1, fin);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -545,26 +682,35 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     if (ext_partial && ext_rows < 0) return PCD_ERR_INVALID_ARG;
     const float *part = ext_partial ? ext_partial : L.partial;     // PcdBnReduce mode 2: sums taken by the dgrad
     const int prow = ext_partial ? ext_rows : grid;
+    const bool two_stage = training && n > 0;      // the apply kernel finishes the reductions itself
+    const double *mid = two_stage ? L.mid : nullptr;
+    const size_t alds = two_stage ? bn_mid_lds_bytes(c) : 0;
+    auto finalize = [&]() {
+        if (two_stage)
+            bn_mid_kernel<<<MID_ROWS, 256, 0, st>>>(part, prow, c, L.mid);
+        else
+            bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
+    };
     if (dtype == PCD_F32) {
         if (!ext_partial)
             bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                                                           save_invstd, relu, L.partial, vec);
-        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
+        finalize();
         if (n > 0)
-            bn_bwd_apply_kernel<float><<<agrid, 256, 0, st>>>(
+            bn_bwd_apply_kernel<float><<<agrid, 256, alds, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec);
+                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid);
     } else {
         typedef unsigned short B;
         if (!ext_partial)
             bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                       gamma, beta, save_mean, save_invstd, relu, L.partial, vec);
-        bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
+        finalize();
         if (n > 0)
-            bn_bwd_apply_kernel<B><<<agrid, 256, 0, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
-                                                         gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                                         relu, training, (B *)dx, (B *)dresidual, vec);
+            bn_bwd_apply_kernel<B><<<agrid, 256, alds, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
+                                                            gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                                                            relu, training, (B *)dx, (B *)dresidual, vec, mid);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

@@ -781,6 +781,38 @@ def test_fused_batchnorm_unaligned_parameter_views():
         assert torch.equal(a, b_)
 
 
+def test_config5_second_300k_point_cloud():
+    """BASELINE config 5 shape (SECOND / VoxelBackBone8x on 300k-point clouds = 120 beams x 2500 azimuth steps,
+    second.yaml:8-17): voxelisation and the first rulebooks bit-exact against the oracle at that size, with the
+    MAX_NUMBER_OF_VOXELS cap both slack (150k) and binding (100k: later first-appearances are dropped), then the
+    plain backbone + HeightCompression forward/backward on the same frame."""
+    from com_amd import hotpath, ops
+    frame = synth.synth_cloud(7, 120, 2500)
+    assert frame.shape == (300000, 5)
+    res = _check_hard([frame], synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000)
+    assert 100000 < res["counts"][0] < 150000
+    capped = _check_hard([frame], synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 100000)
+    assert capped["counts"][0] == 100000
+    idx = _cpu(res["coords"])
+    _check_subm(idx, 1, (41, 1504, 1504))
+    rb, rb_o = _check_conv(idx, 1, (41, 1504, 1504), dict(k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1)))
+    _check_subm(rb_o["out_indices"], 1, (21, 752, 752))
+    torch.manual_seed(2)
+    pts, offs = hotpath.collate_points([frame], DEV)
+    grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+    net = hotpath.VoxelBackBone8x({}, 5, grid).to(DEV)
+    bev = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256})
+    bd = {"points": pts, "frame_offsets": offs, "batch_size": 1}
+    bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000)
+    bd = bev(net(bd))
+    assert bd["spatial_features"].shape == (1, 256, 188, 188)
+    assert bd["multi_scale_3d_features"]["x_conv1"].features.shape == (res["counts"][0], 16)
+    bd["spatial_features"].float().square().mean().backward()
+    from com_amd.spconv import functional as F
+    F.join_deferred_wgrad()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 def test_backbone_end_to_end_shapes_and_determinism():
     """VoxelResBackBone8x + HeightCompression on two 20k-pt frames: output contract of
     spconv_backbone.py:271-291 and bit-reproducibility of forward + backward (no atomics anywhere)."""
