@@ -218,34 +218,42 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
 // (conv tiles deliver one partial row each): 10-12 us -> ~3 us + a 1 us prologue.
 constexpr int MID_ROWS = 16;
 
-__global__ __launch_bounds__(256) void bn_mid_kernel(const float *__restrict__ partial, int nblocks, int c,
-                                                     double *__restrict__ mid) {
-    __shared__ double lds[256];
+__global__ __launch_bounds__(1024) void bn_mid_kernel(const float *__restrict__ partial, int nblocks, int c,
+                                                      double *__restrict__ mid) {
+    __shared__ double lds[1024];
     const int cols = 2 * c;
     int cp = 1;
-    while (cp < cols && cp < 256) cp <<= 1;
-    const int slices = 256 / cp;                       // cols > 256: one slice, columns looped
+    while (cp < cols && cp < 1024) cp <<= 1;
+    const int slices = 1024 / cp;                      // cols > 1024: one slice, columns looped
     const int slice = threadIdx.x / cp;
     for (int col0 = 0; col0 < cols; col0 += cp) {
         const int col = col0 + (threadIdx.x - slice * cp);
         double a = 0.0;
         if (col < cols) {
+            // latency bound (a few dozen rows per slice): 8 independent loads in flight per thread
             int blk = blockIdx.x + MID_ROWS * slice;
             const int step = MID_ROWS * slices;
-            for (; blk + 3 * step < nblocks; blk += 4 * step) {
-                float v[4];
+            for (; blk + 7 * step < nblocks; blk += 8 * step) {
+                float v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = partial[(size_t)(blk + u * step) * cols + col];
+                for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(blk + u * step) * cols + col];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a += (double)v[u];
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
             }
-            for (; blk < nblocks; blk += step) a += (double)partial[(size_t)blk * cols + col];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bq = blk + u * step;
+                v[u] = bq < nblocks ? partial[(size_t)bq * cols + col] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
         }
         lds[threadIdx.x] = a;
         __syncthreads();
         if (slice == 0 && col < cols) {
             double s = 0.0;
-            for (int q = 0; q < slices; ++q) s += lds[q * cp + (threadIdx.x)];
+            for (int q = 0; q < slices; ++q) s += lds[q * cp + threadIdx.x];
             mid[(size_t)blockIdx.x * cols + col] = s;
         }
         __syncthreads();
@@ -596,7 +604,7 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
         const float *part = ext_partial ? ext_partial : L.partial;
         const int prow = ext_partial ? ext_rows : grid;
         if (n > 0)   // two-stage: the apply kernel finishes the statistics itself
-            bn_mid_kernel<<<MID_ROWS, 256, 0, st>>>(part, prow, c, L.mid);
+            bn_mid_kernel<<<MID_ROWS, 1024, 0, st>>>(part, prow, c, L.mid);
         else
             bn_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, n, n_dev, c, gamma, beta, eps, momentum, running_mean,
                                                    running_var, save_mean, save_invstd, L.scale, L.shift);
@@ -687,7 +695,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     const size_t alds = two_stage ? bn_mid_lds_bytes(c) : 0;
     auto finalize = [&]() {
         if (two_stage)
-            bn_mid_kernel<<<MID_ROWS, 256, 0, st>>>(part, prow, c, L.mid);
+            bn_mid_kernel<<<MID_ROWS, 1024, 0, st>>>(part, prow, c, L.mid);
         else
             bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);
     };
