@@ -69,7 +69,9 @@ PROTOTYPES = {
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _sz,
                                 _vp]),
     "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _i, _vp, _sz, _vp]),
+                             _i, _vp, _vp, _sz, _vp]),
+    "pcd_bn_backward_colsum_rows": (_i, [_i, _i, _i]),
+    "pcd_col_sum_finalize": (_i, [_vp, _i, _vp]),
 }
 
 _lib = None
@@ -77,6 +79,14 @@ _lib = None
 
 class PcdError(RuntimeError):
     pass
+
+
+class PcdColsumJob(ctypes.Structure):
+    """include/pcd_ops.h: struct PcdColsumJob."""
+    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int), ("c", ctypes.c_int)]
+
+
+COLSUM_MAX_JOBS = 32
 
 
 class PcdBnReduce(ctypes.Structure):

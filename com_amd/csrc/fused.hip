@@ -29,6 +29,7 @@ struct Piece<float> {
     __device__ static void store(float *p, const float (&v)[4]) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    __device__ static float stored(float v) { return v; }   // the value a store leaves in memory
 };
 template <>
 struct Piece<unsigned short> {
@@ -49,6 +50,7 @@ struct Piece<unsigned short> {
             w[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    __device__ static float stored(float v) { return __uint_as_float((u32)f32_to_bf16_bits(v) << 16); }
 };
 
 // A thread's N per-channel parameters.  16-byte loads when the arrays allow it (`vec`, decided on the host from the
@@ -471,7 +473,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            float *__restrict__ dgamma,
                                                            float *__restrict__ dbeta, int relu,
                                                            int training, T *__restrict__ dx,
-                                                           T *__restrict__ dres, int vec, const double *mid) {
+                                                           T *__restrict__ dres, int vec, const double *mid,
+                                                           float *__restrict__ colsum_partial) {
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
@@ -515,6 +518,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         k1[j] *= inv_n;
         k2[j] *= inv_n;
     }
+    // colsum_partial: column sums of dx AS STORED -- dx is dy of the conv in front of this BatchNorm and its column
+    // sum that conv's bias gradient (replaces a separate pass over dx; one partial row per workgroup)
+    float cs[1][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) cs[0][j] = 0.0f;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float g[N], xv[N], yv[N], o[N];
         Piece<T>::load(dy + e * N, g);
@@ -527,9 +535,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
             g[j] = dz;
             float xhat = (xv[j] - mu[j]) * is[j];
             o[j] = gm[j] * (dz - k1[j] - xhat * k2[j]);
+            cs[0][j] += Piece<T>::stored(o[j]);
         }
         Piece<T>::store(dx + e * N, o);
         if (dres) Piece<T>::store(dres + e * N, g);
+    }
+    if (colsum_partial) {
+        __syncthreads();      // the prologue's use of the dynamic LDS is over
+        block_reduce_store<N, 1>(cs, c, pcs, colsum_partial, (float *)dyn_lds);
+    }
+}
+
+// out[ch] = sum over the rows of partial[nblocks][c] (fixed order): finishes the column sums bn_bwd_apply_kernel took.
+// One workgroup per job; the jobs ride in the kernel arguments (no device-side table to upload, graph-capturable).
+struct ColJobs {
+    PcdColsumJob job[PCD_COLSUM_MAX_JOBS];
+};
+__global__ __launch_bounds__(1024) void col_rows_finalize_kernel(ColJobs jobs) {
+    __shared__ double lds[1024];
+    const float *__restrict__ partial = jobs.job[blockIdx.x].partial;
+    const int nblocks = jobs.job[blockIdx.x].rows, c = jobs.job[blockIdx.x].c;
+    float *out = jobs.job[blockIdx.x].out;
+    int cp = 1;
+    while (cp < c) cp <<= 1;
+    const int slices = 1024 / cp;
+    const int slice = threadIdx.x / cp, ch = threadIdx.x - slice * cp;
+    double a = 0.0;
+    if (ch < c) {
+        int blk = slice;
+        for (; blk + 7 * slices < nblocks; blk += 8 * slices) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(blk + u * slices) * c + ch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+        for (; blk < nblocks; blk += slices) a += (double)partial[(size_t)blk * c + ch];
+    }
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if (slice == 0 && ch < c) {
+        double s = 0.0;
+        for (int q = 0; q < slices; ++q) s += lds[q * cp + ch];
+        out[ch] = (float)s;
     }
 }
 
@@ -673,7 +721,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
                                const float *save_invstd,
                                int relu, int training, void *dx, void *dresidual, float *dgamma,
                                float *dbeta, const int32_t *n_dev, const float *ext_partial, int ext_rows,
-                               void *workspace, size_t workspace_bytes, void *stream) {
+                               float *colsum_partial, void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
@@ -692,7 +740,8 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     const int prow = ext_partial ? ext_rows : grid;
     const bool two_stage = training && n > 0;      // the apply kernel finishes the reductions itself
     const double *mid = two_stage ? L.mid : nullptr;
-    const size_t alds = two_stage ? bn_mid_lds_bytes(c) : 0;
+    size_t alds = two_stage ? bn_mid_lds_bytes(c) : 0;
+    if (colsum_partial && alds < bn_reduce_lds_bytes(c, N)) alds = bn_reduce_lds_bytes(c, N);
     auto finalize = [&]() {
         if (two_stage)
             bn_mid_kernel<<<MID_ROWS, 1024, 0, st>>>(part, prow, c, L.mid);
@@ -708,7 +757,7 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, alds, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid);
+                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid, colsum_partial);
     } else {
         typedef unsigned short B;
         if (!ext_partial)
@@ -718,8 +767,31 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
         if (n > 0)
             bn_bwd_apply_kernel<B><<<agrid, 256, alds, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                             gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                                            relu, training, (B *)dx, (B *)dresidual, vec, mid);
+                                                            relu, training, (B *)dx, (B *)dresidual, vec, mid, colsum_partial);
     }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// rows of the colsum_partial buffer pcd_bn_backward fills ([rows][c] f32): the grid of its apply pass
+extern "C" int pcd_bn_backward_colsum_rows(int dtype, int n, int c) {
+    if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
+    const int pcs = c / (dtype == PCD_F32 ? 4 : 8);
+    return n > 0 ? grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS) : 0;
+}
+
+extern "C" int pcd_col_sum_finalize(const PcdColsumJob *jobs_host, int n_jobs, void *stream) {
+    PCD_ENTER();
+    if (n_jobs < 0 || n_jobs > PCD_COLSUM_MAX_JOBS || (n_jobs > 0 && !jobs_host)) return PCD_ERR_INVALID_ARG;
+    if (n_jobs == 0) return PCD_OK;
+    ColJobs J = {};
+    for (int i = 0; i < n_jobs; ++i) {
+        const PcdColsumJob &j = jobs_host[i];
+        if (j.rows < 0 || j.c <= 0 || j.c > 1024 || !j.out || (j.rows > 0 && !j.partial)) return PCD_ERR_INVALID_ARG;
+        J.job[i] = j;
+    }
+    col_rows_finalize_kernel<<<n_jobs, 1024, 0, (hipStream_t)stream>>>(J);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

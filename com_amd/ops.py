@@ -606,9 +606,11 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
 
 
 def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dres, n_dev=None,
-                dgamma_out=None, dbeta_out=None, beta=None, partials=None):
+                dgamma_out=None, dbeta_out=None, beta=None, partials=None, colsum=False):
     """y may be None (relu, forward without residual, training): the ReLU mask is recomputed from x and the
-    affine parameters (`beta` required then) instead of being read from the saved output."""
+    affine parameters (`beta` required then) instead of being read from the saved output.
+    colsum=True additionally returns (partial [rows, c], rows): per-workgroup column sums of dx for col_sum_finalize
+    (the bias gradient of the conv in front of the BatchNorm)."""
     _require_cuda(dy, x)
     if relu and y is None and (beta is None or not training):
         raise ValueError("bn_backward: y=None needs beta and training statistics")
@@ -621,12 +623,40 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     dgamma = dgamma_out if _usable_out(dgamma_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
     dbeta = dbeta_out if _usable_out(dbeta_out, c) else torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
+    cpart, crows = None, 0
+    if colsum:
+        crows = _tiles(lib.pcd_bn_backward_colsum_rows(_dtype_code(x), n, c), "pcd_bn_backward_colsum_rows")
+        cpart = torch.empty((max(crows, 1), c), dtype=torch.float32, device=dev)
     L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
                                 L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
                                 L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
                                 L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
-                                L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
+                                L.ptr(cpart), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
+    if colsum:
+        return dx, dres, dgamma, dbeta, (cpart, crows)
     return dx, dres, dgamma, dbeta
+
+
+def col_sum_finalize(partial, rows, out=None):
+    """out[c] = sum of the rows of partial [rows, c] (see bn_backward(colsum=True))."""
+    c = partial.shape[1]
+    res = out if _usable_out(out, c) else torch.empty((c,), dtype=torch.float32, device=partial.device)
+    col_sum_finalize_batched([(partial, rows, res)])
+    return res
+
+
+def col_sum_finalize_batched(jobs):
+    """jobs = [(partial [rows, c], rows, out [c] f32)]: all of them in ceil(len / 32) launches."""
+    import ctypes
+    for i in range(0, len(jobs), L.COLSUM_MAX_JOBS):
+        chunk = jobs[i:i + L.COLSUM_MAX_JOBS]
+        arr = (L.PcdColsumJob * len(chunk))()
+        for j, (partial, rows, out) in enumerate(chunk):
+            _require_cuda(partial, out)
+            assert partial.dtype == torch.float32 and partial.is_contiguous() and _usable_out(out, partial.shape[1])
+            arr[j] = L.PcdColsumJob(L.ptr(partial), L.ptr(out), rows, partial.shape[1])
+        L.check(L.lib().pcd_col_sum_finalize(ctypes.cast(arr, ctypes.c_void_p), len(chunk), L.stream_ptr()),
+                "pcd_col_sum_finalize")
 
 
 def col_sum(x, n_dev=None, out=None):

@@ -29,8 +29,22 @@ _SIDE = {}
 _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not yet joined
 
 
+_COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
+
+
 def join_deferred_wgrad():
-    """Make the current stream wait for every side-stream weight-gradient kernel issued so far."""
+    """Make the current stream wait for every side-stream weight-gradient kernel issued so far (and finish the
+    deferred bias gradients with one launch on that stream)."""
+    if _COLSUM_JOBS:
+        side = _side_stream(_COLSUM_JOBS[0][0].device)
+        with torch.cuda.stream(side):
+            ops.col_sum_finalize_batched(_COLSUM_JOBS)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        torch.cuda.current_stream().wait_event(ev)
+        _COLSUM_JOBS.clear()
+        _PENDING.clear()
+        return
     if _PENDING:
         torch.cuda.current_stream().wait_event(_PENDING[-1][0])
         _PENDING.clear()
@@ -86,6 +100,11 @@ class SparseConvFunction(Function):
                             n_dev=rb.n_out_dev, bn_reduce=stats)
         if stats is not None:
             y._pcd_stats = stats
+        # bias gradient = column sum of our dy; when dy comes out of a fused BatchNorm backward that kernel sums it
+        ctx.colsum_link = None
+        if FUSE_BN_REDUCTIONS and bias is not None and ctx.needs_input_grad[2] and out_dtype == torch.bfloat16:
+            ctx.colsum_link = _ColsumLink()
+            y._pcd_colsum_link = ctx.colsum_link
         # the input is the output of a fused BatchNorm: its backward reductions can ride on our data gradient
         link = getattr(features, "_pcd_bn_link", None) if FUSE_BN_REDUCTIONS else None
         if link is not None and not (features.dtype == torch.bfloat16 and x.data_ptr() == features.data_ptr()
@@ -168,6 +187,7 @@ class SparseConvFunction(Function):
             and weight_p.grad.dtype == torch.float32 and weight_p.grad.is_contiguous()
         direct_b = DIRECT_GRAD and bias_p is not None and bias_p.grad is not None \
             and bias_p.grad.dtype == torch.float32 and bias_p.grad.is_contiguous()
+        keep_partial = None
         deferred = (WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not ctx.needs_input_grad[1])
                     and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
@@ -176,14 +196,26 @@ class SparseConvFunction(Function):
                                 out=weight_p.grad if direct_w else None)                 # [Cout, K, Cin] f32
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = ops.col_sum(dy16, n_dev=rb.n_out_dev, out=bias_p.grad if direct_b else None)
+                cl = ctx.colsum_link.result if ctx.colsum_link is not None else None
+                if cl is not None and cl[0].data_ptr() == dy16.data_ptr() and cl[0].shape == dy16.shape:
+                    # the BatchNorm backward that produced dy already summed its columns per workgroup
+                    if deferred and direct_b:
+                        _COLSUM_JOBS.append((cl[1], cl[2], bias_p.grad))     # finished in join_deferred_wgrad()
+                        db = bias_p.grad
+                    else:
+                        db = ops.col_sum_finalize(cl[1], cl[2], out=bias_p.grad if direct_b else None)
+                    keep_partial = cl[1]
+                else:
+                    db = ops.col_sum(dy16, n_dev=rb.n_out_dev, out=bias_p.grad if direct_b else None)
+                if ctx.colsum_link is not None:
+                    ctx.colsum_link.result = None
                 if direct_b:
                     db = None
             if deferred:
                 ev = torch.cuda.Event()
                 ev.record(side)
         if deferred:
-            _PENDING.append((ev, x, dy16))           # inputs stay alive until the lagged join below
+            _PENDING.append((ev, x, dy16, keep_partial))   # inputs stay alive until the lagged join below
             side = None
         if deferred and len(_PENDING) > WGRAD_JOIN_LAG:
             cur.wait_event(_PENDING[-1 - WGRAD_JOIN_LAG][0])
@@ -229,6 +261,14 @@ def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passt
     return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
 
 
+class _ColsumLink:
+    """conv -> BatchNorm behind it: "sum the columns of the dx you produce"; result = (dx, partial, rows)."""
+    __slots__ = ("result",)
+
+    def __init__(self):
+        self.result = None
+
+
 class _BnLink:
     """What the data-gradient kernel of the NEXT conv needs to take this BatchNorm's backward reductions
     (attached to the BatchNorm output as `_pcd_bn_link`; holds no reference to that output)."""
@@ -269,6 +309,8 @@ class FusedBNFunction(Function):
         # without a residual the ReLU mask is recomputed from x in the backward (one [n][c] read less per pass)
         ctx.mask_from_x = bool(relu and residual is None and training and b is not None)
         ctx.save_for_backward(xc, None if ctx.mask_from_x else y, g, b, save_mean, save_invstd)
+        cl = getattr(x, "_pcd_colsum_link", None) if FUSE_BN_REDUCTIONS else None
+        ctx.colsum_link = cl if (cl is not None and xc.data_ptr() == x.data_ptr() and training) else None
         ctx.link = None
         if FUSE_BN_REDUCTIONS and training and xc.dtype == torch.bfloat16:
             ctx.link = _BnLink(bool(relu), xc, save_mean, save_invstd)
@@ -293,11 +335,14 @@ class FusedBNFunction(Function):
             if rdx.data_ptr() == dy.data_ptr() and rdx.shape == dy.shape and dy.dtype == x.dtype \
                     and dy.is_contiguous():
                 partials = (part, rows)              # dy IS the tensor whose kernel took the reductions
-        dx, dres, dgamma, dbeta = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
-                                                  ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev,
-                                                  dgamma_out=gw if direct else None,
-                                                  dbeta_out=gb if direct else None,
-                                                  beta=b if ctx.mask_from_x else None, partials=partials)
+        res = ops.bn_backward(dy, x, y, g, save_mean, save_invstd, ctx.relu, ctx.training,
+                              ctx.has_res and ctx.needs_input_grad[3], n_dev=ctx.n_dev,
+                              dgamma_out=gw if direct else None, dbeta_out=gb if direct else None,
+                              beta=b if ctx.mask_from_x else None, partials=partials,
+                              colsum=ctx.colsum_link is not None)
+        dx, dres, dgamma, dbeta = res[:4]
+        if ctx.colsum_link is not None:
+            ctx.colsum_link.result = (dx,) + res[4]
         if direct:
             dgamma = dbeta = None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,

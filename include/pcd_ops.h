@@ -302,8 +302,22 @@ int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
 int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
                     const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
                     int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                    const int32_t *n_dev, const float *ext_partial, int ext_rows, void *workspace,
-                    size_t workspace_bytes, void *stream);
+                    const int32_t *n_dev, const float *ext_partial, int ext_rows, float *colsum_partial,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* colsum_partial (NULL = off): [pcd_bn_backward_colsum_rows(dtype, n, c)][c] f32, per-workgroup column sums of dx as
+ * stored.  dx is dy of the conv in front of the BatchNorm, its column sum that conv's bias gradient
+ * (spconv_backbone.py:37-44, bias=True inside SparseBasicBlock): pcd_col_sum_finalize adds the rows up in a fixed
+ * order and replaces the pcd_col_sum pass over dx. */
+int pcd_bn_backward_colsum_rows(int dtype, int n, int c);
+/* up to PCD_COLSUM_MAX_JOBS column sums in ONE launch (jobs_host is read during the call; the jobs travel as kernel
+ * arguments): a backbone finishes all its bias gradients at the end of the backward pass with a single kernel */
+#define PCD_COLSUM_MAX_JOBS 32
+typedef struct PcdColsumJob {
+    const float *partial;   /* [rows][c] */
+    float *out;             /* [c] */
+    int rows, c;
+} PcdColsumJob;
+int pcd_col_sum_finalize(const PcdColsumJob *jobs_host, int n_jobs, void *stream);
 
 /* ============================================================================================
  * (a15) update end of the data-parallel step: gradient-norm clipping + Adam on ONE flat fp32 buffer

@@ -483,6 +483,10 @@ def test_conv_epilogue_takes_batchnorm_reductions():
                                 partials=(red.partial, red.rows))
             close(b[3], a[3], ("dbeta", c, relu)), close(b[2], a[2], ("dgamma", c, relu))
             assert float((a[0].float() - b[0].float()).abs().max()) <= 0.02 * float(a[0].float().abs().max())
+            # column sums of dx taken by the same kernel (bias gradient of the conv in front of the BatchNorm)
+            r = ops.bn_backward(dx, y, ysrc, gamma, m1, i1, relu, True, False, beta=beta, colsum=True)
+            assert torch.equal(r[0], a[0])
+            close(ops.col_sum_finalize(*r[4]), ops.col_sum(r[0]), ("colsum", c, relu))
     # the class kernel of a strided conv's data gradient
     rbc = ops.rulebook_conv(idx, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
     for cin, cout in ((16, 32), (64, 64)):
