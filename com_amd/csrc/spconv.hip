@@ -976,11 +976,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 // (One thread per element looping over up to 64 splits left a 16-channel layer with 27 workgroups of 64
 // dependent-latency iterations: 20+ us for a 1.7 MB reduction.)
 template <int V>   // V = 4: four consecutive elements per thread (16-byte loads), n % 4 == 0;  V = 1: scalar
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int splits,
-                                                           size_t n, float *__restrict__ dw) {
-    __shared__ float part[8][32][V];
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int splits, size_t n,
+                                                  float *__restrict__ dw, unsigned block, float *lds) {
+    float(*part)[32][V] = reinterpret_cast<float(*)[32][V]>(lds);   // [8][32][V]
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const size_t e = ((size_t)blockIdx.x * 32 + el) * V;
+    const size_t e = ((size_t)block * 32 + el) * V;
     float s[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) s[j] = 0.0f;
@@ -1028,6 +1028,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         else
             dw[e] = r[0];
     }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int splits,
+                                                           size_t n, float *__restrict__ dw) {
+    __shared__ float lds[8 * 32 * V];
+    wgrad_reduce_body<V>(slab, splits, n, dw, blockIdx.x, lds);
+}
+
+// The slab reductions of up to PCD_WGRAD_MAX_JOBS layers in ONE launch (jobs in the kernel arguments): the
+// weight-gradient stream is as long as the main chain, and every small kernel on it costs ~3.7 us of latency.
+struct RedJobs {
+    struct {
+        const float *slab;
+        float *dw;
+        unsigned long long n;
+        int splits, vec;
+        unsigned first_block;
+    } job[PCD_WGRAD_MAX_JOBS];
+    int n_jobs;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
+    __shared__ float lds[8 * 32 * 4];
+    int j = 0;
+    for (int q = 1; q < J.n_jobs; ++q)
+        if (J.job[q].first_block <= blockIdx.x) j = q;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const unsigned block = blockIdx.x - J.job[j].first_block;
+    if (J.job[j].vec)
+        wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
+    else
+        wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
 }
 
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
@@ -1292,6 +1324,35 @@ extern "C" int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pma
     else
         wgrad_reduce_kernel<1><<<(unsigned)((n + 31) / 32), 256, 0, (hipStream_t)stream>>>(
             (const float *)workspace, splits, n, dweight);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream) {
+    PCD_ENTER();
+    if (n_jobs < 0 || n_jobs > PCD_WGRAD_MAX_JOBS || (n_jobs > 0 && !jobs_host)) return PCD_ERR_INVALID_ARG;
+    RedJobs J = {};
+    unsigned blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const PcdWgradReduceJob &q = jobs_host[i];
+        if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight) return PCD_ERR_INVALID_ARG;
+        if (q.pmax == 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
+        if (!q.workspace) return PCD_ERR_WORKSPACE;
+        int splits, per;
+        wgrad_plan(q.pmax, q.cin, q.cout, &splits, &per);
+        const size_t n = (size_t)q.cout * q.kvol * q.cin;
+        const bool vec = (n & 3) == 0 && (((uintptr_t)q.dweight | (uintptr_t)q.workspace) & 15u) == 0;
+        auto &d = J.job[J.n_jobs++];
+        d.slab = (const float *)q.workspace;
+        d.dw = q.dweight;
+        d.n = n;
+        d.splits = splits;
+        d.vec = vec ? 1 : 0;
+        d.first_block = blocks;
+        blocks += (unsigned)(((vec ? n / 4 : n) + 31) / 32);
+    }
+    if (blocks == 0) return PCD_OK;
+    wgrad_reduce_batched_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(J);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -514,16 +514,18 @@ def _usable_out(out, numel):
             and out.is_cuda)
 
 
-def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None):
+def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None):
     """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
-    (e.g. the parameter's .grad) when given."""
+    (e.g. the parameter's .grad) when given.  `defer` (a list): only the MFMA kernel runs now, into a slab buffer of
+    its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all)."""
     _require_cuda(x, dy, pairs, pair_num)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     assert x.is_contiguous() and dy.is_contiguous() and pairs.is_contiguous()
     cout = dy.shape[1]
     pmax = pairs.shape[2]
     lib = L.lib()
-    ws = _ws(lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax), x.device)
+    wsb = lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax)
+    ws = _ws(wsb, x.device) if defer is None else torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
     dw = out if _usable_out(out, cout * kvol * cin) else \
         torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
 
@@ -543,9 +545,24 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None):
                                           L.ptr(pairs),
                                           L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
                                           L.stream_ptr()), "pcd_sparse_conv_wgrad")
+    if defer is not None:
+        defer.append((ws, dw, kvol, cin, cout, pmax))
+        return dw
     L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
             "pcd_sparse_conv_wgrad_reduce")
     return dw
+
+
+def wgrad_reduce_batched(jobs):
+    """jobs = [(slab workspace, dw, kvol, cin, cout, pmax)] collected by wgrad(defer=...)."""
+    import ctypes
+    for i in range(0, len(jobs), L.WGRAD_MAX_JOBS):
+        chunk = jobs[i:i + L.WGRAD_MAX_JOBS]
+        arr = (L.PcdWgradReduceJob * len(chunk))()
+        for j, (ws, dw, kvol, cin, cout, pmax) in enumerate(chunk):
+            arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax)
+        L.check(L.lib().pcd_sparse_conv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk),
+                                                             L.stream_ptr()), "pcd_sparse_conv_wgrad_reduce_batched")
 
 
 # ---------------------------------------------------------------------------------------------

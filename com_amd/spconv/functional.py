@@ -30,19 +30,24 @@ _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not 
 
 
 _COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
+_WGRAD_JOBS = []    # [(slab, dW, kvol, cin, cout, pmax)] of deferred slab reductions: one launch at the join
 
 
 def join_deferred_wgrad():
     """Make the current stream wait for every side-stream weight-gradient kernel issued so far (and finish the
     deferred bias gradients with one launch on that stream)."""
-    if _COLSUM_JOBS:
-        side = _side_stream(_COLSUM_JOBS[0][0].device)
+    if _COLSUM_JOBS or _WGRAD_JOBS:
+        side = _side_stream((_COLSUM_JOBS or _WGRAD_JOBS)[0][0].device)
         with torch.cuda.stream(side):
-            ops.col_sum_finalize_batched(_COLSUM_JOBS)
+            if _WGRAD_JOBS:
+                ops.wgrad_reduce_batched(_WGRAD_JOBS)
+            if _COLSUM_JOBS:
+                ops.col_sum_finalize_batched(_COLSUM_JOBS)
             ev = torch.cuda.Event()
             ev.record(side)
         torch.cuda.current_stream().wait_event(ev)
         _COLSUM_JOBS.clear()
+        _WGRAD_JOBS.clear()
         _PENDING.clear()
         return
     if _PENDING:
@@ -193,7 +198,8 @@ class SparseConvFunction(Function):
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if ctx.needs_input_grad[1]:
                 dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol,
-                                out=weight_p.grad if direct_w else None)                 # [Cout, K, Cin] f32
+                                out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32
+                                defer=_WGRAD_JOBS if (deferred and direct_w) else None)
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 cl = ctx.colsum_link.result if ctx.colsum_link is not None else None

@@ -257,6 +257,15 @@ int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, con
                           float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
                                  const void *workspace, void *stream);
+/* The same reduction for up to PCD_WGRAD_MAX_JOBS layers in ONE launch (each layer then needs its own workspace
+ * until the call; jobs_host is read during the call, the jobs travel as kernel arguments). */
+#define PCD_WGRAD_MAX_JOBS 32
+typedef struct PcdWgradReduceJob {
+    const void *workspace;
+    float *dweight;
+    int kvol, cin, cout, pmax;
+} PcdWgradReduceJob;
+int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream);
 
 /* ============================================================================================
  * (a13/a14) BEV scatter -- replaces SparseConvTensor.dense() + the view in
