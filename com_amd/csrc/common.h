@@ -169,13 +169,25 @@ static __global__ __launch_bounds__(256) void scan_spine_kernel(int *block_sums,
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < nb; base += 256) {
-        int i = base + threadIdx.x;
-        int v = (i < nb) ? block_sums[i] : 0;
+    // 8 consecutive elements per thread and iteration (8 loads in flight; 2048 entries per barrier pair)
+    for (int base = 0; base < nb; base += 2048) {
+        const int i0 = base + threadIdx.x * 8;
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (i0 + j < nb) ? block_sums[i0 + j] : 0;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int t = v[j];
+            v[j] = sum;
+            sum += t;
+        }
         int total;
-        int ex = block_exclusive_scan(v, lds, total);
+        int ex = block_exclusive_scan(sum, lds, total);
         int carry = carry_s;
-        if (i < nb) block_sums[i] = carry + ex;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j < nb) block_sums[i0 + j] = carry + ex + v[j];
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + total;
         __syncthreads();

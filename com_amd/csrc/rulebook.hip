@@ -727,12 +727,21 @@ __global__ __launch_bounds__(64 * CLS_MAX) void cls_offsets_kernel(int *blk_cnt,
     int *row = blk_cnt + (size_t)q * nblk;
     if (q < ncls) {
         int carry = 0;
-        for (int base = 0; base < nblk; base += 64) {
-            const int i = base + lane_id();
-            const int v = (i < nblk) ? row[i] : 0;
-            const int inc = wave_inclusive_scan(v);
-            if (i < nblk) row[i] = carry + inc - v;
-            carry += __shfl(inc, 63);
+        // 8 chunks of 64 counts in flight: the loop is a chain of load latencies (one wave per class)
+        for (int base = 0; base < nblk; base += 8 * 64) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 64 + lane_id();
+                v[u] = (i < nblk) ? row[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 64 + lane_id();
+                const int inc = wave_inclusive_scan(v[u]);
+                if (i < nblk) row[i] = carry + inc - v[u];
+                carry += __shfl(inc, 63);
+            }
         }
         if (lane_id() == 0) tot[q] = carry;
     }
