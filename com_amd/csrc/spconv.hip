@@ -309,7 +309,8 @@ __device__ __forceinline__ void gg_epilogue(const f32x4 (&acc)[MI][NBW], const i
 // Waves per SIMD the main loop's registers allow (accumulators + two gather register sets + ~24): the epilogue
 // (BnRed) must not push the allocation past that -- these kernels live on occupancy.
 constexpr int gg_waves(int nbw, int mi, int g) {
-    const int est = mi * nbw * 4 + 2 * g * mi * 4 + 32 + (mi == 1 ? 16 : (mi == 2 && g == 1 ? 8 : 0));
+    const int est = mi * nbw * 4 + 2 * g * mi * 4 + 32 + (mi == 1 ? 16 : (mi == 2 && g == 1 ? 8 : 0)) +
+                    (g >= 2 && mi >= 2 ? 16 : 0);
     const int w = 512 / est;
     return w > 7 ? 7 : (w < 1 ? 1 : w);   // (LDS limits the narrow kernels to <= 7 waves per SIMD anyway)
 }
@@ -1163,24 +1164,25 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // Narrow layers (NB 1/2, 300k+ rows): short look-ahead, many waves per SIMD.
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
     const bool resident = wbytes <= 32 * 1024;
-    // Wide layers are latency bound, so occupancy wins over look-ahead (G = 1, one-step stages) and the
-    // rows per wave (MI x 16) shrink with the row count to keep >= ~3 workgroups per CU in flight
-    // (measured on gfx950, 128 ch / 42k rows: MI 1/2/4 = 61/68/77 us; 64 ch / 115k rows: 60/55/53 us).
+    // Wide layers: a contraction step lasts one memory latency (~3.7k clk measured at 128 channels: the gathers
+    // and the weight stage are fetched one step ahead of ~256 clk of MFMA work), so two steps of look-ahead with
+    // 32 rows per wave win once the register budget is sized for them (gg_waves: 3-4 waves per SIMD, no spills):
+    // whole step 4.32 -> 4.19 ms.  4 steps ahead, 16 or 64 rows per wave, or 4-step weight stages are slower
+    // (4.21-4.63).  Few rows (< 48k): 16 rows per wave and more workgroups.
     const int mi = n_rows_out >= 96 * 1024 ? 4 : n_rows_out >= 48 * 1024 ? 2 : 1;
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
         case 1:
             return resident ? launch_gg<1, 1, 2, 0>(GG_ARGS) : launch_gg<1, 1, 2, 4>(GG_ARGS);
         case 2:
+            // (32 channels, staged: <2,2,2,2> / <2,2,2,4> / <2,4,2,2> / <2,2,4,4> / <2,4,1,2> measured 4.20-4.34 vs 4.18)
             return resident ? launch_gg<2, 2, 1, 0>(GG_ARGS) : launch_gg<2, 2, 1, 2>(GG_ARGS);
         case 4:
             if (resident) return launch_gg<4, 2, 2, 0>(GG_ARGS);
-            return mi == 4 ? launch_gg<4, 4, 1, 1>(GG_ARGS)
-                           : mi == 2 ? launch_gg<4, 2, 1, 1>(GG_ARGS) : launch_gg<4, 1, 1, 1>(GG_ARGS);
+            return mi >= 2 ? launch_gg<4, 2, 2, 2>(GG_ARGS) : launch_gg<4, 1, 1, 1>(GG_ARGS);
         case 8:
             if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
-            return mi == 4 ? launch_gg<8, 4, 1, 1>(GG_ARGS)
-                           : mi == 2 ? launch_gg<8, 2, 1, 1>(GG_ARGS) : launch_gg<8, 1, 1, 1>(GG_ARGS);
+            return mi >= 2 ? launch_gg<8, 2, 2, 2>(GG_ARGS) : launch_gg<8, 1, 1, 1>(GG_ARGS);
         default:
             return PCD_ERR_UNSUPPORTED;
     }
