@@ -31,7 +31,10 @@ PROTOTYPES = {
                                _i, _vp, _vp, _sz, _vp]),
     "pcd_mean_vfe": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
-    "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_segment_max_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_segment_max": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_segment_max_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_rulebook_subm_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_workspace_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp, _vp]),

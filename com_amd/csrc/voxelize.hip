@@ -277,13 +277,17 @@ __global__ __launch_bounds__(256) void dyn_accum_kernel(const float *__restrict_
                                                         const u32 *__restrict__ pt_key,
                                                         const u32 *__restrict__ bitmap,
                                                         const int *__restrict__ prefix, int cap,
-                                                        float *sums, int *cnt) {
+                                                        float *sums, int *cnt, int32_t *point_voxel) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     u32 key = pt_key[i];
-    if (key == IDX_NONE) return;
+    if (key == IDX_NONE) {
+        if (point_voxel) point_voxel[i] = -1;
+        return;
+    }
     u32 w = key >> 5;
     int r = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
+    if (point_voxel) point_voxel[i] = r < cap ? r : -1;    // = unq_inv of torch.unique(sorted keys)
     if (r >= cap) return;
     const float *p = pts + (size_t)i * (C + 1) + 1;
     for (int c = 0; c < C; ++c) atomicAdd(&sums[(size_t)r * C + c], p[c]);
@@ -447,7 +451,8 @@ extern "C" int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, in
                                          int batch, const float *range_host,
                                          const float *vsize_host, int cap, float *features,
                                          int32_t *coords, int32_t *counts, int32_t *num_voxels,
-                                         void *workspace, size_t workspace_bytes, void *stream) {
+                                         int32_t *point_voxel, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
     PCD_ENTER();
     if (n_points < 0 || batch <= 0 || cap < 0 || !range_host || !vsize_host || !num_voxels)
         return PCD_ERR_INVALID_ARG;
@@ -483,7 +488,7 @@ extern "C" int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, in
         dyn_emit_coords_kernel<<<pcd_div_up((int)nw, 256), 256, 0, st>>>(bitmap, prefix, (int)nw, G,
                                                                         cap, coords);
         dyn_accum_kernel<<<nb, 256, 0, st>>>(points_b, n_points, num_features, pt_key, bitmap,
-                                             prefix, cap, features, cnt);
+                                             prefix, cap, features, cnt, point_voxel);
         dyn_finalize_kernel<<<pcd_div_up(rows * num_features, 256), 256, 0, st>>>(
             features, cnt, num_voxels, cap, num_features);
     }

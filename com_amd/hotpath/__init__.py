@@ -4,4 +4,4 @@ pcdet/models/backbones_2d/map_to_bev), running on the HIP kernels."""
 from .backbone3d import SparseBasicBlock, VoxelBackBone8x, VoxelResBackBone8x, post_act_block  # noqa: F401
 from .data import VoxelGeneratorWrapper, collate_points, transform_points_to_voxels  # noqa: F401
 from .map_to_bev import HeightCompression, PointPillarScatter  # noqa: F401
-from .vfe import DynamicMeanVFE, MeanVFE, PillarVFE  # noqa: F401
+from .vfe import DynamicMeanVFE, DynamicPillarVFE, MeanVFE, PillarVFE  # noqa: F401

@@ -183,8 +183,9 @@ def mean_vfe(voxels, num_points):
     return out
 
 
-def voxelize_dynamic_mean(points_b, batch_size, point_cloud_range, voxel_size):
-    """pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72: (features [M,C], coords [M,4], counts)."""
+def voxelize_dynamic_mean(points_b, batch_size, point_cloud_range, voxel_size, return_inverse=False):
+    """pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72: (features [M,C], coords [M,4], counts);
+    return_inverse=True adds point_voxel [N] int32 (output row of every point, -1 = dropped: `unq_inv`)."""
     _require_cuda(points_b)
     points_b = points_b.contiguous().float()
     n, c1 = points_b.shape
@@ -201,11 +202,39 @@ def voxelize_dynamic_mean(points_b, batch_size, point_cloud_range, voxel_size):
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.empty((cap,), dtype=torch.int32, device=dev)
     nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+    inv = torch.empty((max(n, 1),), dtype=torch.int32, device=dev) if return_inverse else None
     L.check(lib.pcd_voxelize_dynamic_mean(L.ptr(points_b), n, C, batch_size, rng, vs, cap, L.ptr(feat),
-                                          L.ptr(coords), L.ptr(cnt), L.ptr(nv), L.ptr(ws), ws.numel(),
+                                          L.ptr(coords), L.ptr(cnt), L.ptr(nv), L.ptr(inv), L.ptr(ws), ws.numel(),
                                           L.stream_ptr()), "pcd_voxelize_dynamic_mean")
     m = int(nv.item())
+    if return_inverse:
+        return feat[:m], coords[:m], cnt[:m], inv[:n]
     return feat[:m], coords[:m], cnt[:m]
+
+
+def segment_max(x, seg, m):
+    """out [m, c], arg [m, c]: per-segment maximum of x [n, c] f32 over seg [n] int32 (negative ids skipped) and the
+    smallest row attaining it (torch_scatter.scatter_max, dynamic_pillar_vfe.py:40)."""
+    _require_cuda(x, seg)
+    assert x.dtype == torch.float32 and x.is_contiguous() and seg.dtype == torch.int32 and seg.is_contiguous()
+    n, c = x.shape
+    lib = L.lib()
+    out = torch.empty((m, c), dtype=torch.float32, device=x.device)
+    arg = torch.empty((m, c), dtype=torch.int32, device=x.device)
+    ws = _ws(lib.pcd_segment_max_workspace_bytes(m, c), x.device)
+    L.check(lib.pcd_segment_max(L.ptr(x), L.ptr(seg), n, c, m, L.ptr(out), L.ptr(arg), L.ptr(ws), ws.numel(),
+                                L.stream_ptr()), "pcd_segment_max")
+    return out, arg
+
+
+def segment_max_backward(grad_out, arg, n):
+    _require_cuda(grad_out, arg)
+    g = grad_out.contiguous().float()
+    m, c = g.shape
+    gx = torch.empty((n, c), dtype=torch.float32, device=g.device)
+    L.check(L.lib().pcd_segment_max_backward(L.ptr(g), L.ptr(arg), n, c, m, L.ptr(gx), L.stream_ptr()),
+            "pcd_segment_max_backward")
+    return gx
 
 
 # ---------------------------------------------------------------------------------------------

@@ -96,8 +96,21 @@ size_t pcd_voxelize_dynamic_workspace_bytes(int n_points, int num_features, int 
 int pcd_voxelize_dynamic_mean(const float *points_b, int n_points, int num_features, int batch,
                               const float *range_host, const float *vsize_host, int cap,
                               float *features, int32_t *coords, int32_t *counts,
-                              int32_t *num_voxels, void *workspace, size_t workspace_bytes,
-                              void *stream);
+                              int32_t *num_voxels, int32_t *point_voxel, void *workspace,
+                              size_t workspace_bytes, void *stream);
+/* point_voxel (may be NULL) [n_points] i32: output row of every point (-1: dropped) = `unq_inv` of the
+ * torch.unique(..., return_inverse=True) call of the dynamic VFEs (dynamic_mean_vfe.py:63,
+ * dynamic_pillar_vfe.py:103).
+ *
+ * (a6) dynamic pillar encoder -- replaces torch_scatter.scatter_max in PFNLayerV2 (dynamic_pillar_vfe.py:36-47).
+ *   pcd_segment_max:  out[s][ch] = max over the points i with seg[i] == s of x[i][ch]  (f32; seg < 0 skipped),
+ *   arg[s][ch] = the smallest such i attaining it (deterministic; torch_scatter leaves ties unspecified).
+ *   pcd_segment_max_backward:  grad_x [n][c] = 0 except grad_x[arg[s][ch]][ch] = grad_out[s][ch]. */
+size_t pcd_segment_max_workspace_bytes(int m, int c);
+int pcd_segment_max(const float *x, const int32_t *seg, int n, int c, int m, float *out, int32_t *arg,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int pcd_segment_max_backward(const float *grad_out, const int32_t *arg, int n, int c, int m, float *grad_x,
+                             void *stream);
 
 /* ============================================================================================
  * (a8) SubMConv3d rulebook -- replaces spconv's get_indice_pairs(subm=True) behind

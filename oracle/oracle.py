@@ -118,6 +118,53 @@ def voxelize_dynamic_mean(points_b, point_cloud_range, voxel_size):
     return feat[:m].copy(), coords[:m].copy(), cnt[:m].copy()
 
 
+def dynamic_pillar_vfe(points_b, point_cloud_range, voxel_size, grid_size_xyz, state, use_absolute_xyz=True,
+                       with_distance=False, eps=1e-3):
+    """pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:90-142 in numpy, eval mode (BatchNorm running stats).
+    points_b [n, 6] (b,x,y,z,i,e); `state` = the module's state dict as numpy arrays
+    (pfn_layers.<l>.linear.weight, .norm.weight/.bias/.running_mean/.running_var).
+    Returns (pillar_features [M, C_out] f32, voxel_coords [M, 4] (b, 0, y, x) i32, unq_inv [n_valid] i64)."""
+    pts = _f32(points_b)
+    rng, vs = _f32(point_cloud_range), _f32(voxel_size)
+    gx, gy = int(grid_size_xyz[0]), int(grid_size_xyz[1])
+    cxy = np.floor((pts[:, 1:3] - rng[0:2]) / vs[0:2]).astype(np.int32)                        # :93
+    keep = ((cxy >= 0) & (cxy < np.array([gx, gy], np.int32))).all(1)                          # :94 (x, y only)
+    pts, cxy = pts[keep], cxy[keep]
+    xyz = pts[:, 1:4]
+    merge = pts[:, 0].astype(np.int32) * (gx * gy) + cxy[:, 0] * gy + cxy[:, 1]                # :99-101
+    unq, inv, cnt = np.unique(merge, return_inverse=True, return_counts=True)                  # :103
+    mean = np.zeros((len(unq), 3), np.float32)
+    np.add.at(mean, inv, xyz)
+    mean = (mean / cnt.reshape(-1, 1).astype(np.float32)).astype(np.float32)                   # :105
+    f_cluster = xyz - mean[inv]
+    x_off = np.float32(float(vs[0]) / 2 + float(rng[0]))
+    y_off = np.float32(float(vs[1]) / 2 + float(rng[1]))
+    z_off = np.float32(float(vs[2]) / 2 + float(rng[2]))
+    f_center = np.stack([xyz[:, 0] - (cxy[:, 0].astype(np.float32) * vs[0] + x_off),
+                         xyz[:, 1] - (cxy[:, 1].astype(np.float32) * vs[1] + y_off),
+                         xyz[:, 2] - z_off], 1).astype(np.float32)                             # :108-111
+    parts = [pts[:, 1:] if use_absolute_xyz else pts[:, 4:], f_cluster, f_center]
+    if with_distance:
+        parts.append(np.linalg.norm(xyz, axis=1, keepdims=True).astype(np.float32))
+    feats = np.concatenate(parts, 1).astype(np.float32)
+    n_layers = len({k.split(".")[1] for k in state if k.startswith("pfn_layers.")})
+    for l in range(n_layers):
+        pre = f"pfn_layers.{l}."
+        h = feats @ _f32(state[pre + "linear.weight"]).T
+        if pre + "linear.bias" in state:
+            h = h + _f32(state[pre + "linear.bias"])
+        if pre + "norm.weight" in state:
+            h = (h - _f32(state[pre + "norm.running_mean"])) / np.sqrt(_f32(state[pre + "norm.running_var"]) +
+                                                                   np.float32(eps))
+            h = h * _f32(state[pre + "norm.weight"]) + _f32(state[pre + "norm.bias"])
+        h = np.maximum(h, 0).astype(np.float32)
+        pooled = np.full((len(unq), h.shape[1]), -np.inf, np.float32)
+        np.maximum.at(pooled, inv, h)                                                          # scatter_max, :40
+        feats = pooled if l == n_layers - 1 else np.concatenate([h, pooled[inv]], 1)
+    coords = np.stack([unq // (gx * gy), np.zeros_like(unq), unq % gy, (unq % (gx * gy)) // gy], 1)   # :132-137
+    return feats.astype(np.float32), coords.astype(np.int32), inv.astype(np.int64)
+
+
 # ---------------------------------------------------------------------------------------------
 def conv_out_shape(in_shape, ksize, stride, padding, dilation):
     out = np.zeros(3, np.int32)

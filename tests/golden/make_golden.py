@@ -8,9 +8,9 @@ its sparse-conv arithmetic lives in the un-vendored third-party package ``spconv
 installed here.  So the fixtures come from the two independent sources that ARE runnable:
 
 * the reference's own pure-torch hot-path modules, imported file-by-file from /root/reference
-  on CPU: MeanVFE, PillarVFE, PointPillarScatter, HeightCompression, DynamicMeanVFE (the latter with
-  a ``.cuda()`` identity patch and a ``torch_scatter.scatter_mean`` stand-in, because the image has
-  neither a GPU nor torch_scatter);
+  on CPU: MeanVFE, PillarVFE, PointPillarScatter, HeightCompression, DynamicMeanVFE and DynamicPillarVFE
+  (the last two with a ``.cuda()`` identity patch and torch stand-ins for ``torch_scatter.scatter_mean`` /
+  ``scatter_max``, because the image has neither a GPU nor torch_scatter);
 * ``torch.nn.functional.conv3d`` (fp64) on the densified grid for the sparse-conv semantics
   (SubM k3; SparseConv3d k3/s2/p1, k3/s2/p(0,1,1), k(3,1,1)/s(2,1,1)/p0 -- the four geometries of
   pcdet/models/backbones_3d/spconv_backbone.py:191-232), including the active output set (from the
@@ -19,7 +19,8 @@ installed here.  So the fixtures come from the two independent sources that ARE 
 Nothing from /root/reference is copied: only inputs and outputs (data) are stored.  The CPU
 oracle (oracle/) is then checked against these files by tests/test_oracle_golden.py.
 
-Usage:  python tests/golden/make_golden.py   (needs /root/reference; not needed at test time)
+Usage:  python tests/golden/make_golden.py [g1 .. g6]   (needs /root/reference; not needed at test time;
+        with names only those fixtures are regenerated)
 """
 import hashlib
 import importlib
@@ -284,11 +285,65 @@ def g5():
          spatial_features=bd["spatial_features"].numpy())
 
 
+# ---------------------------------------------------------------------------------------------
+# G6: DynamicPillarVFE (reference module imported with a .cuda() identity patch and torch stand-ins for
+# torch_scatter.scatter_mean / scatter_max) on a 4000-point, 2-frame batch with the PointPillars grid
+def g6():
+    torch.manual_seed(13)
+    frames = [synth.synth_cloud(20 + b, n_beams=16, n_azimuth=125) for b in range(2)]          # 2 x 2000 points
+    pts_b = np.concatenate([np.pad(p, ((0, 0), (1, 0)), constant_values=float(b))
+                            for b, p in enumerate(frames)], 0).astype(np.float32)
+    rng, vs = synth.PILLAR_RANGE, synth.PILLAR_VOXEL
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n, src.shape[1]), dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros((n,), dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return out / cnt.clamp(min=1).unsqueeze(1)
+
+    def scatter_max(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype)
+        out = out.scatter_reduce(0, index.unsqueeze(1).expand(-1, src.shape[1]), src, "amax", include_self=True)
+        return out, None
+
+    ts.scatter_mean, ts.scatter_max = scatter_mean, scatter_max
+    sys.modules["torch_scatter"] = ts
+    old_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        dp = ref_module("pcdet/models/backbones_3d/vfe", "dynamic_pillar_vfe", "refvfe")
+        grid = [int(g) for g in O.grid_size(rng, vs)]
+        cfg = Cfg(USE_NORM=True, WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, NUM_FILTERS=[64, 64])
+        vfe = dp.DynamicPillarVFE(cfg, 5, list(vs), grid, list(rng))
+        with torch.no_grad():
+            for m in vfe.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.uniform_(-0.2, 0.2)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        vfe.eval()
+        with torch.no_grad():
+            bd = vfe({"batch_size": 2, "points": torch.from_numpy(pts_b)})
+    finally:
+        torch.Tensor.cuda = old_cuda
+    state = {k.replace(".", "__"): v.numpy() for k, v in vfe.state_dict().items()}
+    save("g6_dynamic_pillars", points_b=pts_b, pillar_features=bd["pillar_features"].numpy(),
+         voxel_coords=bd["voxel_coords"].numpy().astype(np.int32), range=np.array(rng, np.float32),
+         voxel_size=np.array(vs, np.float32), grid=np.array(grid, np.int32),
+         **{"w__" + k: v for k, v in state.items()})
+
+
 if __name__ == "__main__":
-    g1()
-    g2()
-    g3()
-    g4()
-    g5()
-    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+    only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
+    mpath = os.path.join(HERE, "MANIFEST.json")
+    if only and os.path.exists(mpath):
+        with open(mpath) as f:
+            manifest.update(json.load(f))
+    for fn in (g1, g2, g3, g4, g5, g6):
+        if not only or fn.__name__ in only:
+            fn()
+    with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

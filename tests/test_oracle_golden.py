@@ -153,3 +153,16 @@ def test_empty_rulebooks():
     assert rb["n_out"] == 0 and rb["pair_num"].sum() == 0
     rc = O.rulebook_conv(e, (5, 6, 7), 3, 2, 1)
     assert rc["n_out"] == 0 and list(rc["out_shape"]) == [3, 3, 4]
+
+
+def test_g6_dynamic_pillar_vfe_matches_reference(golden):
+    """numpy restatement of DynamicPillarVFE (dynamic_pillar_vfe.py:90-142) vs the reference module's own output
+    (imported with torch stand-ins for torch_scatter): pillar coordinates bit-exact, features to fp32 rounding."""
+    g = golden("g6_dynamic_pillars")
+    state = {k[3:].replace("__", "."): v for k, v in g.items() if k.startswith("w__")}
+    feat, coords, inv = O.dynamic_pillar_vfe(g["points_b"], g["range"], g["voxel_size"], g["grid"], state)
+    np.testing.assert_array_equal(coords, g["voxel_coords"])
+    assert feat.shape == g["pillar_features"].shape == (coords.shape[0], 64)
+    np.testing.assert_allclose(feat, g["pillar_features"], rtol=1e-4, atol=1e-5)
+    assert inv.max() + 1 == coords.shape[0] and inv.shape[0] < g["points_b"].shape[0]   # out-of-range points dropped
+
