@@ -1167,9 +1167,9 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // Wide layers: a contraction step lasts one memory latency (~3.7k clk measured at 128 channels: the gathers
     // and the weight stage are fetched one step ahead of ~256 clk of MFMA work), so two steps of look-ahead with
     // 32 rows per wave win once the register budget is sized for them (gg_waves: 3-4 waves per SIMD, no spills):
-    // whole step 4.32 -> 4.19 ms.  4 steps ahead, 16 or 64 rows per wave, or 4-step weight stages are slower
-    // (4.21-4.63).  Few rows (< 48k): 16 rows per wave and more workgroups.
-    const int mi = n_rows_out >= 96 * 1024 ? 4 : n_rows_out >= 48 * 1024 ? 2 : 1;
+    // whole step 4.32 -> 4.19 ms at B = 4.  4 steps ahead, 16 or 64 rows per wave, or 4-step weight stages are
+    // slower (4.21-4.63); choosing 16 rows per wave for layers with few rows (< 48k) was also slower
+    // (B = 1 / 2: 432 / 676 -> 457 / 712 frames/s without that rule).
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
         case 1:
@@ -1178,11 +1178,9 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
             // (32 channels, staged: <2,2,2,2> / <2,2,2,4> / <2,4,2,2> / <2,2,4,4> / <2,4,1,2> measured 4.20-4.34 vs 4.18)
             return resident ? launch_gg<2, 2, 1, 0>(GG_ARGS) : launch_gg<2, 2, 1, 2>(GG_ARGS);
         case 4:
-            if (resident) return launch_gg<4, 2, 2, 0>(GG_ARGS);
-            return mi >= 2 ? launch_gg<4, 2, 2, 2>(GG_ARGS) : launch_gg<4, 1, 1, 1>(GG_ARGS);
+            return resident ? launch_gg<4, 2, 2, 0>(GG_ARGS) : launch_gg<4, 2, 2, 2>(GG_ARGS);
         case 8:
-            if (resident) return launch_gg<8, 2, 2, 0>(GG_ARGS);
-            return mi >= 2 ? launch_gg<8, 2, 2, 2>(GG_ARGS) : launch_gg<8, 1, 1, 1>(GG_ARGS);
+            return resident ? launch_gg<8, 2, 2, 0>(GG_ARGS) : launch_gg<8, 2, 2, 2>(GG_ARGS);
         default:
             return PCD_ERR_UNSUPPORTED;
     }
