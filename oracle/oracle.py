@@ -226,8 +226,9 @@ def rulebook_inverse(rb):
                 n_out=rb["n_in"], n_in=rb["n_out"], K=rb["K"])
 
 
-def conv_fwd(x, w, bias, rb):
-    """x [n_in,cin] f32, w [K,cin,cout] f32 -> y [n_out,cout] f32 (gather-GEMM-scatter)."""
+def conv_fwd(x, w, bias, rb, threads=1):
+    """x [n_in,cin] f32, w [K,cin,cout] f32 -> y [n_out,cout] f32 (gather-GEMM-scatter).
+    threads > 1: the OpenMP variant (bench.py's multi-core CPU baseline only)."""
     x, w = _f32(x), _f32(w)
     K, cin, cout = w.shape
     assert x.shape[1] == cin and K == rb["K"]
@@ -235,12 +236,16 @@ def conv_fwd(x, w, bias, rb):
     pmax = pairs.shape[2]
     y = np.zeros((rb["n_out"], cout), np.float32)
     b = _f32(bias) if bias is not None else None
+    if threads > 1:
+        lib().orc_conv_fwd_mt(_p(x), cin, _p(w), _p(b), _p(pairs), _p(_i32(rb["pair_num"])), K, pmax, _p(y),
+                              rb["n_out"], cout, int(threads))
+        return y
     lib().orc_conv_fwd(_p(x), cin, _p(w), _p(b), _p(pairs), _p(_i32(rb["pair_num"])), K, pmax, _p(y),
                        rb["n_out"], cout)
     return y
 
 
-def conv_bwd(x, w, dy, rb, with_bias=False):
+def conv_bwd(x, w, dy, rb, with_bias=False, threads=1):
     x, w, dy = _f32(x), _f32(w), _f32(dy)
     K, cin, cout = w.shape
     pairs = _i32(rb["pairs"])
@@ -248,6 +253,10 @@ def conv_bwd(x, w, dy, rb, with_bias=False):
     dx = np.zeros_like(x)
     dw = np.zeros_like(w)
     db = np.zeros((cout,), np.float32) if with_bias else None
+    if threads > 1:
+        lib().orc_conv_bwd_mt(_p(x), x.shape[0], cin, _p(w), _p(dy), dy.shape[0], cout, _p(pairs),
+                              _p(_i32(rb["pair_num"])), K, pmax, _p(dx), _p(dw), int(threads))
+        return dx, dw, (dy.sum(0) if with_bias else None)
     lib().orc_conv_bwd(_p(x), x.shape[0], cin, _p(w), _p(dy), dy.shape[0], cout, _p(pairs),
                        _p(_i32(rb["pair_num"])), K, pmax, _p(dx), _p(dw), _p(db))
     return dx, dw, db

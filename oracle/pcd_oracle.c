@@ -443,6 +443,93 @@ void orc_conv_bwd(const float *X, int n_in, int cin, const float *W, const float
     }
 }
 
+/*
+ * Multi-threaded variants (OpenMP), used ONLY by bench.py's cpu_baseline leg so that the baseline can use the host's
+ * cores: the same gather-GEMM-scatter arithmetic, parallel over the pairs of one kernel offset (inside one offset
+ * every output row and every input row occurs at most once, so Y / dX rows are written by one thread); dW is
+ * accumulated in per-thread buffers and added up in thread order.
+ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+void orc_conv_fwd_mt(const float *X, int cin, const float *W, const float *bias, const int32_t *pairs,
+                     const int32_t *pair_num, int K, int pmax, float *Y, int n_out, int cout, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < n_out; ++o)
+        for (int c = 0; c < cout; ++c) Y[(size_t)o * cout + c] = bias ? bias[c] : 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
+        const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+        const float *Wk = W + (size_t)k * cin * cout;
+        const int P = pair_num[k];
+#pragma omp parallel for schedule(static)
+        for (int p = 0; p < P; ++p) {
+            const float *x = X + (size_t)pin[p] * cin;
+            float *y = Y + (size_t)pout[p] * cout;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float xv = x[ci];
+                const float *w = Wk + (size_t)ci * cout;
+                for (int co = 0; co < cout; ++co) y[co] += xv * w[co];
+            }
+        }
+    }
+}
+
+void orc_conv_bwd_mt(const float *X, int n_in, int cin, const float *W, const float *dY, int n_out, int cout,
+                     const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *dX, float *dW,
+                     int threads) {
+    (void)n_out;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    const int T = omp_get_max_threads();
+#else
+    const int T = 1;
+#endif
+    memset(dX, 0, (size_t)n_in * cin * sizeof(float));
+    memset(dW, 0, (size_t)K * cin * cout * sizeof(float));
+    float *priv = (float *)calloc((size_t)T * cin * cout, sizeof(float));
+    if (!priv) return;
+    for (int k = 0; k < K; ++k) {
+        const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
+        const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+        const float *Wk = W + (size_t)k * cin * cout;
+        const int P = pair_num[k];
+        memset(priv, 0, (size_t)T * cin * cout * sizeof(float));
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+            float *dWt = priv + (size_t)omp_get_thread_num() * cin * cout;
+#else
+            float *dWt = priv;
+#endif
+#pragma omp for schedule(static)
+            for (int p = 0; p < P; ++p) {
+                const float *x = X + (size_t)pin[p] * cin;
+                float *dx = dX + (size_t)pin[p] * cin;
+                const float *dy = dY + (size_t)pout[p] * cout;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float *w = Wk + (size_t)ci * cout;
+                    float *dw = dWt + (size_t)ci * cout;
+                    const float xv = x[ci];
+                    float acc = 0.0f;
+                    for (int co = 0; co < cout; ++co) {
+                        acc += dy[co] * w[co];
+                        dw[co] += xv * dy[co];
+                    }
+                    dx[ci] += acc;
+                }
+            }
+        }
+        float *dWk = dW + (size_t)k * cin * cout;
+        for (int t = 0; t < T; ++t)
+            for (int e = 0; e < cin * cout; ++e) dWk[e] += priv[(size_t)t * cin * cout + e];
+    }
+    free(priv);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /*
  * SparseConvTensor.dense() + HeightCompression view:
