@@ -32,6 +32,35 @@ def test_library_exports_every_declared_symbol():
     assert lib.pcd_error_string(-3).decode().startswith("batch")
 
 
+def test_header_structs_match_ctypes_mirrors(tmp_path):
+    """The by-value / by-pointer structs of the C ABI (PcdBnReduce, PcdColsumJob, PcdWgradReduceJob) as gcc lays
+    them out from include/pcd_ops.h == the ctypes.Structure mirrors in com_amd/_lib.py (size and field offsets)."""
+    import subprocess
+    from com_amd import _lib
+    structs = {"PcdBnReduce": _lib.PcdBnReduce, "PcdColsumJob": _lib.PcdColsumJob,
+               "PcdWgradReduceJob": _lib.PcdWgradReduceJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pcd_ops.h"', 'int main(void) {']
+    for name, st in structs.items():
+        lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _ in st._fields_:
+            lines.append(f'printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ['return 0; }']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for line in subprocess.check_output([str(exe)]).decode().split("\n"):
+        if line:
+            a, b, c = line.split()
+            got[(a, b)] = int(c)
+    for name, st in structs.items():
+        assert got[(name, "size")] == ctypes.sizeof(st), name
+        for field, _ in st._fields_:
+            assert got[(name, field)] == getattr(st, field).offset, (name, field)
+    assert _lib.COLSUM_MAX_JOBS == 32 and _lib.WGRAD_MAX_JOBS == 32      # PCD_COLSUM_MAX_JOBS / PCD_WGRAD_MAX_JOBS
+
+
 def test_host_only_entry_points_agree_with_oracle():
     """pcd_conv_out_shape and the workspace-size queries are pure host code."""
     from com_amd import ops, _lib
