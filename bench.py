@@ -253,6 +253,7 @@ def main():
     from com_amd.spconv import functional as Fsp
     Fsp.WGRAD_JOIN_LAG = int(os.environ.get('PCD_WGRAD_LAG', '1'))   # lagged join of the side-stream wgrad chain
     Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
+    ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
     Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
     model = HotPath().to(dev)
     model.train()

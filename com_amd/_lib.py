@@ -61,6 +61,8 @@ PROTOTYPES = {
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_reduce_batched": (_i, [_vp, _i, _vp]),
+    "pcd_sparse_conv_wgrad_os_splits": (_i, [_i, _i, _i, _i]),
+    "pcd_sparse_conv_wgrad_os": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "pcd_bev_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_bev_scatter": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_bev_gather": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -96,7 +98,7 @@ COLSUM_MAX_JOBS = 32
 class PcdWgradReduceJob(ctypes.Structure):
     """include/pcd_ops.h: struct PcdWgradReduceJob."""
     _fields_ = [("workspace", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("kvol", ctypes.c_int),
-                ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("pmax", ctypes.c_int)]
+                ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("pmax", ctypes.c_int), ("splits", ctypes.c_int)]
 
 
 WGRAD_MAX_JOBS = 32

@@ -972,6 +972,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output-stationary weight gradient for the 16-channel layers (level 1: 338 k rows at B = 4, 5 SubM convs + the
+// input conv).  The pair-based kernel above gathers TWO 32-byte rows per pair (x and dy), 2 x 7.9 per output row --
+// at this width it is bound by those line fetches (~11 TB/s of L2 -> L1 traffic), and these layers are the last of
+// the backward pass, where nothing hides them.  Here a wave walks 32 consecutive OUTPUT rows per step: dy is read
+// once, in order, and only x is gathered, through nbr_out[k][o], for all K = 27 offsets; the 27 accumulators
+// dW_k (16 x 16 each) stay in registers for the workgroup's whole row range.  Half the gathered lines for 3.4x the
+// (idle) MFMA work.  Rows staged through LDS and transposed with ds_read_b64_tr_b16 as in wgrad_body.
+template <int K>
+__global__ __launch_bounds__(256, 2) void wgrad_os16_kernel(
+    const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
+    const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, const int32_t *__restrict__ n_dev, int rows_per_wg,
+    float *__restrict__ slab, unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int G = 9;                                   // offsets staged per group
+    static_assert(K % G == 0, "offset groups");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned short *Xs = (unsigned short *)smem + (size_t)wave * (G + 1) * 512;   // [G][32 rows][16 ch]
+    unsigned short *Ys = Xs + G * 512;                                            // [32 rows][16 ch]
+    float *tile = (float *)smem;                           // [K][16 co][16 ci], after the main loop
+    const int g = lane >> 4, t = lane & 15;
+    const int xrow = lane >> 1, xpc = lane & 1;            // lane -> (row, 16-byte half of the 32-byte row)
+    const int trow = 4 * g + (t >> 2);
+    const int n = eff_rows(n_dev, n_cap);
+    const int r_begin = blockIdx.x * rows_per_wg;
+    const int r_end = min(n, r_begin + rows_per_wg);
+    f32x4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+    const unsigned x_row_bytes = (unsigned)cin_pad * 2u;
+    const bool x_piece_ok = xpc * 8 < cin_pad;
+    int idx_cur[K], idx_nxt[K];
+    auto load_idx = [&](int r0, int(&idx)[K]) {            // neighbour rows of output row r0 + xrow, all offsets
+        const int row = r0 + xrow;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned off = row < r_end ? ((unsigned)k * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs, off, 0, 0);
+            idx[k] = row < r_end ? v : -1;
+        }
+    };
+    const int r_first = r_begin + wave * 32;
+    load_idx(r_first, idx_cur);
+    for (int r0 = r_first; r0 < r_end; r0 += 128) {
+        load_idx(r0 + 128, idx_nxt);                        // one step ahead
+        const int row = r0 + xrow;
+        const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(
+            yrs, row < r_end ? (unsigned)row * 32u + (unsigned)xpc * 16u : 0xFFFFFFF0u, 0, 0);
+        bf16x8 bfr;
+#pragma unroll
+        for (int grp = 0; grp < K / G; ++grp) {
+            u32x4 xr[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {                   // index -1 -> offset beyond the buffer -> zeros
+                const int i = idx_cur[grp * G + j];
+                const unsigned off = x_piece_ok ? (unsigned)i * x_row_bytes + (unsigned)xpc * 16u : 0xFFFFFFF0u;
+                xr[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+            }
+            if (grp == 0) *reinterpret_cast<u32x4 *>(Ys + xrow * 16 + xpc * 8) = yv;
+#pragma unroll
+            for (int j = 0; j < G; ++j) *reinterpret_cast<u32x4 *>(Xs + j * 512 + xrow * 16 + xpc * 8) = xr[j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (grp == 0) {
+                const unsigned short *b0 = Ys + trow * 16 + (t & 3) * 4;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(b0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(b0 + 16 * 16));
+                bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const unsigned short *a0 = Xs + j * 512 + trow * 16 + (t & 3) * 4;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a0 + 16 * 16));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[grp * G + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[grp * G + j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) idx_cur[k] = idx_nxt[k];
+    }
+    // fixed-order reduction of the 4 waves through LDS, then one slab [cout][K][cin] per workgroup
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *dst = tile + k * 256 + t * 16 + g * 4 + r;     // [co = t][ci = 4g + r]
+                    *dst = (w == 0) ? acc[k][r] : (*dst + acc[k][r]);
+                }
+        }
+        __syncthreads();
+    }
+    float *sl = slab + (size_t)blockIdx.x * 16 * K * cin;
+    for (int e = threadIdx.x; e < K * 256; e += 256) {
+        const int k = e >> 8, co = (e >> 4) & 15, ci = e & 15;
+        if (ci < cin) sl[((size_t)co * K + k) * cin + ci] = tile[e];
+    }
+}
+
+constexpr int WGRAD_OS_ROWS = 1024;     // output rows per workgroup (= per slab); 256 / 512 / 2048: 4.20 / 4.14 / 4.12 vs 4.10 ms
+
 // dw[e] = sum over splits of slab[q][e] in a FIXED order: 8 thread groups sum interleaved subsets of the splits
 // (q = g, g + 8, ...) with independent loads in flight, then the 8 partial sums are added in group order.
 // (One thread per element looping over up to 64 splits left a 16-channel layer with 27 workgroups of 64
@@ -1336,10 +1446,11 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
     for (int i = 0; i < n_jobs; ++i) {
         const PcdWgradReduceJob &q = jobs_host[i];
         if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight) return PCD_ERR_INVALID_ARG;
-        if (q.pmax == 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
+        if (q.pmax == 0 && q.splits <= 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
         if (!q.workspace) return PCD_ERR_WORKSPACE;
         int splits, per;
         wgrad_plan(q.pmax, q.cin, q.cout, &splits, &per);
+        if (q.splits > 0) splits = q.splits;          // slabs written by pcd_sparse_conv_wgrad_os
         const size_t n = (size_t)q.cout * q.kvol * q.cin;
         const bool vec = (n & 3) == 0 && (((uintptr_t)q.dweight | (uintptr_t)q.workspace) & 15u) == 0;
         auto &d = J.job[J.n_jobs++];
@@ -1353,6 +1464,32 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
     }
     if (blocks == 0) return PCD_OK;
     wgrad_reduce_batched_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(J);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// 16-output-channel layers: see wgrad_os16_kernel.  splits (= slabs to reduce) = ceil(n_out / 1024).
+extern "C" int pcd_sparse_conv_wgrad_os_splits(int n_out_rows, int kvol, int cin_pad, int cout) {
+    if (n_out_rows <= 0 || kvol != 27 || cout != 16 || (cin_pad != 8 && cin_pad != 16)) return 0;
+    return pcd_div_up(n_out_rows, WGRAD_OS_ROWS);
+}
+
+extern "C" int pcd_sparse_conv_wgrad_os(const void *x, int n_x, int cin_pad, int cin, const void *dy, int n_out_rows,
+                                        const int32_t *n_out_dev, int cout, const int32_t *nbr_out, int nbr_stride,
+                                        int kvol, void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    const int splits = pcd_sparse_conv_wgrad_os_splits(n_out_rows, kvol, cin_pad, cout);
+    if (splits <= 0 || cin <= 0 || cin > cin_pad) return PCD_ERR_UNSUPPORTED;
+    if (!x || !dy || !nbr_out || !workspace || n_x < 0 || nbr_stride < n_out_rows) return PCD_ERR_INVALID_ARG;
+    if ((double)n_x * cin_pad * 2 >= 4294966000.0 || (double)n_out_rows * cout * 2 >= 4294966000.0)
+        return PCD_ERR_UNSUPPORTED;
+    if (workspace_bytes < (size_t)splits * cout * kvol * cin * sizeof(float)) return PCD_ERR_WORKSPACE;
+    const size_t lds_stage = (size_t)4 * 10 * 512 * sizeof(unsigned short);   // 4 waves x (9 + 1) row tiles
+    const size_t lds_tile = (size_t)27 * 256 * sizeof(float);
+    wgrad_os16_kernel<27><<<splits, 256, lds_stage > lds_tile ? lds_stage : lds_tile, (hipStream_t)stream>>>(
+        (const unsigned short *)x, cin_pad, cin, (const unsigned short *)dy, nbr_out, nbr_stride, n_out_rows, n_out_dev,
+        WGRAD_OS_ROWS, (float *)workspace, (unsigned)((size_t)n_x * cin_pad * 2),
+        (unsigned)((size_t)n_out_rows * cout * 2));
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

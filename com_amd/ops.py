@@ -543,20 +543,45 @@ def _usable_out(out, numel):
             and out.is_cuda)
 
 
-def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None):
+WGRAD_OS = True      # 16-output-channel layers: output-stationary kernel over nbr_out (pcd_sparse_conv_wgrad_os)
+
+
+def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None):
     """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
     (e.g. the parameter's .grad) when given.  `defer` (a list): only the MFMA kernel runs now, into a slab buffer of
-    its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all)."""
+    its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all).
+    `nbr_out` [K, n_out] (+ `n_out_dev`): lets 16-output-channel layers use the output-stationary kernel."""
     _require_cuda(x, dy, pairs, pair_num)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     assert x.is_contiguous() and dy.is_contiguous() and pairs.is_contiguous()
     cout = dy.shape[1]
     pmax = pairs.shape[2]
     lib = L.lib()
-    wsb = lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax)
-    ws = _ws(wsb, x.device) if defer is None else torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
     dw = out if _usable_out(out, cout * kvol * cin) else \
         torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
+    os_splits = 0
+    if WGRAD_OS and nbr_out is not None and nbr_out.is_contiguous() and nbr_out.shape[1] >= dy.shape[0]:
+        os_splits = lib.pcd_sparse_conv_wgrad_os_splits(dy.shape[0], kvol, x.shape[1], cout)
+    if os_splits > 0:
+        slab = torch.empty((os_splits * cout * kvol * cin * 4,), dtype=torch.uint8, device=x.device)
+
+        def meta_os():
+            npairs = int((nbr_out >= 0).sum().item())
+            return dict(bytes=(x.shape[0] * x.shape[1] + dy.shape[0] * cout) * 2 + 8 * npairs + kvol * cin * cout * 4,
+                        flops=2 * npairs * x.shape[1] * cout, rows=dy.shape[0], pairs=npairs)
+
+        with _Timed(f"wgrad_os16_kernel {x.shape[1]}x{cout} K={kvol}", meta_os):
+            L.check(lib.pcd_sparse_conv_wgrad_os(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), dy.shape[0],
+                                                 L.ptr(n_out_dev), cout, L.ptr(nbr_out), nbr_out.shape[1], kvol,
+                                                 L.ptr(slab), slab.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_os")
+        job = (slab, dw, kvol, cin, cout, pmax, os_splits)
+        if defer is not None:
+            defer.append(job)
+        else:
+            wgrad_reduce_batched([job])
+        return dw
+    wsb = lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax)
+    ws = _ws(wsb, x.device) if defer is None else torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
 
     def meta():
         npairs = int(pair_num.sum().item())
@@ -583,13 +608,14 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None):
 
 
 def wgrad_reduce_batched(jobs):
-    """jobs = [(slab workspace, dw, kvol, cin, cout, pmax)] collected by wgrad(defer=...)."""
+    """jobs = [(slab workspace, dw, kvol, cin, cout, pmax[, splits])] collected by wgrad(defer=...)."""
     import ctypes
     for i in range(0, len(jobs), L.WGRAD_MAX_JOBS):
         chunk = jobs[i:i + L.WGRAD_MAX_JOBS]
         arr = (L.PcdWgradReduceJob * len(chunk))()
-        for j, (ws, dw, kvol, cin, cout, pmax) in enumerate(chunk):
-            arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax)
+        for j, job in enumerate(chunk):
+            ws, dw, kvol, cin, cout, pmax = job[:6]
+            arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax, job[6] if len(job) > 6 else 0)
         L.check(L.lib().pcd_sparse_conv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk),
                                                              L.stream_ptr()), "pcd_sparse_conv_wgrad_reduce_batched")
 

@@ -199,7 +199,8 @@ class SparseConvFunction(Function):
             if ctx.needs_input_grad[1]:
                 dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol,
                                 out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32
-                                defer=_WGRAD_JOBS if (deferred and direct_w) else None)
+                                defer=_WGRAD_JOBS if (deferred and direct_w) else None,
+                                nbr_out=rb.nbr_out, n_out_dev=rb.n_out_dev)
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 cl = ctx.colsum_link.result if ctx.colsum_link is not None else None

@@ -277,8 +277,17 @@ typedef struct PcdWgradReduceJob {
     const void *workspace;
     float *dweight;
     int kvol, cin, cout, pmax;
+    int splits;              /* 0: as planned by pcd_sparse_conv_wgrad; > 0: slabs written by pcd_sparse_conv_wgrad_os */
 } PcdWgradReduceJob;
 int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream);
+/* Output-stationary form for layers with 16 output channels (cin_pad 8 or 16, 3x3x3): walks the OUTPUT rows, reads dY in
+ * order once and gathers only X through nbr_out [K][n_out] -- half the gathered rows of the pair form, which binds at
+ * this width.  Writes pcd_sparse_conv_wgrad_os_splits(..) slabs [cout][K][cin] into `workspace` (splits * cout * K * cin
+ * floats); reduce with pcd_sparse_conv_wgrad_reduce_batched (job.splits).  0 splits / PCD_ERR_UNSUPPORTED: not covered. */
+int pcd_sparse_conv_wgrad_os_splits(int n_out_rows, int kvol, int cin_pad, int cout);
+int pcd_sparse_conv_wgrad_os(const void *x, int n_x_rows, int cin_pad, int cin, const void *dy, int n_out_rows,
+                             const int32_t *n_out_dev, int cout, const int32_t *nbr_out, int nbr_stride, int kvol,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (a13/a14) BEV scatter -- replaces SparseConvTensor.dense() + the view in

@@ -658,6 +658,50 @@ def test_bev_scatter_gather_bit_exact(golden, dtype):
     np.testing.assert_array_equal(_cpu(back.float()), _cpu(featp[:, :C].float()))
 
 
+def test_output_stationary_wgrad_equals_pair_form():
+    """pcd_sparse_conv_wgrad_os (16 output channels: walks output rows, gathers x through nbr_out) == the pair-based
+    pcd_sparse_conv_wgrad: bit-exact on small-integer data (every sum exact in fp32), <= 1e-5 of the scale on random
+    data, for SubM (cin 16 and the 5 -> 16 input conv, cin_pad 8) and a strided rulebook's transposed use."""
+    from com_amd import hotpath
+    ops = _ops()
+    torch.manual_seed(31)
+    frames = [synth.synth_cloud(60 + f, 32, 1250) for f in range(2)]
+    pts, offs = hotpath.collate_points(frames, DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
+                            num_features=5, want_voxels=False)
+    idx = res["coords"]
+    n = idx.shape[0]
+    rb = ops.rulebook_subm(idx, 2, [41, 1504, 1504])
+    for cin, cin_pad in ((16, 16), (5, 8)):
+        for exact in (True, False):
+            if exact:
+                x = torch.randint(-1, 2, (n, cin_pad), device=DEV).bfloat16()
+                dy = torch.randint(-1, 2, (n, 16), device=DEV).bfloat16()
+            else:
+                x = torch.randn(n, cin_pad, device=DEV).bfloat16()
+                dy = torch.randn(n, 16, device=DEV).bfloat16()
+            x[:, cin:] = 0
+            keep = ops.WGRAD_OS
+            try:
+                ops.WGRAD_OS = False
+                ref = ops.wgrad(x, cin, dy, rb.pairs, rb.pair_num, 27)
+                ops.WGRAD_OS = True
+                got = ops.wgrad(x, cin, dy, rb.pairs, rb.pair_num, 27, nbr_out=rb.nbr_out)
+            finally:
+                ops.WGRAD_OS = keep
+            assert got.shape == ref.shape == (16, 27, cin)
+            if exact:
+                assert torch.equal(got, ref), (cin, "exact")
+            else:
+                assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), cin
+    assert L_os_splits(n) > 0
+
+
+def L_os_splits(n):
+    from com_amd import _lib
+    return _lib.lib().pcd_sparse_conv_wgrad_os_splits(n, 27, 16, 16)
+
+
 def test_full_size_voxelizer_properties():
     """B = 4 x 160 k points: voxel coordinates are unique per frame and in range, 1 <= num_points <= T, the kept
     points of a voxel all fall into it and appear in point order, voxel ids follow first appearance, the fused
