@@ -46,6 +46,8 @@ PROTOTYPES = {
     "pcd_sparse_conv_gather_gemm_tiles": (_i, [_i, _i, _i, _i, _i]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_rulebook_subm_pairs_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_rulebook_subm_pairs": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
                                       _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),

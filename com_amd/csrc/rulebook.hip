@@ -623,6 +623,52 @@ extern "C" int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const
     return PCD_OK;
 }
 
+// per (offset, wave of 64 rows): number of rows with a neighbour -- what the probe kernels emit as a by-product
+__global__ __launch_bounds__(256) void nbr_wave_count_kernel(const int32_t *__restrict__ tbl, int n,
+                                                             const int32_t *n_dev, int K, int nwaves,
+                                                             int *__restrict__ wave_cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave = i >> 6;
+    const int nn = eff_rows(n_dev, n);
+    for (int k = 0; k < K; ++k) {
+        const int o = (i < nn) ? tbl[(size_t)k * n + i] : -1;
+        const u64 m = __ballot(o >= 0);
+        if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+    }
+}
+
+extern "C" size_t pcd_rulebook_subm_pairs_workspace_bytes(int n, int kvol) {
+    if (n < 0 || kvol <= 0) return 0;
+    int nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    return 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) + ws_piece(kvol, sizeof(int));
+}
+
+// indice_pairs / indice_pair_num of a SubM rulebook from its neighbour table alone (for rulebooks built with
+// pairs == NULL whose pairs turn out to be needed later); same result as pcd_rulebook_subm's.
+extern "C" int pcd_rulebook_subm_pairs(const int32_t *nbr, int n, int kvol, int32_t *pairs, int32_t *pair_num,
+                                       int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    PCD_ENTER();
+    if (n < 0 || kvol <= 0 || !pair_num || (n > 0 && (!nbr || !pairs))) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        pcd_fill(pair_num, 0, kvol * sizeof(int32_t), st);
+        return PCD_OK;
+    }
+    WsCarver ws(workspace, workspace_bytes);
+    const int nwaves = pcd_div_up(n, 64);
+    int *wave_cnt = ws.take<int>((size_t)kvol * nwaves);
+    int *wave_off = ws.take<int>((size_t)kvol * nwaves);
+    int *totals = ws.take<int>(kvol);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    nbr_wave_count_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>(nbr, n, n_dev, kvol, nwaves, wave_cnt);
+    scan_rows_kernel<<<kvol, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
+    if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)kvol * 2 * n * sizeof(int32_t), st);
+    launch_pairs_fill(nbr, n, n_dev, kvol, 1, wave_off, nwaves, pairs, st);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
 extern "C" size_t pcd_rulebook_subm_ranked_workspace_bytes(int n, int kvol) {
     if (n < 0 || kvol <= 0) return 0;
     int nwaves = pcd_div_up(n > 0 ? n : 1, 64);

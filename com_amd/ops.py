@@ -252,12 +252,34 @@ class Rulebook:
         self.subm, self.kvol, self.n_in, self.n_out = subm, kvol, n_in, n_out
         # device-side row counts (static-shape mode): n_in / n_out are then capacities
         self.n_in_dev, self.n_out_dev = n_in_dev, n_out_dev
-        self.nbr_out, self.nbr_in, self.pairs, self.pair_num = nbr_out, nbr_in, pairs, pair_num
+        self.nbr_out, self.nbr_in, self._pairs, self._pair_num = nbr_out, nbr_in, pairs, pair_num
         self.out_indices = out_indices
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.rank = None          # RankMap of the output level (strided builds only)
         self.classes = None       # (perm, vstart, vcap): input rows grouped by stride-parity class (strided, training)
+
+    def _lazy_pairs(self):
+        # a SubM rulebook built without pairs (only kernels that read nbr have used it so far): derive them now
+        if self._pairs is None and self.subm and self.nbr_out is not None and self.n_in > 0:
+            lib = L.lib()
+            n, dev = self.nbr_out.shape[1], self.nbr_out.device
+            self._pairs = torch.empty((self.kvol, 2, n), dtype=torch.int32, device=dev)
+            self._pair_num = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+            ws = _ws(lib.pcd_rulebook_subm_pairs_workspace_bytes(n, self.kvol), dev)
+            L.check(lib.pcd_rulebook_subm_pairs(L.ptr(self.nbr_out), n, self.kvol, L.ptr(self._pairs),
+                                                L.ptr(self._pair_num), 0, L.ptr(self.n_in_dev), L.ptr(ws), ws.numel(),
+                                                L.stream_ptr()), "pcd_rulebook_subm_pairs")
+
+    @property
+    def pairs(self):
+        self._lazy_pairs()
+        return self._pairs
+
+    @property
+    def pair_num(self):
+        self._lazy_pairs()
+        return self._pair_num
 
     def inverse(self):
         """Rulebook of SparseInverseConv3d sharing this indice_key."""
@@ -546,16 +568,19 @@ def _usable_out(out, numel):
 WGRAD_OS = True      # 16-output-channel layers: output-stationary kernel over nbr_out (pcd_sparse_conv_wgrad_os)
 
 
-def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None):
+def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None, rb=None):
     """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
     (e.g. the parameter's .grad) when given.  `defer` (a list): only the MFMA kernel runs now, into a slab buffer of
     its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all).
-    `nbr_out` [K, n_out] (+ `n_out_dev`): lets 16-output-channel layers use the output-stationary kernel."""
-    _require_cuda(x, dy, pairs, pair_num)
+    `nbr_out` [K, n_out] (+ `n_out_dev`): lets 16-output-channel layers use the output-stationary kernel.
+    `rb` (instead of pairs / pair_num / nbr_out): a Rulebook -- its pairs are only touched (and, for a SubM rulebook
+    built without them, only then derived) when the pair-based kernel is the one that runs."""
+    if rb is not None:
+        nbr_out, n_out_dev = rb.nbr_out, rb.n_out_dev
+    _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
-    assert x.is_contiguous() and dy.is_contiguous() and pairs.is_contiguous()
+    assert x.is_contiguous() and dy.is_contiguous()
     cout = dy.shape[1]
-    pmax = pairs.shape[2]
     lib = L.lib()
     dw = out if _usable_out(out, cout * kvol * cin) else \
         torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
@@ -574,12 +599,17 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
             L.check(lib.pcd_sparse_conv_wgrad_os(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), dy.shape[0],
                                                  L.ptr(n_out_dev), cout, L.ptr(nbr_out), nbr_out.shape[1], kvol,
                                                  L.ptr(slab), slab.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_os")
-        job = (slab, dw, kvol, cin, cout, pmax, os_splits)
+        job = (slab, dw, kvol, cin, cout, 0, os_splits)
         if defer is not None:
             defer.append(job)
         else:
             wgrad_reduce_batched([job])
         return dw
+    if rb is not None:
+        pairs, pair_num = rb.pairs, rb.pair_num
+    _require_cuda(pairs, pair_num)
+    assert pairs.is_contiguous()
+    pmax = pairs.shape[2]
     wsb = lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax)
     ws = _ws(wsb, x.device) if defer is None else torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
 

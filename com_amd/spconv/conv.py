@@ -137,8 +137,12 @@ class SparseConvolution(SparseModule):
             else:
                 # rows created by a strided conv of this chain are its bitmap ranks: no hash table needed
                 rank = x.indice_dict.get(("__rank__", x.indices.data_ptr()), None)
+                # 16-channel layers run their weight gradient through nbr_out (ops.WGRAD_OS): their rulebook is built
+                # without indice_pairs (derived on demand if some other consumer asks for them)
+                lazy = ops.WGRAD_OS and self.out_channels == 16 and self.in_channels <= 16 \
+                    and tuple(self.kernel_size) == (3, 3, 3)
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
-                                       self.dilation, n_dev=x.num_rows, rank=rank)
+                                       self.dilation, n_dev=x.num_rows, rank=rank, want_pairs=not lazy)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:

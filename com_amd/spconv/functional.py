@@ -197,10 +197,9 @@ class SparseConvFunction(Function):
                     and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if ctx.needs_input_grad[1]:
-                dwk = ops.wgrad(x, ctx.cin, dy16, rb.pairs, rb.pair_num, rb.kvol,
+                dwk = ops.wgrad(x, ctx.cin, dy16, None, None, rb.kvol,
                                 out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32
-                                defer=_WGRAD_JOBS if (deferred and direct_w) else None,
-                                nbr_out=rb.nbr_out, n_out_dev=rb.n_out_dev)
+                                defer=_WGRAD_JOBS if (deferred and direct_w) else None, rb=rb)
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 cl = ctx.colsum_link.result if ctx.colsum_link is not None else None

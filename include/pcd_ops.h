@@ -159,6 +159,11 @@ int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *
                            int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
+/* indice_pairs / indice_pair_num of a SubM rulebook from its nbr table [kvol][n] alone -- for rulebooks built with
+ * pairs == NULL (the forward and the output-stationary kernels only need nbr) whose pairs are wanted later. */
+size_t pcd_rulebook_subm_pairs_workspace_bytes(int n, int kvol);
+int pcd_rulebook_subm_pairs(const int32_t *nbr, int n, int kvol, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 /* The rank structure the strided build leaves in its workspace is exactly a coordinate -> row map of the OUTPUT
  * level (row id = rank of the linear key): the SubM rulebook of that level (the 'subm2..4' keys that follow
  * every strided conv of spconv_backbone.py:205-229) can use it instead of building and probing a hash table.

@@ -192,6 +192,26 @@ def test_rulebooks_waymo_chain_bit_exact():
         idx, shape = rb_o["out_indices"], tuple(es)
 
 
+def test_subm_pairs_derived_on_demand_equal_built_pairs():
+    """A SubM rulebook built without indice_pairs (16-channel layers only read nbr) hands out exactly the pairs
+    pcd_rulebook_subm would have built, when some consumer asks for them later (pcd_rulebook_subm_pairs)."""
+    ops = _ops()
+    frames = [synth.synth_cloud(f, 32, 1250) for f in range(2)]
+    pts, offs = __import__("com_amd.hotpath", fromlist=["x"]).collate_points(frames, DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
+                            num_features=5, want_voxels=False)
+    idx = res["coords"]
+    full = ops.rulebook_subm(idx, 2, [41, 1504, 1504], pad_pairs=True)
+    lazy = ops.rulebook_subm(idx, 2, [41, 1504, 1504], want_pairs=False)
+    assert lazy._pairs is None
+    assert torch.equal(lazy.nbr_out, full.nbr_out)
+    assert torch.equal(lazy.pair_num, full.pair_num)
+    pn = _cpu(full.pair_num)
+    a, b = _cpu(lazy.pairs), _cpu(full.pairs)
+    for k in range(27):
+        np.testing.assert_array_equal(a[k, :, :pn[k]], b[k, :, :pn[k]])
+
+
 def test_rulebook_edge_cases():
     ops = _ops()
     e = torch.zeros((0, 4), dtype=torch.int32, device=DEV)
