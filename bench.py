@@ -65,10 +65,10 @@ class HotPath(torch.nn.Module):
 
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_v14_pmc_traffic.json) -- PMC counters cannot be read from
+    MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_v15_pmc_traffic.json) -- PMC counters cannot be read from
     inside the timed process, so this is the offline measurement of the same command; None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v14_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v15_pmc_traffic.json")) as f:
             k = json.load(f)["kernels"]
         return k[kernel]["hbm_bytes_per_launch_corrected"] if kernel in k else None
     except Exception:
