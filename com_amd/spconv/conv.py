@@ -142,7 +142,8 @@ class SparseConvolution(SparseModule):
                 lazy = ops.WGRAD_OS and self.out_channels == 16 and self.in_channels <= 16 \
                     and tuple(self.kernel_size) == (3, 3, 3)
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
-                                       self.dilation, n_dev=x.num_rows, rank=rank, want_pairs=not lazy)
+                                       self.dilation, n_dev=x.num_rows, rank=rank,
+                                       want_pairs=self.training and not lazy)   # (inference never needs them)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:
