@@ -19,7 +19,7 @@ installed here.  So the fixtures come from the two independent sources that ARE 
 Nothing from /root/reference is copied: only inputs and outputs (data) are stored.  The CPU
 oracle (oracle/) is then checked against these files by tests/test_oracle_golden.py.
 
-Usage:  python tests/golden/make_golden.py [g1 .. g6]   (needs /root/reference; not needed at test time;
+Usage:  python tests/golden/make_golden.py [g1 .. g7]   (needs /root/reference; not needed at test time;
         with names only those fixtures are regenerated)
 """
 import hashlib
@@ -39,7 +39,48 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from com_amd.utils import synth  # noqa: E402  (product-side synthetic generator, numpy only)
-from oracle import oracle as O  # noqa: E402  (only used for the hard voxelizer INPUT of G1/G4)
+from oracle import oracle as O  # noqa: E402  (grid-size / collate helpers only; the voxels of G1/G4/G7 come
+#                                  from voxelize_hard_np below, NOT from the oracle)
+sys.path.insert(0, HERE)
+import g7_params as P7  # noqa: E402
+
+
+def voxelize_hard_np(points, point_cloud_range, voxel_size, max_points, max_voxels):
+    """Literal numpy / Python-loop transcription of SURVEY.md A.1 (the spconv voxel generator called at
+    pcdet/datasets/processor/data_processor.py:44-60), written independently of oracle/pcd_oracle.c so that
+    the fixtures pin the oracle instead of replaying it: dense coor_to_voxelidx grid, points in caller order,
+    float32 `floor((p - min) / vsize)`, voxel ids in first-appearance order, first `max_points` points kept,
+    new voxels dropped once `max_voxels` exist."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    rng = np.asarray(point_cloud_range, dtype=np.float32)
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    grid = np.round((rng[3:6] - rng[0:3]) / vs).astype(np.int64)              # data_processor.py:127-128 (x, y, z)
+    coor_to_voxelidx = -np.ones((int(grid[2]), int(grid[1]), int(grid[0])), dtype=np.int32)
+    C = pts.shape[1]
+    voxels = np.zeros((max_voxels, max_points, C), dtype=np.float32)
+    coors = np.zeros((max_voxels, 3), dtype=np.int32)
+    num = np.zeros((max_voxels,), dtype=np.int32)
+    voxel_num = 0
+    for i in range(pts.shape[0]):
+        c = np.floor((pts[i, 0:3] - rng[0:3]) / vs)                            # float32 arithmetic, true division
+        if not np.all(np.isfinite(c)):
+            continue
+        c = c.astype(np.int64)
+        if np.any(c < 0) or np.any(c >= grid):
+            continue
+        v = coor_to_voxelidx[c[2], c[1], c[0]]
+        if v == -1:
+            if voxel_num >= max_voxels:
+                continue
+            v = voxel_num
+            voxel_num += 1
+            coor_to_voxelidx[c[2], c[1], c[0]] = v
+            coors[v] = (c[2], c[1], c[0])
+        n = num[v]
+        if n < max_points:
+            voxels[v, n, :] = pts[i, :C]
+            num[v] = n + 1
+    return voxels[:voxel_num].copy(), coors[:voxel_num].copy(), num[:voxel_num].copy()
 
 
 def sha(*arrays):
@@ -85,7 +126,7 @@ def g1():
     torch.manual_seed(7)
     pts = synth.synth_cloud(0, n_beams=16, n_azimuth=250)              # 4000 points
     rng, vs = synth.PILLAR_RANGE, synth.PILLAR_VOXEL
-    voxels, coords, nump = O.voxelize_hard(pts, rng, vs, synth.PILLAR_MAX_POINTS, 32000)
+    voxels, coords, nump = voxelize_hard_np(pts, rng, vs, synth.PILLAR_MAX_POINTS, 32000)
     coords4 = np.pad(coords, ((0, 0), (1, 0)))                          # batch idx 0
     pv = ref_module("pcdet/models/backbones_3d/vfe", "pillar_vfe", "refvfe")
     cfg = Cfg(USE_NORM=True, WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, NUM_FILTERS=[64, 64])
@@ -192,7 +233,7 @@ def g3():
     frames = small_points(23, 700, 2)
     B = 2
     shape = (41, 96, 96)
-    per = [O.voxelize_hard(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
+    per = [voxelize_hard_np(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
     _, coords, _ = O.collate_voxels(per)
     idx = torch.from_numpy(coords).long()
     n = coords.shape[0]
@@ -255,7 +296,7 @@ def g4():
     mv = ref_module("pcdet/models/backbones_3d/vfe", "mean_vfe", "refvfe")
     vfe = mv.MeanVFE(Cfg(), num_point_features=5)
     frames = small_points(31, 1500, 2)
-    per = [O.voxelize_hard(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
+    per = [voxelize_hard_np(p, SMALL_RANGE, SMALL_VOXEL, 5, 5000) for p in frames]
     voxels, coords, nump = O.collate_voxels(per)
     bd = vfe({"voxels": torch.from_numpy(voxels), "voxel_num_points": torch.from_numpy(nump).float()})
     save("g4_meanvfe", points0=frames[0], points1=frames[1], voxels=voxels, coords=coords,
@@ -336,13 +377,144 @@ def g6():
          **{"w__" + k: v for k, v in state.items()})
 
 
+# ---------------------------------------------------------------------------------------------
+# G7: the WHOLE VoxelResBackBone8x + HeightCompression graph (spconv_backbone.py:191-232,254-291,
+# height_compression.py:20-25) forward AND backward on a reduced grid, expressed with dense
+# torch.nn.functional.conv3d (fp64) masked to the active sets (as G3 does per layer), BatchNorm1d(eps 1e-3,
+# training mode) over the active rows, ReLU, residual adds.  Two variants:
+#   "exact": fp64 everywhere (fp32 parameters) -- the mathematically exact reference;
+#   "bf16" : the same chain with every tensor the HIP path STORES in bf16 rounded to bf16 at that point
+#            (input features, conv weights, every conv output, every BatchNorm(+residual)+ReLU output, and
+#            the corresponding gradients in the backward pass) -- what remains between this variant and the
+#            HIP path is fp32 accumulation order, so it is the one the 1e-3 north-star tolerance is checked on.
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.float().bfloat16().double()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float().bfloat16().double()
+
+
+def _g7_chain(feat_in, coords, state, emulate_bf16):
+    B, shape0 = P7.BATCH, (P7.GRID[2] + 1, P7.GRID[1], P7.GRID[0])
+    R = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
+    params = {k: torch.from_numpy(v.copy()).double().requires_grad_(True) for k, v in state.items()}
+    running = {}
+
+    def weight(name):
+        w = params[name]                                          # [Cout, kd, kh, kw, Cin] (spconv 2.x)
+        if emulate_bf16:
+            w = _RoundBF16.apply(w)                               # bf16 weights; gradient goes to the fp32 master copy
+        return w.permute(0, 4, 1, 2, 3)
+
+    def occupancy(idx, shape):
+        return densify(torch.ones((idx.shape[0], 1), dtype=torch.float64), idx, B, shape)
+
+    def gather(dense, idx):
+        return dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+
+    def scatter(rows, idx, shape):
+        d = torch.zeros((B,) + tuple(shape) + (rows.shape[1],), dtype=torch.float64)
+        d = d.index_put((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]), rows)        # dense(): [B, D, H, W, C]
+        return d.permute(0, 4, 1, 2, 3)
+
+    def subm(rows, idx, shape, wname, bname=None):
+        y = F.conv3d(scatter(rows, idx, shape), weight(wname), stride=1, padding=1)
+        y = gather(y, idx)
+        if bname is not None:
+            y = y + params[bname]
+        return R(y)
+
+    def spconv(rows, idx, shape, L):
+        k, st, pd = L["k"], L["s"], L["p"]
+        y = F.conv3d(scatter(rows, idx, shape), weight(L["name"] + ".0.weight"), stride=st, padding=pd)
+        act = F.conv3d(occupancy(idx, shape), torch.ones((1, 1) + tuple(k), dtype=torch.float64), stride=st,
+                       padding=pd)[:, 0] > 0.5
+        oidx = act.nonzero()                                       # sorted by (b, z, y, x): the canonical row order
+        return R(gather(y, oidx)), oidx, tuple(y.shape[2:])
+
+    def bn_act(x, prefix, residual=None):
+        g, b = params[prefix + ".weight"], params[prefix + ".bias"]
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        n = x.shape[0]
+        running[prefix + ".running_mean"] = (P7.BN_MOMENTUM * mean).detach().float().numpy()
+        running[prefix + ".running_var"] = ((1 - P7.BN_MOMENTUM) + P7.BN_MOMENTUM * var * n / max(n - 1, 1)
+                                            ).detach().float().numpy()
+        y = (x - mean) / torch.sqrt(var + P7.BN_EPS) * g + b
+        if residual is not None:
+            y = y + residual
+        return R(torch.relu(y))
+
+    idx = torch.from_numpy(coords).long()
+    shape = shape0
+    x = R(torch.from_numpy(feat_in).double())
+    taps, tap_idx = {}, {}
+    for L in P7.LAYERS:
+        n = L["name"]
+        if L["kind"] == "subm":
+            x = bn_act(subm(x, idx, shape, n + ".0.weight"), n + ".1")
+        elif L["kind"] == "spconv":
+            y, idx, shape = spconv(x, idx, shape, L)
+            x = bn_act(y, n + ".1")
+        else:                                                      # SparseBasicBlock, spconv_backbone.py:50-66
+            ident = x
+            out = bn_act(subm(x, idx, shape, n + ".conv1.weight", n + ".conv1.bias"), n + ".bn1")
+            out = subm(out, idx, shape, n + ".conv2.weight", n + ".conv2.bias")
+            x = bn_act(out, n + ".bn2", residual=ident)
+        if n in P7.TAPS:
+            taps[P7.TAPS[n]] = x
+            tap_idx[P7.TAPS[n]] = (idx.numpy().astype(np.int32), shape)
+    # HeightCompression: dense() [B, C, D, H, W] -> view [B, C*D, H, W]
+    dense = scatter(x, idx, shape)
+    sf = dense.reshape(B, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
+    # loss: coherent quadratic term + a fixed random projection (bf16-representable coefficients)
+    proj = torch.from_numpy(P7.loss_projection(sf.numel())).double().view_as(sf)
+    loss = P7.LOSS_QUAD * 0.5 * (sf * sf).mean() + (sf * proj).sum()
+    loss.backward()
+    return dict(taps=taps, tap_idx=tap_idx, sf=sf, loss=loss, params=params, running=running)
+
+
+def g7():
+    mv = ref_module("pcdet/models/backbones_3d/vfe", "mean_vfe", "refvfe")
+    frames = P7.points(P7.SEED, P7.POINTS_PER_FRAME, P7.BATCH)
+    per = [voxelize_hard_np(p, P7.RANGE, P7.VOXEL, P7.MAX_POINTS, P7.MAX_VOXELS) for p in frames]
+    voxels, coords, nump = O.collate_voxels(per)
+    vfe = mv.MeanVFE(Cfg(), num_point_features=5)
+    feat = vfe({"voxels": torch.from_numpy(voxels), "voxel_num_points": torch.from_numpy(nump).float()}
+               )["voxel_features"].numpy()
+    state = P7.state_dict()
+    out = {"coords": coords, "num_points": nump, "voxel_features": feat,
+           **{f"points{b}": f for b, f in enumerate(frames)}}
+    for tag, emu in (("exact", False), ("bf16", True)):
+        r = _g7_chain(feat, coords, state, emu)
+        for name, t in r["taps"].items():
+            out[f"{tag}_{name}"] = t.detach().float().numpy()
+            if tag == "exact":
+                out[f"idx_{name}"] = r["tap_idx"][name][0]
+                out[f"shape_{name}"] = np.array(r["tap_idx"][name][1], np.int32)
+        out[f"{tag}_spatial_features"] = r["sf"].detach().float().numpy()
+        out[f"{tag}_loss"] = np.array([float(r["loss"])])
+        for k, p in r["params"].items():
+            g = p.grad.float().numpy()
+            out[f"{tag}_grad__{k.replace('.', '__')}"] = P7.grad_sample(g).copy()
+            out[f"{tag}_gnorm__{k.replace('.', '__')}"] = np.array([float(p.grad.norm())])
+        for k, v in r["running"].items():
+            out[f"{tag}_{k.replace('.', '__')}"] = v
+        print(f"g7 {tag}: loss {float(r['loss']):.6f}, rows",
+              {n: int(t.shape[0]) for n, t in r["taps"].items()})
+    save("g7_backbone", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6):
+    for fn in (g1, g2, g3, g4, g5, g6, g7):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
