@@ -74,7 +74,8 @@ def test_g7_oracle_chain_forward_matches_dense_conv3d_chain(golden):
     ref = g["exact_spatial_features"]
     assert sf.shape == ref.shape == (P7.BATCH, 256, 12, 12)
     assert np.linalg.norm(sf - ref) / np.linalg.norm(ref) < 2e-5
-    loss = float((sf.astype(np.float64) * P7.loss_projection(sf.size).reshape(sf.shape)).sum())
+    s64 = sf.astype(np.float64)
+    loss = float(P7.LOSS_QUAD * 0.5 * (s64 * s64).mean() + (s64 * P7.loss_projection(sf.size).reshape(sf.shape)).sum())
     assert abs(loss - float(g["exact_loss"][0])) < 1e-4 * abs(float(g["exact_loss"][0])) + 1e-6
 
 
