@@ -23,11 +23,14 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not touch the GPU; nothing below does before main() decides to spawn)
 import torch.distributed as dist  # noqa: E402
 
-from com_amd import hotpath, ops  # noqa: E402
+from com_amd import hotpath, ops  # noqa: E402   (the HIP library is loaded lazily, on the first op)
+from com_amd import dist as cdist  # noqa: E402
 from com_amd.utils import synth  # noqa: E402
+
+METRIC = "training frames/sec, CenterPoint-VoxelNet Waymo 160k-pt clouds, 1/2/4/8 MI355X"
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
@@ -44,6 +47,13 @@ def parse():
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: replay the captured step (default); eager: one launch per kernel from Python")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the secondary (PCIe-inclusive) timed loop")
+    ap.add_argument("--dump-state", default=None, metavar="PATH",
+                    help="after the timed loop write sha256 of the flat parameters / gradients (rank 0) to PATH")
+    ap.add_argument("--same-shard", action="store_true",
+                    help="validation: every rank processes rank 0's frames (the rank mean then equals one rank's gradient)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU plumbing test of the launcher / result assembly: gloo ranks, no GPU work")
     return ap.parse_args()
 
 
@@ -63,20 +73,30 @@ class HotPath(torch.nn.Module):
         return bd["spatial_features"], bd
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+
+
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_v15_pmc_traffic.json) -- PMC counters cannot be read from
-    inside the timed process, so this is the offline measurement of the same command; None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_v15_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"]
-        return k[kernel]["hbm_bytes_per_launch_corrected"] if kernel in k else None
-    except Exception:
-        return None
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE) -- PMC counters cannot be read from inside the timed
+    process.  Returns (bytes or None, source description incl. the git blob hash of the file that was read)."""
+    import hashlib
+    for rel in (TRAFFIC_FILE, os.path.join("profiles", "r01_v15_pmc_traffic.json")):
+        path = os.path.join(ROOT, rel)
+        try:
+            data = open(path, "rb").read()
+            k = json.loads(data)["kernels"]
+        except Exception:
+            continue
+        blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()[:12]
+        hit = [v for name, v in k.items() if name == kernel or name.startswith(kernel + "<") or name.startswith(kernel + " ")]
+        val = hit[0]["hbm_bytes_per_launch_corrected"] if hit else None
+        return val, f"{rel}@{blob} (offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
+    return None, None
 
 
 def _profiled_groups(step_fn):
-    """One extra step with HIP events around every sparse-conv kernel launch -> per-kernel-group totals."""
+    """One extra step with HIP events around every instrumented launch -> per-kernel-group totals."""
     ops.PROFILE = []
     try:
         step_fn()
@@ -95,35 +115,59 @@ def _profiled_groups(step_fn):
     return groups
 
 
-def measure_roofline(step_fn):
-    """Roofline of the dominant HIP kernel of the step, measured LIVE: one extra training step runs with
-    HIP events (on the launch stream) around every sparse-conv kernel launch (com_amd.ops.PROFILE); launches
-    are grouped by kernel instantiation (the name rocprofv3 reports), the group with the largest total time
-    is the dominant kernel.  achieved = sum of ALGORITHMIC flops (2*P*Cin*Cout) or bytes (SURVEY.md 8d:
-    (N_in*Cin + N_out*Cout)*2 + 8*P + K*Cin*Cout*e) of its launches / sum of their durations.  The bound is
-    "mfma" when the group's arithmetic intensity is above the ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B)."""
-    groups = _profiled_groups(step_fn)
-    if not groups:
-        return None
-    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+RIDGE = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)      # 312 flop/B
+
+
+def _group_roofline(name, g):
     secs = g["ms"] * 1e-3
     ai = g["flops"] / max(g["bytes"], 1)
     tf = g["flops"] / secs / 1e12
     gbs = g["bytes"] / secs / 1e9
-    mfma_bound = ai > MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
-    out = {"bound": "mfma" if mfma_bound else "hbm",
-           "achieved": round(tf if mfma_bound else gbs, 2),
-           "peak": MFMA_BF16_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
-           "unit": "TFLOP/s" if mfma_bound else "GB/s",
-           "frac": round((tf / MFMA_BF16_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
-           "traffic": _pmc_traffic(name),
-           "kernel": name, "launches_per_step": g["launches"],
-           "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
-           "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
-           "algorithmic_flops_per_launch": int(g["flops"] / g["launches"]),
-           "arithmetic_intensity_flop_per_byte": round(ai, 1),
-           "other_frac": {"hbm": round(gbs / HBM_PEAK_GBS, 4), "mfma": round(tf / MFMA_BF16_PEAK_TF, 4)},
-           "all_kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
+    mfma_bound = ai > RIDGE
+    return {"kernel": name, "bound": "mfma" if mfma_bound else "hbm",
+            "achieved": round(tf if mfma_bound else gbs, 2),
+            "peak": MFMA_BF16_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mfma_bound else "GB/s",
+            "frac": round((tf / MFMA_BF16_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
+            "launches_per_step": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+            "ms_per_step": round(g["ms"], 3),
+            "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
+            "algorithmic_flops_per_launch": int(g["flops"] / g["launches"]),
+            "arithmetic_intensity_flop_per_byte": round(ai, 1),
+            "other_frac": {"hbm": round(gbs / HBM_PEAK_GBS, 4), "mfma": round(tf / MFMA_BF16_PEAK_TF, 4)}}
+
+
+def measure_roofline(step_fn, ms_per_step):
+    """Roofline, measured LIVE: one extra training step runs with HIP events (on the launch stream) around every
+    instrumented launch (com_amd.ops.PROFILE); launches are grouped by kernel instantiation (the name rocprofv3
+    reports).  Algorithmic bytes / flops per launch are SURVEY.md 8d's: conv (N_in*Cin + N_out*Cout)*2 + 8*P +
+    K*Cin*Cout*e bytes and 2*P*Cin*Cout flops, rulebook 16*N_in + 8*P (+16*N_out), voxelise 24*N + 36*M,
+    BatchNorm 2..3*N*C*e per pass, BEV N5*(C*e+16) + B*C*D*H*W*e.  The headline object is the group with the
+    largest total time; `kernels` lists every group above 2 % of the instrumented time the same way; `step` is
+    SURVEY 8d's graded figure: the sum of ALL algorithmic bytes / flops of one step over the measured (graph-mode)
+    step time."""
+    groups = _profiled_groups(step_fn)
+    if not groups:
+        return None
+    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "wgrad"))}
+    name, g = max(conv_like.items() or groups.items(), key=lambda kv: kv[1]["ms"])
+    out = _group_roofline(name, g)
+    traffic, source = _pmc_traffic(name)
+    out["traffic"] = traffic
+    out["traffic_source"] = source
+    total_ms = sum(v["ms"] for v in groups.values())
+    out["kernels"] = [_group_roofline(k, v) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+                      if v["ms"] >= 0.02 * total_ms]
+    for kr in out["kernels"]:
+        for drop in ("peak", "unit", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "other_frac"):
+            kr.pop(drop, None)
+    tb, tfl = sum(v["bytes"] for v in groups.values()), sum(v["flops"] for v in groups.values())
+    secs = ms_per_step * 1e-3
+    out["step"] = {"alg_bytes": int(tb), "alg_flops": int(tfl), "ms_per_step": round(ms_per_step, 4),
+                   "hbm_frac": round(tb / secs / 1e9 / HBM_PEAK_GBS, 4),
+                   "mfma_frac": round(tfl / secs / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                   "rulebook_alg_bytes": int(sum(v["bytes"] for k, v in groups.items() if k.startswith("rulebook"))),
+                   "rulebook_ms_eager": round(sum(v["ms"] for k, v in groups.items() if k.startswith("rulebook")), 3)}
     # the same kernel WITHOUT a concurrent weight-gradient kernel on the second stream (in the step the data
     # gradient and the weight gradient of a layer overlap and stretch each other; this is the kernel by itself)
     from com_amd.spconv import functional as Fsp
@@ -134,42 +178,36 @@ def measure_roofline(step_fn):
     finally:
         Fsp.OVERLAP_WGRAD = keep
     if alone and alone["ms"] > 0:
-        tf_a = alone["flops"] / (alone["ms"] * 1e-3) / 1e12
-        gb_a = alone["bytes"] / (alone["ms"] * 1e-3) / 1e9
-        out["isolated"] = {"avg_launch_us": round(1e3 * alone["ms"] / alone["launches"], 2),
-                           "achieved": round(tf_a if mfma_bound else gb_a, 2),
-                           "frac": round((tf_a / MFMA_BF16_PEAK_TF) if mfma_bound else (gb_a / HBM_PEAK_GBS), 4)}
+        iso = _group_roofline(name, alone)
+        out["isolated"] = {"avg_launch_us": iso["avg_launch_us"], "achieved": iso["achieved"], "frac": iso["frac"]}
     return out
 
 
 def measure_cpu_baseline():
-    """CPU baseline ("port"): the C oracle (oracle/pcd_oracle.c, spconv's native gather-GEMM-scatter
-    algorithm, fp32, C compiled -O3 -march=native) on the host's cores, timed on a bounded stratified
-    sample of ONE synthetic frame: voxelisation, every rulebook geometry once, every distinct conv layer
-    type fwd+bwd once (x its multiplicity in VoxelResBackBone8x, spconv_backbone.py:191-232), BN+ReLU via
-    torch-CPU, BEV dense.  Reported as the per-frame total -> frames/s.  The conv arithmetic (95 % of the
-    time) and BN/ReLU run on `cores` threads (OpenMP over the pairs of a kernel offset / torch intra-op);
-    voxelisation, rulebooks and the BEV scatter are sequential algorithms and run on one core.  The
-    single-core total is measured too and quoted in `sample`."""
+    """CPU baseline ("port"): the C oracle (oracle/pcd_oracle.c, spconv's native gather-GEMM-scatter algorithm,
+    fp32, compiled -O3 -march=native) on the host's cores, timed on ONE WHOLE synthetic frame, unsampled: voxelise,
+    MeanVFE, all 9 rulebooks, all 21 convs of VoxelResBackBone8x (spconv_backbone.py:191-232) forward + backward,
+    21 BatchNorm+ReLU fwd+bwd (torch-CPU), BEV dense + its gradient.  value = 1 / median of 3 whole-frame passes.
+    The conv arithmetic and BN run on `cores` threads (OpenMP over the pairs of a kernel offset / torch intra-op);
+    voxelisation, rulebooks and the BEV scatter are sequential algorithms and run on one core.  One single-core
+    pass is timed too (`single_core_value`)."""
     from oracle import oracle as O          # cpu_baseline leg only
-    out = {}
-    for threads in (max(1, min(os.cpu_count() or 1, 64)), 1):
-        out[threads] = _cpu_baseline_once(O, threads)
-        if threads == 1:
-            break
-    mt = max(out)
-    per_frame, parts = out[mt]
-    st_total = out[1][0] if 1 in out else per_frame
+    mt = max(1, min(os.cpu_count() or 1, 64))
+    passes = [_cpu_frame(O, mt) for _ in range(3)]
+    passes.sort(key=lambda t: t[0])
+    per_frame, parts = passes[1]
+    st_total = _cpu_frame(O, 1)[0] if mt > 1 else per_frame
     return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": mt, "kind": "port",
             "host_cores_available": os.cpu_count(), "single_core_value": round(1.0 / st_total, 4),
-            "sample": "1 synthetic 160k-pt frame, fp32 C oracle (spconv native gather-GEMM-scatter): voxelize + "
-                      "9 rulebooks + each distinct VoxelResBackBone8x conv type fwd+bwd once x multiplicity + "
-                      f"BN/ReLU (torch-CPU) + BEV dense; conv and BN on {mt} threads, the rest on 1; "
-                      + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
+            "passes_s": [round(t[0], 3) for t in passes],
+            "sample": "1 whole synthetic 160k-pt frame (unsampled), fp32 C oracle (spconv native gather-GEMM-scatter): "
+                      "voxelize + MeanVFE + 9 rulebooks + all 21 VoxelResBackBone8x convs fwd+bwd + 21 BN/ReLU fwd+bwd "
+                      f"(torch-CPU) + BEV dense fwd+bwd; median of 3 passes; conv and BN on {mt} threads, the rest on "
+                      "1; " + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
                       + f"; all on one core: {st_total:.2f}s per frame"}
 
 
-def _cpu_baseline_once(O, threads):
+def _cpu_frame(O, threads):
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     t_total = {}
@@ -177,56 +215,158 @@ def _cpu_baseline_once(O, threads):
         tiny = {"K": 1, "n_in": 1, "n_out": 1, "pairs": np.zeros((1, 2, 1), np.int32), "pair_num": np.ones((1,), np.int32)}
         O.conv_fwd(np.ones((1, 8), np.float32), np.ones((1, 8, 8), np.float32), None, tiny, threads=threads)
 
-    def timed(name, mult, fn):
+    def timed(name, fn):
         t0 = time.perf_counter()
         r = fn()
-        t_total[name] = t_total.get(name, 0.0) + mult * (time.perf_counter() - t0)
+        t_total[name] = t_total.get(name, 0.0) + (time.perf_counter() - t0)
         return r
 
     pts = synth.synth_cloud(0)
-    v, c, n = timed("voxelize", 1, lambda: O.voxelize_hard(pts, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000))
-    timed("mean_vfe", 1, lambda: O.mean_vfe(v, n))
+    v, c, n = timed("voxelize", lambda: O.voxelize_hard(pts, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000))
+    timed("mean_vfe", lambda: O.mean_vfe(v, n))
     idx = np.pad(c, ((0, 0), (1, 0))).astype(np.int32)
     shape = (41, 1504, 1504)
-    # (level channels, strided-conv geometry leading OUT of the level)
     levels = [(16, dict(k=3, s=2, p=1), 32), (32, dict(k=3, s=2, p=1), 64), (64, dict(k=3, s=2, p=(0, 1, 1)), 128),
               (128, dict(k=(3, 1, 1), s=(2, 1, 1), p=0), 128)]
 
-    def conv_fb(rb, cin, cout, mult, name):
+    def conv_fb(rb, cin, cout):
         x = rng.normal(size=(rb["n_in"], cin)).astype(np.float32)
         w = (rng.normal(size=(rb["K"], cin, cout)) * 0.1).astype(np.float32)
-        y = timed(name, mult, lambda: O.conv_fwd(x, w, None, rb, threads=threads))
-        timed(name, mult, lambda: O.conv_bwd(x, w, y, rb, threads=threads))
+        y = timed("conv", lambda: O.conv_fwd(x, w, None, rb, threads=threads))
+        timed("conv", lambda: O.conv_bwd(x, w, y, rb, threads=threads))
 
-    def bn_relu(nrows, ch, mult):
+    def bn_relu(nrows, ch):
         x = torch.randn(nrows, ch, requires_grad=True)
         bn = torch.nn.BatchNorm1d(ch, eps=1e-3, momentum=0.01)
+
         def f():
-            y = torch.relu(bn(x)); y.sum().backward()
-        timed("bn_relu", mult, f)
+            y = torch.relu(bn(x))
+            y.sum().backward()
+        timed("bn_relu", f)
 
     first = True
     for cl, geo, cnext in levels:
-        rb = timed("rulebook", 2 if first else 1, lambda: O.rulebook_subm(idx, shape))   # subm1 + res1 at level 1
+        rb = timed("rulebook", lambda: O.rulebook_subm(idx, shape))
         if first:
-            conv_fb(rb, 5, 16, 1, "conv")            # conv_input
+            conv_fb(rb, 5, 16)                       # conv_input
+            bn_relu(rb["n_out"], 16)
             first = False
-        conv_fb(rb, cl, cl, 4, "conv")               # 2 SparseBasicBlocks = 4 SubM convs
-        bn_relu(rb["n_out"], cl, 5)
-        rc = timed("rulebook", 1, lambda: O.rulebook_conv(idx, shape, geo["k"], geo["s"], geo["p"]))
-        conv_fb(rc, cl, cnext, 1, "conv")
+        for _ in range(4):                           # 2 SparseBasicBlocks = 4 SubM convs + 4 BatchNorms
+            conv_fb(rb, cl, cl)
+            bn_relu(rb["n_out"], cl)
+        rc = timed("rulebook", lambda: O.rulebook_conv(idx, shape, geo["k"], geo["s"], geo["p"]))
+        conv_fb(rc, cl, cnext)
+        bn_relu(rc["n_out"], cnext)
         idx, shape = rc["out_indices"], tuple(int(s) for s in rc["out_shape"])
-    bn_relu(idx.shape[0], 128, 1)
     feat = rng.normal(size=(idx.shape[0], 128)).astype(np.float32)
-    timed("bev", 2, lambda: O.dense_bev(feat, idx, 1, shape))
+    timed("bev", lambda: O.dense_bev(feat, idx, 1, shape))
+    timed("bev", lambda: O.dense_bev(feat, idx, 1, shape))       # its gradient moves the same bytes
     return sum(t_total.values()), dict(t_total)
+
+
+# ---------------------------------------------------------------------------------------------
+def launch_self(args):
+    """`python bench.py --gpus N` without a launcher: THIS process (which has not touched the GPU) starts N child
+    ranks of the same command line and forwards rank 0's JSON line (children inherit stdout); nothing is exec'ed
+    over a process that initialised HIP.  Non-zero exit if any rank fails."""
+    if not (args.selftest_launch or os.environ.get("PCD_DIST_ONE_GPU")):
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    codes = cdist.launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def selftest_launch(args, rank, world):
+    """CPU plumbing check used by tests/test_distributed_cpu.py: the launcher, the rank environment, the frame
+    sharding, the max-over-ranks timing and the result line, over gloo; no GPU work and no numbers of record."""
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    frames = cdist.shard_frames(0, rank, world, args.batch)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, frames)
+    slowest = cdist.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "selftest": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+                          "allreduce_sum": float(t.item()), "frames": gathered, "slowest": slowest,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class ResidentSource:
+    """Batches resident in HBM before the timed region (the contract's `value`)."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def get(self, j):
+        return self.batches[j % len(self.batches)]
+
+    def release(self, j):
+        pass
+
+
+class H2DSource:
+    """a3 inside the step (dataset.py:252-259 + load_data_to_gpu, pcdet/models/__init__.py:23-34): the collated
+    points of every batch start in PINNED HOST memory and are copied host -> device on a copy stream, two batches
+    ahead, overlapped with the compute of the steps in between; the consumer waits on the batch's event only."""
+
+    def __init__(self, batches, dev):
+        self.host = [(p.cpu().pin_memory(), o.cpu().pin_memory()) for p, o in batches]
+        self.stage = [(torch.empty_like(batches[0][0]), torch.empty_like(batches[0][1])) for _ in range(2)]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.issued = self.taken = 0
+        for _ in range(2):
+            self._issue()
+
+    def _issue(self):
+        k = self.issued
+        self.issued += 1
+        hp, ho = self.host[k % len(self.host)]
+        with torch.cuda.stream(self.stream):
+            self.stage[k % 2][0].copy_(hp, non_blocking=True)       # 15.4 MB host -> device
+            self.stage[k % 2][1].copy_(ho, non_blocking=True)
+            self.ready[k % 2].record(self.stream)
+
+    def get(self, j):
+        """Next batch in sequence (batches alternate; `j` is the consumer's step counter, informational)."""
+        k = self.taken
+        self.taken += 1
+        assert self.issued == k + 2, "one release() per get()"
+        torch.cuda.current_stream().wait_event(self.ready[k % 2])
+        return self.stage[k % 2]
+
+    def release(self, j):
+        """The consumer's reads of the batch just taken have been issued on the current stream: refill its slot."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        self._issue()
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_self(args))             # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)",
+              file=sys.stderr)
+        sys.exit(2)
+    if args.selftest_launch:
+        return selftest_launch(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if os.environ.get("PCD_DIST_ONE_GPU"):                   # validation of the multi-rank control flow on a 1-GPU box
         local_rank = 0
@@ -235,21 +375,23 @@ def main():
     if world > 1:
         backend = os.environ.get("PCD_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm (gloo only for that validation)
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    assert world == args.gpus or world == 1
 
     B = args.batch
-    torch.manual_seed(666 + rank)                            # cf. tools/train.py:86-87
-    # frames sharded by rank (DistributedSampler striding, pcdet/datasets/__init__.py:65-72); two batches
-    # alternate so consecutive steps do not see identical clouds
+    torch.manual_seed(666 + (0 if args.same_shard else rank))   # cf. tools/train.py:86-87
+    # frames sharded by rank with DistributedSampler striding (pcdet/datasets/__init__.py:65-72 ->
+    # com_amd.dist.shard_frames); two global batches alternate so consecutive steps do not see identical clouds
     batches = []
     for j in range(2):
-        first = (j * world + rank) * B
-        frames = [synth.synth_cloud(first + b) for b in range(B)]
+        ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
+        frames = [synth.synth_cloud(f) for f in ids]
         pts, offs = hotpath.collate_points(frames, dev)      # resident in HBM before the timed region
         offs_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
         batches.append((pts, offs_dev))
+    # the static graph reads ONE point buffer: batches are padded to a common row count (offsets say what is real)
+    nmax = max(p.shape[0] for p, _ in batches)
+    batches = [(torch.nn.functional.pad(p, (0, 0, 0, nmax - p.shape[0])) if p.shape[0] < nmax else p, o)
+               for p, o in batches]
 
-    from com_amd import dist as cdist
     from com_amd.spconv import functional as Fsp
     Fsp.WGRAD_JOIN_LAG = int(os.environ.get('PCD_WGRAD_LAG', '1'))   # lagged join of the side-stream wgrad chain
     Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
@@ -263,11 +405,15 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
     bucket = cdist.FlatGradBucket(params)
-    # ... and so do the parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step;
-    # torch.optim.Adam semantics, lr / betas / weight decay of adam_onecycle at its start, centerpoint.yaml:90-96)
+    # ... and so do the parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step_v2) with
+    # the reference's adam_onecycle rule: decoupled weight decay, betas (MOMS, 0.99), lr / momentum from the OneCycle
+    # schedule (tools/train_utils/optimization/__init__.py:19-32,53-56; centerpoint.yaml:81-96), GRAD_NORM_CLIP 10
     flat_param = bucket.flatten_parameters()
-    opt = cdist.FlatAdam(bucket, lr=3e-3 * 0.1, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0,
-                         world=world)
+    total_iters = 30 * 1000                                  # schedule length only shapes lr(it) / mom(it)
+    lr0, mom0 = cdist.one_cycle(0, total_iters)
+    opt = cdist.FlatAdam(bucket, lr=lr0, betas=(mom0, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0,
+                         world=world, decoupled=True)
+    it_count = [0]
     loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
 
     class ProjectionLoss(torch.autograd.Function):
@@ -307,8 +453,10 @@ def main():
         loss = ProjectionLoss.apply(sf)
         if ev is not None: ev("backward")
         bucket.zero()
-        loss.backward()
-        Fsp.join_deferred_wgrad()                            # side-stream wgrad pipeline -> back to this stream
+        try:
+            loss.backward()
+        finally:
+            Fsp.join_deferred_wgrad()                        # side-stream wgrad pipeline -> back to this stream
 
     def fwd_bwd(pts, offs, ev=None):
         if ev is not None: ev("voxelize")
@@ -320,9 +468,17 @@ def main():
     def opt_step():
         opt.step()       # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 3 launches
 
-    def eager_step(i, ev=None):
-        pts, offs = batches[i % 2]
+    def schedule():
+        """lr / momentum of this iteration into the device-side pair the (replayed) optimizer kernel reads."""
+        opt.set_hyper(*cdist.one_cycle(it_count[0], total_iters))
+        it_count[0] += 1
+
+    def eager_step(i, ev=None, source=None):
+        src = source or resident
+        pts, offs = src.get(i)
+        schedule()
         fwd_bwd(pts, offs, ev)
+        src.release(i)
         if ev is not None: ev("allreduce")
         bucket.all_reduce_sum()                              # RCCL over xGMI (no-op at N = 1)
         if ev is not None: ev("optimizer")
@@ -335,84 +491,126 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    resident = ResidentSource(batches)
     use_graph = args.mode == "graph"
     plan = ops.StaticPlan()
     ops.PLAN = plan
     for i in range(max(args.warmup, 2)):                     # eager: also observes the data-dependent row counts
         eager_step(i)
-    if use_graph:
-        # the whole step becomes two hipGraphs (forward+backward | clip+Adam) with the gradient all-reduce in
-        # between; row counts stay on the device, buffers are sized from the observed counts x 1.25
-        try:
-            plan.active = True
-            s_pts, s_offs = batches[0][0].clone(), batches[0][1].clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    fwd_bwd(s_pts, s_offs)
-                    opt_step()
-            torch.cuda.current_stream().wait_stream(side)
+
+    state = {}
+
+    def build_graphs():
+        """Capture the step; returns run_step(i, source).  Called again with larger capacities after an overflow."""
+        plan.active = True
+        plan.prepare(dev)                                    # the sticky flag lives outside the graphs' pools
+        s_pts, s_offs = batches[0][0].clone(), batches[0][1].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd(s_pts, s_offs)
+                opt_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        plan.recorded.clear()
+        # N > 1: two graphs, voxelisation | forward+backward, then the all-reduce and clip+Adam (3 launches).  The
+        # voxelisation of batch i+1 is replayed on a second stream as soon as forward+backward of batch i has
+        # finished, i.e. beside the gradient all-reduce and the optimizer of step i (the reference voxelises in
+        # DataLoader workers, asynchronously to the training step); it owns its memory pool because it runs
+        # concurrently with the optimizer graph.  Every timed step still contains exactly one voxelisation.
+        vox_stream = torch.cuda.Stream()
+        if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH'):   # (the switch exercises the N > 1 form on one GPU)
+            # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
+            # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
+            # first).  Two graph boundaries per step less than the N > 1 form.
+            vox_out = voxelize(s_pts, s_offs)
             torch.cuda.synchronize()
-            plan.recorded.clear()
-            # N > 1: two graphs, voxelisation | forward+backward, then the all-reduce and clip+Adam (3 launches).  The voxelisation of batch i+1 is
-            # replayed on a second stream as soon as forward+backward of batch i has finished, i.e. beside the
-            # gradient all-reduce and the optimizer of step i (the reference voxelises in DataLoader workers,
-            # asynchronously to the training step); it owns its memory pool because it runs concurrently with
-            # the optimizer graph.  Every timed step still contains exactly one voxelisation.
-            vox_stream = torch.cuda.Stream()
-            if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH'):   # (the switch exercises the N > 1 form on one GPU)
-                # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
-                # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
-                # first).  Two graph boundaries per step less than the N > 1 form.
+            g_all = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_all):
+                cur = torch.cuda.current_stream()
+                train_from_voxels(vox_out)
+                vox_stream.wait_stream(cur)
+                with torch.cuda.stream(vox_stream):
+                    vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
+                    assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                opt_step()
+                cur.wait_stream(vox_stream)
+                plan.arm()                                   # sticky overflow check of every replay, inside the graph
+
+            def run_step(i, source=resident):
+                pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
+                schedule()
+                s_pts.copy_(pts, non_blocking=True)          # device -> device
+                s_offs.copy_(offs, non_blocking=True)
+                source.release(i + 1)
+                g_all.replay()
+            state["prime"] = lambda source: None
+        else:
+            g_vox, g_fb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_vox):
                 vox_out = voxelize(s_pts, s_offs)
-                torch.cuda.synchronize()
-                g_all = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_all):
-                    cur = torch.cuda.current_stream()
-                    train_from_voxels(vox_out)
-                    vox_stream.wait_stream(cur)
-                    with torch.cuda.stream(vox_stream):
-                        vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
-                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                    opt_step()
-                    cur.wait_stream(vox_stream)
+            with torch.cuda.graph(g_fb):
+                train_from_voxels(vox_out)
+                plan.arm()
+            ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
 
-                def run_step(i):
-                    pts, offs = batches[(i + 1) % 2]             # the batch this replay voxelises for the next one
-                    s_pts.copy_(pts, non_blocking=True)          # device -> device: the batch is already in HBM
+            def prefetch_voxels(i, source):
+                with torch.cuda.stream(vox_stream):
+                    vox_stream.wait_event(ev_fb)             # the previous forward+backward still reads vox_out
+                    pts, offs = source.get(i)
+                    s_pts.copy_(pts, non_blocking=True)      # device -> device
                     s_offs.copy_(offs, non_blocking=True)
-                    g_all.replay()
-            else:
-                g_vox, g_fb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_vox):
-                    vox_out = voxelize(s_pts, s_offs)
-                with torch.cuda.graph(g_fb):
-                    train_from_voxels(vox_out)
-                ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
+                    source.release(i)
+                    g_vox.replay()
+                    ev_vox.record(vox_stream)
 
-                def prefetch_voxels(i):
-                    pts, offs = batches[i % 2]
-                    with torch.cuda.stream(vox_stream):
-                        vox_stream.wait_event(ev_fb)         # the previous forward+backward still reads vox_out
-                        s_pts.copy_(pts, non_blocking=True)  # device -> device: the batch is already in HBM
-                        s_offs.copy_(offs, non_blocking=True)
-                        g_vox.replay()
-                        ev_vox.record(vox_stream)
+            def run_step(i, source=resident):
+                cur = torch.cuda.current_stream()
+                schedule()
+                cur.wait_event(ev_vox)                       # voxels of batch i
+                g_fb.replay()
+                ev_fb.record(cur)
+                prefetch_voxels(i + 1, source)
+                bucket.all_reduce_sum()
+                opt_step()                                   # three plain launches: cheaper than a graph replay
 
-                def run_step(i):
-                    cur = torch.cuda.current_stream()
-                    cur.wait_event(ev_vox)                   # voxels of batch i
-                    g_fb.replay()
-                    ev_fb.record(cur)
-                    prefetch_voxels(i + 1)
-                    bucket.all_reduce_sum()
-                    opt_step()                               # three plain launches: cheaper than a graph replay
+            def prime(source):
                 ev_fb.record(torch.cuda.current_stream())
-                prefetch_voxels(0)
-            for i in range(2):
-                run_step(i)
-            torch.cuda.synchronize()
+                prefetch_voxels(0, source)
+            state["prime"] = prime
+        return run_step
+
+    def timed_loop(run_step, steps, source, graph):
+        """(elapsed seconds, host-issue seconds) of `steps` steps bracketed by barrier + synchronize."""
+        if graph:
+            state["prime"](source)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run_step(i, source=source)
+            if graph and (i & 7) == 7 and plan.poll():       # sticky device-side flag, read without stalling
+                raise ops.L.PcdError("static capacity overflow during the timed loop")
+        host_issue = time.perf_counter() - t0
+        sync()
+        return time.perf_counter() - t0, host_issue
+
+    run_step = eager_step
+    if use_graph:
+        try:
+            for attempt in range(3):
+                run_step = build_graphs()
+                state["prime"](resident)
+                for i in range(2):
+                    run_step(i)
+                torch.cuda.synchronize()
+                if not plan.poll(wait=True):
+                    break
+                # a batch denser than the observed ones: larger capacities, capture again (the truncated step's
+                # parameters were never used for a measurement)
+                print("[bench] static capacity overflow: re-capturing with larger buffers", file=sys.stderr)
+                plan.active = False
+                plan.grow(1.5)
             plan.check()
         except Exception as exc:                             # never lose the measurement: fall back to eager
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
@@ -420,24 +618,51 @@ def main():
             plan.active = False
             torch.cuda.synchronize()
             run_step = eager_step
-    else:
-        run_step = eager_step
 
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i)
-    host_issue = time.perf_counter() - t0                    # host time to issue all steps (before the sync)
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, host_issue = timed_loop(run_step, args.steps, resident, use_graph)
     if os.environ.get('PCD_BENCH_DEBUG'):
         print(f"[bench] host issue {1e3 * host_issue / max(args.steps, 1):.3f} ms/step, "
               f"wall {1e3 * elapsed / max(args.steps, 1):.3f} ms/step", file=sys.stderr)
+    local_ms = 1e3 * elapsed / max(args.steps, 1)
     elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     fps = world * B * args.steps / elapsed
     if use_graph:
-        plan.check()                                         # no device-side count exceeded its capacity
+        plan.check()                                         # no replay exceeded a capacity (sticky flag + last counts)
+    rank_ms = [local_ms]
+    if world > 1:
+        t = torch.tensor([local_ms], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) for x in allt]
+
+    if args.dump_state and rank == 0:
+        import hashlib
+        torch.cuda.synchronize()
+        with open(args.dump_state, "w") as f:
+            json.dump({"param_sha256": hashlib.sha256(flat_param.data.cpu().numpy().tobytes()).hexdigest(),
+                       "grad_sha256": hashlib.sha256(bucket.flat.cpu().numpy().tobytes()).hexdigest(),
+                       "grad_norm": float(opt.grad_norm.item()), "steps": args.steps, "world": world,
+                       "param_sum": float(flat_param.data.double().sum().item())}, f)
+
+    # secondary figure: the same loop with the points arriving from pinned host memory (a3 inside the step)
+    h2d = None
+    if not args.no_h2d:
+        try:
+            src = H2DSource(batches, dev)
+            el, _ = timed_loop(run_step, args.steps, src, use_graph)
+            el = cdist.max_over_ranks(el, dev)
+            h2d = {"value": round(world * B * args.steps / el, 3), "unit": "frames/s",
+                   "ms_per_step": round(1e3 * el / max(args.steps, 1), 4),
+                   "what": "same timed loop, points of every batch copied from PINNED HOST memory on a copy stream two "
+                           "batches ahead (15.4 MB / step / GPU), overlapped with compute; `value` above is the "
+                           "HBM-resident figure the contract asks for"}
+            if use_graph:
+                plan.check()
+        except Exception as exc:
+            print(f"[bench] H2D-inclusive loop failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            torch.cuda.synchronize()
+    if use_graph:
         plan.active = False                                  # the instrumented steps below run eagerly
 
     if args.stage_times:
@@ -454,21 +679,26 @@ def main():
             print(f"[stage] {n0:10s} gpu {e0.elapsed_time(e1):8.3f} ms   host {1e3 * (h1 - h0):8.3f} ms", file=sys.stderr)
 
     result = {
-        "metric": "training frames/sec, CenterPoint-VoxelNet Waymo 160k-pt clouds, 1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+        "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
         "config": {"workload": "CenterPoint-VoxelNet hot path (hard voxelize+MeanVFE -> VoxelResBackBone8x fwd+bwd -> "
                                "HeightCompression fwd+bwd -> grad all-reduce -> clip -> Adam), Waymo-shaped 160k-pt "
                                "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
                    "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
-                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if world == 1 else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts"
+                   "optimizer": "adam_onecycle (decoupled wd 0.01, betas (OneCycle MOMS, 0.99), clip 10)",
+                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH')) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
                                 if use_graph else "eager launches"},
     }
+    if h2d is not None:
+        result["h2d_inclusive"] = h2d
 
     if not args.no_roofline:
-        roof = measure_roofline(lambda: eager_step(0))   # every rank runs the extra step (collectives inside)
+        roof = measure_roofline(lambda: eager_step(0), ms_per_step)   # every rank runs the extra step (collectives inside)
         if rank == 0:
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

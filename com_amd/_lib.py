@@ -76,6 +76,10 @@ PROTOTYPES = {
     "pcd_adam_flat_step": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _sz,
                                 _vp]),
+    "pcd_adam_flat_step_v2": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
+                                   _vp, _sz, _vp]),
+    "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
     "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _vp, _vp, _sz, _vp]),
     "pcd_bn_backward_colsum_rows": (_i, [_i, _i, _i]),
@@ -104,6 +108,12 @@ class PcdWgradReduceJob(ctypes.Structure):
 
 
 WGRAD_MAX_JOBS = 32
+COUNT_CHECK_MAX = 24
+
+
+class PcdCountCheck(ctypes.Structure):
+    """include/pcd_ops.h: struct PcdCountCheck (static-shape overflow guard)."""
+    _fields_ = [("count", ctypes.c_void_p * COUNT_CHECK_MAX), ("cap", ctypes.c_int32 * COUNT_CHECK_MAX)]
 
 
 class PcdBnReduce(ctypes.Structure):

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
                                                         const double *__restrict__ norm_partial, float max_norm,
                                                         float pre_divisor, const float *__restrict__ step_dev,
                                                         float lr, float beta1, float beta2, float eps, float wd,
-                                                        float *__restrict__ norm_out) {
+                                                        float *__restrict__ norm_out, int decoupled,
+                                                        const float *__restrict__ hyper_dev) {
     __shared__ double total_s;
     if (threadIdx.x < 64) {
         double s = 0.0;
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
     const float coef = fminf(max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f, 1.0f);
     const float gscale = coef / pre_divisor;                                  // g_used = g_sum * gscale
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+    if (hyper_dev) {            // lr / beta1 of THIS step from device memory (a OneCycle schedule driving a replayed graph)
+        lr = hyper_dev[0];
+        beta1 = hyper_dev[1];
+    }
+    const float decay = decoupled ? 1.0f - lr * wd : 1.0f;     // fastai_optim.py:135-150: p *= 1 - wd * lr, then wd = 0
+    const float wd_l2 = decoupled ? 0.0f : wd;
     const float step = step_dev[0] + 1.0f;
     const float bc1 = 1.0f - powf(beta1, step);
     const float bc2 = 1.0f - powf(beta2, step);
@@ -60,7 +67,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
               V[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float gr = G[j] * gscale + wd * P[j];
+            P[j] *= decay;
+            float gr = G[j] * gscale + wd_l2 * P[j];
             M[j] = M[j] + (gr - M[j]) * (1.0f - beta1);
             V[j] = beta2 * V[j] + (1.0f - beta2) * gr * gr;
             float denom = sqrtf(V[j]) / bc2_sqrt + eps;
@@ -74,7 +82,35 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
 
 __global__ void step_inc_kernel(float *step_dev) { step_dev[0] += 1.0f; }
 
+// Sticky capacity-overflow flag of static-shape execution: flag[0] |= 1 (and flag[1] = max over-capacity count
+// seen) when any device-side row count exceeds the capacity its buffers were allocated with.  One thread.
+__global__ void overflow_check_kernel(PcdCountCheck tab, int n, int32_t *flag) {
+    int bad = 0, worst = 0;
+    for (int i = 0; i < n; ++i) {
+        const int v = *tab.count[i];
+        if (v > tab.cap[i]) {
+            bad = 1;
+            worst = max(worst, v - tab.cap[i]);
+        }
+    }
+    if (bad) {
+        flag[0] = 1;
+        if (worst > flag[1]) flag[1] = worst;
+    }
+}
+
 }  // namespace
+
+extern "C" int pcd_static_overflow_check(const PcdCountCheck *table_host, int n, int32_t *flag, void *stream) {
+    PCD_ENTER();
+    if (!table_host || !flag || n < 0 || n > PCD_COUNT_CHECK_MAX) return PCD_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!table_host->count[i]) return PCD_ERR_INVALID_ARG;
+    if (n == 0) return PCD_OK;
+    overflow_check_kernel<<<1, 1, 0, (hipStream_t)stream>>>(*table_host, n, flag);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
 
 extern "C" size_t pcd_adam_flat_workspace_bytes(void) { return ws_piece(NORM_BLOCKS, sizeof(double)); }
 
@@ -82,6 +118,15 @@ extern "C" int pcd_adam_flat_step(float *param, const float *grad, float *exp_av
                                   float lr, float beta1, float beta2, float eps, float weight_decay,
                                   float max_norm, float pre_divisor, float *step_dev, float *norm_out,
                                   void *workspace, size_t workspace_bytes, void *stream) {
+    return pcd_adam_flat_step_v2(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_norm,
+                                 pre_divisor, 0, nullptr, step_dev, norm_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     float max_norm, float pre_divisor, int decoupled_wd, const float *hyper_dev,
+                                     float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
     PCD_ENTER();
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || pre_divisor <= 0.0f) return PCD_ERR_INVALID_ARG;
     if ((n & 3) != 0) return PCD_ERR_UNSUPPORTED;   // the flat buffer is padded to a multiple of 4 by its owner
@@ -98,7 +143,7 @@ extern "C" int pcd_adam_flat_step(float *param, const float *grad, float *exp_av
     if (blocks < 1) blocks = 1;
     adam_flat_kernel<<<blocks, 256, 0, st>>>((float4 *)param, (const float4 *)grad, (float4 *)exp_avg,
                                              (float4 *)exp_avg_sq, n4, partial, max_norm, pre_divisor, step_dev, lr,
-                                             beta1, beta2, eps, weight_decay, norm_out);
+                                             beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev);
     step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

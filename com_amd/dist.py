@@ -90,32 +90,126 @@ class FlatGradBucket:
         return self.flat
 
 
-class FlatAdam:
-    """torch.optim.Adam (L2 weight decay, bias correction) + clip_grad_norm_ on the flat buffers of a
-    FlatGradBucket with flattened parameters, through pcd_adam_flat_step: two passes over the buffers in three
-    launches instead of torch's norm + scalar kernels + scaling pass + multi-tensor Adam.  `step()` expects
-    bucket.flat to hold the SUM of the ranks' gradients (all_reduce_sum) and divides by `world` itself."""
+def one_cycle(step, total_steps, lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+    """(lr, beta1) of training step `step` under the reference's OneCycle schedule
+    (tools/train_utils/optimization/learning_schedules_fastai.py:12-77 with centerpoint.yaml:81-88): cosine from
+    lr_max / div_factor up to lr_max over the first pct_start of the steps while the momentum goes MOMS[0] ->
+    MOMS[1], then cosine down to lr_max / div_factor / 1e4 while the momentum returns."""
+    import math
 
-    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0, world=1):
+    def cos(start, end, pct):
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    a1 = int(total_steps * pct_start)
+    low = lr_max / div_factor
+    if step < a1 or a1 >= total_steps:
+        pct = step / max(a1, 1)
+        return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
+    pct = (step - a1) / max(total_steps - a1, 1)
+    return cos(lr_max, low / 1e4, pct), cos(moms[1], moms[0], pct)
+
+
+class FlatAdam:
+    """clip_grad_norm_ + Adam on the flat buffers of a FlatGradBucket with flattened parameters, through
+    pcd_adam_flat_step_v2: two passes over the buffers in three launches instead of torch's norm + scalar kernels +
+    scaling pass + multi-tensor Adam.  `step()` expects bucket.flat to hold the SUM of the ranks' gradients
+    (all_reduce_sum) and divides by `world` itself.
+
+    decoupled=True (default) is the reference's `adam_onecycle` update (tools/train_utils/optimization/__init__.py:
+    19-32: OptimWrapper(Adam(betas=(0.9, 0.99)), wd, true_wd=True, bn_wd=True); fastai_optim.py:135-150): every
+    parameter -- BatchNorm ones included -- is multiplied by (1 - lr * wd), then Adam runs without a weight-decay
+    term.  decoupled=False is torch.optim.Adam's L2 form.  lr / beta1 live in a device float[2] (`hyper`) so that a
+    OneCycle schedule (`set_hyper(*one_cycle(it, total))`, MOMS start at 0.95) can drive a replayed hipGraph."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0, world=1,
+                 decoupled=True):
         assert getattr(bucket, "flat_param", None) is not None, "call bucket.flatten_parameters() first"
         from . import _lib as L
         self.L, self.bucket = L, bucket
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
-        self.max_norm, self.world = float(max_norm), float(world)
+        self.max_norm, self.world, self.decoupled = float(max_norm), float(world), bool(decoupled)
         p = bucket.flat_param.data
         self.exp_avg = torch.zeros_like(p)
         self.exp_avg_sq = torch.zeros_like(p)
         self.step_dev = torch.zeros((1,), dtype=torch.float32, device=p.device)
         self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=p.device)
+        self.hyper = torch.tensor([self.lr, self.betas[0]], dtype=torch.float32, device=p.device)
+        # pinned staging RING for set_hyper: the host runs ahead of the device when steps are graph replays, so a
+        # staging slot must not be rewritten before its async copy has executed (slot events guard the reuse)
+        self._hyper_host = torch.zeros((64, 2), dtype=torch.float32)
+        if p.is_cuda:
+            self._hyper_host = self._hyper_host.pin_memory()
+        self._hyper_ev = [None] * 64
+        self._hyper_i = 0
         self.ws = torch.empty((max(int(L.lib().pcd_adam_flat_workspace_bytes()), 256),), dtype=torch.uint8, device=p.device)
+
+    def set_hyper(self, lr, beta1):
+        """lr / beta1 of the NEXT step(s) (async H2D of 8 bytes on the current stream; capturable graphs read the
+        device copy)."""
+        self.lr, self.betas = float(lr), (float(beta1), self.betas[1])
+        i = self._hyper_i
+        self._hyper_i = (i + 1) % len(self._hyper_ev)
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()            # only blocks when the host is 64 steps ahead
+        self._hyper_host[i, 0], self._hyper_host[i, 1] = self.lr, self.betas[0]
+        self.hyper.copy_(self._hyper_host[i], non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_ev[i] = ev
 
     def step(self):
         L, b = self.L, self.bucket
         p = b.flat_param.data
-        L.check(L.lib().pcd_adam_flat_step(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                           p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                           self.max_norm, self.world, L.ptr(self.step_dev), L.ptr(self.grad_norm),
-                                           L.ptr(self.ws), self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step")
+        L.check(L.lib().pcd_adam_flat_step_v2(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                              p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                              self.max_norm, self.world, int(self.decoupled), L.ptr(self.hyper),
+                                              L.ptr(self.step_dev), L.ptr(self.grad_norm), L.ptr(self.ws),
+                                              self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v2")
+
+
+def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):
+    """Start `n` ranks of `argv` (a python command line) on THIS node, one process per GPU, the way
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would (tools/scripts/dist_train.sh:18): RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment.  The caller must NOT have
+    touched the GPU (children are new processes, nothing is exec'ed over this one).  Rank 0 inherits stdout; the
+    other ranks' stdout goes to stderr.  Returns the list of exit codes; if a rank fails the others are terminated."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    if master_port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            master_port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(master_port)})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+    t0 = time.time()
+    codes = [None] * n
+    try:
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes) or (timeout is not None and time.time() - t0 > timeout):
+                break
+            time.sleep(0.05)
+    finally:
+        for i, p in enumerate(procs):                 # a failed / timed-out job: stop exactly the PIDs started here
+            if codes[i] is None:
+                p.terminate()
+                try:
+                    codes[i] = p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[i] = p.wait()
+                codes[i] = codes[i] if codes[i] not in (None, 0) else -15
+    return codes
 
 
 def max_over_ranks(value, device="cpu"):

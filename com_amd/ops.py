@@ -69,13 +69,21 @@ class StaticPlan:
     OBSERVED during a few eager steps; afterwards (`active = True`) every buffer is allocated at
     capacity = observed maximum x margin, the real counts stay in device memory (`n_dev` arguments of the
     C ABI) and nothing is read back to the host, so the whole step can be captured in one hipGraph.
-    `check()` (one sync, outside the timed region) verifies that no count exceeded its capacity."""
+    Overflow guard: the kernels clamp to the capacities, so a batch denser than anything observed would be
+    truncated silently.  `arm()` (call it at the END of the step, inside the capture) enqueues a one-thread kernel
+    that compares every recorded device-side count with its capacity and raises a STICKY device flag; it is part
+    of the graph, so EVERY replay is checked.  `poll()` reads the flag without stalling the stream (pinned host
+    copy + event; call it every few steps and before trusting the parameters), `check()` is the synchronous
+    form.  On overflow the caller re-observes (`grow()`), re-captures and repeats the step (bench.py does)."""
 
     def __init__(self, margin=1.25, round_to=1024):
         self.margin, self.round_to = margin, round_to
         self.caps = {}
         self.active = False
         self.recorded = []          # (key, n_dev tensor, capacity) of the captured step
+        self.flag = None            # device int32[2]: {sticky overflow bit, worst excess}
+        self._host_flag = None
+        self._poll_event = None
 
     def observe(self, key, n):
         self.caps[key] = max(self.caps.get(key, 0), int(n))
@@ -89,8 +97,69 @@ class StaticPlan:
     def record(self, key, n_dev, cap):
         self.recorded.append((key, n_dev, cap))
 
+    def prepare(self, device):
+        """Allocate the sticky flag (call BEFORE capturing: it must not live in a graph's private pool)."""
+        import torch
+        if self.flag is None:
+            self.flag = torch.zeros((2,), dtype=torch.int32, device=device)
+            torch.cuda.current_stream().synchronize()
+
+    def arm(self):
+        """Enqueue the overflow check of every recorded count on the current stream (capturable)."""
+        import torch
+        if not self.recorded:
+            return
+        if self.flag is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.PcdError("StaticPlan.arm() inside a capture needs StaticPlan.prepare(device) before it")
+            self.prepare(self.recorded[0][1].device)
+        for i in range(0, len(self.recorded), L.COUNT_CHECK_MAX):
+            chunk = self.recorded[i:i + L.COUNT_CHECK_MAX]
+            tab = L.PcdCountCheck()
+            for j, (_, n_dev, cap) in enumerate(chunk):
+                last = n_dev.reshape(-1)[-1:]
+                tab.count[j] = last.data_ptr()
+                tab.cap[j] = int(cap)
+            import ctypes
+            L.check(L.lib().pcd_static_overflow_check(ctypes.cast(ctypes.pointer(tab), ctypes.c_void_p), len(chunk),
+                                                      L.ptr(self.flag), L.stream_ptr()), "pcd_static_overflow_check")
+
+    def poll(self, wait=False):
+        """Non-blocking overflow poll: returns True (overflow seen), False (clean) or None (no result yet).  The
+        first call starts an async copy of the flag to pinned host memory; later calls read it once it landed."""
+        import torch
+        if self.flag is None:
+            return False
+        if self._poll_event is None:
+            if self._host_flag is None:
+                self._host_flag = torch.zeros((2,), dtype=torch.int32).pin_memory()
+            self._host_flag.copy_(self.flag, non_blocking=True)
+            self._poll_event = torch.cuda.Event()
+            self._poll_event.record()
+            if not wait:
+                return None
+        if wait:
+            self._poll_event.synchronize()
+        elif not self._poll_event.query():
+            return None
+        self._poll_event = None
+        return bool(int(self._host_flag[0]) != 0)
+
+    def grow(self, factor=1.5):
+        """After an overflow: raise every observed count by `factor` (the next capture allocates larger buffers) and
+        clear the sticky flag."""
+        for k in self.caps:
+            self.caps[k] = int(self.caps[k] * factor) + 1
+        if self.flag is not None:
+            self.flag.zero_()
+        self._poll_event = None
+
     def check(self):
-        """Raise if any device-side count of the last replay exceeded its capacity."""
+        """Synchronous: raise if any device-side count of ANY replay since arm() (sticky flag) or of the last one
+        (direct read) exceeded its capacity."""
+        if self.flag is not None and int(self.flag[0].item()) != 0:
+            raise L.PcdError(f"static capacity overflow (sticky flag): a replay exceeded a capacity by up to "
+                             f"{int(self.flag[1].item())} rows; re-observe and re-capture")
         for key, n_dev, cap in self.recorded:
             n = int(n_dev.reshape(-1)[-1].item())
             if n > cap:
@@ -151,11 +220,16 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     mean = buf("voxel_features", (cap, C), torch.float32, want_mean)
     mean16 = buf("voxel_features_bf16", (cap, mean_bf16_stride), torch.bfloat16, bool(mean_bf16_stride))
     counts = buf("counts", (batch + 1,), torch.int32)
-    L.check(lib.pcd_voxelize_hard(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
-                                  L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
-                                  max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
-                                  L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
-                                  L.stream_ptr()), "pcd_voxelize_hard")
+    def meta():                                  # 24 N read + 36 M written (fused form; +104 M for voxels)
+        m_ = int(counts[batch].item())
+        return dict(bytes=24 * n + 36 * m_ + (104 * m_ if want_voxels else 0), flops=0, rows=m_, pairs=0)
+
+    with _Timed("voxelize_hard", meta):
+        L.check(lib.pcd_voxelize_hard(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
+                                      L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
+                                      max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
+                                      L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
+                                      L.stream_ptr()), "pcd_voxelize_hard")
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]
@@ -332,17 +406,23 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     nbr = torch.empty((K, n), dtype=torch.int32, device=dev)
     pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
+    def meta():                                  # read 16 N_in, write 8 P
+        p_ = int((nbr >= 0).sum().item())
+        return dict(bytes=16 * n + 8 * p_, flops=0, rows=n, pairs=p_)
+
     if rank is not None and rank.matches(indices, shp, ks):
         ws = _ws(lib.pcd_rulebook_subm_ranked_workspace_bytes(n, K), dev)
-        L.check(lib.pcd_rulebook_subm_ranked(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
-                                             L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
-                                             L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
-                                             L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
+        with _Timed("rulebook_subm_ranked", meta):
+            L.check(lib.pcd_rulebook_subm_ranked(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                                                 L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
+                                                 L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
+                                                 L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
     else:
         ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
-        L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
-                                      L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
-                                      L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
+        with _Timed("rulebook_subm", meta):
+            L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                                          L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
+                                          L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
     return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
                     [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
 
@@ -364,8 +444,9 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
         raise L.PcdError("pcd_rulebook_conv: bad geometry or key space too large")
     ws = _ws(wsb, dev)
     n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-    L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
-                                        L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+    with _Timed("rulebook_conv_count", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
+        L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
+                                            L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
     static = PLAN is not None and PLAN.active
     if static:
         n_out = PLAN.cap(plan_key)         # capacity; the real count stays in n_out_dev (no host sync)
@@ -379,10 +460,15 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
     pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
-    L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
-                                       L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
-                                       int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
-            "pcd_rulebook_conv_fill")
+    def meta():                                  # read 16 N_in, write 8 P + 16 N_out
+        p_ = int((nbr_in >= 0).sum().item())
+        return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
+
+    with _Timed("rulebook_conv_fill", meta):
+        L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
+                                           L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
+                                           int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "pcd_rulebook_conv_fill")
     rb = Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
                   pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
     # the build's bitmap + prefix stay valid as long as `ws` lives: a SubM conv on out_indices can rank with them
@@ -400,9 +486,10 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
         perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
         vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
         cws = _ws(lib.pcd_rulebook_conv_classes_workspace_bytes(n), dev)
-        L.check(lib.pcd_rulebook_conv_classes(L.ptr(indices), n, L.host_i32(st), L.host_i32(pd), CLS_TILE, L.ptr(perm),
-                                              vcap, L.ptr(vstart), L.ptr(n_dev), L.ptr(cws), cws.numel(),
-                                              L.stream_ptr()), "pcd_rulebook_conv_classes")
+        with _Timed("rulebook_conv_classes", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
+            L.check(lib.pcd_rulebook_conv_classes(L.ptr(indices), n, L.host_i32(st), L.host_i32(pd), CLS_TILE,
+                                                  L.ptr(perm), vcap, L.ptr(vstart), L.ptr(n_dev), L.ptr(cws),
+                                                  cws.numel(), L.stream_ptr()), "pcd_rulebook_conv_classes")
         rb.classes = (perm, vstart, vcap)
     return rb
 
@@ -661,9 +748,11 @@ def bev_scatter(features, indices, batch_size, spatial_shape, channels=None, n_d
     lib = L.lib()
     out = torch.empty((batch_size, C * D, H, W), dtype=features.dtype, device=features.device)
     ws = _ws(lib.pcd_bev_workspace_bytes(batch_size, D, H, W), features.device)
-    L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, L.ptr(n_dev),
-                                batch_size, D, H, W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
-            "pcd_bev_scatter")
+    e = features.element_size()                  # read N5 (C e + 16), write B C D H W e
+    with _Timed("bev_scatter", lambda: dict(bytes=n * (C * e + 16) + out.numel() * e, flops=0, rows=n, pairs=0)):
+        L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, L.ptr(n_dev),
+                                    batch_size, D, H, W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "pcd_bev_scatter")
     return out
 
 
@@ -677,9 +766,11 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
         df = torch.zeros((n, cs), dtype=dout.dtype, device=dout.device)
     else:
         df = torch.empty((n, cs), dtype=dout.dtype, device=dout.device)
-    L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n,
-                                   L.ptr(n_dev), batch_size, D, H, W, L.ptr(df), L.stream_ptr()),
-            "pcd_bev_gather")
+    e = dout.element_size()
+    with _Timed("bev_gather", lambda: dict(bytes=n * (2 * channels * e + 16), flops=0, rows=n, pairs=0)):
+        L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n,
+                                       L.ptr(n_dev), batch_size, D, H, W, L.ptr(df), L.stream_ptr()),
+                "pcd_bev_gather")
     return df
 
 
@@ -698,12 +789,15 @@ def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, 
     save_mean = torch.empty((c,), dtype=torch.float32, device=dev)
     save_invstd = torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
-    L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
-                               float(eps), float(momentum), int(training), L.ptr(running_mean),
-                               L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
-                               L.ptr(n_dev), L.ptr(partials[0]) if partials else None,
-                               partials[1] if partials else 0, L.ptr(ws), ws.numel(), L.stream_ptr()),
-            "pcd_bn_forward")
+    e = x.element_size()                         # 2 N C e (3 with residual) per pass
+    with _Timed("bn_forward", lambda: dict(bytes=(3 if residual is not None else 2) * n * c * e, flops=0, rows=n,
+                                           pairs=0)):
+        L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
+                                   float(eps), float(momentum), int(training), L.ptr(running_mean),
+                                   L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
+                                   L.ptr(n_dev), L.ptr(partials[0]) if partials else None,
+                                   partials[1] if partials else 0, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "pcd_bn_forward")
     return y, save_mean, save_invstd
 
 
@@ -729,11 +823,14 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     if colsum:
         crows = _tiles(lib.pcd_bn_backward_colsum_rows(_dtype_code(x), n, c), "pcd_bn_backward_colsum_rows")
         cpart = torch.empty((max(crows, 1), c), dtype=torch.float32, device=dev)
-    L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
-                                L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
-                                L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
-                                L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
-                                L.ptr(cpart), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
+    e = x.element_size()                         # reads dy, x (, y), writes dx (, dres)
+    with _Timed("bn_backward", lambda: dict(bytes=(3 + (y is not None) + bool(want_dres)) * n * c * e, flops=0,
+                                            rows=n, pairs=0)):
+        L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
+                                    L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
+                                    L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
+                                    L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
+                                    L.ptr(cpart), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
     if colsum:
         return dx, dres, dgamma, dbeta, (cpart, crows)
     return dx, dres, dgamma, dbeta

@@ -368,6 +368,30 @@ size_t pcd_adam_flat_workspace_bytes(void);
 int pcd_adam_flat_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
                        float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes, void *stream);
+/* v2: decoupled_wd != 0 gives the reference's adam_onecycle rule -- OptimWrapper(true_wd=True, bn_wd=True),
+ * tools/train_utils/optimization/__init__.py:19-32 + fastai_optim.py:135-150: every parameter is first multiplied
+ * by (1 - lr * weight_decay), then Adam runs WITHOUT a weight-decay term; decoupled_wd == 0 is torch.optim.Adam's L2
+ * form (v1).  hyper_dev (may be NULL): device float[2] = {lr, beta1} of THIS step, overriding the host arguments, so a
+ * OneCycle schedule (learning_schedules_fastai.py:60-77: lr and MOMS vary every step) can drive a replayed hipGraph;
+ * the bias correction uses the current beta1 like torch.optim.Adam does. */
+int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
+                          int decoupled_wd, const float *hyper_dev, float *step_dev, float *norm_out, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
+ * Static-shape execution guard.  Buffers of a captured step are allocated at CAPACITIES (see "Device-side row
+ * counts" above) and the kernels clamp to them, so a batch denser than the capacity would be truncated silently.
+ * pcd_static_overflow_check enqueues a one-thread kernel that compares up to PCD_COUNT_CHECK_MAX device-side counts
+ * with their capacities: flag[0] |= 1 (sticky) and flag[1] = max(flag[1], count - capacity) on overflow.  The
+ * table is passed by value (host struct); flag is a device int32[2] the caller zeroes once and polls.
+ * ============================================================================================ */
+#define PCD_COUNT_CHECK_MAX 24
+typedef struct PcdCountCheck {
+    const int32_t *count[PCD_COUNT_CHECK_MAX];   /* device pointers to the counts */
+    int32_t cap[PCD_COUNT_CHECK_MAX];            /* capacities                      */
+} PcdCountCheck;
+int pcd_static_overflow_check(const PcdCountCheck *table_host, int n, int32_t *flag, void *stream);
 
 #ifdef __cplusplus
 }

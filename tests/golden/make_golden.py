@@ -19,7 +19,7 @@ installed here.  So the fixtures come from the two independent sources that ARE 
 Nothing from /root/reference is copied: only inputs and outputs (data) are stored.  The CPU
 oracle (oracle/) is then checked against these files by tests/test_oracle_golden.py.
 
-Usage:  python tests/golden/make_golden.py [g1 .. g7]   (needs /root/reference; not needed at test time;
+Usage:  python tests/golden/make_golden.py [g1 .. g8]   (needs /root/reference; not needed at test time;
         with names only those fixtures are regenerated)
 """
 import hashlib
@@ -508,13 +508,54 @@ def g7():
     save("g7_backbone", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G8: the reference's OWN optimizer code -- OptimWrapper(Adam(betas=(0.9, 0.99)), wd, true_wd=True, bn_wd=True) driven
+# by OneCycle (tools/train_utils/optimization/{__init__.py:19-32,fastai_optim.py,learning_schedules_fastai.py}) in the
+# order of tools/train_utils/train_utils.py:78-95 (scheduler.step(it); backward; clip_grad_norm_(10); step) on a small
+# model with a BatchNorm layer: the parameter trajectory and the (lr, momentum) schedule, for com_amd.dist.FlatAdam /
+# one_cycle.
+def g8():
+    from functools import partial
+    fo = ref_module("tools/train_utils/optimization", "fastai_optim", "refopt")
+    ls = ref_module("tools/train_utils/optimization", "learning_schedules_fastai", "refopt")
+    torch.manual_seed(21)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    params = [p for p in model.parameters()]
+    opt = fo.OptimWrapper.create(partial(torch.optim.Adam, betas=(0.9, 0.99)), 3e-3,
+                                 [torch.nn.Sequential(*list(model.children()))], wd=0.01, true_wd=True, bn_wd=True)
+    total = 20
+    sched = ls.OneCycle(opt, total, 0.003, [0.95, 0.85], 10, 0.4)
+    rng = np.random.default_rng(8)
+    flat = lambda: torch.cat([p.detach().reshape(-1) for p in params]).numpy().copy()
+    p0 = flat()
+    n = p0.size
+    grads, traj, lrs, moms = [], [], [], []
+    for it in range(total):
+        sched.step(it)
+        lrs.append(float(opt.lr))
+        moms.append(float(opt.mom))
+        if it < 8:
+            # every other step a gradient large enough for GRAD_NORM_CLIP = 10 to bind
+            g = (rng.normal(size=n) * (6.0 if it % 2 else 0.05)).astype(np.float32)
+            off = 0
+            for p in params:
+                p.grad = torch.from_numpy(g[off:off + p.numel()].copy()).view_as(p)
+                off += p.numel()
+            torch.nn.utils.clip_grad_norm_(params, 10.0)
+            opt.step()
+            grads.append(g)
+            traj.append(flat())
+    save("g8_adam_onecycle", p0=p0, grads=np.stack(grads), params=np.stack(traj), lr=np.array(lrs), mom=np.array(moms),
+         total_steps=np.array([total]))
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:

@@ -1,0 +1,51 @@
+"""GPU: bench.py's execution forms must be the same computation.
+
+  * the N = 1 form (ONE hipGraph per step) and the N > 1 form run on one GPU (PCD_FORCE_3GRAPH=1: voxelise-graph |
+    forward+backward-graph, all-reduce, clip+Adam as plain launches) must leave BIT-IDENTICAL parameters and gradients
+    after the same steps on the same data;
+  * two ranks (PCD_DIST_ONE_GPU=1, gloo, both on cuda:0; bench.py starts them itself from `--gpus 2`) that both
+    process rank 0's frames (--same-shard) sum two identical gradients and divide by the world size -- exact in
+    binary floating point -- so they too must end bit-identical to the one-rank run: this exercises the launcher,
+    the broadcast of rank 0's parameters, the flat-bucket all-reduce and the rank mean inside the fused Adam.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(tmp_path, tag, args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCD_FORCE_3GRAPH", "PCD_DIST_ONE_GPU",
+              "PCD_DIST_BACKEND"):
+        e.pop(k, None)
+    e.update(env or {})
+    dump = tmp_path / f"{tag}.json"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "2",
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--same-shard", "--dump-state", str(dump)] + args
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert "running eagerly" not in r.stderr, r.stderr[-2000:]      # the graph forms really were captured
+    return json.loads(line), json.load(open(dump))
+
+
+@pytest.mark.timeout(1800)
+def test_one_graph_three_graph_and_two_rank_forms_are_bit_identical(tmp_path):
+    res1, st1 = _bench(tmp_path, "one_graph", ["--gpus", "1"])
+    res3, st3 = _bench(tmp_path, "three_graph", ["--gpus", "1"], env={"PCD_FORCE_3GRAPH": "1"})
+    assert res1["n_gpus"] == res3["n_gpus"] == 1
+    assert "one graph" in res1["config"]["execution"] and "voxelise [prefetched" in res3["config"]["execution"]
+    assert st1["param_sha256"] == st3["param_sha256"], (st1, st3)
+    assert st1["grad_sha256"] == st3["grad_sha256"]
+    res2, st2 = _bench(tmp_path, "two_ranks", ["--gpus", "2"], env={"PCD_DIST_ONE_GPU": "1", "PCD_DIST_BACKEND": "gloo"})
+    assert res2["n_gpus"] == 2 and res2["rccl_ranks"] == 2 and len(res2["ms_per_step_ranks"]) == 2
+    assert res2["config"]["global_batch"] == 4 and res2["config"]["parallelism"] == "dp2"
+    assert st2["world"] == 2
+    # bucket.flat holds the rank SUM at N = 2: compare the parameters (which used sum / world) bit for bit
+    assert st2["param_sha256"] == st1["param_sha256"], (st1, st2)

@@ -578,7 +578,7 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         bucket = cdist.FlatGradBucket(mine)
         bucket.flatten_parameters()
         fa = cdist.FlatAdam(bucket, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_norm=max_norm,
-                            world=world)
+                            world=world, decoupled=False)
         for step in range(4):
             grads = [torch.randn(*sh, device=DEV) * (3.0 if step % 2 else 0.05) for sh in shapes]
             for p, g in zip(ref, grads):
@@ -595,6 +595,42 @@ def test_flat_adam_matches_torch_adam_with_clipping():
         assert float(fa.step_dev[0]) == 4.0
         for p, q in zip(ref, mine):
             torch.testing.assert_close(q.detach(), p.detach(), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_flat_adam_decoupled_matches_reference_optimwrapper_trajectory(golden):
+    """Fixture G8 = the reference's OWN optimizer code (OptimWrapper(true_wd=True, bn_wd=True) over Adam(betas=(mom,
+    0.99)) driven by OneCycle, fastai_optim.py:135-150 + learning_schedules_fastai.py:60-77, clip 10) run on a small
+    model for 8 steps: FlatAdam(decoupled=True) + one_cycle must follow the same parameter trajectory -- eagerly and
+    replayed from ONE captured hipGraph whose lr / momentum come from device memory.  fp32, 2e-6 relative."""
+    from com_amd import dist as cdist
+    g = golden("g8_adam_onecycle")
+    total = int(g["total_steps"][0])
+    for graphed in (False, True):
+        p = torch.nn.Parameter(torch.from_numpy(np.pad(g["p0"], (0, (-g["p0"].size) % 4))).to(DEV))
+        bucket = cdist.FlatGradBucket([p])
+        bucket.flatten_parameters()
+        fa = cdist.FlatAdam(bucket, lr=1.0, betas=(0.5, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0, world=1,
+                            decoupled=True)                        # lr / beta1 on the host are overridden by set_hyper
+        graph = None
+        n = g["p0"].size
+        for it in range(g["grads"].shape[0]):
+            fa.set_hyper(*cdist.one_cycle(it, total))
+            bucket.flat[:n].copy_(torch.from_numpy(g["grads"][it]).to(DEV))
+            if not graphed:
+                fa.step()
+            else:
+                if graph is None:
+                    torch.cuda.synchronize()
+                    snap = [t.clone() for t in (bucket.flat_param.data, fa.exp_avg, fa.exp_avg_sq, fa.step_dev)]
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        fa.step()
+                    for t, s0 in zip((bucket.flat_param.data, fa.exp_avg, fa.exp_avg_sq, fa.step_dev), snap):
+                        t.copy_(s0)                                # capture does not execute; be explicit anyway
+                graph.replay()
+            got = bucket.flat_param.data[:n].cpu().numpy()
+            np.testing.assert_allclose(got, g["params"][it], rtol=2e-6, atol=2e-7, err_msg=f"step {it} graphed={graphed}")
 
 
 def test_pack_weights_batched_matches_single():
