@@ -455,8 +455,10 @@ def main():
         bucket.zero()
         try:
             loss.backward()
-        finally:
-            Fsp.join_deferred_wgrad()                        # side-stream wgrad pipeline -> back to this stream
+        except BaseException:
+            Fsp.reset_deferred()                             # stale jobs hold pointers of the aborted step
+            raise
+        Fsp.join_deferred_wgrad()                            # side-stream wgrad pipeline -> back to this stream
 
     def fwd_bwd(pts, offs, ev=None):
         if ev is not None: ev("voxelize")

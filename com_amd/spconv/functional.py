@@ -31,11 +31,34 @@ _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not 
 
 _COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
 _WGRAD_JOBS = []    # [(slab, dW, kvol, cin, cout, pmax)] of deferred slab reductions: one launch at the join
+_DIRECT_WRITTEN = set()   # ids of the parameters whose .grad a kernel has OVERWRITTEN since the last join (DIRECT_GRAD)
+
+
+def reset_deferred():
+    """Drop every pending job of the current step WITHOUT running it (call it when loss.backward() raised: the jobs
+    hold raw pointers into tensors of the aborted step).  join_deferred_wgrad() is the normal end of a step."""
+    _COLSUM_JOBS.clear()
+    _WGRAD_JOBS.clear()
+    _PENDING.clear()
+    _DIRECT_WRITTEN.clear()
+
+
+def _claim_direct(param, what):
+    """DIRECT_GRAD kernels overwrite `.grad`: a second contribution to the same parameter inside one step (a conv
+    module used twice, gradient accumulation over micro-batches without a join in between) would silently replace
+    the first one -- refuse it."""
+    key = (id(param), what)
+    if key in _DIRECT_WRITTEN:
+        raise RuntimeError("DIRECT_GRAD: a second gradient contribution for the same parameter arrived before "
+                           "join_deferred_wgrad(); direct writes overwrite .grad -- disable DIRECT_GRAD for shared "
+                           "modules / micro-batch accumulation")
+    _DIRECT_WRITTEN.add(key)
 
 
 def join_deferred_wgrad():
     """Make the current stream wait for every side-stream weight-gradient kernel issued so far (and finish the
-    deferred bias gradients with one launch on that stream)."""
+    deferred bias gradients with one launch on that stream).  Ends the step for the DIRECT_GRAD bookkeeping."""
+    _DIRECT_WRITTEN.clear()
     if _COLSUM_JOBS or _WGRAD_JOBS:
         side = _side_stream((_COLSUM_JOBS or _WGRAD_JOBS)[0][0].device)
         with torch.cuda.stream(side):
@@ -192,6 +215,10 @@ class SparseConvFunction(Function):
             and weight_p.grad.dtype == torch.float32 and weight_p.grad.is_contiguous()
         direct_b = DIRECT_GRAD and bias_p is not None and bias_p.grad is not None \
             and bias_p.grad.dtype == torch.float32 and bias_p.grad.is_contiguous()
+        if direct_w and ctx.needs_input_grad[1]:
+            _claim_direct(weight_p, "w")
+        if direct_b and ctx.has_bias and ctx.needs_input_grad[2]:
+            _claim_direct(bias_p, "b")
         keep_partial = None
         deferred = (WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not ctx.needs_input_grad[1])
                     and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))

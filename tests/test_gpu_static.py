@@ -182,8 +182,23 @@ def test_direct_gradient_writes_match_autograd_accumulation():
                                                 bf16_features=True)
         sf = bev(net(bd))["spatial_features"]
         torch.sum(sf.reshape(-1) * w, dtype=torch.float32).backward()
+        Fsp.join_deferred_wgrad()                      # end of the step
+        torch.cuda.synchronize()
+        for (n, p), g in zip(net.named_parameters(), ref):
+            assert torch.equal(p.grad, g), n
+        # direct writes OVERWRITE .grad: a second contribution to the same parameters before the step was ended
+        # (gradient accumulation over micro-batches, a module used twice) must be refused, not silently lose the first
+        for b, s in zip(net.buffers(), bn0):
+            b.copy_(s)
+        bd = {"points": pts, "frame_offsets": offs, "batch_size": 2}
+        bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000,
+                                                bf16_features=True)
+        sf1 = bev(net(dict(bd)))["spatial_features"]
+        sf2 = bev(net(dict(bd)))["spatial_features"]
+        with pytest.raises(RuntimeError, match="second gradient contribution"):
+            (torch.sum(sf1.float()) + torch.sum(sf2.float())).backward()
+        Fsp.reset_deferred()
         torch.cuda.synchronize()
     finally:
         Fsp.DIRECT_GRAD = False
-    for (n, p), g in zip(net.named_parameters(), ref):
-        assert torch.equal(p.grad, g), n
+        Fsp.reset_deferred()
