@@ -135,6 +135,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Tile of workgroup blockIdx.x when the REAL row tiles (ceil(n / rows_per_tile), n known on the device only) are dealt
+// to the 8 XCDs in contiguous runs; gridDim.x (a multiple of 8, sized from the capacity) may exceed them.  A bijection
+// of [0, gridDim.x): blocks beyond an XCD's share map to the tile ids past the live range (they own no rows; their
+// BatchNorm partial row is zeroed like any empty tile's).
+__device__ __forceinline__ int xcd_tile(int n, int rows_per_tile) {
+    const int nt = (n + rows_per_tile - 1) / rows_per_tile;
+    const int tpx = min((nt + 7) >> 3, (int)(gridDim.x >> 3));
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    return j < tpx ? xcd * tpx + j : 8 * tpx + (j - tpx) * 8 + xcd;
+}
+
 __device__ __forceinline__ void bnred_zero_row(const BnRed &bn, int tile, int c_out) {
     for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) bn.partial[(size_t)tile * 2 * c_out + e] = 0.0f;
 }
@@ -153,7 +164,8 @@ template <int MI, int NBW, bool OUT_BF16>
 __device__ __forceinline__ void gg_epilogue(const f32x4 (&acc)[MI][NBW], const int (&rows)[MI], int c_out, int col0,
                                             int g, int rl, int wave, int tile, const float *__restrict__ bias,
                                             const void *__restrict__ addend, void *__restrict__ yv, const BnRed &bn,
-                                            float *red) {
+                                            float *red, const bool bystander = false) {
+    // bystander: a wave that owns no rows (the loader waves of ggw_kernel) only joins the final barrier / reduction
     constexpr int Q = gg_quad(NBW);
     constexpr int U = Q >= 2 ? 2 : 1;        // blocks per access unit: 8 channels = 16 bytes of bf16 (4 at Q = 1)
     constexpr int CH = 4 * U;
@@ -180,6 +192,7 @@ __device__ __forceinline__ void gg_epilogue(const f32x4 (&acc)[MI][NBW], const i
             v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
         }
     };
+    if (!bystander)
 #pragma unroll
     for (int qd = 0; qd < NBW / Q; ++qd)
 #pragma unroll
@@ -347,8 +360,7 @@ __global__ __launch_bounds__(256 * WN, gg_waves(NB / WN, MI, G)) void gather_gem
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, speed only): give each
     // XCD a CONTIGUOUS run of row tiles so its private L2 holds 1/8 of the feature matrix (+ halo) instead
     // of every XCD streaming all of it.  gridDim.x is a multiple of 8; surplus tiles exit.
-    const int tiles_per_xcd = gridDim.x >> 3;
-    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    const int tile = xcd_tile(n_out, ROWS);                // contiguous runs of the REAL tiles per XCD
     const int r0wg = tile * ROWS;
     constexpr int c_out = NB * 16;
     if (r0wg >= n_out) {
@@ -605,6 +617,289 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// WIDE gather-GEMM (C_in = 64 / 128): every operand reaches LDS by LDS-DMA (buffer_load_dwordx4 ... lds), nothing
+// is staged through VGPRs.
+//   * Gathered rows are fetched as WHOLE 128-byte lines: one wave instruction moves 8 rows x 128 B (64 input
+//     channels = 2 contraction steps) instead of the 16 rows x 64 B a fragment-shaped load touches -- half the
+//     lines per contraction step through the texture-address path, which is what bounds the fragment-loading
+//     kernel above (MI355X guide: "x operand through LDS in full 128-B lines, filled by glds").  The LDS image of a
+//     DMA is lane-linear, so the XOR swizzle that makes the ds_read_b128 operand reads conflict-free is applied on
+//     the SOURCE side: lane l of instruction j fetches piece (l & 7) ^ ((row >> 1) & 7) of row 8j + (l >> 3), and
+//     the reader of (row, piece) looks at piece ^ ((row >> 1) & 7).
+//   * Packed weights (already in MFMA fragment order = lane-linear) stream through a ring of R stages of 2
+//     contraction steps, each wave issuing a quarter of a stage; gathered rows through a per-wave ring of the same
+//     depth.  A stage is issued R - 1 iterations before it is used; the only waits are one counted
+//     s_waitcnt vmcnt((R - 2) * (GI + WPW)) and one raw s_barrier per stage (never vmcnt(0) at R = 3, never a
+//     __syncthreads(): its fence would drain the DMAs in flight).
+//   * Missing neighbours (index -1) are DMA'd from beyond num_records: the buffer unit returns zeros to LDS
+//     without touching memory; 16-row tiles without any neighbour at an offset skip their MFMAs (wave-uniform mask
+//     from a ballot taken when the stage was issued).
+// Same arithmetic, same summation order per output element as gather_gemm_kernel (steps ascending, fp32
+// accumulate in the MFMA) -> bit-identical results; same epilogue.
+// (a __device__ function, not a lambda: inside a lambda of a __global__ template the target-feature check of the
+// builtin is deferred on the HOST side and silently drops the kernel's host stub)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char *lds_dst_wave_uniform, unsigned voffset) {
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst_wave_uniform, 16, voffset, 0, 0, 0);
+}
+
+template <int NB, int SOFF, int MI, int R, bool OUT_BF16>   // SOFF = stages per offset = C_in / 64
+__global__ __launch_bounds__(512, 1) void ggw_kernel(
+    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+    const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip, int n_out_cap,
+    const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, unsigned x_bytes, unsigned w_bytes,
+    const void *__restrict__ addend, BnRed bn, int dbg) {
+    // 8 waves: waves 0-3 are CONSUMERS (MI x 16 output rows each: LDS operand reads + MFMAs, nothing else), waves
+    // 4-7 are LOADERS (wave 4 + w feeds consumer w: neighbour indices -> DMA offsets, all LDS-DMA instructions).
+    // A wave issues in order, and a VMEM instruction waits in the issue stage while the CU's one texture-address
+    // unit is busy (~32 clk per 1-KiB instruction): with loads and MFMAs in ONE wave per SIMD the MFMA pipe idles
+    // during every such wait (measured: loads alone 32 us, MFMAs alone 31 us, both in one wave 57-63 us whether
+    // issued back to back or interleaved).  Loader wave 4 + w shares SIMD w with consumer w.
+    constexpr int ROWS = 64 * MI;
+    constexpr int ROWB = 128 * SOFF;                       // bytes per feature row
+    constexpr int GI = 2 * MI;                             // DMA instructions per loader per gather stage
+    constexpr int WFR = 2 * NB;                            // 1-KiB weight fragments per stage
+    constexpr int WPW = WFR / 4;                           // ... per loader
+    constexpr int A_STAGE = MI * 2048;                     // bytes per consumer per stage (MI*16 rows x 128 B)
+    constexpr int W_STAGE = WFR * 1024;
+    constexpr int c_out = NB * 16;
+    constexpr int THREADS = 512;
+    static_assert(R == 2 || R == 3, "ring depth");
+    static_assert((R - 2) * (GI + WPW) < 64, "vmcnt field");
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *wring = smem;                                    // [R][W_STAGE]
+    char *aring = smem + R * W_STAGE;                      // [4 consumers][R][A_STAGE]
+    int *nbr_s = (int *)(aring + 4 * R * A_STAGE);         // [K + 1][ROWS]
+    float *red_s = (float *)(nbr_s + (K + 1) * ROWS);      // [4][2][c_out], only with bn.mode
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;                            // consumer index (of the loader: the consumer it feeds)
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD gets a CONTIGUOUS run of row tiles -- of the
+    // REAL tiles.  The grid is sized from the capacity (1.25 x the row count in static-shape mode); splitting the
+    // grid instead of the real tiles would leave the last XCDs idle while the first ones run a second round.
+    const int tile = xcd_tile(n_out, ROWS);
+    const int r0wg = tile * ROWS;
+    if (r0wg >= n_out) {
+        if (bn.mode) bnred_zero_row(bn, tile, c_out);
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+    {   // rulebook tile -> LDS (k-major, coalesced), row K = -1 for the stages beyond the last offset
+        const int total = K * ROWS;
+        for (int base = threadIdx.x; base < total + ROWS; base += 4 * THREADS) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                const int k = idx / ROWS, r = idx - k * ROWS;
+                const int row = r0wg + r;
+                const int krow = flip ? (K - 1 - k) : k;
+                const bool ok = idx < total && row < n_out;
+                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
+                if (!ok) v[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                if (idx < total + ROWS) nbr_s[idx] = v[u];
+            }
+        }
+    }
+    __syncthreads();      // (no DMA in flight yet: a plain barrier)
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
+    char *const awave = aring + wave * (R * A_STAGE);
+    const int wrow0 = wave * (MI * 16);
+    const int T = K * SOFF;                                // stages
+    const int NIT = (T + R - 1) / R * R;                   // iterations (both roles run the same number of barriers)
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // validity of (stage, consumer): any of the consumer's rows has a neighbour at the stage's offset.  Both
+    // roles derive it from the rulebook tile in LDS (the consumer to skip the stage's MFMAs).
+    auto stage_k = [&](int stage) {
+        const int k = SOFF == 2 ? (stage >> 1) : stage;
+        return k < K ? k : K;                              // beyond the last offset: the all -1 row
+    };
+
+    if (loader) {
+        // ------------------------------------------------------------------------------------------- loader
+        // the loader's few instructions go ahead of the consumer's MFMA stream on the shared SIMD
+        if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
+        const int gl_row = lane >> 3;                      // row slot of DMA instruction j: 8 j + (lane >> 3)
+        // source piece = (l & 7) ^ ((row_slot >> 1) & 7) = (l & 7) ^ ((4 j + (l >> 4)) & 7)
+        const unsigned gl_p0 = (unsigned)(lane & 7), gl_p1 = (unsigned)(lane >> 4);
+        auto fire = [&](int stage, auto slot_tag) {
+            constexpr int SLOT = decltype(slot_tag)::value;
+            const unsigned h = SOFF == 2 ? (unsigned)(stage & 1) * 128u : 0u;
+            const int *irow = nbr_s + stage_k(stage) * ROWS + wrow0 + gl_row;
+            int idx[GI];
+#pragma unroll
+            for (int j = 0; j < GI; ++j) idx[j] = irow[8 * j];
+#pragma unroll
+            for (int j = 0; j < GI; ++j) {
+                const unsigned piece = gl_p0 ^ ((4u * j + gl_p1) & 7u);
+                unsigned off = (unsigned)idx[j] * (unsigned)ROWB + h + piece * 16u;   // idx = -1 -> beyond num_records
+                if (dbg & 1) off = 0xFFFFFF00u;                                     // ablation: no gather traffic
+                glds16(xrsrc, awave + SLOT * A_STAGE + j * 1024, off);
+            }
+#pragma unroll
+            for (int f = 0; f < WPW; ++f) {
+                const int frag = wave + 4 * f;
+                const unsigned off = (stage < T && !(dbg & 2))
+                                         ? (unsigned)stage * (unsigned)W_STAGE + (unsigned)lane * 16u + (unsigned)frag * 1024u
+                                         : 0xFFFFFFF0u;
+                glds16(wrsrc, wring + SLOT * W_STAGE + frag * 1024, off);
+            }
+        };
+        // iteration t: stage t must have landed (all but the (R - 2) younger stages' instructions retired), then
+        // the barrier publishes it and frees slot (t - 1) % R for stage t + R - 1
+#define GGW_LOADER_STEP(FIRE_STAGE, SLOT_TAG)                                                             \
+    do {                                                                                                   \
+        if (R == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * (GI + WPW)) : "memory");            \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        fire(FIRE_STAGE, SLOT_TAG);                                                                        \
+    } while (0)
+        if (R == 3) {
+            fire(0, S0{});
+            fire(1, S1{});
+            for (int t = 0; t < NIT; t += 3) {
+                GGW_LOADER_STEP(t + 2, S2{});
+                GGW_LOADER_STEP(t + 3, S0{});
+                GGW_LOADER_STEP(t + 4, S1{});
+            }
+        } else {
+            fire(0, S0{});
+            for (int t = 0; t < NIT; t += 2) {
+                GGW_LOADER_STEP(t + 1, S1{});
+                GGW_LOADER_STEP(t + 2, S0{});
+            }
+        }
+#undef GGW_LOADER_STEP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages beyond T: zeros from beyond num_records
+        f32x4 none[MI][NB];
+        int norows[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) norows[mi] = -1;
+        gg_epilogue<MI, NB, OUT_BF16>(none, norows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s, true);
+        return;
+    }
+
+    // ----------------------------------------------------------------------------------------------- consumer
+    f32x4 acc[MI][NB];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned a_lane = (unsigned)rl * 128u;           // + mi * 2048 + (piece ^ swz) * 16
+    const unsigned a_swz = (unsigned)((rl >> 1) & 7);
+    // does any of this consumer's rows have a neighbour at the stage's offset?  (lane l checks row l of the wave's
+    // MI*16 <= 64 rows; read one iteration ahead so that the LDS latency hides behind MFMAs)
+    auto valid_of = [&](int stage) -> bool {
+        const int i = lane < MI * 16 ? nbr_s[stage_k(stage) * ROWS + wrow0 + lane] : -1;
+        return __builtin_amdgcn_ballot_w64(i >= 0) != 0ull;
+    };
+    auto compute = [&](auto slot_tag, bool valid) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        if (!valid || (dbg & 4)) return;
+        const char *ab = awave + SLOT * A_STAGE;
+        const char *wb = wring + SLOT * W_STAGE;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+            bf16x8 xa[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                xa[mi] = *reinterpret_cast<const bf16x8 *>(ab + mi * 2048 + a_lane + (((unsigned)(cs * 4 + g) ^ a_swz) << 4));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)   // (a 16-row tile without neighbours holds zeros: no branch per MFMA)
+                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, xa[mi], acc[mi][nb], 0, 0, 0);
+            }
+        }
+    };
+#define GGW_CONSUMER_STEP(SLOT_TAG, STAGE)                                                                 \
+    do {                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* this wave's reads of slot (t - 1) % R are done */ \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        const bool vnext = valid_of((STAGE) + 1);                                                          \
+        compute(SLOT_TAG, vcur && (STAGE) < T);                                                            \
+        vcur = vnext;                                                                                      \
+    } while (0)
+    bool vcur = valid_of(0);
+    if (R == 3) {
+        for (int t = 0; t < NIT; t += 3) {
+            GGW_CONSUMER_STEP(S0{}, t);
+            GGW_CONSUMER_STEP(S1{}, t + 1);
+            GGW_CONSUMER_STEP(S2{}, t + 2);
+        }
+    } else {
+        for (int t = 0; t < NIT; t += 2) {
+            GGW_CONSUMER_STEP(S0{}, t);
+            GGW_CONSUMER_STEP(S1{}, t + 1);
+        }
+    }
+#undef GGW_CONSUMER_STEP
+
+    int rows[MI];
+    const int tile_row = wrow0 + rl;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = r0wg + tile_row + mi * 16;
+        rows[mi] = row < n_out ? row : -1;
+    }
+    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
+}
+
+template <int NB, int SOFF, int MI, int R>
+static int launch_ggw(const void *x, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride, int K,
+                      int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
+                      unsigned w_bytes, hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
+    constexpr int ROWS = 64 * MI;
+    int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
+    const size_t lds = (size_t)R * (2 * NB * 1024) + (size_t)4 * R * (MI * 2048) + (size_t)(K + 1) * ROWS * sizeof(int) +
+                       (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
+    if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
+    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;   // ablation switches
+    auto kb = ggw_kernel<NB, SOFF, MI, R, true>;
+    auto kf = ggw_kernel<NB, SOFF, MI, R, false>;
+    if (lds > 64 * 1024) {
+        static size_t raised[2] = {0, 0};
+        const int which = y_dtype == PCD_BF16 ? 0 : 1;
+        if (raised[which] < lds) {
+            if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return PCD_ERR_LAUNCH;
+            raised[which] = lds;
+        }
+    }
+    if (y_dtype == PCD_BF16)
+        kb<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
+                                   n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
+    else
+        kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
+                                   n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
 // rows all share the residues ((c + p) mod s) of the three axes, hence the same 1..8 usable offsets (of 27 for
 // k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
@@ -632,8 +927,7 @@ __global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kern
     int *nbr_s = row_s + ROWS;                             // [8 + 1][ROWS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rl = lane & 15, g = lane >> 4;
-    const int tiles_per_xcd = gridDim.x >> 3;
-    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    const int tile = xcd_tile(vstart[T.ncls], ROWS);       // contiguous runs of the REAL tiles per XCD
     const int v0 = tile * ROWS;
     if (v0 >= vstart[T.ncls]) {
         if (bn.mode) bnred_zero_row(bn, tile, c_out);
@@ -1254,7 +1548,7 @@ extern "C" int pcd_pack_weights_batched(const void *table, int n, int total_bloc
 static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                        const int32_t *nbr, int nbr_stride, int kvol, int flip_k, int n_rows_out,
                        const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype, const void *addend,
-                       const PcdBnReduce *bnr, int *tiles_only, void *stream) {
+                       const PcdBnReduce *bnr, int *tiles_only, void *stream, int dir_hint = -1) {
     if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
     if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
     if (n_rows_out == 0) {
@@ -1280,6 +1574,24 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // whole step 4.32 -> 4.19 ms at B = 4.  4 steps ahead, 16 or 64 rows per wave, or 4-step weight stages are
     // slower (4.21-4.63); choosing 16 rows per wave for layers with few rows (< 48k) was also slower
     // (B = 1 / 2: 432 / 676 -> 457 / 712 frames/s without that rule).
+    // Wide layers (C_in = 64 / 128, C_out = 64 / 128): the LDS-DMA kernel (ggw_kernel).  Rows per workgroup follow the
+    // row count so that the tiles of the LARGEST layers of a level fill the 256 CUs in whole rounds.
+    static const int ggw_mode = getenv("PCD_GGW") ? atoi(getenv("PCD_GGW")) : 1;
+    // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
+    //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
+    const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
+    if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
+        x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 1)) {
+        const unsigned w_bytes = (unsigned)wbytes;
+        const int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
+#define GGW_ARGS x, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only
+#define GGW_MI(NBV, SOFFV)                                                         \
+        (mi == 3 ? launch_ggw<NBV, SOFFV, 3, 3>(GGW_ARGS) : launch_ggw<NBV, SOFFV, 2, 3>(GGW_ARGS))
+        if (c_in == 64) return c_out == 64 ? GGW_MI(4, 1) : GGW_MI(8, 1);
+        return c_out == 64 ? GGW_MI(4, 2) : GGW_MI(8, 2);
+#undef GGW_MI
+#undef GGW_ARGS
+    }
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
         case 1:
@@ -1307,11 +1619,16 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
                        c_out, y, y_dtype, addend, bn_reduce, nullptr, stream);
 }
 
-extern "C" int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out) {
+extern "C" int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out,
+                                                      int is_dgrad) {
     int tiles = 0;
     int rc = gg_dispatch(nullptr, n_rows_in, c_in, nullptr, nullptr, nullptr, 0, kvol, 0, n_rows_out, nullptr, c_out,
-                         nullptr, PCD_BF16, nullptr, nullptr, &tiles, nullptr);
+                         nullptr, PCD_BF16, nullptr, nullptr, &tiles, nullptr, is_dgrad ? 1 : 0);
     return rc == PCD_OK ? tiles : rc;
+}
+
+extern "C" int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out) {
+    return pcd_sparse_conv_gather_gemm_tiles_dir(n_rows_in, c_in, kvol, n_rows_out, c_out, 0);
 }
 
 // a class tile runs only 1..8 of the K offsets: little work per workgroup, so small tiles (more workgroups in

@@ -262,6 +262,9 @@ int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const vo
                                 int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
 /* number of workgroup tiles (= partial rows of bn_reduce) of that launch; < 0: error code */
 int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out);
+/* same for a launch that is a DATA GRADIENT (flip_k != 0 or bn_reduce->mode == 2): the library may pick a different
+ * kernel (tile height) for the two directions */
+int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out, int is_dgrad);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
