@@ -62,6 +62,7 @@ PROTOTYPES = {
                                          _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_sparse_conv_wgrad_v2": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_reduce_batched": (_i, [_vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_os_splits": (_i, [_i, _i, _i, _i]),

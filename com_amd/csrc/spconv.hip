@@ -1075,8 +1075,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
     int cout, const int32_t *__restrict__ pairs, const int32_t *__restrict__ pair_num, int K, int pmax,
     int rows_per_split, int n_splits, int n_chunks, int n_cout_chunks, float *__restrict__ slab,
-    unsigned x_bytes, unsigned dy_bytes) {
+    unsigned x_bytes, unsigned dy_bytes, int n_x_cap, const int32_t *__restrict__ n_x_dev) {
     constexpr int CI = MB * 16, CO = NBW * 16;
+    // the row-range splits partition the REAL input rows (static-shape mode: n_x_cap is a capacity, the count lives
+    // on the device): with capacity-sized ranges the last splits -- the last XCDs' share -- would be empty
+    if (n_x_dev) rows_per_split = (eff_rows(n_x_dev, n_x_cap) + n_splits - 1) / n_splits;
     // LDS row strides (elements).  In dwords the stride is 8 * odd, so that (i) the 8 consecutive pair rows a
     // 32-lane half touches in one ds_read_b64_tr_b16 start on 8 distinct 8-dword windows of the 64 banks and
     // (ii) 4 consecutive rows x 32 B written by 8 consecutive lanes (ds_write_b128) cover 32 distinct banks.
@@ -1483,7 +1486,7 @@ static void wgrad_plan(int pmax, int cin, int cout, int *splits, int *rows_per_s
 template <int MB, int NBW>
 static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int n_dy, int cout,
                         const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *slab,
-                        hipStream_t st) {
+                        hipStream_t st, const int32_t *n_x_dev) {
     constexpr int CI = MB * 16, CO = NBW * 16;
     int splits, per;
     wgrad_plan(pmax, cin, cout, &splits, &per);
@@ -1498,7 +1501,7 @@ static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void
                                                   (const unsigned short *)dy, cout, pairs, pair_num, K,
                                                   pmax, per, splits, ncic * ncoc, ncoc, slab,
                                                   (unsigned)((size_t)n_x * cin_pad * 2),
-                                                  (unsigned)((size_t)n_dy * cout * 2));
+                                                  (unsigned)((size_t)n_dy * cout * 2), n_x, n_x_dev);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -1710,6 +1713,14 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int ci
                                      const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                                      float *dweight, void *workspace, size_t workspace_bytes,
                                      void *stream) {
+    return pcd_sparse_conv_wgrad_v2(x, n_x, nullptr, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, dweight,
+                                    workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin,
+                                        const void *dy, int n_dy, int cout, const int32_t *pairs,
+                                        const int32_t *pair_num, int kvol, int pmax, float *dweight, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin || n_x < 0 || n_dy < 0)
         return PCD_ERR_INVALID_ARG;
@@ -1730,7 +1741,7 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int ci
     int rc = PCD_ERR_UNSUPPORTED;
 #define WG(M, N)                                                                                  \
     if (mb == M && nb == N)                                                                       \
-        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, slab, st);
+        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, slab, st, n_x_dev);
     WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
 #undef WG
     return rc;

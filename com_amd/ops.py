@@ -663,8 +663,9 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     `nbr_out` [K, n_out] (+ `n_out_dev`): lets 16-output-channel layers use the output-stationary kernel.
     `rb` (instead of pairs / pair_num / nbr_out): a Rulebook -- its pairs are only touched (and, for a SubM rulebook
     built without them, only then derived) when the pair-based kernel is the one that runs."""
+    n_in_dev = None
     if rb is not None:
-        nbr_out, n_out_dev = rb.nbr_out, rb.n_out_dev
+        nbr_out, n_out_dev, n_in_dev = rb.nbr_out, rb.n_out_dev, rb.n_in_dev
     _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     assert x.is_contiguous() and dy.is_contiguous()
@@ -713,10 +714,9 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
         return 4 if b >= 4 else (2 if b >= 2 else 1)
 
     with _Timed(f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}> {x.shape[1]}x{cout} K={kvol}", meta):
-        L.check(lib.pcd_sparse_conv_wgrad(L.ptr(x), x.shape[0], x.shape[1], cin, L.ptr(dy), dy.shape[0], cout,
-                                          L.ptr(pairs),
-                                          L.ptr(pair_num), kvol, pmax, L.ptr(dw), L.ptr(ws), ws.numel(),
-                                          L.stream_ptr()), "pcd_sparse_conv_wgrad")
+        L.check(lib.pcd_sparse_conv_wgrad_v2(L.ptr(x), x.shape[0], L.ptr(n_in_dev), x.shape[1], cin, L.ptr(dy),
+                                             dy.shape[0], cout, L.ptr(pairs), L.ptr(pair_num), kvol, pmax, L.ptr(dw),
+                                             L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_v2")
     if defer is not None:
         defer.append((ws, dw, kvol, cin, cout, pmax))
         return dw

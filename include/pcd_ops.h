@@ -276,6 +276,11 @@ size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pm
 int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, const void *dy, int n_dy_rows, int cout,
                           const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                           float *dweight, void *workspace, size_t workspace_bytes, void *stream);
+/* v2: n_x_dev (may be NULL) = device-side count of the real rows of x when n_x is a capacity (static-shape mode): the
+ * row-range splits then partition the real rows, so no workgroup -- and no XCD -- is left with an empty range */
+int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin, const void *dy,
+                             int n_dy, int cout, const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
+                             float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
                                  const void *workspace, void *stream);
 /* The same reduction for up to PCD_WGRAD_MAX_JOBS layers in ONE launch (each layer then needs its own workspace
