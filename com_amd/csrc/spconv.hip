@@ -1583,8 +1583,9 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
     //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
     const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
+    // PCD_GGW: 0 = off, 1 = on (default), 2..4 = on with MI rows-per-wave forced (also for C_in = 64), 6 = forward only
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
-        x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 1)) {
+        x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 6)) {
         const unsigned w_bytes = (unsigned)wbytes;
         const int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
 #define GGW_ARGS x, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only
