@@ -388,6 +388,24 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
+ * (f3) Rotated BEV overlap / IoU and NMS -- replaces pcdet/ops/iou3d_nms (binder: src/iou3d_nms_api.cpp:12-16;
+ *      kernels src/iou3d_nms_kernel.cu:236-413; host reduction src/iou3d_nms.cpp:60-188; Python callers
+ *      iou3d_nms_utils.py:31-116).  Boxes are rows of 7 float32 (x, y, z, dx, dy, dz, heading).
+ *   pcd_boxes_overlap_bev: out[a][b] = area of the BEV intersection (want_iou == 0; boxes_overlap_bev_gpu) or
+ *                          the BEV IoU (want_iou != 0; boxes_iou_bev_gpu), out = [num_a][num_b] f32.
+ *   pcd_nms_bev: greedy NMS over boxes ALREADY SORTED by descending score (as nms_gpu / nms_normal_gpu receive them):
+ *                box i suppresses every later box whose IoU with it exceeds thresh (normal != 0: axis-aligned IoU of
+ *                nms_normal_gpu).  keep = int64[num_boxes] receives the kept indices in ascending order,
+ *                *num_keep_dev (device int32) their number; both stay on the device (the reference returns the
+ *                count through a host loop over a mask it copies back).  workspace: pcd_nms_workspace_bytes(n).
+ * ============================================================================================ */
+int pcd_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b, float *out, int want_iou,
+                          void *stream);
+size_t pcd_nms_workspace_bytes(int num_boxes);
+int pcd_nms_bev(const float *boxes, int num_boxes, float thresh, int normal, long long *keep, int32_t *num_keep_dev,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
  * Static-shape execution guard.  Buffers of a captured step are allocated at CAPACITIES (see "Device-side row
  * counts" above) and the kernels clamp to them, so a batch denser than the capacity would be truncated silently.
  * pcd_static_overflow_check enqueues a one-thread kernel that compares up to PCD_COUNT_CHECK_MAX device-side counts

@@ -296,3 +296,21 @@ def weight_from_spconv2(weight):
     cout = weight.shape[0]
     cin = weight.shape[-1]
     return np.ascontiguousarray(np.transpose(weight.reshape(cout, -1, cin), (1, 2, 0)))
+
+
+# ---------------------------------------------------------------------------------------------
+def boxes_pairwise_bev(boxes_a, boxes_b, want_iou):
+    """pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252 (want_iou) / the overlap area alone: (N, M) float32."""
+    a, b = _f32(boxes_a), _f32(boxes_b)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().orc_boxes_pairwise_bev(_p(a), a.shape[0], _p(b), b.shape[0], int(bool(want_iou)), _p(out))
+    return out
+
+
+def nms_bev(boxes_sorted, thresh, normal=False):
+    """Greedy NMS over score-sorted boxes (iou3d_nms.cpp:100-130 semantics): kept indices, ascending."""
+    b = _f32(boxes_sorted)
+    keep = np.zeros((max(b.shape[0], 1),), np.int64)
+    lib().orc_nms_bev.restype = ctypes.c_int
+    k = lib().orc_nms_bev(_p(b), b.shape[0], ctypes.c_float(thresh), int(bool(normal)), _p(keep))
+    return keep[:k].copy()

@@ -546,3 +546,131 @@ void orc_dense_bev(const float *feat, const int32_t *indices, int n, int c, int 
                 feat[(size_t)r * c + q];
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * Rotated BEV overlap / IoU and greedy NMS: restatement of pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:59-252
+ * (= the device code iou3d_nms_kernel.cu:27-234) and of the mask + host-loop NMS
+ * (iou3d_nms_kernel.cu:267-376, iou3d_nms.cpp:100-130), float32 like the reference.
+ * PARITY STATUS: the reference file cannot be compiled here (it includes <cuda.h> / <cuda_runtime_api.h>, which
+ * this image does not have, and stand-in headers are not allowed) and the reference has no tests for it
+ * ==> "parity unpinned"; tests cross-check the areas against an independent convex-polygon clipping (numpy).
+ */
+typedef struct { float x, y; } orc_p2;
+
+static float orc_cross3(orc_p2 p1, orc_p2 p2, orc_p2 p0) {          /* iou3d_cpu.cpp:63-65 */
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+static int orc_rect_cross(orc_p2 p1, orc_p2 p2, orc_p2 q1, orc_p2 q2) {   /* :67-73 */
+    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+static int orc_in_box2d(const float *box, orc_p2 p) {               /* :75-85 */
+    const float MARGIN = 1e-2f;
+    float c = cosf(-box[6]), s = sinf(-box[6]);
+    float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s);
+    float ry = (p.x - box[0]) * s + (p.y - box[1]) * c;
+    return fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN;
+}
+static int orc_intersection(orc_p2 p1, orc_p2 p0, orc_p2 q1, orc_p2 q0, orc_p2 *ans) {   /* :87-116 */
+    const float EPS = 1e-8f;
+    if (!orc_rect_cross(p0, p1, q0, q1)) return 0;
+    float s1 = orc_cross3(q0, p1, p0), s2 = orc_cross3(p1, q1, p0);
+    float s3 = orc_cross3(p0, q1, q0), s4 = orc_cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    float s5 = orc_cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > EPS) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+static void orc_corners(const float *box, orc_p2 *c) {              /* :134-162 */
+    float hx = box[3] / 2, hy = box[4] / 2;
+    float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
+    float ca = cosf(box[6]), sa = sinf(box[6]);
+    float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
+    for (int k = 0; k < 4; ++k) {                                    /* rotate_around_center, :118-122 */
+        c[k].x = (px[k] - box[0]) * ca + (py[k] - box[1]) * (-sa) + box[0];
+        c[k].y = (px[k] - box[0]) * sa + (py[k] - box[1]) * ca + box[1];
+    }
+    c[4] = c[0];
+}
+float orc_box_overlap_bev(const float *a, const float *b) {          /* :128-220 */
+    orc_p2 ca[5], cb[5], pts[16], centre = {0.f, 0.f};
+    int cnt = 0;
+    orc_corners(a, ca);
+    orc_corners(b, cb);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            orc_p2 x;
+            if (orc_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &x)) {
+                centre.x += x.x;
+                centre.y += x.y;
+                pts[cnt++] = x;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (orc_in_box2d(a, cb[k])) { centre.x += cb[k].x; centre.y += cb[k].y; pts[cnt++] = cb[k]; }
+        if (orc_in_box2d(b, ca[k])) { centre.x += ca[k].x; centre.y += ca[k].y; pts[cnt++] = ca[k]; }
+    }
+    centre.x /= cnt;
+    centre.y /= cnt;
+    for (int j = 0; j < cnt - 1; ++j)                                 /* bubble sort, point_cmp :124-126 */
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (atan2f(pts[i].y - centre.y, pts[i].x - centre.x) >
+                atan2f(pts[i + 1].y - centre.y, pts[i + 1].x - centre.x)) {
+                orc_p2 t = pts[i];
+                pts[i] = pts[i + 1];
+                pts[i + 1] = t;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y;
+        float bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+        area += ax * by - ay * bx;
+    }
+    return fabsf(area) / 2.0f;
+}
+float orc_iou_bev(const float *a, const float *b) {                  /* :222-229 */
+    float sa = a[3] * a[4], sb = b[3] * b[4];
+    float so = orc_box_overlap_bev(a, b);
+    return so / fmaxf(sa + sb - so, 1e-8f);
+}
+static float orc_iou_normal(const float *a, const float *b) {        /* iou3d_nms_kernel.cu:312-324 */
+    float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+    float inter = w * h;
+    return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+void orc_boxes_pairwise_bev(const float *boxes_a, int na, const float *boxes_b, int nb, int want_iou, float *out) {
+    for (int i = 0; i < na; ++i)                                     /* iou3d_cpu.cpp:246-250 */
+        for (int j = 0; j < nb; ++j)
+            out[(size_t)i * nb + j] = want_iou ? orc_iou_bev(boxes_a + (size_t)i * 7, boxes_b + (size_t)j * 7)
+                                               : orc_box_overlap_bev(boxes_a + (size_t)i * 7, boxes_b + (size_t)j * 7);
+}
+/* greedy NMS over boxes sorted by descending score: box i, if still alive, removes every j > i whose IoU with it
+ * exceeds thresh -- the fixed point of the reference's bitmask + host loop.  Returns the number kept. */
+int orc_nms_bev(const float *boxes, int n, float thresh, int normal, int64_t *keep) {
+    unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[kept++] = i;
+        for (int j = i + 1; j < n; ++j) {
+            if (dead[j]) continue;
+            float v = normal ? orc_iou_normal(boxes + (size_t)i * 7, boxes + (size_t)j * 7)
+                             : orc_iou_bev(boxes + (size_t)i * 7, boxes + (size_t)j * 7);
+            if (v > thresh) dead[j] = 1;
+        }
+    }
+    free(dead);
+    return kept;
+}
