@@ -82,6 +82,9 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_pillar_decorate": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pcd_pfn_relu_pool": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pcd_pfn_relu_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_boxes_overlap_bev": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
     "pcd_nms_workspace_bytes": (_sz, [_i]),
     "pcd_nms_bev": (_i, [_vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _sz, _vp]),

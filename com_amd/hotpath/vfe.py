@@ -77,9 +77,25 @@ class PFNLayer(nn.Module):
         h = self.linear(inputs)
         if self.use_norm:                       # BatchNorm over all (pillar, point) rows, channel last
             h = self.norm(h.reshape(m * t, -1)).reshape(m, t, -1)
-        h = F.relu(h)
-        pooled = h.amax(dim=1, keepdim=True)
-        return pooled if self.last_vfe else torch.cat((h, pooled.expand(-1, t, -1)), dim=2)
+        # ReLU + max over the points (+ [h, max] concatenation) in one HIP pass (pcd_pfn_relu_pool)
+        out = _PfnReluPool.apply(h.contiguous().float(), self.last_vfe)
+        return out.unsqueeze(1) if self.last_vfe else out
+
+
+class _PfnReluPool(torch.autograd.Function):
+    """pillar_vfe.py:44-49: relu -> max over the pillar's points -> (repeat + cat for non-final stages)."""
+
+    @staticmethod
+    def forward(ctx, h, last):
+        out, arg = ops.pfn_relu_pool(h, last)
+        ctx.save_for_backward(h, arg)
+        ctx.last = last
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, arg = ctx.saved_tensors
+        return ops.pfn_relu_pool_backward(g, h, arg, ctx.last), None
 
 
 class PillarVFE(VFETemplate):
@@ -109,20 +125,12 @@ class PillarVFE(VFETemplate):
         return self.num_filters[-1]
 
     def forward(self, batch_dict, **kwargs):
-        pts = batch_dict['voxels']                                  # [M, T, C], zero padded
-        count = batch_dict['voxel_num_points'].to(pts.dtype)        # [M]   (not clamped: pillar_vfe.py:97)
-        coords = batch_dict['voxel_coords'].to(pts.dtype)           # [M, 4] (b, z, y, x)
-        xyz = pts[..., :3]
-        mean = xyz.sum(dim=1, keepdim=True) / count.view(-1, 1, 1)
-        size = pts.new_tensor([self.voxel_x, self.voxel_y, self.voxel_z])
-        origin = pts.new_tensor([self.x_offset, self.y_offset, self.z_offset])
-        centre = coords[:, [3, 2, 1]] * size + origin               # (x, y, z) centre of each pillar
-        parts = [pts if self.use_absolute_xyz else pts[..., 3:], xyz - mean, xyz - centre.unsqueeze(1)]
-        if self.with_distance:
-            parts.append(xyz.norm(dim=2, keepdim=True))
-        feats = torch.cat(parts, dim=-1)
-        slot = torch.arange(pts.shape[1], device=pts.device).view(1, -1)
-        feats = feats * (slot < batch_dict['voxel_num_points'].view(-1, 1)).unsqueeze(-1).to(pts.dtype)
+        # decoration (offset to the pillar mean and to the pillar centre, optional range) + padding mask: one HIP
+        # pass over the padded pillars (pcd_pillar_decorate) instead of the reference's mean / sub / cat / mask chain
+        feats = ops.pillar_decorate(batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords'],
+                                    (self.voxel_x, self.voxel_y, self.voxel_z),
+                                    (self.x_offset, self.y_offset, self.z_offset), self.use_absolute_xyz,
+                                    self.with_distance)
         for layer in self.pfn_layers:
             feats = layer(feats)
         batch_dict['pillar_features'] = feats.squeeze(1)

@@ -286,6 +286,43 @@ def voxelize_dynamic_mean(points_b, batch_size, point_cloud_range, voxel_size, r
     return feat[:m], coords[:m], cnt[:m]
 
 
+def pillar_decorate(voxels, num_points, coords, voxel_size, offset, use_absolute_xyz=True, with_distance=False):
+    """pillar_vfe.py:94-118 in one pass: [M, T, C] padded points -> decorated, masked [M, T, C']."""
+    _require_cuda(voxels, num_points, coords)
+    v = voxels.contiguous().float()
+    m, T, C = v.shape
+    nump = num_points.contiguous().to(torch.int32)
+    cd = coords.contiguous().to(torch.int32)
+    c_out = (C if use_absolute_xyz else C - 3) + 6 + (1 if with_distance else 0)
+    out = torch.empty((m, T, c_out), dtype=torch.float32, device=v.device)
+    L.check(L.lib().pcd_pillar_decorate(L.ptr(v), L.ptr(nump), L.ptr(cd), m, T, C, int(use_absolute_xyz),
+                                        int(with_distance), L.host_f32(voxel_size), L.host_f32(offset), L.ptr(out),
+                                        L.stream_ptr()), "pcd_pillar_decorate")
+    return out
+
+
+def pfn_relu_pool(x, last_layer):
+    """(out, arg): ReLU + max over dim 1 of x [M, T, C] (+ [h, max] concatenation for a non-final PFN stage)."""
+    _require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    m, T, C = x.shape
+    out = torch.empty((m, C) if last_layer else (m, T, 2 * C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((m, C), dtype=torch.int32, device=x.device)
+    L.check(L.lib().pcd_pfn_relu_pool(L.ptr(x), m, T, C, int(last_layer), L.ptr(out), L.ptr(arg), L.stream_ptr()),
+            "pcd_pfn_relu_pool")
+    return out, arg
+
+
+def pfn_relu_pool_backward(grad_out, x, arg, last_layer):
+    _require_cuda(grad_out, x, arg)
+    g = grad_out.contiguous().float()
+    m, T, C = x.shape
+    gx = torch.empty_like(x)
+    L.check(L.lib().pcd_pfn_relu_pool_backward(L.ptr(g), L.ptr(x), L.ptr(arg), m, T, C, int(last_layer), L.ptr(gx),
+                                               L.stream_ptr()), "pcd_pfn_relu_pool_backward")
+    return gx
+
+
 def segment_max(x, seg, m):
     """out [m, c], arg [m, c]: per-segment maximum of x [n, c] f32 over seg [n] int32 (negative ids skipped) and the
     smallest row attaining it (torch_scatter.scatter_max, dynamic_pillar_vfe.py:40)."""

@@ -388,6 +388,24 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
+ * (a6) PillarVFE pieces -- pcdet/models/backbones_3d/vfe/pillar_vfe.py:94-118 (decoration + padding mask) and the
+ *      ReLU / max-over-points / concatenation half of PFNLayer (pillar_vfe.py:40-49).  float32.
+ *   pcd_pillar_decorate: voxels [m][T][C] (zero padded), num_points [m], coords [m][4] (b, z, y, x) ->
+ *       out [m][T][C' ], C' = (use_absolute_xyz ? C : C - 3) + 6 (+ 1 with_distance): point features, xyz - pillar mean
+ *       (sum over the T slots / num_points, not clamped), xyz - pillar centre (coord * voxel_size + offset, offset =
+ *       voxel_size / 2 + range_min), optional |xyz|; padding slots (t >= num_points) zeroed.
+ *   pcd_pfn_relu_pool: x [m][T][C] (BatchNorm / Linear output) -> last_layer: out [m][C] = max_t relu(x);
+ *       else out [m][T][2C] = [relu(x), broadcast max].  arg [m][C] = first maximal slot (for the backward).
+ *   pcd_pfn_relu_pool_backward: grad_x [m][T][C] from grad_out of that layout.
+ * ============================================================================================ */
+int pcd_pillar_decorate(const float *voxels, const int32_t *num_points, const int32_t *coords, int m, int T, int C,
+                        int use_absolute_xyz, int with_distance, const float *voxel_size_host,
+                        const float *offset_host, float *out, void *stream);
+int pcd_pfn_relu_pool(const float *x, int m, int T, int C, int last_layer, float *out, int32_t *arg, void *stream);
+int pcd_pfn_relu_pool_backward(const float *grad_out, const float *x, const int32_t *arg, int m, int T, int C,
+                               int last_layer, float *grad_x, void *stream);
+
+/* ============================================================================================
  * (f3) Rotated BEV overlap / IoU and NMS -- replaces pcdet/ops/iou3d_nms (binder: src/iou3d_nms_api.cpp:12-16;
  *      kernels src/iou3d_nms_kernel.cu:236-413; host reduction src/iou3d_nms.cpp:60-188; Python callers
  *      iou3d_nms_utils.py:31-116).  Boxes are rows of 7 float32 (x, y, z, dx, dy, dz, heading).
