@@ -70,6 +70,8 @@ PROTOTYPES = {
     "pcd_bev_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_bev_scatter": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_bev_gather": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pcd_bev_scatter_nhwc": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_bev_gather_nhwc": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_bn_workspace_bytes": (_sz, [_i]),
     "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,

@@ -113,7 +113,123 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(const T *__restrict__ d
     }
 }
 
+// ---- channels-last (NHWC) variants: out[b][y][x][c * D + z], the memory format MIOpen's bf16 convolutions of the
+// dense BEV stack (pcdet/models/backbones_2d/base_bev_backbone.py:30-112) want.  A pixel's C*D channels are one
+// contiguous run; a thread owns (pixel, 16-byte piece of C) for all D heights: D coalesced 16-byte row loads,
+// D interleaved 16-byte stores.  Every output element is written exactly once (zeros included).
+template <typename T>
+__global__ __launch_bounds__(256) void bev_scatter_nhwc_kernel(const T *__restrict__ feat, int C, int c_stride,
+                                                               const int *__restrict__ map, int B, int D, int H, int W,
+                                                               T *__restrict__ out) {
+    constexpr int EPP = 16 / sizeof(T);
+    const int pieces = C / EPP;                               // (C % EPP == 0 checked by the host)
+    const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t npix = (size_t)B * H * W;
+    if (item >= npix * pieces) return;
+    const size_t pix = item / pieces;
+    const int pc = (int)(item - pix * pieces);
+    const int b = (int)(pix / ((size_t)H * W));
+    const size_t yx = pix - (size_t)b * H * W;
+    T buf[8 * EPP];
+    for (int z = 0; z < D; ++z) {
+        const int r = map[((size_t)b * D + z) * H * W + yx];
+        T v[EPP];
+        if (r >= 0) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(feat + (size_t)r * c_stride + pc * EPP);
+            __builtin_memcpy(v, &raw, 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPP; ++j) v[j] = (T)0;
+        }
+#pragma unroll
+        for (int j = 0; j < EPP; ++j) buf[j * D + z] = v[j];
+    }
+    T *o = out + pix * ((size_t)C * D) + (size_t)pc * EPP * D;
+    for (int q = 0; q < D; ++q) {
+        uint4 raw;
+        __builtin_memcpy(&raw, buf + q * EPP, 16);
+        *reinterpret_cast<uint4 *>(o + q * EPP) = raw;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bev_gather_nhwc_kernel(const T *__restrict__ dout, int C, int c_stride,
+                                                              const int4 *__restrict__ idx, int n_cap,
+                                                              const int32_t *n_dev, int D, int H, int W,
+                                                              T *__restrict__ dfeat) {
+    constexpr int EPP = 16 / sizeof(T);
+    const int pieces = C / EPP;
+    const int n = eff_rows(n_dev, n_cap);
+    const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (size_t)n * pieces) return;
+    const int r = (int)(item / pieces), pc = (int)(item - (size_t)r * pieces);
+    const int4 c = idx[r];
+    const T *src = dout + ((((size_t)c.x * H + c.z) * W + c.w) * C + (size_t)pc * EPP) * D + c.y;
+    T v[EPP];
+#pragma unroll
+    for (int j = 0; j < EPP; ++j) v[j] = src[(size_t)j * D];
+    uint4 raw;
+    __builtin_memcpy(&raw, v, 16);
+    *reinterpret_cast<uint4 *>(dfeat + (size_t)r * c_stride + pc * EPP) = raw;
+}
+
 }  // namespace
+
+extern "C" int pcd_bev_scatter_nhwc(const void *features, int c, int c_stride, int dtype, const int32_t *indices, int n,
+                                    const int32_t *n_dev, int batch, int d, int h, int w, void *out, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || c <= 0 || c_stride < c || batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !out) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (!features || !indices)) return PCD_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < pcd_bev_workspace_bytes(batch, d, h, w)) return PCD_ERR_WORKSPACE;
+    if (d > 8) return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int *map = (int *)workspace;
+    const size_t cells = (size_t)batch * d * h * w;
+    pcd_fill(map, 0xFF, cells * sizeof(int), st);
+    if (n > 0)
+        bev_map_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, batch, d, h, w, map);
+    if (dtype == PCD_BF16) {
+        if ((c % 8) || (c_stride % 8)) return PCD_ERR_UNSUPPORTED;
+        const size_t items = (size_t)batch * h * w * (c / 8);
+        bev_scatter_nhwc_kernel<unsigned short><<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
+            (const unsigned short *)features, c, c_stride, map, batch, d, h, w, (unsigned short *)out);
+    } else if (dtype == PCD_F32) {
+        if ((c % 4) || (c_stride % 4)) return PCD_ERR_UNSUPPORTED;
+        const size_t items = (size_t)batch * h * w * (c / 4);
+        bev_scatter_nhwc_kernel<float><<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
+            (const float *)features, c, c_stride, map, batch, d, h, w, (float *)out);
+    } else {
+        return PCD_ERR_INVALID_ARG;
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bev_gather_nhwc(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
+                                   const int32_t *n_dev, int batch, int d, int h, int w, void *dfeatures, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || c <= 0 || c_stride < c || batch <= 0 || d <= 0 || h <= 0 || w <= 0) return PCD_ERR_INVALID_ARG;
+    if (n == 0) return PCD_OK;
+    if (!dout || !indices || !dfeatures) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCD_BF16) {
+        if ((c % 8) || (c_stride % 8)) return PCD_ERR_UNSUPPORTED;
+        const size_t items = (size_t)n * (c / 8);
+        bev_gather_nhwc_kernel<unsigned short><<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
+            (const unsigned short *)dout, c, c_stride, (const int4 *)indices, n, n_dev, d, h, w,
+            (unsigned short *)dfeatures);
+    } else if (dtype == PCD_F32) {
+        if ((c % 4) || (c_stride % 4)) return PCD_ERR_UNSUPPORTED;
+        const size_t items = (size_t)n * (c / 4);
+        bev_gather_nhwc_kernel<float><<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
+            (const float *)dout, c, c_stride, (const int4 *)indices, n, n_dev, d, h, w, (float *)dfeatures);
+    } else {
+        return PCD_ERR_INVALID_ARG;
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
 
 extern "C" size_t pcd_bev_workspace_bytes(int batch, int d, int h, int w) {
     if (batch <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;

@@ -5,3 +5,4 @@ from .backbone3d import SparseBasicBlock, VoxelBackBone8x, VoxelResBackBone8x, p
 from .data import VoxelGeneratorWrapper, collate_points, transform_points_to_voxels  # noqa: F401
 from .map_to_bev import HeightCompression, PointPillarScatter  # noqa: F401
 from .vfe import DynamicMeanVFE, DynamicPillarVFE, MeanVFE, PillarVFE  # noqa: F401
+from .dense2d import BaseBEVBackbone, CenterHeadTowers, SeparateHead  # noqa: F401

@@ -1,0 +1,144 @@
+"""Dense BEV stack behind the hot path: the 2D backbone and the convolutional towers of the
+centre head -- pcdet/models/backbones_2d/base_bev_backbone.py:6-112 and
+pcdet/models/dense_heads/center_head.py:11-46,75-99 -- with the reference's constructor arguments, module / state-dict
+names and `data_dict` keys.  The arithmetic is dense conv2d / BatchNorm2d, i.e. library code (MIOpen); what this
+module adds is the MI355X execution form: bf16 autocast + torch.channels_last end to end, fed by the channels-last
+BEV scatter (`HeightCompression` with CHANNELS_LAST) so that no layout conversion sits between the sparse backbone
+and the first convolution.  Target assignment, losses and box decoding of CenterHead (center_head.py:100-369) stay
+with the reference's Python (out of scope)."""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if not hasattr(cfg, 'get') else cfg.get(key, default)
+
+
+class BaseBEVBackbone(nn.Module):
+    """base_bev_backbone.py:6-112."""
+
+    def __init__(self, model_cfg, input_channels, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.compute_dtype = compute_dtype
+        layer_nums = list(_get(model_cfg, 'LAYER_NUMS', None) or [])
+        layer_strides = list(_get(model_cfg, 'LAYER_STRIDES', None) or [])
+        num_filters = list(_get(model_cfg, 'NUM_FILTERS', None) or [])
+        assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        upsample_strides = list(_get(model_cfg, 'UPSAMPLE_STRIDES', None) or [])
+        num_upsample_filters = list(_get(model_cfg, 'NUM_UPSAMPLE_FILTERS', None) or [])
+        assert len(upsample_strides) == len(num_upsample_filters)
+        bn = lambda c: nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+        c_in_list = [input_channels, *num_filters[:-1]]
+        self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList()
+        for idx in range(len(layer_nums)):
+            layers = [nn.ZeroPad2d(1),
+                      nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
+                                bias=False), bn(num_filters[idx]), nn.ReLU()]
+            for _ in range(layer_nums[idx]):
+                layers += [nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
+                           bn(num_filters[idx]), nn.ReLU()]
+            self.blocks.append(nn.Sequential(*layers))
+            if upsample_strides:
+                stride = upsample_strides[idx]
+                if stride >= 1:
+                    up = nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False)
+                else:
+                    k = int(np.round(1 / stride))
+                    up = nn.Conv2d(num_filters[idx], num_upsample_filters[idx], k, stride=k, bias=False)
+                self.deblocks.append(nn.Sequential(up, bn(num_upsample_filters[idx]), nn.ReLU()))
+        c_in = sum(num_upsample_filters)
+        if len(upsample_strides) > len(layer_nums):
+            self.deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                bn(c_in), nn.ReLU()))
+        self.num_bev_features = c_in
+
+    def forward(self, data_dict):
+        spatial_features = data_dict['spatial_features']
+        with torch.autocast('cuda', dtype=self.compute_dtype, enabled=spatial_features.is_cuda
+                            and self.compute_dtype != torch.float32):
+            x = spatial_features
+            if x.is_cuda and not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)      # (the NHWC scatter makes this a no-op)
+            ups = []
+            for i in range(len(self.blocks)):
+                x = self.blocks[i](x)
+                stride = int(spatial_features.shape[2] / x.shape[2])
+                data_dict['spatial_features_%dx' % stride] = x
+                ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+            if len(ups) > 1:
+                x = torch.cat(ups, dim=1)
+            elif len(ups) == 1:
+                x = ups[0]
+            if len(self.deblocks) > len(self.blocks):
+                x = self.deblocks[-1](x)
+        data_dict['spatial_features_2d'] = x
+        return data_dict
+
+
+class SeparateHead(nn.Module):
+    """center_head.py:11-46."""
+
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name, spec in sep_head_dict.items():
+            fc = []
+            for _ in range(spec['num_conv'] - 1):
+                fc.append(nn.Sequential(nn.Conv2d(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
+                                        nn.BatchNorm2d(input_channels), nn.ReLU()))
+            fc.append(nn.Conv2d(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*fc)
+            if 'hm' in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.kaiming_normal_(m.weight.data)
+                        if m.bias is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(cur_name, fc)
+
+    def forward(self, x):
+        return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+
+
+class CenterHeadTowers(nn.Module):
+    """The convolutional part of CenterHead (center_head.py:75-99 construction, :337-345 forward): `shared_conv` and
+    `heads_list` with the reference's names, returning the list of prediction dicts that `assign_targets` / `get_loss`
+    / `generate_predicted_boxes` consume."""
+
+    def __init__(self, model_cfg, input_channels, class_names_each_head, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        shared = _get(model_cfg, 'SHARED_CONV_CHANNEL')
+        use_bias = bool(_get(model_cfg, 'USE_BIAS_BEFORE_NORM', False))
+        self.shared_conv = nn.Sequential(nn.Conv2d(input_channels, shared, 3, stride=1, padding=1, bias=use_bias),
+                                         nn.BatchNorm2d(shared), nn.ReLU())
+        head_cfg = _get(model_cfg, 'SEPARATE_HEAD_CFG')
+        self.heads_list = nn.ModuleList()
+        for names in class_names_each_head:
+            d = copy.deepcopy(dict(_get(head_cfg, 'HEAD_DICT')))
+            d['hm'] = dict(out_channels=len(names), num_conv=_get(model_cfg, 'NUM_HM_CONV'))
+            self.heads_list.append(SeparateHead(shared, d, init_bias=-2.19, use_bias=use_bias))
+
+    def forward(self, data_dict):
+        x = data_dict['spatial_features_2d']
+        with torch.autocast('cuda', dtype=self.compute_dtype, enabled=x.is_cuda and self.compute_dtype != torch.float32):
+            x = self.shared_conv(x)
+            data_dict['pred_dicts'] = [head(x) for head in self.heads_list]
+        return data_dict
+
+
+CENTERPOINT_BACKBONE_2D = dict(LAYER_NUMS=[5, 5], LAYER_STRIDES=[1, 2], NUM_FILTERS=[128, 256],
+                               UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[256, 256])   # centerpoint.yaml:19-26
+CENTERPOINT_HEAD = dict(SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
+                        SEPARATE_HEAD_CFG=dict(HEAD_ORDER=['center', 'center_z', 'dim', 'rot'], HEAD_DICT={
+                            'center': {'out_channels': 2, 'num_conv': 2}, 'center_z': {'out_channels': 1, 'num_conv': 2},
+                            'dim': {'out_channels': 3, 'num_conv': 2}, 'rot': {'out_channels': 2, 'num_conv': 2}}))

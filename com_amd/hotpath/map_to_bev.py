@@ -10,15 +10,22 @@ def _cfg_get(cfg, name):
 
 
 class HeightCompression(nn.Module):
+    """height_compression.py:10-26.  Optional key CHANNELS_LAST (not in the reference configs): return
+    `spatial_features` [B, C*D, H, W] in torch.channels_last memory format, written that way by the scatter kernel,
+    for the bf16 MIOpen convolutions of the dense BEV stack (com_amd.hotpath.dense2d)."""
+
     def __init__(self, model_cfg, **kwargs):
         super().__init__()
         self.model_cfg = model_cfg
         self.num_bev_features = _cfg_get(model_cfg, 'NUM_BEV_FEATURES')
+        get = model_cfg.get if hasattr(model_cfg, 'get') else (lambda k, d=None: getattr(model_cfg, k, d))
+        self.channels_last = bool(get('CHANNELS_LAST', False))
 
     def forward(self, batch_dict):
         sp = batch_dict['encoded_spconv_tensor']
         # dense() + view(N, C*D, H, W) in one kernel; channel index = c*D + z (height_compression.py:22-23)
-        spatial_features = Fsp.bev_dense(sp.features, sp.indices, sp.batch_size, sp.spatial_shape, sp.num_rows)
+        spatial_features = Fsp.bev_dense(sp.features, sp.indices, sp.batch_size, sp.spatial_shape, sp.num_rows,
+                                         self.channels_last)
         batch_dict['spatial_features'] = spatial_features
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict

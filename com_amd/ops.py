@@ -776,16 +776,25 @@ def wgrad_reduce_batched(jobs):
 
 
 # ---------------------------------------------------------------------------------------------
-def bev_scatter(features, indices, batch_size, spatial_shape, channels=None, n_dev=None):
-    """dense() + view(N, C*D, H, W): height_compression.py:20-25; D == 1 is PointPillarScatter."""
+def bev_scatter(features, indices, batch_size, spatial_shape, channels=None, n_dev=None, channels_last=False):
+    """dense() + view(N, C*D, H, W): height_compression.py:20-25; D == 1 is PointPillarScatter.
+    channels_last=True: the same [N, C*D, H, W] tensor in torch.channels_last memory format (pcd_bev_scatter_nhwc)."""
     _require_cuda(features, indices)
     assert features.is_contiguous() and indices.dtype == torch.int32 and indices.is_contiguous()
     D, H, W = _triple(spatial_shape)
     n, cs = features.shape
     C = channels if channels is not None else cs
     lib = L.lib()
-    out = torch.empty((batch_size, C * D, H, W), dtype=features.dtype, device=features.device)
     ws = _ws(lib.pcd_bev_workspace_bytes(batch_size, D, H, W), features.device)
+    if channels_last:
+        out = torch.empty((batch_size, H, W, C * D), dtype=features.dtype, device=features.device)
+        e = features.element_size()
+        with _Timed("bev_scatter_nhwc", lambda: dict(bytes=n * (C * e + 16) + out.numel() * e, flops=0, rows=n, pairs=0)):
+            L.check(lib.pcd_bev_scatter_nhwc(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n,
+                                             L.ptr(n_dev), batch_size, D, H, W, L.ptr(out), L.ptr(ws), ws.numel(),
+                                             L.stream_ptr()), "pcd_bev_scatter_nhwc")
+        return out.permute(0, 3, 1, 2)
+    out = torch.empty((batch_size, C * D, H, W), dtype=features.dtype, device=features.device)
     e = features.element_size()                  # SURVEY 8d: read N5 (C e + 16), write B C D H W e
     with _Timed("bev_scatter", lambda: dict(bytes=n * (C * e + 16) + out.numel() * e, flops=0, rows=n, pairs=0)):
         L.check(lib.pcd_bev_scatter(L.ptr(features), C, cs, _dtype_code(features), L.ptr(indices), n, L.ptr(n_dev),
@@ -794,9 +803,8 @@ def bev_scatter(features, indices, batch_size, spatial_shape, channels=None, n_d
     return out
 
 
-def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None, n_dev=None):
+def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None, n_dev=None, channels_last=False):
     _require_cuda(dout, indices)
-    dout = dout.contiguous()
     D, H, W = _triple(spatial_shape)
     n = indices.shape[0]
     cs = c_stride if c_stride is not None else channels
@@ -804,6 +812,15 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
         df = torch.zeros((n, cs), dtype=dout.dtype, device=dout.device)
     else:
         df = torch.empty((n, cs), dtype=dout.dtype, device=dout.device)
+    if channels_last:
+        dout = dout.contiguous(memory_format=torch.channels_last)        # memory = [B][H][W][C*D]
+        e = dout.element_size()
+        with _Timed("bev_gather_nhwc", lambda: dict(bytes=n * (2 * channels * e + 16), flops=0, rows=n, pairs=0)):
+            L.check(L.lib().pcd_bev_gather_nhwc(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n,
+                                                L.ptr(n_dev), batch_size, D, H, W, L.ptr(df), L.stream_ptr()),
+                    "pcd_bev_gather_nhwc")
+        return df
+    dout = dout.contiguous()
     e = dout.element_size()
     with _Timed("bev_gather", lambda: dict(bytes=n * (2 * channels * e + 16), flops=0, rows=n, pairs=0)):
         L.check(L.lib().pcd_bev_gather(L.ptr(dout), channels, cs, _dtype_code(dout), L.ptr(indices), n,

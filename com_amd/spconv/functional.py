@@ -267,7 +267,7 @@ class BevDenseFunction(Function):
     """SparseConvTensor.dense() fused with the [B, C*D, H, W] view; backward = gather."""
 
     @staticmethod
-    def forward(ctx, features, indices, batch_size, spatial_shape, n_dev=None):
+    def forward(ctx, features, indices, batch_size, spatial_shape, n_dev=None, channels_last=False):
         f = features.detach().contiguous()
         if f.dtype not in (torch.float32, torch.bfloat16):
             f = f.float()
@@ -275,19 +275,20 @@ class BevDenseFunction(Function):
         c = f.shape[1]
         if pad:
             f = torch.nn.functional.pad(f, (0, pad))
-        out = ops.bev_scatter(f, indices, batch_size, spatial_shape, channels=c, n_dev=n_dev)
-        ctx.meta = (indices, batch_size, list(spatial_shape), c, n_dev)
+        nhwc = bool(channels_last) and pad == 0
+        out = ops.bev_scatter(f, indices, batch_size, spatial_shape, channels=c, n_dev=n_dev, channels_last=nhwc)
+        ctx.meta = (indices, batch_size, list(spatial_shape), c, n_dev, nhwc)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        indices, batch_size, spatial_shape, c, n_dev = ctx.meta
-        df = ops.bev_gather(dout, indices, batch_size, spatial_shape, c, n_dev=n_dev)
-        return df, None, None, None, None
+        indices, batch_size, spatial_shape, c, n_dev, nhwc = ctx.meta
+        df = ops.bev_gather(dout, indices, batch_size, spatial_shape, c, n_dev=n_dev, channels_last=nhwc)
+        return df, None, None, None, None, None
 
 
-def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None):
-    return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev)
+def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None, channels_last=False):
+    return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev, channels_last)
 
 
 def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):

@@ -316,6 +316,16 @@ int pcd_bev_scatter(const void *features, int c, int c_stride, int dtype, const 
                     void *workspace, size_t workspace_bytes, void *stream);
 int pcd_bev_gather(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
                    const int32_t *n_dev, int batch, int d, int h, int w, void *dfeatures, void *stream);
+/* channels-last variants: out / dout are [batch][h][w][c * d] (channel = c * d + z), i.e. the
+ * torch.channels_last layout of the [batch, c * d, h, w] tensor HeightCompression returns
+ * (height_compression.py:20-25) -- what MIOpen's bf16 convolutions of BaseBEVBackbone / CenterHead
+ * (base_bev_backbone.py:30-112, center_head.py:75-99) consume without a layout change.  c % 8 == 0 (bf16) / 4 (f32),
+ * d <= 8. */
+int pcd_bev_scatter_nhwc(const void *features, int c, int c_stride, int dtype, const int32_t *indices, int n,
+                         const int32_t *n_dev, int batch, int d, int h, int w, void *out, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int pcd_bev_gather_nhwc(const void *dout, int c, int c_stride, int dtype, const int32_t *indices, int n,
+                        const int32_t *n_dev, int batch, int d, int h, int w, void *dfeatures, void *stream);
 
 /* ============================================================================================
  * (a11) fused sparse epilogue -- replaces the nn.BatchNorm1d(eps=1e-3, momentum=0.01) -> (+ residual)

@@ -1,0 +1,91 @@
+"""GPU: channels-last BEV hand-off and the dense BEV stack.
+
+  * pcd_bev_scatter_nhwc / pcd_bev_gather_nhwc are pure data movement: BIT-EXACT against the NCHW kernels (which
+    are pinned by the reference HeightCompression fixture G5) and against the reference formula
+    dense().view(N, C*D, H, W) on fixture G5 itself;
+  * BaseBEVBackbone + CenterHeadTowers in bf16 / channels_last against the SAME modules run in float32 NCHW by plain
+    torch (the reference's arithmetic for these layers is exactly torch's conv2d / BatchNorm2d): relative L2 of
+    every output <= 6e-2 (bf16 storage noise through 12-14 conv+BatchNorm layers with random weights: measured 3.2e-2), state-dict names equal to the reference's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nhwc_scatter_gather_bit_exact(golden, dtype):
+    from com_amd import ops
+    g = golden("g5_dense")
+    B, C, D, H, W = [int(v) for v in g["shape"]]
+    # pad C (6) to 8 channels so that both element types have whole 16-byte pieces
+    feat = torch.zeros((g["features"].shape[0], 8), dtype=dtype, device=DEV)
+    feat[:, :C] = torch.from_numpy(g["features"]).to(DEV).to(dtype)
+    idx = torch.from_numpy(g["indices"]).to(DEV)
+    nchw = ops.bev_scatter(feat, idx, B, [D, H, W])
+    nhwc = ops.bev_scatter(feat, idx, B, [D, H, W], channels_last=True)
+    assert nhwc.shape == nchw.shape and nhwc.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(nhwc.contiguous(), nchw)
+    ref = torch.from_numpy(g["spatial_features"]).to(DEV).to(dtype)        # reference HeightCompression output
+    assert torch.equal(nhwc.contiguous().view(B, 8, D, H, W)[:, :C].reshape(B, C * D, H, W), ref)
+    dout = torch.randn(nchw.shape, device=DEV).to(dtype)
+    ga = ops.bev_gather(dout, idx, B, [D, H, W], 8)
+    gb = ops.bev_gather(dout.contiguous(memory_format=torch.channels_last), idx, B, [D, H, W], 8, channels_last=True)
+    assert torch.equal(ga, gb)
+
+
+def test_height_compression_channels_last_module_and_autograd():
+    from com_amd import hotpath, spconv
+    torch.manual_seed(0)
+    B, D, H, W, C = 2, 2, 24, 20, 128
+    lin = torch.randperm(B * D * H * W)[:300].sort()[0]
+    idx = torch.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).int().to(DEV)
+    feat = torch.randn(300, C, device=DEV).bfloat16().requires_grad_(True)
+    outs = []
+    for cl in (False, True):
+        sp = spconv.SparseConvTensor(feat, idx, [D, H, W], B)
+        m = hotpath.HeightCompression({"NUM_BEV_FEATURES": C * D, "CHANNELS_LAST": cl})
+        bd = m({"encoded_spconv_tensor": sp, "encoded_spconv_tensor_stride": 8})
+        sf = bd["spatial_features"]
+        assert sf.is_contiguous(memory_format=torch.channels_last) == cl
+        w = torch.arange(sf.numel(), device=DEV, dtype=torch.float32).reshape(sf.shape).remainder(7.0).bfloat16()
+        feat.grad = None
+        (sf * w).sum().backward()
+        outs.append((sf.detach().contiguous(), feat.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_dense_bev_stack_bf16_channels_last_vs_torch_fp32():
+    from com_amd.hotpath import dense2d
+    torch.manual_seed(1)
+    B, H, W = 2, 48, 40
+    bb = dense2d.BaseBEVBackbone(dense2d.CENTERPOINT_BACKBONE_2D, 256).to(DEV)
+    head = dense2d.CenterHeadTowers(dense2d.CENTERPOINT_HEAD, bb.num_bev_features, [['Vehicle', 'Pedestrian', 'Cyclist']]).to(DEV)
+    # the reference's names (base_bev_backbone.py:28-79, center_head.py:75-99)
+    names = set(dict(bb.named_parameters())) | set(dict(head.named_parameters()))
+    for k in ("blocks.0.1.weight", "blocks.1.16.weight", "deblocks.1.0.weight", "deblocks.0.1.bias",
+              "shared_conv.0.bias", "heads_list.0.hm.1.bias", "heads_list.0.center.0.1.weight", "heads_list.0.rot.1.weight"):
+        assert k in names, k
+    assert bb.num_bev_features == 512
+    x = torch.randn(B, 256, H, W, device=DEV) * (torch.rand(B, 1, H, W, device=DEV) < 0.15)   # sparse BEV map
+    bb.train(); head.train()
+
+    def run(xin, dtype):
+        bb.compute_dtype = head.compute_dtype = dtype
+        for m in list(bb.modules()) + list(head.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        d = head(bb({"spatial_features": xin}))
+        outs = {"spatial_features_2d": d["spatial_features_2d"]}
+        outs.update({"pred_" + k: v for k, v in d["pred_dicts"][0].items()})
+        return outs
+
+    ref = run(x, torch.float32)
+    got = run(x.bfloat16().contiguous(memory_format=torch.channels_last), torch.bfloat16)
+    assert got["spatial_features_2d"].dtype == torch.bfloat16
+    assert got["spatial_features_2d"].is_contiguous(memory_format=torch.channels_last)
+    assert ref["spatial_features_2d"].shape == (B, 512, H, W) and ref["pred_hm"].shape == (B, 3, H, W)
+    for k in ref:
+        e = float((got[k].detach().float() - ref[k].detach()).norm() / (ref[k].detach().norm() + 1e-12))
+        assert e < 6e-2, (k, e)
