@@ -84,6 +84,12 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_fp8_packed_weight_bytes": (_sz, [_i, _i, _i]),
+    "pcd_fp8_pack_weight": (_i, [_vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]),
+    "pcd_fp8_quantize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, ctypes.c_float, _vp, _vp]),
+    "pcd_fp8_dequantize": (_i, [_vp, _sz, ctypes.c_float, _vp, _vp]),
+    "pcd_sparse_conv_gather_gemm_fp8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i,
+                                             ctypes.c_float, _vp, _i, _i, _vp]),
     "pcd_pillar_decorate": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pcd_pfn_relu_pool": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_pfn_relu_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -813,20 +813,27 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
         if (!valid || (dbg & 4)) return;
         const char *ab = awave + SLOT * A_STAGE;
         const char *wb = wring + SLOT * W_STAGE;
+        // all operand fragments of the stage (2 contraction steps) are requested up front, then consumed in order:
+        // the LDS returns in issue order, so the MFMAs of step 0 start when its fragments have landed while those
+        // of step 1 are still in flight (the compiler's own schedule kept ~3 reads ahead of the MFMAs: with one
+        // consumer wave per SIMD that exposed an LDS latency every few MFMAs)
+        bf16x8 xa[2][MI], bw[2][NB];
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs) {
-            bf16x8 xa[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                xa[mi] = *reinterpret_cast<const bf16x8 *>(ab + mi * 2048 + a_lane + (((unsigned)(cs * 4 + g) ^ a_swz) << 4));
+                xa[cs][mi] = *reinterpret_cast<const bf16x8 *>(ab + mi * 2048 + a_lane + (((unsigned)(cs * 4 + g) ^ a_swz) << 4));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
+            for (int nb = 0; nb < NB; ++nb)
+                bw[cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)   // (a 16-row tile without neighbours holds zeros: no branch per MFMA)
-                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, xa[mi], acc[mi][nb], 0, 0, 0);
-            }
-        }
+                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[cs][nb], xa[cs][mi], acc[mi][nb], 0, 0, 0);
     };
 #define GGW_CONSUMER_STEP(SLOT_TAG, STAGE)                                                                 \
     do {                                                                                                   \

@@ -398,6 +398,30 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
+ * (g) fp8 feature path (BASELINE config 5; build-side precision, the reference is fp32): OCP e4m3 activations and
+ *     weights with per-tensor scales, fp32 accumulation (v_mfma_f32_16x16x32_fp8_fp8), for the INFERENCE form of
+ *     post_act_block (spconv_backbone.py:8-27): conv + eval BatchNorm + ReLU + quantisation of the next layer's
+ *     input in ONE kernel.
+ *   pcd_fp8_pack_weight: weight [Cout][K][Cin] f32 -> e4m3(weight * scale_inv) in MFMA fragment order;
+ *       cin_pad = power of two >= 16 (the fp8 row width of the input features).
+ *   pcd_fp8_quantize: x [n][c] (PCD_F32 / PCD_BF16, row stride c_stride) -> e4m3(x * scale_inv) [n][cb], zero padded.
+ *   pcd_fp8_dequantize: count e4m3 bytes -> f32 * scale.
+ *   pcd_sparse_conv_gather_gemm_fp8: y[o][c] = q( relu?( (sum_k x8[nbr[k][o]] . w8[k][:, c]) * alpha[c] + beta[c] ) ),
+ *       alpha = x_scale * w_scale * gamma / sqrt(var + eps), beta = bn_beta - mean * gamma / sqrt(var + eps) (or any
+ *       per-channel affine); y_kind 0: f32, 1: bf16, 2: e4m3(value * out_scale_inv); y_stride in elements.
+ * ============================================================================================ */
+size_t pcd_fp8_packed_weight_bytes(int kvol, int cin_pad, int cout);
+int pcd_fp8_pack_weight(const float *weight, int kvol, int cin, int cin_pad, int cout, float scale_inv, void *packed,
+                        void *stream);
+int pcd_fp8_quantize(const void *x, int dtype, int n, const int32_t *n_dev, int c, int c_stride, int cb,
+                     float scale_inv, void *out, void *stream);
+int pcd_fp8_dequantize(const void *x8, size_t count, float scale, float *out, void *stream);
+int pcd_sparse_conv_gather_gemm_fp8(const void *x8, int n_rows_in, int cin_pad, const void *packed_w, const int32_t *nbr,
+                                    int nbr_stride, int kvol, int flip_k, int n_rows_out,
+                                    const int32_t *n_rows_out_dev, int c_out, const float *alpha, const float *beta,
+                                    int relu, float out_scale_inv, void *y, int y_kind, int y_stride, void *stream);
+
+/* ============================================================================================
  * (a6) PillarVFE pieces -- pcdet/models/backbones_3d/vfe/pillar_vfe.py:94-118 (decoration + padding mask) and the
  *      ReLU / max-over-points / concatenation half of PFNLayer (pillar_vfe.py:40-49).  float32.
  *   pcd_pillar_decorate: voxels [m][T][C] (zero padded), num_points [m], coords [m][4] (b, z, y, x) ->

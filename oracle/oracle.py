@@ -314,3 +314,33 @@ def nms_bev(boxes_sorted, thresh, normal=False):
     lib().orc_nms_bev.restype = ctypes.c_int
     k = lib().orc_nms_bev(_p(b), b.shape[0], ctypes.c_float(thresh), int(bool(normal)), _p(keep))
     return keep[:k].copy()
+
+
+# ---------------------------------------------------------------------------------------------
+def fp8_e4m3_round(a):
+    """float32 -> OCP e4m3 (FN: no infinities, max 448, saturating, round to nearest even, subnormals of 2^-9) ->
+    float32, value-level restatement of the format definition (OCP 8-bit Floating Point Specification v1.0)."""
+    a = np.asarray(a, np.float64)
+    s = np.sign(a)
+    m = np.minimum(np.abs(a), 448.0)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(m > 0, m, 1.0)))
+    e = np.maximum(e, -6.0)                        # below 2^-6 the spacing stays 2^-9 (subnormals)
+    step = 2.0 ** (e - 3)                          # 3 mantissa bits
+    q = np.round(m / step) * step                  # numpy rounds half to even
+    q = np.minimum(q, 448.0)
+    return (s * q).astype(np.float32)
+
+
+def fp8_e4m3_bits(a):
+    """float32 values that ARE e4m3-representable -> their 8-bit encodings (uint8)."""
+    a = np.asarray(a, np.float64)
+    sign = (np.signbit(a)).astype(np.uint8) << 7
+    m = np.abs(a)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(m > 0, m, 1.0)))
+    sub = m < 2.0 ** -6
+    e = np.where(sub, -6.0, e)
+    frac = np.where(sub, m / 2.0 ** -9, (m / 2.0 ** e - 1.0) * 8.0)
+    exp_field = np.where(sub, 0, e + 7).astype(np.int64)
+    return (sign | (exp_field.astype(np.uint8) << 3) | np.round(frac).astype(np.uint8)).astype(np.uint8)
