@@ -84,6 +84,14 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_ball_query_stack": (_i, [_i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_group_points_stack": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_group_points_stack_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_stack_farthest_point_sampling": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_three_nn_stack": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_three_interpolate_stack": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_three_interpolate_stack_grad": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pcd_voxel_query_stack": (_i, [_i, _i, _i, _i, _i, ctypes.c_float, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_fp8_packed_weight_bytes": (_sz, [_i, _i, _i]),
     "pcd_fp8_pack_weight": (_i, [_vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]),
     "pcd_fp8_quantize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, ctypes.c_float, _vp, _vp]),

@@ -398,6 +398,37 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
+ * (f4) PV-RCNN stage-2 natives -- the stacked-batch PointNet++ ops of pcdet/ops/pointnet2/pointnet2_stack (binder
+ *      src/pointnet2_api.cpp; Python callers pointnet2_utils.py:8-303, voxel_query_utils.py:9-47).  "Stacked": the
+ *      points of all batch elements are concatenated, *_batch_cnt[B] (device int32) give the counts.  Semantics are
+ *      the reference kernels' (first nsample hits in ascending index, their tie rules); float32 / int32.
+ *   pcd_ball_query_stack        ball_query_gpu.cu:16-66   idx [M][nsample]; row 0 = -1 when the ball is empty
+ *   pcd_group_points_stack      group_points_gpu.cu:76-107 out [M][C][nsample] (+ _grad: scatter-add, atomics)
+ *   pcd_stack_farthest_point_sampling  sampling_gpu.cu:188-327 (temp must be filled with 1e10 by the caller)
+ *   pcd_three_nn_stack          interpolate_gpu.cu:16-76  dist2 [N][3] (squared), idx [N][3] (global row ids)
+ *   pcd_three_interpolate_stack interpolate_gpu.cu:100-117 (+ _grad :140-155, atomics)
+ *   pcd_voxel_query_stack       voxel_query_gpu.cu:10-88
+ * ============================================================================================ */
+int pcd_ball_query_stack(int B, int M, float radius, int nsample, const float *new_xyz, const int32_t *new_xyz_batch_cnt,
+                         const float *xyz, const int32_t *xyz_batch_cnt, int32_t *idx, void *stream);
+int pcd_group_points_stack(int B, int M, int C, int nsample, const float *features, const int32_t *features_batch_cnt,
+                           const int32_t *idx, const int32_t *idx_batch_cnt, float *out, void *stream);
+int pcd_group_points_stack_grad(int B, int M, int C, int nsample, const float *grad_out, const int32_t *idx,
+                                const int32_t *idx_batch_cnt, const int32_t *features_batch_cnt,
+                                float *grad_features_zeroed, void *stream);
+int pcd_stack_farthest_point_sampling(int B, const float *xyz, float *temp_1e10, const int32_t *xyz_batch_cnt,
+                                      int32_t *idxs, const int32_t *num_sampled_points, void *stream);
+int pcd_three_nn_stack(int B, int N, const float *unknown, const int32_t *unknown_batch_cnt, const float *known,
+                       const int32_t *known_batch_cnt, float *dist2, int32_t *idx, void *stream);
+int pcd_three_interpolate_stack(int N, int C, const float *features, const int32_t *idx, const float *weight, float *out,
+                                void *stream);
+int pcd_three_interpolate_stack_grad(int N, int C, const float *grad_out, const int32_t *idx, const float *weight,
+                                     float *grad_features_zeroed, void *stream);
+int pcd_voxel_query_stack(int M, int R1, int R2, int R3, int nsample, float radius, int z_range, int y_range, int x_range,
+                          const float *new_xyz, const float *xyz, const int32_t *new_coords, const int32_t *point_indices,
+                          int32_t *idx, void *stream);
+
+/* ============================================================================================
  * (g) fp8 feature path (BASELINE config 5; build-side precision, the reference is fp32): OCP e4m3 activations and
  *     weights with per-tensor scales, fp32 accumulation (v_mfma_f32_16x16x32_fp8_fp8), for the INFERENCE form of
  *     post_act_block (spconv_backbone.py:8-27): conv + eval BatchNorm + ReLU + quantisation of the next layer's

@@ -344,3 +344,124 @@ def fp8_e4m3_bits(a):
     frac = np.where(sub, m / 2.0 ** -9, (m / 2.0 ** e - 1.0) * 8.0)
     exp_field = np.where(sub, 0, e + 7).astype(np.int64)
     return (sign | (exp_field.astype(np.uint8) << 3) | np.round(frac).astype(np.uint8)).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# PV-RCNN stage-2 natives: numpy restatements of the reference kernels' sequential semantics
+def _batch_starts(cnt):
+    cnt = np.asarray(cnt, np.int64)
+    return np.concatenate([[0], np.cumsum(cnt)])
+
+
+def ball_query_stack(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt):
+    """ball_query_gpu.cu:16-66 (+ the caller's empty-ball handling, pointnet2_utils.py:36-37)."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    xs, ns = _batch_starts(xyz_cnt), _batch_starts(new_cnt)
+    idx = np.zeros((new_xyz.shape[0], nsample), np.int32)
+    r2 = np.float32(radius) * np.float32(radius)
+    for b in range(len(xyz_cnt)):
+        pts = xyz[xs[b]:xs[b + 1]]
+        for q in range(ns[b], ns[b + 1]):
+            d = pts - new_xyz[q]
+            d2 = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+            d2 = (d2 + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            hits = np.nonzero(d2 < r2)[0][:nsample]
+            if len(hits) == 0:
+                idx[q, 0] = -1
+            else:
+                idx[q, :] = hits[0]
+                idx[q, :len(hits)] = hits
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def stack_fps(xyz, xyz_cnt, npoint):
+    """sampling_gpu.cu:188-327 incl. the tie rule of its 1024-slot reduction tree."""
+    xyz = _f32(xyz)
+    xs = _batch_starts(xyz_cnt)
+    out = []
+    rev = np.array([int(format(t, "010b")[::-1], 2) for t in range(1024)])
+    for b, m in enumerate(npoint):
+        pts = xyz[xs[b]:xs[b + 1]]
+        n = pts.shape[0]
+        temp = np.full((n,), 1e10, np.float32)
+        old = 0
+        sel = [xs[b]]
+        for _ in range(1, m):
+            d = pts - pts[old]
+            d2 = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+            d2 = (d2 + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            temp = np.minimum(d2, temp)
+            best = temp.max()
+            cand = np.nonzero(temp == best)[0]
+            if len(cand) > 1:
+                key = rev[cand % 1024].astype(np.int64) * (1 << 32) + cand
+                old = int(cand[np.argmin(key)])
+            else:
+                old = int(cand[0])
+            sel.append(old + xs[b])
+        out += sel[:m]
+    return np.array(out, np.int32)
+
+
+def three_nn_stack(unknown, unknown_cnt, known, known_cnt):
+    """interpolate_gpu.cu:16-76 -> (squared distances [N, 3], global indices [N, 3])."""
+    unknown, known = _f32(unknown), _f32(known)
+    us, ks = _batch_starts(unknown_cnt), _batch_starts(known_cnt)
+    dist2 = np.zeros((unknown.shape[0], 3), np.float32)
+    idx = np.zeros((unknown.shape[0], 3), np.int32)
+    for b in range(len(known_cnt)):
+        kn = known[ks[b]:ks[b + 1]]
+        for q in range(us[b], us[b + 1]):
+            d = unknown[q] - kn
+            d2 = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+            d2 = (d2 + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            order = np.lexsort((np.arange(len(d2)), d2))[:3]          # strict '<' scan == sort by (d, index)
+            k = len(order)
+            dist2[q, :k] = d2[order]
+            idx[q, :k] = order + ks[b]
+            dist2[q, k:] = np.inf
+            idx[q, k:] = ks[b]
+    return dist2, idx
+
+
+def voxel_query_stack(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """voxel_query_gpu.cu:10-88."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, R1, R2, R3 = point_indices.shape
+    zr, yr, xr = max_range
+    idx = np.zeros((new_coords.shape[0], nsample), np.int32)
+    r2 = np.float32(radius) * np.float32(radius)
+    for q in range(new_coords.shape[0]):
+        b, cz, cy, cx = [int(v) for v in new_coords[q]]
+        cnt = 0
+        for dz in range(-zr, zr + 1):
+            z = cz + dz
+            if z < 0 or z >= R1:
+                continue
+            for dy in range(-yr, yr + 1):
+                y = cy + dy
+                if y < 0 or y >= R2:
+                    continue
+                for dx in range(-xr, xr + 1):
+                    x = cx + dx
+                    if x < 0 or x >= R3:
+                        continue
+                    nb = int(point_indices[b, z, y, x])
+                    if nb < 0:
+                        continue
+                    d = xyz[nb] - new_xyz[q]
+                    d2 = np.float32(np.float32(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1])) + np.float32(d[2] * d[2]))
+                    if d2 > r2:
+                        continue
+                    if cnt < nsample:
+                        if cnt == 0:
+                            idx[q, :] = nb
+                        idx[q, cnt] = nb
+                        cnt += 1
+        if cnt == 0:
+            idx[q, 0] = -1
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
