@@ -84,6 +84,9 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_centerhead_assign_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_centerhead_assign_targets": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, ctypes.c_float, _i, _vp,
+                                           _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcd_ball_query_stack": (_i, [_i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_group_points_stack": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_group_points_stack_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

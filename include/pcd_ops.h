@@ -398,6 +398,22 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
+ * (f2) CenterHead target assignment on the device -- replaces the per-object Python / CPU loop of
+ *      pcdet/models/dense_heads/center_head.py:104-161 (assign_target_of_single_head) for one head, all batch
+ *      elements at once (the caller's loop :163-225), incl. centernet_utils.py:46-107 (Gaussian radius, drawing).
+ *   gt_boxes [batch][n_boxes][code] f32 (x, y, z, dx, dy, dz, heading, ..., class), class 0 = padding;
+ *   class_map_host[n_class_map]: dataset class id -> 1-based id inside this head, 0 = not in this head;
+ *   outputs: heatmap [batch][head_classes][fm_h][fm_w] f32, ret_boxes [batch][num_max_objs][code] f32,
+ *   inds / mask [batch][num_max_objs] int64 (the reference's dtypes); all zero-filled by the call.
+ * ============================================================================================ */
+size_t pcd_centerhead_assign_workspace_bytes(int batch, int num_max_objs);
+int pcd_centerhead_assign_targets(const float *gt_boxes, int batch, int n_boxes, int code_size, const int *class_map_host,
+                                  int n_class_map, int head_classes, int fm_w, int fm_h, int feature_map_stride,
+                                  const float *voxel_size_xy_host, const float *range_xy_host, int num_max_objs,
+                                  float gaussian_overlap, int min_radius, float *heatmap, float *ret_boxes,
+                                  long long *inds, long long *mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ============================================================================================
  * (f4) PV-RCNN stage-2 natives -- the stacked-batch PointNet++ ops of pcdet/ops/pointnet2/pointnet2_stack (binder
  *      src/pointnet2_api.cpp; Python callers pointnet2_utils.py:8-303, voxel_query_utils.py:9-47).  "Stacked": the
  *      points of all batch elements are concatenated, *_batch_cnt[B] (device int32) give the counts.  Semantics are

@@ -19,7 +19,7 @@ installed here.  So the fixtures come from the two independent sources that ARE 
 Nothing from /root/reference is copied: only inputs and outputs (data) are stored.  The CPU
 oracle (oracle/) is then checked against these files by tests/test_oracle_golden.py.
 
-Usage:  python tests/golden/make_golden.py [g1 .. g8]   (needs /root/reference; not needed at test time;
+Usage:  python tests/golden/make_golden.py [g1 .. g9]   (needs /root/reference; not needed at test time;
         with names only those fixtures are regenerated)
 """
 import hashlib
@@ -549,13 +549,81 @@ def g8():
          total_steps=np.array([total]))
 
 
+# ---------------------------------------------------------------------------------------------
+# G9: CenterHead target assignment by the REFERENCE'S OWN code: `assign_target_of_single_head`
+# (pcdet/models/dense_heads/center_head.py:104-161) is extracted from the reference file at generation time (the module
+# itself cannot be imported: it pulls in the compiled iou3d_nms extension) and run with the reference's
+# centernet_utils (imported with an empty `numba` stand-in: its jit-decorated helpers are not used here) on a
+# 3-frame batch incl. the caller's per-head class filtering (center_head.py:193-207), for two head layouts.
+def g9():
+    import ast
+    import textwrap
+    sys.modules.setdefault("numba", types.SimpleNamespace(jit=lambda *a, **k: (lambda f: f)))
+    cu = ref_module("pcdet/models/model_utils", "centernet_utils", "refmu")
+    src = open(os.path.join(REF, "pcdet/models/dense_heads/center_head.py")).read()
+    fn_src = None
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name == "assign_target_of_single_head":
+            fn_src = textwrap.dedent(ast.get_source_segment(src, node))
+    ns = {"torch": torch, "centernet_utils": cu}
+    exec(compile(fn_src, "center_head.assign_target_of_single_head", "exec"), ns)
+    single = ns["assign_target_of_single_head"]
+    rng_xy, vs = synth.WAYMO_RANGE, synth.WAYMO_VOXEL
+    me = types.SimpleNamespace(point_cloud_range=list(rng_xy), voxel_size=list(vs))
+    class_names = ["Vehicle", "Pedestrian", "Cyclist"]
+    rng = np.random.default_rng(9)
+    B, M, H, W, stride, nmax = 3, 60, 188, 188, 8, 50
+    gt = np.zeros((B, M, 8), np.float32)
+    for b in range(B):
+        n = [40, 55, 7][b]
+        gt[b, :n, 0:2] = rng.uniform(-74, 74, (n, 2))
+        gt[b, :n, 2] = rng.uniform(-1, 2, n)
+        cls = rng.integers(1, 4, n)
+        gt[b, :n, 3] = np.where(cls == 1, rng.uniform(3.5, 12, n), rng.uniform(0.5, 2.0, n))
+        gt[b, :n, 4] = np.where(cls == 1, rng.uniform(1.6, 3.0, n), rng.uniform(0.4, 1.0, n))
+        gt[b, :n, 5] = rng.uniform(1.0, 3.0, n)
+        gt[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
+        gt[b, :n, 7] = cls
+    gt[0, 3, 0:2] = [75.3, -75.3]          # outside the range: clamped centre
+    gt[0, 4, 3] = 0.0                      # degenerate box: skipped, keeps its slot
+    gt[1, 0, 0:2] = [75.19, 75.19]         # last cell
+    out = {"gt_boxes": gt, "feature_map_size": np.array([H, W], np.int32), "stride": np.array([stride], np.int32),
+           "num_max_objs": np.array([nmax], np.int32)}
+    all_names = np.array(["bg", *class_names])
+    for tag, heads in (("one", [class_names]), ("two", [["Vehicle"], ["Pedestrian", "Cyclist"]])):
+        for hi, head in enumerate(heads):
+            hm, tb, ii, mm = [], [], [], []
+            for b in range(B):
+                cur = torch.from_numpy(gt[b].copy())
+                names = all_names[cur[:, -1].long().numpy()]
+                rows = []
+                for i, name in enumerate(names):                 # center_head.py:196-202
+                    if name not in head:
+                        continue
+                    t = cur[i].clone()
+                    t[-1] = head.index(name) + 1
+                    rows.append(t[None, :])
+                sel = torch.cat(rows, 0) if rows else cur[:0, :]
+                h, r, i_, m_ = single(me, num_classes=len(head), gt_boxes=sel, feature_map_size=[W, H],
+                                      feature_map_stride=stride, num_max_objs=nmax, gaussian_overlap=0.1, min_radius=2)
+                hm.append(h.numpy()); tb.append(r.numpy()); ii.append(i_.numpy()); mm.append(m_.numpy())
+            hm = np.stack(hm)
+            nz = np.nonzero(hm)
+            out[f"{tag}{hi}_heat_nz"] = np.stack(nz, 1).astype(np.int32)        # sparse form of the heat maps
+            out[f"{tag}{hi}_heat_val"] = hm[nz].astype(np.float32)
+            out[f"{tag}{hi}_boxes"] = np.stack(tb)
+            out[f"{tag}{hi}_inds"] = np.stack(ii)
+            out[f"{tag}{hi}_mask"] = np.stack(mm)
+    save("g9_center_targets", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
