@@ -159,7 +159,7 @@ def measure_roofline(step_fn, ms_per_step):
     groups = _profiled_groups(step_fn)
     if not groups:
         return None
-    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "wgrad"))}
+    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "ggw", "wgrad"))}
     name, g = max(conv_like.items() or groups.items(), key=lambda kv: kv[1]["ms"])
     out = _group_roofline(name, g)
     traffic, source = _pmc_traffic(name)

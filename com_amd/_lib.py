@@ -45,6 +45,7 @@ PROTOTYPES = {
     "pcd_sparse_conv_dgrad_classes_tiles": (_i, [_i, _i]),
     "pcd_sparse_conv_gather_gemm_tiles": (_i, [_i, _i, _i, _i, _i]),
     "pcd_sparse_conv_gather_gemm_tiles_dir": (_i, [_i, _i, _i, _i, _i, _i]),
+    "pcd_sparse_conv_gather_gemm_variant": (_i, [_i, _i, _i, _i, _i, _i]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_pairs_workspace_bytes": (_sz, [_i, _i]),

@@ -1590,6 +1590,12 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
     //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
     const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
+    if (tiles_only && tiles_only[0] == -12345) {       // variant query (pcd_sparse_conv_gather_gemm_variant)
+        static const int m = getenv("PCD_GGW") ? atoi(getenv("PCD_GGW")) : 1;
+        tiles_only[0] = (m && (c_in == 128 || (c_in == 64 && m >= 2 && m <= 4)) && (c_out == 64 || c_out == 128) &&
+                         x_bytes <= 0xFFFF0000u && !(is_dgrad && m == 6)) ? 1 : 0;
+        return PCD_OK;
+    }
     // PCD_GGW: 0 = off, 1 = on (default), 2..4 = on with MI rows-per-wave forced (also for C_in = 64), 6 = forward only
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
         x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 6)) {
@@ -1640,6 +1646,14 @@ extern "C" int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, in
 
 extern "C" int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out) {
     return pcd_sparse_conv_gather_gemm_tiles_dir(n_rows_in, c_in, kvol, n_rows_out, c_out, 0);
+}
+
+extern "C" int pcd_sparse_conv_gather_gemm_variant(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out,
+                                                   int is_dgrad) {
+    int v = -12345;
+    int rc = gg_dispatch(nullptr, n_rows_in, c_in, nullptr, nullptr, nullptr, 0, kvol, 0, n_rows_out > 0 ? n_rows_out : 1,
+                         nullptr, c_out, nullptr, PCD_BF16, nullptr, nullptr, &v, nullptr, is_dgrad ? 1 : 0);
+    return rc == PCD_OK ? v : rc;
 }
 
 // a class tile runs only 1..8 of the K offsets: little work per workgroup, so small tiles (more workgroups in

@@ -676,7 +676,12 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
         tiles = L.lib().pcd_sparse_conv_gather_gemm_tiles_dir(x.shape[0], x.shape[1], kvol, n_rows_out, c_out,
                                                               int(bool(flip_k) or bn_reduce.mode == 2))
         bnr = bn_reduce._struct(_tiles(tiles, "pcd_sparse_conv_gather_gemm_tiles_dir"), c_out, x.device)
-    with _Timed(f"gather_gemm_kernel<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
+    kname = "gather_gemm_kernel"
+    if PROFILE is not None:
+        dg = int(bool(flip_k) or (bn_reduce is not None and bn_reduce.mode == 2))
+        if L.lib().pcd_sparse_conv_gather_gemm_variant(x.shape[0], x.shape[1], kvol, n_rows_out, c_out, dg) == 1:
+            kname = "ggw_kernel"
+    with _Timed(f"{kname}<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
         L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
                                                     L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),

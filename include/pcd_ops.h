@@ -265,6 +265,9 @@ int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_r
 /* same for a launch that is a DATA GRADIENT (flip_k != 0 or bn_reduce->mode == 2): the library may pick a different
  * kernel (tile height) for the two directions */
 int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out, int is_dgrad);
+/* which kernel that launch runs: 0 = gather_gemm_kernel (fragment loads), 1 = ggw_kernel (LDS-DMA, loader / consumer
+ * waves); for profiling tools that group launches by kernel name */
+int pcd_sparse_conv_gather_gemm_variant(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out, int is_dgrad);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
  * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
