@@ -56,6 +56,8 @@ PROTOTYPES = {
     "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                                     _vp, _sz, _vp]),
+    "pcd_rulebook_conv_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp,
+                                     _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),

@@ -386,12 +386,36 @@ __device__ __forceinline__ int axis_out(int c, int p, int d, int s, int k, int n
     return (o * s == t && o < n_out) ? o : -1;
 }
 
+constexpr int CLS_MAX = 8;
+
+__device__ __forceinline__ int row_class(int4 c, int pd, int ph, int pw, int sd, int sh, int sw) {
+    return (((c.y + pd) % sd) * sh + ((c.z + ph) % sh)) * sw + ((c.w + pw) % sw);
+}
+
+// per block of 256 input rows: rows per stride-parity class -> blk_cnt[cls][blk]  (see "Parity classes" below)
+__device__ __forceinline__ void block_class_counts(int cls, int ncls, int *cnt /* LDS [CLS_MAX] */,
+                                                   int *__restrict__ blk_cnt) {
+    if (threadIdx.x < CLS_MAX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int q = 0; q < ncls; ++q) {
+        u64 m = __ballot(cls == q);
+        if (lane_id() == 0 && m) atomicAdd(&cnt[q], __popcll(m));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncls) blk_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// blk_cnt != NULL: the launch also counts the rows of every parity class (ncls of them) per block
 __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
-                                                        unsigned char *__restrict__ bytemap) {
+                                                        unsigned char *__restrict__ bytemap, int ncls,
+                                                        int *__restrict__ blk_cnt) {
+    __shared__ int ccnt[CLS_MAX];
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= eff_rows(n_dev, n)) return;
-    int4 c = idx[i];
+    const bool live = i < eff_rows(n_dev, n);
+    int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
+    if (blk_cnt) block_class_counts(live ? row_class(c, G.pd, G.ph, G.pw, G.sd, G.sh, G.sw) : -1, ncls, ccnt, blk_cnt);
+    if (!live) return;
     // validity is tested once per axis level (kd + nz*kh + nz*ny*kw tests instead of 3*K)
     for (int a = 0; a < G.kd; ++a) {
         const int oz = axis_out(c.y, G.pd, G.dd, G.sd, a, G.Do);
@@ -410,63 +434,244 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__
     }
 }
 
-// bytemap (32 cells = 32 bytes per thread, two 16-byte loads) -> occupancy bitmap words
-__global__ __launch_bounds__(256) void conv_pack_kernel(const uint4 *__restrict__ bytemap, size_t nwords,
-                                                        u32 *__restrict__ bitmap) {
-    size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= nwords) return;
-    uint4 lo = bytemap[2 * w], hi = bytemap[2 * w + 1];
-    const u32 v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+// ---- the scan over the occupancy bitmap, two launches without a spine kernel --------------------------------
+// pass 1 (conv_pack_sum_kernel): bytemap -> bitmap words, popcount of every block of PK_WORDS words -> bsums[blk]
+//         and, added up by atomics (integer: order-free), of every 64 blocks -> super[blk / 64];
+// pass 2 (conv_scan_emit_kernel): every block rebuilds its own base from at most (#supers + 63) of those sums --
+//         a few hundred L2-resident ints -- instead of waiting for a one-block spine scan in a launch of its own.
+constexpr int PK_WORDS = 1024;
+
+__device__ __forceinline__ u32 pack16(uint4 v) {   // 16 bytes of 0 / 1 -> 16 bits
+    const u32 q[4] = {v.x, v.y, v.z, v.w};
     u32 bits = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        // bytes are 0 / 1: gather bit 0 of each byte into 4 consecutive bits
-        u32 t = v[j] & 0x01010101u;
+    for (int j = 0; j < 4; ++j) {
+        u32 t = q[j] & 0x01010101u;
         t = (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
         bits |= t << (4 * j);
     }
-    bitmap[w] = bits;
+    return bits;
 }
 
-struct PopcWord {
-    const u32 *bitmap;
-    __device__ int operator()(int i) const { return __popc(bitmap[i]); }
-};
+__device__ __forceinline__ int block_sum(int v, int *lds /* [4] */) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int t = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return t;
+}
 
-__global__ __launch_bounds__(256) void conv_emit_out_kernel(const u32 *__restrict__ bitmap,
-                                                            const int *__restrict__ prefix,
-                                                            int nwords, ConvGeom G, int n_out,
-                                                            int32_t *out_indices) {
-    int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= nwords) return;
-    u32 bits = bitmap[w];
-    int r = prefix[w];
-    while (bits) {
-        int bpos = __ffs(bits) - 1;
-        bits &= bits - 1;
-        u32 key = ((u32)w << 5) + bpos;
-        int x = key % G.Wo;
-        u32 t = key / G.Wo;
-        int y = t % G.Ho;
-        t /= G.Ho;
-        int z = t % G.Do;
-        int b = t / G.Do;
-        if (r < n_out) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(b, z, y, x);
-        ++r;
+// one 16-byte piece (half a word) per lane and load, 8 loads in flight; lane pairs combine their halves
+__global__ __launch_bounds__(256) void conv_pack_sum_kernel(const uint4 *__restrict__ bytemap, size_t nwords,
+                                                            u32 *__restrict__ bitmap, int *__restrict__ bsums,
+                                                            int *__restrict__ super) {
+    __shared__ int lds[4];
+    const size_t h0 = (size_t)blockIdx.x * (2 * PK_WORDS) + threadIdx.x, nh = 2 * nwords;
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const size_t h = h0 + (size_t)j * 256;
+        v[j] = h < nh ? bytemap[h] : make_uint4(0, 0, 0, 0);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const size_t h = h0 + (size_t)j * 256;
+        const u32 mine = pack16(v[j]);
+        cnt += __popc(mine);
+        const u32 other = (u32)__shfl_xor((int)mine, 1, 64);
+        if (!(threadIdx.x & 1) && h < nh) bitmap[h >> 1] = mine | (other << 16);
+    }
+    const int total = block_sum(cnt, lds);
+    if (threadIdx.x == 0) {
+        bsums[blockIdx.x] = total;
+        if (total) atomicAdd(&super[blockIdx.x >> 6], total);
     }
 }
 
+__device__ __forceinline__ void fill_ff(void *p, size_t bytes, size_t tid, size_t nthreads) {   // bytes % 4 == 0
+    const size_t n16 = bytes / 16;
+    const uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (size_t e = tid; e < n16; e += nthreads) reinterpret_cast<uint4 *>(p)[e] = v;
+    if (tid < (bytes % 16) / 4) reinterpret_cast<u32 *>(p)[n16 * 4 + tid] = ~0u;
+}
+
+// blk_cnt[cls][blk] -> virtual row of the block's first row of that class (exclusive prefix inside the class +
+// the tile-aligned class start), vstart[0 .. ncls]; one WAVE per class, run by ONE block of 256 threads
+__device__ void class_offsets(int *blk_cnt, int nblk, int ncls, int tile, int *vstart, int *tot /* LDS [CLS_MAX] */,
+                              int *start /* LDS [CLS_MAX + 1] */) {
+    for (int q = threadIdx.x >> 6; q < ncls; q += 4) {
+        int *row = blk_cnt + (size_t)q * nblk;
+        int carry = 0;
+        // 8 chunks of 64 counts in flight: the loop is a chain of load latencies
+        for (int base = 0; base < nblk; base += 8 * 64) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 64 + lane_id();
+                v[u] = (i < nblk) ? row[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 64 + lane_id();
+                const int inc = wave_inclusive_scan(v[u]);
+                if (i < nblk) row[i] = carry + inc - v[u];
+                carry += __shfl(inc, 63);
+            }
+        }
+        if (lane_id() == 0) tot[q] = carry;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int vb = 0;
+        for (int c = 0; c < ncls; ++c) {
+            start[c] = vb;
+            vstart[c] = vb;
+            vb = (vb + tot[c] + tile - 1) / tile * tile;
+        }
+        vstart[ncls] = vb;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x >> 6; q < ncls; q += 4) {
+        int *row = blk_cnt + (size_t)q * nblk;
+        const int st = start[q];
+        for (int i = lane_id(); i < nblk; i += 64) row[i] += st;
+    }
+}
+
+struct ScanSide {          // what the scan launch does besides the scan (all optional)
+    int32_t *out_indices;  // emit the coordinates of the set cells (row = rank), rows < n_out only
+    int n_out;
+    void *fill_a;          // 0xFF fills (nbr_out, perm): spread over all blocks of the launch
+    size_t fill_a_bytes;
+    void *fill_b;
+    size_t fill_b_bytes;
+    int *blk_cnt;          // parity classes: the LAST block of the grid (an extra one) turns counts into offsets
+    int cls_nblk, ncls, cls_tile;
+    int *vstart;
+};
+
+// blocks [0, nblk): prefix[w] = number of set cells in words < w, n_out = all of them; out_indices.
+__global__ __launch_bounds__(256) void conv_scan_emit_kernel(const u32 *__restrict__ bitmap, int nwords, int nblk,
+                                                             const int *__restrict__ bsums,
+                                                             const int *__restrict__ super, int *__restrict__ prefix,
+                                                             int *__restrict__ n_out_dev, ConvGeom G, ScanSide S) {
+    __shared__ int lds[4];
+    __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
+    const int blk = blockIdx.x;
+    const bool cls_block = S.blk_cnt != nullptr && blk == (int)gridDim.x - 1;
+    if (cls_block) {
+        class_offsets(S.blk_cnt, S.cls_nblk, S.ncls, S.cls_tile, S.vstart, ctot, cstart);
+        return;
+    }
+    if (blk < nblk) {
+        const int w0 = blk * PK_WORDS + threadIdx.x * 4;
+        u32 b[4] = {0u, 0u, 0u, 0u};
+        if (w0 + 3 < nwords) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(bitmap + w0);
+            b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (w0 + j < nwords) ? bitmap[w0 + j] : 0u;
+        }
+        // base of this block: whole supers before it + the blocks of its own super before it
+        int acc = 0;
+        const int sb = blk >> 6;
+        for (int i = threadIdx.x; i < sb; i += 256) acc += super[i];
+        if ((int)threadIdx.x < (blk & 63)) acc += bsums[(sb << 6) + threadIdx.x];
+        const int base = block_sum(acc, lds);
+        if (blk == 0 && n_out_dev) {
+            int t = 0;
+            const int nsuper = (nblk + 63) >> 6;
+            for (int i = threadIdx.x; i < nsuper; i += 256) t += super[i];
+            t = block_sum(t, lds);
+            if (threadIdx.x == 0) *n_out_dev = t;
+        }
+        const int c0 = __popc(b[0]), c1 = __popc(b[1]), c2 = __popc(b[2]), c3 = __popc(b[3]);
+        int total;
+        const int ex = base + block_exclusive_scan(c0 + c1 + c2 + c3, lds, total);
+        const int pre[4] = {ex, ex + c0, ex + c0 + c1, ex + c0 + c1 + c2};
+        if (w0 + 3 < nwords) {
+            *reinterpret_cast<int4 *>(prefix + w0) = make_int4(pre[0], pre[1], pre[2], pre[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + j < nwords) prefix[w0 + j] = pre[j];
+        }
+        if (S.out_indices) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 bits = b[j];
+                int r = pre[j];
+                while (bits) {
+                    const int bpos = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    const u32 key = ((u32)(w0 + j) << 5) + bpos;
+                    const int x = key % G.Wo;
+                    u32 t = key / G.Wo;
+                    const int y = t % G.Ho;
+                    t /= G.Ho;
+                    const int z = t % G.Do;
+                    const int bq = t / G.Do;
+                    if (r < S.n_out) reinterpret_cast<int4 *>(S.out_indices)[r] = make_int4(bq, z, y, x);
+                    ++r;
+                }
+            }
+        }
+    }
+    const size_t nthreads = (size_t)(gridDim.x - (S.blk_cnt ? 1 : 0)) * 256, tid = (size_t)blk * 256 + threadIdx.x;
+    if (S.fill_a) fill_ff(S.fill_a, S.fill_a_bytes, tid, nthreads);
+    if (S.fill_b) fill_ff(S.fill_b, S.fill_b_bytes, tid, nthreads);
+}
+
+// Pair-list offsets without a scan launch: the producer adds every wave's count into the sum of its group of 64
+// waves (wsuper[k][wave / 64], zeroed beforehand; integer atomics: order-free); pairs_fill_super_kernel rebuilds a
+// wave's offset from the groups before it + the waves of its own group before it.
+__device__ __forceinline__ void publish_wave_count(int *__restrict__ wave_cnt, int *__restrict__ wsuper, int k,
+                                                   int wave, int nwaves, int nws, bool hit) {
+    const u64 m = __ballot(hit);
+    if (lane_id() == 0 && wave < nwaves) {
+        const int c = __popcll(m);
+        wave_cnt[(size_t)k * nwaves + wave] = c;
+        if (wsuper && c) atomicAdd(&wsuper[(size_t)k * nws + (wave >> 6)], c);
+    }
+}
+
+// perm != NULL: the launch also writes the parity-class permutation of the input rows (blk_off from class_offsets)
 __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
                                                         const u32 *__restrict__ bitmap,
                                                         const int *__restrict__ prefix, int n_out,
                                                         int32_t *__restrict__ nbr_in,
                                                         int32_t *__restrict__ nbr_out,
-                                                        int *__restrict__ wave_cnt, int nwaves) {
+                                                        int *__restrict__ wave_cnt, int nwaves,
+                                                        int *__restrict__ wsuper, int nws, int ncls,
+                                                        const int *__restrict__ blk_off,
+                                                        int32_t *__restrict__ perm) {
+    __shared__ int wcnt[4][CLS_MAX];
     int i = blockIdx.x * 256 + threadIdx.x;
     bool live = i < eff_rows(n_dev, n);
     int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
     int wave = i >> 6;
+    if (perm) {
+        const int cls = live ? row_class(c, G.pd, G.ph, G.pw, G.sd, G.sh, G.sw) : -1;
+        const int w = threadIdx.x >> 6;
+        const u64 lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+        int rank = 0;
+        for (int q = 0; q < ncls; ++q) {
+            u64 m = __ballot(cls == q);
+            if (cls == q) rank = __popcll(m & lt);
+            if (lane_id() == 0) wcnt[w][q] = __popcll(m);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int before = 0;
+            for (int ww = 0; ww < w; ++ww) before += wcnt[ww][cls];
+            perm[blk_off[(size_t)cls * gridDim.x + blockIdx.x] + before + rank] = i;
+        }
+    }
     int k = 0;
     for (int a = 0; a < G.kd; ++a)
         for (int bq = 0; bq < G.kh; ++bq)
@@ -479,11 +684,85 @@ __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__
                     if (o < n_out) nbr_out[(size_t)k * n_out + o] = i; else o = -1;
                 }
                 if (live) nbr_in[(size_t)k * n + i] = o;
-                if (wave_cnt) {
-                    u64 m = __ballot(o >= 0);
-                    if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
-                }
+                if (wave_cnt) publish_wave_count(wave_cnt, wsuper, k, wave, nwaves, nws, o >= 0);
             }
+}
+
+// pairs_fill_kernel with the offsets rebuilt from (wave_cnt, wsuper) -- see publish_wave_count; also writes
+// pair_num[k] = total of table row kr (block 0).  K <= 343.
+template <int KT>
+__global__ __launch_bounds__(256) void pairs_fill_super_kernel(const int32_t *__restrict__ tbl, int n,
+                                                               const int32_t *n_dev, int K, int flip,
+                                                               const int *__restrict__ wave_cnt, int nwaves,
+                                                               const int *__restrict__ wsuper, int nws,
+                                                               int32_t *__restrict__ pairs,
+                                                               int32_t *__restrict__ pair_num) {
+    __shared__ int off_s[343][4];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int wave0 = blockIdx.x * 4, sb = wave0 >> 6, m = wave0 & 63;   // m <= 60: the block's 4 waves share a group
+    for (int kr = w; kr < K; kr += 4) {
+        int acc = 0;
+        for (int i = lane; i < sb; i += 64) acc += wsuper[(size_t)kr * nws + i];
+        const int wi = (sb << 6) + lane;
+        const int c = (wi < nwaves && lane < m + 4) ? wave_cnt[(size_t)kr * nwaves + wi] : 0;
+        const int inc = wave_inclusive_scan(c);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane >= m && lane < m + 4) off_s[kr][lane - m] = acc + inc - c;
+        if (blockIdx.x == 0 && pair_num) {
+            int t = 0;
+            for (int i = lane; i < nws; i += 64) t += wsuper[(size_t)kr * nws + i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+            if (lane == 0) pair_num[flip ? K - 1 - kr : kr] = t;
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nn = eff_rows(n_dev, n);
+    if (KT > 0) {
+        int o[KT > 0 ? KT : 1];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            int kr = flip ? KT - 1 - k : k;
+            o[k] = (i < nn) ? tbl[(size_t)kr * n + i] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            int kr = flip ? KT - 1 - k : k;
+            int tot;
+            int r = wave_rank(o[k] >= 0, tot);
+            if (o[k] >= 0) {
+                int pos = off_s[kr][w] + r;
+                pairs[((size_t)k * 2 + 0) * n + pos] = i;
+                pairs[((size_t)k * 2 + 1) * n + pos] = o[k];
+            }
+        }
+        return;
+    }
+    for (int k = 0; k < K; ++k) {
+        int kr = flip ? K - 1 - k : k;
+        int o = (i < nn) ? tbl[(size_t)kr * n + i] : -1;
+        int tot;
+        int r = wave_rank(o >= 0, tot);
+        if (o >= 0) {
+            int pos = off_s[kr][w] + r;
+            pairs[((size_t)k * 2 + 0) * n + pos] = i;
+            pairs[((size_t)k * 2 + 1) * n + pos] = o;
+        }
+    }
+}
+
+static void launch_pairs_fill_super(const int32_t *tbl, int n, const int32_t *n_dev, int K, int flip,
+                                    const int *wave_cnt, int nwaves, const int *wsuper, int nws, int32_t *pairs,
+                                    int32_t *pair_num, hipStream_t st) {
+    int nb = pcd_div_up(n, 256);
+    if (K == 27)
+        pairs_fill_super_kernel<27><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_cnt, nwaves, wsuper, nws, pairs,
+                                                        pair_num);
+    else
+        pairs_fill_super_kernel<0><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_cnt, nwaves, wsuper, nws, pairs,
+                                                       pair_num);
 }
 
 static int make_geom(const int *shape, const int *ks, const int *st, const int *pd, const int *dl,
@@ -515,11 +794,13 @@ struct ConvWs {
     u32 *bitmap;
     int *prefix;
     int *bsums;
+    int *super;      // popcount sums of 64 scan blocks each      } zeroed together with the bytemap
+    int *wsuper;     // [K][nws]: pair counts of 64 waves each     } (one fill: they follow it in the workspace)
     int *wave_cnt;
-    int *wave_off;
-    int *totals;
+    int *blk_cnt;    // [CLS_MAX][n / 256]: parity-class rows per block
     size_t nwords;
-    int nwaves;
+    size_t zero_bytes;   // bytemap .. end of wsuper
+    int nwaves, nws, nblk, nsuper;
 };
 
 static int conv_ws_layout(void *workspace, size_t bytes, int n, int batch, const ConvGeom &G,
@@ -528,16 +809,81 @@ static int conv_ws_layout(void *workspace, size_t bytes, int n, int batch, const
     if (vol >= 4294967295.0 || vol <= 0) return PCD_ERR_KEYSPACE;
     L.nwords = ((size_t)vol + 31) / 32;
     L.nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    L.nws = pcd_div_up(L.nwaves, 64);
+    L.nblk = (int)((L.nwords + PK_WORDS - 1) / PK_WORDS);
+    L.nsuper = pcd_div_up(L.nblk, 64);
     WsCarver ws(workspace, bytes);
-    L.bitmap = ws.take<u32>(L.nwords);
+    L.bitmap = ws.take<u32>(L.nwords);           // (bitmap, prefix) first: pcd_rulebook_conv_rank_layout
     L.prefix = ws.take<int>(L.nwords + 1);
+    const size_t zero_from = ws.off;
     L.bytemap = ws.take<unsigned char>(L.nwords * 32);
-    L.bsums = ws.take<int>(pcd_div_up((int)L.nwords, 256) + 2);
+    L.super = ws.take<int>(L.nsuper);
+    L.wsuper = ws.take<int>((size_t)G.K * L.nws);
+    L.zero_bytes = ws.off - zero_from;
+    L.bsums = ws.take<int>(L.nblk);
     L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
-    L.wave_off = ws.take<int>((size_t)G.K * L.nwaves);
-    L.totals = ws.take<int>(G.K);
+    L.blk_cnt = ws.take<int>((size_t)CLS_MAX * pcd_div_up(n > 0 ? n : 1, 256));
     if (need) *need = ws.off;
     return ws.ok ? PCD_OK : PCD_ERR_WORKSPACE;
+}
+
+// The launches of a strided build.  count: fill, mark (+ class counts), pack + sums, scan (+ emit + 0xFF fills +
+// class offsets when the outputs are known already); fill: neighbour tables (+ class permutation), pair lists.
+struct ClsOut {
+    int ncls, tile, vcap;
+    int32_t *perm, *vstart;
+};
+
+static void conv_launch_mark(const int32_t *indices, int n, const int32_t *n_dev, const ConvGeom &G, const ConvWs &L,
+                             const ClsOut *C, hipStream_t st) {
+    pcd_fill(L.bytemap, 0, L.zero_bytes, st);
+    if (n > 0)
+        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap,
+                                                             C ? C->ncls : 0, C ? L.blk_cnt : nullptr);
+    conv_pack_sum_kernel<<<L.nblk, 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords, L.bitmap, L.bsums, L.super);
+}
+
+static void conv_launch_scan(int n, const ConvGeom &G, const ConvWs &L, int32_t *n_out_dev, int n_out,
+                             int32_t *out_indices, int32_t *nbr_out, const ClsOut *C, hipStream_t st) {
+    ScanSide S = {};
+    size_t fill = 0;
+    if (out_indices) {
+        S.out_indices = out_indices;
+        S.n_out = n_out;
+        S.fill_a = nbr_out;
+        S.fill_a_bytes = (size_t)G.K * n_out * sizeof(int32_t);
+        fill = S.fill_a_bytes;
+        if (C && n > 0) {
+            S.fill_b = C->perm;
+            S.fill_b_bytes = (size_t)C->vcap * sizeof(int32_t);
+            S.blk_cnt = L.blk_cnt;
+            S.cls_nblk = pcd_div_up(n, 256);
+            S.ncls = C->ncls;
+            S.cls_tile = C->tile;
+            S.vstart = C->vstart;
+            fill += S.fill_b_bytes;
+        }
+    }
+    // enough threads that the fills are a handful of 16-byte stores each
+    size_t blocks = fill / (256 * 16 * 8) + 1;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < (size_t)L.nblk) blocks = L.nblk;
+    if (S.blk_cnt) ++blocks;
+    conv_scan_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(L.bitmap, (int)L.nwords, L.nblk, L.bsums, L.super,
+                                                            L.prefix, n_out_dev, G, S);
+}
+
+static void conv_launch_fill(const int32_t *indices, int n, const int32_t *n_dev, const ConvGeom &G, const ConvWs &L,
+                             int n_out, int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
+                             int pad_pairs, const ClsOut *C, hipStream_t st) {
+    conv_fill_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix,
+                                                         n_out, nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr,
+                                                         L.nwaves, L.wsuper, L.nws, C ? C->ncls : 0, L.blk_cnt,
+                                                         C ? C->perm : nullptr);
+    if (pairs) {
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
+        launch_pairs_fill_super(nbr_in, n, n_dev, G.K, 0, L.wave_cnt, L.nwaves, L.wsuper, L.nws, pairs, pair_num, st);
+    }
 }
 
 }  // namespace
@@ -741,71 +1087,19 @@ extern "C" int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_sha
 //   perm   [vcap] : virtual row -> input row, -1 = padding; class segments start at multiples of `tile`
 //   vstart [ncls + 1] (device): first virtual row of every class, vstart[ncls] = end
 // The order inside a class is the input-row order (stable), so results do not depend on scheduling.
-constexpr int CLS_MAX = 8;
-
-__device__ __forceinline__ int row_class(int4 c, int pd, int ph, int pw, int sd, int sh, int sw) {
-    return (((c.y + pd) % sd) * sh + ((c.z + ph) % sh)) * sw + ((c.w + pw) % sw);
-}
-
 __global__ __launch_bounds__(256) void cls_count_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
                                                         ConvGeom G, int ncls, int *__restrict__ blk_cnt) {
     __shared__ int cnt[CLS_MAX];
-    if (threadIdx.x < CLS_MAX) cnt[threadIdx.x] = 0;
-    __syncthreads();
     int i = blockIdx.x * 256 + threadIdx.x;
     int cls = -1;
     if (i < eff_rows(n_dev, n)) cls = row_class(idx[i], G.pd, G.ph, G.pw, G.sd, G.sh, G.sw);
-    for (int q = 0; q < ncls; ++q) {
-        u64 m = __ballot(cls == q);
-        if (lane_id() == 0 && m) atomicAdd(&cnt[q], __popcll(m));
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < ncls) blk_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+    block_class_counts(cls, ncls, cnt, blk_cnt);
 }
 
-// one block, one WAVE per class: blk_cnt[cls][blk] -> virtual row of the block's first row of that class
-// (exclusive prefix inside the class + the tile-aligned class start)
-__global__ __launch_bounds__(64 * CLS_MAX) void cls_offsets_kernel(int *blk_cnt, int nblk, int ncls, int tile,
-                                                                   int *vstart) {
+__global__ __launch_bounds__(256) void cls_offsets_kernel(int *blk_cnt, int nblk, int ncls, int tile, int *vstart) {
     __shared__ int tot[CLS_MAX];
     __shared__ int start[CLS_MAX + 1];
-    const int q = threadIdx.x >> 6;
-    int *row = blk_cnt + (size_t)q * nblk;
-    if (q < ncls) {
-        int carry = 0;
-        // 8 chunks of 64 counts in flight: the loop is a chain of load latencies (one wave per class)
-        for (int base = 0; base < nblk; base += 8 * 64) {
-            int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 64 + lane_id();
-                v[u] = (i < nblk) ? row[i] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 64 + lane_id();
-                const int inc = wave_inclusive_scan(v[u]);
-                if (i < nblk) row[i] = carry + inc - v[u];
-                carry += __shfl(inc, 63);
-            }
-        }
-        if (lane_id() == 0) tot[q] = carry;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int vb = 0;
-        for (int c = 0; c < ncls; ++c) {
-            start[c] = vb;
-            vstart[c] = vb;
-            vb = (vb + tot[c] + tile - 1) / tile * tile;
-        }
-        vstart[ncls] = vb;
-    }
-    __syncthreads();
-    if (q < ncls) {
-        const int st = start[q];
-        for (int i = lane_id(); i < nblk; i += 64) row[i] += st;
-    }
+    class_offsets(blk_cnt, nblk, ncls, tile, vstart, tot, start);
 }
 
 __global__ __launch_bounds__(256) void cls_fill_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
@@ -857,7 +1151,7 @@ extern "C" int pcd_rulebook_conv_classes(const int32_t *indices, int n, const in
     hipStream_t st = (hipStream_t)stream;
     pcd_fill(perm, 0xFF, (size_t)vcap * sizeof(int32_t), st);
     cls_count_kernel<<<nblk, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, ncls, blk_cnt);
-    cls_offsets_kernel<<<1, 64 * CLS_MAX, 0, st>>>(blk_cnt, nblk, ncls, tile, vstart_dev);
+    cls_offsets_kernel<<<1, 256, 0, st>>>(blk_cnt, nblk, ncls, tile, vstart_dev);
     cls_fill_kernel<<<nblk, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, ncls, blk_cnt, perm);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -894,14 +1188,8 @@ extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
     if (rc != PCD_OK) return rc;
     if (n > 0 && !indices) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    pcd_fill(L.bytemap, 0, L.nwords * 32, st);
-    if (n > 0)
-        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap);
-    conv_pack_kernel<<<(unsigned)((L.nwords + 255) / 256), 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords,
-                                                                        L.bitmap);
-    PopcWord pw{L.bitmap};
-    rc = scan_exclusive(pw, (int)L.nwords, L.prefix, L.bsums, n_out_dev, st);
-    if (rc != PCD_OK) return rc;
+    conv_launch_mark(indices, n, n_dev, G, L, nullptr, st);
+    conv_launch_scan(n, G, L, n_out_dev, 0, nullptr, nullptr, nullptr, st);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -931,18 +1219,47 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
         return PCD_OK;
     }
     if (!indices || !out_indices || !nbr_in || !nbr_out) return PCD_ERR_INVALID_ARG;
-    conv_emit_out_kernel<<<pcd_div_up((int)L.nwords, 256), 256, 0, st>>>(L.bitmap, L.prefix,
-                                                                        (int)L.nwords, G, n_out,
-                                                                        out_indices);
-    pcd_fill(nbr_out, 0xFF, (size_t)G.K * n_out * sizeof(int32_t), st);
-    int nb = pcd_div_up(n, 256);
-    conv_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix, n_out,
-                                         nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr, L.nwaves);
-    if (pairs) {
-        scan_rows_kernel<<<G.K, 256, 0, st>>>(L.wave_cnt, L.wave_off, L.nwaves, L.totals, pair_num, 0);
-        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
-        launch_pairs_fill(nbr_in, n, n_dev, G.K, 0, L.wave_off, L.nwaves, pairs, st);
+    // the scan again, now with its outputs (prefix comes out the same); the pair-count sums restart from zero so
+    // that a second fill over the same workspace stays correct
+    if (pairs) pcd_fill(L.wsuper, 0, (size_t)G.K * L.nws * sizeof(int), st);
+    conv_launch_scan(n, G, L, nullptr, n_out, out_indices, nbr_out, nullptr, st);
+    conv_launch_fill(indices, n, n_dev, G, L, n_out, nbr_in, nbr_out, pairs, pair_num, pad_pairs, nullptr, st);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// count + fill + parity classes in one call when the number of output rows is bounded by a capacity known on the
+// host (static plans): 6 launches (5 without pair lists), nothing read back.
+extern "C" int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                                       const int *ksize_host, const int *stride_host, const int *pad_host,
+                                       const int *dil_host, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices,
+                                       int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
+                                       int pad_pairs, int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev,
+                                       const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n <= 0 || batch <= 0 || n_out_cap <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
+    if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (!indices || !out_indices || !nbr_in || !nbr_out) return PCD_ERR_INVALID_ARG;
+    if ((pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    ConvGeom G;
+    int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
+    if (rc != PCD_OK) return rc;
+    if (G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return PCD_ERR_INVALID_ARG;
+    ClsOut C = {G.sd * G.sh * G.sw, cls_tile, vcap, perm, vstart_dev};
+    const bool classes = perm != nullptr;
+    if (classes) {
+        if (C.ncls > CLS_MAX) return PCD_ERR_UNSUPPORTED;
+        if (cls_tile <= 0 || !vstart_dev || vcap < (n + cls_tile - 1) / cls_tile * cls_tile + C.ncls * cls_tile)
+            return PCD_ERR_INVALID_ARG;
     }
+    ConvWs L;
+    rc = conv_ws_layout(workspace, workspace_bytes, n, batch, G, L, nullptr);
+    if (rc != PCD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    conv_launch_mark(indices, n, n_dev, G, L, classes ? &C : nullptr, st);
+    conv_launch_scan(n, G, L, n_out_dev, n_out_cap, out_indices, nbr_out, classes ? &C : nullptr, st);
+    conv_launch_fill(indices, n, n_dev, G, L, n_out_cap, nbr_in, nbr_out, pairs, pair_num, pad_pairs,
+                     classes ? &C : nullptr, st);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

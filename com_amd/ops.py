@@ -480,32 +480,57 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     if wsb == 0:
         raise L.PcdError("pcd_rulebook_conv: bad geometry or key space too large")
     ws = _ws(wsb, dev)
-    n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-    with _Timed("rulebook_conv_count", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
-        L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
-                                            L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)      # always written by the scan launch
     static = PLAN is not None and PLAN.active
-    if static:
-        n_out = PLAN.cap(plan_key)         # capacity; the real count stays in n_out_dev (no host sync)
-        PLAN.record(plan_key, n_out_dev, n_out)
-    else:
-        n_out = int(n_out_dev.item())      # host sync: data-dependent number of output rows
-        if PLAN is not None and plan_key is not None:
-            PLAN.observe(plan_key, n_out)
-    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
-    nbr_in = torch.empty((K, n), dtype=torch.int32, device=dev)
-    nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
-    pairs = torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
-    pair_num = torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None
+    ncls = st[0] * st[1] * st[2]
+    classes = None
+
+    def outputs(n_out):
+        return (torch.empty((n_out, 4), dtype=torch.int32, device=dev),
+                torch.empty((K, n), dtype=torch.int32, device=dev),
+                torch.empty((K, n_out), dtype=torch.int32, device=dev),
+                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None,
+                torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None)
+
     def meta():                                  # read 16 N_in, write 8 P + 16 N_out
         p_ = int((nbr_in >= 0).sum().item())
         return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
 
-    with _Timed("rulebook_conv_fill", meta):
-        L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
-                                           L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
-                                           int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
-                "pcd_rulebook_conv_fill")
+    if static and n > 0:
+        # capacity known on the host: both phases and the parity classes in one call, nothing read back
+        n_out = PLAN.cap(plan_key)
+        PLAN.record(plan_key, n_out_dev, n_out)
+        out_indices, nbr_in, nbr_out, pairs, pair_num = outputs(n_out)
+        perm = vstart = None
+        vcap = 0
+        if want_pairs and ncls <= 8:
+            vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
+            perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
+            vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
+            classes = (perm, vstart, vcap)
+        with _Timed("rulebook_conv_build", meta):
+            L.check(lib.pcd_rulebook_conv_build(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(n_out_dev),
+                                                L.ptr(out_indices), L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs),
+                                                L.ptr(pair_num), int(pad_pairs), CLS_TILE, L.ptr(perm), vcap,
+                                                L.ptr(vstart), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_rulebook_conv_build")
+    else:
+        with _Timed("rulebook_conv_count", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
+            L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
+                                                L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+        if static:
+            n_out = PLAN.cap(plan_key)         # capacity; the real count stays in n_out_dev (no host sync)
+            PLAN.record(plan_key, n_out_dev, n_out)
+        else:
+            n_out = int(n_out_dev.item())      # host sync: data-dependent number of output rows
+            if PLAN is not None and plan_key is not None:
+                PLAN.observe(plan_key, n_out)
+        out_indices, nbr_in, nbr_out, pairs, pair_num = outputs(n_out)
+        with _Timed("rulebook_conv_fill", meta):
+            L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
+                                               L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
+                                               int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_rulebook_conv_fill")
     rb = Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
                   pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
     # the build's bitmap + prefix stay valid as long as `ws` lives: a SubM conv on out_indices can rank with them
@@ -516,9 +541,10 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     nw = int(nwords.value)
     rb.rank = RankMap(ws, ws[boff.value:boff.value + 4 * nw].view(torch.int32),
                       ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape)
-    if want_pairs and st[0] * st[1] * st[2] <= 8:
+    if classes is not None:
+        rb.classes = classes
+    elif want_pairs and ncls <= 8:
         # training: input rows grouped by stride-parity class for the data gradient (dgrad_classes)
-        ncls = st[0] * st[1] * st[2]
         vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
         perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
         vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)

@@ -159,6 +159,20 @@ int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *
                            int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Both phases (+ the parity classes of pcd_rulebook_conv_classes when perm != NULL) in ONE call for callers that
+ * bound the number of output rows on the host (`n_out_cap`: buffers are sized for it, rows beyond it are dropped and
+ * n_out_dev[0] still receives the real count -- static plans / hipGraph capture, nothing is read back).  Same
+ * results as _count + _fill + _classes; six dependent launches (five without pair lists) instead of fifteen:
+ * fill, mark (+ class counts), pack + block sums, scan + emit + 0xFF fills + class offsets, neighbour tables
+ * (+ class permutation), pair lists.  Workspace: pcd_rulebook_conv_workspace_bytes.
+ * Replaces the same get_indice_pairs(subm=False) call (spconv_backbone.py:14-15,205-229). */
+int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                            const int *ksize_host, const int *stride_host, const int *pad_host,
+                            const int *dil_host, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices,
+                            int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                            int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* indice_pairs / indice_pair_num of a SubM rulebook from its nbr table [kvol][n] alone -- for rulebooks built with
  * pairs == NULL (the forward and the output-stationary kernels only need nbr) whose pairs are wanted later. */
 size_t pcd_rulebook_subm_pairs_workspace_bytes(int n, int kvol);

@@ -192,6 +192,63 @@ def test_rulebooks_waymo_chain_bit_exact():
         idx, shape = rb_o["out_indices"], tuple(es)
 
 
+def test_strided_build_in_one_call_equals_the_two_phase_build():
+    """pcd_rulebook_conv_build (static plans: capacity known on the host, 6 launches) against
+    pcd_rulebook_conv_count + _fill + _classes on the four geometries of the chain, full-size frame, with the real
+    row count of the INPUT in device memory and padded capacities on both sides."""
+    ops = _ops()
+    frames = [synth.synth_cloud(0)]
+    (v, c, n), _ = _hard_oracle_batch(frames, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000)
+    idx_np, shape = c, [41, 1504, 1504]
+    chain = [dict(k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1)), dict(k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1)),
+             dict(k=(3, 3, 3), s=(2, 2, 2), p=(0, 1, 1)), dict(k=(3, 1, 1), s=(2, 1, 1), p=(0, 0, 0))]
+    for lvl, geo in enumerate(chain):
+        n_real = idx_np.shape[0]
+        cap_in = (n_real * 5 // 4 + 1023) // 1024 * 1024
+        idx = torch.zeros((cap_in, 4), dtype=torch.int32, device=DEV)
+        idx[:n_real] = torch.from_numpy(idx_np).to(DEV)
+        idx[n_real:] = 7                                    # garbage beyond the real count must not be read
+        n_dev = torch.tensor([n_real], dtype=torch.int32, device=DEV)
+        ref = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], pad_pairs=True, n_dev=n_dev)
+        plan = ops.StaticPlan()
+        plan.observe(("conv", lvl), ref.n_out)
+        plan.active = True
+        ops.PLAN = plan
+        try:
+            rb = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], pad_pairs=True, n_dev=n_dev,
+                                   plan_key=("conv", lvl))
+        finally:
+            ops.PLAN = None
+        m = ref.n_out
+        assert rb.n_out >= m and int(rb.n_out_dev.item()) == m and rb.out_shape == ref.out_shape
+        assert torch.equal(rb.out_indices[:m], ref.out_indices)
+        assert torch.equal(rb.nbr_out[:, :m], ref.nbr_out) and bool((rb.nbr_out[:, m:] == -1).all())
+        assert torch.equal(rb.nbr_in[:, :n_real], ref.nbr_in[:, :n_real])
+        assert torch.equal(rb.pair_num, ref.pair_num) and torch.equal(rb.pairs, ref.pairs)
+        (perm, vstart, vcap), (perm_r, vstart_r, vcap_r) = rb.classes, ref.classes
+        assert vcap == vcap_r and torch.equal(vstart, vstart_r) and torch.equal(perm, perm_r)
+        # the rank map the build leaves behind serves the SubM rulebook of the new level
+        if ref.out_shape[0] >= 3:
+            a = ops.rulebook_subm(ref.out_indices, 1, ref.out_shape, rank=ref.rank)
+            b = ops.rulebook_subm(rb.out_indices, 1, rb.out_shape, rank=rb.rank, n_dev=rb.n_out_dev)
+            assert torch.equal(b.nbr_out[:, :m], a.nbr_out)
+        # overflow: a capacity below the real count drops rows, reports the real count
+        plan = ops.StaticPlan(margin=1.0, round_to=1)
+        plan.observe(("conv", lvl), m // 2)
+        plan.active = True
+        ops.PLAN = plan
+        try:
+            small = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], n_dev=n_dev, plan_key=("conv", lvl))
+        finally:
+            ops.PLAN = None
+        assert int(small.n_out_dev.item()) == m and small.n_out == m // 2 + 1
+        assert torch.equal(small.out_indices, ref.out_indices[:small.n_out])
+        keep = ref.nbr_in[:, :n_real].clone()
+        keep[keep >= small.n_out] = -1
+        assert torch.equal(small.nbr_in[:, :n_real], keep)
+        idx_np, shape = ref.out_indices.cpu().numpy(), ref.out_shape
+
+
 def test_subm_pairs_derived_on_demand_equal_built_pairs():
     """A SubM rulebook built without indice_pairs (16-channel layers only read nbr) hands out exactly the pairs
     pcd_rulebook_subm would have built, when some consumer asks for them later (pcd_rulebook_subm_pairs)."""
