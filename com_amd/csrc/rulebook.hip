@@ -629,13 +629,13 @@ __global__ __launch_bounds__(256) void conv_scan_emit_kernel(const u32 *__restri
 // Pair-list offsets without a scan launch: the producer adds every wave's count into the sum of its group of 64
 // waves (wsuper[k][wave / 64], zeroed beforehand; integer atomics: order-free); pairs_fill_super_kernel rebuilds a
 // wave's offset from the groups before it + the waves of its own group before it.
-__device__ __forceinline__ void publish_wave_count(int *__restrict__ wave_cnt, int *__restrict__ wsuper, int k,
-                                                   int wave, int nwaves, int nws, bool hit) {
+__device__ __forceinline__ void publish_wave_count(int *__restrict__ wave_cnt, int *blk_sum /* LDS [K] */, int k,
+                                                   int wave, int nwaves, bool hit) {
     const u64 m = __ballot(hit);
     if (lane_id() == 0 && wave < nwaves) {
         const int c = __popcll(m);
         wave_cnt[(size_t)k * nwaves + wave] = c;
-        if (wsuper && c) atomicAdd(&wsuper[(size_t)k * nws + (wave >> 6)], c);
+        if (c) atomicAdd(&blk_sum[k], c);   // the block's 4 waves lie in one group: one global atomic per (block, k)
     }
 }
 
@@ -651,10 +651,15 @@ __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__
                                                         const int *__restrict__ blk_off,
                                                         int32_t *__restrict__ perm) {
     __shared__ int wcnt[4][CLS_MAX];
+    __shared__ int blk_sum[343];
     int i = blockIdx.x * 256 + threadIdx.x;
     bool live = i < eff_rows(n_dev, n);
     int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
     int wave = i >> 6;
+    if (wave_cnt) {
+        for (int q = threadIdx.x; q < G.K; q += 256) blk_sum[q] = 0;
+        __syncthreads();
+    }
     if (perm) {
         const int cls = live ? row_class(c, G.pd, G.ph, G.pw, G.sd, G.sh, G.sw) : -1;
         const int w = threadIdx.x >> 6;
@@ -684,8 +689,13 @@ __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__
                     if (o < n_out) nbr_out[(size_t)k * n_out + o] = i; else o = -1;
                 }
                 if (live) nbr_in[(size_t)k * n + i] = o;
-                if (wave_cnt) publish_wave_count(wave_cnt, wsuper, k, wave, nwaves, nws, o >= 0);
+                if (wave_cnt) publish_wave_count(wave_cnt, blk_sum, k, wave, nwaves, o >= 0);
             }
+    if (wave_cnt) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < G.K; q += 256)
+            if (blk_sum[q]) atomicAdd(&wsuper[(size_t)q * nws + (blockIdx.x >> 4)], blk_sum[q]);
+    }
 }
 
 // pairs_fill_kernel with the offsets rebuilt from (wave_cnt, wsuper) -- see publish_wave_count; also writes

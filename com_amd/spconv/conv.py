@@ -149,6 +149,7 @@ class SparseConvolution(SparseModule):
         else:
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, n_dev=x.num_rows,
+                                   want_pairs=self.training,      # (pair lists / parity classes: backward only)
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)))
             out_idx, out_shape = rb.out_indices, rb.out_shape
             if rb.rank is not None:
