@@ -481,6 +481,7 @@ def main():
             Fsp.reset_deferred()                             # stale jobs hold pointers of the aborted step
             raise
         Fsp.join_deferred_wgrad()                            # side-stream wgrad pipeline -> back to this stream
+        ops.stamp("bwd_end")
 
     def fwd_bwd(pts, offs, ev=None):
         if ev is not None: ev("voxelize")
@@ -491,6 +492,8 @@ def main():
 
     def opt_step():
         opt.step()       # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 3 launches
+        if not os.environ.get('PCD_PACK_LATE'):
+            model.backbone_3d.pack_after_update()            # the next step's weight packs, off its critical path
 
     def schedule():
         """lr / momentum of this iteration into the device-side pair the (replayed) optimizer kernel reads."""
@@ -556,11 +559,15 @@ def main():
                 train_from_voxels(vox_out)
                 vox_stream.wait_stream(cur)
                 with torch.cuda.stream(vox_stream):
+                    ops.stamp("vox_begin")
                     vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
                     assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                    ops.stamp("vox_end")
                 opt_step()
+                ops.stamp("opt_end")
                 cur.wait_stream(vox_stream)
                 plan.arm()                                   # sticky overflow check of every replay, inside the graph
+                ops.stamp("step_end")
 
             def run_step(i, source=resident):
                 pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
@@ -643,6 +650,21 @@ def main():
             torch.cuda.synchronize()
             run_step = eager_step
 
+    if os.environ.get('PCD_STAMPS'):
+        # time points inside the replayed graph (device clock, 100 MHz), averaged over the timed steps
+        ops.STAMPS = {"buf": torch.zeros((32,), dtype=torch.int64, device=dev), "names": []}
+        if use_graph:
+            run_step = build_graphs()
+            state["prime"](resident)
+        acc = None
+        for i in range(10):
+            run_step(i)
+            torch.cuda.synchronize()
+            v = ops.STAMPS["buf"].cpu().numpy().astype(np.float64)[:len(ops.STAMPS["names"])]
+            if i >= 2:
+                d = (v - v[0]) / 100.0
+                acc = d if acc is None else acc + d
+        print("[stamps us] " + "  ".join(f"{n}={a / 8:.0f}" for n, a in zip(ops.STAMPS["names"], acc)), file=sys.stderr)
     elapsed, host_issue = timed_loop(run_step, args.steps, resident, use_graph)
     if os.environ.get('PCD_BENCH_DEBUG'):
         print(f"[bench] host issue {1e3 * host_issue / max(args.steps, 1):.3f} ms/step, "

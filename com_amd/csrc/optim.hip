@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
 
 __global__ void step_inc_kernel(float *step_dev) { step_dev[0] += 1.0f; }
 
+// device clock (100 MHz, shared by all queues) into slot[0]: time points INSIDE a replayed hipGraph, where neither
+// events nor the profiler (which changes how the graph is scheduled) can be used
+__global__ void stamp_kernel(unsigned long long *slot) { slot[0] = wall_clock64(); }
+
 // Sticky capacity-overflow flag of static-shape execution: flag[0] |= 1 (and flag[1] = max over-capacity count
 // seen) when any device-side row count exceeds the capacity its buffers were allocated with.  One thread.
 __global__ void overflow_check_kernel(PcdCountCheck tab, int n, int32_t *flag) {
@@ -145,6 +149,14 @@ extern "C" int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp
                                              (float4 *)exp_avg_sq, n4, partial, max_norm, pre_divisor, step_dev, lr,
                                              beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev);
     step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_debug_stamp(uint64_t *slot, void *stream) {
+    PCD_ENTER();
+    if (!slot) return PCD_ERR_INVALID_ARG;
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>((unsigned long long *)slot);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

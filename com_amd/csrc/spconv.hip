@@ -1277,6 +1277,216 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// 128 x 128 channels.  Two things differ from wgrad_kernel:
+//  * the four 64 x 64 chunks of dW_k belong to the four WAVES of one workgroup, which stage every gathered row of X and
+//    dY ONCE per workgroup (double-buffered in LDS) instead of once per chunk: 16 load instructions per 32 pairs
+//    instead of 32, and no cross-wave reduction (every wave owns its chunk of the tile);
+//  * the work is cut into EQUAL PAIR COUNTS, not into (offset, row range) items.  The pair lists of the 27 offsets
+//    differ 2.4 x in length (centre : corner) and all workgroups are resident at once, so with one row-range grid for
+//    every offset the launch lasted as long as its centre-offset items while the SIMDs held waves 50 % of the time
+//    (SQ_WAVE_CYCLES).  Here the concatenation of all pair lists (offset-major) is cut into `nb` chunks of T pairs
+//    (T a multiple of the 32-pair step); a chunk that crosses an offset boundary writes one tile per offset it
+//    touches.  Tile (chunk c, offset k) has index c + k -- unique and, per offset, a contiguous run -- so the fixed-order
+//    reduction of offset k is  sum of tiles [first_k, first_k + count_k)  (header at the start of the workspace).
+//    A tile is stored in register order (1 KiB per store instruction); wgrad_tiles_reduce_body undoes it.
+// Chunks are dealt to the XCDs by their position inside their offset (chunk i of m -> XCD 8 i / m): pair lists are
+// ascending in input row, so every XCD sees one eighth of the rows of X and dY for all offsets, which its L2 holds.
+constexpr int WG128_HDR_BYTES = 4096;   // {first tile, tile count} per offset (K <= 343), then the tiles
+
+__global__ __launch_bounds__(256, 4) void wgrad128_kernel(
+    const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const int32_t *__restrict__ pairs,
+    const int32_t *__restrict__ pair_num, int K, int pmax, int nb, void *__restrict__ ws, unsigned x_bytes,
+    unsigned dy_bytes) {
+    constexpr int C = 128, XS = WgradStride<C>::value;   // 144 elements = 72 dwords = 8 * odd
+    constexpr int BUF = 32 * XS;                          // elements of one staged 32-row block
+    __shared__ __attribute__((aligned(16))) unsigned short stage[2 * 2 * BUF];   // [buffer][X | dY][32][XS]
+    __shared__ int pre_s[344];                            // pre_s[k] = pairs of the offsets before k
+    __shared__ int sel_s[2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        int carry = 0;
+        for (int base = 0; base < K; base += 64) {
+            const int i = base + lane;
+            const int v = i < K ? pair_num[i] : 0;
+            const int inc = wave_inclusive_scan(v);
+            if (i < K) pre_s[i + 1] = carry + inc;
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) pre_s[0] = 0;
+    }
+    __syncthreads();
+    const int Ptot = pre_s[K];
+    int T = ((Ptot + nb - 1) / nb + 31) & ~31;
+    if (T < 32) T = 32;
+    int *hdr = reinterpret_cast<int *>(ws);
+    float *tiles = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + WG128_HDR_BYTES);
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < K; k += 256) {
+            const int lo = pre_s[k], hi = pre_s[k + 1];
+            hdr[2 * k] = lo / T + k;
+            hdr[2 * k + 1] = hi > lo ? (hi - 1) / T - lo / T + 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        // the j-th chunk of XCD xc: offsets in order, chunk i of the m chunks an offset owns (those that START in it)
+        // goes to XCD floor(8 i / m)
+        const int xc = blockIdx.x & 7;
+        int j = blockIdx.x >> 3, c = -1, kk = 0;
+        for (int k = 0; k < K; ++k) {
+            const int a0 = (pre_s[k] + T - 1) / T, a1 = (pre_s[k + 1] + T - 1) / T, m = a1 - a0;
+            const int i0 = (xc * m + 7) / 8, i1 = ((xc + 1) * m + 7) / 8;
+            if (j < i1 - i0) {
+                c = a0 + i0 + j;
+                kk = k;
+                break;
+            }
+            j -= i1 - i0;
+        }
+        sel_s[0] = c;
+        sel_s[1] = kk;
+    }
+    __syncthreads();
+    const int c = sel_s[0];
+    if (c < 0) return;
+    int k = sel_s[1];
+
+    const int cic = wave >> 1, coc = wave & 1;            // this wave's 64 x 64 chunk
+    // staging: wave w gathers pair rows [8w, 8w + 8) of the 32-pair step, 4 whole rows (256 B) per load instruction
+    const int srow = lane >> 4, spc = lane & 15;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)dy_bytes, 0x00020000);
+    const int g = lane >> 4, t = lane & 15;
+    const int trow = 4 * g + (t >> 2);                     // pair row <-> contraction index: as in wgrad_kernel
+    struct Rows { u32x4 x[2], y[2]; };
+
+    int q0 = c * T;
+    const int q1 = min(q0 + T, Ptot);
+    while (q0 < q1) {
+        while (pre_s[k + 1] <= q0) ++k;                    // (offsets without pairs)
+        const int kend = min(q1, pre_s[k + 1]);
+        const int p_begin = q0 - pre_s[k], p_end = kend - pre_s[k];
+        const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
+        const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb_ = 0; nb_ < 4; ++nb_) acc[mb][nb_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ONE index load per wave and step (lanes 0-31: input rows of the 32 pairs, lanes 32-63: output rows), handed
+        // to the staging lanes by shuffles
+        auto load_idx = [&](int p0) {
+            const int pp = p0 + (lane & 31);
+            int v = -1;
+            if (pp < p_end) v = (lane < 32) ? pin[pp] : pout[pp];
+            return v;
+        };
+        auto load_rows = [&](int idx) {   // index -1 -> offset beyond num_records -> zeros, no memory access
+            Rows R;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xi = __shfl(idx, wave * 8 + j * 4 + srow);
+                const int yi = __shfl(idx, 32 + wave * 8 + j * 4 + srow);
+                R.x[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (unsigned)xi * (C * 2u) + spc * 16u, 0, 0);
+                R.y[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (unsigned)yi * (C * 2u) + spc * 16u, 0, 0);
+            }
+            return R;
+        };
+        auto store_rows = [&](int buf, const Rows &R) {
+            unsigned short *Xs = stage + buf * 2 * BUF, *Ys = Xs + BUF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wave * 8 + j * 4 + srow;
+                *reinterpret_cast<u32x4 *>(Xs + r * XS + spc * 8) = R.x[j];
+                *reinterpret_cast<u32x4 *>(Ys + r * XS + spc * 8) = R.y[j];
+            }
+        };
+        auto compute = [&](int buf) {
+            const unsigned short *Xs = stage + buf * 2 * BUF, *Ys = Xs + BUF;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const unsigned short *a0 = Xs + trow * XS + cic * 64 + mb * 16 + (t & 3) * 4;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3))) *)(a0 + 16 * XS));
+                af[mb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int nb_ = 0; nb_ < 4; ++nb_) {
+                const unsigned short *b0 = Ys + trow * XS + coc * 64 + nb_ * 16 + (t & 3) * 4;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(b0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3))) *)(b0 + 16 * XS));
+                bfr[nb_] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb_ = 0; nb_ < 4; ++nb_)
+                    acc[mb][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb_], acc[mb][nb_], 0, 0, 0);
+        };
+        // Software pipeline: rows one step ahead in registers, pair indices one step ahead of their rows (a second
+        // step of rows in flight costs 32 VGPRs = one resident workgroup per CU less, and gained nothing).
+        // Step s stages pairs [p_begin + 32 s, + 32); beyond p_end everything is -1 / zeros.
+        int i1 = load_idx(p_begin);
+        Rows A = load_rows(i1);                            // step 0
+        i1 = load_idx(p_begin + 32);
+        store_rows(0, A);
+        __syncthreads();
+        int buf = 0;
+        for (int p0 = p_begin; p0 < p_end; p0 += 32, buf ^= 1) {
+            A = load_rows(i1);                             // step s + 1
+            i1 = load_idx(p0 + 64);
+            compute(buf);
+            store_rows(buf ^ 1, A);                        // (read in the previous step, before that step's barrier)
+            __syncthreads();
+        }
+        // tile (c, k) in register order: acc[mb][nb][r] = dW_k[co = coc*64 + nb*16 + t][ci = cic*64 + mb*16 + g*4 + r]
+        float *tile = tiles + (size_t)(c + k) * (C * C);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb_ = 0; nb_ < 4; ++nb_)
+                *reinterpret_cast<float4 *>(tile + (((wave * 16 + mb * 4 + nb_) * 64 + lane) << 2)) =
+                    make_float4(acc[mb][nb_][0], acc[mb][nb_][1], acc[mb][nb_][2], acc[mb][nb_][3]);
+        q0 = kend;
+    }
+}
+
+// dW[co][k][ci] = sum of the tiles of offset k in tile order (wgrad128_kernel); block -> (k, 1/16 of the tile)
+__device__ __forceinline__ void wgrad_tiles_reduce_body(const void *__restrict__ ws, int K, float *__restrict__ dw,
+                                                        unsigned block) {
+    constexpr int C = 128;
+    const int k = block >> 4, e4 = ((block & 15) << 8) + threadIdx.x;   // float4 index inside the tile (4096 of them)
+    const int *hdr = reinterpret_cast<const int *>(ws);
+    const float4 *tiles = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ws) + WG128_HDR_BYTES);
+    const int first = hdr[2 * k], count = hdr[2 * k + 1];
+    const float4 *src = tiles + (size_t)first * (C * C / 4) + e4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = 0;
+    for (; q + 3 < count; q += 4) {   // 4 loads in flight, summed in tile order
+        const float4 a = src[(size_t)q * (C * C / 4)], b = src[(size_t)(q + 1) * (C * C / 4)];
+        const float4 c2 = src[(size_t)(q + 2) * (C * C / 4)], d = src[(size_t)(q + 3) * (C * C / 4)];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c2.x; s.y += c2.y; s.z += c2.z; s.w += c2.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; q < count; ++q) {
+        const float4 a = src[(size_t)q * (C * C / 4)];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const int lane = e4 & 63, mn = (e4 >> 6) & 15, wave = e4 >> 10;
+    const int ci = (wave >> 1) * 64 + (mn >> 2) * 16 + (lane >> 4) * 4, co = (wave & 1) * 64 + (mn & 3) * 16 + (lane & 15);
+    *reinterpret_cast<float4 *>(dw + ((size_t)co * K + k) * C + ci) = s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_tiles_reduce_kernel(const void *__restrict__ ws, int K,
+                                                                 float *__restrict__ dw) {
+    wgrad_tiles_reduce_body(ws, K, dw, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Output-stationary weight gradient for the 16-channel layers (level 1: 338 k rows at B = 4, 5 SubM convs + the
 // input conv).  The pair-based kernel above gathers TWO 32-byte rows per pair (x and dy), 2 x 7.9 per output row --
 // at this width it is bound by those line fetches (~11 TB/s of L2 -> L1 traffic), and these layers are the last of
@@ -1471,7 +1681,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
         if (J.job[q].first_block <= blockIdx.x) j = q;
     j = __builtin_amdgcn_readfirstlane(j);
     const unsigned block = blockIdx.x - J.job[j].first_block;
-    if (J.job[j].vec)
+    if (J.job[j].vec == 2)   // tiles of wgrad128_kernel (n = kernel volume)
+        wgrad_tiles_reduce_body(J.job[j].slab, (int)J.job[j].n, J.job[j].dw, block);
+    else if (J.job[j].vec)
         wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
     else
         wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
@@ -1480,6 +1692,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
 // (layers that are cut into >= 4 channel chunks already have 4x the workgroups: twice the rows per split there,
 // measured 79 -> 72 us at 128 x 128 channels)
+static bool wgrad128_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PCD_WG128");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+static int wgrad128_chunks() {   // equal-pair chunks of wgrad128_kernel: three resident workgroups per CU
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("PCD_WG128_NB");
+        v = e ? atoi(e) : 768;
+        if (v < 8) v = 8;
+        v = (v + 7) / 8 * 8;
+    }
+    return v;
+}
+static bool wgrad128_use(int cin, int cout) { return cin == 128 && cout == 128 && wgrad128_enabled(); }
+
 static void wgrad_plan(int pmax, int cin, int cout, int *splits, int *rows_per_split) {
     const int chunks = pcd_div_up(cin, 64) * pcd_div_up(cout, 64);
     int s = pcd_div_up(pmax > 0 ? pmax : 1, chunks >= 4 ? 8192 : 4096);
@@ -1725,6 +1957,8 @@ extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int 
 
 extern "C" size_t pcd_sparse_conv_wgrad_workspace_bytes(int kvol, int cin, int cout, int pmax) {
     if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0) return 0;
+    if (wgrad128_use(cin, cout))
+        return (size_t)WG128_HDR_BYTES + (size_t)(wgrad128_chunks() + kvol) * cin * cout * sizeof(float);
     int splits, per;
     wgrad_plan(pmax, cin, cout, &splits, &per);
     return (size_t)splits * cout * kvol * cin * sizeof(float);
@@ -1759,6 +1993,16 @@ extern "C" int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n
     if (workspace_bytes < pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax) || !workspace)
         return PCD_ERR_WORKSPACE;
     float *slab = (float *)workspace;
+    if (wgrad128_use(cin, cout)) {
+        if (cin_pad != 128 || kvol > 343) return PCD_ERR_UNSUPPORTED;
+        const int nb = wgrad128_chunks();
+        const int grid = nb + 8 * kvol;   // per XCD: its share of the chunks, + up to one more per offset (rounding)
+        wgrad128_kernel<<<grid, 256, 0, st>>>((const unsigned short *)x, (const unsigned short *)dy, pairs, pair_num,
+                                              kvol, pmax, nb, workspace, (unsigned)((size_t)n_x * cin_pad * 2),
+                                              (unsigned)((size_t)n_dy * cout * 2));
+        PCD_RETURN_IF_LAUNCH_FAILED();
+        return PCD_OK;
+    }
     int mb = chunk_blocks(cin), nb = chunk_blocks(cout);
     int rc = PCD_ERR_UNSUPPORTED;
 #define WG(M, N)                                                                                  \
@@ -1776,6 +2020,11 @@ extern "C" int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pma
     size_t n = (size_t)cout * kvol * cin;
     if (pmax == 0) return PCD_OK;  // pcd_sparse_conv_wgrad already zeroed dweight
     if (!workspace) return PCD_ERR_WORKSPACE;
+    if (wgrad128_use(cin, cout)) {
+        wgrad_tiles_reduce_kernel<<<(unsigned)kvol * 16, 256, 0, (hipStream_t)stream>>>(workspace, kvol, dweight);
+        PCD_RETURN_IF_LAUNCH_FAILED();
+        return PCD_OK;
+    }
     int splits, per;
     wgrad_plan(pmax, cin, cout, &splits, &per);
     if ((n & 3) == 0 && (((uintptr_t)dweight | (uintptr_t)workspace) & 15u) == 0)
@@ -1799,6 +2048,17 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
         if (q.pmax == 0 && q.splits <= 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
         if (!q.workspace) return PCD_ERR_WORKSPACE;
         int splits, per;
+        if (q.splits <= 0 && wgrad128_use(q.cin, q.cout)) {
+            auto &d = J.job[J.n_jobs++];
+            d.slab = (const float *)q.workspace;
+            d.dw = q.dweight;
+            d.n = (unsigned long long)q.kvol;
+            d.splits = 0;
+            d.vec = 2;
+            d.first_block = blocks;
+            blocks += (unsigned)q.kvol * 16;
+            continue;
+        }
         wgrad_plan(q.pmax, q.cin, q.cout, &splits, &per);
         if (q.splits > 0) splits = q.splits;          // slabs written by pcd_sparse_conv_wgrad_os
         const size_t n = (size_t)q.cout * q.kvol * q.cin;

@@ -61,6 +61,22 @@ def _require_cuda(*tensors):
             raise L.PcdError("hot-path ops need HIP device tensors (there is no CPU fallback)")
 
 
+STAMPS = None          # tools: {"buf": int64 device tensor, "names": [...]} -> stamp(name) records the device clock
+
+
+def stamp(name):
+    """Diagnostics (off unless ops.STAMPS is set): device clock at this point of the current stream, also inside a
+    hipGraph capture -- every replay refreshes the slot."""
+    if STAMPS is None:
+        return
+    names = STAMPS["names"]
+    if name not in names:
+        names.append(name)
+    i = names.index(name)
+    buf = STAMPS["buf"]
+    L.check(L.lib().pcd_debug_stamp(buf.data_ptr() + 8 * i, L.stream_ptr()), "pcd_debug_stamp")
+
+
 # ---------------------------------------------------------------------------------------------
 class StaticPlan:
     """Capacities for "static shape" execution (hipGraph capture of a whole training step).

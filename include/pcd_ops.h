@@ -535,6 +535,10 @@ typedef struct PcdCountCheck {
 } PcdCountCheck;
 int pcd_static_overflow_check(const PcdCountCheck *table_host, int n, int32_t *flag, void *stream);
 
+/* Diagnostics: the device clock (100 MHz) into slot[0] at this point of the stream -- a time point inside a replayed
+ * hipGraph, which events cannot give and a profiler perturbs (tools/exp_stamps.py).  No reference counterpart. */
+int pcd_debug_stamp(uint64_t *slot, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
