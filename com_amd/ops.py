@@ -797,7 +797,9 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
         b = (c + 15) // 16
         return 4 if b >= 4 else (2 if b >= 2 else 1)
 
-    with _Timed(f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}> {x.shape[1]}x{cout} K={kvol}", meta):
+    kname = "wgrad128_kernel" if (cin == 128 and cout == 128 and x.shape[1] == 128) else \
+        f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}>"
+    with _Timed(f"{kname} {x.shape[1]}x{cout} K={kvol}", meta):
         L.check(lib.pcd_sparse_conv_wgrad_v2(L.ptr(x), x.shape[0], L.ptr(n_in_dev), x.shape[1], cin, L.ptr(dy),
                                              dy.shape[0], cout, L.ptr(pairs), L.ptr(pair_num), kvol, pmax, L.ptr(dw),
                                              L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_v2")

@@ -34,7 +34,10 @@ def timed_graph(fn, key, n_out, reps=10, inner=8):
         for _ in range(reps):
             g.replay()
         e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / (reps * inner) * 1e-3
+        dt = e0.elapsed_time(e1) / (reps * inner) * 1e-3
+        del g                                     # free the graph's pool NOW, not inside the next timed region
+        import gc; gc.collect(); torch.cuda.synchronize()
+        return dt
     finally:
         ops.PLAN = None
 
