@@ -284,7 +284,8 @@ int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int
 int pcd_sparse_conv_gather_gemm_variant(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out, int is_dgrad);
 
 /* dW[cout][k][cin] = sum_{(i,o) in pairs[k]} dY[o][cout] * X[i][cin]   (f32, parameter layout).
- * Two launches: pcd_sparse_conv_wgrad fills per-split partial slabs in `workspace` (MFMA kernel),
+ * Two launches: pcd_sparse_conv_wgrad fills partial results in `workspace` (MFMA kernel) -- per row-range slabs, or at
+ * 128 x 128 channels one tile per (equal-pair chunk, offset) behind a small header --,
  * pcd_sparse_conv_wgrad_reduce sums them in a fixed order into dweight (deterministic, no atomics).
  * `dweight` of the first call is only used when pmax == 0 (it is zeroed); it may be NULL otherwise.
  * pairs[k][0] (rows of x, n_x_rows of them) must be ascending inside each k (canonical order): the
