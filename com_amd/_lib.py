@@ -147,11 +147,16 @@ class PcdCountCheck(ctypes.Structure):
     _fields_ = [("count", ctypes.c_void_p * COUNT_CHECK_MAX), ("cap", ctypes.c_int32 * COUNT_CHECK_MAX)]
 
 
+BN_MID_ROWS = 16          # include/pcd_ops.h: PCD_BN_MID_ROWS
+BN_EXT_MID = -1           # include/pcd_ops.h: PCD_BN_EXT_MID
+BN_COUNTER_STRIDE = 32    # include/pcd_ops.h: PCD_BN_COUNTER_STRIDE
+
+
 class PcdBnReduce(ctypes.Structure):
     """include/pcd_ops.h: struct PcdBnReduce (conv-epilogue reductions for the BatchNorm beside the conv)."""
     _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p),
-                ("partial_rows", ctypes.c_int)]
+                ("partial_rows", ctypes.c_int), ("mid", ctypes.c_void_p), ("counters", ctypes.c_void_p)]
 
 
 def build(force=False):

@@ -218,7 +218,7 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
 // the 2c columns, fixed order) -> mid[MID_ROWS][2c]; every workgroup of the apply kernel then adds the MID_ROWS
 // rows itself (16 loads per column, L2 hits) instead of waiting for one workgroup to chew through up to 5000 rows
 // (conv tiles deliver one partial row each): 10-12 us -> ~3 us + a 1 us prologue.
-constexpr int MID_ROWS = 16;
+constexpr int MID_ROWS = PCD_BN_MID_ROWS;   // (spconv.hip's fused form of this reduction relies on the value)
 
 __global__ __launch_bounds__(1024) void bn_mid_kernel(const float *__restrict__ partial, int nblocks, int c,
                                                       double *__restrict__ mid) {
@@ -640,7 +640,10 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
     const int pcs = c / N;
     int grid = grid_for((size_t)n * pcs, pcs);
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
-    if (ext_partial && ext_rows < 0) return PCD_ERR_INVALID_ARG;
+    const bool ext_mid = ext_partial && ext_rows == PCD_BN_EXT_MID;   // the conv launch folded its rows already
+    if (ext_partial && ext_rows < 0 && !ext_mid) return PCD_ERR_INVALID_ARG;
+    if (ext_mid && !(training && n > 0)) return PCD_ERR_INVALID_ARG;
+    if (ext_mid) L.mid = (double *)ext_partial;
     if (training) {
         if (ext_partial)   // the conv epilogue already took the sums (PcdBnReduce mode 1)
             ;
@@ -651,7 +654,9 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
                                                                   L.partial);
         const float *part = ext_partial ? ext_partial : L.partial;
         const int prow = ext_partial ? ext_rows : grid;
-        if (n > 0)   // two-stage: the apply kernel finishes the statistics itself
+        if (ext_mid)
+            ;
+        else if (n > 0)   // two-stage: the apply kernel finishes the statistics itself
             bn_mid_kernel<<<MID_ROWS, 1024, 0, st>>>(part, prow, c, L.mid);
         else
             bn_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, n, n_dev, c, gamma, beta, eps, momentum, running_mean,
@@ -735,7 +740,10 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     int grid = grid_for((size_t)n * pcs, pcs);
     int agrid = grid_for((size_t)n * pcs, pcs, MAX_APPLY_BLOCKS);
     const int vec = aligned16(gamma, beta, save_mean, save_invstd, dgamma, dbeta) ? 1 : 0;
-    if (ext_partial && ext_rows < 0) return PCD_ERR_INVALID_ARG;
+    const bool ext_mid = ext_partial && ext_rows == PCD_BN_EXT_MID;   // the dgrad launch folded its rows already
+    if (ext_partial && ext_rows < 0 && !ext_mid) return PCD_ERR_INVALID_ARG;
+    if (ext_mid && !(training && n > 0)) return PCD_ERR_INVALID_ARG;
+    if (ext_mid) L.mid = (double *)ext_partial;
     const float *part = ext_partial ? ext_partial : L.partial;     // PcdBnReduce mode 2: sums taken by the dgrad
     const int prow = ext_partial ? ext_rows : grid;
     const bool two_stage = training && n > 0;      // the apply kernel finishes the reductions itself
@@ -743,7 +751,9 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
     size_t alds = two_stage ? bn_mid_lds_bytes(c) : 0;
     if (colsum_partial && alds < bn_reduce_lds_bytes(c, N)) alds = bn_reduce_lds_bytes(c, N);
     auto finalize = [&]() {
-        if (two_stage)
+        if (ext_mid)
+            ;
+        else if (two_stage)
             bn_mid_kernel<<<MID_ROWS, 1024, 0, st>>>(part, prow, c, L.mid);
         else
             bn_bwd_finalize_kernel<<<1, 1024, 0, st>>>(part, prow, c, dgamma, dbeta);

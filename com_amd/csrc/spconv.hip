@@ -119,6 +119,8 @@ struct BnRed {
     const unsigned short *y;      // mode 2, relu: BatchNorm(+residual)+ReLU output (the conv's own input features)
     const float *mean, *invstd;
     float *partial;
+    double *mid;                  // != NULL: the launch also folds the partial rows into MID_ROWS rows (below)
+    int *counters;                // [MID_ROWS][BN_COUNTER_STRIDE], zero between launches
 };
 
 // sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in all of them
@@ -146,8 +148,91 @@ __device__ __forceinline__ int xcd_tile(int n, int rows_per_tile) {
     return j < tpx ? xcd * tpx + j : 8 * tpx + (j - tpx) * 8 + xcd;
 }
 
+// ---- the BatchNorm "mid" reduction inside the conv launch ------------------------------------------------------
+// pcd_bn_forward / pcd_bn_backward fold the partial rows of a launch into BN_MID_ROWS rows of doubles with a kernel of
+// their own (fused.hip: bn_mid_kernel, mid row r = sum of the partial rows t with t % 16 == r) before the apply pass;
+// that kernel is 16 small workgroups, but as a graph node on the critical chain it costs ~10 us of latency, 42 times
+// per step.  With BnRed.mid the conv launch does it: the workgroup that delivers the LAST partial row of a group
+// (a counter per group; rows are published with agent-scope stores and read back with agent-scope loads -- plain
+// stores are only visible to other XCDs after an L2 write-back) sums the group's rows, in a fixed order of its own
+// (doubles: it agrees with bn_mid_kernel's order to ~1e-16 relative).  The counter returns to zero for the next launch.
+constexpr int BN_MID_ROWS = 16;
+constexpr int BN_COUNTER_STRIDE = PCD_BN_COUNTER_STRIDE;   // ints between two group counters
+
+__device__ __forceinline__ float ld_agent(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// mid[r][col] = sum of the partial rows r, r + 16, r + 32, ... (all threads of the workgroup; `lds`: 1024 doubles).
+// tpc threads per column take every tpc-th row of the group, 8 loads in flight, then one thread per column adds the
+// tpc sums in order: fixed order, ~20 registers (the narrow conv kernels run at 7 waves / SIMD, i.e. 72 VGPRs).
+__device__ __forceinline__ void bn_mid_row(const float *partial, int nblocks, int c, int r, double *__restrict__ mid,
+                                           double *lds) {
+    const int cols = 2 * c;
+    int cw = 1;                                            // columns handled per pass: a power of two <= blockDim
+    while (cw < cols && cw < (int)blockDim.x) cw <<= 1;
+    const int tpc = (int)blockDim.x / cw;                  // >= 1 (blockDim is a power of two)
+    const int j = threadIdx.x / cw, t = threadIdx.x - j * cw;
+    const int stride = BN_MID_ROWS * tpc;
+    for (int col0 = 0; col0 < cols; col0 += cw) {
+        const int col = col0 + t;
+        double a = 0.0;
+        if (col < cols) {
+            for (int blk = r + BN_MID_ROWS * j; blk < nblocks; blk += 8 * stride) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int bq = blk + q * stride;
+                    v[q] = ld_agent(partial + (size_t)(bq < nblocks ? bq : blk) * cols + col);
+                    if (bq >= nblocks) v[q] = 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a += (double)v[q];
+            }
+        }
+        lds[threadIdx.x] = a;
+        __syncthreads();
+        if (j == 0 && col < cols) {
+            double s2 = 0.0;
+            for (int q = 0; q < tpc; ++q) s2 += lds[q * cw + t];
+            mid[(size_t)r * cols + col] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// partial row `tile` = get(e), e in [0, 2 c_out); all threads of the workgroup, uniformly
+template <class F>
+__device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_out, F get) {
+    float *dst = bn.partial + (size_t)tile * 2 * c_out;
+    if (!bn.mid) {
+        for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) dst[e] = get(e);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_base[];   // the launch's dynamic LDS (>= 8 KiB, free now)
+    __shared__ int last_s;
+    for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x)
+        __hip_atomic_store(dst + e, get(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row has reached the coherence point ...
+    __syncthreads();
+    const int nrows = gridDim.x, r = tile & (BN_MID_ROWS - 1);
+    if (tile == 0)                                         // fewer tiles than groups: the empty groups' rows are zero
+        for (int e = nrows * 2 * c_out + threadIdx.x; e < BN_MID_ROWS * 2 * c_out; e += blockDim.x) bn.mid[e] = 0.0;
+    if (threadIdx.x == 0) {                                // ... before this workgroup counts as arrived
+        // (one counter per 128-byte line: agent-scope atomics on ONE line serialise at ~35 ns each -- 46 us for the
+        //  1320 workgroups of a level-1 conv when the 16 counters shared a line)
+        int *cnt = bn.counters + r * BN_COUNTER_STRIDE;
+        const int expect = (nrows - r + BN_MID_ROWS - 1) / BN_MID_ROWS;
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == expect - 1;
+        if (last_s) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last_s) bn_mid_row(bn.partial, nrows, c_out, r, bn.mid, reinterpret_cast<double *>(smem_base));
+}
+
 __device__ __forceinline__ void bnred_zero_row(const BnRed &bn, int tile, int c_out) {
-    for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) bn.partial[(size_t)tile * 2 * c_out + e] = 0.0f;
+    bnred_publish(bn, tile, c_out, [](int) { return 0.0f; });
 }
 
 // Channel order inside the packed weights.  The MFMA leaves lane (g, rl) with rows m = 4g..4g+3 of every 16-channel
@@ -297,9 +382,9 @@ __device__ __forceinline__ void gg_epilogue(const f32x4 (&acc)[MI][NBW], const i
         }
     if (OUT_BF16 && bn.mode) {
         __syncthreads();
-        for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x)
-            bn.partial[(size_t)tile * 2 * c_out + e] =
-                ((red[e] + red[2 * c_out + e]) + red[4 * c_out + e]) + red[6 * c_out + e];
+        bnred_publish(bn, tile, c_out, [&](int e) {
+            return ((red[e] + red[2 * c_out + e]) + red[4 * c_out + e]) + red[6 * c_out + e];
+        });
     }
 }
 
@@ -570,6 +655,11 @@ static int make_bnred(const PcdBnReduce *r, int y_dtype, int c_out, int grid, Bn
     b.mean = r->mean;
     b.invstd = r->invstd;
     b.partial = r->partial;
+    if (r->mid) {
+        if (!r->counters || r->partial_rows != grid) return PCD_ERR_INVALID_ARG;   // groups are counted over the grid
+        b.mid = r->mid;
+        b.counters = r->counters;
+    }
     *out = b;
     return PCD_OK;
 }

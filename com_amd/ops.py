@@ -576,6 +576,24 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 CLS_TILE = 256
 
 
+import os as _os
+BN_FUSED_MID = _os.environ.get("PCD_BN_FUSED_MID", "1") != "0"   # fold the BatchNorm "mid" reduction into the conv launches
+_BN_COUNTER_POOL = {}     # device -> [int32 zeros [slots * 16], next slot]
+
+
+def _bn_counters(device):
+    """16 zeroed int32 counters (one per 128-byte line) for one conv launch with a fused mid reduction.  The kernels return them to zero, so a
+    pool allocated (and zeroed) ONCE is handed out round-robin; 1024 slots: far more launches than are ever in flight."""
+    key = str(device)
+    ent = _BN_COUNTER_POOL.get(key)
+    if ent is None:
+        ent = _BN_COUNTER_POOL[key] = [torch.zeros((1024 * L.BN_MID_ROWS * L.BN_COUNTER_STRIDE,), dtype=torch.int32,
+                                                   device=device), 0]
+    slot, per = ent[1], L.BN_MID_ROWS * L.BN_COUNTER_STRIDE
+    ent[1] = (slot + 1) % 1024
+    return ent[0][slot * per:(slot + 1) * per]
+
+
 class BnReduce:
     """Per-channel sums a conv kernel takes over its OUTPUT tile for the BatchNorm beside it (C ABI: PcdBnReduce).
     mode 1: forward statistics (sum y, sum y^2); mode 2: the two BatchNorm-backward reductions, the conv output
@@ -603,8 +621,17 @@ class BnReduce:
     def _struct(self, tiles, c_out, device):
         self.partial = torch.empty((max(tiles, 1), 2, c_out), dtype=torch.float32, device=device)
         self.rows = tiles
+        mid = counters = None
+        if BN_FUSED_MID and tiles > 0:
+            # the conv launch also folds its partial rows into the 16 rows the BatchNorm apply pass starts from
+            # (no bn_mid launch between the conv and the apply pass): hand `mid` on as the "partials"
+            mid = torch.empty((L.BN_MID_ROWS, 2, c_out), dtype=torch.float64, device=device)
+            counters = _bn_counters(device)
+            self.partial_rows, self.partial_keep = tiles, self.partial
+            self.partial, self.rows = mid, L.BN_EXT_MID
         return L.PcdBnReduce(self.mode, int(self.relu), L.ptr(self.x), L.ptr(self.y), L.ptr(self.mean),
-                             L.ptr(self.invstd), L.ptr(self.partial), tiles)
+                             L.ptr(self.invstd), L.ptr(self.partial_keep if mid is not None else self.partial), tiles,
+                             L.ptr(mid), L.ptr(counters))
 
 
 def _tiles(v, what):

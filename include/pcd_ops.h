@@ -217,7 +217,18 @@ typedef struct PcdBnReduce {
     const float *mean, *invstd;
     float *partial;           /* out: [partial_rows][2][c_out] f32 */
     int partial_rows;
+    /* Optional: the launch itself folds the partial rows into the PCD_BN_MID_ROWS rows the BatchNorm apply passes start
+     * from (otherwise pcd_bn_forward / _backward run a small kernel for that -- one more dependent launch on the chain):
+     * mid [PCD_BN_MID_ROWS][2][c_out] f64, handed to the BatchNorm call as ext_partial with ext_rows = PCD_BN_EXT_MID;
+     * counters [PCD_BN_MID_ROWS * PCD_BN_COUNTER_STRIDE] i32 (one counter per 128-byte line) must be ZERO when the launch
+     * starts and are zero again when it ends (keep them in a buffer zeroed once); partial_rows must then equal the
+     * tile count exactly. */
+    double *mid;
+    int32_t *counters;
 } PcdBnReduce;
+#define PCD_BN_MID_ROWS 16
+#define PCD_BN_COUNTER_STRIDE 32
+#define PCD_BN_EXT_MID (-1)
 
 /* Parity classes of the input rows of a strided conv, for its data gradient: input coordinate c reaches an output
  * cell through kernel index k only if (c + p - k*d) is a multiple of the stride, so the residues ((c + p) mod s) of

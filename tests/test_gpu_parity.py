@@ -535,7 +535,9 @@ def test_conv_epilogue_takes_batchnorm_reductions():
         y = ops.gather_gemm(x, ops.pack_weight(w, 0), bias, rb.nbr_out, 27, False, n, c, torch.bfloat16, bn_reduce=st)
         y_plain = ops.gather_gemm(x, ops.pack_weight(w, 0), bias, rb.nbr_out, 27, False, n, c, torch.bfloat16)
         assert torch.equal(y.view(torch.int16), y_plain.view(torch.int16))
-        assert st.partial.shape == (st.rows, 2, c)
+        # (ops.BN_FUSED_MID: the launch folded its rows into the 16 "mid" rows the apply pass starts from)
+        assert st.partial.shape == ((16, 2, c) if ops.BN_FUSED_MID else (st.rows, 2, c))
+        assert (st.rows == -1 and st.partial.dtype == torch.float64) if ops.BN_FUSED_MID else st.rows > 0
         close(st.partial[:, 0].double().sum(0), y.double().sum(0), ("sum", c))
         close(st.partial[:, 1].double().sum(0), (y.double() ** 2).sum(0), ("sumsq", c))
         gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.3
@@ -545,6 +547,19 @@ def test_conv_epilogue_takes_batchnorm_reductions():
                                     partials=(st.partial, st.rows))
         close(m2, m1, "mean"), close(i2, i1, "invstd")
         assert float((o1.float() - o2.float()).abs().max()) <= 0.02 * float(o1.float().abs().max())
+        # the fold inside the conv launch vs the separate bn_mid launch: both sum doubles in a fixed order of their own
+        ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+        try:
+            st_b = ops.BnReduce(1)
+            y_b = ops.gather_gemm(x, ops.pack_weight(w, 0), bias, rb.nbr_out, 27, False, n, c, torch.bfloat16,
+                                  bn_reduce=st_b)
+        finally:
+            ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+        o3, m3, i3 = ops.bn_forward(y_b, None, gamma, beta, 1e-3, 0.01, True, rm.clone(), rv.clone(), True,
+                                    partials=(st_b.partial, st_b.rows))
+        assert float((m3 - m2).abs().max()) <= 1e-6 * float(m2.abs().max()) + 1e-9
+        assert float((i3 - i2).abs().max()) <= 1e-6 * float(i2.abs().max())
+        assert float((o3.float() - o2.float()).abs().max()) <= 0.01 * float(o2.float().abs().max())   # (bf16 ulp flips)
         # backward reductions: y / o1 / m1 / i1 describe a BatchNorm(+ReLU) whose output feeds the next conv
         pd = ops.pack_weight(w, 1)
         dyn = torch.randn(n, c, device=DEV).bfloat16()
@@ -560,6 +575,17 @@ def test_conv_epilogue_takes_batchnorm_reductions():
                                 partials=(red.partial, red.rows))
             close(b[3], a[3], ("dbeta", c, relu)), close(b[2], a[2], ("dgamma", c, relu))
             assert float((a[0].float() - b[0].float()).abs().max()) <= 0.02 * float(a[0].float().abs().max())
+            ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+            try:
+                red_b = ops.BnReduce(2, relu, x=y, y=ysrc, mean=m1, invstd=i1)
+                ops.gather_gemm(dyn, pd, None, rb.nbr_out, 27, True, n, c, torch.bfloat16, addend=add, bn_reduce=red_b)
+            finally:
+                ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+            b2 = ops.bn_backward(dx, y, ysrc, gamma, m1, i1, relu, True, False, beta=beta,
+                                 partials=(red_b.partial, red_b.rows))
+            for q in (2, 3):
+                assert float((b2[q] - b[q]).abs().max()) <= 1e-6 * float(b[q].abs().max()) + 1e-7
+            assert float((b2[0].float() - b[0].float()).abs().max()) <= 0.01 * float(b[0].float().abs().max())
             # column sums of dx taken by the same kernel (bias gradient of the conv in front of the BatchNorm)
             r = ops.bn_backward(dx, y, ysrc, gamma, m1, i1, relu, True, False, beta=beta, colsum=True)
             assert torch.equal(r[0], a[0])
@@ -579,6 +605,16 @@ def test_conv_epilogue_takes_batchnorm_reductions():
         b = ops.bn_backward(dx, xin, yout, gamma, mean, invstd, True, True, False,
                             partials=(red.partial, red.rows))
         close(b[3], a[3], ("cls dbeta", cin)), close(b[2], a[2], ("cls dgamma", cin))
+        ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+        try:
+            red_b = ops.BnReduce(2, True, x=xin, y=yout, mean=mean, invstd=invstd)
+            ops.dgrad_classes(dyn, ops.pack_weight(w, 1), rbc, cin, torch.bfloat16, bn_reduce=red_b)
+        finally:
+            ops.BN_FUSED_MID = not ops.BN_FUSED_MID
+        b2 = ops.bn_backward(dx, xin, yout, gamma, mean, invstd, True, True, False,
+                             partials=(red_b.partial, red_b.rows))
+        for q in (2, 3):
+            assert float((b2[q] - b[q]).abs().max()) <= 1e-6 * float(b[q].abs().max()) + 1e-7
 
 
 @pytest.mark.gpu
