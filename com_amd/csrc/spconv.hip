@@ -1330,38 +1330,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
-    // fixed-order reduction of the 4 waves through LDS: tile[cout_l][cin_l]
+    // fixed-order reduction of the 4 waves through LDS, in REGISTER order: tile[(mb * NBW + nb) * 64 + lane] is the
+    // lane's f32x4 -- lane-linear 16-byte accesses, no bank conflicts (the [cout][cin] scatter this replaces put the
+    // 16 lanes of a row 64 dwords apart: 16-way conflicts, 3.9 M cycles per launch at 64 x 64 = 9 % of the kernel).
+    // (The main loop's padded staging is conflict-free for the transposing reads and nearly so for the writes; an
+    //  unpadded XOR-swizzled layout measured the same in isolation and, by letting more of these workgroups become
+    //  resident beside the data-gradient kernels, 2 % SLOWER in the training step.)
     __syncthreads();
+    float4 *tile4 = reinterpret_cast<float4 *>(tile);
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int ci = mb * 16 + g * 4 + r;
-                        int co = nb * 16 + t;
-                        float *dst = tile + co * CI + ci;
-                        *dst = (w == 0) ? acc[mb][nb][r] : (*dst + acc[mb][nb][r]);
+                for (int nb = 0; nb < NBW; ++nb) {
+                    float4 *dst = tile4 + (mb * NBW + nb) * 64 + lane;
+                    float4 v = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
+                    if (w != 0) {
+                        const float4 o = *dst;
+                        v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w;
                     }
+                    *dst = v;
+                }
         }
         __syncthreads();
     }
-    // slab[split][cout][K][cin]
+    // slab[split][cout][K][cin]; element (co, ci..ci+3) lives at lane (g = ci % 16 / 4, t = co % 16) of block
+    // (mb = ci / 16, nb = co / 16)
     float *sl = slab + (size_t)split * cout * K * cin;
-    if ((cin & 3) == 0) {   // 16-byte stores: consecutive cin are contiguous in the slab and in the tile
-        for (int e = threadIdx.x; e < CI * CO / 4; e += 256) {
-            int ci = (e % (CI / 4)) * 4, co = e / (CI / 4);
-            if (ci0 + ci < cin && co0 + co < cout)
-                *reinterpret_cast<float4 *>(sl + ((size_t)(co0 + co) * K + k) * cin + ci0 + ci) =
-                    *reinterpret_cast<const float4 *>(tile + co * CI + ci);
-        }
-    } else {
-        for (int e = threadIdx.x; e < CI * CO; e += 256) {
-            int ci = e % CI, co = e / CI;
-            if (ci0 + ci < cin && co0 + co < cout)
-                sl[((size_t)(co0 + co) * K + k) * cin + ci0 + ci] = tile[co * CI + ci];
+    for (int e = threadIdx.x; e < CI * CO / 4; e += 256) {
+        const int ci = (e % (CI / 4)) * 4, co = e / (CI / 4);
+        const float4 v = tile4[((ci >> 4) * NBW + (co >> 4)) * 64 + ((ci & 15) >> 2) * 16 + (co & 15)];
+        if (co0 + co >= cout) continue;
+        float *d = sl + ((size_t)(co0 + co) * K + k) * cin + ci0 + ci;
+        if ((cin & 3) == 0) {   // 16-byte stores: consecutive cin are contiguous in the slab
+            if (ci0 + ci < cin) *reinterpret_cast<float4 *>(d) = v;
+        } else {
+            const float q[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4; ++j)
+                if (ci0 + ci + j < cin) d[j] = q[j];
         }
     }
 }
