@@ -838,6 +838,36 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     return dw
 
 
+def gather_gemm_f32(x, weight, bias, nbr, kvol, flip_k, n_rows_out, n_dev=None, addend=None):
+    """fp32-exact y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]^T (+ addend): x [n_in, c_in] f32, weight [c_out, K, c_in] f32
+    (parameter layout; for a data gradient pass weight.permute(2, 1, 0) and dy).  Parity work, not speed."""
+    _require_cuda(x, weight, nbr)
+    assert x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() and weight.is_contiguous()
+    assert nbr.is_contiguous() and weight.shape[1] == kvol and weight.shape[2] == x.shape[1]
+    c_out = weight.shape[0]
+    y = torch.empty((n_rows_out, c_out), dtype=torch.float32, device=x.device)
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == torch.float32 and addend.is_contiguous()
+    b = bias.detach().float().contiguous() if bias is not None else None
+    L.check(L.lib().pcd_sparse_conv_gather_gemm_f32(L.ptr(x), x.shape[0], x.shape[1], L.ptr(weight), L.ptr(b),
+                                                    L.ptr(nbr), nbr.shape[1], kvol, int(bool(flip_k)), n_rows_out,
+                                                    L.ptr(n_dev), c_out, L.ptr(y), L.ptr(addend), L.stream_ptr()),
+            "pcd_sparse_conv_gather_gemm_f32")
+    return y
+
+
+def wgrad_f32(x, dy, pairs, pair_num, kvol):
+    """fp32-exact dW [c_out, K, c_in] = sum over the pairs of dy[o]^T x[i] (fixed order)."""
+    _require_cuda(x, dy, pairs, pair_num)
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    assert pairs.is_contiguous()
+    dw = torch.empty((dy.shape[1], kvol, x.shape[1]), dtype=torch.float32, device=x.device)
+    L.check(L.lib().pcd_sparse_conv_wgrad_f32(L.ptr(x), x.shape[0], x.shape[1], L.ptr(dy), dy.shape[0], dy.shape[1],
+                                              L.ptr(pairs), L.ptr(pair_num), kvol, pairs.shape[2], L.ptr(dw),
+                                              L.stream_ptr()), "pcd_sparse_conv_wgrad_f32")
+    return dw
+
+
 def wgrad_reduce_batched(jobs):
     """jobs = [(slab workspace, dw, kvol, cin, cout, pmax[, splits])] collected by wgrad(defer=...)."""
     import ctypes

@@ -291,7 +291,60 @@ def bev_dense(features, indices, batch_size, spatial_shape, n_dev=None, channels
     return BevDenseFunction.apply(features, indices, batch_size, spatial_shape, n_dev, channels_last)
 
 
+EXACT_FP32 = False     # fp32 features -> the fp32-exact kernels (v_mfma_f32_16x16x4_f32) instead of bf16 operands
+
+
+class SparseConvExactFunction(Function):
+    """The same op in fp32 end to end (pcd_sparse_conv_gather_gemm_f32 / _wgrad_f32): what the reference computes
+    (fp32 weights and features through spconv).  For parity work -- a whole backbone against an fp64 chain at 1e-3,
+    reference checkpoints' activations -- not for speed."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, rb, passthrough=False):
+        x = features.detach().float().contiguous()
+        cin = weight.shape[-1]
+        if x.shape[1] != cin:
+            x = x[:, :cin].contiguous()
+        w = weight.detach().float().reshape(weight.shape[0], -1, cin).contiguous()    # [c_out, K, c_in]
+        y = ops.gather_gemm_f32(x, w, bias, rb.nbr_out, rb.kvol, False, rb.n_out, n_dev=rb.n_out_dev)
+        ctx.rb, ctx.has_bias, ctx.passthrough, ctx.in_cols = rb, bias is not None, passthrough, features.shape[1]
+        ctx.wshape = weight.shape
+        ctx.save_for_backward(x, w)
+        if passthrough:
+            return y, features.view_as(features)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, d_ident=None):
+        x, w = ctx.saved_tensors
+        rb = ctx.rb
+        if dy is None:
+            return (d_ident, None, None, None, None)
+        dy = dy.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = w.permute(2, 1, 0).contiguous()                  # [c_in, K, c_out]
+            add = d_ident.float().contiguous() if (d_ident is not None and ctx.in_cols == w.shape[2]) else None
+            if rb.subm:
+                dx = ops.gather_gemm_f32(dy, wt, None, rb.nbr_out, rb.kvol, True, rb.n_in, n_dev=rb.n_in_dev, addend=add)
+            else:
+                dx = ops.gather_gemm_f32(dy, wt, None, rb.nbr_in, rb.kvol, False, rb.n_in, n_dev=rb.n_in_dev, addend=add)
+            if d_ident is not None and add is None:
+                dx = dx + d_ident.float()[:, :dx.shape[1]]
+            if ctx.in_cols != dx.shape[1]:
+                dx = torch.nn.functional.pad(dx, (0, ctx.in_cols - dx.shape[1]))
+        elif d_ident is not None:
+            dx = d_ident
+        if ctx.needs_input_grad[1]:
+            dw = ops.wgrad_f32(x, dy, rb.pairs, rb.pair_num, rb.kvol).view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_sum(dy)
+        return (dx, dw, db, None, None)
+
+
 def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+    if EXACT_FP32 and features.dtype == torch.float32:
+        return SparseConvExactFunction.apply(features, weight, bias, rb, passthrough)
     return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
 
 

@@ -547,6 +547,23 @@ typedef struct PcdCountCheck {
 } PcdCountCheck;
 int pcd_static_overflow_check(const PcdCountCheck *table_host, int n, int32_t *flag, void *stream);
 
+/* ============================================================================================
+ * fp32-exact forms of the sparse convolution (features, weights, results in fp32; v_mfma_f32_16x16x4_f32).  The
+ * reference runs fp32 end to end (spconv with fp32 weights behind spconv_backbone.py:12-15, pcdet/utils/spconv_utils.py:3-6);
+ * these entry points exist for PARITY work -- reproducing a reference checkpoint's activations to fp32 accuracy and
+ * checking a whole backbone end to end at 1e-3 without bf16 rounding noise -- not for speed.
+ *   weight  [c_out][kvol][c_in] f32 (the parameter layout, no packing); for a data gradient pass the transposed
+ *           weight [c_in][kvol][c_out] as `weight` and dy as `x` (flip_k as pcd_sparse_conv_gather_gemm)
+ *   wgrad   dweight [c_out][kvol][c_in], pairs in canonical order; fixed summation order (deterministic)
+ * c_out <= 128 per call. */
+int pcd_sparse_conv_gather_gemm_f32(const float *x, int n_rows_in, int c_in, const float *weight, const float *bias,
+                                    const int32_t *nbr, int nbr_stride, int kvol, int flip_k, int n_rows_out,
+                                    const int32_t *n_rows_out_dev, int c_out, float *y, const float *addend,
+                                    void *stream);
+int pcd_sparse_conv_wgrad_f32(const float *x, int n_x_rows, int c_in, const float *dy, int n_dy_rows, int c_out,
+                              const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax, float *dweight,
+                              void *stream);
+
 /* Diagnostics: the device clock (100 MHz) into slot[0] at this point of the stream -- a time point inside a replayed
  * hipGraph, which events cannot give and a profiler perturbs (tools/exp_stamps.py).  No reference counterpart. */
 int pcd_debug_stamp(uint64_t *slot, void *stream);

@@ -349,6 +349,45 @@ def test_sparse_conv_arithmetic_small_grid(golden, cin, cout):
     _conv_case(idx, 2, shape, GEOMS["conv_k3_s2_p1"], cin, cout, 2, False)
 
 
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (64, 64), (128, 128)])
+def test_sparse_conv_fp32_exact_kernels(golden, cin, cout):
+    """pcd_sparse_conv_gather_gemm_f32 / _wgrad_f32 (fp32 operands, v_mfma_f32_16x16x4_f32) against the oracle on
+    UNROUNDED fp32 inputs: forward, data gradient (SubM: flipped offsets; strided: input-stationary table) and weight
+    gradient to fp32 accuracy."""
+    ops = _ops()
+    g = golden("g3_conv")
+    idx, shape = g["indices"], tuple(int(v) for v in g["spatial_shape"])
+    rng = np.random.default_rng(100 + cin + cout)
+    for subm, geo in ((True, None), (False, GEOMS["conv_k3_s2_p1"]), (False, GEOMS["conv_k311_s211_p0"])):
+        if subm:
+            rb_o = O.rulebook_subm(idx, shape)
+            rb = ops.rulebook_subm(torch.from_numpy(idx).to(DEV), 2, list(shape))
+        else:
+            rb_o = O.rulebook_conv(idx, shape, geo["k"], geo["s"], geo["p"])
+            rb = ops.rulebook_conv(torch.from_numpy(idx).to(DEV), 2, list(shape), geo["k"], geo["s"], geo["p"])
+        K = rb.kvol
+        x = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+        w = (rng.standard_normal((K, cin, cout)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        gy = rng.standard_normal((rb_o["n_out"], cout)).astype(np.float32)
+        y_ref = O.conv_fwd(x, w, b, rb_o)
+        dx_ref, dw_ref = O.conv_bwd(x, w, gy, rb_o)[:2]
+        xt, gyt = torch.from_numpy(x).to(DEV), torch.from_numpy(gy).to(DEV)
+        wt = torch.from_numpy(_w_to_param(w)).to(DEV)                    # [cout, K, cin]
+        y = ops.gather_gemm_f32(xt, wt, torch.from_numpy(b).to(DEV), rb.nbr_out, K, False, rb.n_out)
+        tol = lambda ref: 3e-6 * float(np.abs(ref).max()) + 1e-7
+        np.testing.assert_allclose(_cpu(y), y_ref, rtol=0, atol=tol(y_ref))
+        wtt = wt.permute(2, 1, 0).contiguous()
+        if subm:
+            dx = ops.gather_gemm_f32(gyt, wtt, None, rb.nbr_out, K, True, rb.n_in)
+        else:
+            dx = ops.gather_gemm_f32(gyt, wtt, None, rb.nbr_in, K, False, rb.n_in)
+        np.testing.assert_allclose(_cpu(dx), dx_ref, rtol=0, atol=tol(dx_ref))
+        dw = ops.wgrad_f32(xt, gyt, rb.pairs, rb.pair_num, K)
+        assert torch.equal(dw, ops.wgrad_f32(xt, gyt, rb.pairs, rb.pair_num, K))
+        np.testing.assert_allclose(_cpu(dw), _w_to_param(dw_ref), rtol=0, atol=tol(dw_ref))
+
+
 def test_sparse_conv_other_geometries(golden):
     g = golden("g3_conv")
     idx, shape = g["indices"], tuple(int(v) for v in g["spatial_shape"])
