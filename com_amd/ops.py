@@ -586,6 +586,10 @@ def _bn_counters(device):
     pool allocated (and zeroed) ONCE is handed out round-robin; 1024 slots: far more launches than are ever in flight."""
     key = str(device)
     ent = _BN_COUNTER_POOL.get(key)
+    if ent is None and torch.cuda.is_current_stream_capturing():
+        # first use inside a graph capture: memory allocated now belongs to that graph's pool and dies with it -- do
+        # not cache it; a per-launch buffer, zeroed by a memset node of the graph itself, serves this capture
+        return torch.zeros((L.BN_MID_ROWS * L.BN_COUNTER_STRIDE,), dtype=torch.int32, device=device)
     if ent is None:
         ent = _BN_COUNTER_POOL[key] = [torch.zeros((1024 * L.BN_MID_ROWS * L.BN_COUNTER_STRIDE,), dtype=torch.int32,
                                                    device=device), 0]
