@@ -115,22 +115,42 @@ __device__ __forceinline__ u32 blk_key(int b, int bz, int by, int bx, int Dz, in
     return (((u32)b * Dz + bz) * Hy + by) * Wx + bx;
 }
 
+// Rows arrive in first-appearance order of a range-image sweep: neighbouring rows mostly fall into the same 4x4x4
+// block.  Lanes that hold the same block as the lane before them form a RUN; only the run's first lane probes the
+// table (one CAS) and ORs the run's combined cell mask in (one atomic) -- 2 atomics per run instead of 2 per row.
 __global__ __launch_bounds__(256) void blk_insert_kernel(const int4 *__restrict__ idx, int n,
                                                          const int32_t *n_dev, int Dz, int Hy, int Wx, Blk *table,
                                                          u32 mask, int32_t *__restrict__ rowslot) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= eff_rows(n_dev, n)) return;
-    int4 c = idx[i];
-    const u32 key1 = blk_key(c.x, c.y >> 2, c.z >> 2, c.w >> 2, Dz, Hy, Wx) + 1u;
-    u32 h = hash_u32(key1) & mask;
-    for (;;) {
-        u32 prev = table[h].key1;
-        if (prev == 0u) prev = atomicCAS(&table[h].key1, 0u, key1);
-        if (prev == 0u || prev == key1) break;
-        h = (h + 1) & mask;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < eff_rows(n_dev, n);
+    const int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
+    const u32 key1 = live ? blk_key(c.x, c.y >> 2, c.z >> 2, c.w >> 2, Dz, Hy, Wx) + 1u : 0u;   // 0: dead lane
+    u64 bits = live ? 1ull << (((c.y & 3) << 4) | ((c.z & 3) << 2) | (c.w & 3)) : 0ull;
+    const u32 prev_key = (u32)__shfl_up((int)key1, 1);
+    const bool head = lane == 0 || prev_key != key1;
+    const u64 heads = __ballot(head);
+    const int head_lane = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+    // suffix OR inside the run: afterwards the run's first lane holds the OR of all its members
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 t = __shfl_down(bits, d);
+        const int hl = __shfl_down(head_lane, d);
+        if (lane + d < 64 && hl == head_lane) bits |= t;
     }
-    atomicOr((unsigned long long *)&table[h].mask, 1ull << (((c.y & 3) << 4) | ((c.z & 3) << 2) | (c.w & 3)));
-    rowslot[i] = (int)h;
+    u32 h = 0;
+    if (head && live) {
+        h = hash_u32(key1) & mask;
+        for (;;) {
+            u32 prev = table[h].key1;
+            if (prev == 0u) prev = atomicCAS(&table[h].key1, 0u, key1);
+            if (prev == 0u || prev == key1) break;
+            h = (h + 1) & mask;
+        }
+        atomicOr((unsigned long long *)&table[h].mask, bits);
+    }
+    h = (u32)__shfl((int)h, head_lane);
+    if (live) rowslot[i] = (int)h;
 }
 
 // base of every non-empty block in the row list: popcount prefix inside a 4096-slot chunk (4 slots per thread,
