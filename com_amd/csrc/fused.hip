@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int relu,
                                                        T *__restrict__ y, int vec, BnFin fin) {
+    __builtin_amdgcn_s_setprio(3);   // critical chain: ahead of the weight-gradient waves sharing the SIMD (spconv.hip)
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            int training, T *__restrict__ dx,
                                                            T *__restrict__ dres, int vec, const double *mid,
                                                            float *__restrict__ colsum_partial) {
+    __builtin_amdgcn_s_setprio(3);   // critical chain: ahead of the weight-gradient waves sharing the SIMD (spconv.hip)
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
