@@ -476,7 +476,6 @@ def main():
             # gradient; rocBLAS dot is not graph-capturable, hence mul + sum)
             loss = ProjectionLoss.apply(bd["spatial_features"])
         if ev is not None: ev("backward")
-        bucket.zero()
         try:
             loss.backward()
         except BaseException:
@@ -494,6 +493,7 @@ def main():
 
     def opt_step():
         opt.step()       # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 3 launches
+        bucket.zero()    # zero_grad for the NEXT step here, beside the voxelisation, not in front of its backward pass
         if not os.environ.get('PCD_PACK_LATE'):
             model.backbone_3d.pack_after_update()            # the next step's weight packs, off its critical path
 
