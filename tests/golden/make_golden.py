@@ -617,13 +617,75 @@ def g9():
     save("g9_center_targets", **out)
 
 
+def g10():
+    """CenterHead losses: the reference's own `neg_loss_cornernet`, `_reg_loss`, `_gather_feat`,
+    `_transpose_and_gather_feat` (pcdet/utils/loss_utils.py, extracted by name and executed as they stand) and the
+    `get_loss` arithmetic of center_head.py:230-262 on small random predictions / targets, values and gradients."""
+    import ast
+    import textwrap
+    src = open(os.path.join(REF, "pcdet/utils/loss_utils.py")).read()
+    want = {"neg_loss_cornernet", "_reg_loss", "_gather_feat", "_transpose_and_gather_feat"}
+    ns = {"torch": torch, "np": np}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            exec(compile(textwrap.dedent(ast.get_source_segment(src, node)), "loss_utils." + node.name, "exec"), ns)
+    rng = np.random.default_rng(10)
+    B, H, W, nmax, code = 2, 24, 20, 12, 8
+    order = [("center", 2), ("center_z", 1), ("dim", 3), ("rot", 2)]
+    out = {"cls_weight": np.array([1.0], np.float32), "loc_weight": np.array([2.0], np.float32),
+           "code_weights": np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], np.float32),
+           "head_order": np.array([n for n, _ in order])}
+    total = None
+    leaves = []
+    for hi, nc in enumerate((1, 2)):
+        hm_logit = torch.from_numpy(rng.standard_normal((B, nc, H, W)).astype(np.float32)).requires_grad_(True)
+        gt = np.clip(rng.random((B, nc, H, W)).astype(np.float32) ** 6, 0, 0.98)
+        n_obj = [5, 0][hi] if hi == 1 else 7                       # head 1: no positive at all in frame 1 .. see below
+        inds = np.zeros((B, nmax), np.int64)
+        mask = np.zeros((B, nmax), np.int64)
+        for b in range(B):
+            k = [7, 3][b] if hi == 0 else [5, 0][b]
+            cells = rng.choice(H * W, k, replace=False)
+            inds[b, :k] = cells
+            mask[b, :k] = 1
+            for c_ in cells:
+                gt[b, rng.integers(0, nc), c_ // W, c_ % W] = 1.0
+        if hi == 1:
+            gt[:, :, :, :] = np.where(gt == 1.0, 0.97, gt)            # head 1: num_pos == 0 -> the reference's other branch
+        boxes_t = rng.standard_normal((B, nmax, code)).astype(np.float32)
+        regs = {n: torch.from_numpy(rng.standard_normal((B, c, H, W)).astype(np.float32)).requires_grad_(True)
+                for n, c in order}
+        pred = torch.clamp(hm_logit.sigmoid(), min=1e-4, max=1 - 1e-4)                  # center_head.py:226-228
+        hm_loss, conf = ns["neg_loss_cornernet"](pred, torch.from_numpy(gt))
+        pred_boxes = torch.cat([regs[n] for n, _ in order], dim=1)
+        feat = ns["_transpose_and_gather_feat"](pred_boxes, torch.from_numpy(inds))     # RegLossCenterNet.forward
+        rl = ns["_reg_loss"](feat, torch.from_numpy(boxes_t), torch.from_numpy(mask))
+        loc_loss = (rl * torch.tensor(out["code_weights"])).sum() * 2.0
+        head_loss = hm_loss * 1.0 + loc_loss
+        total = head_loss if total is None else total + head_loss
+        leaves.append((hi, hm_logit, regs))
+        out.update({f"h{hi}_hm_logit": hm_logit.detach().numpy(), f"h{hi}_heatmap": gt, f"h{hi}_inds": inds,
+                    f"h{hi}_mask": mask, f"h{hi}_target_boxes": boxes_t, f"h{hi}_hm_loss": hm_loss.detach().numpy()[None],
+                    f"h{hi}_confidence": np.array([float(conf)], np.float32), f"h{hi}_reg_loss": rl.detach().numpy(),
+                    f"h{hi}_loc_loss": loc_loss.detach().numpy()[None]})
+        for n, _ in order:
+            out[f"h{hi}_{n}"] = regs[n].detach().numpy()
+    total.backward()
+    out["loss"] = total.detach().numpy()[None]
+    for hi, hm_logit, regs in leaves:
+        out[f"h{hi}_grad_hm_logit"] = hm_logit.grad.numpy()
+        for n, _ in order:
+            out[f"h{hi}_grad_{n}"] = regs[n].grad.numpy()
+    save("g10_center_loss", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
