@@ -12,6 +12,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .conv2d_fast import Conv3x3
+
 
 def _get(cfg, key, default=None):
     if isinstance(cfg, dict):
@@ -37,11 +39,18 @@ class BaseBEVBackbone(nn.Module):
         c_in_list = [input_channels, *num_filters[:-1]]
         self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList()
         for idx in range(len(layer_nums)):
-            layers = [nn.ZeroPad2d(1),
-                      nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
-                                bias=False), bn(num_filters[idx]), nn.ReLU()]
+            if layer_strides[idx] == 1:
+                # ZeroPad2d(1) + padding 0 == padding 1: one conv the HIP kernel covers (the pad module stays, as an
+                # identity, so that the Sequential indices -- the state-dict keys -- are the reference's)
+                layers = [nn.Identity(),
+                          Conv3x3(c_in_list[idx], num_filters[idx], kernel_size=3, stride=1, padding=1, bias=False),
+                          bn(num_filters[idx]), nn.ReLU()]
+            else:
+                layers = [nn.ZeroPad2d(1),
+                          nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
+                                    bias=False), bn(num_filters[idx]), nn.ReLU()]
             for _ in range(layer_nums[idx]):
-                layers += [nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
+                layers += [Conv3x3(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
                            bn(num_filters[idx]), nn.ReLU()]
             self.blocks.append(nn.Sequential(*layers))
             if upsample_strides:
@@ -91,7 +100,7 @@ class SeparateHead(nn.Module):
         for cur_name, spec in sep_head_dict.items():
             fc = []
             for _ in range(spec['num_conv'] - 1):
-                fc.append(nn.Sequential(nn.Conv2d(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
+                fc.append(nn.Sequential(Conv3x3(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
                                         nn.BatchNorm2d(input_channels), nn.ReLU()))
             fc.append(nn.Conv2d(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
             fc = nn.Sequential(*fc)
@@ -119,7 +128,7 @@ class CenterHeadTowers(nn.Module):
         self.compute_dtype = compute_dtype
         shared = _get(model_cfg, 'SHARED_CONV_CHANNEL')
         use_bias = bool(_get(model_cfg, 'USE_BIAS_BEFORE_NORM', False))
-        self.shared_conv = nn.Sequential(nn.Conv2d(input_channels, shared, 3, stride=1, padding=1, bias=use_bias),
+        self.shared_conv = nn.Sequential(Conv3x3(input_channels, shared, 3, stride=1, padding=1, bias=use_bias),
                                          nn.BatchNorm2d(shared), nn.ReLU())
         head_cfg = _get(model_cfg, 'SEPARATE_HEAD_CFG')
         self.heads_list = nn.ModuleList()

@@ -842,6 +842,35 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     return dw
 
 
+def conv2d_pack_weight(weight, mode=0):
+    """nn.Conv2d weight [cout, cin, 3, 3] f32 -> MFMA fragment order (mode 0: forward, 1: data gradient)."""
+    _require_cuda(weight)
+    w = weight.detach().float().contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    nbytes = L.lib().pcd_conv2d_packed_weight_bytes(cin, cout, mode)
+    packed = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().pcd_conv2d_pack_weight(L.ptr(w), cin, cout, mode, L.ptr(packed), L.stream_ptr()),
+            "pcd_conv2d_pack_weight")
+    return packed
+
+
+def conv2d_3x3_nhwc(x, packed_w, cout, bias=None):
+    """y = conv2d(x, w, bias, stride 1, padding 1) for x [B, H, W, cin] bf16 contiguous (= channels_last storage of an
+    NCHW tensor); returns [B, H, W, cout] bf16.  Data gradient: conv2d_3x3_nhwc(dy, pack(w, 1), cin)."""
+    _require_cuda(x, packed_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    B, H, W, cin = x.shape
+    y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    with _Timed(f"conv2d_3x3_kernel {cin}->{cout} {H}x{W}",
+                lambda: dict(bytes=(x.numel() + y.numel()) * 2 + 9 * cin * cout * 2, flops=2 * 9 * B * H * W * cin * cout,
+                             rows=B * H * W, pairs=0)):
+        L.check(L.lib().pcd_conv2d_3x3_nhwc(L.ptr(x), B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
+                                            L.stream_ptr()), "pcd_conv2d_3x3_nhwc")
+    return y
+
+
 def gather_gemm_f32(x, weight, bias, nbr, kvol, flip_k, n_rows_out, n_dev=None, addend=None):
     """fp32-exact y[o] = bias + sum_k x[nbr[k'][o]] @ W[k]^T (+ addend): x [n_in, c_in] f32, weight [c_out, K, c_in] f32
     (parameter layout; for a data gradient pass weight.permute(2, 1, 0) and dy).  Parity work, not speed."""

@@ -564,6 +564,19 @@ int pcd_sparse_conv_wgrad_f32(const float *x, int n_x_rows, int c_in, const floa
                               const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax, float *dweight,
                               void *stream);
 
+/* ============================================================================================
+ * (f1) Dense 3x3 convolution, stride 1, padding 1, over channels-last bf16 maps: the nn.Conv2d(k = 3, padding = 1) layers
+ *      of BaseBEVBackbone / CenterHead (pcdet/models/backbones_2d/base_bev_backbone.py:30-112,
+ *      dense_heads/center_head.py:11-46; MIOpen in the reference).  Implicit GEMM on MFMA, fp32 accumulate.
+ *   weight  [cout][cin][3][3] f32 (torch OIHW); pcd_conv2d_pack_weight(mode 0) -> forward pack,
+ *           (mode 1) -> data-gradient pack: run the SAME conv entry point on dy with cin / cout swapped
+ *   x, y    [batch][height][width][channels] bf16 (torch.channels_last storage of an NCHW tensor)
+ * cin % 32 == 0 (forward) / cout % 32 == 0 (mode 1), cout % 16 == 0. */
+size_t pcd_conv2d_packed_weight_bytes(int cin, int cout, int mode);
+int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, void *packed, void *stream);
+int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w, int cout,
+                        const float *bias, void *y, void *stream);
+
 /* Diagnostics: the device clock (100 MHz) into slot[0] at this point of the stream -- a time point inside a replayed
  * hipGraph, which events cannot give and a profiler perturbs (tools/exp_stamps.py).  No reference counterpart. */
 int pcd_debug_stamp(uint64_t *slot, void *stream);
