@@ -90,3 +90,28 @@ class Conv3x3(nn.Conv2d):
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         return _Conv3x3Function.apply(x, self.weight, self.bias)
+
+
+class BatchNormReLU2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (+ the nn.ReLU behind it when relu=True) on channels-last bf16 maps through the fused BatchNorm
+    kernels of the sparse path (fused.hip: a [B, H, W, C] map is the same [rows, C] matrix as a sparse tensor's
+    features) -- two streaming passes forward, two backward, ReLU included, instead of MIOpen's BatchNorm kernels plus
+    an elementwise ReLU each way.  Same parameters / buffers / state-dict keys as nn.BatchNorm2d
+    (base_bev_backbone.py:40-41,49-50, center_head.py:19-20); other inputs take nn.BatchNorm2d's own path."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine,
+                         track_running_stats=track_running_stats)
+        self.relu = bool(relu)
+
+    def forward(self, x):
+        from ..spconv import functional as Fsp
+        if ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 \
+                and x.is_contiguous(memory_format=torch.channels_last):
+            B, C, H, W = x.shape
+            rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+            if Fsp._fusable(self, rows):
+                y = Fsp.batch_norm_act(self, rows, None, self.relu)
+                return y.view(B, H, W, C).permute(0, 3, 1, 2)
+        y = super().forward(x)
+        return torch.relu(y) if self.relu else y

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .conv2d_fast import Conv3x3
+from .conv2d_fast import BatchNormReLU2d, Conv3x3
 
 
 def _get(cfg, key, default=None):
@@ -35,7 +35,8 @@ class BaseBEVBackbone(nn.Module):
         upsample_strides = list(_get(model_cfg, 'UPSAMPLE_STRIDES', None) or [])
         num_upsample_filters = list(_get(model_cfg, 'NUM_UPSAMPLE_FILTERS', None) or [])
         assert len(upsample_strides) == len(num_upsample_filters)
-        bn = lambda c: nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+        # (BatchNorm + the ReLU behind it in one module; an nn.Identity keeps the reference's Sequential layout)
+        bn = lambda c: BatchNormReLU2d(c, eps=1e-3, momentum=0.01, relu=True)
         c_in_list = [input_channels, *num_filters[:-1]]
         self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList()
         for idx in range(len(layer_nums)):
@@ -44,14 +45,14 @@ class BaseBEVBackbone(nn.Module):
                 # identity, so that the Sequential indices -- the state-dict keys -- are the reference's)
                 layers = [nn.Identity(),
                           Conv3x3(c_in_list[idx], num_filters[idx], kernel_size=3, stride=1, padding=1, bias=False),
-                          bn(num_filters[idx]), nn.ReLU()]
+                          bn(num_filters[idx]), nn.Identity()]
             else:
                 layers = [nn.ZeroPad2d(1),
                           nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
-                                    bias=False), bn(num_filters[idx]), nn.ReLU()]
+                                    bias=False), bn(num_filters[idx]), nn.Identity()]
             for _ in range(layer_nums[idx]):
                 layers += [Conv3x3(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
-                           bn(num_filters[idx]), nn.ReLU()]
+                           bn(num_filters[idx]), nn.Identity()]
             self.blocks.append(nn.Sequential(*layers))
             if upsample_strides:
                 stride = upsample_strides[idx]
@@ -60,12 +61,12 @@ class BaseBEVBackbone(nn.Module):
                 else:
                     k = int(np.round(1 / stride))
                     up = nn.Conv2d(num_filters[idx], num_upsample_filters[idx], k, stride=k, bias=False)
-                self.deblocks.append(nn.Sequential(up, bn(num_upsample_filters[idx]), nn.ReLU()))
+                self.deblocks.append(nn.Sequential(up, bn(num_upsample_filters[idx]), nn.Identity()))
         c_in = sum(num_upsample_filters)
         if len(upsample_strides) > len(layer_nums):
             self.deblocks.append(nn.Sequential(
                 nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
-                bn(c_in), nn.ReLU()))
+                bn(c_in), nn.Identity()))
         self.num_bev_features = c_in
 
     def forward(self, data_dict):
@@ -101,7 +102,7 @@ class SeparateHead(nn.Module):
             fc = []
             for _ in range(spec['num_conv'] - 1):
                 fc.append(nn.Sequential(Conv3x3(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
-                                        nn.BatchNorm2d(input_channels), nn.ReLU()))
+                                        BatchNormReLU2d(input_channels, relu=True), nn.Identity()))
             fc.append(nn.Conv2d(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
             fc = nn.Sequential(*fc)
             if 'hm' in cur_name:
@@ -129,7 +130,7 @@ class CenterHeadTowers(nn.Module):
         shared = _get(model_cfg, 'SHARED_CONV_CHANNEL')
         use_bias = bool(_get(model_cfg, 'USE_BIAS_BEFORE_NORM', False))
         self.shared_conv = nn.Sequential(Conv3x3(input_channels, shared, 3, stride=1, padding=1, bias=use_bias),
-                                         nn.BatchNorm2d(shared), nn.ReLU())
+                                         BatchNormReLU2d(shared, relu=True), nn.Identity())
         head_cfg = _get(model_cfg, 'SEPARATE_HEAD_CFG')
         self.heads_list = nn.ModuleList()
         for names in class_names_each_head:

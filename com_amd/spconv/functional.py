@@ -438,7 +438,7 @@ class FusedBNFunction(Function):
 
 def _fusable(bn, x):
     import torch.nn as nn
-    if not isinstance(bn, nn.BatchNorm1d) or not x.is_cuda or x.dim() != 2:
+    if not isinstance(bn, nn.modules.batchnorm._BatchNorm) or not x.is_cuda or x.dim() != 2:   # (1d; 2d via hotpath.conv2d_fast)
         return False
     if x.dtype not in (torch.float32, torch.bfloat16):
         return False
