@@ -103,7 +103,7 @@ class SeparateHead(nn.Module):
             for _ in range(spec['num_conv'] - 1):
                 fc.append(nn.Sequential(Conv3x3(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
                                         BatchNormReLU2d(input_channels, relu=True), nn.Identity()))
-            fc.append(nn.Conv2d(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
+            fc.append(Conv3x3(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
             fc = nn.Sequential(*fc)
             if 'hm' in cur_name:
                 fc[-1].bias.data.fill_(init_bias)

@@ -93,7 +93,8 @@ def test_dense_bev_stack_bf16_channels_last_vs_torch_fp32():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,hw,bias", [(128, 128, (47, 52), False), (256, 128, (40, 33), False),
-                                               (64, 64, (24, 24), True), (512, 64, (20, 18), True)])
+                                               (64, 64, (24, 24), True), (512, 64, (20, 18), True),
+                                               (64, 3, (31, 17), True)])
 def test_conv3x3_hip_kernel_forward_and_gradients(cin, cout, hw, bias):
     """hotpath.conv2d_fast.Conv3x3 (implicit-GEMM MFMA kernel: forward + data gradient; weight gradient through the
     sparse pair kernel over dense pair lists) against torch conv2d in fp32 on the same bf16-rounded operands: outputs
