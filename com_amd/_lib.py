@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pcd_debug_stamp": (_i, [_vp, _vp]),
     "pcd_conv2d_packed_weight_bytes": (_sz, [_i, _i, _i]),
     "pcd_conv2d_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pcd_conv2d_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_conv2d_3x3_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_gather_gemm_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),

@@ -27,14 +27,13 @@ constexpr int W_BYTES = 9 * 4 * 64 * 16;   // one chunk's weights: [tap][cout bl
 // [16 g, 16 g + 16) across the 4 blocks
 __host__ __device__ inline int chan_of(int mb, int i) { return (i >> 2) * 16 + mb * 4 + (i & 3); }
 
-// weight [cout][cin][3][3] f32 (OIHW) -> packed [cout / 64][cin / 32][tap][mb][lane][8] bf16
+// weight [cout][cin][3][3] f32 (OIHW) -> packed [cout_pad / 64][cin / 32][tap][mb][lane][8] bf16; output channels
+// in [cout, cout_pad) are zero (small heads run padded).
 // mode 1 (data gradient): the roles of cin / cout swap and the taps rotate by 180 degrees
-__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int mode,
-                                                          unsigned short *__restrict__ packed, size_t total) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte lane piece per thread
-    if (e >= total) return;
+__device__ __forceinline__ void conv2d_pack_piece(const float *__restrict__ w, int cin, int cout, int cout_pad, int mode,
+                                                  unsigned short *__restrict__ packed, size_t e) {
     const int n_out = mode == 0 ? cout : cin, n_in = mode == 0 ? cin : cout;
-    const int ncc = n_in / 32;
+    const int ncc = (mode == 0 ? cin : cout_pad) / 32;
     const int lane = (int)(e & 63);
     size_t q = e >> 6;
     const int mb = (int)(q & 3); q >>= 2;
@@ -56,6 +55,24 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
     out.x = v[0] | ((u32)v[1] << 16); out.y = v[2] | ((u32)v[3] << 16);
     out.z = v[4] | ((u32)v[5] << 16); out.w = v[6] | ((u32)v[7] << 16);
     reinterpret_cast<uint4 *>(packed)[e] = out;
+}
+
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int cout_pad,
+                                                          int mode, unsigned short *__restrict__ packed, size_t total) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte lane piece per thread
+    if (e < total) conv2d_pack_piece(w, cin, cout, cout_pad, mode, packed, e);
+}
+
+// all packs of a model in ONE launch: table rows {weight, packed, cin, cout, cout_pad, mode, first block, pieces}
+__global__ __launch_bounds__(256) void conv2d_pack_batched_kernel(const long long *__restrict__ table, int n) {
+    int j = 0;
+    for (int q = 1; q < n; ++q)
+        if (table[(size_t)q * 8 + 6] <= (long long)blockIdx.x) j = q;
+    const long long *row = table + (size_t)j * 8;
+    const size_t e = (size_t)(blockIdx.x - row[6]) * 256 + threadIdx.x;
+    if (e < (size_t)row[7])
+        conv2d_pack_piece((const float *)row[0], (int)row[2], (int)row[3], (int)row[4], (int)row[5],
+                          (unsigned short *)row[1], e);
 }
 
 __global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short *__restrict__ x, int B, int H, int W,
@@ -176,20 +193,32 @@ __global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short
 
 }  // namespace
 
+static int pad32(int c) { return (c + 31) / 32 * 32; }
+
+// (output channels are padded to a multiple of 32: the data gradient contracts over them in steps of 32)
 extern "C" size_t pcd_conv2d_packed_weight_bytes(int cin, int cout, int mode) {
     if (cin <= 0 || cout <= 0 || (mode != 0 && mode != 1)) return 0;
-    const int n_out = mode == 0 ? cout : cin, n_in = mode == 0 ? cin : cout;
-    return (size_t)((n_out + 63) / 64) * ((n_in + 31) / 32) * W_BYTES;
+    const int cp = pad32(cout);
+    const int n_out = mode == 0 ? cp : cin, n_in = mode == 0 ? cin : cp;
+    return (size_t)((n_out + 63) / 64) * (n_in / 32) * W_BYTES;
 }
 
 extern "C" int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, void *packed, void *stream) {
     PCD_ENTER();
     if (!weight || !packed || cin <= 0 || cout <= 0 || (mode != 0 && mode != 1)) return PCD_ERR_INVALID_ARG;
-    const int n_in = mode == 0 ? cin : cout;
-    if (n_in % 32) return PCD_ERR_UNSUPPORTED;
+    if (cin % 32) return PCD_ERR_UNSUPPORTED;
     const size_t total = pcd_conv2d_packed_weight_bytes(cin, cout, mode) / 16;
     conv2d_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        weight, cin, cout, mode, (unsigned short *)packed, total);
+        weight, cin, cout, pad32(cout), mode, (unsigned short *)packed, total);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_conv2d_pack_weights_batched(const void *table, int n, int total_blocks, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || total_blocks < 0 || (n > 0 && !table)) return PCD_ERR_INVALID_ARG;
+    if (n == 0 || total_blocks == 0) return PCD_OK;
+    conv2d_pack_batched_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const long long *)table, n);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -202,7 +231,7 @@ extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int wid
     if (cin % 32 || cout % 16) return PCD_ERR_UNSUPPORTED;
     const double xb = (double)batch * height * width * cin * 2;
     if (xb >= 4294966000.0) return PCD_ERR_UNSUPPORTED;
-    const size_t wb = pcd_conv2d_packed_weight_bytes(cin, cout, 0);
+    const size_t wb = (size_t)((cout + 63) / 64) * (cin / 32) * W_BYTES;   // bytes of the pack the kernel reads
     const size_t lds = 2 * (size_t)IN_BYTES + 2 * (size_t)W_BYTES;
     static bool raised = false;
     if (!raised) {

@@ -39,34 +39,39 @@ def _dense_pairs(B, H, W, device):
     return pairs, num
 
 
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
 class _Conv3x3Function(torch.autograd.Function):
     """Output channel counts that are not a multiple of 32 (the 1 / 2 / 3-channel final convs of the head towers) run
-    with the weights zero-padded to 32 channels: MIOpen spends 0.4 ms on each of those tiny convs."""
+    padded with zero weights (the packs carry the padding): MIOpen spends 0.4 ms on each of those tiny convs.
+    pack_f / pack_d: packs made ahead (Conv3x3Packs), or None: packed here."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, pack_f, pack_d):
         # x: [B, C, H, W] bf16, channels_last storage
         xn = x.detach().permute(0, 2, 3, 1)
         assert xn.is_contiguous()
         cout = weight.shape[0]
-        cp = (cout + 31) // 32 * 32          # (the data gradient contracts over the output channels in steps of 32)
-        w = weight.detach().float()
+        cp = _pad32(cout)
         b = bias.detach().float() if bias is not None else None
-        if cp != cout:
-            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - cout))
-            b = torch.nn.functional.pad(b, (0, cp - cout)) if b is not None else None
-        y = ops.conv2d_3x3_nhwc(xn, ops.conv2d_pack_weight(w, 0), cp, b)
+        if b is not None and cp != cout:
+            b = torch.nn.functional.pad(b, (0, cp - cout))
+        if pack_f is None:
+            pack_f = ops.conv2d_pack_weight(weight, 0)
+        y = ops.conv2d_3x3_nhwc(xn, pack_f, cp, b)
         if cp != cout:
             y = y[..., :cout].contiguous()
-        ctx.save_for_backward(xn, w)
-        ctx.has_bias, ctx.cout, ctx.wdtype = bias is not None, cout, weight.dtype
+        ctx.save_for_backward(xn, weight, pack_d)
+        ctx.has_bias, ctx.cout = bias is not None, cout
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        xn, w = ctx.saved_tensors                      # w: f32, output channels padded to a multiple of 32
+        xn, weight, pack_d = ctx.saved_tensors
         B, H, W, cin = xn.shape
-        cout, cp = ctx.cout, w.shape[0]
+        cout, cp = ctx.cout, _pad32(ctx.cout)
         dyn = dy.permute(0, 2, 3, 1)
         if dyn.dtype != torch.bfloat16:
             dyn = dyn.to(torch.bfloat16)
@@ -75,14 +80,16 @@ class _Conv3x3Function(torch.autograd.Function):
         dyn = dyn.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_3x3_nhwc(dyn, ops.conv2d_pack_weight(w, 1), cin).permute(0, 3, 1, 2)
+            if pack_d is None:
+                pack_d = ops.conv2d_pack_weight(weight, 1)
+            dx = ops.conv2d_3x3_nhwc(dyn, pack_d, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             pairs, num = _dense_pairs(B, H, W, xn.device)
             dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)      # [cp, 9, cin] f32
-            dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(ctx.wdtype)
+            dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dyn.reshape(-1, cp)[:, :cout].float().sum(0)
-        return dx, dw, db
+        return dx, dw, db, None, None
 
 
 class Conv3x3(nn.Conv2d):
@@ -94,7 +101,8 @@ class Conv3x3(nn.Conv2d):
         return (ENABLED and bf16 and x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.stride == (1, 1)
                 and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
                 and self.padding_mode == 'zeros' and self.in_channels % 32 == 0
-                and x.shape[0] * x.shape[2] * x.shape[3] * max(self.in_channels, self.out_channels) * 2 < 2 ** 32 - 4096)
+                and x.shape[0] * x.shape[2] * x.shape[3] * max(self.in_channels, _pad32(self.out_channels)) * 2
+                < 2 ** 32 - 4096)
 
     def forward(self, x):
         if not self._fast(x):
@@ -103,7 +111,53 @@ class Conv3x3(nn.Conv2d):
             x = x.to(torch.bfloat16)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        return _Conv3x3Function.apply(x, self.weight, self.bias)
+        pf = pd = None
+        ahead = getattr(self, "_packs_ahead", None)
+        if ahead is not None:                        # Conv3x3Packs.run() since the last weight update: use them ONCE
+            pf, pd = ahead
+            self._packs_ahead = None
+        return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
+
+
+class Conv3x3Packs:
+    """Forward + data-gradient packs of all Conv3x3 modules of a model in ONE launch (pcd_conv2d_pack_weights_batched)
+    into persistent buffers -- call `run()` right after every optimizer step (the weights do not change again before
+    the next forward; 2 x 22 small pack launches otherwise sit in front of the convs of the CenterPoint BEV stack).
+    A module uses the packs for exactly one forward / backward and packs by itself again afterwards, so a forgotten
+    `run()` costs time, never correctness."""
+
+    def __init__(self, model):
+        import ctypes  # noqa: F401
+        from .. import _lib as L
+        self.convs = [m for m in model.modules() if isinstance(m, Conv3x3) and m.kernel_size == (3, 3)
+                      and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 32 == 0
+                      and m.weight.is_cuda and m.weight.dtype == torch.float32]
+        rows, first, self.bufs = [], 0, []
+        lib = L.lib()
+        for m in self.convs:
+            cin, cout = m.in_channels, m.out_channels
+            pair = []
+            for mode in (0, 1):
+                nbytes = lib.pcd_conv2d_packed_weight_bytes(cin, cout, mode)
+                buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=m.weight.device)
+                rows.append([m.weight.data_ptr(), buf.data_ptr(), cin, cout, _pad32(cout), mode, first, nbytes // 16])
+                first += (nbytes // 16 + 255) // 256
+                pair.append(buf)
+            self.bufs.append(tuple(pair))
+        self.total_blocks = first
+        self.keys = tuple(m.weight.data_ptr() for m in self.convs)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(self.convs[0].weight.device) if rows else None
+
+    def run(self):
+        from .. import _lib as L
+        if self.table is None:
+            return
+        if self.keys != tuple(m.weight.data_ptr() for m in self.convs):
+            raise L.PcdError("Conv3x3Packs: a weight moved since the plan was built (build a new plan)")
+        L.check(L.lib().pcd_conv2d_pack_weights_batched(L.ptr(self.table), len(self.convs) * 2, self.total_blocks,
+                                                        L.stream_ptr()), "pcd_conv2d_pack_weights_batched")
+        for m, pair in zip(self.convs, self.bufs):
+            m._packs_ahead = pair
 
 
 class BatchNormReLU2d(nn.BatchNorm2d):

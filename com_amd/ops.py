@@ -843,7 +843,8 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
 
 
 def conv2d_pack_weight(weight, mode=0):
-    """nn.Conv2d weight [cout, cin, 3, 3] f32 -> MFMA fragment order (mode 0: forward, 1: data gradient)."""
+    """nn.Conv2d weight [cout, cin, 3, 3] f32 -> MFMA fragment order (mode 0: forward, 1: data gradient); the output
+    channels are zero-padded to a multiple of 32 (run the conv with that count)."""
     _require_cuda(weight)
     w = weight.detach().float().contiguous()
     cout, cin = w.shape[0], w.shape[1]

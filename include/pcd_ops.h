@@ -571,9 +571,14 @@ int pcd_sparse_conv_wgrad_f32(const float *x, int n_x_rows, int c_in, const floa
  *   weight  [cout][cin][3][3] f32 (torch OIHW); pcd_conv2d_pack_weight(mode 0) -> forward pack,
  *           (mode 1) -> data-gradient pack: run the SAME conv entry point on dy with cin / cout swapped
  *   x, y    [batch][height][width][channels] bf16 (torch.channels_last storage of an NCHW tensor)
- * cin % 32 == 0 (forward) / cout % 32 == 0 (mode 1), cout % 16 == 0. */
+ * cin % 32 == 0; packs pad the output channels with zeros to a multiple of 32 (run the conv with that padded count:
+ * the data gradient contracts over it in steps of 32). */
 size_t pcd_conv2d_packed_weight_bytes(int cin, int cout, int mode);
 int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, void *packed, void *stream);
+/* all packs of a model in one launch: `table` = n device rows of 8 int64 {weight ptr, packed ptr, cin, cout,
+ * cout padded to 32, mode, first workgroup, 16-byte pieces = packed bytes / 16}, total_blocks = sum of
+ * ceil(pieces / 256) (rows ordered by first workgroup) */
+int pcd_conv2d_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w, int cout,
                         const float *bias, void *y, void *stream);
 
