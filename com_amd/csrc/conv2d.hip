@@ -75,14 +75,15 @@ __global__ __launch_bounds__(256) void conv2d_pack_batched_kernel(const long lon
                           (unsigned short *)row[1], e);
 }
 
-__global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short *__restrict__ x, int B, int H, int W,
+template <int WB>   // weight stage buffers: 2 = double buffered (113 KB LDS, 1 workgroup / CU); 1 = single (77 KB, 2 / CU)
+__global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const unsigned short *__restrict__ x, int B, int H, int W,
                                                              int cin, const uint4 *__restrict__ wp, int cout,
                                                              const float *__restrict__ bias,
                                                              unsigned short *__restrict__ y, unsigned x_bytes,
                                                              unsigned w_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *in_s = smem;                       // [2][IN_BYTES]
-    char *w_s = smem + 2 * IN_BYTES;         // [2][W_BYTES]
+    char *w_s = smem + 2 * IN_BYTES;         // [WB][W_BYTES]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = lane & 15, g = lane >> 4;
     const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short
         }
 #pragma unroll
         for (int it = 0; it < 9; ++it)
-            *reinterpret_cast<u32x4 *>(w_s + buf * W_BYTES + (it * 256 + threadIdx.x) * 16) = w_r[it];
+            *reinterpret_cast<u32x4 *>(w_s + (WB == 2 ? buf : 0) * W_BYTES + (it * 256 + threadIdx.x) * 16) = w_r[it];
     };
 
     f32x4 acc[4][4];
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short
     for (int cc = 0; cc < ncc; ++cc) {
         const int buf = cc & 1;
         if (cc + 1 < ncc) load_chunk(cc + 1);
-        const char *ins = in_s + buf * IN_BYTES, *ws = w_s + buf * W_BYTES;
+        const char *ins = in_s + buf * IN_BYTES, *ws = w_s + (WB == 2 ? buf : 0) * W_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_3x3_kernel(const unsigned short
                 for (int pb = 0; pb < 4; ++pb)
                     acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bf[pb], acc[mb][pb], 0, 0, 0);
         }
+        if (WB == 1) __syncthreads();                      // single weight stage: everyone is done reading it
         if (cc + 1 < ncc) store_chunk(buf ^ 1);            // (read in the previous iteration, before its barrier)
         __syncthreads();
     }
@@ -231,20 +233,28 @@ extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int wid
     if (cin % 32 || cout % 16) return PCD_ERR_UNSUPPORTED;
     const double xb = (double)batch * height * width * cin * 2;
     if (xb >= 4294966000.0) return PCD_ERR_UNSUPPORTED;
-    const size_t wb = (size_t)((cout + 63) / 64) * (cin / 32) * W_BYTES;   // bytes of the pack the kernel reads
-    const size_t lds = 2 * (size_t)IN_BYTES + 2 * (size_t)W_BYTES;
+    const size_t wb_bytes = (size_t)((cout + 63) / 64) * (cin / 32) * W_BYTES;   // bytes of the pack the kernel reads
+    static const int wb = getenv("PCD_CONV2D_WB") ? atoi(getenv("PCD_CONV2D_WB")) : 1;   // (1: 28-35 % of the MFMA peak, 2: 21-27 %)
+    const size_t lds = 2 * (size_t)IN_BYTES + (size_t)(wb == 1 ? 1 : 2) * (size_t)W_BYTES;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)conv2d_3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv2d_3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * IN_BYTES + 2 * W_BYTES)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv2d_3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * IN_BYTES + W_BYTES)) != hipSuccess)
             return PCD_ERR_LAUNCH;
         raised = true;
     }
     const int tiles = batch * ((height + TP - 1) / TP) * ((width + TP - 1) / TP);
     dim3 grid((unsigned)tiles, (unsigned)((cout + 63) / 64));
-    conv2d_3x3_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
-                                                              (const uint4 *)packed_w, cout, bias,
-                                                              (unsigned short *)y, (unsigned)xb, (unsigned)wb);
+    if (wb == 1)
+        conv2d_3x3_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
+                                                                     (const uint4 *)packed_w, cout, bias,
+                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes);
+    else
+        conv2d_3x3_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
+                                                                     (const uint4 *)packed_w, cout, bias,
+                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
