@@ -406,6 +406,9 @@ def main():
     # the side-stream weight-gradient chain is joined once, at the end of the backward pass (a lag >= the number of
     # convs; lag 1 measured 0.5 % slower: every join is an edge that orders a main-chain kernel behind a weight gradient)
     Fsp.WGRAD_JOIN_LAG = int(os.environ.get('PCD_WGRAD_LAG', '32'))
+    # voxel rows in (b, z, y, x) key order (pcd_voxelize_hard_sorted: the same voxels as the reference's voxeliser, numbered
+    # like torch.unique / spconv's strided convs number theirs); PCD_ROW_ORDER=first = first-appearance ids
+    ROW_ORDER = os.environ.get('PCD_ROW_ORDER', 'key')
     Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
     ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
     Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
@@ -468,7 +471,8 @@ def main():
         bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
         bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
                                                 synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True,
-                                                out=out["_result"] if out is not None else None)
+                                                out=out["_result"] if out is not None else None,
+                                                row_order=ROW_ORDER)
         bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B,
                "_result": bd["voxelize_result"]}
         if "voxel_num_rows" in bd:

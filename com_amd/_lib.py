@@ -29,6 +29,9 @@ PROTOTYPES = {
     "pcd_voxelize_hard_workspace_bytes": (_sz, [_i, _i, _i]),
     "pcd_voxelize_hard": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _i, _vp, _vp, _sz, _vp]),
+    "pcd_voxelize_hard_sorted_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
+    "pcd_voxelize_hard_sorted": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                      _i, _vp, _vp, _sz, _vp]),
     "pcd_mean_vfe": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -160,12 +160,58 @@ __global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *ran
     voxel_counts[batch] = base;
 }
 
+// Key-sorted row order (row_order = 1): the KEPT voxels (first-appearance rank below the per-frame cap, exactly the
+// reference's set) are numbered by their (b, z, y, x) key instead -- the order spconv's strided convs and
+// torch.unique produce anyway -- so that the neighbours a level-1 conv gathers lie in nearby rows.  No sort: an
+// occupancy bitmap over the key space, counts per 1024-key chunk taken while marking, one scan of the chunk
+// counts; a voxel's row = chunk prefix + set bits below it inside its chunk (one 128-byte line).
+constexpr int VOX_CHUNK_WORDS = 32;
+
+__global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
+    const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
+    VoxGeom G, const int *__restrict__ rank, const int *frame_rank0, const int32_t *voxel_counts,
+    u32 *bitmap, int *chunk_cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int rk = rank[i];
+    if (rank[i + 1] == rk) return;                 // not the first point of a voxel
+    const int b = frame_of(offs, batch, i);
+    if (rk - frame_rank0[b] >= voxel_counts[b]) return;
+    const float *p0 = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p0[0], p0[1], p0[2]};
+    int cx, cy, cz;
+    voxel_coord(xyz, G, cx, cy, cz);
+    const u32 key = (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+    atomicOr(bitmap + (key >> 5), 1u << (key & 31));            // one first point per voxel: every mark is new
+    atomicAdd(chunk_cnt + (key >> 10), 1);
+}
+
+__device__ __forceinline__ int vox_sorted_row(const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix,
+                                              u32 key) {
+    const u32 chunk = key >> 10;
+    const int w_in = (int)((key >> 5) & 31u);
+    const uint4 *line = reinterpret_cast<const uint4 *>(bitmap + (size_t)chunk * VOX_CHUNK_WORDS);
+    int r = chunk_prefix[chunk];
+    for (int q = 0; q * 4 <= w_in; ++q) {
+        const uint4 v = line[q];
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wi = q * 4 + j;
+            if (wi < w_in) r += __popc(w[j]);
+            else if (wi == w_in) r += __popc(w[j] & ((1u << (key & 31)) - 1u));
+        }
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(256) void vox_emit_kernel(
     const float *__restrict__ pts, int n, int stride, int feat_off, int C,
     const int32_t *__restrict__ offs, int batch, VoxGeom G, int T, int L, const u32 *__restrict__ best,
     const int32_t *__restrict__ pt_slot, const int *__restrict__ rank, const int *frame_rank0,
     const int *frame_base, const int32_t *voxel_counts, float *voxels, int32_t *coords,
-    int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride) {
+    int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride,
+    const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int rk = rank[i];
@@ -179,6 +225,8 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     float xyz[3] = {p0[0], p0[1], p0[2]};
     int cx, cy, cz;
     voxel_coord(xyz, G, cx, cy, cz);
+    if (bitmap)    // key order (frames are the key's major digit: frame b still owns rows frame_base[b] ..)
+        row = vox_sorted_row(bitmap, chunk_prefix, (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx);
     reinterpret_cast<int4 *>(coords)[row] = make_int4(b, cz, cy, cx);
     float sum[16];
     for (int c = 0; c < C; ++c) sum[c] = 0.0f;
@@ -332,10 +380,25 @@ static u32 table_capacity(int n) {
 }  // namespace
 
 // =============================================================================================
-extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points, int batch) {
+static bool sorted_words(int batch, const VoxGeom &G, size_t *nwords, size_t *nchunks) {
+    const double vol = (double)batch * G.gx * G.gy * G.gz;
+    if (vol >= 4294967295.0 - 1024.0) return false;
+    *nchunks = ((size_t)vol + 1023) / 1024;
+    *nwords = *nchunks * VOX_CHUNK_WORDS;
+    return true;
+}
+
+static size_t hard_workspace_bytes(int n_points, int max_points, int batch, const VoxGeom *G) {
     if (n_points < 0 || max_points <= 0 || batch <= 0) return 0;
     u32 cap = table_capacity(n_points);
     size_t b = 0;
+    if (G) {
+        size_t nw, nc;
+        if (!sorted_words(batch, *G, &nw, &nc)) return 0;
+        b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels
+        b += ws_piece(nc + 1, sizeof(int));                // chunk counts -> prefix (in place)
+        b += ws_piece(pcd_div_up((int)nc, 256) + 2, sizeof(int));
+    }
     b += ws_piece((size_t)cap * slot_words(max_points), sizeof(u32));   // {key u64, best u32[T]} records
     b += ws_piece(n_points + 1, sizeof(int32_t));          // pt_slot
     b += ws_piece(n_points + 1, sizeof(int));              // rank
@@ -344,13 +407,24 @@ extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points
     return b;
 }
 
-extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_stride,
-                                 int feat_offset, int num_features, const int32_t *frame_offsets,
-                                 int batch, const float *range_host, const float *vsize_host,
-                                 int max_points, int max_voxels, int cap, float *voxels,
-                                 int32_t *coords, int32_t *num_points, float *mean_f32,
-                                 void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points, int batch) {
+    return hard_workspace_bytes(n_points, max_points, batch, nullptr);
+}
+
+extern "C" size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
+                                                           const float *range_host, const float *vsize_host) {
+    if (!range_host || !vsize_host) return 0;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    return hard_workspace_bytes(n_points, max_points, batch, &G);
+}
+
+static int voxelize_hard_impl(const float *points, int n_points, int point_stride,
+                              int feat_offset, int num_features, const int32_t *frame_offsets,
+                              int batch, const float *range_host, const float *vsize_host,
+                              int max_points, int max_voxels, int cap, float *voxels,
+                              int32_t *coords, int32_t *num_points, float *mean_f32,
+                              void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                              void *workspace, size_t workspace_bytes, void *stream, bool key_order) {
     PCD_ENTER();
     if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
         !frame_offsets || !range_host || !vsize_host || !coords || !num_points || !voxel_counts)
@@ -362,9 +436,18 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
     hipStream_t st = (hipStream_t)stream;
     VoxGeom G = make_geom(range_host, vsize_host);
     if ((double)batch * G.gx * G.gy * G.gz >= 1.8e19) return PCD_ERR_KEYSPACE;
-    if (workspace_bytes < pcd_voxelize_hard_workspace_bytes(n_points, max_points, batch))
+    size_t nw = 0, nc = 0;
+    if (key_order && !sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
+    if (workspace_bytes < hard_workspace_bytes(n_points, max_points, batch, key_order ? &G : nullptr))
         return PCD_ERR_WORKSPACE;
     WsCarver ws(workspace, workspace_bytes);
+    u32 *bitmap = nullptr;
+    int *chunk_prefix = nullptr, *chunk_bsums = nullptr;
+    if (key_order) {
+        bitmap = ws.take<u32>(nw);
+        chunk_prefix = ws.take<int>(nc + 1);
+        chunk_bsums = ws.take<int>(pcd_div_up((int)nc, 256) + 2);
+    }
     u32 tcap = table_capacity(n_points);
     const int L = slot_words(max_points);
     u32 *tab = ws.take<u32>((size_t)tcap * L);
@@ -399,15 +482,53 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
     }
     vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
                                         frame_base, voxel_counts);
+    if (n_points > 0 && key_order) {
+        // (bitmap and chunk counts are adjacent workspace pieces: one fill)
+        pcd_fill(bitmap, 0, (size_t)((char *)(chunk_prefix + nc + 1) - (char *)bitmap), st);
+        vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
+                                                   G, rank, frame_rank0, voxel_counts, bitmap, chunk_prefix);
+        StoredFlag cf{chunk_prefix};
+        const int ncb = pcd_div_up((int)nc, 256);
+        scan_reduce_kernel<StoredFlag><<<ncb, 256, 0, st>>>(cf, (int)nc, chunk_bsums);
+        scan_spine_kernel<<<1, 256, 0, st>>>(chunk_bsums, ncb, nullptr);
+        scan_down_kernel<StoredFlag><<<ncb, 256, 0, st>>>(cf, (int)nc, chunk_bsums, chunk_prefix);   // in place
+        PCD_RETURN_IF_LAUNCH_FAILED();
+    }
     if (n_points > 0) {
         vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                             num_features, frame_offsets, batch, G, max_points, L, best,
                                             pt_slot, rank, frame_rank0, frame_base, voxel_counts,
                                             voxels, coords, num_points, mean_f32,
-                                            (unsigned short *)mean_bf16, mean_bf16_stride);
+                                            (unsigned short *)mean_bf16, mean_bf16_stride, bitmap, chunk_prefix);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_stride,
+                                 int feat_offset, int num_features, const int32_t *frame_offsets,
+                                 int batch, const float *range_host, const float *vsize_host,
+                                 int max_points, int max_voxels, int cap, float *voxels,
+                                 int32_t *coords, int32_t *num_points, float *mean_f32,
+                                 void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
+                              range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
+                              mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
+                              false);
+}
+
+extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride,
+                                        int feat_offset, int num_features, const int32_t *frame_offsets,
+                                        int batch, const float *range_host, const float *vsize_host,
+                                        int max_points, int max_voxels, int cap, float *voxels,
+                                        int32_t *coords, int32_t *num_points, float *mean_f32,
+                                        void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
+                              range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
+                              mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
+                              true);
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

@@ -200,12 +200,16 @@ def grid_size(point_cloud_range, voxel_size):
 
 # ---------------------------------------------------------------------------------------------
 def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
-                  feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None):
+                  feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None,
+                  row_order="first"):
     """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
     rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
     voxel_features, voxel_features_bf16, counts (host list per frame)).
     `out` (static-shape mode): the dict a previous call returned -- its tensors are written again instead of
-    allocating new ones (a prefetched voxelisation then lands in the buffers the consumer already holds)."""
+    allocating new ones (a prefetched voxelisation then lands in the buffers the consumer already holds).
+    `row_order`: "first" = the reference's first-appearance voxel ids; "key" = the same voxels numbered by ascending
+    (b, z, y, x) (pcd_voxelize_hard_sorted: spatially coherent rows for the sparse convs)."""
+    assert row_order in ("first", "key")
     _require_cuda(points)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
     dev = points.device
@@ -221,7 +225,16 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     if static:
         cap = min(cap, PLAN.cap("voxels"))
     lib = L.lib()
-    ws = _ws(lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch), dev)
+    if row_order == "key":
+        ws_bytes = lib.pcd_voxelize_hard_sorted_workspace_bytes(n, max_points, batch, L.host_f32(point_cloud_range),
+                                                                L.host_f32(voxel_size))
+        if ws_bytes == 0:
+            raise RuntimeError("pcd_voxelize_hard_sorted: key space of the grid exceeds 32 bits")
+        entry = lib.pcd_voxelize_hard_sorted
+    else:
+        ws_bytes = lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch)
+        entry = lib.pcd_voxelize_hard
+    ws = _ws(ws_bytes, dev)
     def buf(key, shape, dtype, want=True):
         if not want:
             return None
@@ -241,11 +254,11 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         return dict(bytes=24 * n + 36 * m_ + (104 * m_ if want_voxels else 0), flops=0, rows=m_, pairs=0)
 
     with _Timed("voxelize_hard", meta):
-        L.check(lib.pcd_voxelize_hard(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
-                                      L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
-                                      max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
-                                      L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
-                                      L.stream_ptr()), "pcd_voxelize_hard")
+        L.check(entry(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
+                      L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
+                      max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
+                      L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
+                      L.stream_ptr()), "pcd_voxelize_hard")
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]

@@ -80,6 +80,22 @@ int pcd_voxelize_hard(const float *points, int n_points, int point_stride, int f
                       int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
                       int32_t *voxel_counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same operation, same kept set (the first max_voxels voxels per frame in first-appearance order, their first
+ * max_points points in point order -- data_processor.py:44-60), rows numbered by ascending (b, z, y, x) key instead of
+ * by first appearance: the order torch.unique (dynamic_mean_vfe.py:57-66) and spconv's strided convs give their rows.
+ * Every consumer of the hot path (mean_vfe.py:25-29 -> spconv_backbone.py:239-246) is invariant to the row order;
+ * with training's shuffled points (data_processor.py:103-113) the first-appearance order is random in space, the key
+ * order keeps the 27 neighbours of a level-1 row in nearby rows.  Needs batch*gz*gy*gx < 2^32 - 1024 (PCD_ERR_KEYSPACE
+ * otherwise); the workspace holds an occupancy bitmap of that many bits. */
+size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
+                                                const float *range_host /*[6]*/, const float *vsize_host /*[3]*/);
+int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride, int feat_offset,
+                             int num_features, const int32_t *frame_offsets, int batch,
+                             const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
+                             int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
+                             int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
+                             int32_t *voxel_counts, void *workspace, size_t workspace_bytes, void *stream);
+
 /* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
 int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
                  int num_features, float *out, void *stream);
