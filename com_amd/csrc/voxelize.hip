@@ -160,17 +160,23 @@ __global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *ran
     voxel_counts[batch] = base;
 }
 
-// Key-sorted row order (row_order = 1): the KEPT voxels (first-appearance rank below the per-frame cap, exactly the
-// reference's set) are numbered by their (b, z, y, x) key instead -- the order spconv's strided convs and
+// Key-sorted row order (pcd_voxelize_hard_sorted): the KEPT voxels (first-appearance rank below the per-frame cap,
+// exactly the reference's set) are numbered by their (b, z, y, x) key instead -- the order spconv's strided convs and
 // torch.unique produce anyway -- so that the neighbours a level-1 conv gathers lie in nearby rows.  No sort: an
-// occupancy bitmap over the key space, counts per 1024-key chunk taken while marking, one scan of the chunk
-// counts; a voxel's row = chunk prefix + set bits below it inside its chunk (one 128-byte line).
+// occupancy bitmap over the key space, population counts per 128-byte CHUNK (1024 keys) taken by one coalesced pass
+// over the bitmap, an exclusive scan of the chunk counts; a voxel's row = its chunk's prefix + the set bits below its
+// own inside the chunk (one line per lookup).  Marking costs one memory-side atomic per voxel -- the only one: ~13 G
+// atomics/s device-wide measured, and a second atomic per voxel on a per-chunk counter (contended: neighbouring
+// voxels share chunks) took the mark kernel from 18 to 62 us.
 constexpr int VOX_CHUNK_WORDS = 32;
+
+__device__ __forceinline__ u32 vox_key_u32(const VoxGeom &G, int b, int cz, int cy, int cx) {
+    return (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+}
 
 __global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
     const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
-    VoxGeom G, const int *__restrict__ rank, const int *frame_rank0, const int32_t *voxel_counts,
-    u32 *bitmap, int *chunk_cnt) {
+    VoxGeom G, const int *__restrict__ rank, const int *frame_rank0, const int32_t *voxel_counts, u32 *bitmap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int rk = rank[i];
@@ -181,9 +187,79 @@ __global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
     float xyz[3] = {p0[0], p0[1], p0[2]};
     int cx, cy, cz;
     voxel_coord(xyz, G, cx, cy, cz);
-    const u32 key = (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
-    atomicOr(bitmap + (key >> 5), 1u << (key & 31));            // one first point per voxel: every mark is new
-    atomicAdd(chunk_cnt + (key >> 10), 1);
+    const u32 key = vox_key_u32(G, b, cz, cy, cx);
+    atomicOr(bitmap + (key >> 5), 1u << (key & 31));
+}
+
+// chunk population counts: a block covers 256 chunks in 8 rounds of 32, 8 lanes per chunk (16 bytes each: whole
+// 1-KiB wave loads); also block sums and sums per 64 blocks ("supers", zeroed by the caller)
+__global__ __launch_bounds__(256) void vox_chunk_count_kernel(const u32 *__restrict__ bitmap, int nchunks,
+                                                              int *__restrict__ cnt, int *bsums, int *supers) {
+    __shared__ int wsum[4];
+    const int c0 = blockIdx.x * 256;
+    const int sub = threadIdx.x >> 3, q = threadIdx.x & 7;
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j * 32 + sub;
+        v[j] = c < nchunks ? reinterpret_cast<const uint4 *>(bitmap + (size_t)c * VOX_CHUNK_WORDS)[q]
+                           : make_uint4(0u, 0u, 0u, 0u);
+    }
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int p = __popc(v[j].x) + __popc(v[j].y) + __popc(v[j].z) + __popc(v[j].w);
+        total += p;
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        const int c = c0 + j * 32 + sub;
+        if (q == 0 && c < nchunks) cnt[c] = p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bsums[blockIdx.x] = t;
+        if (t) atomicAdd(supers + (blockIdx.x >> 6), t);
+    }
+}
+
+// chunk counts -> exclusive prefix over all chunks, in place (the block's base from supers + block sums)
+__global__ __launch_bounds__(256) void vox_chunk_prefix_kernel(int *cnt, int nchunks, const int *__restrict__ bsums,
+                                                               const int *__restrict__ supers) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int blk = blockIdx.x;
+    {   // base = supers before this block's group + block sums before it inside the group (<= 63 + n/16384 values)
+        int part = 0;
+        const int ns = blk >> 6, g0 = ns << 6;
+        for (int j = threadIdx.x; j < ns; j += 256) part += supers[j];
+        if ((int)threadIdx.x < blk - g0) part += bsums[g0 + threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int c = blk * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mine = c < nchunks ? cnt[c] : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (c < nchunks) cnt[c] = before + incl - mine;
 }
 
 __device__ __forceinline__ int vox_sorted_row(const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix,
@@ -192,9 +268,12 @@ __device__ __forceinline__ int vox_sorted_row(const u32 *__restrict__ bitmap, co
     const int w_in = (int)((key >> 5) & 31u);
     const uint4 *line = reinterpret_cast<const uint4 *>(bitmap + (size_t)chunk * VOX_CHUNK_WORDS);
     int r = chunk_prefix[chunk];
-    for (int q = 0; q * 4 <= w_in; ++q) {
-        const uint4 v = line[q];
-        const u32 w[4] = {v.x, v.y, v.z, v.w};
+    uint4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = line[q];                 // (one line: all eight requests in flight)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const u32 w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int wi = q * 4 + j;
@@ -226,7 +305,7 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     int cx, cy, cz;
     voxel_coord(xyz, G, cx, cy, cz);
     if (bitmap)    // key order (frames are the key's major digit: frame b still owns rows frame_base[b] ..)
-        row = vox_sorted_row(bitmap, chunk_prefix, (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx);
+        row = vox_sorted_row(bitmap, chunk_prefix, vox_key_u32(G, b, cz, cy, cx));
     reinterpret_cast<int4 *>(coords)[row] = make_int4(b, cz, cy, cx);
     float sum[16];
     for (int c = 0; c < C; ++c) sum[c] = 0.0f;
@@ -396,8 +475,9 @@ static size_t hard_workspace_bytes(int n_points, int max_points, int batch, cons
         size_t nw, nc;
         if (!sorted_words(batch, *G, &nw, &nc)) return 0;
         b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels
-        b += ws_piece(nc + 1, sizeof(int));                // chunk counts -> prefix (in place)
-        b += ws_piece(pcd_div_up((int)nc, 256) + 2, sizeof(int));
+        b += ws_piece(pcd_div_up((int)nc, 256 * 64) + 1, sizeof(int));   // sums per 64 blocks
+        b += ws_piece(nc + 1, sizeof(int));                              // chunk counts -> prefix (in place)
+        b += ws_piece(pcd_div_up((int)nc, 256) + 2, sizeof(int));        // block sums
     }
     b += ws_piece((size_t)cap * slot_words(max_points), sizeof(u32));   // {key u64, best u32[T]} records
     b += ws_piece(n_points + 1, sizeof(int32_t));          // pt_slot
@@ -442,9 +522,10 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         return PCD_ERR_WORKSPACE;
     WsCarver ws(workspace, workspace_bytes);
     u32 *bitmap = nullptr;
-    int *chunk_prefix = nullptr, *chunk_bsums = nullptr;
+    int *chunk_supers = nullptr, *chunk_bsums = nullptr, *chunk_prefix = nullptr;
     if (key_order) {
         bitmap = ws.take<u32>(nw);
+        chunk_supers = ws.take<int>(pcd_div_up((int)nc, 256 * 64) + 1);
         chunk_prefix = ws.take<int>(nc + 1);
         chunk_bsums = ws.take<int>(pcd_div_up((int)nc, 256) + 2);
     }
@@ -483,15 +564,13 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
                                         frame_base, voxel_counts);
     if (n_points > 0 && key_order) {
-        // (bitmap and chunk counts are adjacent workspace pieces: one fill)
-        pcd_fill(bitmap, 0, (size_t)((char *)(chunk_prefix + nc + 1) - (char *)bitmap), st);
+        // (bitmap and supers are adjacent workspace pieces: one fill)
+        pcd_fill(bitmap, 0, (size_t)((char *)chunk_prefix - (char *)bitmap), st);
         vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
-                                                   G, rank, frame_rank0, voxel_counts, bitmap, chunk_prefix);
-        StoredFlag cf{chunk_prefix};
+                                                   G, rank, frame_rank0, voxel_counts, bitmap);
         const int ncb = pcd_div_up((int)nc, 256);
-        scan_reduce_kernel<StoredFlag><<<ncb, 256, 0, st>>>(cf, (int)nc, chunk_bsums);
-        scan_spine_kernel<<<1, 256, 0, st>>>(chunk_bsums, ncb, nullptr);
-        scan_down_kernel<StoredFlag><<<ncb, 256, 0, st>>>(cf, (int)nc, chunk_bsums, chunk_prefix);   // in place
+        vox_chunk_count_kernel<<<ncb, 256, 0, st>>>(bitmap, (int)nc, chunk_prefix, chunk_bsums, chunk_supers);
+        vox_chunk_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, chunk_supers);
         PCD_RETURN_IF_LAUNCH_FAILED();
     }
     if (n_points > 0) {
