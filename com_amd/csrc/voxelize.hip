@@ -174,7 +174,7 @@ __device__ __forceinline__ u32 vox_key_u32(const VoxGeom &G, int b, int cz, int 
     return (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
 }
 
-__global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
+__global__ __launch_bounds__(256) void vox_sorted_mark_wide_kernel(
     const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
     VoxGeom G, const int *__restrict__ rank, const int *frame_rank0, const int32_t *voxel_counts, u32 *bitmap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -191,10 +191,85 @@ __global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
     atomicOr(bitmap + (key >> 5), 1u << (key & 31));
 }
 
+// (also the per-frame table of vox_frames_kernel: every block derives it from the ranks at the frame boundaries --
+//  batch + 1 loads and a serial loop over the frames by one thread -- and block 0 publishes it for the emit kernel)
+constexpr int VOX_FOLD_FRAMES = 256;
+__global__ __launch_bounds__(256) void vox_sorted_mark_kernel(
+    const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
+    VoxGeom G, const int *__restrict__ rank, int max_voxels, int cap, int *frame_rank0, int *frame_base,
+    int32_t *voxel_counts, u32 *bitmap) {
+    __shared__ int r_s[VOX_FOLD_FRAMES + 1];
+    __shared__ int m_s[VOX_FOLD_FRAMES];
+    for (int b = threadIdx.x; b <= batch; b += 256) r_s[b] = rank[offs[b]];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int base = 0;
+        for (int b = 0; b < batch; ++b) {
+            int m = r_s[b + 1] - r_s[b];
+            if (m > max_voxels) m = max_voxels;
+            if (base + m > cap) m = cap - base;
+            m_s[b] = m;
+            if (blockIdx.x == 0) {
+                frame_rank0[b] = r_s[b];
+                frame_base[b] = base;
+                voxel_counts[b] = m;
+            }
+            base += m;
+        }
+        if (blockIdx.x == 0) voxel_counts[batch] = base;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int rk = rank[i];
+    if (rank[i + 1] == rk) return;                 // not the first point of a voxel
+    const int b = frame_of(offs, batch, i);
+    if (rk - r_s[b] >= m_s[b]) return;
+    const float *p0 = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p0[0], p0[1], p0[2]};
+    int cx, cy, cz;
+    voxel_coord(xyz, G, cx, cy, cz);
+    const u32 key = vox_key_u32(G, b, cz, cy, cx);
+    atomicOr(bitmap + (key >> 5), 1u << (key & 31));
+}
+
+// Sum of the block sums in front of block `blk`, taken by the block itself (no spine launch; up to VOX_DIRECT_BLOCKS
+// blocks = 16 loads per thread -- beyond that the caller runs scan_spine_kernel and passes spined = 1: bsums then
+// hold the exclusive prefixes already).  (Sums per 64 blocks gathered with atomicAdd by the reduce pass were slower
+// than the spine launch they replaced: 64 memory-side atomics on one address serialise at ~150 ns each.)
+constexpr int VOX_DIRECT_BLOCKS = 4096;
+__device__ __forceinline__ int blocks_before(int blk, const int *__restrict__ bsums, int spined, int *wsum /*[4] LDS*/,
+                                             int *base_s /*LDS*/) {
+    if (spined) return bsums[blk];
+    int part = 0;
+    for (int j = threadIdx.x; j < blk; j += 256) part += bsums[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) *base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return *base_s;
+}
+
+// flags -> exclusive ranks in place, rank[n] = number of voxels
+__global__ __launch_bounds__(256) void vox_flag_down_kernel(int *rank, int n, const int *__restrict__ bsums,
+                                                            int spined) {
+    __shared__ int lds[4];
+    __shared__ int base_s;
+    const int base = blocks_before(blockIdx.x, bsums, spined, lds, &base_s);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int v = (i < n) ? rank[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, total);
+    if (i < n) rank[i] = base + ex;
+    if (i == n - 1) rank[n] = base + ex + v;
+}
+
 // chunk population counts: a block covers 256 chunks in 8 rounds of 32, 8 lanes per chunk (16 bytes each: whole
-// 1-KiB wave loads); also block sums and sums per 64 blocks ("supers", zeroed by the caller)
+// 1-KiB wave loads); also block sums
 __global__ __launch_bounds__(256) void vox_chunk_count_kernel(const u32 *__restrict__ bitmap, int nchunks,
-                                                              int *__restrict__ cnt, int *bsums, int *supers) {
+                                                              int *__restrict__ cnt, int *bsums) {
     __shared__ int wsum[4];
     const int c0 = blockIdx.x * 256;
     const int sub = threadIdx.x >> 3, q = threadIdx.x & 7;
@@ -221,30 +296,17 @@ __global__ __launch_bounds__(256) void vox_chunk_count_kernel(const u32 *__restr
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = total;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        bsums[blockIdx.x] = t;
-        if (t) atomicAdd(supers + (blockIdx.x >> 6), t);
+        bsums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
-// chunk counts -> exclusive prefix over all chunks, in place (the block's base from supers + block sums)
+// chunk counts -> exclusive prefix over all chunks, in place
 __global__ __launch_bounds__(256) void vox_chunk_prefix_kernel(int *cnt, int nchunks, const int *__restrict__ bsums,
-                                                               const int *__restrict__ supers) {
+                                                               int spined) {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int blk = blockIdx.x;
-    {   // base = supers before this block's group + block sums before it inside the group (<= 63 + n/16384 values)
-        int part = 0;
-        const int ns = blk >> 6, g0 = ns << 6;
-        for (int j = threadIdx.x; j < ns; j += 256) part += supers[j];
-        if ((int)threadIdx.x < blk - g0) part += bsums[g0 + threadIdx.x];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-    }
+    const int base0 = blocks_before(blk, bsums, spined, wsum, &base_s);
     const int c = blk * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int mine = c < nchunks ? cnt[c] : 0;
@@ -257,7 +319,7 @@ __global__ __launch_bounds__(256) void vox_chunk_prefix_kernel(int *cnt, int nch
     __syncthreads();
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    int before = base_s;
+    int before = base0;
     for (int w = 0; w < wv; ++w) before += wsum[w];
     if (c < nchunks) cnt[c] = before + incl - mine;
 }
@@ -475,7 +537,6 @@ static size_t hard_workspace_bytes(int n_points, int max_points, int batch, cons
         size_t nw, nc;
         if (!sorted_words(batch, *G, &nw, &nc)) return 0;
         b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels
-        b += ws_piece(pcd_div_up((int)nc, 256 * 64) + 1, sizeof(int));   // sums per 64 blocks
         b += ws_piece(nc + 1, sizeof(int));                              // chunk counts -> prefix (in place)
         b += ws_piece(pcd_div_up((int)nc, 256) + 2, sizeof(int));        // block sums
     }
@@ -522,10 +583,9 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         return PCD_ERR_WORKSPACE;
     WsCarver ws(workspace, workspace_bytes);
     u32 *bitmap = nullptr;
-    int *chunk_supers = nullptr, *chunk_bsums = nullptr, *chunk_prefix = nullptr;
+    int *chunk_bsums = nullptr, *chunk_prefix = nullptr;
     if (key_order) {
         bitmap = ws.take<u32>(nw);
-        chunk_supers = ws.take<int>(pcd_div_up((int)nc, 256 * 64) + 1);
         chunk_prefix = ws.take<int>(nc + 1);
         chunk_bsums = ws.take<int>(pcd_div_up((int)nc, 256) + 2);
     }
@@ -540,9 +600,14 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     int *frame_rank0 = ws.take<int>(batch + 1);
     int *frame_base = ws.take<int>(batch + 1);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
+    int nb = pcd_div_up(n_points, 256);
+    const bool fast_sorted = key_order && n_points > 0 && batch <= VOX_FOLD_FRAMES;
+    if (key_order && n_points > 0)
+        pcd_fill(bitmap, 0, nw * sizeof(u32), st);
+    // (forking this fill onto a helper stream beside the insert pass -- event fork / join inside the call -- crashed
+    //  the HIP runtime when the call was captured into a graph from a stream that had itself joined the capture)
     // one memset to 0xFF sets both sentinels (empty key, no candidate)
     pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
-    int nb = pcd_div_up(n_points, 256);
     if (n_points > 0) {
         vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                               frame_offsets, batch, G, max_points, L, keys, best,
@@ -550,28 +615,46 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         PCD_RETURN_IF_LAUNCH_FAILED();
     }
     int rc = PCD_OK;
-    if (n_points > 0) {
+    auto chunk_scan = [&]() {
+        const int ncb = pcd_div_up((int)nc, 256);
+        const int spined = ncb > VOX_DIRECT_BLOCKS;
+        vox_chunk_count_kernel<<<ncb, 256, 0, st>>>(bitmap, (int)nc, chunk_prefix, chunk_bsums);
+        if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(chunk_bsums, ncb, nullptr);
+        vox_chunk_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, spined);
+    };
+    if (fast_sorted) {
+        // 6 launches behind the insert pass (the generic form below: 10): block sums added up by the consuming blocks
+        // instead of scan spines, the per-frame table folded into the mark kernel
         FirstFlag ff{pt_slot, best, L, rank};
-        StoredFlag sf{rank};
+        const int spined = nb > VOX_DIRECT_BLOCKS;
         scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
-        scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
-        scan_down_kernel<StoredFlag><<<nb, 256, 0, st>>>(sf, n_points, bsums, rank);   // in place
+        if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+        vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
+        vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
+                                                   G, rank, max_voxels, cap, frame_rank0, frame_base, voxel_counts,
+                                                   bitmap);
+        chunk_scan();
         PCD_RETURN_IF_LAUNCH_FAILED();
     } else {
-        rc = scan_exclusive(StoredFlag{rank}, 0, rank, bsums, nullptr, st);
-        if (rc != PCD_OK) return rc;
-    }
-    vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
-                                        frame_base, voxel_counts);
-    if (n_points > 0 && key_order) {
-        // (bitmap and supers are adjacent workspace pieces: one fill)
-        pcd_fill(bitmap, 0, (size_t)((char *)chunk_prefix - (char *)bitmap), st);
-        vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
-                                                   G, rank, frame_rank0, voxel_counts, bitmap);
-        const int ncb = pcd_div_up((int)nc, 256);
-        vox_chunk_count_kernel<<<ncb, 256, 0, st>>>(bitmap, (int)nc, chunk_prefix, chunk_bsums, chunk_supers);
-        vox_chunk_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, chunk_supers);
-        PCD_RETURN_IF_LAUNCH_FAILED();
+        if (n_points > 0) {
+            FirstFlag ff{pt_slot, best, L, rank};
+            StoredFlag sf{rank};
+            scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
+            scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+            scan_down_kernel<StoredFlag><<<nb, 256, 0, st>>>(sf, n_points, bsums, rank);   // in place
+            PCD_RETURN_IF_LAUNCH_FAILED();
+        } else {
+            rc = scan_exclusive(StoredFlag{rank}, 0, rank, bsums, nullptr, st);
+            if (rc != PCD_OK) return rc;
+        }
+        vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0,
+                                            frame_base, voxel_counts);
+        if (n_points > 0 && key_order) {     // (more than VOX_FOLD_FRAMES frames)
+            vox_sorted_mark_wide_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets,
+                                                            batch, G, rank, frame_rank0, voxel_counts, bitmap);
+            chunk_scan();
+            PCD_RETURN_IF_LAUNCH_FAILED();
+        }
     }
     if (n_points > 0) {
         vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
