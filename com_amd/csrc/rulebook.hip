@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__
 // pass 2 (conv_scan_emit_kernel): every block rebuilds its own base from at most (#supers + 63) of those sums --
 //         a few hundred L2-resident ints -- instead of waiting for a one-block spine scan in a launch of its own.
 constexpr int PK_WORDS = 1024;
+constexpr int CONV_DIRECT_BLOCKS = 4096;
 
 __device__ __forceinline__ u32 pack16(uint4 v) {   // 16 bytes of 0 / 1 -> 16 bits
     const u32 q[4] = {v.x, v.y, v.z, v.w};
@@ -486,7 +487,7 @@ __device__ __forceinline__ int block_sum(int v, int *lds /* [4] */) {
 // one 16-byte piece (half a word) per lane and load, 8 loads in flight; lane pairs combine their halves
 __global__ __launch_bounds__(256) void conv_pack_sum_kernel(const uint4 *__restrict__ bytemap, size_t nwords,
                                                             u32 *__restrict__ bitmap, int *__restrict__ bsums,
-                                                            int *__restrict__ super) {
+                                                            int *__restrict__ super, int direct) {
     __shared__ int lds[4];
     const size_t h0 = (size_t)blockIdx.x * (2 * PK_WORDS) + threadIdx.x, nh = 2 * nwords;
     uint4 v[8];
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void conv_pack_sum_kernel(const uint4 *__restr
     const int total = block_sum(cnt, lds);
     if (threadIdx.x == 0) {
         bsums[blockIdx.x] = total;
-        if (total) atomicAdd(&super[blockIdx.x >> 6], total);
+        if (total && !direct) atomicAdd(&super[blockIdx.x >> 6], total);
     }
 }
 
@@ -576,7 +577,8 @@ struct ScanSide {          // what the scan launch does besides the scan (all op
 // blocks [0, nblk): prefix[w] = number of set cells in words < w, n_out = all of them; out_indices.
 __global__ __launch_bounds__(256) void conv_scan_emit_kernel(const u32 *__restrict__ bitmap, int nwords, int nblk,
                                                              const int *__restrict__ bsums,
-                                                             const int *__restrict__ super, int *__restrict__ prefix,
+                                                             const int *__restrict__ super, int direct,
+                                                             int *__restrict__ prefix,
                                                              int *__restrict__ n_out_dev, ConvGeom G, ScanSide S) {
     __shared__ int lds[4];
     __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
@@ -596,16 +598,26 @@ __global__ __launch_bounds__(256) void conv_scan_emit_kernel(const u32 *__restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = (w0 + j < nwords) ? bitmap[w0 + j] : 0u;
         }
-        // base of this block: whole supers before it + the blocks of its own super before it
+        // base of this block: whole supers before it + the blocks of its own super before it; up to
+        // CONV_DIRECT_BLOCKS blocks (direct): all block sums before it (<= 16 L2-resident loads per thread, and the
+        // pack pass needs no atomics: 64 of them on one address serialise at ~150 ns each)
         int acc = 0;
-        const int sb = blk >> 6;
-        for (int i = threadIdx.x; i < sb; i += 256) acc += super[i];
-        if ((int)threadIdx.x < (blk & 63)) acc += bsums[(sb << 6) + threadIdx.x];
+        if (direct) {
+            for (int i = threadIdx.x; i < blk; i += 256) acc += bsums[i];
+        } else {
+            const int sb = blk >> 6;
+            for (int i = threadIdx.x; i < sb; i += 256) acc += super[i];
+            if ((int)threadIdx.x < (blk & 63)) acc += bsums[(sb << 6) + threadIdx.x];
+        }
         const int base = block_sum(acc, lds);
         if (blk == 0 && n_out_dev) {
             int t = 0;
-            const int nsuper = (nblk + 63) >> 6;
-            for (int i = threadIdx.x; i < nsuper; i += 256) t += super[i];
+            if (direct) {
+                for (int i = threadIdx.x; i < nblk; i += 256) t += bsums[i];
+            } else {
+                const int nsuper = (nblk + 63) >> 6;
+                for (int i = threadIdx.x; i < nsuper; i += 256) t += super[i];
+            }
             t = block_sum(t, lds);
             if (threadIdx.x == 0) *n_out_dev = t;
         }
@@ -870,7 +882,8 @@ static void conv_launch_mark(const int32_t *indices, int n, const int32_t *n_dev
     if (n > 0)
         conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap,
                                                              C ? C->ncls : 0, C ? L.blk_cnt : nullptr);
-    conv_pack_sum_kernel<<<L.nblk, 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords, L.bitmap, L.bsums, L.super);
+    conv_pack_sum_kernel<<<L.nblk, 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords, L.bitmap, L.bsums, L.super,
+                                                 L.nblk <= CONV_DIRECT_BLOCKS);
 }
 
 static void conv_launch_scan(int n, const ConvGeom &G, const ConvWs &L, int32_t *n_out_dev, int n_out,
@@ -900,7 +913,7 @@ static void conv_launch_scan(int n, const ConvGeom &G, const ConvWs &L, int32_t 
     if (blocks < (size_t)L.nblk) blocks = L.nblk;
     if (S.blk_cnt) ++blocks;
     conv_scan_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(L.bitmap, (int)L.nwords, L.nblk, L.bsums, L.super,
-                                                            L.prefix, n_out_dev, G, S);
+                                                            L.nblk <= CONV_DIRECT_BLOCKS, L.prefix, n_out_dev, G, S);
 }
 
 static void conv_launch_fill(const int32_t *indices, int n, const int32_t *n_dev, const ConvGeom &G, const ConvWs &L,
