@@ -201,6 +201,20 @@ def test_rulebooks_waymo_chain_bit_exact():
         idx, shape = rb_o["out_indices"], tuple(es)
 
 
+def test_thirteen_frames_take_the_spine_and_super_paths():
+    """Above 4096 scan blocks the kernels stop adding up the block sums themselves: the first-point scan and the
+    chunk scan of the key-ordered voxeliser run a spine launch (> 1.05 M points, > 4.2 M chunks = 12 Waymo grids) and the
+    strided rulebook scan goes back to sums per 64 blocks (> 4.2 M bitmap words).  13 frames of 90 k points cross all
+    three thresholds; voxels in both row orders and the level-1 -> 2 rulebook are compared with the oracle."""
+    frames = [synth.synth_cloud(20 + f, 64, 1400) for f in range(13)]
+    assert sum(p.shape[0] for p in frames) > 4096 * 256
+    res = _check_hard(frames, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS)
+    c = _cpu(res["coords"])
+    geo = dict(k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1))
+    rb, _ = _check_conv(c, 13, (41, 1504, 1504), geo)
+    assert rb.out_shape == [21, 752, 752] and 13 * 21 * 752 * 752 // 32 > 4096 * 1024
+
+
 def test_strided_build_in_one_call_equals_the_two_phase_build():
     """pcd_rulebook_conv_build (static plans: capacity known on the host, 6 launches) against
     pcd_rulebook_conv_count + _fill + _classes on the four geometries of the chain, full-size frame, with the real
