@@ -352,7 +352,13 @@ class H2DSource:
         k = self.taken
         self.taken += 1
         assert self.issued == k + 2, "one release() per get()"
-        torch.cuda.current_stream().wait_event(self.ready[k % 2])
+        if os.environ.get('PCD_H2D_STREAM_WAIT'):
+            torch.cuda.current_stream().wait_event(self.ready[k % 2])
+        else:
+            # the copy was issued two steps ago: the HOST waits for it (it has long finished; this only keeps the
+            # host from running more than two steps ahead) instead of putting a cross-queue barrier in front of
+            # every step on the compute stream
+            self.ready[k % 2].synchronize()
         return self.stage[k % 2]
 
     def release(self, j):
