@@ -483,6 +483,8 @@ def main():
                "_result": bd["voxelize_result"]}
         if "voxel_num_rows" in bd:
             bd2["voxel_num_rows"] = bd["voxel_num_rows"]
+        if "voxel_rank" in bd:
+            bd2["voxel_rank"] = bd["voxel_rank"]             # coordinate -> row map: level-1 SubM without a hash table
         if not (ops.PLAN is not None and ops.PLAN.active):
             last["voxels"] = sum(bd["voxel_counts"])
         return bd2

@@ -29,9 +29,10 @@ PROTOTYPES = {
     "pcd_voxelize_hard_workspace_bytes": (_sz, [_i, _i, _i]),
     "pcd_voxelize_hard": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _i, _vp, _vp, _sz, _vp]),
-    "pcd_voxelize_hard_sorted_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
+    "pcd_voxelize_hard_sorted_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp, _i]),
+    "pcd_voxelize_hard_sorted_rank_words": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
     "pcd_voxelize_hard_sorted": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                                      _i, _vp, _vp, _sz, _vp]),
+                                      _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_mean_vfe": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -55,6 +56,8 @@ PROTOTYPES = {
     "pcd_rulebook_subm_pairs": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
                                       _vp]),
+    "pcd_rulebook_subm_ranked4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
+                                       _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,

@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256) void blk_probe_kernel(const int4 *__restrict__
 // SubM rulebook of a level whose rows ARE the bitmap ranks of the strided conv that created it (row id = rank of
 // the linear key): a neighbour lookup is one bitmap word + one prefix word, both shared by the x-neighbours and
 // by the neighbouring rows of the (key-sorted) wave -- no hash table is built or probed.
-template <int KD, int KH, int KW>
+// PW = words per prefix entry: 1 (the strided builds' maps: one prefix per bitmap word) or 4 (the key-ordered voxeliser's
+// map of the level-1 grid, pcd_voxelize_hard_sorted: one prefix per 16-byte group, the rank adds the set bits of the
+// group's words in front -- a quarter of the prefix memory for a grid of 371 M cells).
+template <int KD, int KH, int KW, int PW>
 __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
                                                         const u32 *__restrict__ bitmap,
@@ -294,35 +297,55 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
                                                         int32_t *__restrict__ nbr, int *__restrict__ wave_cnt,
                                                         int nwaves) {
     constexpr int K = KD * KH * KW;
+    constexpr int KB = PW == 1 ? K : KH * KW;      // offsets whose loads are in flight together
     const int o = blockIdx.x * 256 + threadIdx.x;
     const bool live = o < eff_rows(n_dev, n);
     const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
     const int wave = o >> 6;
-    u32 bits[K];
-    int pre[K];
-    int sh[K];  // bit position, or -1: outside the grid / dead lane
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int a = k / (KH * KW), bq = (k / KW) % KH, cq = k % KW;
-        const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh, x = c.w + (cq - KW / 2) * G.dw;
-        const bool inb = live && z >= 0 && z < G.D && y >= 0 && y < G.H && x >= 0 && x < G.W;
-        const u32 key = inb ? lin_key(c.x, z, y, x, G.D, G.H, G.W) : 0u;
-        sh[k] = inb ? (int)(key & 31) : -1;
-        bits[k] = bitmap[key >> 5];   // unconditional (word 0 for dead lanes): independent loads in flight
-        pre[k] = prefix[key >> 5];
-    }
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        u32 below[KB];     // set bits of the prefix group in front of the probed bit
+        u32 hit[KB];
+        int pre[KB];
+        bool inside[KB];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        int r = -1;
-        if (sh[k] >= 0 && ((bits[k] >> sh[k]) & 1u)) {
-            r = pre[k] + __popc(bits[k] & ((1u << sh[k]) - 1u));
-            if (r >= n) r = -1;  // beyond the row capacity: that row does not exist
+        for (int kk = 0; kk < KB; ++kk) {
+            const int k = k0 + kk;
+            const int a = k / (KH * KW), bq = (k / KW) % KH, cq = k % KW;
+            const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh, x = c.w + (cq - KW / 2) * G.dw;
+            const bool inb = live && z >= 0 && z < G.D && y >= 0 && y < G.H && x >= 0 && x < G.W;
+            const u32 key = inb ? lin_key(c.x, z, y, x, G.D, G.H, G.W) : 0u;
+            inside[kk] = inb;
+            const u32 sh = key & 31;
+            if (PW == 1) {
+                const u32 w = bitmap[key >> 5];   // unconditional (word 0 for dead lanes): independent loads in flight
+                pre[kk] = prefix[key >> 5];
+                hit[kk] = (w >> sh) & 1u;
+                below[kk] = (u32)__popc(w & ((1u << sh) - 1u));
+            } else {
+                const uint4 q = reinterpret_cast<const uint4 *>(bitmap)[key >> 7];
+                pre[kk] = prefix[key >> 7];
+                const u32 wi = (key >> 5) & 3u;
+                const u32 w = wi == 0 ? q.x : wi == 1 ? q.y : wi == 2 ? q.z : q.w;
+                hit[kk] = (w >> sh) & 1u;
+                below[kk] = (u32)__popc(w & ((1u << sh) - 1u)) + (wi > 0 ? (u32)__popc(q.x) : 0u) +
+                            (wi > 1 ? (u32)__popc(q.y) : 0u) + (wi > 2 ? (u32)__popc(q.z) : 0u);
+            }
         }
-        if (2 * k + 1 == K && live) r = o;
-        if (live) nbr[(size_t)k * n + o] = r;
-        if (wave_cnt) {
-            u64 m = __ballot(r >= 0);
-            if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int k = k0 + kk;
+            int r = -1;
+            if (inside[kk] && hit[kk]) {
+                r = pre[kk] + (int)below[kk];
+                if (r >= n) r = -1;  // beyond the row capacity: that row does not exist
+            }
+            if (2 * k + 1 == K && live) r = o;
+            if (live) nbr[(size_t)k * n + o] = r;
+            if (wave_cnt) {
+                u64 m = __ballot(r >= 0);
+                if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+            }
         }
     }
 }
@@ -1064,11 +1087,11 @@ extern "C" size_t pcd_rulebook_subm_ranked_workspace_bytes(int n, int kvol) {
     return 2 * ws_piece((size_t)kvol * nwaves, sizeof(int)) + ws_piece(kvol, sizeof(int));
 }
 
-extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
-                                        const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
-                                        const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
-                                        int pad_pairs, const int32_t *n_dev, void *workspace,
-                                        size_t workspace_bytes, void *stream) {
+static int subm_ranked_impl(const int32_t *indices, int n, int batch, const int *shape_host,
+                           const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                           const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                           int pad_pairs, const int32_t *n_dev, void *workspace,
+                           size_t workspace_bytes, void *stream, int prefix_words) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
     if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
@@ -1091,8 +1114,12 @@ extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch
     int *totals = ws.take<int>(G.K);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n, 256);
-    subm_rank_kernel<3, 3, 3><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
-                                                 pairs ? wave_cnt : nullptr, nwaves);
+    if (prefix_words == 4)
+        subm_rank_kernel<3, 3, 3, 4><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
+                                                        pairs ? wave_cnt : nullptr, nwaves);
+    else
+        subm_rank_kernel<3, 3, 3, 1><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
+                                                        pairs ? wave_cnt : nullptr, nwaves);
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
@@ -1100,6 +1127,24 @@ extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
+                                        const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                                        const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                                        int pad_pairs, const int32_t *n_dev, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    return subm_ranked_impl(indices, n, batch, shape_host, ksize_host, dil_host, bitmap, prefix, nbr, pairs, pair_num,
+                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" int pcd_rulebook_subm_ranked4(const int32_t *indices, int n, int batch, const int *shape_host,
+                                         const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                                         const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                                         int pad_pairs, const int32_t *n_dev, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    return subm_ranked_impl(indices, n, batch, shape_host, ksize_host, dil_host, bitmap, prefix, nbr, pairs, pair_num,
+                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 4);
 }
 
 extern "C" int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_shape_host, const int *ksize_host,

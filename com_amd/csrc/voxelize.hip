@@ -26,6 +26,7 @@ struct VoxGeom {
     float r0, r1, r2;
     float v0, v1, v2;
     int gx, gy, gz;
+    int kz;   // z extent of the KEY space of the key-ordered form (>= gz: the backbones' sparse_shape has gz + 1 planes)
 };
 
 __device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &G, int &cx, int &cy,
@@ -163,15 +164,16 @@ __global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *ran
 // Key-sorted row order (pcd_voxelize_hard_sorted): the KEPT voxels (first-appearance rank below the per-frame cap,
 // exactly the reference's set) are numbered by their (b, z, y, x) key instead -- the order spconv's strided convs and
 // torch.unique produce anyway -- so that the neighbours a level-1 conv gathers lie in nearby rows.  No sort: an
-// occupancy bitmap over the key space, population counts per 128-byte CHUNK (1024 keys) taken by one coalesced pass
-// over the bitmap, an exclusive scan of the chunk counts; a voxel's row = its chunk's prefix + the set bits below its
-// own inside the chunk (one line per lookup).  Marking costs one memory-side atomic per voxel -- the only one: ~13 G
+// occupancy bitmap over the key space, population counts per 16-byte GROUP (128 keys) taken by one coalesced pass
+// over the bitmap, an exclusive scan of the group counts; a voxel's row = its group's prefix + the set bits below its
+// own inside the group (16 + 4 bytes per lookup).  Bitmap + group prefixes ARE the coordinate -> row map of level 1:
+// handed to the caller (rank_bitmap / rank_prefix) they replace the hash table of the level-1 SubM rulebook
+// (pcd_rulebook_subm_ranked4).  Marking costs one memory-side atomic per voxel -- the only one: ~13 G
 // atomics/s device-wide measured, and a second atomic per voxel on a per-chunk counter (contended: neighbouring
 // voxels share chunks) took the mark kernel from 18 to 62 us.
-constexpr int VOX_CHUNK_WORDS = 32;
 
 __device__ __forceinline__ u32 vox_key_u32(const VoxGeom &G, int b, int cz, int cy, int cx) {
-    return (((u32)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+    return (((u32)b * G.kz + cz) * G.gy + cy) * G.gx + cx;
 }
 
 __global__ __launch_bounds__(256) void vox_sorted_mark_wide_kernel(
@@ -266,84 +268,73 @@ __global__ __launch_bounds__(256) void vox_flag_down_kernel(int *rank, int n, co
     if (i == n - 1) rank[n] = base + ex + v;
 }
 
-// chunk population counts: a block covers 256 chunks in 8 rounds of 32, 8 lanes per chunk (16 bytes each: whole
-// 1-KiB wave loads); also block sums
-__global__ __launch_bounds__(256) void vox_chunk_count_kernel(const u32 *__restrict__ bitmap, int nchunks,
+// Prefix GROUPS of 4 bitmap words (16 bytes, 128 keys): population count of every group.  A block covers 2048 groups
+// in 8 coalesced rounds (whole 4-KiB block loads); also block sums.
+constexpr int VOX_GROUPS_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void vox_group_count_kernel(const uint4 *__restrict__ bitmap4, int ngroups,
                                                               int *__restrict__ cnt, int *bsums) {
-    __shared__ int wsum[4];
-    const int c0 = blockIdx.x * 256;
-    const int sub = threadIdx.x >> 3, q = threadIdx.x & 7;
+    __shared__ int lds[4];
+    const int g0 = blockIdx.x * VOX_GROUPS_PER_BLOCK + threadIdx.x;
     uint4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j * 32 + sub;
-        v[j] = c < nchunks ? reinterpret_cast<const uint4 *>(bitmap + (size_t)c * VOX_CHUNK_WORDS)[q]
-                           : make_uint4(0u, 0u, 0u, 0u);
+        const int g = g0 + j * 256;
+        v[j] = g < ngroups ? bitmap4[g] : make_uint4(0u, 0u, 0u, 0u);
     }
     int total = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        int p = __popc(v[j].x) + __popc(v[j].y) + __popc(v[j].z) + __popc(v[j].w);
+        const int p = __popc(v[j].x) + __popc(v[j].y) + __popc(v[j].z) + __popc(v[j].w);
         total += p;
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        p += __shfl_xor(p, 4);
-        const int c = c0 + j * 32 + sub;
-        if (q == 0 && c < nchunks) cnt[c] = p;
+        const int g = g0 + j * 256;
+        if (g < ngroups) cnt[g] = p;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bsums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
+    int block_total;
+    block_exclusive_scan(total, lds, block_total);
+    if (threadIdx.x == 0) bsums[blockIdx.x] = block_total;
 }
 
-// chunk counts -> exclusive prefix over all chunks, in place
-__global__ __launch_bounds__(256) void vox_chunk_prefix_kernel(int *cnt, int nchunks, const int *__restrict__ bsums,
+// group counts -> exclusive prefix over all groups, in place (8 consecutive groups per thread)
+__global__ __launch_bounds__(256) void vox_group_prefix_kernel(int *cnt, int ngroups, const int *__restrict__ bsums,
                                                                int spined) {
-    __shared__ int wsum[4];
+    __shared__ int lds[4];
     __shared__ int base_s;
-    const int blk = blockIdx.x;
-    const int base0 = blocks_before(blk, bsums, spined, wsum, &base_s);
-    const int c = blk * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int mine = c < nchunks ? cnt[c] : 0;
-    int incl = mine;
+    const int base0 = blocks_before(blockIdx.x, bsums, spined, lds, &base_s);
+    const int g0 = blockIdx.x * VOX_GROUPS_PER_BLOCK + threadIdx.x * 8;
+    int v[8];
+    if (g0 + 7 < ngroups) {
+        const int4 a = *reinterpret_cast<const int4 *>(cnt + g0), b = *reinterpret_cast<const int4 *>(cnt + g0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+        for (int j = 0; j < 8; ++j) v[j] = g0 + j < ngroups ? cnt[g0 + j] : 0;
     }
-    __syncthreads();
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int before = base0;
-    for (int w = 0; w < wv; ++w) before += wsum[w];
-    if (c < nchunks) cnt[c] = before + incl - mine;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = v[j];
+        v[j] = sum;
+        sum += t;
+    }
+    int block_total;
+    const int ex = base0 + block_exclusive_scan(sum, lds, block_total);
+    if (g0 + 7 < ngroups) {
+        *reinterpret_cast<int4 *>(cnt + g0) = make_int4(ex + v[0], ex + v[1], ex + v[2], ex + v[3]);
+        *reinterpret_cast<int4 *>(cnt + g0 + 4) = make_int4(ex + v[4], ex + v[5], ex + v[6], ex + v[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (g0 + j < ngroups) cnt[g0 + j] = ex + v[j];
+    }
 }
 
-__device__ __forceinline__ int vox_sorted_row(const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix,
+__device__ __forceinline__ int vox_sorted_row(const u32 *__restrict__ bitmap, const int *__restrict__ group_prefix,
                                               u32 key) {
-    const u32 chunk = key >> 10;
-    const int w_in = (int)((key >> 5) & 31u);
-    const uint4 *line = reinterpret_cast<const uint4 *>(bitmap + (size_t)chunk * VOX_CHUNK_WORDS);
-    int r = chunk_prefix[chunk];
-    uint4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = line[q];                 // (one line: all eight requests in flight)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const u32 w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int wi = q * 4 + j;
-            if (wi < w_in) r += __popc(w[j]);
-            else if (wi == w_in) r += __popc(w[j] & ((1u << (key & 31)) - 1u));
-        }
-    }
-    return r;
+    const uint4 q = reinterpret_cast<const uint4 *>(bitmap)[key >> 7];
+    const u32 wi = (key >> 5) & 3u, sh = key & 31u;
+    const u32 w = wi == 0 ? q.x : wi == 1 ? q.y : wi == 2 ? q.z : q.w;
+    return group_prefix[key >> 7] + __popc(w & ((1u << sh) - 1u)) + (wi > 0 ? __popc(q.x) : 0) +
+           (wi > 1 ? __popc(q.y) : 0) + (wi > 2 ? __popc(q.z) : 0);
 }
 
 __global__ __launch_bounds__(256) void vox_emit_kernel(
@@ -503,6 +494,7 @@ static VoxGeom make_geom(const float *range, const float *vs) {
         g[j] = (int)llround(d);  // data_processor.py:127-128
     }
     G.gx = g[0]; G.gy = g[1]; G.gz = g[2];
+    G.kz = G.gz;
     return G;
 }
 
@@ -522,10 +514,10 @@ static u32 table_capacity(int n) {
 
 // =============================================================================================
 static bool sorted_words(int batch, const VoxGeom &G, size_t *nwords, size_t *nchunks) {
-    const double vol = (double)batch * G.gx * G.gy * G.gz;
+    const double vol = (double)batch * G.gx * G.gy * G.kz;
     if (vol >= 4294967295.0 - 1024.0) return false;
-    *nchunks = ((size_t)vol + 1023) / 1024;
-    *nwords = *nchunks * VOX_CHUNK_WORDS;
+    *nchunks = ((size_t)vol + 127) / 128;            // prefix groups of 4 words
+    *nwords = *nchunks * 4;
     return true;
 }
 
@@ -536,9 +528,9 @@ static size_t hard_workspace_bytes(int n_points, int max_points, int batch, cons
     if (G) {
         size_t nw, nc;
         if (!sorted_words(batch, *G, &nw, &nc)) return 0;
-        b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels
-        b += ws_piece(nc + 1, sizeof(int));                              // chunk counts -> prefix (in place)
-        b += ws_piece(pcd_div_up((int)nc, 256) + 2, sizeof(int));        // block sums
+        b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels (unless the caller's)
+        b += ws_piece(nc + 8, sizeof(int));                // group counts -> prefix, in place (unless the caller's)
+        b += ws_piece(pcd_div_up((int)nc, VOX_GROUPS_PER_BLOCK) + 2, sizeof(int));        // block sums
     }
     b += ws_piece((size_t)cap * slot_words(max_points), sizeof(u32));   // {key u64, best u32[T]} records
     b += ws_piece(n_points + 1, sizeof(int32_t));          // pt_slot
@@ -553,9 +545,12 @@ extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points
 }
 
 extern "C" size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
-                                                           const float *range_host, const float *vsize_host) {
+                                                           const float *range_host, const float *vsize_host,
+                                                           int key_depth) {
     if (!range_host || !vsize_host) return 0;
     VoxGeom G = make_geom(range_host, vsize_host);
+    if (key_depth > 0 && key_depth < G.gz) return 0;
+    if (key_depth > 0) G.kz = key_depth;
     return hard_workspace_bytes(n_points, max_points, batch, &G);
 }
 
@@ -565,7 +560,8 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
                               int max_points, int max_voxels, int cap, float *voxels,
                               int32_t *coords, int32_t *num_points, float *mean_f32,
                               void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
-                              void *workspace, size_t workspace_bytes, void *stream, bool key_order) {
+                              void *workspace, size_t workspace_bytes, void *stream, bool key_order,
+                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth) {
     PCD_ENTER();
     if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
         !frame_offsets || !range_host || !vsize_host || !coords || !num_points || !voxel_counts)
@@ -576,6 +572,10 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     if (mean_bf16 && mean_bf16_stride < num_features) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     VoxGeom G = make_geom(range_host, vsize_host);
+    if (key_depth > 0) {
+        if (key_depth < G.gz) return PCD_ERR_INVALID_ARG;
+        G.kz = key_depth;
+    }
     if ((double)batch * G.gx * G.gy * G.gz >= 1.8e19) return PCD_ERR_KEYSPACE;
     size_t nw = 0, nc = 0;
     if (key_order && !sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
@@ -586,8 +586,12 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     int *chunk_bsums = nullptr, *chunk_prefix = nullptr;
     if (key_order) {
         bitmap = ws.take<u32>(nw);
-        chunk_prefix = ws.take<int>(nc + 1);
-        chunk_bsums = ws.take<int>(pcd_div_up((int)nc, 256) + 2);
+        chunk_prefix = ws.take<int>(nc + 8);
+        chunk_bsums = ws.take<int>(pcd_div_up((int)nc, VOX_GROUPS_PER_BLOCK) + 2);
+        if (rank_bitmap && rank_prefix) {               // the caller keeps the coordinate -> row map
+            bitmap = rank_bitmap;
+            chunk_prefix = rank_prefix;
+        }
     }
     u32 tcap = table_capacity(n_points);
     const int L = slot_words(max_points);
@@ -616,11 +620,11 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     }
     int rc = PCD_OK;
     auto chunk_scan = [&]() {
-        const int ncb = pcd_div_up((int)nc, 256);
+        const int ncb = pcd_div_up((int)nc, VOX_GROUPS_PER_BLOCK);
         const int spined = ncb > VOX_DIRECT_BLOCKS;
-        vox_chunk_count_kernel<<<ncb, 256, 0, st>>>(bitmap, (int)nc, chunk_prefix, chunk_bsums);
+        vox_group_count_kernel<<<ncb, 256, 0, st>>>((const uint4 *)bitmap, (int)nc, chunk_prefix, chunk_bsums);
         if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(chunk_bsums, ncb, nullptr);
-        vox_chunk_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, spined);
+        vox_group_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, spined);
     };
     if (fast_sorted) {
         // 6 launches behind the insert pass (the generic form below: 10): block sums added up by the consuming blocks
@@ -677,7 +681,20 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
     return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
-                              false);
+                              false, nullptr, nullptr, 0);
+}
+
+extern "C" int pcd_voxelize_hard_sorted_rank_words(int batch, const float *range_host, const float *vsize_host,
+                                                   int key_depth, size_t *bitmap_words, size_t *prefix_words) {
+    if (batch <= 0 || !range_host || !vsize_host || !bitmap_words || !prefix_words) return PCD_ERR_INVALID_ARG;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    if (key_depth > 0 && key_depth < G.gz) return PCD_ERR_INVALID_ARG;
+    if (key_depth > 0) G.kz = key_depth;
+    size_t nw, nc;
+    if (!sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
+    *bitmap_words = nw;
+    *prefix_words = nc + 8;
+    return PCD_OK;
 }
 
 extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride,
@@ -686,11 +703,13 @@ extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int p
                                         int max_points, int max_voxels, int cap, float *voxels,
                                         int32_t *coords, int32_t *num_points, float *mean_f32,
                                         void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                                        int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
                                         void *workspace, size_t workspace_bytes, void *stream) {
+    if ((rank_bitmap != nullptr) != (rank_prefix != nullptr) || key_depth < 0) return PCD_ERR_INVALID_ARG;
     return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
-                              true);
+                              true, rank_bitmap, rank_prefix, key_depth);
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

@@ -105,8 +105,13 @@ class _BackboneBase(nn.Module):
         feats = voxel_features
         if self.feature_dtype is not None and feats.dtype != self.feature_dtype:
             feats = feats.to(self.feature_dtype)
-        return SparseConvTensor(features=feats, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
-                                batch_size=batch_size, num_rows=batch_dict.get('voxel_num_rows', None))
+        x = SparseConvTensor(features=feats, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
+                             batch_size=batch_size, num_rows=batch_dict.get('voxel_num_rows', None))
+        rank = batch_dict.get('voxel_rank', None)
+        if rank is not None and rank.indices is x.indices and list(rank.shape) == list(x.spatial_shape):
+            # key-ordered voxel rows: the voxeliser's bitmap ranks ARE the row ids -> level-1 SubM without a hash table
+            x.indice_dict[("__rank__", x.indices.data_ptr())] = rank
+        return x
 
     def _bump_bn_counters(self):
         """num_batches_tracked += 1 for every BatchNorm1d in ONE multi-tensor launch instead of 21."""

@@ -3,6 +3,7 @@
 Every function here calls the HIP library; nothing is computed in Python/torch except buffer
 allocation, the one host read-back of a data-dependent row count, and trivial views.
 """
+import ctypes
 import math
 
 import torch
@@ -201,14 +202,16 @@ def grid_size(point_cloud_range, voxel_size):
 # ---------------------------------------------------------------------------------------------
 def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
                   feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None,
-                  row_order="first"):
+                  row_order="first", key_depth=0):
     """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
     rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
     voxel_features, voxel_features_bf16, counts (host list per frame)).
     `out` (static-shape mode): the dict a previous call returned -- its tensors are written again instead of
     allocating new ones (a prefetched voxelisation then lands in the buffers the consumer already holds).
     `row_order`: "first" = the reference's first-appearance voxel ids; "key" = the same voxels numbered by ascending
-    (b, z, y, x) (pcd_voxelize_hard_sorted: spatially coherent rows for the sparse convs)."""
+    (b, z, y, x) (pcd_voxelize_hard_sorted: spatially coherent rows for the sparse convs); the result then carries
+    `rank`, the coordinate -> row map (RankMap) the level-1 SubM rulebook is built from -- laid out for a grid of
+    `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1)."""
     assert row_order in ("first", "key")
     _require_cuda(points)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
@@ -227,7 +230,7 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     lib = L.lib()
     if row_order == "key":
         ws_bytes = lib.pcd_voxelize_hard_sorted_workspace_bytes(n, max_points, batch, L.host_f32(point_cloud_range),
-                                                                L.host_f32(voxel_size))
+                                                                L.host_f32(voxel_size), int(key_depth))
         if ws_bytes == 0:
             raise RuntimeError("pcd_voxelize_hard_sorted: key space of the grid exceeds 32 bits")
         entry = lib.pcd_voxelize_hard_sorted
@@ -249,29 +252,44 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     mean = buf("voxel_features", (cap, C), torch.float32, want_mean)
     mean16 = buf("voxel_features_bf16", (cap, mean_bf16_stride), torch.bfloat16, bool(mean_bf16_stride))
     counts = buf("counts", (batch + 1,), torch.int32)
+    rank_bm = rank_px = None
+    if row_order == "key":        # the coordinate -> row map of the output: kept for the level-1 SubM rulebook
+        nbw, npw = ctypes.c_size_t(), ctypes.c_size_t()
+        L.check(lib.pcd_voxelize_hard_sorted_rank_words(batch, L.host_f32(point_cloud_range), L.host_f32(voxel_size),
+                                                        int(key_depth), ctypes.byref(nbw), ctypes.byref(npw)),
+                "pcd_voxelize_hard_sorted_rank_words")
+        rank_bm = buf("rank_bitmap", (nbw.value,), torch.int32)
+        rank_px = buf("rank_prefix", (npw.value,), torch.int32)
     def meta():                                  # 24 N read + 36 M written (fused form; +104 M for voxels)
         m_ = int(counts[batch].item())
         return dict(bytes=24 * n + 36 * m_ + (104 * m_ if want_voxels else 0), flops=0, rows=m_, pairs=0)
 
     with _Timed("voxelize_hard", meta):
+        extra = (int(key_depth), L.ptr(rank_bm), L.ptr(rank_px)) if row_order == "key" else ()
         L.check(entry(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
                       L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
                       max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
-                      L.ptr(mean16), mean_bf16_stride, L.ptr(counts), L.ptr(ws), ws.numel(),
+                      L.ptr(mean16), mean_bf16_stride, L.ptr(counts), *extra, L.ptr(ws), ws.numel(),
                       L.stream_ptr()), "pcd_voxelize_hard")
+    gz, gy, gx = grid_size(point_cloud_range, voxel_size)[::-1]
+    gz = max(gz, int(key_depth))
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]
         PLAN.record("voxels", num_rows, cap)
         return dict(voxels=voxels, coords=coords, num_points=nump, voxel_features=mean,
-                    voxel_features_bf16=mean16, counts=counts, num_rows=num_rows)
+                    voxel_features_bf16=mean16, counts=counts, num_rows=num_rows, rank_bitmap=rank_bm,
+                    rank_prefix=rank_px,
+                    rank=RankMap(None, rank_bm, rank_px, coords, [gz, gy, gx], 4) if rank_bm is not None else None)
     host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
     m = host_counts[-1]
     if PLAN is not None:
         PLAN.observe("voxels", m)
-    return dict(num_rows=None,voxels=voxels[:m] if want_voxels else None, coords=coords[:m], num_points=nump[:m],
+    coords_m = coords[:m]
+    return dict(num_rows=None,voxels=voxels[:m] if want_voxels else None, coords=coords_m, num_points=nump[:m],
                 voxel_features=mean[:m] if want_mean else None,
-                voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1])
+                voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1],
+                rank=RankMap(None, rank_bm, rank_px, coords_m, [gz, gy, gx], 4) if rank_bm is not None else None)
 
 
 def mean_vfe(voxels, num_points):
@@ -451,8 +469,9 @@ class RankMap:
     + exclusive popcount prefix (row id = rank of the linear key).  Views into the build's workspace, which this
     object keeps alive.  `indices` is the out_indices tensor the ranks refer to."""
 
-    def __init__(self, ws, bitmap, prefix, indices, shape):
+    def __init__(self, ws, bitmap, prefix, indices, shape, prefix_words=1):
         self.ws, self.bitmap, self.prefix, self.indices, self.shape = ws, bitmap, prefix, indices, list(shape)
+        self.prefix_words = prefix_words      # 1: one prefix per bitmap word; 4: pcd_voxelize_hard_sorted's map
 
     def matches(self, indices, shape, ks):
         return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
@@ -479,10 +498,11 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     if rank is not None and rank.matches(indices, shp, ks):
         ws = _ws(lib.pcd_rulebook_subm_ranked_workspace_bytes(n, K), dev)
         with _Timed("rulebook_subm_ranked", meta):
-            L.check(lib.pcd_rulebook_subm_ranked(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
-                                                 L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
-                                                 L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
-                                                 L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
+            entry = lib.pcd_rulebook_subm_ranked4 if rank.prefix_words == 4 else lib.pcd_rulebook_subm_ranked
+            L.check(entry(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
+                          L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
+                          L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
+                          L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
     else:
         ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
         with _Timed("rulebook_subm", meta):

@@ -86,15 +86,26 @@ int pcd_voxelize_hard(const float *points, int n_points, int point_stride, int f
  * Every consumer of the hot path (mean_vfe.py:25-29 -> spconv_backbone.py:239-246) is invariant to the row order;
  * with training's shuffled points (data_processor.py:103-113) the first-appearance order is random in space, the key
  * order keeps the 27 neighbours of a level-1 row in nearby rows.  Needs batch*gz*gy*gx < 2^32 - 1024 (PCD_ERR_KEYSPACE
- * otherwise); the workspace holds an occupancy bitmap of that many bits. */
+ * otherwise); the workspace holds an occupancy bitmap of that many bits.
+ *   rank_bitmap / rank_prefix (both or neither): caller-owned buffers of pcd_voxelize_hard_sorted_rank_words() words
+ *   that receive the coordinate -> row map of the output -- bit (key) of rank_bitmap set for every kept voxel,
+ *   rank_prefix[g] = number of set bits in front of the 128-bit group g -- the map pcd_rulebook_subm_ranked4 builds the
+ *   level-1 SubM rulebook from (no hash table).  NULL: the map lives in the workspace and dies with the call.
+ *   key_depth: z extent of the key space, key = ((b * key_depth + z) * gy + y) * gx + x; 0 = gz.  The 3D backbones use
+ *   sparse_shape = grid_size[::-1] + [1, 0, 0] (spconv_backbone.py:87,187): pass gz + 1 so that the map has the layout
+ *   the rulebook of that shape addresses.  The row ORDER does not depend on it. */
 size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
-                                                const float *range_host /*[6]*/, const float *vsize_host /*[3]*/);
+                                                const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
+                                                int key_depth);
+int pcd_voxelize_hard_sorted_rank_words(int batch, const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
+                                        int key_depth, size_t *bitmap_words, size_t *prefix_words);
 int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride, int feat_offset,
                              int num_features, const int32_t *frame_offsets, int batch,
                              const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
                              int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
                              int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
-                             int32_t *voxel_counts, void *workspace, size_t workspace_bytes, void *stream);
+                             int32_t *voxel_counts, int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
 int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
@@ -207,6 +218,13 @@ int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_shape_host, co
                                   const int *stride_host, const int *pad_host, const int *dil_host,
                                   size_t *bitmap_offset, size_t *prefix_offset, size_t *nwords);
 size_t pcd_rulebook_subm_ranked_workspace_bytes(int n, int kvol);
+/* pcd_rulebook_subm_ranked4: the same for the map pcd_voxelize_hard_sorted hands out (one prefix per group of 4 bitmap
+ * words): the SubM rulebook of level 1 (spconv_backbone.py:199-203, 'subm1' / 'res1') without a hash table. */
+int pcd_rulebook_subm_ranked4(const int32_t *indices, int n, int batch, const int *shape_host,
+                              const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
+                              const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                              int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                              void *stream);
 int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
                              const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                              const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,

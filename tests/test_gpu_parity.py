@@ -201,6 +201,45 @@ def test_rulebooks_waymo_chain_bit_exact():
         idx, shape = rb_o["out_indices"], tuple(es)
 
 
+def test_level1_subm_rulebook_from_the_voxelisers_rank_map():
+    """pcd_voxelize_hard_sorted hands out the coordinate -> row map of its (key-ordered) rows; the level-1 SubM
+    rulebook built from it (pcd_rulebook_subm_ranked4, no hash table) must equal the oracle's and the hash build's --
+    neighbour table, pair lists and counts, bit for bit -- on two full frames, in the sparse_shape of the backbones
+    (gz + 1 planes), also with the real row count in device memory and padded capacity."""
+    from com_amd.hotpath import collate_points
+    ops = _ops()
+    frames = [synth.synth_cloud(f) for f in (5, 6)]
+    pts, offs = collate_points(frames, DEV)
+    shape = [41, 1504, 1504]
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
+                            want_voxels=False, row_order="key", key_depth=41)
+    rank, idx = res["rank"], res["coords"]
+    assert rank is not None and rank.prefix_words == 4 and rank.matches(idx, shape, [3, 3, 3])
+    rb_o = O.rulebook_subm(_cpu(idx), tuple(shape))
+    rb_r = ops.rulebook_subm(idx, 2, shape, pad_pairs=True, rank=rank)
+    rb_h = ops.rulebook_subm(idx, 2, shape, pad_pairs=True)
+    for rb in (rb_r, rb_h):
+        np.testing.assert_array_equal(_cpu(rb.nbr_out), rb_o["nbr_out"])
+        np.testing.assert_array_equal(_cpu(rb.pair_num), rb_o["pair_num"])
+        np.testing.assert_array_equal(_cpu(rb.pairs), rb_o["pairs"])
+    # a key space of gz planes (key_depth 0) addresses another layout: the map must refuse the 41-plane shape
+    res40 = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
+                              num_features=5, want_voxels=False, row_order="key")
+    assert not res40["rank"].matches(res40["coords"], shape, [3, 3, 3])
+    np.testing.assert_array_equal(_cpu(res40["coords"]), _cpu(idx))
+    rb40 = ops.rulebook_subm(res40["coords"], 2, [40, 1504, 1504], pad_pairs=True, rank=res40["rank"])
+    np.testing.assert_array_equal(_cpu(rb40.nbr_out), O.rulebook_subm(_cpu(idx), (40, 1504, 1504))["nbr_out"])
+    # static shapes: capacity above the row count, the count in device memory
+    n = idx.shape[0]
+    cap = (n * 5 // 4 + 255) // 256 * 256
+    big = torch.full((cap, 4), 7, dtype=torch.int32, device=DEV)
+    big[:n] = idx
+    rank_big = ops.RankMap(None, rank.bitmap, rank.prefix, big, shape, 4)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=DEV)
+    rb_s = ops.rulebook_subm(big, 2, shape, want_pairs=False, n_dev=n_dev, rank=rank_big)
+    np.testing.assert_array_equal(_cpu(rb_s.nbr_out)[:, :n], rb_o["nbr_out"])
+
+
 def test_thirteen_frames_take_the_spine_and_super_paths():
     """Above 4096 scan blocks the kernels stop adding up the block sums themselves: the first-point scan and the
     chunk scan of the key-ordered voxeliser run a spine launch (> 1.05 M points, > 4.2 M chunks = 12 Waymo grids) and the
