@@ -59,11 +59,11 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     pts, offs = hotpath.collate_points(frames, dev)
     res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
                             num_features=5, want_voxels=False,
-                            row_order=os.environ.get('PCD_ROW_ORDER', 'key'))   # (what bench.py runs)
+                            row_order=os.environ.get('PCD_ROW_ORDER', 'key'), key_depth=41)   # (what bench.py runs)
     idx, shape = res['coords'], [41, 1504, 1504]
     rows = []
     tot_bytes = tot_t = tot_g = 0.0
-    rank = None
+    rank = res.get('rank', None)       # key-ordered rows: the voxeliser's coordinate -> row map serves level 1
     geos = [None, (3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)]
     for lvl, geo in enumerate(geos):
         if geo is not None:
