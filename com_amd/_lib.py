@@ -100,6 +100,11 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_centerhead_loss_workspace_bytes": (_sz, [_i]),
+    "pcd_centerhead_loss_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
+                                         _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _sz, _vp]),
+    "pcd_centerhead_loss_backward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp,
+                                          _vp, _vp, _i, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "pcd_centerhead_assign_workspace_bytes": (_sz, [_i, _i]),
     "pcd_centerhead_assign_targets": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, ctypes.c_float, _i, _vp,
                                            _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -85,3 +85,83 @@ class CenterHeadLoss(torch.nn.Module):
         tb['rpn_loss'] = loss.detach()
         tb['confidence'] = confidence / len(pred_dicts)
         return loss, tb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _FusedHeadLoss(torch.autograd.Function):
+    """One head of `get_loss` through pcd_centerhead_loss_forward / _backward (centerhead.hip): 2 + 2 launches."""
+
+    @staticmethod
+    def forward(ctx, hm, heatmap, inds, masks, target_boxes, code_weights, cls_weight, loc_weight, *regs):
+        import ctypes
+        from .. import _lib as L
+        assert hm.is_cuda and hm.dim() == 4 and heatmap.dtype == torch.float32 and heatmap.is_contiguous()
+        assert inds.dtype == torch.int64 and masks.dtype == torch.int64 and inds.is_contiguous() and masks.is_contiguous()
+        assert target_boxes.dtype == torch.float32 and target_boxes.is_contiguous()
+        B, C, H, W = hm.shape
+        dims = sum(int(r.shape[1]) for r in regs)
+        assert dims == target_boxes.shape[2] and all(r.dtype == regs[0].dtype for r in regs)
+        lib = L.lib()
+        code_weights = code_weights[:dims].to(device=hm.device, dtype=torch.float32).contiguous()
+        out = torch.empty((6 + dims,), dtype=torch.float32, device=hm.device)
+        ws = torch.empty((int(lib.pcd_centerhead_loss_workspace_bytes(dims)),), dtype=torch.uint8, device=hm.device)
+
+        def dt(t):
+            assert t.dtype in (torch.float32, torch.bfloat16), t.dtype
+            return L.PCD_F32 if t.dtype == torch.float32 else L.PCD_BF16
+        geo = dict(hm_strides=(ctypes.c_longlong * 4)(*hm.stride()),
+                   reg_ptrs=(ctypes.c_void_p * len(regs))(*[r.data_ptr() for r in regs]),
+                   reg_ch=(ctypes.c_int * len(regs))(*[int(r.shape[1]) for r in regs]),
+                   reg_strides=(ctypes.c_longlong * (4 * len(regs)))(*[v for r in regs for v in r.stride()]))
+        L.check(lib.pcd_centerhead_loss_forward(
+            L.ptr(hm), dt(hm), geo["hm_strides"], L.ptr(heatmap), B, C, H, W, geo["reg_ptrs"], geo["reg_ch"],
+            dt(regs[0]) if regs else L.PCD_F32, geo["reg_strides"], len(regs), L.ptr(inds), L.ptr(masks),
+            L.ptr(target_boxes), int(inds.shape[1]), L.ptr(code_weights), float(cls_weight), float(loc_weight),
+            L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_centerhead_loss_forward")
+        ctx.save_for_backward(hm, heatmap, inds, masks, target_boxes, code_weights, out, *regs)
+        ctx.weights = (float(cls_weight), float(loc_weight))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        import ctypes
+        from .. import _lib as L
+        hm, heatmap, inds, masks, target_boxes, code_weights, out, *regs = ctx.saved_tensors
+        B, C, H, W = hm.shape
+        lib = L.lib()
+        d_hm = torch.empty_like(hm)                      # (same strides: the kernels address gradients like the inputs)
+        d_regs = [torch.empty_like(r) for r in regs]
+        assert d_hm.stride() == hm.stride() and all(d.stride() == r.stride() for d, r in zip(d_regs, regs))
+        g = g_loss.detach().to(torch.float32).reshape(1).contiguous()
+
+        def dt(t):
+            return L.PCD_F32 if t.dtype == torch.float32 else L.PCD_BF16
+        L.check(lib.pcd_centerhead_loss_backward(
+            L.ptr(hm), L.ptr(d_hm), dt(hm), (ctypes.c_longlong * 4)(*hm.stride()), L.ptr(heatmap), B, C, H, W,
+            (ctypes.c_void_p * len(regs))(*[r.data_ptr() for r in regs]),
+            (ctypes.c_void_p * len(regs))(*[d.data_ptr() for d in d_regs]),
+            (ctypes.c_int * len(regs))(*[int(r.shape[1]) for r in regs]), dt(regs[0]) if regs else L.PCD_F32,
+            (ctypes.c_longlong * (4 * len(regs)))(*[v for r in regs for v in r.stride()]), len(regs), L.ptr(inds),
+            L.ptr(masks), L.ptr(target_boxes), int(inds.shape[1]), L.ptr(code_weights), ctx.weights[0], ctx.weights[1],
+            L.ptr(out), L.ptr(g), L.stream_ptr()), "pcd_centerhead_loss_backward")
+        return (d_hm, None, None, None, None, None, None, None, *d_regs)
+
+
+class FusedCenterHeadLoss(CenterHeadLoss):
+    """CenterHeadLoss with every head's loss and gradients in four HIP launches (no elementwise chain)."""
+
+    def forward(self, pred_dicts, target_dicts):
+        tb, loss, confidence = {}, 0, 0
+        for idx, pred in enumerate(pred_dicts):
+            regs = [pred[name] for name in self.head_order]
+            head_loss, out = _FusedHeadLoss.apply(pred['hm'], target_dicts['heatmaps'][idx], target_dicts['inds'][idx],
+                                                  target_dicts['masks'][idx], target_dicts['target_boxes'][idx],
+                                                  self.code_weights, self.cls_weight, self.loc_weight, *regs)
+            loss = loss + head_loss if idx else head_loss
+            tb['hm_loss_head_%d' % idx] = out[1]
+            tb['loc_loss_head_%d' % idx] = out[2]
+            confidence = confidence + out[3] if idx else out[3]
+        tb['rpn_loss'] = loss.detach()
+        tb['confidence'] = confidence / len(pred_dicts)
+        return loss, tb

@@ -476,6 +476,32 @@ int pcd_centerhead_assign_targets(const float *gt_boxes, int batch, int n_boxes,
                                   float gaussian_overlap, int min_radius, float *heatmap, float *ret_boxes,
                                   long long *inds, long long *mask, void *workspace, size_t workspace_bytes, void *stream);
 
+/* (f2) CenterHead.get_loss of one head (center_head.py:226-262): cls_weight * neg_loss_cornernet(clamp(sigmoid(hm)),
+ *      heatmap) (loss_utils.py:611-643) + loc_weight * sum_d code_weights[d] * RegLossCenterNet_d (loss_utils.py:
+ *      1317-1390) -- and its gradients -- in 2 + 2 launches instead of ~100 elementwise launches, without the
+ *      reference's host round trips (`if num_pos == 0`, `.item()`).  Predictions are addressed through element
+ *      strides {batch, channel, y, x} (NCHW or channels-last), dtype PCD_F32 / PCD_BF16; arithmetic in fp32.
+ *   forward : out[0] = loss, [1] = hm_loss, [2] = loc_loss, [3] = mean confidence at the positives (nan without any,
+ *             as the reference), [4] = num_pos, [5] = number of objects, [6 .. 6 + D) = L1 per code dimension
+ *   backward: d_hm / reg_grads (same layout and dtype as the predictions; every element is written) for an upstream
+ *             gradient *grad_out (device scalar).  `out` is the forward's.
+ *   regression branches in HEAD_ORDER (their channels concatenated give the D code dimensions of target_boxes). */
+size_t pcd_centerhead_loss_workspace_bytes(int code_dims);
+int pcd_centerhead_loss_forward(const void *hm, int hm_dtype, const long long *hm_strides_host /*[4]*/,
+                                const float *gt_heatmap, int batch, int num_classes, int height, int width,
+                                const void *const *reg_ptrs_host, const int *reg_channels_host, int reg_dtype,
+                                const long long *reg_strides_host /*[n_reg][4]*/, int n_reg, const long long *inds,
+                                const long long *masks, const float *target_boxes, int num_max_objs,
+                                const float *code_weights /*device [D]*/, float cls_weight, float loc_weight,
+                                float *out /*device [6 + D]*/, void *workspace, size_t workspace_bytes, void *stream);
+int pcd_centerhead_loss_backward(const void *hm, void *d_hm, int hm_dtype, const long long *hm_strides_host,
+                                 const float *gt_heatmap, int batch, int num_classes, int height, int width,
+                                 const void *const *reg_ptrs_host, void *const *reg_grads_host,
+                                 const int *reg_channels_host, int reg_dtype, const long long *reg_strides_host,
+                                 int n_reg, const long long *inds, const long long *masks, const float *target_boxes,
+                                 int num_max_objs, const float *code_weights, float cls_weight, float loc_weight,
+                                 const float *out, const float *grad_out, void *stream);
+
 /* ============================================================================================
  * (f4) PV-RCNN stage-2 natives -- the stacked-batch PointNet++ ops of pcdet/ops/pointnet2/pointnet2_stack (binder
  *      src/pointnet2_api.cpp; Python callers pointnet2_utils.py:8-303, voxel_query_utils.py:9-47).  "Stacked": the

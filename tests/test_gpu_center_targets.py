@@ -71,3 +71,71 @@ def test_center_head_loss_on_device_targets_equals_cpu_evaluation(golden):
     assert all(v.is_cuda for v in tb.values())                      # logged scalars stay on the device
     for k in g_gpu:
         assert float((g_gpu[k] - g_cpu[k]).abs().max()) <= 1e-5 * float(g_cpu[k].abs().max()) + 1e-9, k
+
+
+@pytest.mark.gpu
+def test_fused_center_head_loss_kernels_equal_the_module(golden):
+    """pcd_centerhead_loss_forward / _backward (2 + 2 launches) against CenterHeadLoss (the torch restatement pinned to
+    the reference by fixture G10) evaluated on the CPU in fp32: loss, logged scalars and every prediction gradient --
+    fp32 NCHW predictions, bf16 channels-last predictions (what the towers emit under autocast), objects sharing a
+    pixel, saturated logits (the clamp's zero-gradient region) and a batch without any positive."""
+    from com_amd.hotpath import center_loss as CL
+    from com_amd.hotpath import targets as T
+    g = golden("g9_center_targets")
+    names = ["Vehicle", "Pedestrian", "Cyclist"]
+    gt = torch.from_numpy(g["gt_boxes"]).to("cuda")
+    H, W = (int(v) for v in g["feature_map_size"])
+    tg = T.assign_targets(gt, (H, W), names, [names], synth.WAYMO_RANGE, synth.WAYMO_VOXEL, int(g["stride"][0]),
+                          num_max_objs=int(g["num_max_objs"][0]))
+    # objects sharing a pixel: copy the first object's index into the second and third of frame 0
+    tg["inds"][0][0, 1] = tg["inds"][0][0, 0]
+    tg["inds"][0][0, 2] = tg["inds"][0][0, 0]
+    assert int(tg["masks"][0][0, :3].sum()) == 3
+    order = [("center", 2), ("center_z", 1), ("dim", 3), ("rot", 2)]
+    B = gt.shape[0]
+    torch.manual_seed(5)
+    pred = {"hm": torch.randn(B, 3, H, W) * 3.0}
+    pred["hm"][0, 0, :4, :4] = 30.0                                # sigmoid beyond 1 - 1e-4: clamped, zero gradient
+    pred["hm"][0, 1, :4, :4] = -30.0
+    pred.update({n: torch.randn(B, c, H, W) for n, c in order})
+    cw = (1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 2.0, 2.0)
+    ref_mod = CL.CenterHeadLoss([n for n, _ in order], cls_weight=1.0, loc_weight=2.0, code_weights=cw)
+    fused = CL.FusedCenterHeadLoss([n for n, _ in order], cls_weight=1.0, loc_weight=2.0, code_weights=cw).to("cuda")
+
+    def ref(p32, t):
+        p = {k: v.clone().requires_grad_(True) for k, v in p32.items()}
+        loss, tb = ref_mod([p], {k: [x.cpu() for x in v] for k, v in t.items()})
+        (loss * 1.7).backward()
+        return loss.detach(), {k: v.grad for k, v in p.items()}, tb
+
+    def run(dtype, channels_last, t):
+        p = {}
+        for k, v in pred.items():
+            x = v.to("cuda", dtype)
+            if channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            p[k] = x.requires_grad_(True)
+        loss, tb = fused([p], t)
+        (loss * 1.7).backward()
+        torch.cuda.synchronize()
+        return loss.detach().cpu(), {k: v.grad.float().cpu() for k, v in p.items()}, {k: v.cpu() for k, v in tb.items()}, p
+
+    for t_case in ("objects", "empty"):
+        t = tg if t_case == "objects" else {k: [torch.zeros_like(x) for x in v] for k, v in tg.items()}
+        for dtype, cl in ((torch.float32, False), (torch.bfloat16, True)):
+            p32 = {k: v.to(dtype).float() for k, v in pred.items()}          # the values the kernel sees
+            l_ref, g_ref, tb_ref = ref(p32, t)
+            l, gr, tb, p = run(dtype, cl, t)
+            assert abs(float(l) - float(l_ref)) <= 2e-5 * abs(float(l_ref)), (t_case, dtype, float(l), float(l_ref))
+            for k in ("hm_loss_head_0", "loc_loss_head_0"):
+                assert abs(float(tb[k]) - float(tb_ref[k])) <= 2e-5 * abs(float(tb_ref[k])) + 1e-7, (t_case, k)
+            if t_case == "objects":
+                assert abs(float(tb["confidence"]) - float(tb_ref["confidence"])) <= 1e-5
+            else:
+                assert torch.isnan(tb["confidence"]) and torch.isnan(tb_ref["confidence"])
+            tol = 1e-5 if dtype == torch.float32 else 4e-3             # (bf16 gradients: one rounding of the result)
+            for k in gr:
+                assert p[k].grad.dtype == dtype and p[k].grad.stride() == p[k].stride()
+                scale = float(g_ref[k].abs().max())
+                assert float((gr[k] - g_ref[k]).abs().max()) <= tol * scale + 1e-9, (t_case, dtype, k)
+            assert float(gr["hm"][0, 0, :4, :4].abs().max()) == 0.0 and float(gr["hm"][0, 1, :4, :4].abs().max()) == 0.0
