@@ -88,7 +88,7 @@ class _Conv3x3Function(torch.autograd.Function):
             dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)      # [cp, 9, cin] f32
             dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dyn.reshape(-1, cp)[:, :cout].float().sum(0)
+            db = ops.col_sum(dyn.reshape(-1, cp))[:cout]        # fp32 column sums in a fixed order (one small pass over dy)
         return dx, dw, db, None, None
 
 
