@@ -6,6 +6,8 @@ parameters and state-dict keys, base_bev_backbone.py:37-51 / center_head.py:17-2
 anything the kernel does not cover (other kernel sizes / strides, CPU tensors, fp32 maps outside a bf16 autocast
 region, cin % 32 != 0) takes
 nn.Conv2d's own path."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -41,6 +43,9 @@ def _dense_pairs(B, H, W, device):
 
 def _pad32(c):
     return (c + 31) // 32 * 32
+
+
+BATCH_BN_COUNTERS = os.environ.get('PCD_BN2D_BUMP', '1') != '0'
 
 
 class _Conv3x3Function(torch.autograd.Function):
@@ -181,5 +186,24 @@ class BatchNormReLU2d(nn.BatchNorm2d):
             if Fsp._fusable(self, rows):
                 y = Fsp.batch_norm_act(self, rows, None, self.relu)
                 return y.view(B, H, W, C).permute(0, 3, 1, 2)
+        if getattr(self, "_defer_nbt", False) and self.training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.sub_(1)         # bump_bn_counters() already counted this call
         y = super().forward(x)
         return torch.relu(y) if self.relu else y
+
+
+def bump_bn_counters(module):
+    """num_batches_tracked += 1 for every BatchNormReLU2d below `module` in ONE multi-tensor launch (the modules then
+    skip their own increment): 20 one-element launches per step otherwise sit between the convs of the BEV stack."""
+    if not BATCH_BN_COUNTERS:
+        return
+    bns = module.__dict__.get("_bn2d_list")
+    if bns is None:
+        bns = [m for m in module.modules() if isinstance(m, BatchNormReLU2d)]
+        for m in bns:
+            m._defer_nbt = True
+        module.__dict__["_bn2d_list"] = bns
+    if module.training:
+        counters = [m.num_batches_tracked for m in bns if m.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import conv2d_fast
 from .conv2d_fast import BatchNormReLU2d, Conv3x3
 
 
@@ -70,6 +71,7 @@ class BaseBEVBackbone(nn.Module):
         self.num_bev_features = c_in
 
     def forward(self, data_dict):
+        conv2d_fast.bump_bn_counters(self)
         spatial_features = data_dict['spatial_features']
         with torch.autocast('cuda', dtype=self.compute_dtype, enabled=spatial_features.is_cuda
                             and self.compute_dtype != torch.float32):
@@ -139,6 +141,7 @@ class CenterHeadTowers(nn.Module):
             self.heads_list.append(SeparateHead(shared, d, init_bias=-2.19, use_bias=use_bias))
 
     def forward(self, data_dict):
+        conv2d_fast.bump_bn_counters(self)
         x = data_dict['spatial_features_2d']
         with torch.autocast('cuda', dtype=self.compute_dtype, enabled=x.is_cuda and self.compute_dtype != torch.float32):
             x = self.shared_conv(x)

@@ -16,3 +16,15 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
     print(f"{v[0]:5d} {v[1]:9.1f} us  {k}")
 PY
 tail -1 gpurun_out/dh_bench.log | cut -c1-200
+python - <<'PY'
+import re, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for l in open("gpurun_out/dh_seq.txt"):
+    q, t0, dur, name = l.split(None, 3)
+    if not any(k in name for k in ("elementwise", "reduce_kernel<", "Cat", "rocclr", "scatter_gather", "index", "SubTensor", "multi_tensor", "FillFunctor")):
+        continue
+    agg[name.strip()[:140]][0] += 1; agg[name.strip()[:140]][1] += float(dur)
+print("torch / runtime glue kernels in the step:")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{v[0]:5d} {v[1]:9.1f} us  {k}")
+PY
