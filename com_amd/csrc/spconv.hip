@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(256, 4) void wgrad128_kernel(
 
 // dW[co][k][ci] = sum of the tiles of offset k in tile order (wgrad128_kernel); block -> (k, 1/16 of the tile)
 __device__ __forceinline__ void wgrad_tiles_reduce_body(const void *__restrict__ ws, int K, float *__restrict__ dw,
-                                                        unsigned block) {
+                                                        unsigned block, int tr = 0) {
     constexpr int C = 128;
     const int k = block >> 4, e4 = ((block & 15) << 8) + threadIdx.x;   // float4 index inside the tile (4096 of them)
     const int *hdr = reinterpret_cast<const int *>(ws);
@@ -1582,6 +1582,13 @@ __device__ __forceinline__ void wgrad_tiles_reduce_body(const void *__restrict__
     }
     const int lane = e4 & 63, mn = (e4 >> 6) & 15, wave = e4 >> 10;
     const int ci = (wave >> 1) * 64 + (mn >> 2) * 16 + (lane >> 4) * 4, co = (wave & 1) * 64 + (mn & 3) * 16 + (lane & 15);
+    if (tr) {          // [cout][cin][K] (see wgrad_reduce_body)
+        dw[((size_t)co * C + ci + 0) * K + k] = s.x;
+        dw[((size_t)co * C + ci + 1) * K + k] = s.y;
+        dw[((size_t)co * C + ci + 2) * K + k] = s.z;
+        dw[((size_t)co * C + ci + 3) * K + k] = s.w;
+        return;
+    }
     *reinterpret_cast<float4 *>(dw + ((size_t)co * K + k) * C + ci) = s;
 }
 
@@ -1706,7 +1713,8 @@ constexpr int WGRAD_OS_ROWS = 1024;     // output rows per workgroup (= per slab
 // dependent-latency iterations: 20+ us for a 1.7 MB reduction.)
 template <int V>   // V = 4: four consecutive elements per thread (16-byte loads), n % 4 == 0;  V = 1: scalar
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int splits, size_t n,
-                                                  float *__restrict__ dw, unsigned block, float *lds) {
+                                                  float *__restrict__ dw, unsigned block, float *lds,
+                                                  int tr_k = 0, int tr_cin = 0) {
     float(*part)[32][V] = reinterpret_cast<float(*)[32][V]>(lds);   // [8][32][V]
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t e = ((size_t)block * 32 + el) * V;
@@ -1752,7 +1760,17 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab
 #pragma unroll
             for (int t = 1; t < 8; ++t) r[j] += part[t][el][j];
         }
-        if (V == 4)
+        if (tr_k > 0) {
+            // nn.Conv2d parameter layout [cout][cin][K] instead of [cout][K][cin] (the dense 3x3 convs of the BEV stack
+            // write their gradient straight into .grad): element e = (co K + k) cin + ci -> (co cin + ci) K + k
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const size_t ej = e + j;
+                const size_t ci = ej % (size_t)tr_cin, t = ej / (size_t)tr_cin;
+                const size_t k = t % (size_t)tr_k, co = t / (size_t)tr_k;
+                dw[(co * tr_cin + ci) * tr_k + k] = r[j];
+            }
+        } else if (V == 4)
             *reinterpret_cast<float4 *>(dw + e) = make_float4(r[0], r[1 % V], r[2 % V], r[3 % V]);
         else
             dw[e] = r[0];
@@ -1775,6 +1793,7 @@ struct RedJobs {
         unsigned long long n;
         int splits, vec;
         unsigned first_block;
+        int tr_k, tr_cin;        // > 0: write [cout][cin][K]
     } job[PCD_WGRAD_MAX_JOBS];
     int n_jobs;
 };
@@ -1786,11 +1805,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
     j = __builtin_amdgcn_readfirstlane(j);
     const unsigned block = blockIdx.x - J.job[j].first_block;
     if (J.job[j].vec == 2)   // tiles of wgrad128_kernel (n = kernel volume)
-        wgrad_tiles_reduce_body(J.job[j].slab, (int)J.job[j].n, J.job[j].dw, block);
+        wgrad_tiles_reduce_body(J.job[j].slab, (int)J.job[j].n, J.job[j].dw, block, J.job[j].tr_k);
     else if (J.job[j].vec)
-        wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
+        wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
+                             J.job[j].tr_k, J.job[j].tr_cin);
     else
-        wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds);
+        wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
+                             J.job[j].tr_k, J.job[j].tr_cin);
 }
 
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
@@ -2148,7 +2169,8 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
     unsigned blocks = 0;
     for (int i = 0; i < n_jobs; ++i) {
         const PcdWgradReduceJob &q = jobs_host[i];
-        if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight) return PCD_ERR_INVALID_ARG;
+        if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight || (q.layout != 0 && q.layout != 1))
+            return PCD_ERR_INVALID_ARG;
         if (q.pmax == 0 && q.splits <= 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
         if (!q.workspace) return PCD_ERR_WORKSPACE;
         int splits, per;
@@ -2160,6 +2182,8 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
             d.splits = 0;
             d.vec = 2;
             d.first_block = blocks;
+            d.tr_k = q.layout == 1 ? q.kvol : 0;
+            d.tr_cin = q.cin;
             blocks += (unsigned)q.kvol * 16;
             continue;
         }
@@ -2174,6 +2198,8 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
         d.splits = splits;
         d.vec = vec ? 1 : 0;
         d.first_block = blocks;
+        d.tr_k = q.layout == 1 ? q.kvol : 0;
+        d.tr_cin = q.cin;
         blocks += (unsigned)(((vec ? n / 4 : n) + 31) / 32);
     }
     if (blocks == 0) return PCD_OK;

@@ -70,6 +70,8 @@ class _Conv3x3Function(torch.autograd.Function):
             y = y[..., :cout].contiguous()
         ctx.save_for_backward(xn, weight, pack_d)
         ctx.has_bias, ctx.cout = bias is not None, cout
+        ctx.weight_param = weight if isinstance(weight, nn.Parameter) else None
+        ctx.bias_param = bias if isinstance(bias, nn.Parameter) else None
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -83,17 +85,65 @@ class _Conv3x3Function(torch.autograd.Function):
         if cp != cout:
             dyn = torch.nn.functional.pad(dyn, (0, cp - cout))
         dyn = dyn.contiguous()
+        from ..spconv import functional as Fsp
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        cur = torch.cuda.current_stream()
+        # as in the sparse convs (spconv/functional.py): the data gradient is issued first on the current stream, the
+        # weight / bias gradients run on the side stream from an event recorded before it; with DIRECT_GRAD they are
+        # written straight into .grad (the slab reduction deferred to ONE launch at the join, in the parameter's own
+        # [cout, cin, 3, 3] layout) and the join is lagged -- no copy, no AccumulateGrad add, no per-layer reduce launch
+        side = ready = None
+        if Fsp.OVERLAP_WGRAD and ctx.needs_input_grad[0] and (want_w or want_b):
+            ready = torch.cuda.Event()
+            ready.record(cur)
         if ctx.needs_input_grad[0]:
             if pack_d is None:
                 pack_d = ops.conv2d_pack_weight(weight, 1)
             dx = ops.conv2d_3x3_nhwc(dyn, pack_d, cin).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            pairs, num = _dense_pairs(B, H, W, xn.device)
-            dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)      # [cp, 9, cin] f32
-            dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.col_sum(dyn.reshape(-1, cp))[:cout]        # fp32 column sums in a fixed order (one small pass over dy)
+        if ready is not None:
+            side = Fsp._side_stream(dyn.device)
+            side.wait_event(ready)
+        wp, bp = ctx.weight_param, ctx.bias_param
+
+        def direct(p):
+            return (Fsp.DIRECT_GRAD and cp == cout and p is not None and p.grad is not None
+                    and p.grad.dtype == torch.float32 and p.grad.is_contiguous())
+        direct_w, direct_b = want_w and direct(wp), want_b and direct(bp)
+        deferred = (Fsp.WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not want_w)
+                    and (direct_b or not want_b))
+        if direct_w and deferred:
+            Fsp._claim_direct(wp, "w")
+        if direct_b and deferred:
+            Fsp._claim_direct(bp, "b")
+        with torch.cuda.stream(side) if side is not None else Fsp._NullCtx():
+            if want_w:
+                pairs, num = _dense_pairs(B, H, W, xn.device)
+                if direct_w and deferred:
+                    ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9, out=wp.grad,
+                              defer=Fsp._WGRAD_JOBS, conv2d_layout=True)
+                else:
+                    dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)  # [cp, 9, cin] f32
+                    dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
+            if want_b:
+                if direct_b and deferred:
+                    ops.col_sum(dyn.reshape(-1, cp), out=bp.grad)
+                else:
+                    db = ops.col_sum(dyn.reshape(-1, cp))[:cout]   # fp32 column sums in a fixed order
+            if deferred:
+                ev = torch.cuda.Event()
+                ev.record(side)
+        if deferred:
+            Fsp._PENDING.append((ev, xn, dyn, None))     # inputs stay alive until the lagged join
+            if len(Fsp._PENDING) > Fsp.WGRAD_JOIN_LAG:
+                cur.wait_event(Fsp._PENDING[-1 - Fsp.WGRAD_JOIN_LAG][0])
+                del Fsp._PENDING[:len(Fsp._PENDING) - Fsp.WGRAD_JOIN_LAG]
+        elif side is not None:
+            cur.wait_stream(side)
+            for t in (dw, db):
+                if t is not None:
+                    t.record_stream(cur)
         return dx, dw, db, None, None
 
 

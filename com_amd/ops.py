@@ -804,13 +804,17 @@ def _usable_out(out, numel):
 WGRAD_OS = True      # 16-output-channel layers: output-stationary kernel over nbr_out (pcd_sparse_conv_wgrad_os)
 
 
-def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None, rb=None):
+def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None, rb=None,
+          conv2d_layout=False):
     """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
     (e.g. the parameter's .grad) when given.  `defer` (a list): only the MFMA kernel runs now, into a slab buffer of
     its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all).
     `nbr_out` [K, n_out] (+ `n_out_dev`): lets 16-output-channel layers use the output-stationary kernel.
     `rb` (instead of pairs / pair_num / nbr_out): a Rulebook -- its pairs are only touched (and, for a SubM rulebook
-    built without them, only then derived) when the pair-based kernel is the one that runs."""
+    built without them, only then derived) when the pair-based kernel is the one that runs.
+    `conv2d_layout` (needs `defer`): the deferred reduction writes dW as [Cout, Cin, K] -- the memory layout of an
+    nn.Conv2d weight [Cout, Cin, 3, 3] -- so `out` can be that parameter's .grad."""
+    assert not conv2d_layout or defer is not None
     n_in_dev = None
     if rb is not None:
         nbr_out, n_out_dev, n_in_dev = rb.nbr_out, rb.n_out_dev, rb.n_in_dev
@@ -868,7 +872,7 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
                                              dy.shape[0], cout, L.ptr(pairs), L.ptr(pair_num), kvol, pmax, L.ptr(dw),
                                              L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_v2")
     if defer is not None:
-        defer.append((ws, dw, kvol, cin, cout, pmax))
+        defer.append((ws, dw, kvol, cin, cout, pmax, 0, 1 if conv2d_layout else 0))
         return dw
     L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
             "pcd_sparse_conv_wgrad_reduce")
@@ -943,7 +947,8 @@ def wgrad_reduce_batched(jobs):
         arr = (L.PcdWgradReduceJob * len(chunk))()
         for j, job in enumerate(chunk):
             ws, dw, kvol, cin, cout, pmax = job[:6]
-            arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax, job[6] if len(job) > 6 else 0)
+            arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax, job[6] if len(job) > 6 else 0,
+                                         job[7] if len(job) > 7 else 0)
         L.check(L.lib().pcd_sparse_conv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk),
                                                              L.stream_ptr()), "pcd_sparse_conv_wgrad_reduce_batched")
 

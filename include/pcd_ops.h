@@ -354,6 +354,8 @@ typedef struct PcdWgradReduceJob {
     float *dweight;
     int kvol, cin, cout, pmax;
     int splits;              /* 0: as planned by pcd_sparse_conv_wgrad; > 0: slabs written by pcd_sparse_conv_wgrad_os */
+    int layout;              /* of dweight: 0 = [cout][K][cin] (spconv weights), 1 = [cout][cin][K] (nn.Conv2d weights
+                              * [cout, cin, 3, 3]: the dense 3x3 convs of the BEV stack write straight into .grad) */
 } PcdWgradReduceJob;
 int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream);
 /* Output-stationary form for layers with 16 output channels (cin_pad 8 or 16, 3x3x3): walks the OUTPUT rows, reads dY in
