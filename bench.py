@@ -530,9 +530,16 @@ def main():
             if args.dense_head:
                 conv_packs.run()
 
+    DEVICE_SCHEDULE = os.environ.get('PCD_DEVICE_SCHEDULE', '1') != '0'
+    if DEVICE_SCHEDULE:
+        # OneCycle as a device table indexed by the optimizer's own step counter (looked up inside the replayed graph):
+        # no 8-byte host -> device copy in front of every step
+        opt.set_schedule([cdist.one_cycle(i, total_iters) for i in range(total_iters)])
+
     def schedule():
         """lr / momentum of this iteration into the device-side pair the (replayed) optimizer kernel reads."""
-        opt.set_hyper(*cdist.one_cycle(it_count[0], total_iters))
+        if not DEVICE_SCHEDULE:
+            opt.set_hyper(*cdist.one_cycle(it_count[0], total_iters))
         it_count[0] += 1
 
     def eager_step(i, ev=None, source=None):

@@ -142,6 +142,15 @@ class FlatAdam:
         self._hyper_ev = [None] * 64
         self._hyper_i = 0
         self.ws = torch.empty((max(int(L.lib().pcd_adam_flat_workspace_bytes()), 256),), dtype=torch.uint8, device=p.device)
+        self.schedule = None
+
+    def set_schedule(self, pairs):
+        """The whole (lr, beta1) schedule as a device table [T, 2] (row = number of updates done so far, the last row
+        repeats): `step()` then looks this step's pair up on the device -- inside a replayed hipGraph too -- and no
+        per-step host -> device copy (`set_hyper`) sits in front of the step."""
+        t = torch.as_tensor(pairs, dtype=torch.float32)
+        assert t.dim() == 2 and t.shape[1] == 2 and t.shape[0] >= 1
+        self.schedule = t.to(self.hyper.device).contiguous()
 
     def set_hyper(self, lr, beta1):
         """lr / beta1 of the NEXT step(s) (async H2D of 8 bytes on the current stream; capturable graphs read the
@@ -161,6 +170,9 @@ class FlatAdam:
     def step(self):
         L, b = self.L, self.bucket
         p = b.flat_param.data
+        if self.schedule is not None:
+            idx = self.step_dev.to(torch.int64).clamp_(max=self.schedule.shape[0] - 1)
+            self.hyper.copy_(self.schedule.index_select(0, idx).view(2))
         L.check(L.lib().pcd_adam_flat_step_v2(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                               p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                               self.max_norm, self.world, int(self.decoupled), L.ptr(self.hyper),

@@ -800,16 +800,19 @@ def test_flat_adam_decoupled_matches_reference_optimwrapper_trajectory(golden):
     from com_amd import dist as cdist
     g = golden("g8_adam_onecycle")
     total = int(g["total_steps"][0])
-    for graphed in (False, True):
+    for graphed, table in ((False, False), (True, False), (False, True), (True, True)):
         p = torch.nn.Parameter(torch.from_numpy(np.pad(g["p0"], (0, (-g["p0"].size) % 4))).to(DEV))
         bucket = cdist.FlatGradBucket([p])
         bucket.flatten_parameters()
         fa = cdist.FlatAdam(bucket, lr=1.0, betas=(0.5, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0, world=1,
                             decoupled=True)                        # lr / beta1 on the host are overridden by set_hyper
+        if table:      # the whole schedule as a device table, looked up by the optimizer's own step counter (bench.py)
+            fa.set_schedule([cdist.one_cycle(i, total) for i in range(g["grads"].shape[0])])
         graph = None
         n = g["p0"].size
         for it in range(g["grads"].shape[0]):
-            fa.set_hyper(*cdist.one_cycle(it, total))
+            if not table:
+                fa.set_hyper(*cdist.one_cycle(it, total))
             bucket.flat[:n].copy_(torch.from_numpy(g["grads"][it]).to(DEV))
             if not graphed:
                 fa.step()
@@ -824,7 +827,8 @@ def test_flat_adam_decoupled_matches_reference_optimwrapper_trajectory(golden):
                         t.copy_(s0)                                # capture does not execute; be explicit anyway
                 graph.replay()
             got = bucket.flat_param.data[:n].cpu().numpy()
-            np.testing.assert_allclose(got, g["params"][it], rtol=2e-6, atol=2e-7, err_msg=f"step {it} graphed={graphed}")
+            np.testing.assert_allclose(got, g["params"][it], rtol=2e-6, atol=2e-7,
+                                       err_msg=f"step {it} graphed={graphed} table={table}")
 
 
 def test_pack_weights_batched_matches_single():
