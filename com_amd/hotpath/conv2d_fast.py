@@ -152,7 +152,7 @@ class Conv3x3(nn.Conv2d):
 
     def _fast(self, x):
         bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
-                                             and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+                                             and torch.get_autocast_dtype('cuda') == torch.bfloat16)
         return (ENABLED and bf16 and x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.stride == (1, 1)
                 and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
                 and self.padding_mode == 'zeros' and self.in_channels % 32 == 0
