@@ -1968,8 +1968,14 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     }
 #define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
-        case 1:
-            return resident ? launch_gg<1, 1, 2, 0>(GG_ARGS) : launch_gg<1, 1, 2, 4>(GG_ARGS);
+        case 1: {
+            // 16 channels (level 1).  With key-ordered voxel rows (pcd_voxelize_hard_sorted) 32 rows per wave and one
+            // step of look-ahead win: whole step 3.46 -> 3.42 ms (<1,2,2,0> 3.43, <1,4,*,0> 3.47-3.48, <1,1,1/4,0> 3.46);
+            // rows in first-appearance order preferred <1,1,2,0> (PCD_GG1=0).
+            static const int v1 = getenv("PCD_GG1") ? atoi(getenv("PCD_GG1")) : 1;
+            if (resident) return v1 ? launch_gg<1, 2, 1, 0>(GG_ARGS) : launch_gg<1, 1, 2, 0>(GG_ARGS);
+            return launch_gg<1, 1, 2, 4>(GG_ARGS);
+        }
         case 2:
             // (32 channels, staged: <2,2,2,2> / <2,2,2,4> / <2,4,2,2> / <2,2,4,4> / <2,4,1,2> measured 4.20-4.34 vs 4.18)
             return resident ? launch_gg<2, 2, 1, 0>(GG_ARGS) : launch_gg<2, 2, 1, 2>(GG_ARGS);
