@@ -1825,11 +1825,13 @@ static bool wgrad128_enabled() {
     }
     return v == 1;
 }
-static int wgrad128_chunks() {   // equal-pair chunks of wgrad128_kernel: three resident workgroups per CU
+static int wgrad128_chunks() {   // equal-pair chunks of wgrad128_kernel: two workgroups per CU
+    // (768 = three per CU was the isolated optimum; in the step 512 wins by 0.6 % -- 3.424 vs 3.447 ms, 384 / 640: 3.436 /
+    //  3.451 -- a third less tile traffic for the reduction: 512 x 64 KiB per layer)
     static int v = 0;
     if (v == 0) {
         const char *e = getenv("PCD_WG128_NB");
-        v = e ? atoi(e) : 768;
+        v = e ? atoi(e) : 512;
         if (v < 8) v = 8;
         v = (v + 7) / 8 * 8;
     }
