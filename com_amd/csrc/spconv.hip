@@ -1841,7 +1841,10 @@ static bool wgrad128_use(int cin, int cout) { return cin == 128 && cout == 128 &
 
 static void wgrad_plan(int pmax, int cin, int cout, int *splits, int *rows_per_split) {
     const int chunks = pcd_div_up(cin, 64) * pcd_div_up(cout, 64);
-    int s = pcd_div_up(pmax > 0 ? pmax : 1, chunks >= 4 ? 8192 : 4096);
+    // input rows per split (x 2 for layers cut into >= 4 channel chunks): 6144 measured best in the step (3.420 ms;
+    // 3072 / 4096 / 5120 / 7168 / 8192: 3.450 / 3.432 / 3.430 / 3.429 / 3.425) -- fewer, larger slabs to reduce
+    static const int scale = getenv("PCD_WG_ROWS") && atoi(getenv("PCD_WG_ROWS")) >= 256 ? atoi(getenv("PCD_WG_ROWS")) : 6144;
+    int s = pcd_div_up(pmax > 0 ? pmax : 1, chunks >= 4 ? 2 * scale : scale);
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     int per = pcd_div_up(pmax > 0 ? pmax : 1, s);

@@ -76,11 +76,10 @@ def test_host_only_entry_points_agree_with_oracle():
     assert lib.pcd_voxelize_hard_workspace_bytes(160000, 5, 1) > 160000 * 8
     assert lib.pcd_packed_weight_bytes(27, 16, 16, 0) == 14 * 1 * 64 * 8 * 2      # ceil(27*16/32) steps
     assert lib.pcd_packed_weight_bytes(27, 5, 16, 0) == 7 * 1 * 64 * 8 * 2        # 5 -> 8 channels
-    # 128 x 128 channels = 4 chunks of 64 x 64 -> 8192-row splits (5 for 40000 rows); 64 x 64 -> 4096-row splits
-    # 128 x 128: header + (512 equal-pair chunks + one tile per offset) tiles of 128 x 128 floats; else row-range slabs
+    # 128 x 128: header + (512 equal-pair chunks + one tile per offset) tiles of 128 x 128 floats; else row-range slabs:
+    # 64 x 64 -> 6144-row splits (7 for 40000 rows)
     assert lib.pcd_sparse_conv_wgrad_workspace_bytes(27, 128, 128, 40000) == 4096 + (512 + 27) * 128 * 128 * 4
-    assert lib.pcd_sparse_conv_wgrad_workspace_bytes(27, 64, 64, 40000) == 10 * 64 * 27 * 64 * 4
-    assert lib.pcd_sparse_conv_wgrad_workspace_bytes(27, 64, 64, 40000) == 10 * 64 * 27 * 64 * 4
+    assert lib.pcd_sparse_conv_wgrad_workspace_bytes(27, 64, 64, 40000) == 7 * 64 * 27 * 64 * 4
     assert ops.grid_size((-75.2, -75.2, -2, 75.2, 75.2, 4), (0.1, 0.1, 0.15)) == [1504, 1504, 40]
 
 
