@@ -105,6 +105,24 @@ def _pmc_traffic(kernel):
     return None, None
 
 
+def _event_overhead_ms():
+    """What a HIP-event bracket measures around NOTHING (record, record on the launch stream): subtracted from every
+    bracketed launch, so that the per-launch figures are kernel durations (what rocprofv3 --kernel-trace reports for
+    the same launches) and not duration + the cost of the second event."""
+    vals = []
+    for _ in range(32):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        vals.append((e0, e1))
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in vals)
+    return t[len(t) // 2]
+
+
+EVENT_OVERHEAD_MS = [None]
+
+
 def _profiled_groups(step_fn):
     """One extra step with HIP events around every instrumented launch -> per-kernel-group totals."""
     ops.PROFILE = []
@@ -114,11 +132,13 @@ def _profiled_groups(step_fn):
         recs = ops.PROFILE
     finally:
         ops.PROFILE = None
+    if EVENT_OVERHEAD_MS[0] is None:
+        EVENT_OVERHEAD_MS[0] = _event_overhead_ms()
     groups = {}
     for key, e0, e1, meta in recs:
         name = key.split(" ")[0] + (" " + key.split(" ")[1] if key.startswith("wgrad") else "")
         g = groups.setdefault(name, dict(ms=0.0, bytes=0, flops=0, launches=0))
-        g["ms"] += e0.elapsed_time(e1)
+        g["ms"] += max(e0.elapsed_time(e1) - EVENT_OVERHEAD_MS[0], 0.0)
         g["bytes"] += meta["bytes"]
         g["flops"] += meta["flops"]
         g["launches"] += 1
@@ -165,6 +185,7 @@ def measure_roofline(step_fn, ms_per_step):
     traffic, source = _pmc_traffic(name)
     out["traffic"] = traffic
     out["traffic_source"] = source
+    out["event_overhead_us"] = round(1e3 * EVENT_OVERHEAD_MS[0], 2)      # (already subtracted per launch)
     total_ms = sum(v["ms"] for v in groups.values())
     out["kernels"] = [_group_roofline(k, v) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
                       if v["ms"] >= 0.02 * total_ms]
