@@ -307,6 +307,30 @@ def boxes_pairwise_bev(boxes_a, boxes_b, want_iou):
     return out
 
 
+_REF_IOU = None
+
+
+def ref_iou3d_available():
+    """True when oracle/_ref/libiou3d_ref.so (the REFERENCE's iou3d_cpu.cpp compiled unmodified by
+    oracle/ref_build/Makefile) is present."""
+    return os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libiou3d_ref.so"))
+
+
+def ref_boxes_iou_bev_cpu(boxes_a, boxes_b):
+    """The reference itself: `boxes_iou_bev_cpu` (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252) through the C shim
+    oracle/ref_build/iou3d_ref_shim.cpp.  (N, M) float32."""
+    global _REF_IOU
+    if _REF_IOU is None:
+        import torch  # noqa: F401  (libiou3d_ref.so links against libtorch; importing torch resolves it)
+        _REF_IOU = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libiou3d_ref.so"))
+    a, b = _f32(boxes_a), _f32(boxes_b)
+    assert a.ndim == 2 and a.shape[1] == 7 and b.ndim == 2 and b.shape[1] == 7
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    rc = _REF_IOU.ref_boxes_iou_bev_cpu(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+    assert rc == 1
+    return out
+
+
 def nms_bev(boxes_sorted, thresh, normal=False):
     """Greedy NMS over score-sorted boxes (iou3d_nms.cpp:100-130 semantics): kept indices, ascending."""
     b = _f32(boxes_sorted)

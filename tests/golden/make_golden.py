@@ -679,13 +679,37 @@ def g10():
     save("g10_center_loss", **out)
 
 
+def g13():
+    """Rotated BEV IoU by the REFERENCE ITSELF: pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp compiled unmodified into
+    oracle/_ref/libiou3d_ref.so (oracle/ref_build/Makefile), `boxes_iou_bev_cpu` (:232-252) on 150 x 120 random boxes
+    (18 000 pairs, ~16 % overlapping) + a 12 x 12 block of degenerate pairs (identical, touching, contained, crossed at
+    90 degrees, zero-size, tiny angle).  Stored: the boxes and the reference's IoU matrix."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "ref_build"), "-s"])
+    rng = np.random.default_rng(13)
+
+    def boxes(n, spread):
+        xy = rng.uniform(-spread, spread, (n, 2))
+        z = rng.uniform(-1, 1, (n, 1))
+        size = np.stack([rng.uniform(0.4, 12, n), rng.uniform(0.4, 3, n), rng.uniform(1, 3, n)], 1)
+        ang = rng.uniform(-np.pi, np.pi, (n, 1))
+        return np.concatenate([xy, z, size, ang], 1).astype(np.float32)
+    a, b = boxes(150, 8.0), boxes(120, 8.0)
+    d = np.array([[0, 0, 0, 4, 2, 1.5, 0], [0, 0, 0, 4, 2, 1.5, 0], [4, 0, 0, 4, 2, 1.5, 0], [0, 2, 0, 4, 2, 1.5, 0],
+                  [0, 0, 0, 4, 2, 1.5, np.pi / 2], [0, 0, 0, 0, 0, 1, 0], [1, 1, 0, 4, 2, 1.5, 1e-3],
+                  [0, 0, 0, 2, 4, 1.5, np.pi / 2], [0.5, 0.25, 0, 1, 0.5, 1, 0.3], [0, 0, 0, 4, 2, 1.5, np.pi],
+                  [0, 0, 0, 4, 2, 1.5, -np.pi / 4], [100, 100, 0, 4, 2, 1.5, 0.7]], np.float32)
+    save("g13_iou3d_ref", boxes_a=a, boxes_b=b, iou_ab=O.ref_boxes_iou_bev_cpu(a, b), boxes_d=d,
+         iou_dd=O.ref_boxes_iou_bev_cpu(d, d))
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g13):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
