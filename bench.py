@@ -149,7 +149,7 @@ RIDGE = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)      # 312 flop/B
 
 
 def _group_roofline(name, g):
-    secs = g["ms"] * 1e-3
+    secs = max(g["ms"], 1e-9) * 1e-3           # (every launch of a group can clamp to 0 after the event-overhead subtraction)
     ai = g["flops"] / max(g["bytes"], 1)
     tf = g["flops"] / secs / 1e12
     gbs = g["bytes"] / secs / 1e9

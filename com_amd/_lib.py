@@ -99,6 +99,10 @@ PROTOTYPES = {
     "pcd_adam_flat_step_v2": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp,
                                    _vp, _sz, _vp]),
+    "pcd_adam_flat_step_v3": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
+                                   _vp, _vp, _vp, _sz, _vp]),
+    "pcd_stream_capture_id": (_i, [_vp, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
     "pcd_centerhead_loss_workspace_bytes": (_sz, [_i]),
     "pcd_centerhead_loss_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,

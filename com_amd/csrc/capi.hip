@@ -22,3 +22,19 @@ extern "C" void pcd_set_last_hip_error(int code) { g_last_hip_error = code; }
 extern "C" const char *pcd_last_hip_error_string(void) {
     return hipGetErrorString((hipError_t)g_last_hip_error);
 }
+
+// 0 when `stream` is not capturing, else the id of the capture it belongs to (hipStreamGetCaptureInfo): lets the host
+// side key per-graph resources (e.g. the counter blocks of the fused BatchNorm reductions) by the capture they were
+// allocated in, so that two graphs -- or a graph and eager launches -- never share a counter.
+extern "C" int pcd_stream_capture_id(void *stream, unsigned long long *id_out) {
+    if (!id_out) return PCD_ERR_INVALID_ARG;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id);
+    if (e != hipSuccess) {
+        pcd_set_last_hip_error((int)e);
+        return PCD_ERR_LAUNCH;
+    }
+    *id_out = st == hipStreamCaptureStatusActive ? (id ? id : 1ull) : 0ull;
+    return PCD_OK;
+}

@@ -167,6 +167,7 @@ namespace {
 constexpr int CHL_BLOCKS = 256;     // partial rows of the forward pass
 constexpr int CHL_MAX_REG = 8;      // regression branches per head
 constexpr int CHL_MAX_DIM = 16;     // code dimensions
+constexpr int CHL_MAX_OBJS = 2048;  // objects per frame (num_max_objs; the reference uses 500): LDS list of the backward
 
 struct ChlMap {                     // one prediction map [B][c][H][W] behind strides
     const void *p;
@@ -344,7 +345,6 @@ __global__ __launch_bounds__(256) void chl_backward_kernel(ChlMap hm, const floa
 // A block per frame.  The masked objects are first compacted into LDS in object order (typically < 100 of the 500
 // slots); then one thread per object: the FIRST object of a pixel adds up the gradients of all objects of that pixel (in
 // object order) and stores them.
-constexpr int CHL_MAX_OBJS = 2048;
 __global__ __launch_bounds__(256) void chl_scatter_kernel(ChlRegs regs, int W, const long long *__restrict__ ind,
                                                           const long long *__restrict__ mask,
                                                           const float *__restrict__ target, int M,
@@ -441,6 +441,7 @@ extern "C" int pcd_centerhead_loss_forward(const void *hm, int hm_dtype, const l
     if (workspace_bytes < pcd_centerhead_loss_workspace_bytes(R.dims)) return PCD_ERR_WORKSPACE;
     if ((double)batch * (num_classes > CHL_MAX_DIM ? num_classes : CHL_MAX_DIM) * height * width >= 4294967295.0)
         return PCD_ERR_UNSUPPORTED;
+    if (num_max_objs > CHL_MAX_OBJS) return PCD_ERR_UNSUPPORTED;   // (the backward pass could not follow)
     hipStream_t st = (hipStream_t)stream;
     const int pstride = 4 + CHL_MAX_DIM + 2;
     chl_forward_kernel<<<CHL_BLOCKS, 256, 0, st>>>(H_, gt_heatmap, batch, num_classes, height, width, R, inds, masks,
@@ -474,6 +475,7 @@ extern "C" int pcd_centerhead_loss_backward(const void *hm, void *d_hm, int hm_d
     if ((double)batch * (num_classes > CHL_MAX_DIM ? num_classes : CHL_MAX_DIM) * height * width >= 4294967295.0 ||
         (double)height * width >= 2147483647.0)
         return PCD_ERR_UNSUPPORTED;
+    if (num_max_objs > CHL_MAX_OBJS) return PCD_ERR_UNSUPPORTED;   // chl_scatter_kernel compacts a frame's objects in LDS
     hipStream_t st = (hipStream_t)stream;
     chl_backward_kernel<<<1024, 256, 0, st>>>(H_, gt_heatmap, batch, num_classes, height, width, R, out, grad_out,
                                               cls_weight);

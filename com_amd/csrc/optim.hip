@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
                                                         float pre_divisor, const float *__restrict__ step_dev,
                                                         float lr, float beta1, float beta2, float eps, float wd,
                                                         float *__restrict__ norm_out, int decoupled,
-                                                        const float *__restrict__ hyper_dev) {
+                                                        float *__restrict__ hyper_dev,
+                                                        const float *__restrict__ schedule, int schedule_len) {
     __shared__ double total_s;
     if (threadIdx.x < 64) {
         double s = 0.0;
@@ -50,7 +51,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
     const float coef = fminf(max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f, 1.0f);
     const float gscale = coef / pre_divisor;                                  // g_used = g_sum * gscale
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
-    if (hyper_dev) {            // lr / beta1 of THIS step from device memory (a OneCycle schedule driving a replayed graph)
+    if (schedule) {             // the whole OneCycle table on the device: row = number of updates done so far
+        int row = (int)step_dev[0];
+        row = row < schedule_len - 1 ? row : schedule_len - 1;
+        lr = schedule[2 * row];
+        beta1 = schedule[2 * row + 1];
+        if (hyper_dev && blockIdx.x == 0 && threadIdx.x == 0) {      // (kept observable; nobody in this launch reads it)
+            hyper_dev[0] = lr;
+            hyper_dev[1] = beta1;
+        }
+    } else if (hyper_dev) {     // lr / beta1 of THIS step from device memory (set_hyper driving a replayed graph)
         lr = hyper_dev[0];
         beta1 = hyper_dev[1];
     }
@@ -131,7 +141,18 @@ extern "C" int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp
                                      float max_norm, float pre_divisor, int decoupled_wd, const float *hyper_dev,
                                      float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes,
                                      void *stream) {
+    return pcd_adam_flat_step_v3(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_norm,
+                                 pre_divisor, decoupled_wd, const_cast<float *>(hyper_dev), nullptr, 0, step_dev,
+                                 norm_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     float max_norm, float pre_divisor, int decoupled_wd, float *hyper_dev,
+                                     const float *schedule_dev, int schedule_len, float *step_dev, float *norm_out,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
+    if (schedule_dev && schedule_len <= 0) return PCD_ERR_INVALID_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || pre_divisor <= 0.0f) return PCD_ERR_INVALID_ARG;
     if ((n & 3) != 0) return PCD_ERR_UNSUPPORTED;   // the flat buffer is padded to a multiple of 4 by its owner
     if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) != 0)
@@ -147,7 +168,8 @@ extern "C" int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp
     if (blocks < 1) blocks = 1;
     adam_flat_kernel<<<blocks, 256, 0, st>>>((float4 *)param, (const float4 *)grad, (float4 *)exp_avg,
                                              (float4 *)exp_avg_sq, n4, partial, max_norm, pre_divisor, step_dev, lr,
-                                             beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev);
+                                             beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev,
+                                             schedule_dev, schedule_len);
     step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

@@ -232,7 +232,16 @@ __device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_o
         if (last_s) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (last_s) bn_mid_row(bn.partial, nrows, c_out, r, bn.mid, reinterpret_cast<double *>(smem_base));
+    if (last_s) {
+        // Memory-model note: publication is done at the ISA level -- every row element is an agent-scope (sc1, write-
+        // through to the device coherence point) store whose completion the writer awaits (s_waitcnt vmcnt(0)) before
+        // the workgroup barrier that precedes its counter increment, and bn_mid_row reads with agent-scope loads.  A
+        // C++-level release on the fetch_add would add an L2 write-back (buffer_wbl2) to EVERY workgroup of the conv
+        // launch; the acquire side is cheap (16 workgroups per launch) and is taken here so that nothing the compiler
+        // or a cache could hold from before the counter read is reused.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        bn_mid_row(bn.partial, nrows, c_out, r, bn.mid, reinterpret_cast<double *>(smem_base));
+    }
 }
 
 __device__ __forceinline__ void bnred_zero_row(const BnRed &bn, int tile, int c_out) {

@@ -115,25 +115,29 @@ class FlatAdam:
     scaling pass + multi-tensor Adam.  `step()` expects bucket.flat to hold the SUM of the ranks' gradients
     (all_reduce_sum) and divides by `world` itself.
 
-    decoupled=True (default) is the reference's `adam_onecycle` update (tools/train_utils/optimization/__init__.py:
-    19-32: OptimWrapper(Adam(betas=(0.9, 0.99)), wd, true_wd=True, bn_wd=True); fastai_optim.py:135-150): every
-    parameter -- BatchNorm ones included -- is multiplied by (1 - lr * wd), then Adam runs without a weight-decay
-    term.  decoupled=False is torch.optim.Adam's L2 form.  lr / beta1 live in a device float[2] (`hyper`) so that a
-    OneCycle schedule (`set_hyper(*one_cycle(it, total))`, MOMS start at 0.95) can drive a replayed hipGraph."""
+    decoupled=False (default) is torch.optim.Adam's L2 weight decay.  decoupled=True is the reference's
+    `adam_onecycle` update (tools/train_utils/optimization/__init__.py:19-32: OptimWrapper(Adam(betas=(0.9, 0.99)), wd,
+    true_wd=True, bn_wd=True); fastai_optim.py:135-150): every parameter -- BatchNorm ones included -- is multiplied by
+    (1 - lr * wd), then Adam runs without a weight-decay term.  lr / beta1 live in a device float[2] (`hyper`) so that
+    a OneCycle schedule can drive a replayed hipGraph: either `set_schedule(table)` (the kernel looks the step's row
+    up itself) or `set_hyper(*one_cycle(it, total))` per step.  Assigning `opt.lr = x` / `opt.betas = (b1, b2)` takes
+    effect on the next step() as with torch optimizers (the device pair is refreshed; beta2 is a launch argument,
+    i.e. baked into an already captured graph)."""
 
     def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0, world=1,
-                 decoupled=True):
+                 decoupled=False):
         assert getattr(bucket, "flat_param", None) is not None, "call bucket.flatten_parameters() first"
         from . import _lib as L
         self.L, self.bucket = L, bucket
-        self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self._lr, self._betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self._hyper_dirty = False
         self.max_norm, self.world, self.decoupled = float(max_norm), float(world), bool(decoupled)
         p = bucket.flat_param.data
         self.exp_avg = torch.zeros_like(p)
         self.exp_avg_sq = torch.zeros_like(p)
         self.step_dev = torch.zeros((1,), dtype=torch.float32, device=p.device)
         self.grad_norm = torch.zeros((1,), dtype=torch.float32, device=p.device)
-        self.hyper = torch.tensor([self.lr, self.betas[0]], dtype=torch.float32, device=p.device)
+        self.hyper = torch.tensor([self._lr, self._betas[0]], dtype=torch.float32, device=p.device)
         # pinned staging RING for set_hyper: the host runs ahead of the device when steps are graph replays, so a
         # staging slot must not be rewritten before its async copy has executed (slot events guard the reuse)
         self._hyper_host = torch.zeros((64, 2), dtype=torch.float32)
@@ -143,6 +147,22 @@ class FlatAdam:
         self._hyper_i = 0
         self.ws = torch.empty((max(int(L.lib().pcd_adam_flat_workspace_bytes()), 256),), dtype=torch.uint8, device=p.device)
         self.schedule = None
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr, self._hyper_dirty = float(value), True
+
+    @property
+    def betas(self):
+        return self._betas
+
+    @betas.setter
+    def betas(self, value):
+        self._betas, self._hyper_dirty = (float(value[0]), float(value[1])), True
 
     def set_schedule(self, pairs):
         """The whole (lr, beta1) schedule as a device table [T, 2] (row = number of updates done so far, the last row
@@ -155,7 +175,7 @@ class FlatAdam:
     def set_hyper(self, lr, beta1):
         """lr / beta1 of the NEXT step(s) (async H2D of 8 bytes on the current stream; capturable graphs read the
         device copy)."""
-        self.lr, self.betas = float(lr), (float(beta1), self.betas[1])
+        self._lr, self._betas, self._hyper_dirty = float(lr), (float(beta1), self._betas[1]), False
         i = self._hyper_i
         self._hyper_i = (i + 1) % len(self._hyper_ev)
         if self._hyper_ev[i] is not None:
@@ -170,14 +190,16 @@ class FlatAdam:
     def step(self):
         L, b = self.L, self.bucket
         p = b.flat_param.data
-        if self.schedule is not None:
-            idx = self.step_dev.to(torch.int64).clamp_(max=self.schedule.shape[0] - 1)
-            self.hyper.copy_(self.schedule.index_select(0, idx).view(2))
-        L.check(L.lib().pcd_adam_flat_step_v2(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                              p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+        if self._hyper_dirty:                          # `opt.lr = ...` / `opt.betas = ...` since the last step
+            self.set_hyper(self._lr, self._betas[0])
+        sched = self.schedule                          # (the kernel reads row min(step, T - 1) itself: no lookup launches)
+        L.check(L.lib().pcd_adam_flat_step_v3(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                              p.numel(), self._lr, self._betas[0], self._betas[1], self.eps, self.wd,
                                               self.max_norm, self.world, int(self.decoupled), L.ptr(self.hyper),
+                                              L.ptr(sched) if sched is not None else None,
+                                              int(sched.shape[0]) if sched is not None else 0,
                                               L.ptr(self.step_dev), L.ptr(self.grad_norm), L.ptr(self.ws),
-                                              self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v2")
+                                              self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v3")
 
 
 def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):

@@ -154,7 +154,10 @@ class _BackboneBase(nn.Module):
             pf.advance()
         if getattr(self, "_packed_ahead", False):              # pack_after_update() ran since the last update
             self._packed_ahead = False
-            return
+            # ... and no weight changed behind torch's back since (load_state_dict / broadcast / manual edits bump
+            # `_version`; the flat Adam kernel does not, and it is the update pack_after_update() follows)
+            if self._packed_versions == [c.weight._version for c in self._conv_list]:
+                return
         pack_side = Fsp._side_stream(dev)                      # the wgrad stream is idle during the forward
         pack_side.wait_stream(cur)
         with torch.cuda.stream(pack_side):
@@ -170,6 +173,7 @@ class _BackboneBase(nn.Module):
             return                                             # no forward yet: the first one packs by itself
         self._pack_all()
         self._packed_ahead = True
+        self._packed_versions = [c.weight._version for c in self._conv_list]
 
     def _pack_all(self):
         """All forward (+ dgrad) weight packs of the backbone in one launch."""

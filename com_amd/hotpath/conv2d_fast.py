@@ -169,8 +169,9 @@ class Conv3x3(nn.Conv2d):
         pf = pd = None
         ahead = getattr(self, "_packs_ahead", None)
         if ahead is not None:                        # Conv3x3Packs.run() since the last weight update: use them ONCE
-            pf, pd = ahead
             self._packs_ahead = None
+            if ahead[2] == self.weight._version:     # (an in-place change since run() -- load_state_dict, broadcast,
+                pf, pd = ahead[0], ahead[1]          #  a manual edit -- bumps the version: pack again from the weights)
         return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
 
 
@@ -179,7 +180,8 @@ class Conv3x3Packs:
     into persistent buffers -- call `run()` right after every optimizer step (the weights do not change again before
     the next forward; 2 x 22 small pack launches otherwise sit in front of the convs of the CenterPoint BEV stack).
     A module uses the packs for exactly one forward / backward and packs by itself again afterwards, so a forgotten
-    `run()` costs time, never correctness."""
+    `run()` costs time, never correctness; packs made BEFORE a torch-visible in-place change of the weight
+    (load_state_dict, checkpoint restore, dist.broadcast, manual edits: all bump `weight._version`) are dropped."""
 
     def __init__(self, model):
         import ctypes  # noqa: F401
@@ -212,7 +214,7 @@ class Conv3x3Packs:
         L.check(L.lib().pcd_conv2d_pack_weights_batched(L.ptr(self.table), len(self.convs) * 2, self.total_blocks,
                                                         L.stream_ptr()), "pcd_conv2d_pack_weights_batched")
         for m, pair in zip(self.convs, self.bufs):
-            m._packs_ahead = pair
+            m._packs_ahead = (pair[0], pair[1], m.weight._version)
 
 
 class BatchNormReLU2d(nn.BatchNorm2d):

@@ -611,23 +611,41 @@ CLS_TILE = 256
 
 import os as _os
 BN_FUSED_MID = _os.environ.get("PCD_BN_FUSED_MID", "1") != "0"   # fold the BatchNorm "mid" reduction into the conv launches
-_BN_COUNTER_POOL = {}     # device -> [int32 zeros [slots * 16], next slot]
+_BN_COUNTER_POOL = {}     # device -> [int32 zeros [slots * 16], next slot]     (eager launches)
+_BN_CAPTURE_BLOCK = {}    # device -> [capture id, int32 zeros, next slot]      (launches recorded into ONE hipGraph)
+_BN_SLOTS = 1024
+
+
+def _capture_id():
+    import ctypes
+    cid = ctypes.c_ulonglong(0)
+    L.check(L.lib().pcd_stream_capture_id(L.stream_ptr(), ctypes.byref(cid)), "pcd_stream_capture_id")
+    return int(cid.value)
 
 
 def _bn_counters(device):
-    """16 zeroed int32 counters (one per 128-byte line) for one conv launch with a fused mid reduction.  The kernels return them to zero, so a
-    pool allocated (and zeroed) ONCE is handed out round-robin; 1024 slots: far more launches than are ever in flight."""
+    """16 zeroed int32 counters (one per 128-byte line) for one conv launch with a fused mid reduction.  The kernels
+    return them to zero.  Eager launches take slots round-robin from a pool zeroed once (1024 slots: far more launches
+    than are ever in flight on one device).  Launches recorded into a hipGraph NEVER share a slot with anything else:
+    every capture owns blocks allocated inside it (its private memory pool; zeroed by ONE memset node per block), slots
+    are handed out once per capture -- so eager launches, a second graph or a re-capture running concurrently on
+    another stream cannot bump a captured launch's counters."""
     key = str(device)
+    per = L.BN_MID_ROWS * L.BN_COUNTER_STRIDE
+    cid = _capture_id() if torch.cuda.is_current_stream_capturing() else 0
+    if cid:
+        blk = _BN_CAPTURE_BLOCK.get(key)
+        if blk is None or blk[0] != cid or blk[2] >= _BN_SLOTS:
+            blk = _BN_CAPTURE_BLOCK[key] = [cid, torch.zeros((_BN_SLOTS * per,), dtype=torch.int32, device=device), 0]
+        slot = blk[2]
+        blk[2] += 1
+        return blk[1][slot * per:(slot + 1) * per]
+    _BN_CAPTURE_BLOCK.pop(key, None)               # (drop the reference: the block lives as long as its graph's pool)
     ent = _BN_COUNTER_POOL.get(key)
-    if ent is None and torch.cuda.is_current_stream_capturing():
-        # first use inside a graph capture: memory allocated now belongs to that graph's pool and dies with it -- do
-        # not cache it; a per-launch buffer, zeroed by a memset node of the graph itself, serves this capture
-        return torch.zeros((L.BN_MID_ROWS * L.BN_COUNTER_STRIDE,), dtype=torch.int32, device=device)
     if ent is None:
-        ent = _BN_COUNTER_POOL[key] = [torch.zeros((1024 * L.BN_MID_ROWS * L.BN_COUNTER_STRIDE,), dtype=torch.int32,
-                                                   device=device), 0]
-    slot, per = ent[1], L.BN_MID_ROWS * L.BN_COUNTER_STRIDE
-    ent[1] = (slot + 1) % 1024
+        ent = _BN_COUNTER_POOL[key] = [torch.zeros((_BN_SLOTS * per,), dtype=torch.int32, device=device), 0]
+    slot = ent[1]
+    ent[1] = (slot + 1) % _BN_SLOTS
     return ent[0][slot * per:(slot + 1) * per]
 
 
@@ -848,6 +866,10 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
         return dw
     if rb is not None:
         pairs, pair_num = rb.pairs, rb.pair_num
+    if pairs is None or pair_num is None:
+        raise L.PcdError("weight gradient needs the rulebook's pair lists, but this rulebook was built without them "
+                         "(want_pairs=False: the layer saw no tensor requiring grad when it built the rulebook, e.g. "
+                         "under torch.no_grad()); rebuild it with gradients enabled")
     _require_cuda(pairs, pair_num)
     assert pairs.is_contiguous()
     pmax = pairs.shape[2]

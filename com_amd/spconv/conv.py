@@ -143,13 +143,13 @@ class SparseConvolution(SparseModule):
                     and tuple(self.kernel_size) == (3, 3, 3)
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
                                        self.dilation, n_dev=x.num_rows, rank=rank,
-                                       want_pairs=self.training and not lazy)   # (inference never needs them)
+                                       want_pairs=self._needs_backward(x) and not lazy)   # (inference never needs them)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, n_dev=x.num_rows,
-                                   want_pairs=self.training,      # (pair lists / parity classes: backward only)
+                                   want_pairs=self._needs_backward(x),   # (pair lists / parity classes: backward only)
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)))
             out_idx, out_shape = rb.out_indices, rb.out_shape
             if rb.rank is not None:
@@ -159,6 +159,13 @@ class SparseConvolution(SparseModule):
             # we also remember the INPUT side
             x.indice_dict[self.indice_key] = (rb, x.indices, list(x.spatial_shape))
         return rb, out_idx, out_shape
+
+    def _needs_backward(self, x):
+        """Pair lists / parity classes are what the weight and strided data gradients read: build them whenever autograd
+        will run through this layer -- decided by the autograd state, NOT by module.training (fine-tuning with frozen
+        BatchNorm runs model.eval() with trainable weights)."""
+        return torch.is_grad_enabled() and (self.weight.requires_grad or x.features.requires_grad or
+                                            (self.bias is not None and self.bias.requires_grad))
 
     def forward(self, input, passthrough=False):
         """passthrough=True (residual blocks): returns (output, identity_features) where identity_features aliases

@@ -50,6 +50,9 @@ const char *pcd_build_arch(void);         /* "gfx950" */
 /* text of the HIP runtime error behind the calling thread's last PCD_ERR_LAUNCH */
 const char *pcd_last_hip_error_string(void);
 void pcd_set_last_hip_error(int code);    /* internal use */
+/* *id_out = 0 when `stream` is not being captured into a hipGraph, else the id of that capture (host-side keying of
+ * per-graph resources; no reference counterpart: the reference has no graph capture) */
+int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
 
 /* ============================================================================================
  * (a1) hard voxelisation -- replaces spconv.utils.VoxelGeneratorV2.generate /
@@ -461,6 +464,14 @@ int pcd_adam_flat_step_v2(float *param, const float *grad, float *exp_avg, float
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
                           int decoupled_wd, const float *hyper_dev, float *step_dev, float *norm_out, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* v3: the WHOLE OneCycle schedule as a device table schedule_dev[schedule_len][2] = {lr, beta1} per update
+ * (learning_schedules_fastai.py:60-77 evaluated once on the host): the kernel reads row min(*step_dev, len - 1) itself
+ * -- no lookup launches in front of the step -- and mirrors the pair into hyper_dev (may be NULL).  schedule_dev ==
+ * NULL: v2 behaviour. */
+int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
+                          int decoupled_wd, float *hyper_dev, const float *schedule_dev, int schedule_len,
+                          float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (f2) CenterHead target assignment on the device -- replaces the per-object Python / CPU loop of
