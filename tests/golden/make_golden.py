@@ -679,6 +679,225 @@ def g10():
     save("g10_center_loss", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G11 / G12: the COM curriculum head by the REFERENCE'S OWN code.  `CurriculumCenterHead.cluster`,
+# `.assign_targets`, `.assign_target_of_single_head`, `.sigmoid`, `.get_loss`
+# (pcdet/models/dense_heads/curriculum_center_head.py:108-358,414-459) are extracted from the reference file at
+# generation time as they stand and bound to a bare class (the module itself cannot be imported: it pulls in the compiled
+# iou3d_nms extension), `FocalLossCenterCurriculum` + `RegLossCenterNet` + their helpers (pcdet/utils/loss_utils.py:
+# 998-1390) likewise; centernet_utils is imported with an empty `numba` stand-in (its jit helpers are not used here).
+def _ref_com_head():
+    import ast
+    import textwrap
+    import torch.nn as nn
+    sys.modules.setdefault("numba", types.SimpleNamespace(jit=lambda *a, **k: (lambda f: f)))
+    cu = ref_module("pcdet/models/model_utils", "centernet_utils", "refmu")
+    lsrc = open(os.path.join(REF, "pcdet/utils/loss_utils.py")).read()
+    lns = {"torch": torch, "np": np, "nn": nn, "centernet_utils": cu}
+    want = {"FocalLossCenterCurriculum", "RegLossCenterNet", "_reg_loss", "_gather_feat", "_transpose_and_gather_feat"}
+    for node in ast.parse(lsrc).body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in want:
+            exec(compile(textwrap.dedent(ast.get_source_segment(lsrc, node)), "loss_utils." + node.name, "exec"), lns)
+    hsrc = open(os.path.join(REF, "pcdet/models/dense_heads/curriculum_center_head.py")).read()
+    hns = {"torch": torch, "np": np, "centernet_utils": cu}
+    methods = {}
+    for node in ast.parse(hsrc).body:
+        if isinstance(node, ast.ClassDef) and node.name == "CurriculumCenterHead":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name in ("cluster", "assign_targets", "sigmoid", "get_loss",
+                                                                   "assign_target_of_single_head", "group_classifier"):
+                    exec(compile(textwrap.dedent(ast.get_source_segment(hsrc, fn)), "curriculum_center_head." + fn.name,
+                                 "exec"), hns)
+                    methods[fn.name] = hns[fn.name]
+    Head = type("RefCurriculumCenterHead", (), methods)
+    return Head, lns
+
+
+class _AttrDict(dict):
+    """EasyDict stand-in: attribute access + .get (what the reference's cfg objects offer)."""
+    __getattr__ = dict.__getitem__
+
+
+def _com_boxes(rng, B, M, counts, rng_lo, rng_hi):
+    gt = np.zeros((B, M, 8), np.float32)
+    npgt = np.zeros((B, M), np.float32)
+    true_object = np.zeros((B, M), np.float32)
+    occ = np.zeros((B, M), np.float32)
+    facade = np.zeros((B, M), np.float32)
+    for b in range(B):
+        n = counts[b]
+        gt[b, :n, 0] = rng.uniform(rng_lo[0], rng_hi[0], n)
+        gt[b, :n, 1] = rng.uniform(rng_lo[1], rng_hi[1], n)
+        gt[b, :n, 2] = rng.uniform(-1, 2, n)
+        cls = rng.integers(1, 4, n)
+        gt[b, :n, 3] = np.where(cls == 1, rng.uniform(3.5, 12, n), rng.uniform(0.5, 2.0, n))
+        gt[b, :n, 4] = np.where(cls == 1, rng.uniform(1.6, 3.0, n), rng.uniform(0.4, 1.0, n))
+        gt[b, :n, 5] = rng.uniform(1.0, 3.0, n)
+        gt[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
+        gt[b, :n, 7] = cls
+        npgt[b, :n] = rng.integers(0, 40, n)
+        true_object[b, :n] = rng.choice([1, 1, 1, 2], n)           # 1 = real object, 2 = pasted by the augmentor
+        occ[b, :n] = rng.choice([0.0, 0.05, 0.0875, 0.1, 0.2, 0.21, 0.25, 0.3, 0.34, 0.41, 0.5, 0.61, 0.7, 0.81, 0.9, 1.0], n)
+        facade[b, :n] = rng.integers(0, 4, n)
+    return gt, npgt, true_object, occ, facade
+
+
+def _sparse(prefix, arr, out, fill=0.0):
+    nz = np.nonzero(arr != fill)
+    out[prefix + "_nz"] = np.stack(nz, 1).astype(np.int32)
+    out[prefix + "_val"] = arr[nz]
+
+
+def g11():
+    """COM target assignment: cluster() -> group ids, assign_targets() -> heat maps, boxes, inds, float masks,
+    radius_map [B, num_max, 5] (class, cx, cy, radius, group), heatmap_mask (ones) -- on a 3-frame batch over the Waymo
+    voxel grid at stride 8 (the composition BASELINE config 3 names) for the one-head layout of
+    tools/cfgs/waymo_models/com/*.yaml and a two-head layout, with and without the MIN_POINTS epoch gate."""
+    Head, _ = _ref_com_head()
+    class_names = ["Vehicle", "Pedestrian", "Cyclist"]
+    rng = np.random.default_rng(11)
+    B, M, H, W, stride, nmax = 3, 60, 188, 188, 8, 50
+    gt, npgt, true_object, occ, facade = _com_boxes(rng, B, M, [40, 55, 7], (-74, -74), (74, 74))
+    gt[0, 3, 0:2] = [75.3, -75.3]          # outside the range: clamped centre
+    gt[0, 4, 3] = 0.0                      # degenerate box: skipped, keeps its (all-zero) slot
+    gt[1, 0, 0:2] = [75.19, 75.19]         # last cell
+    gt[1, 1, 0:2] = [29.9, 0.0]            # distance bins 30 / 50 from both sides
+    gt[1, 2, 0:2] = [30.0, 0.0]
+    gt[1, 3, 0:2] = [30.000002, 0.0]
+    gt[1, 4, 0:2] = [0.0, 50.0]
+    gt[1, 5, 3] = 6.0                      # length bin edge
+    gt[1, 5, 7] = 1
+    out = {"gt_boxes": gt, "num_points_in_gt": npgt, "true_object": true_object, "occupancy_ratio": occ,
+           "facade_type": facade, "feature_map_size": np.array([H, W], np.int32), "stride": np.array([stride], np.int32),
+           "num_max_objs": np.array([nmax], np.int32)}
+    layouts = (("one", [class_names]), ("two", [["Vehicle"], ["Pedestrian", "Cyclist"]]))
+    for tag, heads in layouts:
+        for gate, (epoch, thr, minp) in (("nogate", (3, 100, 0)), ("gate", (3, 100, 5)), ("late", (101, 100, 5))):
+            me = Head()
+            me.point_cloud_range, me.voxel_size = list(synth.WAYMO_RANGE), list(synth.WAYMO_VOXEL)
+            me.class_names, me.class_names_each_head = class_names, heads
+            me.epoch, me.epoch_thredhold, me.min_points = epoch, thr, minp
+            me.model_cfg = _AttrDict(TARGET_ASSIGNER_CONFIG=_AttrDict(FEATURE_MAP_STRIDE=stride, NUM_MAX_OBJS=nmax,
+                                                                      GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2))
+            tg = torch.from_numpy(gt.copy())             # (the reference rewrites the class column in place, :260)
+            group = me.cluster(gt_boxes=tg, true_object=torch.from_numpy(true_object),
+                               occupancy_ratio=torch.from_numpy(occ), facade_type=torch.from_numpy(facade))
+            out["group"] = group.numpy()
+            td = me.assign_targets(tg, feature_map_size=torch.Size([H, W]), npgt=torch.from_numpy(npgt),
+                                   true_object=group)
+            for hi in range(len(heads)):
+                k = f"{tag}_{gate}_h{hi}"
+                _sparse(k + "_heat", td["heatmaps"][hi].numpy(), out)
+                out[k + "_boxes"] = td["target_boxes"][hi].numpy()
+                out[k + "_inds"] = td["inds"][hi].numpy()
+                out[k + "_mask"] = td["masks"][hi].numpy()
+                out[k + "_radius_map"] = td["radius_map"][hi].numpy()
+                hmk = td["heatmap_mask"][hi].numpy()
+                assert hmk.shape == (B, len(heads[hi]), H, W) and (hmk == 1).all()
+                assert td["masks"][hi].dtype == torch.float32 and td["radius_map"][hi].dtype == torch.int64
+    save("g11_com_targets", **out)
+
+
+def g12():
+    """COM loss: CurriculumCenterHead.get_loss = FocalLossCenterCurriculum (per-group confidence sums / counts,
+    average confidence + its EMA, UCL per-object weights drawn into the heat-map mask and the box mask) +
+    RegLossCenterNet, values and gradients, for: the shipped COM setting (UCL False, conf_shape (3, 96)); UCL True with a
+    fixed threshold; UCL True with the EMA threshold over two consecutive steps; UCL True outside [START, END]; STRAIGHT;
+    CENTER; a head without a single positive.  Targets come from the reference's assign_targets on a 40 x 36 map."""
+    Head, lns = _ref_com_head()
+    class_names = ["Vehicle", "Pedestrian", "Cyclist"]
+    order = [("center", 2), ("center_z", 1), ("dim", 3), ("rot", 2)]
+    B, M, H, W, stride, nmax = 3, 40, 36, 40, 2, 30
+    pc_range, vs = [-20.0, -18.0, -2.0, 20.0, 18.0, 4.0], [0.5, 0.5, 0.15]
+    rng = np.random.default_rng(12)
+    out = {"point_cloud_range": np.array(pc_range, np.float32), "voxel_size": np.array(vs, np.float32),
+           "feature_map_size": np.array([H, W], np.int32), "stride": np.array([stride], np.int32),
+           "num_max_objs": np.array([nmax], np.int32), "head_order": np.array([n for n, _ in order]),
+           "code_weights": np.ones(8, np.float32), "cls_weight": np.array([1.0], np.float32),
+           "loc_weight": np.array([2.0], np.float32)}
+    cases = {
+        "com": dict(cur=dict(UCL=False, THRESHOLD=0.2, ELONGATION=-10, HEIGHT=1, FIX=True), epoch=5, steps=2, counts=[25, 31, 4]),
+        "ucl_fix": dict(cur=dict(UCL=True, FIX=True, ELONGATION=-10, HEIGHT=1), epoch=5, steps=1, counts=[25, 31, 4]),
+        "ucl_ema": dict(cur=dict(UCL=True, FIX=False, ELONGATION=-6, HEIGHT=0.8, ALPHA=0.3, ADD=1), epoch=5, steps=2, counts=[20, 12, 9]),
+        "ucl_off_epoch": dict(cur=dict(UCL=True, FIX=True, START=10, END=20), epoch=5, steps=1, counts=[10, 12, 3]),
+        "straight": dict(cur=dict(UCL=True, FIX=True, STRAIGHT=True, K=0.7), epoch=0, steps=1, counts=[14, 9, 11]),
+        "center": dict(cur=dict(UCL=True, FIX=True, CENTER=True, RADIUS=3), epoch=1, steps=1, counts=[14, 9, 11]),
+        "radius": dict(cur=dict(UCL=True, FIX=True, RADIUS=3), epoch=1, steps=1, counts=[14, 19, 11]),
+        "nopos": dict(cur=dict(UCL=True, FIX=True), epoch=1, steps=1, counts=[0, 0, 0]),
+    }
+    out["cases"] = np.array(sorted(cases))
+    for name, cs in cases.items():
+        me = Head()
+        me.point_cloud_range, me.voxel_size = pc_range, vs
+        me.class_names, me.class_names_each_head = class_names, [class_names]
+        me.epoch, me.epoch_thredhold, me.min_points = cs["epoch"], 100, 0
+        me.model_cfg = _AttrDict(
+            TARGET_ASSIGNER_CONFIG=_AttrDict(FEATURE_MAP_STRIDE=stride, NUM_MAX_OBJS=nmax, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+            LOSS_CONFIG=_AttrDict(LOSS_WEIGHTS={"cls_weight": 1.0, "loc_weight": 2.0, "code_weights": [1.0] * 8}),
+            LOSS_CURRICULUM=cs["cur"])
+        me.separate_head_cfg = _AttrDict(HEAD_ORDER=[n for n, _ in order])
+        me.hm_loss_func = lns["FocalLossCenterCurriculum"](me.model_cfg, conf_shape=(3, 96))
+        me.reg_loss_func = lns["RegLossCenterNet"]()
+        me.forward_ret_dict = {}
+        out[name + "_curriculum"] = np.array(json.dumps(cs["cur"]))
+        out[name + "_epoch"] = np.array([cs["epoch"]], np.int32)
+        out[name + "_steps"] = np.array([cs["steps"]], np.int32)
+        for st in range(cs["steps"]):
+            gt, npgt, true_object, occ, facade = _com_boxes(rng, B, M, cs["counts"], (-19.5, -17.5), (19.5, 17.5))
+            if name != "nopos" and st == 0:
+                gt[0, 1, 0:2] = gt[0, 0, 0:2] + np.float32(0.3)           # two objects in one cell / overlapping masks
+                gt[0, 1, 7] = gt[0, 0, 7]
+            tg = torch.from_numpy(gt.copy())
+            group = me.cluster(gt_boxes=tg, true_object=torch.from_numpy(true_object),
+                               occupancy_ratio=torch.from_numpy(occ), facade_type=torch.from_numpy(facade))
+            td = me.assign_targets(tg, feature_map_size=torch.Size([H, W]), npgt=torch.from_numpy(npgt), true_object=group)
+            hm_logit = torch.from_numpy((rng.standard_normal((B, 3, H, W)) * 2.0 - 1.0).astype(np.float32)).requires_grad_(True)
+            regs = {n: torch.from_numpy(rng.standard_normal((B, c, H, W)).astype(np.float32)).requires_grad_(True)
+                    for n, c in order}
+            me.forward_ret_dict["target_dicts"] = td
+            me.forward_ret_dict["pred_dicts"] = [dict(hm=hm_logit, **regs)]
+            masks_before = td["masks"][0].numpy().copy()
+            loss, tb = me.get_loss()
+            loss.backward()
+            k = f"{name}_s{st}"
+            out.update({k + "_gt_boxes": gt, k + "_num_points_in_gt": npgt, k + "_true_object": true_object,
+                        k + "_occupancy_ratio": occ, k + "_facade_type": facade, k + "_hm_logit": hm_logit.detach().numpy(),
+                        k + "_grad_hm_logit": hm_logit.grad.numpy(), k + "_loss": loss.detach().numpy()[None],
+                        k + "_hm_loss": np.array([tb["hm_loss_head_0"]], np.float32),
+                        k + "_loc_loss": np.array([tb["loc_loss_head_0"]], np.float32),
+                        k + "_confidence": np.array([tb["confidence"]], np.float32),
+                        k + "_avg_confidence_ema": np.array([me.hm_loss_func.avg_confidence], np.float64),
+                        k + "_confidence_all": me.hm_loss_func.confidence_all[0].numpy(),
+                        k + "_num_all": me.hm_loss_func.confidence_all[1].numpy(),
+                        k + "_masks": masks_before, k + "_radius_map": td["radius_map"][0].numpy(),
+                        k + "_inds": td["inds"][0].numpy(), k + "_target_boxes": td["target_boxes"][0].numpy()})
+            _sparse(k + "_heat", td["heatmaps"][0].numpy(), out)
+            _sparse(k + "_heatmap_mask_after", td["heatmap_mask"][0].numpy(), out, fill=1.0)   # (drawn in place by UCL)
+            for n, _ in order:
+                out[f"{k}_{n}"] = regs[n].detach().numpy()
+                out[f"{k}_grad_{n}"] = regs[n].grad.numpy()
+    save("g12_com_loss", **out)
+
+
+def g14():
+    """COM per-epoch group-confidence exchange (tools/train_utils/train_utils.py:57,111-112,208-216,269-287): per rank
+    the epoch SUM of the per-step (3, 96) confidence sums / counts (python `sum` of a list of float32 tensors), the
+    all_gather of both, the rank sum in rank order, conf / (num + 0.1).  Restated literally on synthetic per-step
+    tensors of two ranks (no process group needed: all_gather just returns every rank's tensor)."""
+    rng = np.random.default_rng(14)
+    ranks, steps = 2, 7
+    conf = rng.random((ranks, steps, 3, 96)).astype(np.float32) * rng.integers(0, 6, (ranks, steps, 3, 96)).astype(np.float32)
+    num = rng.integers(0, 6, (ranks, steps, 3, 96)).astype(np.float32)
+    per_rank_conf = [sum([torch.from_numpy(conf[r, s]) for s in range(steps)]) for r in range(ranks)]   # :208
+    per_rank_num = [sum([torch.from_numpy(num[r, s]) for s in range(steps)]) for r in range(ranks)]
+    confidence_list = sum([np.array(t) for t in per_rank_conf])                                          # :274-276
+    num_list = sum([np.array(t) for t in per_rank_num])
+    result = confidence_list / (num_list + 0.1)                                                          # :287
+    single = np.array(per_rank_conf[0] / (per_rank_num[0] + 0.01))                                       # :325 (no dist)
+    save("g14_com_epoch_gather", conf=conf, num=num, result=result.astype(np.float32), result_dtype=np.array(str(result.dtype)),
+         single_rank0=single)
+
+
 def g13():
     """Rotated BEV IoU by the REFERENCE ITSELF: pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp compiled unmodified into
     oracle/_ref/libiou3d_ref.so (oracle/ref_build/Makefile), `boxes_iou_bev_cpu` (:232-252) on 150 x 120 random boxes
@@ -709,7 +928,7 @@ if __name__ == "__main__":
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
