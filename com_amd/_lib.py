@@ -104,6 +104,16 @@ PROTOTYPES = {
                                    _vp, _vp, _vp, _sz, _vp]),
     "pcd_stream_capture_id": (_i, [_vp, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
+    "pcd_com_cluster_groups": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pcd_com_assign_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_com_assign_targets": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp,
+                                    _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pcd_com_loss_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_com_loss_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i,
+                                  _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _sz, _vp]),
+    "pcd_com_loss_backward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
+                                   _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "pcd_centerhead_loss_workspace_bytes": (_sz, [_i]),
     "pcd_centerhead_loss_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
                                          _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _sz, _vp]),
@@ -172,6 +182,18 @@ class PcdCountCheck(ctypes.Structure):
 BN_MID_ROWS = 16          # include/pcd_ops.h: PCD_BN_MID_ROWS
 BN_EXT_MID = -1           # include/pcd_ops.h: PCD_BN_EXT_MID
 BN_COUNTER_STRIDE = 32    # include/pcd_ops.h: PCD_BN_COUNTER_STRIDE
+
+
+class PcdComCurriculum(ctypes.Structure):
+    """include/pcd_ops.h: struct PcdComCurriculum (LOSS_CURRICULUM of the COM head)."""
+    _fields_ = [("ucl", ctypes.c_int), ("fix_threshold", ctypes.c_int), ("straight", ctypes.c_int),
+                ("tuning", ctypes.c_int), ("only_center", ctypes.c_int), ("apply", ctypes.c_int), ("add", ctypes.c_int),
+                ("radius", ctypes.c_int), ("k_straight", ctypes.c_double), ("elongation", ctypes.c_double),
+                ("height", ctypes.c_double), ("alpha", ctypes.c_double), ("threshold", ctypes.c_double),
+                ("conf_classes", ctypes.c_int), ("conf_groups", ctypes.c_int)]
+
+
+PCD_COM_CLUSTER_X5 = 0
 
 
 class PcdBnReduce(ctypes.Structure):

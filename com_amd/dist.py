@@ -202,6 +202,28 @@ class FlatAdam:
                                               self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v3")
 
 
+def gather_group_confidence(conf_epoch, num_epoch):
+    """COM's per-epoch exchange (tools/train_utils/train_utils.py:269-287): every rank contributes the epoch sums of
+    its per-step (3, 96) group-confidence sums and counts (`FocalLossCenterCurriculumState.epoch_confidence` /
+    `.epoch_num`); all_gather both (RCCL when the tensors live on the GPU), add the ranks' tensors in rank order and
+    return conf / (num + 0.1) as the float32 numpy array the reference hands to COMAug's database sampler
+    (`confidence_groups`, :321-323).  Without a process group: conf / (num + 0.01) (:325)."""
+    import numpy as np
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return (conf_epoch / (num_epoch + 0.01)).cpu().numpy()
+    world = dist.get_world_size()
+    out = []
+    for t in (conf_epoch, num_epoch):
+        t = t.contiguous()
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        acc = np.zeros(tuple(t.shape), np.float32)
+        for p in parts:                                   # sum(list) = ((0 + r0) + r1) + ... in float32
+            acc = acc + p.cpu().numpy()
+        out.append(acc)
+    return out[0] / (out[1] + 0.1)
+
+
 def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):
     """Start `n` ranks of `argv` (a python command line) on THIS node, one process per GPU, the way
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would (tools/scripts/dist_train.sh:18): RANK /

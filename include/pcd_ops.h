@@ -516,6 +516,78 @@ int pcd_centerhead_loss_backward(const void *hm, void *d_hm, int hm_dtype, const
                                  const float *out, const float *grad_out, void *stream);
 
 /* ============================================================================================
+ * (f2, BASELINE config 3) The COM curriculum head on the device.  Replaces, for one head and the whole batch:
+ *   pcd_com_cluster_groups   CurriculumCenterHead.cluster         pcdet/models/dense_heads/curriculum_center_head.py:414-459
+ *   pcd_com_assign_targets   assign_targets / assign_target_of_single_head  same file :108-307 (+ centernet_utils.py:46-106)
+ *   pcd_com_loss_forward     CurriculumCenterHead.get_loss of one head (:309-358) = FocalLossCenterCurriculum.neg_loss
+ *                            (pcdet/utils/loss_utils.py:1178-1310) incl. confidence_of_all_groups (:1134-1176: the
+ *                            conf_shape (3, 96) sums / counts a 288-iteration host loop produces every step), the
+ *                            average-confidence EMA (:1214), the UCL per-object weights (:1231-1291, drawn into
+ *                            heatmap_mask and box_mask in place as the reference does) + RegLossCenterNet with the
+ *                            float box mask (:1317-1390)
+ *   pcd_com_loss_backward    autograd of the above w.r.t. the heat-map logits and the regression maps
+ * No host synchronisation anywhere (the reference: one .item() per object and per head, torch.where per group).
+ *
+ *   gt_boxes [B][M][code] f32, last column = 1-based class id (0 = padding); true_object / occupancy_ratio /
+ *   facade_type / num_points_in_gt [B][M] f32 (load_data_to_gpu casts everything to float); group [B][M] i64.
+ *   radius_map [B][num_max][cols] i64, cols = 5: (class in head, centre x, centre y, radius, group), 4 without groups.
+ *   mask / box_mask [B][num_max] f32 (the reference's float `masks`), heatmap_mask [B][C][H][W] f32.
+ *   owner [B][C][H][W] i32: scratch, zeroed ONCE by its owner (the kernels return it to zero); mask_sum [C][H][W] f32:
+ *   written by the forward pass for the backward pass (both only touched when cur.ucl != 0; may be NULL otherwise).
+ *   state double[2]: {EMA of the average confidence (in/out), this step's average confidence (out)}.
+ *   out f32[6 + dims]: loss, hm_loss, loc_loss, avg_confidence, num_pos (mask-weighted), sum of box_mask, L1 per dim.
+ *   conf_all / num_all f32[conf_classes * conf_groups]: this step's sums / counts; conf_epoch / num_epoch (may be NULL):
+ *   += them (the epoch sums train_utils.py:111-112,208 builds from a Python list).
+ * The [B, 1, C, H, W] mask broadcast of loss_utils.py:1293-1297 (every frame's term weighted by the frame-SUM of the
+ * mask) is reproduced as it stands -- fixture G12 holds the reference's numbers. */
+#define PCD_COM_CLUSTER_X5 0        /* CurriculumCenterHead.cluster (used by CurriculumCenterHead_x5, head_zoo.py:145-149) */
+typedef struct PcdComCurriculum {   /* MODEL.DENSE_HEAD.LOSS_CURRICULUM as FocalLossCenterCurriculum.__init__ reads it */
+    int ucl;                        /* UCL (default True) */
+    int fix_threshold;              /* FIX */
+    int straight;                   /* STRAIGHT */
+    int tuning;                     /* TUNING */
+    int only_center;                /* CENTER */
+    int apply;                      /* START <= epoch <= END, evaluated by the caller */
+    int add;                        /* ADD */
+    int radius;                     /* RADIUS (0 = the object's own Gaussian radius + ADD) */
+    double k_straight;              /* K */
+    double elongation;              /* ELONGATION */
+    double height;                  /* HEIGHT */
+    double alpha;                   /* ALPHA */
+    double threshold;               /* self.threshold: 0.5 (loss_utils.py:1054; the YAML's THRESHOLD key is not read) */
+    int conf_classes, conf_groups;  /* conf_shape; 0, 0 = None */
+} PcdComCurriculum;
+int pcd_com_cluster_groups(const float *gt_boxes, int batch, int n_boxes, int code_size, const float *true_object,
+                           const float *occupancy_ratio, const float *facade_type, int variant, long long *group,
+                           void *stream);
+size_t pcd_com_assign_workspace_bytes(int batch, int num_max_objs);
+/* gate_min_points = (epoch <= EPOCH_THRED): objects with num_points_in_gt < min_points are skipped (:178-179);
+ * class_map_host as for pcd_centerhead_assign_targets; group may be NULL (radius_map column 4 = 0) */
+int pcd_com_assign_targets(const float *gt_boxes, int batch, int n_boxes, int code_size, const int *class_map_host,
+                           int n_class_map, int head_classes, int fm_w, int fm_h, int feature_map_stride,
+                           const float *voxel_size_xy_host, const float *range_xy_host, int num_max_objs,
+                           float gaussian_overlap, int min_radius, const float *num_points_in_gt, const long long *group,
+                           int gate_min_points, float min_points, float *heatmap, float *ret_boxes, long long *inds,
+                           float *mask, long long *radius_map, int radius_map_cols, float *heatmap_mask, void *workspace,
+                           size_t workspace_bytes, void *stream);
+size_t pcd_com_loss_workspace_bytes(int batch, int num_max_objs);
+int pcd_com_loss_forward(const void *hm, int hm_dtype, const long long *hm_strides_host, const float *gt_heatmap, int batch,
+                         int num_classes, int height, int width, const void *const *reg_ptrs_host,
+                         const int *reg_channels_host, int reg_dtype, const long long *reg_strides_host, int n_reg,
+                         const long long *inds, float *box_mask, const float *target_boxes, const long long *radius_map,
+                         int radius_map_cols, int num_max_objs, float *heatmap_mask, int32_t *owner, float *mask_sum,
+                         const PcdComCurriculum *cur_host, const float *code_weights, float cls_weight, float loc_weight,
+                         double *state, float *out, float *conf_all, float *num_all, float *conf_epoch, float *num_epoch,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int pcd_com_loss_backward(const void *hm, void *d_hm, int hm_dtype, const long long *hm_strides_host,
+                          const float *gt_heatmap, int batch, int num_classes, int height, int width,
+                          const void *const *reg_ptrs_host, void *const *reg_grads_host, const int *reg_channels_host,
+                          int reg_dtype, const long long *reg_strides_host, int n_reg, const long long *inds,
+                          const float *box_mask, const float *target_boxes, int num_max_objs, const float *mask_sum,
+                          const float *code_weights, float cls_weight, float loc_weight, const float *out,
+                          const float *grad_out, void *stream);
+
+/* ============================================================================================
  * (f4) PV-RCNN stage-2 natives -- the stacked-batch PointNet++ ops of pcdet/ops/pointnet2/pointnet2_stack (binder
  *      src/pointnet2_api.cpp; Python callers pointnet2_utils.py:8-303, voxel_query_utils.py:9-47).  "Stacked": the
  *      points of all batch elements are concatenated, *_batch_cnt[B] (device int32) give the counts.  Semantics are

@@ -38,7 +38,7 @@ def test_header_structs_match_ctypes_mirrors(tmp_path):
     import subprocess
     from com_amd import _lib
     structs = {"PcdBnReduce": _lib.PcdBnReduce, "PcdColsumJob": _lib.PcdColsumJob,
-               "PcdWgradReduceJob": _lib.PcdWgradReduceJob}
+               "PcdWgradReduceJob": _lib.PcdWgradReduceJob, "PcdComCurriculum": _lib.PcdComCurriculum}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pcd_ops.h"', 'int main(void) {']
     for name, st in structs.items():
         lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
