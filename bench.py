@@ -8,8 +8,10 @@ BEV scatter -> loss -> backward (dgrad + wgrad of every conv, BEV gather) -> DDP
 (N > 1, RCCL over xGMI) -> grad-norm clip (centerpoint.yaml:96) -> Adam step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel,
-timed live with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port
-on a bounded stratified sample of the same workload).
+timed live with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port:
+every conv fwd+bwd, rulebook and BatchNorm of ONE whole frame, median of 3 passes) and `full_model`
+(the complete CenterPoint step with the COM curriculum head -- BaseBEVBackbone + CenterHead towers +
+COM targets / losses -- measured by a child run of `bench.py --dense-head --com`).
 """
 import argparse
 import json
@@ -53,8 +55,17 @@ def parse():
     ap.add_argument("--same-shard", action="store_true",
                     help="validation: every rank processes rank 0's frames (the rank mean then equals one rank's gradient)")
     ap.add_argument("--dense-head", action="store_true",
-                    help="secondary figure: BaseBEVBackbone + CenterHead conv towers (bf16, channels-last, MIOpen) "
-                         "behind the hot path instead of the projection-loss stand-in")
+                    help="the complete CenterPoint step: BaseBEVBackbone + CenterHead towers (bf16, channels-last; "
+                         "hand-written 3x3 convs) + device-side targets and losses behind the hot path instead of the "
+                         "linear-functional stand-in")
+    ap.add_argument("--com", action="store_true",
+                    help="with --dense-head (implied): the COM curriculum head of BASELINE config 3 -- cluster(), "
+                         "curriculum targets with radius_map / groups, FocalLossCenterCurriculum with the (3, 96) "
+                         "group-confidence sums, epoch all_gather after the timed loop")
+    ap.add_argument("--com-ucl", action="store_true", help="with --com: LOSS_CURRICULUM.UCL = True (per-object weights)")
+    ap.add_argument("--distinct-batches", type=int, default=16, help="distinct global batches the timed loop cycles through")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the secondary loop over frames with 0-20 %% ray drop-out")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU plumbing test of the launcher / result assembly: gloo ranks, no GPU work")
     return ap.parse_args()
@@ -102,6 +113,26 @@ def _pmc_traffic(kernel):
         hit = [v for name, v in k.items() if name == kernel or name.startswith(kernel + "<") or name.startswith(kernel + " ")]
         val = hit[0]["hbm_bytes_per_launch_corrected"] if hit else None
         return val, f"{rel}@{blob} (offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
+    return None, None
+
+
+def _rocprof_avg_us(kernel):
+    """Average launch duration of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this
+    same command (profiles/*_kernel_stats_eager.txt), reported BESIDE the live HIP-event figure: (us, file) or (None, None)."""
+    import glob
+    import re
+    m = re.match(r"(\w+)<NB=(\d+)>", kernel)
+    pat = re.compile(re.escape(m.group(1)) + r"<" + m.group(2) + r",") if m else re.compile(re.escape(kernel.split(" ")[0]) + r"[<(]")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_eager.txt")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for path in reversed(files):
+        try:
+            for line in open(path):
+                parts = line.split(None, 4)
+                if len(parts) == 5 and parts[0].isdigit() and pat.search(parts[4]):
+                    return float(parts[2]), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
     return None, None
 
 
@@ -186,6 +217,9 @@ def measure_roofline(step_fn, ms_per_step):
     out["traffic"] = traffic
     out["traffic_source"] = source
     out["event_overhead_us"] = round(1e3 * EVENT_OVERHEAD_MS[0], 2)      # (already subtracted per launch)
+    rp, rp_src = _rocprof_avg_us(name)
+    if rp is not None:           # the profiler's figure for the same kernel (another box, another run): both are reported
+        out["rocprof"] = {"avg_launch_us": rp, "frac": round(out["frac"] * out["avg_launch_us"] / rp, 4), "source": rp_src}
     total_ms = sum(v["ms"] for v in groups.values())
     out["kernels"] = [_group_roofline(k, v) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
                       if v["ms"] >= 0.02 * total_ms]
@@ -390,8 +424,36 @@ class H2DSource:
         self._issue()
 
 
+def measure_full_model(args):
+    """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
+    run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
+    loops have finished; the child is a new process, nothing is exec'ed over this one."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dense-head", "--com", "--gpus", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not line:
+            return {"error": f"child rc {out.returncode}: {out.stderr.decode()[-400:]}"}
+        r = json.loads(line[-1])
+        return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                "config": r["config"]["workload"], "com": r.get("com"), "child_wall_s": round(time.perf_counter() - t0, 1),
+                "what": "child run `bench.py --dense-head --com`: hot path + BaseBEVBackbone + CenterHead towers + COM "
+                        "curriculum targets / FocalLossCenterCurriculum / RegLoss, one hipGraph per step"}
+    except Exception as exc:                                  # never lose the headline
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     args = parse()
+    if args.com:
+        args.dense_head = True
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_self(args))             # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
@@ -409,25 +471,45 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_world1 = world == 1 and bool(os.environ.get("PCD_RCCL_WORLD1"))
     if world > 1:
         backend = os.environ.get("PCD_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm (gloo only for that validation)
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    elif rccl_world1:
+        # validation on a 1-GPU box: a real RCCL communicator of ONE rank; the N > 1 three-graph form then runs with the
+        # real dist.all_reduce of the flat bucket between the graph replays (sum over one rank = identity)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     B = args.batch
     torch.manual_seed(666 + (0 if args.same_shard else rank))   # cf. tools/train.py:86-87
     # frames sharded by rank with DistributedSampler striding (pcdet/datasets/__init__.py:65-72 ->
-    # com_amd.dist.shard_frames); two global batches alternate so consecutive steps do not see identical clouds
-    batches = []
-    for j in range(2):
-        ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
-        frames = [synth.synth_cloud(f) for f in ids]
-        pts, offs = hotpath.collate_points(frames, dev)      # resident in HBM before the timed region
-        offs_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
-        batches.append((pts, offs_dev))
+    # com_amd.dist.shard_frames); `--distinct-batches` (16) global batches of DISTINCT full 160k-point frames cycle
+    # through the timed loop: voxel / row counts differ from step to step (M = 80..87 k per frame), the static
+    # capacities are sized from the warm-up steps only, and a denser batch would trip the overflow guard
+    n_batches = max(2, args.distinct_batches)
+
+    def make_batches(drop=None):
+        out = []
+        for j in range(n_batches):
+            ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
+            frames = [synth.synth_cloud(f) for f in ids]
+            if drop is not None:                             # ragged variant: 0-20 % of every frame's rays are lost
+                frames = [f[:int(round(f.shape[0] * (1.0 - drop.uniform(0.0, 0.2))))] for f in frames]
+            pts, offs = hotpath.collate_points(frames, dev)  # resident in HBM before the timed region
+            out.append((pts, torch.tensor(offs, dtype=torch.int32, device=dev)))
+        return out
+
+    def pad_batches(bs, rows):
+        return [(torch.nn.functional.pad(p, (0, 0, 0, rows - p.shape[0])) if p.shape[0] < rows else p, o) for p, o in bs]
+
+    batches = make_batches()
     # the static graph reads ONE point buffer: batches are padded to a common row count (offsets say what is real)
     nmax = max(p.shape[0] for p, _ in batches)
-    batches = [(torch.nn.functional.pad(p, (0, 0, 0, nmax - p.shape[0])) if p.shape[0] < nmax else p, o)
-               for p, o in batches]
+    batches = pad_batches(batches, nmax)
 
     from com_amd.spconv import functional as Fsp
     # the side-stream weight-gradient chain is joined once, at the end of the backward pass (a lag >= the number of
@@ -447,6 +529,7 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
     bucket = cdist.FlatGradBucket(params)
+    bucket.force_collective = rccl_world1
     # ... and so do the parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step_v2) with
     # the reference's adam_onecycle rule: decoupled weight decay, betas (MOMS, 0.99), lr / momentum from the OneCycle
     # schedule (tools/train_utils/optimization/__init__.py:19-32,53-56; centerpoint.yaml:81-96), GRAD_NORM_CLIP 10
@@ -456,20 +539,9 @@ def main():
     opt = cdist.FlatAdam(bucket, lr=lr0, betas=(mom0, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0,
                          world=world, decoupled=True)
     it_count = [0]
+    # stand-in for the dense head when only the hot path is timed: loss = <spatial_features, fixed random tensor>
+    # (ops.LinearFunctionalLoss: pcd_dot_bf16 forward, pcd_scale_bf16 backward -- 2 + 1 HIP launches)
     loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
-
-    class ProjectionLoss(torch.autograd.Function):
-        """Stand-in for the dense head: loss = <spatial_features, fixed random tensor> (fp32 sum); its gradient
-        is that tensor times the upstream scalar -- one elementwise kernel, no autograd temporaries."""
-
-        @staticmethod
-        def forward(ctx, sf):
-            ctx.shape = sf.shape
-            return torch.sum(sf.reshape(-1) * loss_w, dtype=torch.float32)
-
-        @staticmethod
-        def backward(ctx, g):
-            return (loss_w * g.to(loss_w.dtype)).view(ctx.shape)
 
     last = {}
     CLASS_NAMES = ['Vehicle', 'Pedestrian', 'Cyclist']
@@ -481,7 +553,7 @@ def main():
                              cls_weight=1.0, loc_weight=2.0).to(dev)                        # centerpoint.yaml:52-58
         from com_amd.hotpath import conv2d_fast
         conv_packs = conv2d_fast.Conv3x3Packs(model)       # all dense 3x3 weight packs in one launch per step
-        rs = np.random.default_rng(1234 + rank)
+        rs = np.random.default_rng(1234 + (0 if args.same_shard else rank))
         gtb = np.zeros((B, 96, 8), np.float32)             # [x, y, z, dx, dy, dz, heading, class], 0 = padding
         for b in range(B):
             n = int(rs.integers(40, 90))
@@ -494,6 +566,20 @@ def main():
             gtb[b, :n, 6] = rs.uniform(-np.pi, np.pi, n)
             gtb[b, :n, 7] = cls
         gt_boxes = torch.from_numpy(gtb).to(dev)
+        if args.com:
+            # BASELINE config 3: CurriculumCenterHead_x5 (head_zoo.py:145-149) on the voxel backbone's stride-8 map, the
+            # LOSS_CURRICULUM of tools/cfgs/waymo_models/com/centercurriculum_pillar_3cls_b2_com.yaml:168-173 (UCL False,
+            # FIX True) unless --com-ucl; per-object attributes COMAug's dataloader provides, synthetic here
+            from com_amd.hotpath import com_head
+            com_cur = dict(UCL=bool(args.com_ucl), THRESHOLD=0.2, ELONGATION=-10, HEIGHT=1, FIX=True)
+            head_loss = com_head.CurriculumCenterHeadLoss(dense2d.CENTERPOINT_HEAD['SEPARATE_HEAD_CFG']['HEAD_ORDER'],
+                                                          com_cur, conf_shape=(3, 96), cls_weight=1.0, loc_weight=2.0).to(dev)
+            valid = gtb[..., 7] > 0
+            com_npgt = torch.from_numpy(np.where(valid, rs.integers(1, 400, valid.shape), 0).astype(np.float32)).to(dev)
+            com_true = torch.from_numpy(np.where(valid, rs.choice([1, 1, 1, 2], valid.shape), 0).astype(np.float32)).to(dev)
+            com_occ = torch.from_numpy(np.where(valid, rs.random(valid.shape), 0).astype(np.float32)).to(dev)
+            com_facade = torch.from_numpy(np.where(valid, rs.integers(0, 4, valid.shape), 0).astype(np.float32)).to(dev)
+            com_epoch = 5
 
     def voxelize(pts, offs, out=None):
         """hard voxelisation + fused MeanVFE of one batch (what the reference's DataLoader workers do on the CPU)"""
@@ -520,13 +606,21 @@ def main():
             # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
             # and get_loss = focal(hm) + L1(boxes) (center_head.py:163-262) without its host round trips
             preds = model.dense_head(model.backbone_2d(bd))["pred_dicts"]
-            tg = targets.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
-                                        synth.WAYMO_VOXEL, 8, num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
-            loss, _ = head_loss(preds, tg)
+            if args.com:
+                # CurriculumCenterHead.forward / get_loss (curriculum_center_head.py:461-487,313-358) on the device
+                group = com_head.cluster(gt_boxes, com_true, com_occ, com_facade)
+                tg = com_head.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
+                                             synth.WAYMO_VOXEL, 8, com_npgt, true_object=group, num_max_objs=500,
+                                             gaussian_overlap=0.1, min_radius=2, epoch=com_epoch, epoch_threshold=100,
+                                             min_points=0)
+                loss, _ = head_loss(preds, tg, epoch=com_epoch)
+            else:
+                tg = targets.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
+                                            synth.WAYMO_VOXEL, 8, num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
+                loss, _ = head_loss(preds, tg)
         else:
-            # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense
-            # gradient; rocBLAS dot is not graph-capturable, hence mul + sum)
-            loss = ProjectionLoss.apply(bd["spatial_features"])
+            # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense gradient)
+            loss = ops.LinearFunctionalLoss.apply(bd["spatial_features"], loss_w)
         if ev is not None: ev("backward")
         try:
             loss.backward()
@@ -610,7 +704,7 @@ def main():
         # DataLoader workers, asynchronously to the training step); it owns its memory pool because it runs
         # concurrently with the optimizer graph.  Every timed step still contains exactly one voxelisation.
         vox_stream = torch.cuda.Stream()
-        if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH'):   # (the switch exercises the N > 1 form on one GPU)
+        if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1:   # (the switches exercise the N > 1 form on one GPU)
             # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
             # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
             # first).  Two graph boundaries per step less than the N > 1 form.
@@ -690,6 +784,7 @@ def main():
         return time.perf_counter() - t0, host_issue
 
     run_step = eager_step
+    recaptures = [0]
     if use_graph:
         try:
             for attempt in range(3):
@@ -703,6 +798,7 @@ def main():
                 # a batch denser than the observed ones: larger capacities, capture again (the truncated step's
                 # parameters were never used for a measurement)
                 print("[bench] static capacity overflow: re-capturing with larger buffers", file=sys.stderr)
+                recaptures[0] += 1
                 plan.active = False
                 plan.grow(1.5)
             plan.check()
@@ -771,6 +867,49 @@ def main():
         except Exception as exc:
             print(f"[bench] H2D-inclusive loop failed ({type(exc).__name__}: {exc})", file=sys.stderr)
             torch.cuda.synchronize()
+    # secondary figure: frames that lost 0-20 % of their rays (every frame a different fraction): row counts vary by up
+    # to 20 % from step to step under the SAME captured graph / capacities; a capacity overflow (sticky device flag)
+    # re-captures with larger buffers and is counted
+    ragged = None
+    if not args.no_ragged:
+        try:
+            rb = pad_batches(make_batches(np.random.default_rng(4242 + rank)), nmax)
+            rsrc = ResidentSource(rb)
+            el = None
+            for attempt in range(3):
+                try:
+                    el, _ = timed_loop(run_step, args.steps, rsrc, use_graph)
+                    if use_graph:
+                        plan.check()
+                    break
+                except ops.L.PcdError:
+                    recaptures[0] += 1
+                    plan.active = False
+                    plan.grow(1.5)
+                    run_step = build_graphs()
+            if el is not None:
+                el = cdist.max_over_ranks(el, dev)
+                real = [int(o[-1].item()) for _, o in rb]
+                ragged = {"value": round(world * B * args.steps / el, 3), "unit": "frames/s",
+                          "ms_per_step": round(1e3 * el / max(args.steps, 1), 4),
+                          "points_per_batch_min_max": [min(real), max(real)],
+                          "what": "same captured step over batches whose frames lost 0-20 % of their rays (variable row "
+                                  "counts under static capacities); NOT the headline workload"}
+        except Exception as exc:
+            print(f"[bench] ragged loop failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            torch.cuda.synchronize()
+    com_report = None
+    if args.com:
+        # COM's per-epoch exchange (train_utils.py:269-287): all_gather of the (3, 96) epoch sums -> what COMAug's sampler gets
+        torch.cuda.synchronize()
+        st_ = head_loss.hm_loss_func
+        conf = cdist.gather_group_confidence(st_.epoch_confidence, st_.epoch_num)
+        com_report = {"head": "CurriculumCenterHead_x5 (conf_shape (3, 96)), LOSS_CURRICULUM " + json.dumps(com_cur),
+                      "groups_seen": int((st_.epoch_num > 0).sum().item()),
+                      "objects_counted": float(st_.epoch_num.sum().item()),
+                      "avg_confidence_ema": round(st_.avg_confidence, 6),
+                      "confidence_groups_mean": round(float(conf[conf > 0].mean()) if (conf > 0).any() else 0.0, 6),
+                      "epoch_gather": "all_gather of 2 x (3, 96) float32 over " + ("RCCL" if world > 1 else "1 rank (no process group)")}
     if use_graph:
         plan.active = False                                  # the instrumented steps below run eagerly
 
@@ -793,6 +932,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
         "config": {"workload": "CenterPoint-VoxelNet hot path (hard voxelize+MeanVFE -> VoxelResBackBone8x fwd+bwd -> "
                                "HeightCompression fwd+bwd -> grad all-reduce -> clip -> Adam), Waymo-shaped 160k-pt "
@@ -800,12 +940,22 @@ def main():
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
                    "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
                    "optimizer": "adam_onecycle (decoupled wd 0.01, betas (OneCycle MOMS, 0.99), clip 10)",
-                   "dense_head": bool(args.dense_head),
-                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH')) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
+                   "dense_head": bool(args.dense_head), "com_head": bool(args.com),
+                   "distinct_batches": n_batches, "recaptures": recaptures[0],
+                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
                                 if use_graph else "eager launches"},
     }
     if h2d is not None:
         result["h2d_inclusive"] = h2d
+    if ragged is not None:
+        result["ragged"] = ragged
+    if com_report is not None:
+        result["com"] = com_report
+    if args.dense_head:
+        result["config"]["workload"] = ("FULL CenterPoint-VoxelNet step (hot path + BaseBEVBackbone + CenterHead towers + "
+                                        + ("COM curriculum head: cluster / radius_map targets / FocalLossCenterCurriculum"
+                                           if args.com else "CenterHead targets / focal + L1 losses")
+                                        + "), Waymo-shaped 160k-pt synthetic clouds")
 
     if not args.no_roofline:
         roof = measure_roofline(lambda: eager_step(0), ms_per_step)   # every rank runs the extra step (collectives inside)
@@ -813,10 +963,14 @@ def main():
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_full_model and not args.dense_head:
+        torch.cuda.synchronize()
+        result["full_model"] = measure_full_model(args)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -103,6 +103,9 @@ PROTOTYPES = {
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
                                    _vp, _vp, _vp, _sz, _vp]),
     "pcd_stream_capture_id": (_i, [_vp, _vp]),
+    "pcd_dot_bf16_workspace_bytes": (_sz, []),
+    "pcd_dot_bf16": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "pcd_scale_bf16": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "pcd_static_overflow_check": (_i, [_vp, _i, _vp, _vp]),
     "pcd_com_cluster_groups": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pcd_com_assign_workspace_bytes": (_sz, [_i, _i]),

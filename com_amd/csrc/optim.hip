@@ -92,6 +92,59 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
 
 __global__ void step_inc_kernel(float *step_dev) { step_dev[0] += 1.0f; }
 
+// <a, b> of two bf16 vectors (fp32 products, double partial sums) and y = a * s[0]: the forward / backward of a linear
+// functional of the BEV map (bench.py's stand-in for the dense head's loss when only the sparse hot path is timed) in
+// 2 + 1 launches instead of torch's cast / mul / sum chain.
+constexpr int DOT_BLOCKS = 512;
+__global__ __launch_bounds__(256) void dot_bf16_partials_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b,
+                                                                size_t n8, double *__restrict__ partial) {
+    __shared__ double lds[4];
+    float acc = 0.0f;
+    double s = 0.0;
+    int k = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)DOT_BLOCKS * 256) {
+        const uint4 va = a[i], vb = b[i];
+        const u32 wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc += __uint_as_float(wa[j] << 16) * __uint_as_float(wb[j] << 16);
+            acc += __uint_as_float(wa[j] & 0xffff0000u) * __uint_as_float(wb[j] & 0xffff0000u);
+        }
+        if (++k == 16) {                     // spill the fp32 run into the double sum every 128 products
+            s += (double)acc;
+            acc = 0.0f;
+            k = 0;
+        }
+    }
+    s += (double)acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+__global__ __launch_bounds__(64) void dot_finalize_kernel(const double *__restrict__ partial, float *__restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < DOT_BLOCKS; i += 64) s += partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+__global__ __launch_bounds__(256) void scale_bf16_kernel(const uint4 *__restrict__ a, const float *__restrict__ sc,
+                                                         size_t n8, uint4 *__restrict__ y) {
+    const float s = sc[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 va = a[i];
+        const u32 w[4] = {va.x, va.y, va.z, va.w};
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (u32)f32_to_bf16_bits(__uint_as_float(w[j] << 16) * s) |
+                   ((u32)f32_to_bf16_bits(__uint_as_float(w[j] & 0xffff0000u) * s) << 16);
+        y[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // device clock (100 MHz, shared by all queues) into slot[0]: time points INSIDE a replayed hipGraph, where neither
 // events nor the profiler (which changes how the graph is scheduled) can be used
 __global__ void stamp_kernel(unsigned long long *slot) { slot[0] = wall_clock64(); }
@@ -171,6 +224,31 @@ extern "C" int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp
                                              beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev,
                                              schedule_dev, schedule_len);
     step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_dot_bf16_workspace_bytes(void) { return ws_piece(DOT_BLOCKS, sizeof(double)); }
+
+extern "C" int pcd_dot_bf16(const void *a, const void *b, size_t n, float *out, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    PCD_ENTER();
+    if (!a || !b || !out || (n & 7) != 0 || ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) != 0) return PCD_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < pcd_dot_bf16_workspace_bytes()) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    dot_bf16_partials_kernel<<<DOT_BLOCKS, 256, 0, st>>>((const uint4 *)a, (const uint4 *)b, n / 8, (double *)workspace);
+    dot_finalize_kernel<<<1, 64, 0, st>>>((const double *)workspace, out);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_scale_bf16(const void *a, const float *scale_dev, size_t n, void *y, void *stream) {
+    PCD_ENTER();
+    if (!a || !y || !scale_dev || (n & 7) != 0 || ((((uintptr_t)a) | ((uintptr_t)y)) & 15u) != 0) return PCD_ERR_INVALID_ARG;
+    if (n == 0) return PCD_OK;
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    scale_bf16_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)a, scale_dev, n / 8, (uint4 *)y);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

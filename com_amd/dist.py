@@ -37,6 +37,7 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.numel = n
+        self.force_collective = False      # run the all-reduce even in a 1-rank group (exercises RCCL on a 1-GPU box)
         self.flat = torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=dev)   # padded for 16-byte kernels
         off = 0
         for p in self.params:
@@ -76,7 +77,7 @@ class FlatGradBucket:
 
     def all_reduce_sum(self):
         """Gradient SUM over the ranks (one collective); pair with clip_divisor_(..., pre_divisor=world_size)."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat
 
@@ -215,6 +216,8 @@ def gather_group_confidence(conf_epoch, num_epoch):
     out = []
     for t in (conf_epoch, num_epoch):
         t = t.contiguous()
+        if dist.get_backend() == "gloo":
+            t = t.cpu()                                   # (CPU tests / one-GPU validation runs)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         acc = np.zeros(tuple(t.shape), np.float32)
@@ -239,12 +242,26 @@ def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):
             s.bind(("127.0.0.1", 0))
             master_port = s.getsockname()[1]
     procs = []
+    # per-rank CPU affinity: the host cores are dealt to the ranks in contiguous blocks (rank r launches and polls from
+    # its own cores; with 8 ranks on one node the launch threads otherwise migrate across sockets); PCD_NO_AFFINITY=1 skips
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = []
+    per = len(cores) // n if (cores and not os.environ.get("PCD_NO_AFFINITY")) else 0
+
+    def pin(r):
+        if per < 1:
+            return None
+        mine = set(cores[r * per:(r + 1) * per])
+        return lambda: os.sched_setaffinity(0, mine)
+
     for r in range(n):
         e = dict(os.environ if env is None else env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(master_port)})
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr, preexec_fn=pin(r)))
     t0 = time.time()
     codes = [None] * n
     try:

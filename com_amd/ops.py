@@ -901,6 +901,34 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     return dw
 
 
+class LinearFunctionalLoss(torch.autograd.Function):
+    """loss = <x, w> for a bf16 map x and a fixed bf16 tensor w (fp32 products, fp64 partial sums): pcd_dot_bf16 forward,
+    pcd_scale_bf16 backward -- 2 + 1 launches.  bench.py's stand-in for the dense head when only the sparse hot path is
+    timed (a dense, non-trivial gradient for every BEV cell)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _require_cuda(x, w)
+        assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.numel() == w.numel() and x.numel() % 8 == 0
+        assert x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)
+        lib = L.lib()
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(lib.pcd_dot_bf16_workspace_bytes()),), dtype=torch.uint8, device=x.device)
+        L.check(lib.pcd_dot_bf16(L.ptr(x), L.ptr(w), x.numel(), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "pcd_dot_bf16")
+        ctx.save_for_backward(w)
+        ctx.like = x
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        gx = torch.empty_like(ctx.like)                    # (same memory layout as x: w pairs with x's storage order)
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        L.check(L.lib().pcd_scale_bf16(L.ptr(w), L.ptr(gs), w.numel(), L.ptr(gx), L.stream_ptr()), "pcd_scale_bf16")
+        return gx, None
+
+
 def conv2d_pack_weight(weight, mode=0):
     """nn.Conv2d weight [cout, cin, 3, 3] f32 -> MFMA fragment order (mode 0: forward, 1: data gradient); the output
     channels are zero-padded to a multiple of 32 (run the conv with that count)."""

@@ -727,6 +727,13 @@ int pcd_conv2d_pack_weights_batched(const void *table, int n, int total_blocks, 
 int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w, int cout,
                         const float *bias, void *y, void *stream);
 
+/* <a, b> of two bf16 vectors (fp32 products, fp64 partial sums) -> out[0], and y = bf16(a * scale_dev[0]): forward and
+ * backward of a fixed linear functional of the BEV map -- bench.py's stand-in for the dense head's loss when only the
+ * sparse hot path is timed (no reference counterpart).  n % 8 == 0, 16-byte aligned. */
+size_t pcd_dot_bf16_workspace_bytes(void);
+int pcd_dot_bf16(const void *a, const void *b, size_t n, float *out, void *workspace, size_t workspace_bytes, void *stream);
+int pcd_scale_bf16(const void *a, const float *scale_dev, size_t n, void *y, void *stream);
+
 /* Diagnostics: the device clock (100 MHz) into slot[0] at this point of the stream -- a time point inside a replayed
  * hipGraph, which events cannot give and a profiler perturbs (tools/exp_stamps.py).  No reference counterpart. */
 int pcd_debug_stamp(uint64_t *slot, void *stream);

@@ -161,3 +161,55 @@ def test_one_cycle_schedule_matches_reference_fixture(golden):
     np.testing.assert_allclose(mine[:, 0], g["lr"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(mine[:, 1], g["mom"], rtol=1e-12, atol=0)
     assert mine[0, 1] == 0.95 and abs(mine[0, 0] - 3e-4) < 1e-15   # MOMS[0], LR / DIV_FACTOR
+
+
+def _gather_worker(rank, world, port, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from com_amd import dist as cdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_com_epoch_gather.npz"))
+    conf = torch.zeros(3, 96)
+    num = torch.zeros(3, 96)
+    for s in range(g["conf"].shape[1]):                      # what the loss kernel does per step: += in float32
+        conf += torch.from_numpy(g["conf"][rank, s])
+        num += torch.from_numpy(g["num"][rank, s])
+    out = cdist.gather_group_confidence(conf, num)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_com_epoch_gather_two_ranks_matches_reference_arithmetic_g14():
+    """COM's per-epoch (3, 96) all_gather (tools/train_utils/train_utils.py:269-287) over a world-size-2 gloo group:
+    every rank ends with exactly the array the reference's arithmetic gives (fixture G14), float32."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_com_epoch_gather.npz"))
+    for r in range(2):
+        assert got[r].dtype == np.float32
+        np.testing.assert_array_equal(got[r], g["result"])
+
+
+def test_com_epoch_gather_without_a_process_group_g14():
+    import numpy as np
+    import torch
+    from com_amd import dist as cdist
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_com_epoch_gather.npz"))
+    conf = sum(torch.from_numpy(g["conf"][0, s]) for s in range(g["conf"].shape[1]))
+    num = sum(torch.from_numpy(g["num"][0, s]) for s in range(g["num"].shape[1]))
+    np.testing.assert_array_equal(cdist.gather_group_confidence(conf, num), g["single_rank0"])

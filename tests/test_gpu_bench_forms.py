@@ -22,12 +22,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(tmp_path, tag, args, env=None):
     e = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCD_FORCE_3GRAPH", "PCD_DIST_ONE_GPU",
-              "PCD_DIST_BACKEND"):
+              "PCD_DIST_BACKEND", "PCD_RCCL_WORLD1"):
         e.pop(k, None)
     e.update(env or {})
     dump = tmp_path / f"{tag}.json"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "2",
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--same-shard", "--dump-state", str(dump)] + args
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--distinct-batches", "3",
+           "--same-shard", "--dump-state", str(dump)] + args
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -48,4 +49,28 @@ def test_one_graph_three_graph_and_two_rank_forms_are_bit_identical(tmp_path):
     assert res2["config"]["global_batch"] == 4 and res2["config"]["parallelism"] == "dp2"
     assert st2["world"] == 2
     # bucket.flat holds the rank SUM at N = 2: compare the parameters (which used sum / world) bit for bit
+    assert st2["param_sha256"] == st1["param_sha256"], (st1, st2)
+
+
+@pytest.mark.timeout(1800)
+def test_rccl_communicator_runs_the_three_graph_form_on_one_gpu(tmp_path):
+    """backend="nccl" (= RCCL) must have executed on hardware before an 8-GPU run depends on it: a ONE-rank RCCL
+    communicator, the N > 1 three-graph form, the real dist.all_reduce of the flat gradient bucket between the graph
+    replays.  A sum over one rank is the identity, so the parameters must equal the one-graph run bit for bit."""
+    res1, st1 = _bench(tmp_path, "one_graph_b", ["--gpus", "1"])
+    resr, str_ = _bench(tmp_path, "rccl_world1", ["--gpus", "1"], env={"PCD_RCCL_WORLD1": "1"})
+    assert resr["collective_backend"] == "nccl" and "voxelise [prefetched" in resr["config"]["execution"]
+    assert str_["param_sha256"] == st1["param_sha256"], (st1, str_)
+
+
+@pytest.mark.timeout(2400)
+def test_com_full_model_forms_are_bit_identical(tmp_path):
+    """BASELINE config 3 as bench.py composes it (`--dense-head --com`: hot path + BaseBEVBackbone + CenterHead towers +
+    COM curriculum targets / FocalLossCenterCurriculum, all inside the captured step): one-graph form == two ranks with
+    identical shards (gloo on one GPU), incl. the (3, 96) epoch all_gather behind the timed loop."""
+    args = ["--dense-head", "--com"]
+    res1, st1 = _bench(tmp_path, "com_one", ["--gpus", "1"] + args)
+    assert res1["config"]["com_head"] and res1["com"]["groups_seen"] > 10 and res1["com"]["objects_counted"] > 0
+    res2, st2 = _bench(tmp_path, "com_two", ["--gpus", "2"] + args, env={"PCD_DIST_ONE_GPU": "1", "PCD_DIST_BACKEND": "gloo"})
+    assert res2["n_gpus"] == 2 and res2["com"]["groups_seen"] == res1["com"]["groups_seen"]
     assert st2["param_sha256"] == st1["param_sha256"], (st1, st2)
