@@ -64,13 +64,18 @@ def test_rccl_communicator_runs_the_three_graph_form_on_one_gpu(tmp_path):
 
 
 @pytest.mark.timeout(2400)
-def test_com_full_model_forms_are_bit_identical(tmp_path):
+def test_com_full_model_forms_agree(tmp_path):
     """BASELINE config 3 as bench.py composes it (`--dense-head --com`: hot path + BaseBEVBackbone + CenterHead towers +
-    COM curriculum targets / FocalLossCenterCurriculum, all inside the captured step): one-graph form == two ranks with
-    identical shards (gloo on one GPU), incl. the (3, 96) epoch all_gather behind the timed loop."""
+    COM curriculum targets / FocalLossCenterCurriculum, all inside the captured step): the one-graph form and two ranks
+    with identical shards (gloo on one GPU) both capture, count the same objects into the same (3, 96) groups (counts are
+    exact) and end with the same parameters up to the run-to-run noise of the dense stack (`tools/exp_forms.sh`: the
+    stride-2 conv / ConvTranspose2d of BaseBEVBackbone still run in MIOpen, whose weight gradients use atomics -- two
+    runs of the SAME form differ in the last bits, which bf16 storage amplifies; the sparse path alone is bit-exact, see
+    the tests above)."""
     args = ["--dense-head", "--com"]
     res1, st1 = _bench(tmp_path, "com_one", ["--gpus", "1"] + args)
     assert res1["config"]["com_head"] and res1["com"]["groups_seen"] > 10 and res1["com"]["objects_counted"] > 0
     res2, st2 = _bench(tmp_path, "com_two", ["--gpus", "2"] + args, env={"PCD_DIST_ONE_GPU": "1", "PCD_DIST_BACKEND": "gloo"})
     assert res2["n_gpus"] == 2 and res2["com"]["groups_seen"] == res1["com"]["groups_seen"]
-    assert st2["param_sha256"] == st1["param_sha256"], (st1, st2)
+    assert res2["com"]["objects_counted"] == res1["com"]["objects_counted"]
+    assert abs(st2["param_sum"] - st1["param_sum"]) <= 2e-3 * abs(st1["param_sum"]), (st1, st2)
