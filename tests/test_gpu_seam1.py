@@ -1,0 +1,77 @@
+"""GPU: import seam 1 alone.  A backbone written like a stock model file (tools/seam1_model.py: only `spconv.*` names,
+torch BatchNorm1d / ReLU / residual add on `.features` through replace_feature, fp32 features) must compute what the
+fused `com_amd.hotpath.VoxelResBackBone8x` computes from the same state dict: taps and parameter gradients agree to the
+bf16-storage noise between an fp32-feature chain and a bf16-feature chain (relative L2; bounds below), indices bit-exact.
+Also prints the eager forward+backward time of both (INTEGRATION.md quotes the numbers)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from com_amd import hotpath, ops
+from com_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_stock_model_file_over_seam1_matches_the_fused_backbone():
+    import seam1_model as S
+    dev = "cuda"
+    torch.manual_seed(3)
+    frames = [synth.synth_cloud(f, 32, 1250) for f in range(2)]                 # 2 x 40k points
+    pts, offs = hotpath.collate_points(frames, dev)
+    bd0 = hotpath.transform_points_to_voxels({"points": pts, "frame_offsets": offs, "batch_size": 2}, synth.WAYMO_RANGE,
+                                             synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS,
+                                             fuse_mean=True)
+    grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+    fused = hotpath.VoxelResBackBone8x({}, 5, grid).to(dev).train()
+    stock = S.StockVoxelResBackBone8x(5, grid).to(dev).train()
+    missing = stock.load_state_dict(fused.state_dict(), strict=True)            # same names, same layouts
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+    def run(model):
+        for p in model.parameters():
+            p.grad = None
+        bd = model({"voxel_features": bd0["voxel_features"], "voxel_coords": bd0["voxel_coords"], "batch_size": 2})
+        out = bd["encoded_spconv_tensor"]
+        w = torch.linspace(-1, 1, out.features.shape[1], device=dev)
+        (out.features.float() * w).mean().backward()
+        from com_amd.spconv import functional as Fsp
+        Fsp.join_deferred_wgrad()
+        return bd
+
+    bf, bs = run(fused), run(stock)
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        a, b = bs["multi_scale_3d_features"][k], bf["multi_scale_3d_features"][k]
+        assert torch.equal(a.indices, b.indices)
+        assert _rel(a.features, b.features) < 3e-2, (k, _rel(a.features, b.features))
+    assert torch.equal(bs["encoded_spconv_tensor"].indices, bf["encoded_spconv_tensor"].indices)
+    assert _rel(bs["encoded_spconv_tensor"].features, bf["encoded_spconv_tensor"].features) < 4e-2
+    worst = 0.0
+    for (n, p), (_, q) in zip(stock.named_parameters(), fused.named_parameters()):
+        if p.grad is None or q.grad is None or float(q.grad.norm()) == 0:
+            continue
+        if n.endswith(("conv1.bias", "conv2.bias")):
+            continue          # a conv bias in front of a BatchNorm has a mathematically ZERO gradient: rounding noise on both sides
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.flatten().float(), q.grad.flatten().float(), dim=0))
+        worst = max(worst, 1 - cos)
+        assert cos > 0.8, (n, cos)
+    # timing (eager; informational)
+    for name, model in (("fused", fused), ("stock", stock)):
+        for _ in range(2):
+            run(model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run(model)
+        torch.cuda.synchronize()
+        print(f"[seam1] {name}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms fwd+bwd (2 x 40k points, eager)")
