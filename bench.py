@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--com-ucl", action="store_true", help="with --com: LOSS_CURRICULUM.UCL = True (per-object weights)")
     ap.add_argument("--distinct-batches", type=int, default=16, help="distinct global batches the timed loop cycles through")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary loop over frames with 0-20 %% ray drop-out")
+    ap.add_argument("--no-stage2", action="store_true", help="skip the PV-RCNN stage-2 (config 4) secondary figure")
     ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU plumbing test of the launcher / result assembly: gloo ranks, no GPU work")
@@ -424,6 +425,70 @@ class H2DSource:
         self._issue()
 
 
+def measure_stage2(B, dev):
+    """`stage2` (BASELINE config 4 as a workload): PV-RCNN's second stage over the hot path's outputs at the sizes of
+    pv_rcnn.yaml:87-118,161-166 -- VoxelBackBone8x on the same B x 160k-point frames, then (timed) farthest point sampling
+    of 4096 keypoints per frame, ball-query set abstraction over raw points / x_conv3 / x_conv4 + BEV interpolation, and
+    RoI-grid pooling for 128 RoIs x 6^3 grid points per frame (com_amd.hotpath.pvrcnn_stage2 over the HIP natives of
+    com_amd.pointnet2_stack; tests/test_gpu_stage2.py checks every index tensor against the oracle at this size)."""
+    from com_amd.hotpath import pvrcnn_stage2 as S2
+    try:
+        frames = [synth.synth_cloud(f) for f in range(B)]
+        pts, offs = hotpath.collate_points(frames, dev)
+        bd = hotpath.transform_points_to_voxels({"points": pts, "frame_offsets": offs, "batch_size": B}, synth.WAYMO_RANGE,
+                                                synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS,
+                                                fuse_mean=True)
+        grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+        backbone = hotpath.VoxelBackBone8x({}, 5, grid).to(dev).eval()
+        to_bev = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256})
+        vsa = S2.VoxelSetAbstraction(synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 256, 5, backbone.backbone_channels).to(dev).eval()
+        pool = S2.RoIGridPool(vsa.num_point_features).to(dev).eval()
+        rs = np.random.default_rng(7)
+        rois = np.zeros((B, 128, 7), np.float32)
+        rois[..., 0:2] = rs.uniform(-60, 60, (B, 128, 2))
+        rois[..., 2] = rs.uniform(-0.5, 1.5, (B, 128))
+        rois[..., 3:6] = np.stack([rs.uniform(0.6, 10, (B, 128)), rs.uniform(0.5, 2.8, (B, 128)), rs.uniform(1, 3, (B, 128))], -1)
+        rois[..., 6] = rs.uniform(-np.pi, np.pi, (B, 128))
+        with torch.no_grad():
+            bd = to_bev(backbone(bd))
+            keep = ((pts[:, 1] >= synth.WAYMO_RANGE[0]) & (pts[:, 1] <= synth.WAYMO_RANGE[3]) &
+                    (pts[:, 2] >= synth.WAYMO_RANGE[1]) & (pts[:, 2] <= synth.WAYMO_RANGE[4]))
+            bd["points"] = pts[keep].contiguous()
+            bd["point_frame_counts"] = torch.bincount(bd["points"][:, 0].long(), minlength=B).to(torch.int32)
+            bd["spatial_features_stride"] = 8
+            bd["rois"] = torch.from_numpy(rois).to(dev)
+            scores = None
+
+            def run():
+                nonlocal scores
+                out = vsa(bd)
+                if scores is None:
+                    scores = torch.sigmoid(torch.randn(out["point_features"].shape[0], device=dev))
+                out["point_cls_scores"] = scores
+                return pool(out)
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / n
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            S2.sample_keypoints(bd["points"], bd["point_frame_counts"], 4096)
+            e1.record()
+            torch.cuda.synchronize()
+        return {"ms_per_batch": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "frames": B,
+                "fps_4096_keypoints_ms": round(e0.elapsed_time(e1), 3),
+                "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points + set abstraction over "
+                        "raw points, x_conv3, x_conv4 + BEV + RoI-grid pooling 128 RoIs x 216 points/frame; the "
+                        "sequential FPS (4095 dependent iterations over 160k points) dominates"}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def measure_full_model(args):
     """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
     run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
@@ -431,7 +496,7 @@ def measure_full_model(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--dense-head", "--com", "--gpus", "1", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model"]
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -973,6 +1038,8 @@ def main():
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_stage2 and not args.dense_head:
+        result["stage2"] = measure_stage2(B, dev)
     if rank == 0 and world == 1 and not args.no_full_model and not args.dense_head:
         torch.cuda.synchronize()
         result["full_model"] = measure_full_model(args)
