@@ -1012,6 +1012,312 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
 }
 
 // ---------------------------------------------------------------------------------------------
+// WINDOW gather-GEMM for SubM 3x3x3 layers with C_in = 64 over KEY-ORDERED rows (rows numbered by ascending (b, z, y, x),
+// which every level of the hot path is): the inputs a tile of consecutive output rows needs at the 9 offsets that share
+// dz are (almost always) ONE contiguous run of input rows -- the lines (z + dz, y - 1 .. y + 1) are neighbours in row
+// space -- about 1.2-1.5 x the tile.  So instead of 27 gathers per output row (27 x 128 B through the texture-address
+// unit, the bound of gather_gemm_kernel / ggw_kernel) the loader waves DMA three WINDOWS of contiguous rows into LDS once
+// per tile (coalesced 1-KiB instructions, 1.75 x ROWS rows each, XOR-swizzled like ggw's gather image) and the consumers
+// address their MFMA operands through the rulebook tile: operand row = nbr - window_lo.  A missing neighbour reads a
+// zero row; a neighbour outside its window (rows of a tile that straddles a frame / z boundary, very long lines) is
+// loaded straight from global memory by the lanes concerned (exec-masked, rare).  Weights stream through the same ring
+// of stages as in ggw_kernel -- they are now the larger part of the DMA traffic.
+// Same operands, same MFMA sequence per output element (offsets ascending) as the other two kernels -> bit-identical.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NB, int MI, int R, bool OUT_BF16>
+__global__ __launch_bounds__(512, (MI == 1 ? 4 : 1)) void ggwin_kernel(
+    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
+    int n_in, void *__restrict__ yv, unsigned x_bytes, unsigned w_bytes, const void *__restrict__ addend, BnRed bn,
+    int dbg) {
+    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
+    constexpr int K = 27, GRP = 9;
+    constexpr int ROWS = 64 * MI;
+    constexpr int WCAP = (ROWS * 3 / 2 + 31) / 32 * 32;    // window rows (multiple of 4 loaders x 8 rows)
+    constexpr int WIN_B = WCAP * 128;                      // bytes per window
+    constexpr int WINI = WCAP / 32;                        // window DMA instructions per loader and window
+    constexpr int WFR = 2 * NB;                            // 1-KiB weight fragments per stage
+    constexpr int WPW = WFR / 4;                           // ... per loader
+    constexpr int W_STAGE = WFR * 1024;
+    constexpr int c_out = NB * 16;
+    static_assert(R % 2 == 0 && (R - 2) * WPW < 64, "ring depth: even (slot parity = operand register set), vmcnt field");
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *wring = smem;                                    // [R][W_STAGE]
+    char *win = smem + R * W_STAGE;                        // [3][WCAP][128 B]
+    char *zero_row = win + 3 * WIN_B;                      // 128 B of zeros (missing neighbours)
+    int *nbr_s = (int *)(zero_row + 128);                  // [K + 1][ROWS]
+    int *bounds = nbr_s + (K + 1) * ROWS;                  // [3] window lo
+    float *red_s = (float *)(bounds + 8);                  // [4][2][c_out], only with bn.mode
+
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    const int tile = xcd_tile(n_out, ROWS);
+    const int r0wg = tile * ROWS;
+    if (r0wg >= n_out) {
+        if (bn.mode) bnred_zero_row(bn, tile, c_out);
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
+    const int wrow0 = wave * (MI * 16);
+    constexpr int T = K;                                   // stages (one per offset: C_in = 64 = 2 contraction steps)
+    constexpr int NIT = (T + R - 1) / R * R;               // steps of both roles (stages >= T are no-ops)
+
+    if (loader) {
+        // ------------------------------------------------------------------------------------------- loader
+        if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
+        auto fire = [&](int stage, auto slot_tag) {
+            constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+            for (int f = 0; f < WPW; ++f) {
+                const int frag = wave + 4 * f;
+                const unsigned off = (stage < T && !(dbg & 2))
+                                         ? (unsigned)stage * (unsigned)W_STAGE + (unsigned)lane * 16u + (unsigned)frag * 1024u
+                                         : 0xFFFFFFF0u;
+                glds16(wrsrc, wring + SLOT * W_STAGE + frag * 1024, off);
+            }
+        };
+        // the weights of the first R - 1 stages go out at once: they need nothing from the rulebook tile and their
+        // memory latency then runs beside the consumers' staging of that tile
+        static_for<0, R - 1>([&](auto j) { fire(decltype(j)::value, j); });
+        if (threadIdx.x >= 256 && threadIdx.x < 288) reinterpret_cast<int *>(zero_row)[threadIdx.x - 256] = 0;
+        __builtin_amdgcn_s_barrier();                      // (1) bounds[] initialised by the consumers
+        __builtin_amdgcn_s_barrier();                      // (2) nbr_s complete, per-wave minima merged into bounds[]
+        // windows: instruction j of loader w moves window rows 32 j + 8 w + (lane >> 3), piece (lane & 7) ^ ((row >> 1) & 7)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int lo = bounds[q];
+            const int wlo_q = lo == 0x7fffffff ? 0 : (lo & ~1);
+#pragma unroll
+            for (int j = 0; j < WINI; ++j) {
+                const int wr = 32 * j + 8 * wave + (lane >> 3);
+                const int src = wlo_q + wr;
+                const unsigned piece = (unsigned)(lane & 7) ^ ((unsigned)(wr >> 1) & 7u);
+                unsigned off = (unsigned)src * 128u + piece * 16u;
+                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;                    // beyond the last row: zeros
+                glds16(xrsrc, win + q * WIN_B + (32 * j + 8 * wave) * 128, off);
+            }
+        }
+        // The consumers read the operands of stage t + 1 while they run the MFMAs of stage t: barrier P publishes the
+        // windows and stage 0; barrier t publishes stage t + 1 and frees the slot of stage t (whose reads the consumers
+        // completed before arriving) for stage t + R.  Before barrier t only the R - 2 stages t + 2 .. t + R - 1 may be
+        // in flight.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // windows (issued last) + every stage fired so far
+        __builtin_amdgcn_s_barrier();                      // barrier P
+        fire(R - 1, std::integral_constant<int, R - 1>{});
+        for (int t = 0; t < NIT; t += R)
+            static_for<0, R>([&](auto j) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * WPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+                fire(t + decltype(j)::value + R, j);
+            });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x4 none[MI][NB];
+        int norows[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) norows[mi] = -1;
+        gg_epilogue<MI, NB, OUT_BF16>(none, norows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s, true);
+        return;
+    }
+
+    // ----------------------------------------------------------------------------------------------- consumer
+    {   // rulebook tile -> LDS (k-major, coalesced), row K = -1; per-thread minimum of the three dz groups on the way
+        const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+        constexpr int CT = 256;
+        if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;
+        int lo_t[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        const int total = K * ROWS;
+        for (int base = threadIdx.x; base < total + ROWS; base += 4 * CT) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * CT;
+                const int k = idx / ROWS, r = idx - k * ROWS;
+                const int row = r0wg + r;
+                const int krow = flip ? (K - 1 - k) : k;
+                const bool ok = idx < total && row < n_out;
+                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
+                if (!ok) v[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * CT;
+                if (idx < total + ROWS) nbr_s[idx] = v[u];
+                if (idx < total && v[u] >= 0) {
+                    const int grp = idx / (GRP * ROWS);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q == grp) lo_t[q] = min(lo_t[q], v[u]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // (1)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int lo = lo_t[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o));
+            if (lane == 0) atomicMin(bounds + q, lo);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // (2)
+    }
+    int wlo[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int lo = bounds[q];
+        wlo[q] = lo == 0x7fffffff ? 0 : (lo & ~1);         // even: the swizzle of a row depends on (window row >> 1)
+    }
+    f32x4 acc[MI][NB];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // neighbour indices of the lane's MI rows at a stage (row rl of every 16-row block), read two stages ahead
+    auto idx_of = [&](int stage, int (&out)[MI]) {
+        const int k = stage < K ? stage : K;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) out[mi] = nbr_s[k * ROWS + wrow0 + mi * 16 + rl];
+    };
+    // operand registers: two sets (stage parity), so that the LDS reads of stage t + 1 overlap the MFMAs of stage t
+    bf16x8 xa[2][2][MI], bw[2][2][NB];
+    bool have[2] = {false, false};
+    auto fetch = [&](auto slot_tag, int stage, const int (&ix)[MI]) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int SET = SLOT & 1;                             // R is even: slot parity = stage parity
+        bool any = false;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) any = any || ix[mi] >= 0;
+        have[SET] = __builtin_amdgcn_ballot_w64(any) != 0ull && stage < T && !(dbg & 4);
+        if (!have[SET]) return;                                   // no neighbour at this offset: no reads, no MFMAs
+        const int q = stage / GRP;
+        const int lo = q == 0 ? wlo[0] : (q == 1 ? wlo[1] : wlo[2]);
+        const char *wbase = win + q * WIN_B;
+        const char *wb = wring + SLOT * W_STAGE;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int w = ix[mi] - lo;
+            const bool inside = ix[mi] >= 0 && (unsigned)w < (unsigned)WCAP;
+            const char *rowp = inside ? wbase + w * 128 : zero_row;
+            const unsigned swz = inside ? (unsigned)(w >> 1) & 7u : 0u;
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+                xa[SET][cs][mi] = *reinterpret_cast<const bf16x8 *>(rowp + (((unsigned)(cs * 4 + g) ^ swz) << 4));
+        }
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bw[SET][cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int w = ix[mi] - lo;
+            if (ix[mi] >= 0 && (unsigned)w >= (unsigned)WCAP) {    // rare: straight from global memory (L2)
+                const bf16x8 *src = reinterpret_cast<const bf16x8 *>(x + (size_t)ix[mi] * 64);
+                xa[SET][0][mi] = src[g];
+                xa[SET][1][mi] = src[4 + g];
+            }
+        }
+    };
+    auto mfmas = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (!have[SET]) return;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[SET][cs][nb], xa[SET][cs][mi], acc[mi][nb], 0, 0, 0);
+    };
+    int ixe[MI], ixo[MI];                                           // indices of the next even / odd stage
+    idx_of(0, ixe);
+    idx_of(1, ixo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // barrier P: windows + stage 0 published
+    fetch(std::integral_constant<int, 0>{}, 0, ixe);
+    idx_of(2, ixe);
+    // step t: (reads of stage t complete) barrier t -> stage t + 1 published; fetch stage t + 1 (other set); MFMAs of t
+    for (int t = 0; t < NIT; t += R)
+        static_for<0, R>([&](auto j) {
+            constexpr int J = decltype(j)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr ((J & 1) == 0) {
+                fetch(std::integral_constant<int, (J + 1) % R>{}, t + J + 1, ixo);
+                idx_of(t + J + 3, ixo);
+            } else {
+                fetch(std::integral_constant<int, (J + 1) % R>{}, t + J + 1, ixe);
+                idx_of(t + J + 3, ixe);
+            }
+            mfmas(std::integral_constant<int, J & 1>{});
+        });
+
+    int rows[MI];
+    const int tile_row = wrow0 + rl;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = r0wg + tile_row + mi * 16;
+        rows[mi] = row < n_out ? row : -1;
+    }
+    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
+}
+
+template <int NB, int MI>
+static int launch_ggwin(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
+                        int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
+                        unsigned w_bytes, hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
+    constexpr int R = MI == 1 ? 4 : 8, K = 27;
+    constexpr int ROWS = 64 * MI;
+    constexpr int WCAP = (ROWS * 3 / 2 + 31) / 32 * 32;
+    int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
+    const size_t lds = (size_t)R * (2 * NB * 1024) + (size_t)3 * WCAP * 128 + 128 + (size_t)(K + 1) * ROWS * sizeof(int) + 32 +
+                       (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
+    if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
+    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
+    auto kb = ggwin_kernel<NB, MI, R, true>;
+    auto kf = ggwin_kernel<NB, MI, R, false>;
+    if (lds > 64 * 1024) {
+        static size_t raised[2] = {0, 0};
+        const int which = y_dtype == PCD_BF16 ? 0 : 1;
+        if (raised[which] < lds) {
+            if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return PCD_ERR_LAUNCH;
+            raised[which] = lds;
+        }
+    }
+    if (y_dtype == PCD_BF16)
+        kb<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                   n_out_dev, n_in, y, x_bytes, w_bytes, addend, bn, dbg);
+    else
+        kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                   n_out_dev, n_in, y, x_bytes, w_bytes, addend, bn, dbg);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
 // rows all share the residues ((c + p) mod s) of the three axes, hence the same 1..8 usable offsets (of 27 for
 // k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
@@ -1961,11 +2267,26 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
     //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
     const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
+    // SubM 3x3x3, 64 -> 64 (n_in == n_out): the window kernel (PCD_GGWIN=0 turns it off, =3 uses 48 rows per wave)
+    static const int ggwin_mode = getenv("PCD_GGWIN") ? atoi(getenv("PCD_GGWIN")) : 0;
+    if (tiles_only && tiles_only[0] == -12345 && ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 &&
+        n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
+        tiles_only[0] = 2;
+        return PCD_OK;
+    }
     if (tiles_only && tiles_only[0] == -12345) {       // variant query (pcd_sparse_conv_gather_gemm_variant)
         static const int m = getenv("PCD_GGW") ? atoi(getenv("PCD_GGW")) : 1;
         tiles_only[0] = (m && (c_in == 128 || (c_in == 64 && m >= 2 && m <= 4)) && (c_out == 64 || c_out == 128) &&
                          x_bytes <= 0xFFFF0000u && !(is_dgrad && m == 6)) ? 1 : 0;
         return PCD_OK;
+    }
+    if (ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 && n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
+        const unsigned w_bytes = (unsigned)wbytes;
+        if (ggwin_mode == 3)
+            return launch_ggwin<4, 1>(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
+                                      y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only);
+        return launch_ggwin<4, 2>(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
+                                  y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only);
     }
     // PCD_GGW: 0 = off, 1 = on (default), 2..4 = on with MI rows-per-wave forced (also for C_in = 64), 6 = forward only
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&

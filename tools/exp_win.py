@@ -1,0 +1,42 @@
+"""Window gather-GEMM (ggwin_kernel, PCD_GGWIN=1) against the generic kernels on the level-3 SubM 64->64 layer of the B = 4
+workload: bit-identical outputs (forward, flipped = data gradient, with bias / addend / BatchNorm sums), time of both.
+Run once per PCD_GGWIN value (the switch is read once per process); argv[1] = file to save / compare the outputs."""
+import sys, os, torch, hashlib
+sys.path.insert(0, '.')
+from com_amd import ops, hotpath
+from com_amd.utils import synth
+dev = 'cuda'
+B = int(os.environ.get("EXP_B", "4"))
+frames = [synth.synth_cloud(f) for f in range(B)]
+pts, offs = hotpath.collate_points(frames, dev)
+res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5, want_voxels=False)
+idx, shape = res['coords'], [41, 1504, 1504]
+CH = 64
+for geo in ((3, 2, 1), (3, 2, 1)):
+    rb = ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2]); idx, shape = rb.out_indices, rb.out_shape
+n = idx.shape[0]
+rb = ops.rulebook_subm(idx, B, shape)
+torch.manual_seed(0)
+x = torch.randn(n, CH, device=dev).bfloat16(); w = torch.randn(CH, 27, CH, device=dev) * 0.05
+bias = torch.randn(CH, device=dev)
+add = torch.randn(n, CH, device=dev).bfloat16()
+pw, pd = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
+def t(fn, reps=20):
+    for _ in range(3): fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+outs = {
+    "fwd": ops.gather_gemm(x, pw, None, rb.nbr_out, 27, False, n, CH, torch.bfloat16),
+    "fwd_bias_f32": ops.gather_gemm(x, pw, bias, rb.nbr_out, 27, False, n, CH, torch.float32),
+    "dgrad_add": ops.gather_gemm(x, pd, None, rb.nbr_out, 27, True, n, CH, torch.bfloat16, addend=add),
+}
+torch.cuda.synchronize()
+h = {k: hashlib.sha256(v.cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:16] for k, v in outs.items()}
+pairs = int(rb.pair_num.sum())
+us = t(lambda: ops.gather_gemm(x, pw, None, rb.nbr_out, 27, False, n, CH, torch.bfloat16))
+usd = t(lambda: ops.gather_gemm(x, pd, None, rb.nbr_out, 27, True, n, CH, torch.bfloat16, addend=add))
+print("GGWIN=" + os.environ.get('PCD_GGWIN', '-'), "DBG=" + os.environ.get("PCD_GGW_DBG", "0"), f"rows {n} pairs {pairs}: fwd {us:.1f} us dgrad {usd:.1f} us -> "
+      f"{2*pairs*CH*CH/us*1e-6:.0f} TFLOP/s", h, "finite", bool(torch.isfinite(outs['fwd'].float()).all()), flush=True)
