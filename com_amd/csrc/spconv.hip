@@ -207,7 +207,7 @@ __device__ __forceinline__ void bn_mid_row(const float *partial, int nblocks, in
 
 // partial row `tile` = get(e), e in [0, 2 c_out); all threads of the workgroup, uniformly
 template <class F>
-__device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_out, F get) {
+__device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_out, F get, int nrows_arg = -1) {
     float *dst = bn.partial + (size_t)tile * 2 * c_out;
     if (!bn.mid) {
         for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) dst[e] = get(e);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_o
         __hip_atomic_store(dst + e, get(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row has reached the coherence point ...
     __syncthreads();
-    const int nrows = gridDim.x, r = tile & (BN_MID_ROWS - 1);
+    const int nrows = nrows_arg >= 0 ? nrows_arg : (int)gridDim.x, r = tile & (BN_MID_ROWS - 1);
     if (tile == 0)                                         // fewer tiles than groups: the empty groups' rows are zero
         for (int e = nrows * 2 * c_out + threadIdx.x; e < BN_MID_ROWS * 2 * c_out; e += blockDim.x) bn.mid[e] = 0.0;
     if (threadIdx.x == 0) {                                // ... before this workgroup counts as arrived
@@ -1318,6 +1318,341 @@ static int launch_ggwin(const void *x, int n_in, const void *wp, const float *bi
 }
 
 // ---------------------------------------------------------------------------------------------
+// REGISTER-RESIDENT-WEIGHT window gather-GEMM: SubM 3x3x3, 64 -> 64, key-ordered rows.  What the experiments with
+// ggwin_kernel showed (tools/exp_win.py): with the gathers replaced by windows the weight stream (221 KB per tile, one
+// barrier per 8 KB stage, ~3.7 k clk of DMA latency per stage to hide) and the per-tile prologue (rulebook tile ->
+// window bounds -> window DMA: two dependent memory latencies) are what is left, and at one workgroup per CU nothing
+// hides them.  Here:
+//   * wave w of a 4-wave workgroup owns output channel block w (16 channels) of ALL rows of a tile and keeps its
+//     27 x 2 weight fragments in REGISTERS (216 VGPRs; one wave per SIMD, 512 registers) for the whole launch: no
+//     weight traffic, no stage barriers in the offset loop (27 offsets fully unrolled);
+//   * a workgroup is PERSISTENT over a contiguous run of <= SMAX 64-row tiles: the rulebook run is staged once (one
+//     latency), all window bounds come from it at once, and the three windows of tile s + 1 are DMA'd into the second
+//     LDS buffer while tile s is computed -- two barriers per tile, no exposed latency after the first tile;
+//   * operands: LDS window reads through the rulebook tile (as ggwin_kernel), fetched one offset ahead of the MFMAs.
+// LDS traffic: every wave reads all 64 rows' fragments (8 KiB per offset and wave) for 8 MFMAs -> LDS-bound at ~2x the
+// MFMA time, i.e. up to half of the matrix peak.  Same operands and the same MFMA sequence per output element as the
+// other kernels (offsets ascending, the two contraction steps in order) -> bit-identical conv outputs.
+constexpr int GGR_ROWS = 64;          // rows per tile
+constexpr int GGR_WCAP = 96;          // window rows (1.5 x)
+constexpr int GGR_SMAX = 8;           // tiles per workgroup (LDS: operand-address table of the run)
+constexpr int GGR_SCRATCH = 8192;     // head of the dynamic LDS: bnred_publish's scratch / column sums
+constexpr int GGR_WBUF = 3 * GGR_WCAP * 128 + 256;   // three windows + a row of zeros (+ pad: 256-byte multiple)
+
+typedef __attribute__((address_space(3))) const bf16x8 *lds_frag_ptr;
+typedef __attribute__((address_space(3))) const int *lds_int_ptr;
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 1) void ggreg_kernel(
+    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
+    int n_in, void *__restrict__ yv, unsigned x_bytes, const void *__restrict__ addend, BnRed bn, int bn_rows, int dbg) {
+    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
+    constexpr int K = 27, GRP = 9, NB = 4, c_out = 64;
+    constexpr int ROWS = GGR_ROWS, WCAP = GGR_WCAP, SMAX = GGR_SMAX;
+    constexpr int WIN_B = WCAP * 128, WBUF = GGR_WBUF;
+    constexpr unsigned ZREL = 3 * WIN_B;                   // the zero row of a window buffer ((ZREL >> 8) & 7 == 0: no swizzle)
+    static_assert(((ZREL >> 8) & 7u) == 0 && ((WIN_B >> 8) & 7) == 0 && (WBUF & 255) == 0, "swizzle bits of the window layout");
+    constexpr int WINI = 3 * WCAP / 32;                    // window DMA instructions per wave and tile (9)
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    float *red_s = (float *)smem;                          // [2][c_out] (inside the scratch head)
+    int *bounds = (int *)(smem + GGR_SCRATCH);             // [SMAX][4]
+    int *tab_s = bounds + SMAX * 4;                        // [K][SMAX * ROWS]: operand offsets relative to the window buffer
+    char *win = (char *)(tab_s + K * SMAX * ROWS);         // [2][WBUF]
+    // 32-bit LDS addresses (generic pointers cost a 64-bit add and an address-space test per operand read)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned tab_a = lds0 + (unsigned)((char *)tab_s - smem), win_a = lds0 + (unsigned)(win - smem);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    // tiles of this workgroup: the n_sub real tiles are dealt to the workgroups in contiguous runs of `per`, XCD by XCD
+    const int n_sub = (n_out + ROWS - 1) / ROWS;
+    const int nwg = gridDim.x;
+    const int per = (n_sub + nwg - 1) / nwg;               // <= SMAX (the grid is sized from the capacity)
+    const int chunk = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+    const int t0 = chunk * per;
+    const int nt = max(0, min(per, n_sub - t0));
+    // the BatchNorm partial rows beyond the real tiles are zeroed by their round-robin owners (every row published once)
+    auto zero_surplus = [&]() {
+        if (!bn.mode) return;
+        for (int t = n_sub + (int)blockIdx.x; t < bn_rows; t += nwg)
+            bnred_publish(bn, t, c_out, [](int) { return 0.0f; }, bn_rows);
+    };
+    if (nt == 0) {
+        zero_surplus();
+        return;
+    }
+    // ---- weights -> registers: fragment (cs, nb = wave) of every offset (packed order: ((k * 2 + cs) * NB + nb) * 64 + lane)
+    bf16x8 bw[K][2];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+            const uint4 v = wp[((size_t)(k * 2 + cs) * NB + wave) * 64 + lane];
+            bw[k][cs] = __builtin_bit_cast(bf16x8, v);
+        }
+    // ---- rulebook run -> operand-address table.  Wave w takes the tiles s = w, w + 4, ..; its 64 lanes are the tile's 64
+    // rows (one coalesced 256-byte load per offset).  Per dz group: minimum of the valid indices (lane-local over the 9
+    // offsets + one wave reduction) = window start; table entry = byte offset of the neighbour's row inside the window
+    // buffer, ZREL (a row of zeros) for a missing neighbour, -(index + 2) for a neighbour outside its window.
+    const int r0 = t0 * ROWS;
+    if (threadIdx.x < 64) {                                 // the zero rows of both window buffers
+        reinterpret_cast<int *>(win + ZREL)[threadIdx.x & 31] = 0;
+        reinterpret_cast<int *>(win + WBUF + ZREL)[threadIdx.x & 31] = 0;
+    }
+    {
+        const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+        for (int sb = wave; sb < nt; sb += 4) {
+            const int row = r0 + sb * ROWS + lane;
+            const bool ok = row < n_out;
+            int v[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int krow = flip ? (K - 1 - k) : k;
+                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int lo = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int t = ok ? v[q * GRP + j] : -1;
+                    lo = t >= 0 ? min(lo, t) : lo;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o));
+                lo = lo == 0x7fffffff ? 0 : (lo & ~1);       // even: the swizzle of a row depends on (window row >> 1)
+                if (lane == 0) bounds[sb * 4 + q] = lo;
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int t = ok ? v[q * GRP + j] : -1;
+                    const int w = t - lo;
+                    int e = (int)ZREL;
+                    if (t >= 0) e = (unsigned)w < (unsigned)WCAP ? q * WIN_B + w * 128 : -(t + 2);
+                    tab_s[(q * GRP + j) * (SMAX * ROWS) + sb * ROWS + lane] = e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    // windows of tile s -> buffer s & 1: instruction j of wave w moves rows 32 j' + 8 w + (lane >> 3) of window q (j = 3 q + j')
+    auto fire_windows = [&](int s) {
+        char *dst = win + (s & 1) * WBUF;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int wlo = bounds[s * 4 + q];
+#pragma unroll
+            for (int j = 0; j < WCAP / 32; ++j) {
+                const int wr = 32 * j + 8 * wave + (lane >> 3);
+                const int src = wlo + wr;
+                const unsigned piece = (unsigned)(lane & 7) ^ ((unsigned)(wr >> 1) & 7u);
+                unsigned off = (unsigned)src * 128u + piece * 16u;
+                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;
+                glds16(xrsrc, dst + q * WIN_B + (32 * j + 8 * wave) * 128, off);
+            }
+        }
+    };
+    fire_windows(0);
+    const unsigned g4 = (unsigned)g << 4;
+    for (int s = 0; s < nt; ++s) {
+        // (A) every wave has finished tile s - 1: its window buffer may be refilled for tile s + 1
+        if (s > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (s + 1 < nt) {
+            fire_windows(s + 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WINI) : "memory");     // windows of tile s landed (s + 1 in flight)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                       // (B) every wave's share of the windows of tile s is in LDS
+        const unsigned wb_a = win_a + (unsigned)(s & 1) * (unsigned)WBUF;
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned trow_a = tab_a + (unsigned)(s * ROWS + rl) * 4u;     // + (k * SMAX * ROWS + rb * 16) * 4
+        bf16x8 xa[2][4][2];                                 // [set][row block][contraction step]
+        int ev[2][4];
+        auto load_tab = [&](int k, int (&o)[4]) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                o[rb] = *(lds_int_ptr)(trow_a + (unsigned)(k * (SMAX * ROWS) + rb * 16) * 4u);
+        };
+        auto fetch = [&](const int (&e)[4], bf16x8 (&dst)[4][2]) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const unsigned v = e[rb] < 0 ? ZREL : (unsigned)e[rb];
+                const unsigned swz4 = (v >> 4) & 0x70u;                      // ((window row >> 1) & 7) << 4
+                const unsigned a0 = wb_a + v + (g4 ^ swz4);
+                dst[rb][0] = *(lds_frag_ptr)a0;
+                dst[rb][1] = *(lds_frag_ptr)(a0 ^ 64u);                      // piece 4 + g: bit 6 of the in-row offset
+            }
+            // rare: a neighbour outside its window comes straight from global memory (one wave-uniform test per offset)
+            if (__builtin_amdgcn_ballot_w64((e[0] | e[1] | e[2] | e[3]) < 0) != 0ull) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    if (e[rb] < 0) {
+                        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(x + (size_t)(-(e[rb] + 2)) * 64);
+                        dst[rb][0] = src[g];
+                        dst[rb][1] = src[4 + g];
+                    }
+            }
+        };
+        load_tab(0, ev[0]);
+        load_tab(1, ev[1]);
+        fetch(ev[0], xa[0]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k + 1 < K) fetch(ev[(k + 1) & 1], xa[(k + 1) & 1]);
+            if (k + 2 < K) load_tab(k + 2, ev[k & 1]);
+            if (!(dbg & 4)) {
+#pragma unroll
+                for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[k][cs], xa[k & 1][rb][cs], acc[rb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb][0] += (float)xa[k & 1][rb][0][0] + (float)xa[k & 1][rb][1][0];   // keep the reads alive
+            }
+        }
+        // ---- epilogue of tile s: lane (g, rl) holds channels g * 16 + wave * 4 .. + 3 of rows rb * 16 + rl
+        const int tile = t0 + s;
+        const int col = g * 16 + wave * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const float4 t = *reinterpret_cast<const float4 *>(bias + col);
+            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+        }
+        float bs[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row = tile * ROWS + rb * 16 + rl;
+            if (row >= n_out) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[rb][j] + (bias ? bv[j] : 0.0f);
+            const size_t at = (size_t)row * c_out + col;
+            if (OUT_BF16) {
+                if (addend) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + at);
+                    v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
+                    v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
+                }
+                const u32 o0 = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
+                const u32 o1 = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
+                *reinterpret_cast<uint2 *>((unsigned short *)yv + at) = make_uint2(o0, o1);
+                if (bn.mode) {
+                    const float d[4] = {__uint_as_float(o0 << 16), __uint_as_float(o0 & 0xffff0000u),
+                                        __uint_as_float(o1 << 16), __uint_as_float(o1 & 0xffff0000u)};
+                    if (bn.mode == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bs[j] += d[j];
+                            bq[j] += d[j] * d[j];
+                        }
+                    } else {
+                        const uint2 tx = *reinterpret_cast<const uint2 *>(bn.x + at);
+                        const float xv[4] = {__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u),
+                                             __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u)};
+                        float tv[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (bn.relu) {
+                            const uint2 ty = *reinterpret_cast<const uint2 *>(bn.y + at);
+                            tv[0] = __uint_as_float(ty.x << 16); tv[1] = __uint_as_float(ty.x & 0xffff0000u);
+                            tv[2] = __uint_as_float(ty.y << 16); tv[3] = __uint_as_float(ty.y & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float dz = (bn.relu && !(tv[j] > 0.0f)) ? 0.0f : d[j];
+                            bs[j] += dz;
+                            bq[j] += dz * xv[j];
+                        }
+                    }
+                }
+            } else {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (addend) {
+                    const float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + at);
+                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                }
+                *reinterpret_cast<float4 *>((float *)yv + at) = o;
+            }
+        }
+        if (OUT_BF16 && bn.mode) {
+            if (bn.mode == 2) {
+                const float4 mu = *reinterpret_cast<const float4 *>(bn.mean + col);
+                const float4 is = *reinterpret_cast<const float4 *>(bn.invstd + col);
+                bq[0] = (bq[0] - mu.x * bs[0]) * is.x; bq[1] = (bq[1] - mu.y * bs[1]) * is.y;
+                bq[2] = (bq[2] - mu.z * bs[2]) * is.z; bq[3] = (bq[3] - mu.w * bs[3]) * is.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bs[j] = row16_sum(bs[j]);
+                bq[j] = row16_sum(bq[j]);
+            }
+            if (rl == 0) {
+                *reinterpret_cast<float4 *>(red_s + col) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+                *reinterpret_cast<float4 *>(red_s + c_out + col) = make_float4(bq[0], bq[1], bq[2], bq[3]);
+            }
+            __syncthreads();
+            float mine = threadIdx.x < 2 * c_out ? red_s[threadIdx.x] : 0.0f;
+            __syncthreads();                                 // (red_s lies inside bnred_publish's scratch)
+            bnred_publish(bn, tile, c_out, [&](int) { return mine; }, bn_rows);
+        }
+    }
+    zero_surplus();
+}
+
+// grid of the persistent kernel for a capacity of n_out rows: one workgroup per CU unless its run would exceed SMAX tiles
+static int ggreg_grid(int n_out) {
+    const int n_sub = pcd_div_up(n_out, GGR_ROWS);
+    int grid = 256;
+    if (pcd_div_up(n_sub, grid) > GGR_SMAX) grid = pcd_div_up(pcd_div_up(n_sub, GGR_SMAX), 8) * 8;
+    return grid;
+}
+static int ggreg_bn_rows(int n_out) { return pcd_div_up(pcd_div_up(n_out, GGR_ROWS), 8) * 8; }
+
+static int launch_ggreg(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
+                        int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
+                        hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
+    const int bn_rows = ggreg_bn_rows(n_out);
+    if (tiles_only) {
+        *tiles_only = bn_rows;
+        return PCD_OK;
+    }
+    const int grid = ggreg_grid(n_out);
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, 64, bn_rows, &bn)) return rc;
+    const size_t lds = (size_t)GGR_SCRATCH + GGR_SMAX * 16 + (size_t)27 * GGR_SMAX * GGR_ROWS * sizeof(int) +
+                       (size_t)2 * GGR_WBUF + 256;
+    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
+    auto kb = ggreg_kernel<true>;
+    auto kf = ggreg_kernel<false>;
+    static size_t raised[2] = {0, 0};
+    const int which = y_dtype == PCD_BF16 ? 0 : 1;
+    if (raised[which] < lds) {
+        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PCD_ERR_LAUNCH;
+        raised[which] = lds;
+    }
+    if (y_dtype == PCD_BF16)
+        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                   n_out_dev, n_in, y, x_bytes, addend, bn, bn_rows, dbg);
+    else
+        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                   n_out_dev, n_in, y, x_bytes, addend, bn, bn_rows, dbg);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
 // rows all share the residues ((c + p) mod s) of the three axes, hence the same 1..8 usable offsets (of 27 for
 // k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
@@ -2282,6 +2617,9 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     }
     if (ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 && n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
         const unsigned w_bytes = (unsigned)wbytes;
+        if (ggwin_mode >= 4)
+            return launch_ggreg(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
+                                y_dtype, x_bytes, st, addend, bnr, tiles_only);
         if (ggwin_mode == 3)
             return launch_ggwin<4, 1>(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
                                       y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only);
