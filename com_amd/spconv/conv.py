@@ -180,8 +180,11 @@ class SparseConvolution(SparseModule):
             cur.wait_event(ev)                      # built on the prefetch stream: order this stream after it ONCE
             rb.joined_stream = cur.cuda_stream
             first_use = True
+        fp8 = getattr(self, "fp8_train", None)
+        if fp8 is not None and not (self.training and torch.is_grad_enabled()):
+            fp8 = None                                  # (the fp8-forward training form; inference has Fp8Backbone)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad,
-                                passthrough)
+                                passthrough, fp8)
         ident = None
         if passthrough:
             feats, ident = feats

@@ -1,4 +1,8 @@
-"""fp8 (OCP e4m3) INFERENCE path of the plain sparse backbone -- BASELINE config 5 (SECOND / VoxelNet,
+"""fp8 (OCP e4m3) paths of the plain sparse backbone: the fused INFERENCE form (`Fp8Backbone`) and the fp8-FORWARD
+TRAINING form (`enable_fp8_training`: e4m3 forward convs with static per-tensor scales, batch-statistics BatchNorm and
+the bf16 backward pass of the normal path -- straight-through gradients).
+
+fp8 (OCP e4m3) INFERENCE path of the plain sparse backbone -- BASELINE config 5 (SECOND / VoxelNet,
 tools/cfgs/waymo_models/second.yaml:8-17 -> VoxelBackBone8x, spconv_backbone.py:69-180).  Build-side precision: the
 reference computes in fp32.
 
@@ -141,3 +145,56 @@ class Fp8Backbone(torch.nn.Module):
         batch_dict.update({'multi_scale_3d_features': ms,
                            'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
         return batch_dict
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Fp8TrainState:
+    """fp8 forward of ONE conv layer during training (attached to the module as `fp8_train`; used by
+    com_amd.spconv.functional.SparseConvFunction.forward).  Static per-tensor scales: `scale_x` from a calibration pass
+    (amax of the layer's input / 448), `scale_w` from the weight's amax at calibration (saturating casts absorb the drift
+    of a few hundred optimizer steps; call `enable_fp8_training` again to refresh).  The e4m3 weight pack is redone on
+    every forward (the weights change every step): one small launch per layer, like the bf16 packs."""
+
+    def __init__(self, conv, scale_x, scale_w):
+        self.conv, self.scale_x, self.scale_w = conv, float(scale_x), float(scale_w)
+        self.cin_pad = max(16, 1 << (conv.in_channels - 1).bit_length())
+        dev = conv.weight.device
+        self.alpha = torch.full((conv.out_channels,), self.scale_x * self.scale_w, dtype=torch.float32, device=dev)
+        self.zeros = torch.zeros((conv.out_channels,), dtype=torch.float32, device=dev)
+
+    def forward(self, x_bf16, bias_f32, rb, cout, out_dtype):
+        x8 = quantize(x_bf16, self.scale_x, self.cin_pad, n_dev=rb.n_in_dev)
+        packed = pack_weight(self.conv.weight, self.cin_pad, self.scale_w)
+        kind = "bf16" if out_dtype == torch.bfloat16 else "f32"
+        return conv_fp8(x8, packed, rb, cout, self.alpha, bias_f32 if bias_f32 is not None else self.zeros, False, kind)
+
+
+@torch.no_grad()
+def enable_fp8_training(backbone, batch_dict, skip_first=True):
+    """Calibrate (one bf16 forward in the CURRENT mode of the module) and switch every sparse conv with >= 16 input
+    channels to the fp8 forward.  Returns {conv name: (scale_x, scale_w)}.  `disable_fp8_training` undoes it."""
+    from .conv import SparseConvolution
+    convs = [(n, m) for n, m in backbone.named_modules() if isinstance(m, SparseConvolution) and m.in_channels >= 16]
+    amax, hooks = {}, []
+    for name, m in convs:
+        m.fp8_train = None
+
+        def pre(mod, args, name=name):
+            amax[name] = float(args[0].features.float().abs().max())
+        hooks.append(m.register_forward_pre_hook(pre))
+    backbone(dict(batch_dict))
+    for h in hooks:
+        h.remove()
+    out = {}
+    for name, m in convs:
+        sx = max(amax.get(name, 0.0), 1e-6) / E4M3_MAX
+        sw = max(float(m.weight.detach().float().abs().max()), 1e-12) / E4M3_MAX
+        m.fp8_train = Fp8TrainState(m, sx, sw)
+        out[name] = (sx, sw)
+    return out
+
+
+def disable_fp8_training(backbone):
+    for m in backbone.modules():
+        if hasattr(m, "fp8_train"):
+            m.fp8_train = None

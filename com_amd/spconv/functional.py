@@ -111,7 +111,7 @@ class SparseConvFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None):
         """passthrough=True also returns `features` itself as a second output (the identity branch of a residual
         block): backward then receives the gradients of BOTH branches in one call and adds the identity gradient
         inside the dgrad kernel's epilogue instead of through a separate elementwise kernel."""
@@ -124,8 +124,15 @@ class SparseConvFunction(Function):
         stats = None
         if FUSE_BN_REDUCTIONS and out_dtype == torch.bfloat16 and cout % 16 == 0 and ctx.needs_input_grad[1]:
             stats = ops.BnReduce(1)              # training: a BatchNorm follows every conv of the backbones
-        y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
-                            n_dev=rb.n_out_dev, bn_reduce=stats)
+        if fp8 is not None and cin_pad >= 16:
+            # fp8 FORWARD (BASELINE config 5 as a training step): e4m3 operands with the layer's static per-tensor
+            # scales, fp32 accumulation, bf16 / f32 result; the backward pass below is the bf16 one on the saved bf16
+            # input (straight-through: the quantisation is treated as the identity).  No BatchNorm sums in this epilogue.
+            y = fp8.forward(x, b, rb, cout, out_dtype)
+            stats = None
+        else:
+            y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
+                                n_dev=rb.n_out_dev, bn_reduce=stats)
         if stats is not None:
             y._pcd_stats = stats
         # bias gradient = column sum of our dy; when dy comes out of a fused BatchNorm backward that kernel sums it
@@ -158,7 +165,7 @@ class SparseConvFunction(Function):
         x, weight = ctx.saved_tensors
         rb = ctx.rb
         if dy is None:                               # only the identity branch received a gradient
-            return (d_ident, None, None, None, None, None, None)
+            return (d_ident, None, None, None, None, None, None, None)
         dy16 = _to_bf16_padded(dy, ctx.cout)
         dx = dw = db = None
         # dgrad and wgrad only share their inputs: at B = 4 neither fills the chip (1-4 waves per SIMD), so the
@@ -260,7 +267,7 @@ class SparseConvFunction(Function):
                     t.record_stream(cur)
         if dx is None and d_ident is not None:
             dx = d_ident
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class BevDenseFunction(Function):
@@ -342,10 +349,10 @@ class SparseConvExactFunction(Function):
         return (dx, dw, db, None, None)
 
 
-def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None):
     if EXACT_FP32 and features.dtype == torch.float32:
         return SparseConvExactFunction.apply(features, weight, bias, rb, passthrough)
-    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
+    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough, fp8)
 
 
 class _ColsumLink:
