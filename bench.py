@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--com-ucl", action="store_true", help="with --com: LOSS_CURRICULUM.UCL = True (per-object weights)")
     ap.add_argument("--distinct-batches", type=int, default=16, help="distinct global batches the timed loop cycles through")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary loop over frames with 0-20 %% ray drop-out")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE config 5 as a TRAINING step: SECOND's plain VoxelBackBone8x on 300k-point clouds "
+                         "(120 beams x 2500 az) with the fp8 (e4m3) forward convs of com_amd.spconv.fp8, bf16 backward")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the child run that measures --config5")
     ap.add_argument("--no-stage2", action="store_true", help="skip the PV-RCNN stage-2 (config 4) secondary figure")
     ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
     ap.add_argument("--selftest-launch", action="store_true",
@@ -77,11 +81,12 @@ class HotPath(torch.nn.Module):
     dense_head=True appends backbone_2d + the conv towers of dense_head (centerpoint.yaml:19-46) in bf16 /
     channels_last."""
 
-    def __init__(self, dense_head=False):
+    def __init__(self, dense_head=False, plain=False):
         super().__init__()
         grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
         self.vfe = hotpath.MeanVFE({}, 5)
-        self.backbone_3d = hotpath.VoxelResBackBone8x({}, 5, grid)
+        # plain=True: SECOND's backbone (tools/cfgs/waymo_models/second.yaml:13-14 -> VoxelBackBone8x), config 5
+        self.backbone_3d = (hotpath.VoxelBackBone8x if plain else hotpath.VoxelResBackBone8x)({}, 5, grid)
         self.map_to_bev_module = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256, "CHANNELS_LAST": dense_head})
         if dense_head:
             from com_amd.hotpath import dense2d
@@ -489,14 +494,15 @@ def measure_stage2(B, dev):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def measure_full_model(args):
+def measure_full_model(args, flags=("--dense-head", "--com"), what=None):
     """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
     run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
-    loops have finished; the child is a new process, nothing is exec'ed over this one."""
+    loops have finished; the child is a new process, nothing is exec'ed over this one.  (`fp8_config5` reuses this
+    with `--config5`.)"""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--dense-head", "--com", "--gpus", "1", "--steps", str(args.steps),
+    cmd = [sys.executable, os.path.abspath(__file__), *flags, "--gpus", "1", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2"]
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -509,8 +515,9 @@ def measure_full_model(args):
         r = json.loads(line[-1])
         return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                 "config": r["config"]["workload"], "com": r.get("com"), "child_wall_s": round(time.perf_counter() - t0, 1),
-                "what": "child run `bench.py --dense-head --com`: hot path + BaseBEVBackbone + CenterHead towers + COM "
-                        "curriculum targets / FocalLossCenterCurriculum / RegLoss, one hipGraph per step"}
+                "points_per_frame": r["config"].get("points_per_frame"), "voxels_per_frame": r["config"].get("voxels_per_frame"),
+                "what": what or "child run `bench.py --dense-head --com`: hot path + BaseBEVBackbone + CenterHead towers + "
+                        "COM curriculum targets / FocalLossCenterCurriculum / RegLoss, one hipGraph per step"}
     except Exception as exc:                                  # never lose the headline
         return {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -556,12 +563,13 @@ def main():
     # through the timed loop: voxel / row counts differ from step to step (M = 80..87 k per frame), the static
     # capacities are sized from the warm-up steps only, and a denser batch would trip the overflow guard
     n_batches = max(2, args.distinct_batches)
+    BEAMS = 120 if args.config5 else 64                       # 120 x 2500 = 300 000 points per frame (config 5)
 
     def make_batches(drop=None):
         out = []
         for j in range(n_batches):
             ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
-            frames = [synth.synth_cloud(f) for f in ids]
+            frames = [synth.synth_cloud(f, BEAMS, 2500) for f in ids]
             if drop is not None:                             # ragged variant: 0-20 % of every frame's rays are lost
                 frames = [f[:int(round(f.shape[0] * (1.0 - drop.uniform(0.0, 0.2))))] for f in frames]
             pts, offs = hotpath.collate_points(frames, dev)  # resident in HBM before the timed region
@@ -586,7 +594,7 @@ def main():
     Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
     ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
     Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
-    model = HotPath(dense_head=args.dense_head).to(dev)
+    model = HotPath(dense_head=args.dense_head, plain=args.config5).to(dev)
     model.train()
     if world > 1:                                            # what DDP does at construction (tools/train.py:165-166)
         for t in list(model.parameters()) + list(model.buffers()):
@@ -661,6 +669,7 @@ def main():
             bd2["voxel_rank"] = bd["voxel_rank"]             # coordinate -> row map: level-1 SubM without a hash table
         if not (ops.PLAN is not None and ops.PLAN.active):
             last["voxels"] = sum(bd["voxel_counts"])
+            last["bd2"] = bd2
         return bd2
 
     def train_from_voxels(bd2, ev=None):
@@ -746,6 +755,13 @@ def main():
     ops.PLAN = plan
     for i in range(max(args.warmup, 2)):                     # eager: also observes the data-dependent row counts
         eager_step(i)
+        if args.config5 and i == 0:
+            # calibrate on the first batch (amax of every conv input / weight -> static e4m3 scales), then every
+            # sparse conv with >= 16 input channels runs its FORWARD in fp8 (backward: bf16, straight-through)
+            from com_amd.spconv import fp8 as fp8mod
+            with torch.no_grad():
+                scales = fp8mod.enable_fp8_training(model.backbone_3d, model.vfe(dict(last["bd2"])))
+            last["fp8_layers"] = len(scales)
 
     state = {}
 
@@ -1026,6 +1042,13 @@ def main():
         result["ragged"] = ragged
     if com_report is not None:
         result["com"] = com_report
+    if args.config5:
+        result["config"]["workload"] = ("SECOND / VoxelNet hot path (hard voxelize+MeanVFE -> VoxelBackBone8x fwd+bwd -> "
+                                        "HeightCompression fwd+bwd -> clip -> Adam), fp8 (e4m3) FORWARD convs on "
+                                        f"{last.get('fp8_layers', 0)} layers, bf16 backward, 300k-pt synthetic clouds "
+                                        "(120 beams x 2500 az), MAX_NUMBER_OF_VOXELS 150000 per frame")
+        result["config"]["points_per_frame"] = 300000
+        result["dtype"] = "fp8 forward (e4m3, fp32 accumulate) / bf16 backward"
     if args.dense_head:
         result["config"]["workload"] = ("FULL CenterPoint-VoxelNet step (hot path + BaseBEVBackbone + CenterHead towers + "
                                         + ("COM curriculum head: cluster / radius_map targets / FocalLossCenterCurriculum"
@@ -1038,11 +1061,17 @@ def main():
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
-    if rank == 0 and world == 1 and not args.no_stage2 and not args.dense_head:
+    if rank == 0 and world == 1 and not args.no_stage2 and not args.dense_head and not args.config5:
         result["stage2"] = measure_stage2(B, dev)
-    if rank == 0 and world == 1 and not args.no_full_model and not args.dense_head:
+    if rank == 0 and world == 1 and not args.no_full_model and not args.dense_head and not args.config5:
         torch.cuda.synchronize()
         result["full_model"] = measure_full_model(args)
+    if rank == 0 and world == 1 and not args.no_fp8 and not args.dense_head and not args.config5:
+        result["fp8_config5"] = measure_full_model(
+            args, flags=("--config5",),
+            what="child run `bench.py --config5`: BASELINE config 5 as a TRAINING step -- SECOND's VoxelBackBone8x on "
+                 "300k-point clouds, fp8 (e4m3, v_mfma_f32_16x16x32_fp8_fp8) forward convs with static per-tensor scales, "
+                 "batch-statistics BatchNorm, bf16 backward; one hipGraph per step")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -27,7 +27,7 @@ def _bench(tmp_path, tag, args, env=None):
     e.update(env or {})
     dump = tmp_path / f"{tag}.json"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "2",
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--distinct-batches", "3",
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--distinct-batches", "3",
            "--same-shard", "--dump-state", str(dump)] + args
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
