@@ -1487,7 +1487,8 @@ __global__ __launch_bounds__(256, 1) void ggreg_kernel(
         auto fetch = [&](const int (&e)[4], bf16x8 (&dst)[4][2]) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const unsigned v = e[rb] < 0 ? ZREL : (unsigned)e[rb];
+                unsigned v = e[rb] < 0 ? ZREL : (unsigned)e[rb];
+                if (dbg & 8) v = (unsigned)(rb * 16 + rl) * 128u;            // ablation: consecutive rows (conflict-free pattern)
                 const unsigned swz4 = (v >> 4) & 0x70u;                      // ((window row >> 1) & 7) << 4
                 const unsigned a0 = wb_a + v + (g4 ^ swz4);
                 dst[rb][0] = *(lds_frag_ptr)a0;
@@ -1507,10 +1508,11 @@ __global__ __launch_bounds__(256, 1) void ggreg_kernel(
         load_tab(0, ev[0]);
         load_tab(1, ev[1]);
         fetch(ev[0], xa[0]);
+        if (dbg & 16) fetch(ev[1], xa[1]);                                   // ablation: operands fetched once per tile
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k + 1 < K) fetch(ev[(k + 1) & 1], xa[(k + 1) & 1]);
-            if (k + 2 < K) load_tab(k + 2, ev[k & 1]);
+            if (k + 1 < K && !(dbg & 16)) fetch(ev[(k + 1) & 1], xa[(k + 1) & 1]);
+            if (k + 2 < K && !(dbg & 16)) load_tab(k + 2, ev[k & 1]);
             if (!(dbg & 4)) {
 #pragma unroll
                 for (int cs = 0; cs < 2; ++cs)
