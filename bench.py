@@ -69,6 +69,7 @@ def parse():
                     help="BASELINE config 5 as a TRAINING step: SECOND's plain VoxelBackBone8x on 300k-point clouds "
                          "(120 beams x 2500 az) with the fp8 (e4m3) forward convs of com_amd.spconv.fp8, bf16 backward")
     ap.add_argument("--no-fp8", action="store_true", help="skip the child run that measures --config5")
+    ap.add_argument("--no-regime", action="store_true", help="skip the rulebook bandwidth-regime child run (B = 4 and B = 32)")
     ap.add_argument("--no-stage2", action="store_true", help="skip the PV-RCNN stage-2 (config 4) secondary figure")
     ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
     ap.add_argument("--selftest-launch", action="store_true",
@@ -494,6 +495,27 @@ def measure_stage2(B, dev):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def measure_regime():
+    """`roofline.rulebook`: the rulebook chain of one forward pass (9 builds) at B = 4 (reference batch) and B = 32 (the
+    bandwidth regime SURVEY 8d asks for), algorithmic bytes 16 N_in + 8 P (+ 16 N_out) over the time of the builds
+    replayed from a hipGraph, as fractions of the 8 TB/s HBM peak -- tools/regime.py run as a child process."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "regime.py"), "4", "32"], cwd=ROOT,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        rows = [json.loads(l) for l in out.stdout.decode().splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not rows:
+            return {"error": f"rc {out.returncode}: {out.stderr.decode()[-300:]}"}
+        res = {"unit": "fraction of 8 TB/s over SURVEY 8d's algorithmic bytes", "north_star_floor": 0.60}
+        for r in rows:
+            res[f"B{r['frames']}"] = {"chain_us_graph": r["rulebook_chain_graph_us"], "chain_us_eager": r["rulebook_chain_us"],
+                                      "alg_MB": r["alg_MB"], "GBps_graph": r["graph_GBps"], "frac": r["graph_frac_of_8TBps"],
+                                      "builds_us_graph": {f"{b['kind']}_L{b['level']}": b["graph_us"] for b in r["builds"]}}
+        return res
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def measure_full_model(args, flags=("--dense-head", "--com"), what=None):
     """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
     run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
@@ -502,7 +524,7 @@ def measure_full_model(args, flags=("--dense-head", "--com"), what=None):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), *flags, "--gpus", "1", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8"]
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-regime"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -1059,6 +1081,10 @@ def main():
         roof = measure_roofline(lambda: eager_step(0), ms_per_step)   # every rank runs the extra step (collectives inside)
         if rank == 0:
             result["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_regime and not args.no_roofline and not args.dense_head and not args.config5 \
+            and result.get("roofline"):
+        torch.cuda.synchronize()
+        result["roofline"]["rulebook"] = measure_regime()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
     if rank == 0 and world == 1 and not args.no_stage2 and not args.dense_head and not args.config5:
