@@ -184,7 +184,7 @@ class SparseConvolution(SparseModule):
         if fp8 is not None and not (self.training and torch.is_grad_enabled()):
             fp8 = None                                  # (the fp8-forward training form; inference has Fp8Backbone)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad,
-                                passthrough, fp8)
+                                passthrough, **({"fp8": fp8} if fp8 is not None else {}))
         ident = None
         if passthrough:
             feats, ident = feats
