@@ -181,6 +181,123 @@ __global__ __launch_bounds__(1024) void stack_fps_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// COOPERATIVE farthest point sampling for large frames (VoxelSetAbstraction samples 4096 keypoints from ~160 k raw
+// points per frame, voxel_set_abstraction.py:236-263): the reference -- and stack_fps_kernel above -- give ONE
+// workgroup per frame 4095 dependent passes over all of the frame's points (~30 us each at 160 k points: 120 ms).
+// Here G workgroups share a frame: each keeps a slice of the points and their running distances in LDS, finds its
+// local farthest point, publishes (distance, index) and meets the others at a per-frame barrier (a monotonic
+// arrival counter, agent scope); every workgroup then reduces the G candidates itself.  The argmax key is the TOTAL
+// order fps_better (distance, then the reference tree's bit-reversed thread id, then the index), so the selected points
+// are the reference's whatever the partition.  All B x G workgroups must be resident at once (the host keeps
+// B x G <= 256 with one workgroup per CU); the spin is bounded and raises `err` instead of hanging the device.
+constexpr int FPS_COOP_MAXG = 64;
+
+__global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ xyz_cnt,
+                                                             int32_t *__restrict__ idxs,
+                                                             const int32_t *__restrict__ num_sampled, int G, int slice_cap,
+                                                             unsigned long long *__restrict__ cand, unsigned *__restrict__ counters,
+                                                             int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) float fps_lds[];
+    float *px = fps_lds, *py = px + slice_cap, *pz = py + slice_cap, *tmp = pz + slice_cap;
+    __shared__ float wd[4];
+    __shared__ int wk[4];
+    __shared__ int old_s;
+    const int b = blockIdx.x / G, gi = blockIdx.x - b * G;
+    int start = 0, ostart = 0;
+    for (int k = 0; k < b; ++k) {
+        start += xyz_cnt[k];
+        ostart += num_sampled[k];
+    }
+    const int n = xyz_cnt[b], m = num_sampled[b];
+    const float *pts = xyz + (size_t)start * 3;
+    int32_t *out = idxs + ostart;
+    const int per = (n + G - 1) / G;
+    const int lo = min(n, gi * per), hi = min(n, lo + per);
+    const int cnt = hi - lo;                                // <= slice_cap (checked by the host against max_cnt)
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int k = tid; k < cnt; k += 256) {
+        px[k] = pts[(size_t)(lo + k) * 3];
+        py[k] = pts[(size_t)(lo + k) * 3 + 1];
+        pz[k] = pts[(size_t)(lo + k) * 3 + 2];
+        tmp[k] = 1e10f;
+    }
+    if (gi == 0 && tid == 0 && m > 0) out[0] = start;
+    __syncthreads();
+    unsigned long long *cb = cand + (size_t)b * 2 * FPS_COOP_MAXG;
+    unsigned *ctr = counters + b * 32;                      // one counter per 128-byte line
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = pts[(size_t)old * 3], y1 = pts[(size_t)old * 3 + 1], z1 = pts[(size_t)old * 3 + 2];
+        FpsBest best = {-1.0f, tid};                       // (never wins: every real distance is >= 0)
+        for (int k = tid; k < cnt; k += 256) {
+            const float x2 = px[k], y2 = py[k], z2 = pz[k];
+            const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+            const float d2 = fminf(d, tmp[k]);
+            tmp[k] = d2;
+            const FpsBest c = {d2, lo + k};
+            if (fps_better(c, best)) best = c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            FpsBest o;
+            o.d = __shfl_xor(best.d, off);
+            o.k = __shfl_xor(best.k, off);
+            if (fps_better(o, best)) best = o;
+        }
+        if ((tid & 63) == 0) {
+            wd[wave] = best.d;
+            wk[wave] = best.k;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            FpsBest v = {wd[0], wk[0]};
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const FpsBest o = {wd[w], wk[w]};
+                if (fps_better(o, v)) v = o;
+            }
+            const unsigned long long packed = ((unsigned long long)__float_as_uint(v.d) << 32) | (unsigned)v.k;
+            __hip_atomic_store(cb + (j & 1) * FPS_COOP_MAXG + gi, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidate is at the coherence point ...
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the arrival
+            const unsigned want = (unsigned)G * (unsigned)j;
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {                               // ~ seconds: a workgroup of the frame is not resident
+                    *err = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            FpsBest v = {-2.0f, 0x7fffffff};
+            if (tid < G) {
+                const unsigned long long pk = __hip_atomic_load(cb + (j & 1) * FPS_COOP_MAXG + tid, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                v.d = __uint_as_float((unsigned)(pk >> 32));
+                v.k = (int)(unsigned)pk;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                FpsBest o;
+                o.d = __shfl_xor(v.d, off);
+                o.k = __shfl_xor(v.k, off);
+                if (fps_better(o, v)) v = o;
+            }
+            if (tid == 0) {
+                old_s = v.k;
+                if (gi == 0) out[j] = v.k + start;
+            }
+        }
+        __syncthreads();
+        old = old_s;
+        if (*err) return;                                               // (uniform enough: everyone leaves within an iteration)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct Nn3 {
     float d[3];
     int k[3];
@@ -365,6 +482,44 @@ extern "C" int pcd_stack_farthest_point_sampling(int B, const float *xyz, float 
     PCD_ENTER();
     if (B <= 0 || !xyz || !temp_1e10 || !xyz_batch_cnt || !idxs || !num_sampled_points) return PCD_ERR_INVALID_ARG;
     stack_fps_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(xyz, temp_1e10, xyz_batch_cnt, idxs, num_sampled_points);
+    PN2_CHECK_LAUNCH();
+}
+
+extern "C" size_t pcd_stack_fps_coop_workspace_bytes(int B) {
+    if (B <= 0) return 0;
+    return ws_piece((size_t)B * 2 * FPS_COOP_MAXG, sizeof(unsigned long long)) + ws_piece((size_t)B * 32, sizeof(unsigned)) + 256;
+}
+
+// max_cnt_host: an upper bound of every frame's point count (the host knows it: the counts come from its collate step).
+// Returns PCD_ERR_UNSUPPORTED when the cooperative form does not apply (too many frames for one workgroup per CU):
+// call pcd_stack_farthest_point_sampling then.
+extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, const int32_t *xyz_batch_cnt, int32_t *idxs,
+                                                      const int32_t *num_sampled_points, int max_cnt_host, void *workspace,
+                                                      size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (B <= 0 || !xyz || !xyz_batch_cnt || !idxs || !num_sampled_points || max_cnt_host <= 0) return PCD_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < pcd_stack_fps_coop_workspace_bytes(B)) return PCD_ERR_WORKSPACE;
+    int G = 256 / B;
+    if (G > FPS_COOP_MAXG) G = FPS_COOP_MAXG;
+    if (G < 2) return PCD_ERR_UNSUPPORTED;
+    const int slice_cap = pcd_div_up(max_cnt_host, G);
+    const size_t lds = (size_t)slice_cap * 16;
+    if (lds > 96 * 1024) return PCD_ERR_UNSUPPORTED;          // (keeps one workgroup per CU; 393 k points per frame at G = 64)
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    unsigned long long *cand = (unsigned long long *)w;
+    unsigned *counters = (unsigned *)(w + ws_piece((size_t)B * 2 * FPS_COOP_MAXG, sizeof(unsigned long long)));
+    int *err = (int *)((char *)counters + ws_piece((size_t)B * 32, sizeof(unsigned)));
+    pcd_fill(counters, 0, ws_piece((size_t)B * 32, sizeof(unsigned)) + 256, st);
+    static size_t raised = 0;
+    if (raised < lds) {
+        if (hipFuncSetAttribute((const void *)stack_fps_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return PCD_ERR_LAUNCH;
+        raised = lds;
+    }
+    stack_fps_coop_kernel<<<B * G, 256, lds, st>>>(xyz, xyz_batch_cnt, idxs, num_sampled_points, G, slice_cap, cand, counters,
+                                                  err);
     PN2_CHECK_LAUNCH();
 }
 

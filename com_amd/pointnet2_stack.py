@@ -89,6 +89,10 @@ class QueryAndGroup(nn.Module):
         return new_features, idx
 
 
+COOP_FPS_MIN_POINTS = 16384     # frames at least this large take the cooperative kernel
+FPS_CHECK_ERR = True            # read the barrier-timeout flag back (one host sync; FPS is an eager op)
+
+
 class StackFarthestPointSampling(Function):
     @staticmethod
     def forward(ctx, xyz, xyz_batch_cnt, npoint):
@@ -100,10 +104,24 @@ class StackFarthestPointSampling(Function):
                 npoint = [npoint for _ in range(B)]
             npoint = torch.tensor(npoint, device=xyz.device).int()
         npoint = _i32(npoint)
-        temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
         out = torch.empty((int(npoint.sum().item()),), dtype=torch.int32, device=xyz.device)
-        L.check(L.lib().pcd_stack_farthest_point_sampling(B, L.ptr(xyz.float()), L.ptr(temp), L.ptr(_i32(xyz_batch_cnt)),
-                                                          L.ptr(out), L.ptr(npoint), L.stream_ptr()),
+        cnt = _i32(xyz_batch_cnt)
+        lib = L.lib()
+        max_cnt = int(cnt.max().item()) if B > 0 else 0
+        if max_cnt >= COOP_FPS_MIN_POINTS:
+            # large frames: 256 / B workgroups share a frame (same selected points; see pointnet2.hip)
+            ws = torch.empty((int(lib.pcd_stack_fps_coop_workspace_bytes(B)),), dtype=torch.uint8, device=xyz.device)
+            rc = lib.pcd_stack_farthest_point_sampling_coop(B, L.ptr(xyz.float()), L.ptr(cnt), L.ptr(out), L.ptr(npoint),
+                                                            max_cnt, L.ptr(ws), ws.numel(), L.stream_ptr())
+            if rc == 0:
+                if FPS_CHECK_ERR and int(ws[-256:].view(torch.int32)[0].item()) != 0:
+                    raise L.PcdError("cooperative FPS: a workgroup of a frame was not resident (barrier timed out)")
+                return out
+            if rc != -2:                                       # PCD_ERR_UNSUPPORTED: too many frames / slice too large
+                L.check(rc, "pcd_stack_farthest_point_sampling_coop")
+        temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
+        L.check(lib.pcd_stack_farthest_point_sampling(B, L.ptr(xyz.float()), L.ptr(temp), L.ptr(cnt),
+                                                      L.ptr(out), L.ptr(npoint), L.stream_ptr()),
                 "pcd_stack_farthest_point_sampling")
         return out
 

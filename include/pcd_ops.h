@@ -608,6 +608,13 @@ int pcd_group_points_stack_grad(int B, int M, int C, int nsample, const float *g
                                 float *grad_features_zeroed, void *stream);
 int pcd_stack_farthest_point_sampling(int B, const float *xyz, float *temp_1e10, const int32_t *xyz_batch_cnt,
                                       int32_t *idxs, const int32_t *num_sampled_points, void *stream);
+/* cooperative form for large frames (4096 keypoints of ~160 k raw points, voxel_set_abstraction.py:236-263): 256 / B (<= 64)
+ * workgroups share a frame, same selected points (same total order of the argmax); PCD_ERR_UNSUPPORTED when B > 128 or a
+ * frame's slice does not fit LDS -- fall back to the call above.  max_cnt_host >= every frame's point count. */
+size_t pcd_stack_fps_coop_workspace_bytes(int B);
+int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, const int32_t *xyz_batch_cnt, int32_t *idxs,
+                                           const int32_t *num_sampled_points, int max_cnt_host, void *workspace,
+                                           size_t workspace_bytes, void *stream);
 int pcd_three_nn_stack(int B, int N, const float *unknown, const int32_t *unknown_batch_cnt, const float *known,
                        const int32_t *known_batch_cnt, float *dist2, int32_t *idx, void *stream);
 int pcd_three_interpolate_stack(int N, int C, const float *features, const int32_t *idx, const float *weight, float *out,

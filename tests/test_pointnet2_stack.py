@@ -131,3 +131,28 @@ def test_gpu_voxel_query_matches_oracle():
         ridx, rempty = O.voxel_query_stack(rng_, radius, ns, xyz, new_xyz, new_coords, p2v)
         np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
         np.testing.assert_array_equal(empty.cpu().numpy(), rempty)
+
+
+@pytest.mark.gpu
+def test_gpu_cooperative_fps_matches_oracle_and_single_workgroup_kernel():
+    """Frames >= 16 k points take the cooperative kernel (256 / B workgroups per frame): same indices as the oracle
+    (reference tie rule) incl. exact ties, ragged frame sizes, an odd number of frames, and as the one-workgroup kernel."""
+    import torch
+    from com_amd import pointnet2_stack as P
+    rng = np.random.default_rng(12)
+    cnt = [40000, 17001, 23000]
+    xyz = _cloud(rng, cnt, 60.0)
+    xyz[100:140] = xyz[100]                        # duplicated points -> exact distance ties
+    xyz[45000:45200] = np.round(xyz[45000:45200])  # lattice points -> many equal distances
+    npoint = [300, 64, 257]
+    t = torch.from_numpy(xyz).cuda()
+    c = torch.tensor(cnt, dtype=torch.int32).cuda()
+    got = P.stack_farthest_point_sample(t, c, npoint)
+    np.testing.assert_array_equal(got.cpu().numpy(), O.stack_fps(xyz, cnt, npoint))
+    keep = P.COOP_FPS_MIN_POINTS
+    try:
+        P.COOP_FPS_MIN_POINTS = 1 << 30            # force the one-workgroup kernel
+        ref = P.stack_farthest_point_sample(t, c, npoint)
+    finally:
+        P.COOP_FPS_MIN_POINTS = keep
+    assert torch.equal(got, ref)
