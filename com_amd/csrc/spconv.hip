@@ -2591,7 +2591,8 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     //   else                    -> double-buffered stages of SG steps
     // Narrow layers (NB 1/2, 300k+ rows): short look-ahead, many waves per SIMD.
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
-    const bool resident = wbytes <= 32 * 1024;
+    static const size_t resident_kb = getenv("PCD_GG_RESIDENT_KB") ? (size_t)atoi(getenv("PCD_GG_RESIDENT_KB")) : 32;
+    const bool resident = wbytes <= resident_kb * 1024;
     // Wide layers: a contraction step lasts one memory latency (~3.7k clk measured at 128 channels: the gathers
     // and the weight stage are fetched one step ahead of ~256 clk of MFMA work), so two steps of look-ahead with
     // 32 rows per wave win once the register budget is sized for them (gg_waves: 3-4 waves per SIMD, no spills):
