@@ -6,3 +6,4 @@ from .data import VoxelGeneratorWrapper, collate_points, transform_points_to_vox
 from .map_to_bev import HeightCompression, PointPillarScatter  # noqa: F401
 from .vfe import DynamicMeanVFE, DynamicPillarVFE, MeanVFE, PillarVFE  # noqa: F401
 from .dense2d import BaseBEVBackbone, CenterHeadTowers, SeparateHead  # noqa: F401
+from .curriculum_head import CurriculumCenterHead, CurriculumCenterHead_x5  # noqa: F401

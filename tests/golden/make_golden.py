@@ -898,6 +898,32 @@ def g14():
          single_rank0=single)
 
 
+def g15():
+    """Box decoding by the REFERENCE's own `decode_bbox_from_heatmap` (+ `_topk`, `_transpose_and_gather_feat`;
+    pcdet/models/model_utils/centernet_utils.py:181-279, imported with an empty `numba` stand-in) on random head maps of a
+    2-frame batch, K = 40, score threshold 0.1, the POST_CENTER_LIMIT_RANGE of the COM configs."""
+    sys.modules.setdefault("numba", types.SimpleNamespace(jit=lambda *a, **k: (lambda f: f)))
+    cu = ref_module("pcdet/models/model_utils", "centernet_utils", "refmu")
+    rng = np.random.default_rng(15)
+    B, C, H, W, K = 2, 3, 47, 47, 40
+    t = lambda *sh, s=1.0: torch.from_numpy((rng.standard_normal(sh) * s).astype(np.float32))
+    hm = torch.sigmoid(t(B, C, H, W, s=2.0) - 2.0)
+    rot, center, center_z, dim = t(B, 2, H, W), torch.rand(B, 2, H, W), t(B, 1, H, W), torch.exp(t(B, 3, H, W, s=0.3))
+    limit = torch.tensor([-80, -80, -10.0, 80, 80, 10.0]).float()
+    out = cu.decode_bbox_from_heatmap(heatmap=hm, rot_cos=rot[:, 0:1], rot_sin=rot[:, 1:2], center=center, center_z=center_z,
+                                      dim=dim, point_cloud_range=list(synth.WAYMO_RANGE), voxel_size=list(synth.WAYMO_VOXEL),
+                                      feature_map_stride=32, K=K, circle_nms=False, score_thresh=0.1,
+                                      post_center_limit_range=limit)
+    arrays = dict(hm=hm.numpy(), rot=rot.numpy(), center=center.numpy(), center_z=center_z.numpy(), dim=dim.numpy(),
+                  K=np.array([K], np.int32), stride=np.array([32], np.int32), limit=limit.numpy())
+    for k, d in enumerate(out):
+        arrays[f"boxes{k}"] = d["pred_boxes"].numpy()
+        arrays[f"scores{k}"] = d["pred_scores"].numpy()
+        arrays[f"labels{k}"] = d["pred_labels"].numpy()
+    assert all(len(d["pred_boxes"]) > 5 for d in out)
+    save("g15_decode", **arrays)
+
+
 def g13():
     """Rotated BEV IoU by the REFERENCE ITSELF: pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp compiled unmodified into
     oracle/_ref/libiou3d_ref.so (oracle/ref_build/Makefile), `boxes_iou_bev_cpu` (:232-252) on 150 x 120 random boxes
@@ -928,7 +954,7 @@ if __name__ == "__main__":
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
