@@ -1611,6 +1611,299 @@ __global__ __launch_bounds__(256, 1) void ggreg_kernel(
     zero_surplus();
 }
 
+// ---------------------------------------------------------------------------------------------
+// WAVE-LEVEL window gather-GEMM: SubM 3x3x3, 32 -> 32, key-ordered rows.  The lesson of ggwin / ggreg (one wave per SIMD
+// cannot hide a per-tile serial section) turned around: every WAVE is its own pipeline -- it owns 32-row tiles, DMAs its
+// own three windows (48 rows x 64 B each) into a private LDS area, waits only for its own DMAs (no workgroup barrier in
+// the loop) and computes the 27 offsets from LDS; the 54 KB of packed weights are resident in LDS for the whole
+// (persistent) workgroup.  8 waves per CU run these pipelines out of phase, which is what hides the latencies.
+constexpr int GWV_ROWS = 32, GWV_WCAP = 48, GWV_WAVES = 8;
+constexpr int GWV_WIN_B = GWV_WCAP * 64;                   // bytes per window (64-byte rows)
+constexpr int GWV_QSTRIDE = GWV_WIN_B + 256;               // a zero row (window row -1) in front of every window, 256-byte aligned
+constexpr int GWV_WAVE_B = 3 * GWV_QSTRIDE;                // a wave's three windows (9984 B)
+constexpr int GWV_W_BYTES = 27 * 2 * 1024;                 // packed weights: 27 offsets x 2 channel blocks x 1 KiB
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(64 * GWV_WAVES, 2) void ggwave_kernel(
+    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
+    int n_in, void *__restrict__ yv, unsigned x_bytes, const void *__restrict__ addend, BnRed bn, int dbg) {
+    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
+    constexpr int K = 27, GRP = 9, c_out = 32, ROWS = GWV_ROWS, WCAP = GWV_WCAP, WIN_B = GWV_WIN_B;
+    const int n_out = eff_rows(n_out_dev, n_out_cap);
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    char *wlds = smem + GGR_SCRATCH;                        // [27][2][64 lanes][16 B]
+    char *wins = wlds + GWV_W_BYTES;                        // [waves][GWV_WAVE_B]
+    float *red_s = (float *)smem;                           // [waves][2][c_out] inside the scratch head (end of kernel only)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    // weights -> LDS once (lane-linear image of the packed fragments)
+    for (int e = threadIdx.x; e < GWV_W_BYTES / 16; e += 64 * GWV_WAVES)
+        reinterpret_cast<uint4 *>(wlds)[e] = wp[e];
+    char *mywin = wins + wave * GWV_WAVE_B;
+    // window q of this wave: rows 0 .. WCAP - 1 at mywin + q * QSTRIDE + 256; the 64 bytes in front of row 0 are zeros
+    // ("window row -1" = a missing neighbour: no select in the operand address)
+    if (lane < 48) reinterpret_cast<int *>(mywin + (lane >> 4) * GWV_QSTRIDE + 192)[lane & 15] = 0;
+    __syncthreads();
+    const unsigned w_a = lds0 + (unsigned)(wlds - smem) + (unsigned)lane * 16u;
+    const unsigned win_a = lds0 + (unsigned)(mywin - smem) + 256u;                 // row 0 of window 0
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
+    // tiles: contiguous runs per wave, XCD by XCD (workgroup b runs on XCD b % 8)
+    const int n_tiles = (n_out + ROWS - 1) / ROWS;
+    const int nwv = gridDim.x * GWV_WAVES;
+    const int chunk = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * GWV_WAVES + wave;
+    const int per = (n_tiles + nwv - 1) / nwv;
+    const int t_begin = min(n_tiles, chunk * per), t_end = min(n_tiles, t_begin + per);
+    float bs[8], bq[8];                                     // BatchNorm column sums of this wave (channels g * 8 .. + 7)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = bq[j] = 0.0f;
+    const int col = g * 8;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[col + j] : 0.0f;
+    // minimum / maximum over the 16 lanes of a DPP row (every row of 16 lanes holds all 32 rows of the tile: no cross-row step)
+    auto row16_min = [](int v) {
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));     // row_ror:4
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));     // row_ror:8
+        return v;
+    };
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int row0 = tile * ROWS;
+        // neighbour indices in FRAGMENT mapping: ix[k][mi] = nbr[k][row0 + mi * 16 + rl] (the 4 lane groups load the same words)
+        int ix[K][2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int krow = flip ? (K - 1 - k) : k;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = row0 + mi * 16 + rl;
+                const unsigned off = row < n_out ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+                const int v = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
+                ix[k][mi] = row < n_out ? v : -1;
+            }
+        }
+        // window starts (multiples of 4) and whether every neighbour lies inside its window
+        int wlo[3];
+        bool fits = true;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int lo = 0x7fffffff, nhi = 0x7fffffff;           // nhi = -(max valid index) - 1 (so that one kind of reduction serves)
+#pragma unroll
+            for (int j = 0; j < GRP; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int t = ix[q * GRP + j][mi];
+                    lo = min(lo, t >= 0 ? t : 0x7fffffff);
+                    nhi = min(nhi, ~t);                       // ~t = -t - 1; t = -1 -> 0 (index "-1"), harmless
+                }
+            lo = row16_min(lo);
+            nhi = row16_min(nhi);
+            wlo[q] = lo == 0x7fffffff ? 0 : (lo & ~3);
+            fits = fits && (~nhi - wlo[q] < WCAP);
+        }
+        // windows -> the wave's LDS area: instruction j moves rows 16 j + (lane >> 2), 16-byte piece (lane & 3) ^ ((row >> 2) & 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the previous tile's operand reads are done)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < WCAP / 16; ++j) {
+                const int wr = 16 * j + (lane >> 2);
+                const int src = wlo[q] + wr;
+                const unsigned piece = (unsigned)(lane & 3) ^ ((unsigned)(wr >> 2) & 3u);
+                unsigned off = (unsigned)src * 64u + piece * 16u;
+                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;
+                glds16(xrsrc, mywin + q * GWV_QSTRIDE + 256 + 16 * j * 64, off);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's own DMAs: no barrier, nobody else reads them
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (__builtin_amdgcn_ballot_w64(!fits) == 0ull) {
+            // FAST path (every neighbour inside its window): operand address = 7 integer instructions, no selects --
+            // window row w = max(index - lo, -1) (row -1 = zeros), byte = w * 64 + ((g ^ ((w >> 2) & 3)) << 4)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int q = k / GRP;
+                bf16x8 xa[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int w = max(ix[k][mi] - wlo[q], -1);
+                    const unsigned p = ((unsigned)g ^ ((unsigned)(w >> 2) & 3u)) << 4;
+                    xa[mi] = *(lds_frag_ptr)(win_a + (unsigned)(q * GWV_QSTRIDE) + (unsigned)(w * 64) + p);
+                }
+                if (!(dbg & 4)) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const bf16x8 bw = *(lds_frag_ptr)(w_a + (unsigned)((k * 2 + nb) * 1024));
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, xa[mi], acc[mi][nb], 0, 0, 0);
+                    }
+                } else {
+                    acc[0][0][0] += (float)xa[0][0] + (float)xa[1][0];
+                }
+            }
+        } else {
+            // rare (a tile straddling a frame / z boundary, very long lines): operands straight from global memory
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                int i0 = 0, i1 = 0;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk)
+                    if (kk == k) {
+                        i0 = ix[kk][0];
+                        i1 = ix[kk][1];
+                    }
+                const bf16x8 zero = {};
+                bf16x8 xa[2];
+                xa[0] = i0 >= 0 ? reinterpret_cast<const bf16x8 *>(x + (size_t)i0 * 32)[g] : zero;
+                xa[1] = i1 >= 0 ? reinterpret_cast<const bf16x8 *>(x + (size_t)i1 * 32)[g] : zero;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const bf16x8 bw = *(lds_frag_ptr)(w_a + (unsigned)((k * 2 + nb) * 1024));
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, xa[mi], acc[mi][nb], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: lane (g, rl) holds channels g * 8 + nb * 4 + j of rows mi * 16 + rl (Q = 2 interleave of the packs)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = row0 + mi * 16 + rl;
+            if (row >= n_out) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[mi][j >> 2][j & 3] + bv[j];
+            const size_t at = (size_t)row * c_out + col;
+            if (OUT_BF16) {
+                if (addend) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>((const unsigned short *)addend + at);
+                    const u32 tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[2 * j] += __uint_as_float(tw[j] << 16);
+                        v[2 * j + 1] += __uint_as_float(tw[j] & 0xffff0000u);
+                    }
+                }
+                u32 o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+                *reinterpret_cast<uint4 *>((unsigned short *)yv + at) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (bn.mode) {
+                    float d[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        d[2 * j] = __uint_as_float(o[j] << 16);
+                        d[2 * j + 1] = __uint_as_float(o[j] & 0xffff0000u);
+                    }
+                    if (bn.mode == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            bs[j] += d[j];
+                            bq[j] += d[j] * d[j];
+                        }
+                    } else {
+                        const uint4 tx = *reinterpret_cast<const uint4 *>(bn.x + at);
+                        const u32 xw[4] = {tx.x, tx.y, tx.z, tx.w};
+                        u32 yw[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                        if (bn.relu) {
+                            const uint4 ty = *reinterpret_cast<const uint4 *>(bn.y + at);
+                            yw[0] = ty.x; yw[1] = ty.y; yw[2] = ty.z; yw[3] = ty.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xv = (j & 1) ? __uint_as_float(xw[j >> 1] & 0xffff0000u) : __uint_as_float(xw[j >> 1] << 16);
+                            const float tv = (j & 1) ? __uint_as_float(yw[j >> 1] & 0xffff0000u) : __uint_as_float(yw[j >> 1] << 16);
+                            const float dz = (bn.relu && !(tv > 0.0f)) ? 0.0f : d[j];
+                            bs[j] += dz;
+                            bq[j] += dz * xv;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4 o = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+                    if (addend) {
+                        const float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + at + 4 * u);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                    }
+                    *reinterpret_cast<float4 *>((float *)yv + at + 4 * u) = o;
+                }
+            }
+        }
+    }
+    if (OUT_BF16 && bn.mode) {          // ONE partial row per workgroup: the waves' sums over all their tiles
+        if (bn.mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[j] = (bq[j] - bn.mean[col + j] * bs[j]) * bn.invstd[col + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bs[j] = row16_sum(bs[j]);
+            bq[j] = row16_sum(bq[j]);
+        }
+        __syncthreads();                 // (the scratch head is free: every wave has left its loop)
+        if (rl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red_s[(wave * 2 + 0) * c_out + col + j] = bs[j];
+                red_s[(wave * 2 + 1) * c_out + col + j] = bq[j];
+            }
+        }
+        __syncthreads();
+        float mine = 0.0f;
+        if (threadIdx.x < 2 * c_out)
+            for (int w = 0; w < GWV_WAVES; ++w) mine += red_s[(w * 2 + (threadIdx.x / c_out)) * c_out + (threadIdx.x % c_out)];
+        __syncthreads();
+        bnred_publish(bn, (int)blockIdx.x, c_out, [&](int) { return mine; });
+    }
+}
+
+static int ggwave_grid() { return 256; }                   // one persistent workgroup (8 independent waves) per CU
+
+static int launch_ggwave(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
+                         int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
+                         hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
+    const int grid = ggwave_grid();
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, 32, grid, &bn)) return rc;
+    const size_t lds = (size_t)GGR_SCRATCH + GWV_W_BYTES + (size_t)GWV_WAVES * GWV_WAVE_B;
+    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
+    auto kb = ggwave_kernel<true>;
+    auto kf = ggwave_kernel<false>;
+    static size_t raised[2] = {0, 0};
+    const int which = y_dtype == PCD_BF16 ? 0 : 1;
+    if (raised[which] < lds) {
+        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PCD_ERR_LAUNCH;
+        raised[which] = lds;
+    }
+    if (y_dtype == PCD_BF16)
+        kb<<<grid, 64 * GWV_WAVES, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                              n_out_dev, n_in, y, x_bytes, addend, bn, dbg);
+    else
+        kf<<<grid, 64 * GWV_WAVES, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
+                                              n_out_dev, n_in, y, x_bytes, addend, bn, dbg);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
 // grid of the persistent kernel for a capacity of n_out rows: one workgroup per CU unless its run would exceed SMAX tiles
 static int ggreg_grid(int n_out) {
     const int n_sub = pcd_div_up(n_out, GGR_ROWS);
@@ -2605,6 +2898,16 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
     //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
     const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
+    // SubM 3x3x3, 32 -> 32 (n_in == n_out): the wave-level window kernel (PCD_GGWAVE=1)
+    static const int ggwave_mode = getenv("PCD_GGWAVE") ? atoi(getenv("PCD_GGWAVE")) : 0;
+    if (ggwave_mode && c_in == 32 && c_out == 32 && kvol == 27 && n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
+        if (tiles_only && tiles_only[0] == -12345) {
+            tiles_only[0] = 3;
+            return PCD_OK;
+        }
+        return launch_ggwave(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype,
+                             x_bytes, st, addend, bnr, tiles_only);
+    }
     // SubM 3x3x3, 64 -> 64 (n_in == n_out): the window kernel (PCD_GGWIN=0 turns it off, =3 uses 48 rows per wave)
     static const int ggwin_mode = getenv("PCD_GGWIN") ? atoi(getenv("PCD_GGWIN")) : 0;
     if (tiles_only && tiles_only[0] == -12345 && ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 &&

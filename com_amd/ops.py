@@ -804,7 +804,7 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     if PROFILE is not None:
         dg = int(bool(flip_k) or (bn_reduce is not None and bn_reduce.mode == 2))
         variant = L.lib().pcd_sparse_conv_gather_gemm_variant(x.shape[0], x.shape[1], kvol, n_rows_out, c_out, dg)
-        kname = {1: "ggw_kernel", 2: "ggwin_kernel"}.get(variant, kname)
+        kname = {1: "ggw_kernel", 2: "ggwin_kernel", 3: "ggwave_kernel"}.get(variant, kname)
     with _Timed(f"{kname}<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
         L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
                                                     L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,

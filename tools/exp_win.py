@@ -11,8 +11,8 @@ frames = [synth.synth_cloud(f) for f in range(B)]
 pts, offs = hotpath.collate_points(frames, dev)
 res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5, want_voxels=False)
 idx, shape = res['coords'], [41, 1504, 1504]
-CH = 64
-for geo in ((3, 2, 1), (3, 2, 1)):
+CH = int(os.environ.get("EXP_CH", "64"))
+for geo in ((3, 2, 1), (3, 2, 1))[:2 if CH == 64 else 1]:
     rb = ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2]); idx, shape = rb.out_indices, rb.out_shape
 n = idx.shape[0]
 rb = ops.rulebook_subm(idx, B, shape)
@@ -38,5 +38,5 @@ h = {k: hashlib.sha256(v.cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[
 pairs = int(rb.pair_num.sum())
 us = t(lambda: ops.gather_gemm(x, pw, None, rb.nbr_out, 27, False, n, CH, torch.bfloat16))
 usd = t(lambda: ops.gather_gemm(x, pd, None, rb.nbr_out, 27, True, n, CH, torch.bfloat16, addend=add))
-print("GGWIN=" + os.environ.get('PCD_GGWIN', '-'), "DBG=" + os.environ.get("PCD_GGW_DBG", "0"), f"rows {n} pairs {pairs}: fwd {us:.1f} us dgrad {usd:.1f} us -> "
+print(f"CH={CH} GGWAVE=" + os.environ.get('PCD_GGWAVE', '-') + " GGWIN=" + os.environ.get('PCD_GGWIN', '-'), "DBG=" + os.environ.get("PCD_GGW_DBG", "0"), f"rows {n} pairs {pairs}: fwd {us:.1f} us dgrad {usd:.1f} us -> "
       f"{2*pairs*CH*CH/us*1e-6:.0f} TFLOP/s", h, "finite", bool(torch.isfinite(outs['fwd'].float()).all()), flush=True)
