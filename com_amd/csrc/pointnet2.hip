@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__rest
     if (gi == 0 && tid == 0 && m > 0) out[0] = start;
     __syncthreads();
     unsigned long long *cb = cand + (size_t)b * 2 * FPS_COOP_MAXG;
-    unsigned *ctr = counters + b * 32;                      // one counter per 128-byte line
+    (void)counters;
     int old = 0;
     for (int j = 1; j < m; ++j) {
         const float x1 = pts[(size_t)old * 3], y1 = pts[(size_t)old * 3 + 1], z1 = pts[(size_t)old * 3 + 2];
@@ -256,29 +256,34 @@ __global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__rest
                 const FpsBest o = {wd[w], wk[w]};
                 if (fps_better(o, v)) v = o;
             }
-            const unsigned long long packed = ((unsigned long long)__float_as_uint(v.d) << 32) | (unsigned)v.k;
+            // one 64-bit word per candidate: [63:52] iteration tag, [51:20] distance bits, [19:0] frame-local index
+            const unsigned long long packed = ((unsigned long long)(j & 0xFFF) << 52) |
+                                              ((unsigned long long)__float_as_uint(v.d) << 20) | (unsigned)(v.k & 0xFFFFF);
             __hip_atomic_store(cb + (j & 1) * FPS_COOP_MAXG + gi, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the candidate is at the coherence point ...
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the arrival
-            const unsigned want = (unsigned)G * (unsigned)j;
+        }
+        // every workgroup polls the G slots of this iteration's buffer until all carry the tag j (ONE round trip per
+        // iteration: no arrival counter).  Buffer parity: a slot is rewritten at iteration j + 2 at the earliest, which
+        // needs every workgroup's candidate j + 1, i.e. every workgroup has finished reading iteration j.
+        if (tid < 64) {
+            FpsBest v = {-2.0f, 0x7fffffff};
             int spins = 0;
-            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            for (;;) {
+                bool ok = true;
+                if (tid < G) {
+                    const unsigned long long pk = __hip_atomic_load(cb + (j & 1) * FPS_COOP_MAXG + tid, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (int)(pk >> 52) == (j & 0xFFF);
+                    v.d = __uint_as_float((unsigned)(pk >> 20));
+                    v.k = (int)(pk & 0xFFFFFull);
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 22)) {                               // ~ seconds: a workgroup of the frame is not resident
-                    *err = 1;
+                    if (tid == 0) *err = 1;
                     break;
                 }
             }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            FpsBest v = {-2.0f, 0x7fffffff};
-            if (tid < G) {
-                const unsigned long long pk = __hip_atomic_load(cb + (j & 1) * FPS_COOP_MAXG + tid, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-                v.d = __uint_as_float((unsigned)(pk >> 32));
-                v.k = (int)(unsigned)pk;
-            }
+            if (tid >= G) v = {-2.0f, 0x7fffffff};
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 FpsBest o;
@@ -504,13 +509,13 @@ extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, c
     if (G < 2) return PCD_ERR_UNSUPPORTED;
     const int slice_cap = pcd_div_up(max_cnt_host, G);
     const size_t lds = (size_t)slice_cap * 16;
-    if (lds > 96 * 1024) return PCD_ERR_UNSUPPORTED;          // (keeps one workgroup per CU; 393 k points per frame at G = 64)
+    if (lds > 96 * 1024 || max_cnt_host > (1 << 20)) return PCD_ERR_UNSUPPORTED;   // (one workgroup per CU; 20-bit indices)
     hipStream_t st = (hipStream_t)stream;
     char *w = (char *)workspace;
     unsigned long long *cand = (unsigned long long *)w;
     unsigned *counters = (unsigned *)(w + ws_piece((size_t)B * 2 * FPS_COOP_MAXG, sizeof(unsigned long long)));
     int *err = (int *)((char *)counters + ws_piece((size_t)B * 32, sizeof(unsigned)));
-    pcd_fill(counters, 0, ws_piece((size_t)B * 32, sizeof(unsigned)) + 256, st);
+    pcd_fill(workspace, 0, pcd_stack_fps_coop_workspace_bytes(B), st);   // candidate tags 0 (no iteration has tag 0 before j = 4096), err = 0
     static size_t raised = 0;
     if (raised < lds) {
         if (hipFuncSetAttribute((const void *)stack_fps_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
