@@ -302,6 +302,67 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
     const bool live = o < eff_rows(n_dev, n);
     const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
     const int wave = o >> 6;
+    if (KW == 3 && G.dw == 1) {
+        // The three x-neighbours of a (dz, dy) line are three CONSECUTIVE keys: one fetch of the bitmap (the word / group of
+        // key - 1 and, across a word boundary, its successor) and ONE prefix serve all three -- the prefix sums are
+        // cumulative, so rank(key) = prefix(first word) + set bits in front of the key within the fetched run.  A third of
+        // the probe loads of the per-offset form below (which remains for dilated kernels).
+#pragma unroll
+        for (int l0 = 0; l0 < KD * KH; l0 += (PW == 1 ? KD * KH : KH)) {
+            constexpr int LB = PW == 1 ? KD * KH : KH;       // lines whose loads are in flight together
+            u64 run[LB];
+            int pre[LB];
+            int p0[LB];
+            bool line_ok[LB];
+#pragma unroll
+            for (int ll = 0; ll < LB; ++ll) {
+                const int l = l0 + ll;
+                const int a = l / KH, bq = l % KH;
+                const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh;
+                const bool ok = live && z >= 0 && z < G.D && y >= 0 && y < G.H;
+                line_ok[ll] = ok;
+                const u32 keyc = ok ? lin_key(c.x, z, y, c.w, G.D, G.H, G.W) : 1u;      // key of (z, y, x)
+                const u32 key0 = keyc == 0u ? 0u : keyc - 1u;                           // key of x - 1 (x = 0: not probed)
+                const u32 w0 = key0 >> 5;
+                p0[ll] = (int)(keyc - 1u - (w0 << 5));                                  // bit of x - 1 in the run (-1 at key 0)
+                if (PW == 1) {
+                    const u32 lo = bitmap[w0], hi = bitmap[w0 + 1];     // (the maps are padded by one word)
+                    pre[ll] = prefix[w0];
+                    run[ll] = (u64)lo | ((u64)hi << 32);
+                } else {
+                    const uint4 q = reinterpret_cast<const uint4 *>(bitmap)[w0 >> 2];
+                    const u32 wi = w0 & 3u;
+                    const u32 lo = wi == 0 ? q.x : wi == 1 ? q.y : wi == 2 ? q.z : q.w;
+                    u32 hi = wi == 0 ? q.y : wi == 1 ? q.z : wi == 2 ? q.w : 0u;
+                    if (wi == 3u && p0[ll] >= 30) hi = bitmap[w0 + 1];                  // rare: the run leaves the 16-byte group
+                    pre[ll] = prefix[w0 >> 2] + (wi > 0 ? __popc(q.x) : 0) + (wi > 1 ? __popc(q.y) : 0) + (wi > 2 ? __popc(q.z) : 0);
+                    run[ll] = (u64)lo | ((u64)hi << 32);
+                }
+            }
+#pragma unroll
+            for (int ll = 0; ll < LB; ++ll)
+#pragma unroll
+                for (int cq = 0; cq < 3; ++cq) {
+                    const int k = (l0 + ll) * 3 + cq;
+                    const int x = c.w + cq - 1;
+                    int r = -1;
+                    if (line_ok[ll] && x >= 0 && x < G.W) {
+                        const int p = p0[ll] + cq;
+                        if ((run[ll] >> p) & 1ull) {
+                            r = pre[ll] + __popcll(run[ll] & ((1ull << p) - 1ull));
+                            if (r >= n) r = -1;
+                        }
+                    }
+                    if (2 * k + 1 == K && live) r = o;
+                    if (live) nbr[(size_t)k * n + o] = r;
+                    if (wave_cnt) {
+                        u64 m = __ballot(r >= 0);
+                        if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int k0 = 0; k0 < K; k0 += KB) {
         u32 below[KB];     // set bits of the prefix group in front of the probed bit
