@@ -193,6 +193,8 @@ class FocalLossCenterCurriculumState:
 
     def owner(self, like):
         if self._owner is None or self._owner.numel() < like.numel() or self._owner.device != like.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.PcdError("COM loss (UCL): run one eager step before graph capture (the owner plane is allocated once)")
             self._owner = torch.zeros((like.numel(),), dtype=torch.int32, device=like.device)   # zeroed once; self-cleaning
         return self._owner
 
@@ -218,10 +220,19 @@ class CurriculumCenterHeadLoss(torch.nn.Module):
         self.register_buffer("code_weights", torch.tensor(code_weights, dtype=torch.float32), persistent=False)
         self.hm_loss_func = None          # FocalLossCenterCurriculumState, created on the first forward's device
 
+    def init_state(self, device):
+        """Create the device-side state (EMA, (3, 96) tensors, epoch sums).  Done by the first forward; call it yourself
+        before capturing the first step into a hipGraph: state allocated during a capture would live in the graph's
+        private pool and die with it."""
+        if torch.cuda.is_current_stream_capturing():
+            raise L.PcdError("CurriculumCenterHeadLoss: run one eager step (or init_state(device)) before graph capture")
+        self.hm_loss_func = FocalLossCenterCurriculumState(self.conf_shape, device)
+        return self.hm_loss_func
+
     def forward(self, pred_dicts, target_dicts, epoch=0):
         dev = pred_dicts[0]['hm'].device
         if self.hm_loss_func is None:
-            self.hm_loss_func = FocalLossCenterCurriculumState(self.conf_shape, dev)
+            self.init_state(dev)
         st = self.hm_loss_func
         cur = curriculum_struct(self.curriculum, epoch, self.conf_shape)
         tb, loss = {}, 0
