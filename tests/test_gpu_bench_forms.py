@@ -80,3 +80,15 @@ def test_com_full_model_forms_agree(tmp_path):
     assert res2["com"]["objects_counted"] == res1["com"]["objects_counted"]
     # (tools/exp_forms.sh: two runs of the SAME dense-head form differ by up to ~1.5 % in this sum after 6 steps)
     assert abs(st2["param_sum"] - st1["param_sum"]) <= 4e-2 * abs(st1["param_sum"]), (st1, st2)
+
+
+@pytest.mark.timeout(1200)
+def test_config5_fp8_forward_training_step_captures_at_300k_points(tmp_path):
+    """BASELINE config 5 as bench.py runs it: SECOND's VoxelBackBone8x, 300 k-point clouds (the 150 k voxel cap binds), e4m3
+    forward convs on 11 layers + bf16 backward inside ONE captured step; and the same workload with the bf16 forward."""
+    res8, st8 = _bench(tmp_path, "cfg5_fp8", ["--gpus", "1", "--config5"])
+    assert "fp8 (e4m3) FORWARD convs on 11 layers" in res8["config"]["workload"] and res8["config"]["points_per_frame"] == 300000
+    assert res8["config"]["voxels_per_frame"] > 100000 and res8["value"] > 0 and "one graph" in res8["config"]["execution"]
+    res16, st16 = _bench(tmp_path, "cfg5_bf16", ["--gpus", "1", "--config5"], env={"PCD_CONFIG5_BF16": "1"})
+    assert st8["param_sha256"] != st16["param_sha256"]                      # the fp8 forward really ran
+    assert abs(st8["param_sum"] - st16["param_sum"]) <= 2e-2 * abs(st16["param_sum"])
