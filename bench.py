@@ -697,11 +697,14 @@ def main():
     def train_from_voxels(bd2, ev=None):
         """MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into the bucket)"""
         bd = model.map_to_bev_module(model.backbone_3d(model.vfe(dict(bd2))))
+        if ops.STAMPS is not None and bd["spatial_features"].requires_grad:
+            bd["spatial_features"].register_hook(lambda g: ops.stamp("dense_bwd_end"))
         if args.dense_head:
             # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, MIOpen), then the REAL CenterHead step of the
             # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
             # and get_loss = focal(hm) + L1(boxes) (center_head.py:163-262) without its host round trips
             preds = model.dense_head(model.backbone_2d(bd))["pred_dicts"]
+            ops.stamp("dense_fwd_end")
             if args.com:
                 # CurriculumCenterHead.forward / get_loss (curriculum_center_head.py:461-487,313-358) on the device
                 group = com_head.cluster(gt_boxes, com_true, com_occ, com_facade)
@@ -717,6 +720,7 @@ def main():
         else:
             # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense gradient)
             loss = ops.LinearFunctionalLoss.apply(bd["spatial_features"], loss_w)
+        ops.stamp("loss_end")
         if ev is not None: ev("backward")
         try:
             loss.backward()
@@ -924,7 +928,7 @@ def main():
 
     if os.environ.get('PCD_STAMPS'):
         # time points inside the replayed graph (device clock, 100 MHz), averaged over the timed steps
-        ops.STAMPS = {"buf": torch.zeros((32,), dtype=torch.int64, device=dev), "names": []}
+        ops.STAMPS = {"buf": torch.zeros((128,), dtype=torch.int64, device=dev), "names": []}
         if use_graph:
             run_step = build_graphs()
             state["prime"](resident)

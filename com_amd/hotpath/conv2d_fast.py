@@ -118,6 +118,9 @@ class _Conv3x3Function(torch.autograd.Function):
         if direct_b and deferred:
             Fsp._claim_direct(bp, "b")
         with torch.cuda.stream(side) if side is not None else Fsp._NullCtx():
+            if ops.STAMPS is not None:
+                Fsp._STAMP_SEQ[0] += 1
+                ops.stamp(f"d2w{Fsp._STAMP_SEQ[0]}_{cin}x{cout}")
             if want_w:
                 pairs, num = _dense_pairs(B, H, W, xn.device)
                 if direct_w and deferred:

@@ -31,6 +31,7 @@ _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not 
 
 _COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
 _WGRAD_JOBS = []    # [(slab, dW, kvol, cin, cout, pmax)] of deferred slab reductions: one launch at the join
+_STAMP_SEQ = [0]    # diagnostics (ops.STAMPS): running index of the dense weight-gradient launches of a step
 _DIRECT_WRITTEN = set()   # ids of the parameters whose .grad a kernel has OVERWRITTEN since the last join (DIRECT_GRAD)
 
 
@@ -59,6 +60,7 @@ def join_deferred_wgrad():
     """Make the current stream wait for every side-stream weight-gradient kernel issued so far (and finish the
     deferred bias gradients with one launch on that stream).  Ends the step for the DIRECT_GRAD bookkeeping."""
     _DIRECT_WRITTEN.clear()
+    _STAMP_SEQ[0] = 0
     if _COLSUM_JOBS or _WGRAD_JOBS:
         side = _side_stream((_COLSUM_JOBS or _WGRAD_JOBS)[0][0].device)
         with torch.cuda.stream(side):
@@ -66,6 +68,7 @@ def join_deferred_wgrad():
                 ops.wgrad_reduce_batched(_WGRAD_JOBS)
             if _COLSUM_JOBS:
                 ops.col_sum_finalize_batched(_COLSUM_JOBS)
+            ops.stamp("side_end")
             ev = torch.cuda.Event()
             ev.record(side)
         torch.cuda.current_stream().wait_event(ev)
