@@ -69,6 +69,7 @@ PROTOTYPES = {
     "pcd_conv2d_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pcd_conv2d_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_conv2d_3x3_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "pcd_conv2d_planes_nhwc": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "pcd_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
@@ -92,6 +93,10 @@ PROTOTYPES = {
     "pcd_col_sum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
                             _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcd_bn_forward_ld": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
+                               _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcd_bn_backward_ld": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i, _vp, _vp, _sz, _vp]),
     "pcd_adam_flat_workspace_bytes": (_sz, []),
     "pcd_adam_flat_step": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _sz,

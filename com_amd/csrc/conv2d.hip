@@ -11,6 +11,7 @@
 // CONSECUTIVE output channels of its pixel: two 16-byte stores).  The data gradient is the same kernel on weights
 // packed transposed and rotated (mode 1).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
     if (e < total) conv2d_pack_piece(w, cin, cout, cout_pad, mode, packed, e);
 }
 
+__device__ __forceinline__ void planes_pack_dispatch(const float *w, int cin, int cout, int mode, unsigned short *packed,
+                                                     size_t e);   // (modes 2..7, below)
+
 // all packs of a model in ONE launch: table rows {weight, packed, cin, cout, cout_pad, mode, first block, pieces}
 __global__ __launch_bounds__(256) void conv2d_pack_batched_kernel(const long long *__restrict__ table, int n) {
     int j = 0;
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(256) void conv2d_pack_batched_kernel(const long lon
         if (table[(size_t)q * 8 + 6] <= (long long)blockIdx.x) j = q;
     const long long *row = table + (size_t)j * 8;
     const size_t e = (size_t)(blockIdx.x - row[6]) * 256 + threadIdx.x;
-    if (e < (size_t)row[7])
+    if (e >= (size_t)row[7]) return;
+    if (row[5] >= 2)
+        planes_pack_dispatch((const float *)row[0], (int)row[2], (int)row[3], (int)row[5], (unsigned short *)row[1], e);
+    else
         conv2d_pack_piece((const float *)row[0], (int)row[2], (int)row[3], (int)row[4], (int)row[5],
                           (unsigned short *)row[1], e);
 }
@@ -193,13 +200,257 @@ __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The three layers of BaseBEVBackbone the 3x3 kernel does not cover (base_bev_backbone.py:36-75): the stride-2 3x3 conv
+// that opens block 2 and the ConvTranspose2d(k = stride) of the two deblocks, forward and data gradient, on the same
+// tile machinery.  A stride-2 map splits into 4 PARITY PLANES (y & 1, x & 1); per plane each of these operators is a
+// stride-1 stencil with 1, 2 or 4 taps on the half-resolution ("coarse") grid:
+//   GATHER  (coarse OUTPUT): y[oy][ox] += W[tap] x[2 (oy + d) + py][2 (ox + d') + px]  over all planes and their taps
+//           = Conv2d(3, stride 2, pad 1) forward, and the data gradient of ConvTranspose2d(2, stride 2)
+//   SCATTER (coarse INPUT) : y[2 cy + py][2 cx + px] = sum over the plane's taps W[tap] x[cy + d][cx + d']
+//           = data gradient of that Conv2d, forward of that ConvTranspose2d; blockIdx.z = output plane
+//   K1: ConvTranspose2d(1, stride 1) = a 1x1 conv (one plane, one tap), both directions through SCATTER.
+// Workgroup = 16 x 16 coarse pixels x 64 output channels as above; per (plane, 32-channel chunk) stage the 18 x 18 tile
+// of that plane (double buffered) and the plane's 1-4 weight taps (single buffered): 57 KB of LDS, two workgroups / CU.
+enum { K_C3S2 = 0, K_K2S2 = 1, K_K1 = 2 };
+
+template <int KIND> __host__ __device__ constexpr int pl_count() { return KIND == K_K1 ? 1 : 4; }
+template <int KIND> __host__ __device__ constexpr int pl_step() { return KIND == K_K1 ? 1 : 2; }
+template <int KIND> __host__ __device__ constexpr int ax_n(int par) { return (KIND == K_C3S2 && par) ? 2 : 1; }
+// kernel index / coarse offset of tap t of an axis with parity par
+template <int KIND> __host__ __device__ constexpr int ax_k(int par, int t) {
+    return KIND == K_C3S2 ? (par ? (t ? 2 : 0) : 1) : (KIND == K_K2S2 ? par : 0);
+}
+template <int KIND, bool GATHER> __host__ __device__ constexpr int ax_d(int par, int t) {
+    return (KIND == K_C3S2 && par && t == 0) ? (GATHER ? -1 : 1) : 0;
+}
+template <int KIND> __host__ __device__ constexpr int pl_taps(int plane) {
+    return ax_n<KIND>(plane >> 1) * ax_n<KIND>(plane & 1);
+}
+template <int KIND> __host__ __device__ constexpr int pl_base(int plane) {
+    int s = 0;
+    for (int p = 0; p < plane; ++p) s += pl_taps<KIND>(p);
+    return s;
+}
+template <int KIND> __host__ __device__ constexpr int taps_total() { return pl_base<KIND>(pl_count<KIND>()); }
+template <int KIND> __host__ __device__ constexpr int taps_max() { return KIND == K_C3S2 ? 4 : 1; }
+template <int KIND> __host__ __device__ constexpr int kernel_w() { return KIND == K_C3S2 ? 3 : (KIND == K_K2S2 ? 2 : 1); }
+
+// packs of the plane kernels: [n_out_pad / 64][n_in / 32][tap, plane-major][mb][lane][8] bf16.
+// Element (o, c, ky, kx) of the operator sits at w[o * so + c * sc + ky * KW + kx] (so / sc: see pcd_conv2d_pack_* modes)
+template <int KIND>
+__device__ __forceinline__ void planes_pack_piece(const float *__restrict__ w, int n_out, int n_in, long long so, long long sc,
+                                                  unsigned short *__restrict__ packed, size_t e) {
+    constexpr int NT = taps_total<KIND>(), KW = kernel_w<KIND>();
+    const int ncc = n_in / 32;
+    const int lane = (int)(e & 63);
+    size_t q = e >> 6;
+    const int mb = (int)(q & 3); q >>= 2;
+    const int tap = (int)(q % NT); q /= NT;
+    const int cc = (int)(q % ncc);
+    const int cg = (int)(q / ncc);
+    int plane = 0;
+#pragma unroll
+    for (int p = 1; p < pl_count<KIND>(); ++p)
+        if (tap >= pl_base<KIND>(p)) plane = p;
+    const int t = tap - pl_base<KIND>(plane);
+    const int py = plane >> 1, px = plane & 1;
+    const int nx = ax_n<KIND>(px);
+    const int ky = ax_k<KIND>(py, t / nx), kx = ax_k<KIND>(px, t % nx);
+    const int o = cg * 64 + chan_of(mb, lane & 15);
+    const int k0 = cc * 32 + (lane >> 4) * 8;
+    unsigned short v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = k0 + j;
+        const float f = (o < n_out && c < n_in) ? w[(size_t)o * so + (size_t)c * sc + ky * KW + kx] : 0.0f;
+        v[j] = f32_to_bf16_bits(f);
+    }
+    uint4 out;
+    out.x = v[0] | ((u32)v[1] << 16); out.y = v[2] | ((u32)v[3] << 16);
+    out.z = v[4] | ((u32)v[5] << 16); out.w = v[6] | ((u32)v[7] << 16);
+    reinterpret_cast<uint4 *>(packed)[e] = out;
+}
+
+// pack modes 2..7 -> (kind, operator strides); cin / cout are the LAYER's channel counts
+struct PlanePack { int kind, n_out, n_in; long long so, sc; };
+__host__ __device__ inline PlanePack plane_pack_of(int mode, int cin, int cout) {
+    switch (mode) {
+    case 2: return PlanePack{K_C3S2, cout, cin, (long long)cin * 9, 9};          // Conv2d(3, s 2) forward
+    case 3: return PlanePack{K_C3S2, cin, cout, 9, (long long)cin * 9};          //                data gradient
+    case 4: return PlanePack{K_K2S2, cout, cin, 4, (long long)cout * 4};         // ConvTranspose2d(2, s 2) forward
+    case 5: return PlanePack{K_K2S2, cin, cout, (long long)cout * 4, 4};         //                data gradient
+    case 6: return PlanePack{K_K1, cout, cin, 1, (long long)cout};               // ConvTranspose2d(1, s 1) forward
+    default: return PlanePack{K_K1, cin, cout, (long long)cout, 1};              // (7)            data gradient
+    }
+}
+__device__ __forceinline__ void planes_pack_dispatch(const float *w, int cin, int cout, int mode, unsigned short *packed,
+                                                     size_t e) {
+    const PlanePack P = plane_pack_of(mode, cin, cout);
+    if (P.kind == K_C3S2) planes_pack_piece<K_C3S2>(w, P.n_out, P.n_in, P.so, P.sc, packed, e);
+    else if (P.kind == K_K2S2) planes_pack_piece<K_K2S2>(w, P.n_out, P.n_in, P.so, P.sc, packed, e);
+    else planes_pack_piece<K_K1>(w, P.n_out, P.n_in, P.so, P.sc, packed, e);
+}
+
+__global__ __launch_bounds__(256) void planes_pack_kernel(const float *__restrict__ w, int cin, int cout, int mode,
+                                                          unsigned short *__restrict__ packed, size_t total) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < total) planes_pack_dispatch(w, cin, cout, mode, packed, e);
+}
+
+template <int KIND, bool GATHER>
+__global__ __launch_bounds__(256, 2) void conv2d_planes_kernel(const unsigned short *__restrict__ x, int B, int Hi, int Wi,
+                                                               int cin, const uint4 *__restrict__ wp, int cout,
+                                                               const float *__restrict__ bias,
+                                                               unsigned short *__restrict__ y, int Ho, int Wo,
+                                                               unsigned x_bytes, unsigned w_bytes) {
+    constexpr int NP = pl_count<KIND>(), ST = pl_step<KIND>(), NT = taps_total<KIND>(), MAXT = taps_max<KIND>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *in_s = smem;                       // [2][IN_BYTES]
+    char *w_s = smem + 2 * IN_BYTES;         // [MAXT][4 KB]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const int Hc = GATHER ? Ho : Hi, Wc = GATHER ? Wo : Wi;          // the coarse grid the tiles cover
+    const int tiles_x = (Wc + TP - 1) / TP, tiles_y = (Hc + TP - 1) / TP;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int cg = blockIdx.y;
+    const int zplane = GATHER ? 0 : (int)blockIdx.z;
+    const int x0 = tx * TP, y0 = ty * TP;
+    const int ncc = cin / 32;
+    const int stages = (GATHER ? NP : 1) * ncc;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
+
+    u32x4 in_r[6], w_r[MAXT];
+    auto load_stage = [&](int s) {
+        const int plane = GATHER ? s / ncc : zplane;
+        const int cc = GATHER ? s - plane * ncc : s;
+        const int py = plane >> 1, px = plane & 1;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p >> 2, piece = p & 3;
+            const int ry = pix / HT, rx = pix - ry * HT;
+            int gy = y0 + ry - 1, gx = x0 + rx - 1;                  // coarse position of this tile pixel
+            if (GATHER) { gy = gy * ST + py; gx = gx * ST + px; }    // -> the plane's pixel of the fine input
+            const bool ok = p < HT * HT * 4 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+            const unsigned off = ok ? (unsigned)((((size_t)b * Hi + gy) * Wi + gx) * cin * 2 + piece * 16 + cc * 64)
+                                    : 0xFFFFFFF0u;
+            in_r[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+        }
+        const int nt = pl_taps<KIND>(plane);
+        const unsigned wbase = (unsigned)((((size_t)cg * ncc + cc) * NT + pl_base<KIND>(plane)) * 4096);
+#pragma unroll
+        for (int it = 0; it < MAXT; ++it)
+            w_r[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, it < nt ? wbase + (unsigned)(it * 256 + threadIdx.x) * 16u : 0xFFFFFFF0u, 0, 0);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            if (p < HT * HT * 4) *reinterpret_cast<u32x4 *>(in_s + buf * IN_BYTES + p * 16) = in_r[it];
+        }
+#pragma unroll
+        for (int it = 0; it < MAXT; ++it)
+            *reinterpret_cast<u32x4 *>(w_s + (it * 256 + threadIdx.x) * 16) = w_r[it];
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acc[mb][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto mma_plane = [&](auto plane_c, const char *ins) {
+        constexpr int P = decltype(plane_c)::value;
+        constexpr int py = P >> 1, px = P & 1, ny = ax_n<KIND>(py), nx = ax_n<KIND>(px);
+#pragma unroll
+        for (int ty_ = 0; ty_ < ny; ++ty_)
+#pragma unroll
+            for (int tx_ = 0; tx_ < nx; ++tx_) {
+                const int tt = ty_ * nx + tx_;
+                const int dy = ax_d<KIND, GATHER>(py, ty_), dx = ax_d<KIND, GATHER>(px, tx_);
+                bf16x8 af[4], bf[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    af[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(w_s + ((tt * 4 + mb) * 64 + lane) * 16));
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const int r = wave * 4 + pb;
+                    bf[pb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(
+                                                            ins + ((r + 1 + dy) * HT + (m + 1 + dx)) * 64 + g * 16));
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb)
+                        acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bf[pb], acc[mb][pb], 0, 0, 0);
+            }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) load_stage(s + 1);
+        const char *ins = in_s + buf * IN_BYTES;
+        const int plane = GATHER ? s / ncc : zplane;
+        if (NP == 1 || plane == 0) mma_plane(std::integral_constant<int, 0>{}, ins);
+        else if (plane == 1) mma_plane(std::integral_constant<int, 1>{}, ins);
+        else if (plane == 2) mma_plane(std::integral_constant<int, 2>{}, ins);
+        else mma_plane(std::integral_constant<int, 3>{}, ins);
+        __syncthreads();                                   // the weight stage (and this tile buffer) have been read
+        if (s + 1 < stages) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    const int c0 = cg * 64 + g * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = (bias && c0 + j < cout) ? bias[c0 + j] : 0.0f;
+    const int opy = zplane >> 1, opx = zplane & 1;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        int gy = y0 + wave * 4 + pb, gx = x0 + m;
+        if (gy >= Hc || gx >= Wc) continue;
+        if (!GATHER) { gy = gy * ST + opy; gx = gx * ST + opx; }
+        if (gy >= Ho || gx >= Wo || c0 >= cout) continue;
+        u32 o[8];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const u32 lo0 = f32_to_bf16_bits(acc[mb][pb][0] + bv[mb * 4 + 0]);
+            const u32 hi0 = f32_to_bf16_bits(acc[mb][pb][1] + bv[mb * 4 + 1]);
+            const u32 lo1 = f32_to_bf16_bits(acc[mb][pb][2] + bv[mb * 4 + 2]);
+            const u32 hi1 = f32_to_bf16_bits(acc[mb][pb][3] + bv[mb * 4 + 3]);
+            o[mb * 2] = lo0 | (hi0 << 16);
+            o[mb * 2 + 1] = lo1 | (hi1 << 16);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(y + (((size_t)b * Ho + gy) * Wo + gx) * cout + c0);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
 }  // namespace
 
 static int pad32(int c) { return (c + 31) / 32 * 32; }
 
 // (output channels are padded to a multiple of 32: the data gradient contracts over them in steps of 32)
+static size_t planes_pack_bytes(int cin, int cout, int mode) {
+    const PlanePack P = plane_pack_of(mode, cin, cout);
+    if (P.n_in % 32) return 0;
+    const int nt = P.kind == K_C3S2 ? taps_total<K_C3S2>() : (P.kind == K_K2S2 ? taps_total<K_K2S2>() : taps_total<K_K1>());
+    return (size_t)((P.n_out + 63) / 64) * (P.n_in / 32) * nt * 4096;
+}
+
 extern "C" size_t pcd_conv2d_packed_weight_bytes(int cin, int cout, int mode) {
-    if (cin <= 0 || cout <= 0 || (mode != 0 && mode != 1)) return 0;
+    if (cin <= 0 || cout <= 0 || mode < 0 || mode > 7) return 0;
+    if (mode >= 2) return planes_pack_bytes(cin, cout, mode);
     const int cp = pad32(cout);
     const int n_out = mode == 0 ? cp : cin, n_in = mode == 0 ? cin : cp;
     return (size_t)((n_out + 63) / 64) * (n_in / 32) * W_BYTES;
@@ -207,7 +458,15 @@ extern "C" size_t pcd_conv2d_packed_weight_bytes(int cin, int cout, int mode) {
 
 extern "C" int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, void *packed, void *stream) {
     PCD_ENTER();
-    if (!weight || !packed || cin <= 0 || cout <= 0 || (mode != 0 && mode != 1)) return PCD_ERR_INVALID_ARG;
+    if (!weight || !packed || cin <= 0 || cout <= 0 || mode < 0 || mode > 7) return PCD_ERR_INVALID_ARG;
+    if (mode >= 2) {
+        const size_t pieces = planes_pack_bytes(cin, cout, mode) / 16;
+        if (pieces == 0) return PCD_ERR_UNSUPPORTED;
+        planes_pack_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+            weight, cin, cout, mode, (unsigned short *)packed, pieces);
+        PCD_RETURN_IF_LAUNCH_FAILED();
+        return PCD_OK;
+    }
     if (cin % 32) return PCD_ERR_UNSUPPORTED;
     const size_t total = pcd_conv2d_packed_weight_bytes(cin, cout, mode) / 16;
     conv2d_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
@@ -257,4 +516,57 @@ extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int wid
                                                                      (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+
+template <int KIND, bool GATHER>
+static int launch_planes(const void *x, int batch, int hi, int wi, int cin, const void *packed_w, int cout,
+                         const float *bias, void *y, int ho, int wo, hipStream_t stream) {
+    constexpr int NT = taps_total<KIND>();
+    const size_t lds = 2 * (size_t)IN_BYTES + (size_t)taps_max<KIND>() * 4096;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)conv2d_planes_kernel<KIND, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PCD_ERR_LAUNCH;
+        raised = true;
+    }
+    const int hc = GATHER ? ho : hi, wc = GATHER ? wo : wi;
+    const int tiles = batch * ((hc + TP - 1) / TP) * ((wc + TP - 1) / TP);
+    const size_t wb_bytes = (size_t)((cout + 63) / 64) * (cin / 32) * NT * 4096;
+    dim3 grid((unsigned)tiles, (unsigned)((cout + 63) / 64), GATHER ? 1u : (unsigned)pl_count<KIND>());
+    conv2d_planes_kernel<KIND, GATHER><<<grid, 256, lds, stream>>>(
+        (const unsigned short *)x, batch, hi, wi, cin, (const uint4 *)packed_w, cout, bias, (unsigned short *)y, ho, wo,
+        (unsigned)((size_t)batch * hi * wi * cin * 2), (unsigned)wb_bytes);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_conv2d_planes_nhwc(int pack_mode, const void *x, int batch, int hi, int wi, int cin,
+                                      const void *packed_w, int cout, const float *bias, void *y, int ho, int wo,
+                                      void *stream) {
+    PCD_ENTER();
+    if (batch <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0) return PCD_ERR_INVALID_ARG;
+    if (!x || !packed_w || !y || pack_mode < 2 || pack_mode > 7) return PCD_ERR_INVALID_ARG;
+    if (cin % 32 || cout % 16) return PCD_ERR_UNSUPPORTED;
+    if ((double)batch * hi * wi * cin * 2 >= 4294966000.0 || (double)batch * ho * wo * cout * 2 >= 1.7e10)
+        return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch (pack_mode) {
+    case 2:   // Conv2d(3, stride 2, padding 1) forward: x fine [hi, wi] -> y coarse
+        if (ho != (hi - 1) / 2 + 1 || wo != (wi - 1) / 2 + 1) return PCD_ERR_INVALID_ARG;
+        return launch_planes<K_C3S2, true>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
+    case 3:   // its data gradient: x = dy coarse [hi, wi] -> y = dx fine [ho, wo]
+        if (hi != (ho - 1) / 2 + 1 || wi != (wo - 1) / 2 + 1) return PCD_ERR_INVALID_ARG;
+        return launch_planes<K_C3S2, false>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
+    case 4:   // ConvTranspose2d(2, stride 2) forward: coarse -> fine
+        if (ho != 2 * hi || wo != 2 * wi) return PCD_ERR_INVALID_ARG;
+        return launch_planes<K_K2S2, false>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
+    case 5:   // its data gradient: fine -> coarse
+        if (hi != 2 * ho || wi != 2 * wo) return PCD_ERR_INVALID_ARG;
+        return launch_planes<K_K2S2, true>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
+    default:  // 6 / 7: ConvTranspose2d(1, stride 1) forward / data gradient
+        if (ho != hi || wo != wi) return PCD_ERR_INVALID_ARG;
+        return launch_planes<K_K1, false>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
+    }
 }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
                                                        int n_cap, const int32_t *n_dev, int c,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int relu,
-                                                       T *__restrict__ y, int vec, BnFin fin) {
+                                                       T *__restrict__ y, int vec, BnFin fin, int y_ld) {
     __builtin_amdgcn_s_setprio(3);   // critical chain: ahead of the weight-gradient waves sharing the SIMD (spconv.hip)
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -373,7 +373,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
         load_params<N>(scale, piece * N, vec, sc);
         load_params<N>(shift, piece * N, vec, sh);
     }
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    // y may be a column block of a wider matrix (row stride y_ld elements): row = e / pcs advances by a whole number
+    // of rows per grid stride
+    const size_t e0 = (size_t)blockIdx.x * 256 + threadIdx.x, S = (size_t)gridDim.x * 256;
+    size_t ye = (e0 / pcs) * (size_t)(y_ld / N) + piece;
+    const size_t ystep = (S / pcs) * (size_t)(y_ld / N);
+    for (size_t e = e0; e < total; e += S, ye += ystep) {
         float v[N], r[N];
         Piece<T>::load(x + e * N, v);
         if (res) Piece<T>::load(res + e * N, r);
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
             if (relu) o = o > 0.0f ? o : 0.0f;
             v[j] = o;
         }
-        Piece<T>::store(y + e * N, v);
+        Piece<T>::store(y + ye * N, v);
     }
 }
 
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
                                                             const float *__restrict__ beta,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, int relu,
-                                                            float *__restrict__ partial, int vec) {
+                                                            float *__restrict__ partial, int vec, int dy_ld) {
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pcs = c / N;
@@ -430,20 +435,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
     // two rows of loads (4-6 x 16 bytes) in flight per thread, same accumulation order as the plain loop
     const size_t S = (size_t)gridDim.x * 256;
     size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; e + S < total; e += 2 * S) {
+    size_t de = (e / pcs) * (size_t)(dy_ld / N) + piece;               // dy: row stride dy_ld elements
+    const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
+    for (; e + S < total; e += 2 * S, de += 2 * dstep) {
         float g[2][N], xv[2][N], yv[2][N];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            Piece<T>::load(dy + (e + u * S) * N, g[u]);
+            Piece<T>::load(dy + (de + u * dstep) * N, g[u]);
             Piece<T>::load(x + (e + u * S) * N, xv[u]);
             if (relu && !mask_from_x) Piece<T>::load(y + (e + u * S) * N, yv[u]);
         }
         accumulate(g[0], xv[0], yv[0]);
         accumulate(g[1], xv[1], yv[1]);
     }
-    for (; e < total; e += S) {
+    for (; e < total; e += S, de += dstep) {
         float g[N], xv[N], yv[N];
-        Piece<T>::load(dy + e * N, g);
+        Piece<T>::load(dy + de * N, g);
         Piece<T>::load(x + e * N, xv);
         if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
         accumulate(g, xv, yv);
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            float *__restrict__ dbeta, int relu,
                                                            int training, T *__restrict__ dx,
                                                            T *__restrict__ dres, int vec, const double *mid,
-                                                           float *__restrict__ colsum_partial) {
+                                                           float *__restrict__ colsum_partial, int dy_ld) {
     __builtin_amdgcn_s_setprio(3);   // critical chain: ahead of the weight-gradient waves sharing the SIMD (spconv.hip)
     constexpr int N = Piece<T>::N;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -525,9 +532,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     float cs[1][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) cs[0][j] = 0.0f;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t e0 = (size_t)blockIdx.x * 256 + threadIdx.x, S = (size_t)gridDim.x * 256;
+    size_t de = (e0 / pcs) * (size_t)(dy_ld / N) + piece;              // dy: row stride dy_ld elements
+    const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
+    for (size_t e = e0; e < total; e += S, de += dstep) {
         float g[N], xv[N], yv[N], o[N];
-        Piece<T>::load(dy + e * N, g);
+        Piece<T>::load(dy + de * N, g);
         Piece<T>::load(x + e * N, xv);
         if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
 #pragma unroll
@@ -623,14 +633,15 @@ extern "C" size_t pcd_bn_workspace_bytes(int c) {
            ws_piece((size_t)MID_ROWS * 2 * c, sizeof(double));
 }
 
-extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
-                              const float *gamma, const float *beta, float eps, float momentum,
-                              int training, float *running_mean, float *running_var, int relu, void *y,
-                              float *save_mean, float *save_invstd, const int32_t *n_dev,
-                              const float *ext_partial, int ext_rows, void *workspace, size_t workspace_bytes,
-                              void *stream) {
+extern "C" int pcd_bn_forward_ld(const void *x, const void *residual, int dtype, int n, int c,
+                                 const float *gamma, const float *beta, float eps, float momentum,
+                                 int training, float *running_mean, float *running_var, int relu, void *y, int y_ld,
+                                 float *save_mean, float *save_invstd, const int32_t *n_dev,
+                                 const float *ext_partial, int ext_rows, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (y_ld < c || y_ld % (dtype == PCD_F32 ? 4 : 8)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
     if (!training && (!running_mean || !running_var)) return PCD_ERR_INVALID_ARG;
     if (training && (!save_mean || !save_invstd)) return PCD_ERR_INVALID_ARG;
@@ -683,14 +694,25 @@ extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, in
         const size_t lds = training ? bn_mid_lds_bytes(c) : 0;
         if (dtype == PCD_F32)
             bn_apply_kernel<float><<<agrid, 256, lds, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
-                                                           L.scale, L.shift, relu, (float *)y, 1, fin);
+                                                           L.scale, L.shift, relu, (float *)y, 1, fin, y_ld);
         else
             bn_apply_kernel<unsigned short><<<agrid, 256, lds, st>>>(
                 (const unsigned short *)x, (const unsigned short *)residual, n, n_dev, c, L.scale, L.shift, relu,
-                (unsigned short *)y, 1, fin);
+                (unsigned short *)y, 1, fin, y_ld);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+extern "C" int pcd_bn_forward(const void *x, const void *residual, int dtype, int n, int c,
+                              const float *gamma, const float *beta, float eps, float momentum,
+                              int training, float *running_mean, float *running_var, int relu, void *y,
+                              float *save_mean, float *save_invstd, const int32_t *n_dev,
+                              const float *ext_partial, int ext_rows, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+    return pcd_bn_forward_ld(x, residual, dtype, n, c, gamma, beta, eps, momentum, training, running_mean, running_var,
+                             relu, y, c, save_mean, save_invstd, n_dev, ext_partial, ext_rows, workspace,
+                             workspace_bytes, stream);
 }
 
 __global__ __launch_bounds__(1024) void col_sum_finalize_kernel(const float *__restrict__ partial, int nblocks,
@@ -723,14 +745,15 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, c
     return PCD_OK;
 }
 
-extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
-                               const float *gamma, const float *beta, const float *save_mean,
-                               const float *save_invstd,
-                               int relu, int training, void *dx, void *dresidual, float *dgamma,
-                               float *dbeta, const int32_t *n_dev, const float *ext_partial, int ext_rows,
-                               float *colsum_partial, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int pcd_bn_backward_ld(const void *dy, int dy_ld, const void *x, const void *y, int dtype, int n, int c,
+                                  const float *gamma, const float *beta, const float *save_mean,
+                                  const float *save_invstd,
+                                  int relu, int training, void *dx, void *dresidual, float *dgamma,
+                                  float *dbeta, const int32_t *n_dev, const float *ext_partial, int ext_rows,
+                                  float *colsum_partial, void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (n < 0 || c <= 0 || (dtype != PCD_F32 && dtype != PCD_BF16)) return PCD_ERR_INVALID_ARG;
+    if (dy_ld < c || dy_ld % (dtype == PCD_F32 ? 4 : 8)) return PCD_ERR_INVALID_ARG;
     if (!shape_ok(c, dtype)) return PCD_ERR_UNSUPPORTED;
     if (!save_mean || !save_invstd || !dgamma || !dbeta) return PCD_ERR_INVALID_ARG;
     if (n > 0 && (!dy || !x || !dx)) return PCD_ERR_INVALID_ARG;
@@ -764,25 +787,38 @@ extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int
         if (!ext_partial)
             bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                                                          save_invstd, relu, L.partial, vec);
+                                                          save_invstd, relu, L.partial, vec, dy_ld);
         finalize();
         if (n > 0)
             bn_bwd_apply_kernel<float><<<agrid, 256, alds, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
-                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid, colsum_partial);
+                save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid, colsum_partial,
+                dy_ld);
     } else {
         typedef unsigned short B;
         if (!ext_partial)
             bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
-                                                      gamma, beta, save_mean, save_invstd, relu, L.partial, vec);
+                                                      gamma, beta, save_mean, save_invstd, relu, L.partial, vec, dy_ld);
         finalize();
         if (n > 0)
             bn_bwd_apply_kernel<B><<<agrid, 256, alds, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                             gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                                            relu, training, (B *)dx, (B *)dresidual, vec, mid, colsum_partial);
+                                                            relu, training, (B *)dx, (B *)dresidual, vec, mid, colsum_partial,
+                                                            dy_ld);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+extern "C" int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int n, int c,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd,
+                               int relu, int training, void *dx, void *dresidual, float *dgamma,
+                               float *dbeta, const int32_t *n_dev, const float *ext_partial, int ext_rows,
+                               float *colsum_partial, void *workspace, size_t workspace_bytes, void *stream) {
+    return pcd_bn_backward_ld(dy, c, x, y, dtype, n, c, gamma, beta, save_mean, save_invstd, relu, training, dx, dresidual,
+                              dgamma, dbeta, n_dev, ext_partial, ext_rows, colsum_partial, workspace, workspace_bytes,
+                              stream);
 }
 
 // rows of the colsum_partial buffer pcd_bn_backward fills ([rows][c] f32): the grid of its apply pass

@@ -48,6 +48,105 @@ def _pad32(c):
 BATCH_BN_COUNTERS = os.environ.get('PCD_BN2D_BUMP', '1') != '0'
 
 
+def _plane_pairs(mode_f, B, hi, wi, device):
+    """Dense pair lists for the WEIGHT gradients of the plane operators (conv2d.hip, pack modes 2 / 4 / 6), in the
+    (gathered row, accumulated row) convention of the sparse pair kernels, built once per map shape:
+      mode 2  Conv2d(3, stride 2, padding 1): tap k = ky * 3 + kx pairs the fine INPUT pixel (2 oy + ky - 1, 2 ox + kx - 1)
+              with the coarse output pixel (oy, ox) -> dW [cout, 9, cin]
+      mode 4  ConvTranspose2d(2, stride 2): tap k = a * 2 + b pairs the fine OUTPUT pixel (2 y + a, 2 x + b) with the coarse
+              input pixel (y, x); the kernel runs with the roles of x / dy swapped so that dW comes out as [cin, 4, cout],
+              i.e. in the parameter's own [cin, cout, 2, 2] layout after the conv2d_layout reduction
+      mode 6  ConvTranspose2d(1, stride 1): identity pairs.
+    (hi, wi) = size of the layer's INPUT map.  Returns pairs [K, 2, n], pair_num [K]."""
+    key = ("planes", mode_f, B, hi, wi, str(device))
+    hit = _PAIRS.get(key)
+    if hit is not None:
+        return hit
+    if mode_f == 2:
+        ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+        n = B * ho * wo
+        p = torch.arange(n, device=device, dtype=torch.int64)
+        b, oy, ox = p // (ho * wo), (p // wo) % ho, p % wo
+        pairs = torch.full((9, 2, n), -1, dtype=torch.int32, device=device)
+        num = torch.zeros((9,), dtype=torch.int32, device=device)
+        for k in range(9):
+            fy, fx = 2 * oy + k // 3 - 1, 2 * ox + k % 3 - 1
+            ok = (fy >= 0) & (fy < hi) & (fx >= 0) & (fx < wi)
+            m = int(ok.sum())
+            pairs[k, 0, :m] = ((b * hi + fy) * wi + fx)[ok].int()
+            pairs[k, 1, :m] = p[ok].int()
+            num[k] = m
+    elif mode_f == 4:
+        n = B * hi * wi
+        p = torch.arange(n, device=device, dtype=torch.int64)
+        b, y, x = p // (hi * wi), (p // wi) % hi, p % wi
+        pairs = torch.empty((4, 2, n), dtype=torch.int32, device=device)
+        for k in range(4):
+            pairs[k, 0] = ((b * 2 * hi + 2 * y + k // 2) * (2 * wi) + 2 * x + k % 2).int()
+            pairs[k, 1] = p.int()
+        num = torch.full((4,), n, dtype=torch.int32, device=device)
+    else:
+        n = B * hi * wi
+        p = torch.arange(n, device=device, dtype=torch.int32)
+        pairs = torch.stack([p, p]).reshape(1, 2, n).contiguous()
+        num = torch.full((1,), n, dtype=torch.int32, device=device)
+    _PAIRS[key] = (pairs, num)
+    return pairs, num
+
+
+def _scheduled_backward(need_dx, want_w, want_b, wp, bp, direct_ok, dgrad, wgrad, bsum, keep):
+    """The backward schedule shared by the dense convs (as in the sparse convs, spconv/functional.py): the data gradient
+    is issued first on the current stream, the weight / bias gradients run on the side stream from an event recorded
+    before it; with DIRECT_GRAD they are written straight into .grad (the slab reduction deferred to ONE launch at the
+    join, in the parameter's own layout) and the join is lagged -- no copy, no AccumulateGrad add, no per-layer reduce
+    launch.  dgrad() -> dx; wgrad(direct) -> dw or None; bsum(direct) -> db or None; keep = tensors alive until the join."""
+    from ..spconv import functional as Fsp
+    dx = dw = db = None
+    cur = torch.cuda.current_stream()
+    side = ready = None
+    if Fsp.OVERLAP_WGRAD and need_dx and (want_w or want_b):
+        ready = torch.cuda.Event()
+        ready.record(cur)
+    if need_dx:
+        dx = dgrad()
+    if ready is not None:
+        side = Fsp._side_stream(keep[0].device)
+        side.wait_event(ready)
+
+    def direct(p):
+        return (Fsp.DIRECT_GRAD and direct_ok and p is not None and p.grad is not None
+                and p.grad.dtype == torch.float32 and p.grad.is_contiguous())
+    direct_w, direct_b = want_w and direct(wp), want_b and direct(bp)
+    deferred = (Fsp.WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not want_w)
+                and (direct_b or not want_b))
+    if direct_w and deferred:
+        Fsp._claim_direct(wp, "w")
+    if direct_b and deferred:
+        Fsp._claim_direct(bp, "b")
+    with torch.cuda.stream(side) if side is not None else Fsp._NullCtx():
+        if ops.STAMPS is not None:
+            Fsp._STAMP_SEQ[0] += 1
+            ops.stamp(f"d2w{Fsp._STAMP_SEQ[0]}")
+        if want_w:
+            dw = wgrad(direct_w and deferred)
+        if want_b:
+            db = bsum(direct_b and deferred)
+        if deferred:
+            ev = torch.cuda.Event()
+            ev.record(side)
+    if deferred:
+        Fsp._PENDING.append((ev,) + tuple(keep) + (None,))     # inputs stay alive until the lagged join
+        if len(Fsp._PENDING) > Fsp.WGRAD_JOIN_LAG:
+            cur.wait_event(Fsp._PENDING[-1 - Fsp.WGRAD_JOIN_LAG][0])
+            del Fsp._PENDING[:len(Fsp._PENDING) - Fsp.WGRAD_JOIN_LAG]
+    elif side is not None:
+        cur.wait_stream(side)
+        for t in (dw, db):
+            if t is not None:
+                t.record_stream(cur)
+    return dx, dw, db
+
+
 class _Conv3x3Function(torch.autograd.Function):
     """Output channel counts that are not a multiple of 32 (the 1 / 2 / 3-channel final convs of the head towers) run
     padded with zero weights (the packs carry the padding): MIOpen spends 0.4 ms on each of those tiny convs.
@@ -86,67 +185,31 @@ class _Conv3x3Function(torch.autograd.Function):
             dyn = torch.nn.functional.pad(dyn, (0, cp - cout))
         dyn = dyn.contiguous()
         from ..spconv import functional as Fsp
-        dx = dw = db = None
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        cur = torch.cuda.current_stream()
-        # as in the sparse convs (spconv/functional.py): the data gradient is issued first on the current stream, the
-        # weight / bias gradients run on the side stream from an event recorded before it; with DIRECT_GRAD they are
-        # written straight into .grad (the slab reduction deferred to ONE launch at the join, in the parameter's own
-        # [cout, cin, 3, 3] layout) and the join is lagged -- no copy, no AccumulateGrad add, no per-layer reduce launch
-        side = ready = None
-        if Fsp.OVERLAP_WGRAD and ctx.needs_input_grad[0] and (want_w or want_b):
-            ready = torch.cuda.Event()
-            ready.record(cur)
-        if ctx.needs_input_grad[0]:
-            if pack_d is None:
-                pack_d = ops.conv2d_pack_weight(weight, 1)
-            dx = ops.conv2d_3x3_nhwc(dyn, pack_d, cin).permute(0, 3, 1, 2)
-        if ready is not None:
-            side = Fsp._side_stream(dyn.device)
-            side.wait_event(ready)
         wp, bp = ctx.weight_param, ctx.bias_param
 
-        def direct(p):
-            return (Fsp.DIRECT_GRAD and cp == cout and p is not None and p.grad is not None
-                    and p.grad.dtype == torch.float32 and p.grad.is_contiguous())
-        direct_w, direct_b = want_w and direct(wp), want_b and direct(bp)
-        deferred = (Fsp.WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not want_w)
-                    and (direct_b or not want_b))
-        if direct_w and deferred:
-            Fsp._claim_direct(wp, "w")
-        if direct_b and deferred:
-            Fsp._claim_direct(bp, "b")
-        with torch.cuda.stream(side) if side is not None else Fsp._NullCtx():
-            if ops.STAMPS is not None:
-                Fsp._STAMP_SEQ[0] += 1
-                ops.stamp(f"d2w{Fsp._STAMP_SEQ[0]}_{cin}x{cout}")
-            if want_w:
-                pairs, num = _dense_pairs(B, H, W, xn.device)
-                if direct_w and deferred:
-                    ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9, out=wp.grad,
-                              defer=Fsp._WGRAD_JOBS, conv2d_layout=True)
-                else:
-                    dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)  # [cp, 9, cin] f32
-                    dw = dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
-            if want_b:
-                if direct_b and deferred:
-                    ops.col_sum(dyn.reshape(-1, cp), out=bp.grad)
-                else:
-                    db = ops.col_sum(dyn.reshape(-1, cp))[:cout]   # fp32 column sums in a fixed order
-            if deferred:
-                ev = torch.cuda.Event()
-                ev.record(side)
-        if deferred:
-            Fsp._PENDING.append((ev, xn, dyn, None))     # inputs stay alive until the lagged join
-            if len(Fsp._PENDING) > Fsp.WGRAD_JOIN_LAG:
-                cur.wait_event(Fsp._PENDING[-1 - Fsp.WGRAD_JOIN_LAG][0])
-                del Fsp._PENDING[:len(Fsp._PENDING) - Fsp.WGRAD_JOIN_LAG]
-        elif side is not None:
-            cur.wait_stream(side)
-            for t in (dw, db):
-                if t is not None:
-                    t.record_stream(cur)
+        def dgrad():
+            pd = pack_d if pack_d is not None else ops.conv2d_pack_weight(weight, 1)
+            return ops.conv2d_3x3_nhwc(dyn, pd, cin).permute(0, 3, 1, 2)
+
+        def wgrad(direct):
+            pairs, num = _dense_pairs(B, H, W, xn.device)
+            if direct:
+                ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9, out=wp.grad,
+                          defer=Fsp._WGRAD_JOBS, conv2d_layout=True)
+                return None
+            dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)  # [cp, 9, cin] f32
+            return dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
+
+        def bsum(direct):
+            if direct:
+                ops.col_sum(dyn.reshape(-1, cp), out=bp.grad)
+                return None
+            return ops.col_sum(dyn.reshape(-1, cp))[:cout]   # fp32 column sums in a fixed order
+
+        dx, dw, db = _scheduled_backward(ctx.needs_input_grad[0], want_w, want_b, wp, bp, cp == cout, dgrad, wgrad, bsum,
+                                         (xn, dyn))
         return dx, dw, db, None, None
 
 
@@ -178,6 +241,128 @@ class Conv3x3(nn.Conv2d):
         return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
 
 
+class _ConvPlanesFunction(torch.autograd.Function):
+    """The stride-2 3x3 conv (mode 2) and the k = stride transposed convs (modes 4, 6) of BaseBEVBackbone through the
+    plane kernels of conv2d.hip; the data gradient is the same kernel family with the next odd pack mode, the weight
+    gradient the sparse pair kernels over dense pair lists (_plane_pairs).  No bias (base_bev_backbone.py:38,58,66)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pack_f, pack_d, mode_f):
+        xn = x.detach().permute(0, 2, 3, 1)
+        assert xn.is_contiguous()
+        B, H, W, _ = xn.shape
+        _, cout = ops.conv2d_layer_channels(weight, mode_f)
+        out_hw = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if mode_f == 2 else ((2 * H, 2 * W) if mode_f == 4 else (H, W))
+        if pack_f is None:
+            pack_f = ops.conv2d_pack_weight(weight, mode_f)
+        y = ops.conv2d_planes_nhwc(mode_f, xn, pack_f, cout, out_hw)
+        ctx.save_for_backward(xn, weight, pack_d)
+        ctx.mode_f = mode_f
+        ctx.weight_param = weight if isinstance(weight, nn.Parameter) else None
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, weight, pack_d = ctx.saved_tensors
+        mode_f = ctx.mode_f
+        B, H, W, cin = xn.shape
+        _, cout = ops.conv2d_layer_channels(weight, mode_f)
+        dyn = dy.permute(0, 2, 3, 1)
+        if dyn.dtype != torch.bfloat16:
+            dyn = dyn.to(torch.bfloat16)
+        dyn = dyn.contiguous()
+        from ..spconv import functional as Fsp
+        wp = ctx.weight_param
+        kk = {2: 9, 4: 4, 6: 1}[mode_f]
+
+        def dgrad():
+            pd = pack_d if pack_d is not None else ops.conv2d_pack_weight(weight, mode_f + 1)
+            return ops.conv2d_planes_nhwc(mode_f + 1, dyn, pd, cin, (H, W)).permute(0, 3, 1, 2)
+
+        def wgrad(direct):
+            pairs, num = _plane_pairs(mode_f, B, H, W, xn.device)
+            if mode_f == 2:       # gathered rows = x (contraction c = cin), accumulated rows = dy (o = cout)
+                a, ca, b_, cb = xn.reshape(-1, cin), cin, dyn.reshape(-1, cout), cout
+            else:                 # transposed convs: roles swapped -> dW [cin, K, cout] = the parameter's layout
+                a, ca, b_, cb = dyn.reshape(-1, cout), cout, xn.reshape(-1, cin), cin
+            if direct:
+                ops.wgrad(a, ca, b_, pairs, num, kk, out=wp.grad, defer=Fsp._WGRAD_JOBS, conv2d_layout=True)
+                return None
+            dwk = ops.wgrad(a, ca, b_, pairs, num, kk)                    # [cb, K, ca] f32
+            k = int(round(kk ** 0.5))
+            return dwk.permute(0, 2, 1).reshape(cb, ca, k, k).to(weight.dtype)
+
+        dx, dw, _ = _scheduled_backward(ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, wp, None, True, dgrad,
+                                        wgrad, None, (xn, dyn))
+        return dx, dw, None, None, None
+
+
+def _plane_input(x):
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+def _bf16_region(x):
+    return x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+
+
+class _PlaneConvMixin:
+    MODE_F = None
+
+    def _take_packs(self):
+        pf = pd = None
+        ahead = getattr(self, "_packs_ahead", None)
+        if ahead is not None:
+            self._packs_ahead = None
+            if ahead[2] == self.weight._version:
+                pf, pd = ahead[0], ahead[1]
+        return pf, pd
+
+
+class Conv3x3S2(_PlaneConvMixin, nn.Conv2d):
+    """nn.Conv2d(k = 3, stride 2, padding 1, bias=False) -- the conv that opens a down-sampling block
+    (base_bev_backbone.py:36-41: ZeroPad2d(1) + Conv2d(padding=0), the same arithmetic) -- through the plane kernels."""
+    MODE_F = 2
+
+    def _fast(self, x):
+        return (ENABLED and _bf16_region(x) and x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3)
+                and self.stride == (2, 2) and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
+                and self.padding_mode == 'zeros' and self.bias is None and self.in_channels % 32 == 0
+                and self.out_channels % 32 == 0
+                and x.shape[0] * x.shape[2] * x.shape[3] * max(self.in_channels, self.out_channels) * 2 < 2 ** 32 - 4096)
+
+    def forward(self, x):
+        if not self._fast(x):
+            return super().forward(x)
+        pf, pd = self._take_packs()
+        return _ConvPlanesFunction.apply(_plane_input(x), self.weight, pf, pd, 2)
+
+
+class UpConvT(_PlaneConvMixin, nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(k = stride in {1, 2}, bias=False) -- the deblocks (base_bev_backbone.py:55-62) -- through the
+    plane kernels (k = 2: four 1-tap planes written with stride 2, no intermediate + pixel shuffle pass)."""
+
+    @property
+    def MODE_F(self):
+        return 4 if self.kernel_size == (2, 2) else 6
+
+    def _fast(self, x):
+        return (ENABLED and _bf16_region(x) and x.is_cuda and x.dim() == 4 and self.kernel_size in ((1, 1), (2, 2))
+                and self.stride == self.kernel_size and self.padding == (0, 0) and self.output_padding == (0, 0)
+                and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
+                and self.in_channels % 32 == 0 and self.out_channels % 32 == 0
+                and x.shape[0] * x.shape[2] * x.shape[3] * 4 * max(self.in_channels, self.out_channels) * 2 < 2 ** 32 - 4096)
+
+    def forward(self, x, output_size=None):
+        if output_size is not None or not self._fast(x):
+            return super().forward(x, output_size)
+        pf, pd = self._take_packs()
+        return _ConvPlanesFunction.apply(_plane_input(x), self.weight, pf, pd, self.MODE_F)
+
+
 class Conv3x3Packs:
     """Forward + data-gradient packs of all Conv3x3 modules of a model in ONE launch (pcd_conv2d_pack_weights_batched)
     into persistent buffers -- call `run()` right after every optimizer step (the weights do not change again before
@@ -189,15 +374,25 @@ class Conv3x3Packs:
     def __init__(self, model):
         import ctypes  # noqa: F401
         from .. import _lib as L
-        self.convs = [m for m in model.modules() if isinstance(m, Conv3x3) and m.kernel_size == (3, 3)
-                      and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 32 == 0
-                      and m.weight.is_cuda and m.weight.dtype == torch.float32]
+        self.convs, self.modes = [], []
+        for m in model.modules():
+            if not (hasattr(m, "weight") and m.weight is not None and m.weight.is_cuda and m.weight.dtype == torch.float32):
+                continue
+            if isinstance(m, Conv3x3) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
+                    and m.in_channels % 32 == 0:
+                self.convs.append(m), self.modes.append((0, 1))
+            elif isinstance(m, Conv3x3S2) and m.stride == (2, 2) and m.padding == (1, 1) and m.bias is None \
+                    and m.in_channels % 32 == 0 and m.out_channels % 32 == 0:
+                self.convs.append(m), self.modes.append((2, 3))
+            elif isinstance(m, UpConvT) and m.kernel_size in ((1, 1), (2, 2)) and m.stride == m.kernel_size \
+                    and m.bias is None and m.in_channels % 32 == 0 and m.out_channels % 32 == 0:
+                self.convs.append(m), self.modes.append((m.MODE_F, m.MODE_F + 1))
         rows, first, self.bufs = [], 0, []
         lib = L.lib()
-        for m in self.convs:
+        for m, modes in zip(self.convs, self.modes):
             cin, cout = m.in_channels, m.out_channels
             pair = []
-            for mode in (0, 1):
+            for mode in modes:
                 nbytes = lib.pcd_conv2d_packed_weight_bytes(cin, cout, mode)
                 buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=m.weight.device)
                 rows.append([m.weight.data_ptr(), buf.data_ptr(), cin, cout, _pad32(cout), mode, first, nbytes // 16])
@@ -232,19 +427,53 @@ class BatchNormReLU2d(nn.BatchNorm2d):
                          track_running_stats=track_running_stats)
         self.relu = bool(relu)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out (optional): a [B, C, H, W] channel block of a wider channels-last map; when the fused training path
+        runs, y is written THERE (self.wrote_out = True) and the returned tensor is that view -- otherwise `out` is
+        ignored and the caller concatenates as usual."""
         from ..spconv import functional as Fsp
+        self.wrote_out = False
         if ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 \
                 and x.is_contiguous(memory_format=torch.channels_last):
             B, C, H, W = x.shape
             rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
             if Fsp._fusable(self, rows):
-                y = Fsp.batch_norm_act(self, rows, None, self.relu)
+                out_rows = None
+                if out is not None and self.training and self.relu and self.bias is not None \
+                        and out.shape == x.shape and out.dtype == x.dtype and out.stride(1) == 1:
+                    out_rows = out.permute(0, 2, 3, 1).reshape(B * H * W, C)
+                    if out_rows.data_ptr() != out.data_ptr() or out_rows.stride(1) != 1:
+                        out_rows = None                                   # (reshape had to copy: not a column block)
+                y = Fsp.batch_norm_act(self, rows, None, self.relu, out=out_rows)
+                self.wrote_out = out_rows is not None
                 return y.view(B, H, W, C).permute(0, 3, 1, 2)
         if getattr(self, "_defer_nbt", False) and self.training and self.num_batches_tracked is not None:
             self.num_batches_tracked.sub_(1)         # bump_bn_counters() already counted this call
         y = super().forward(x)
         return torch.relu(y) if self.relu else y
+
+
+class ConcatChannelBlocks(torch.autograd.Function):
+    """torch.cat(parts, dim=1) when the parts already ARE the channel blocks of `wide` (each BatchNorm wrote its output
+    there): returns `wide`, no copy; backward hands every part its channel block of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, wide, *parts):
+        off = 0
+        for p in parts:
+            assert p.data_ptr() == wide.data_ptr() + off * wide.element_size() and p.stride() == wide.stride()
+            off += p.shape[1]
+        assert off == wide.shape[1]
+        ctx.widths = [p.shape[1] for p in parts]
+        return wide.view_as(wide)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [None], 0
+        for w in ctx.widths:
+            outs.append(g[:, off:off + w])
+            off += w
+        return tuple(outs)
 
 
 def bump_bn_counters(module):

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import conv2d_fast
-from .conv2d_fast import BatchNormReLU2d, Conv3x3
+from .conv2d_fast import BatchNormReLU2d, ConcatChannelBlocks, Conv3x3, Conv3x3S2, UpConvT
 
 
 def _get(cfg, key, default=None):
@@ -24,6 +24,7 @@ def _get(cfg, key, default=None):
 
 class BaseBEVBackbone(nn.Module):
     """base_bev_backbone.py:6-112."""
+    SHARE_CAT = True     # deblock BatchNorms write into the concatenated map (False: torch.cat, for A/B tests)
 
     def __init__(self, model_cfg, input_channels, compute_dtype=torch.bfloat16):
         super().__init__()
@@ -47,6 +48,11 @@ class BaseBEVBackbone(nn.Module):
                 layers = [nn.Identity(),
                           Conv3x3(c_in_list[idx], num_filters[idx], kernel_size=3, stride=1, padding=1, bias=False),
                           bn(num_filters[idx]), nn.Identity()]
+            elif layer_strides[idx] == 2:
+                # ZeroPad2d(1) + Conv2d(3, stride 2, padding 0) == Conv2d(3, stride 2, padding 1): the plane kernel
+                layers = [nn.Identity(),
+                          Conv3x3S2(c_in_list[idx], num_filters[idx], kernel_size=3, stride=2, padding=1, bias=False),
+                          bn(num_filters[idx]), nn.Identity()]
             else:
                 layers = [nn.ZeroPad2d(1),
                           nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0,
@@ -58,15 +64,16 @@ class BaseBEVBackbone(nn.Module):
             if upsample_strides:
                 stride = upsample_strides[idx]
                 if stride >= 1:
-                    up = nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False)
+                    up = UpConvT(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False)
                 else:
                     k = int(np.round(1 / stride))
                     up = nn.Conv2d(num_filters[idx], num_upsample_filters[idx], k, stride=k, bias=False)
                 self.deblocks.append(nn.Sequential(up, bn(num_upsample_filters[idx]), nn.Identity()))
         c_in = sum(num_upsample_filters)
+        self.num_bev_features_cat = sum(num_upsample_filters[:len(layer_nums)])
         if len(upsample_strides) > len(layer_nums):
             self.deblocks.append(nn.Sequential(
-                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                UpConvT(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
                 bn(c_in), nn.Identity()))
         self.num_bev_features = c_in
 
@@ -78,13 +85,31 @@ class BaseBEVBackbone(nn.Module):
             x = spatial_features
             if x.is_cuda and not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)      # (the NHWC scatter makes this a no-op)
-            ups = []
+            ups, wide, off = [], None, 0
+            # the deblocks' BatchNorms write straight into the concatenated map when they can (no torch.cat pass,
+            # and their backward reads its channel block of the gradient in place)
+            share = (self.SHARE_CAT and len(self.deblocks) >= len(self.blocks) > 1 and x.is_cuda and x.dtype == torch.bfloat16
+                     and all(isinstance(d[1], BatchNormReLU2d) for d in self.deblocks[:len(self.blocks)]))
             for i in range(len(self.blocks)):
                 x = self.blocks[i](x)
                 stride = int(spatial_features.shape[2] / x.shape[2])
                 data_dict['spatial_features_%dx' % stride] = x
-                ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
-            if len(ups) > 1:
+                if len(self.deblocks) == 0:
+                    ups.append(x)
+                elif not share:
+                    ups.append(self.deblocks[i](x))
+                else:
+                    u = self.deblocks[i][0](x)
+                    if wide is None:
+                        wide = torch.empty((u.shape[0], u.shape[2], u.shape[3], self.num_bev_features_cat), dtype=u.dtype,
+                                           device=u.device).permute(0, 3, 1, 2)
+                    blk = wide[:, off:off + u.shape[1]] if u.shape[2:] == wide.shape[2:] else None
+                    ups.append(self.deblocks[i][2](self.deblocks[i][1](u, out=blk)))
+                    share = share and bool(self.deblocks[i][1].wrote_out)
+                    off += u.shape[1]
+            if len(ups) > 1 and share and off == wide.shape[1]:
+                x = ConcatChannelBlocks.apply(wide, *ups)
+            elif len(ups) > 1:
                 x = torch.cat(ups, dim=1)
             elif len(ups) == 1:
                 x = ups[0]

@@ -929,13 +929,27 @@ class LinearFunctionalLoss(torch.autograd.Function):
         return gx, None
 
 
+PLANE_MODES = {  # pack mode -> (parameter layout, kernel size): see pcd_conv2d_planes_nhwc
+    2: ("conv", 3), 3: ("conv", 3), 4: ("convT", 2), 5: ("convT", 2), 6: ("convT", 1), 7: ("convT", 1)}
+
+
+def conv2d_layer_channels(weight, mode):
+    """(cin, cout) of the LAYER a conv / transposed-conv weight belongs to (nn.Conv2d: [cout, cin, k, k];
+    nn.ConvTranspose2d: [cin, cout, k, k])."""
+    if mode >= 2 and PLANE_MODES[mode][0] == "convT":
+        return weight.shape[0], weight.shape[1]
+    return weight.shape[1], weight.shape[0]
+
+
 def conv2d_pack_weight(weight, mode=0):
     """nn.Conv2d weight [cout, cin, 3, 3] f32 -> MFMA fragment order (mode 0: forward, 1: data gradient); the output
-    channels are zero-padded to a multiple of 32 (run the conv with that count)."""
+    channels are zero-padded to a multiple of 32 (run the conv with that count).  Modes 2..7: the stride-2 conv and the
+    transposed convs of the plane kernels (conv2d_planes_nhwc)."""
     _require_cuda(weight)
     w = weight.detach().float().contiguous()
-    cout, cin = w.shape[0], w.shape[1]
-    assert tuple(w.shape[2:]) == (3, 3)
+    cin, cout = conv2d_layer_channels(w, mode)
+    k = PLANE_MODES[mode][1] if mode >= 2 else 3
+    assert tuple(w.shape[2:]) == (k, k)
     nbytes = L.lib().pcd_conv2d_packed_weight_bytes(cin, cout, mode)
     packed = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
     L.check(L.lib().pcd_conv2d_pack_weight(L.ptr(w), cin, cout, mode, L.ptr(packed), L.stream_ptr()),
@@ -956,6 +970,25 @@ def conv2d_3x3_nhwc(x, packed_w, cout, bias=None):
                              rows=B * H * W, pairs=0)):
         L.check(L.lib().pcd_conv2d_3x3_nhwc(L.ptr(x), B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
                                             L.stream_ptr()), "pcd_conv2d_3x3_nhwc")
+    return y
+
+
+def conv2d_planes_nhwc(mode, x, packed_w, cout, out_hw, bias=None):
+    """The stride-2 conv / transposed convs of BaseBEVBackbone on channels-last bf16 maps (pack modes 2..7 of
+    pcd_conv2d_planes_nhwc): x [B, hi, wi, cin] -> [B, ho, wo, cout]; `cout` = channels of the result."""
+    _require_cuda(x, packed_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    B, hi, wi, cin = x.shape
+    ho, wo = out_hw
+    y = torch.empty((B, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    taps = {2: 9, 3: 9, 4: 4, 5: 4, 6: 1, 7: 1}[mode]
+    coarse = B * min(hi, ho) * min(wi, wo)
+    with _Timed(f"conv2d_planes_kernel<{mode}> {cin}->{cout} {hi}x{wi}",
+                lambda: dict(bytes=(x.numel() + y.numel()) * 2 + taps * cin * cout * 2, flops=2 * taps * coarse * cin * cout,
+                             rows=coarse, pairs=0)):
+        L.check(L.lib().pcd_conv2d_planes_nhwc(mode, L.ptr(x), B, hi, wi, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
+                                               ho, wo, L.stream_ptr()), "pcd_conv2d_planes_nhwc")
     return y
 
 
@@ -1058,29 +1091,40 @@ def bev_gather(dout, indices, batch_size, spatial_shape, channels, c_stride=None
 
 
 # ---------------------------------------------------------------------------------------------
+def _row_block(t, n, c):
+    """row stride (elements) of a [n, c] column block of a wider row-major matrix (or of a plain contiguous [n, c])."""
+    assert t.shape == (n, c) and t.stride(1) == 1 and t.stride(0) >= c, "need unit column stride"
+    return t.stride(0) if n > 1 else c
+
+
 def bn_forward(x, residual, gamma, beta, eps, momentum, training, running_mean, running_var, relu, n_dev=None,
-               partials=None):
+               partials=None, out=None):
     """Fused BatchNorm1d (+residual) (+ReLU) over [n, c] (spconv_backbone.py:21-25,50-66).
     `partials` = (tensor [rows, 2, c], rows): column sums the producing conv already took (BnReduce mode 1).
+    `out`: a [n, c] column block of a wider matrix to write y into (pcd_bn_forward_ld).
     Returns (y, save_mean, save_invstd)."""
     _require_cuda(x)
     assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype))
     n, c = x.shape
     dev = x.device
     lib = L.lib()
-    y = torch.empty_like(x)
+    if out is not None:
+        assert out.dtype == x.dtype and out.device == x.device
+        y, y_ld = out, _row_block(out, n, c)
+    else:
+        y, y_ld = torch.empty_like(x), c
     save_mean = torch.empty((c,), dtype=torch.float32, device=dev)
     save_invstd = torch.empty((c,), dtype=torch.float32, device=dev)
     ws = _ws(lib.pcd_bn_workspace_bytes(c), dev)
     e = x.element_size()                         # SURVEY 8d: 2 N C e (3 with residual) per pass
     with _Timed("bn_forward", lambda: dict(bytes=(3 if residual is not None else 2) * n * c * e, flops=0, rows=n,
                                            pairs=0)):
-        L.check(lib.pcd_bn_forward(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
-                                   float(eps), float(momentum), int(training), L.ptr(running_mean),
-                                   L.ptr(running_var), int(relu), L.ptr(y), L.ptr(save_mean), L.ptr(save_invstd),
-                                   L.ptr(n_dev), L.ptr(partials[0]) if partials else None,
-                                   partials[1] if partials else 0, L.ptr(ws), ws.numel(), L.stream_ptr()),
-                "pcd_bn_forward")
+        L.check(lib.pcd_bn_forward_ld(L.ptr(x), L.ptr(residual), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
+                                      float(eps), float(momentum), int(training), L.ptr(running_mean),
+                                      L.ptr(running_var), int(relu), L.ptr(y), int(y_ld), L.ptr(save_mean),
+                                      L.ptr(save_invstd), L.ptr(n_dev), L.ptr(partials[0]) if partials else None,
+                                      partials[1] if partials else 0, L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "pcd_bn_forward_ld")
     return y, save_mean, save_invstd
 
 
@@ -1093,8 +1137,11 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     _require_cuda(dy, x)
     if relu and y is None and (beta is None or not training):
         raise ValueError("bn_backward: y=None needs beta and training statistics")
-    dy = dy.contiguous()
     n, c = x.shape
+    if not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) >= c and dy.stride(0) % (16 // dy.element_size()) == 0
+            and dy.data_ptr() % 16 == 0):
+        dy = dy.contiguous()                     # (a column block of a wider gradient is read in place)
+    dy_ld = _row_block(dy, n, c)
     dev = x.device
     lib = L.lib()
     dx = torch.empty_like(x)
@@ -1109,11 +1156,11 @@ def bn_backward(dy, x, y, gamma, save_mean, save_invstd, relu, training, want_dr
     e = x.element_size()                         # reads dy, x (, y), writes dx (, dres)
     with _Timed("bn_backward", lambda: dict(bytes=(3 + (y is not None) + bool(want_dres)) * n * c * e, flops=0,
                                             rows=n, pairs=0)):
-        L.check(lib.pcd_bn_backward(L.ptr(dy), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma), L.ptr(beta),
-                                    L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training), L.ptr(dx),
-                                    L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
-                                    L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
-                                    L.ptr(cpart), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward")
+        L.check(lib.pcd_bn_backward_ld(L.ptr(dy), int(dy_ld), L.ptr(x), L.ptr(y), _dtype_code(x), n, c, L.ptr(gamma),
+                                       L.ptr(beta), L.ptr(save_mean), L.ptr(save_invstd), int(relu), int(training),
+                                       L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(n_dev),
+                                       L.ptr(partials[0]) if partials else None, partials[1] if partials else 0,
+                                       L.ptr(cpart), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_bn_backward_ld")
     if colsum:
         return dx, dres, dgamma, dbeta, (cpart, crows)
     return dx, dres, dgamma, dbeta

@@ -381,7 +381,8 @@ class FusedBNFunction(Function):
     (spconv_backbone.py:21-25,50-66); parameters / buffers stay in the caller's nn.BatchNorm1d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu, n_dev=None):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, n_dev=None, out=None):
+        # out: a [n, c] column block of a wider matrix that receives y (the concatenated map of BaseBEVBackbone)
         xc = x.detach().contiguous()
         rc = residual.detach().contiguous() if residual is not None else None
         if rc is not None and rc.dtype != xc.dtype:
@@ -396,7 +397,7 @@ class FusedBNFunction(Function):
                 and xc.dtype == torch.bfloat16 and st.partial.shape[2] == xc.shape[1]:
             partials = (st.partial, st.rows)         # the conv that produced x already summed its columns
         y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
-                                                   bn.running_var, relu, n_dev=n_dev, partials=partials)
+                                                   bn.running_var, relu, n_dev=n_dev, partials=partials, out=out)
         if not training:
             save_mean = bn.running_mean
             save_invstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -405,6 +406,8 @@ class FusedBNFunction(Function):
         ctx.bn = bn
         # without a residual the ReLU mask is recomputed from x in the backward (one [n][c] read less per pass)
         ctx.mask_from_x = bool(relu and residual is None and training and b is not None)
+        if out is not None and not ctx.mask_from_x:
+            raise RuntimeError("FusedBNFunction(out=...): only for the training form without a residual")
         ctx.save_for_backward(xc, None if ctx.mask_from_x else y, g, b, save_mean, save_invstd)
         cl = getattr(x, "_pcd_colsum_link", None) if FUSE_BN_REDUCTIONS else None
         ctx.colsum_link = cl if (cl is not None and xc.data_ptr() == x.data_ptr() and training) else None
@@ -443,7 +446,7 @@ class FusedBNFunction(Function):
         if direct:
             dgamma = dbeta = None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                dres, None, None, None)
+                dres, None, None, None, None)
 
 
 def _fusable(bn, x):
@@ -460,12 +463,14 @@ def _fusable(bn, x):
     return (256 % pcs) == 0 and (bn.running_mean is not None or bn.training)
 
 
-def batch_norm_act(bn, x, residual=None, relu=True, n_dev=None):
-    """y = relu?(bn(x) + residual?) through the fused HIP kernels when the shape allows, else torch."""
+def batch_norm_act(bn, x, residual=None, relu=True, n_dev=None, out=None):
+    """y = relu?(bn(x) + residual?) through the fused HIP kernels when the shape allows, else torch.
+    out (fused path only): column block of a wider matrix to write y into."""
     if _fusable(bn, x):
         if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_defer_nbt", False):
             bn.num_batches_tracked.add_(1)
-        return FusedBNFunction.apply(x, bn.weight, bn.bias, residual, bn, relu, n_dev)
+        return FusedBNFunction.apply(x, bn.weight, bn.bias, residual, bn, relu, n_dev, out)
+    assert out is None
     if n_dev is not None:
         raise RuntimeError("static-shape mode needs the fused BatchNorm path (unsupported channel count / dtype)")
     y = bn(x)

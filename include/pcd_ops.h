@@ -426,6 +426,20 @@ int pcd_bn_backward(const void *dy, const void *x, const void *y, int dtype, int
                     int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     const int32_t *n_dev, const float *ext_partial, int ext_rows, float *colsum_partial,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* The same two calls for a BatchNorm whose OUTPUT (forward) / output GRADIENT (backward) is a column block of a wider
+ * row-major matrix: y_ld / dy_ld = row stride in elements (>= c, a multiple of the 16-byte piece).  Lets the two
+ * deblock BatchNorms of BaseBEVBackbone write straight into the concatenated map and read their halves of its
+ * gradient (base_bev_backbone.py:103-108 torch.cat) without a copy either way. */
+int pcd_bn_forward_ld(const void *x, const void *residual, int dtype, int n, int c, const float *gamma,
+                      const float *beta, float eps, float momentum, int training, float *running_mean,
+                      float *running_var, int relu, void *y, int y_ld, float *save_mean, float *save_invstd,
+                      const int32_t *n_dev, const float *ext_partial, int ext_rows, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int pcd_bn_backward_ld(const void *dy, int dy_ld, const void *x, const void *y, int dtype, int n, int c,
+                       const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                       int relu, int training, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                       const int32_t *n_dev, const float *ext_partial, int ext_rows, float *colsum_partial,
+                       void *workspace, size_t workspace_bytes, void *stream);
 /* colsum_partial (NULL = off): [pcd_bn_backward_colsum_rows(dtype, n, c)][c] f32, per-workgroup column sums of dx as
  * stored.  dx is dy of the conv in front of the BatchNorm, its column sum that conv's bias gradient
  * (spconv_backbone.py:37-44, bias=True inside SparseBasicBlock): pcd_col_sum_finalize adds the rows up in a fixed
@@ -733,6 +747,17 @@ int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, voi
 int pcd_conv2d_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w, int cout,
                         const float *bias, void *y, void *stream);
+/* The other three layers of BaseBEVBackbone (base_bev_backbone.py:36-75; MIOpen in the reference), forward and data
+ * gradient, as per-parity-plane stencils on the same tiles.  pack modes (pcd_conv2d_pack_weight / _packed_weight_bytes /
+ * the batched table take them too; cin / cout are the LAYER's channel counts, the weight is the torch parameter):
+ *   2  Conv2d(cin, cout, 3, stride 2, padding 1) forward          x [b][hi][wi][cin]  -> y [b][ho][wo][cout], ho = (hi-1)/2+1
+ *   3  its data gradient                                           dy [b][hi][wi][cout] -> dx [b][ho][wo][cin], hi = (ho-1)/2+1
+ *   4  ConvTranspose2d(cin, cout, 2, stride 2) forward             x [b][hi][wi][cin]  -> y [b][2hi][2wi][cout]
+ *   5  its data gradient                                           dy [b][hi][wi][cout] -> dx [b][hi/2][wi/2][cin]
+ *   6 / 7  ConvTranspose2d(cin, cout, 1, stride 1) forward / data gradient (a 1 x 1 conv)
+ * `cin` / `cout` of THIS call are the channel counts of x and y (i.e. swapped for the data gradients); both % 32 == 0. */
+int pcd_conv2d_planes_nhwc(int pack_mode, const void *x, int batch, int hi, int wi, int cin, const void *packed_w,
+                           int cout, const float *bias, void *y, int ho, int wo, void *stream);
 
 /* <a, b> of two bf16 vectors (fp32 products, fp64 partial sums) -> out[0], and y = bf16(a * scale_dev[0]): forward and
  * backward of a fixed linear functional of the BEV map -- bench.py's stand-in for the dense head's loss when only the

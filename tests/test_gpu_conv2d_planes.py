@@ -1,0 +1,153 @@
+"""GPU: the stride-2 3x3 conv and the two ConvTranspose2d of BaseBEVBackbone (base_bev_backbone.py:36-75) through
+pcd_conv2d_planes_nhwc -- forward and data gradient against torch's float32 conv2d / conv_transpose2d on the SAME
+bf16-rounded operands (the reference's arithmetic for these layers is exactly torch's): the only differences are the
+fp32 summation order and the bf16 rounding of the result, so the bound is one bf16 ulp of the largest magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref):
+    err = (got.float() - ref).abs().max().item()
+    assert err <= 2 ** -7 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(128, 256, (188, 188)), (32, 64, (37, 50)), (64, 32, (33, 18)), (32, 32, (16, 2))])
+def test_conv3x3_stride2_forward_and_data_gradient(cin, cout, hw):
+    from com_amd import ops
+    torch.manual_seed(1)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, cin, H, W, device=DEV).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, device=DEV) * (2.0 / (9 * cin)) ** 0.5)
+    wr = w.bfloat16().float()
+    bias = torch.randn(cout, device=DEV)
+    ref = F.conv2d(x.float(), wr, bias, stride=2, padding=1)
+    Ho, Wo = ref.shape[2:]
+    y = ops.conv2d_planes_nhwc(2, _nhwc(x), ops.conv2d_pack_weight(w, 2), cout, (Ho, Wo), bias=bias)
+    _close(y.permute(0, 3, 1, 2), ref)
+    dy = torch.randn(B, cout, Ho, Wo, device=DEV).bfloat16()
+    xr = x.float().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=2, padding=1).backward(dy.float())
+    dx = ops.conv2d_planes_nhwc(3, _nhwc(dy), ops.conv2d_pack_weight(w, 3), cin, (H, W))
+    _close(dx.permute(0, 3, 1, 2), xr.grad)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(256, 256, (94, 94)), (32, 64, (19, 23)), (64, 32, (16, 16))])
+def test_conv_transpose_2x2_stride2_forward_and_data_gradient(cin, cout, hw):
+    from com_amd import ops
+    torch.manual_seed(2)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, cin, H, W, device=DEV).bfloat16()
+    w = torch.randn(cin, cout, 2, 2, device=DEV) * (1.0 / cin) ** 0.5
+    wr = w.bfloat16().float()
+    ref = F.conv_transpose2d(x.float(), wr, None, stride=2)
+    y = ops.conv2d_planes_nhwc(4, _nhwc(x), ops.conv2d_pack_weight(w, 4), cout, (2 * H, 2 * W))
+    _close(y.permute(0, 3, 1, 2), ref)
+    dy = torch.randn(B, cout, 2 * H, 2 * W, device=DEV).bfloat16()
+    xr = x.float().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, stride=2).backward(dy.float())
+    dx = ops.conv2d_planes_nhwc(5, _nhwc(dy), ops.conv2d_pack_weight(w, 5), cin, (H, W))
+    _close(dx.permute(0, 3, 1, 2), xr.grad)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(128, 256, (188, 188)), (32, 32, (21, 40))])
+def test_conv_transpose_1x1_forward_and_data_gradient(cin, cout, hw):
+    from com_amd import ops
+    torch.manual_seed(3)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, cin, H, W, device=DEV).bfloat16()
+    w = torch.randn(cin, cout, 1, 1, device=DEV) * (1.0 / cin) ** 0.5
+    wr = w.bfloat16().float()
+    ref = F.conv_transpose2d(x.float(), wr, None, stride=1)
+    y = ops.conv2d_planes_nhwc(6, _nhwc(x), ops.conv2d_pack_weight(w, 6), cout, (H, W))
+    _close(y.permute(0, 3, 1, 2), ref)
+    dy = torch.randn(B, cout, H, W, device=DEV).bfloat16()
+    xr = x.float().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, stride=1).backward(dy.float())
+    dx = ops.conv2d_planes_nhwc(7, _nhwc(dy), ops.conv2d_pack_weight(w, 7), cin, (H, W))
+    _close(dx.permute(0, 3, 1, 2), xr.grad)
+
+
+def _module_case(kind, cin, cout, hw):
+    from com_amd.hotpath.conv2d_fast import Conv3x3S2, UpConvT
+    if kind == "s2":
+        m = Conv3x3S2(cin, cout, 3, stride=2, padding=1, bias=False).cuda()
+        ref = lambda xr, wr: F.conv2d(xr, wr, None, stride=2, padding=1)
+    else:
+        k = 2 if kind == "t2" else 1
+        m = UpConvT(cin, cout, k, stride=k, bias=False).cuda()
+        ref = lambda xr, wr: F.conv_transpose2d(xr, wr, None, stride=k)
+    return m, ref
+
+
+@pytest.mark.parametrize("kind,cin,cout,hw", [("s2", 128, 256, (47, 52)), ("s2", 32, 64, (20, 18)),
+                                              ("t2", 256, 256, (24, 26)), ("t2", 64, 32, (9, 31)),
+                                              ("t1", 128, 256, (40, 33)), ("t1", 32, 32, (5, 7))])
+def test_plane_modules_forward_and_all_gradients(kind, cin, cout, hw):
+    """Conv3x3S2 / UpConvT (drop-in nn.Conv2d / nn.ConvTranspose2d subclasses) against torch in fp32 on the same
+    bf16-rounded operands: y and dx within bf16 output rounding, dW (pair kernels over the dense pair lists, in the
+    PARAMETER's layout -- [cin, cout, k, k] for the transposed convs) within 2e-3; fp32 inputs take torch's own path."""
+    torch.manual_seed(cin + cout + hw[0])
+    B, (H, W) = 2, hw
+    m, ref = _module_case(kind, cin, cout, hw)
+    x = torch.randn(B, cin, H, W, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = m(x)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = m.weight.detach().bfloat16().float().requires_grad_(True)
+    yr = ref(xr, wr)
+    assert yr.shape == y.shape
+    yr.backward(gy.float())
+    rel = lambda a, b: float((a.detach().float() - b.detach()).abs().max() / b.detach().abs().max())
+    assert rel(y, yr) <= 6e-3 and rel(x.grad, xr.grad) <= 6e-3, (rel(y, yr), rel(x.grad, xr.grad))
+    assert m.weight.grad.shape == m.weight.shape and rel(m.weight.grad, wr.grad) <= 2e-3, rel(m.weight.grad, wr.grad)
+    y32 = m(x.detach().float())                                        # outside autocast: nn's own fp32 path
+    assert y32.dtype == torch.float32 and rel(y32, yr) <= 2e-2
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("s2", 128, 256), ("t2", 256, 256), ("t1", 128, 256)])
+def test_plane_modules_direct_deferred_gradients_and_packs_ahead(kind, cin, cout):
+    """bench.py's mode (DIRECT_GRAD + lagged join: dW written into a pre-allocated .grad by the deferred slab reduction
+    in the parameter's layout) and packs made ahead by Conv3x3Packs: bit-identical to the plain path."""
+    from com_amd.hotpath.conv2d_fast import Conv3x3Packs
+    from com_amd.spconv import functional as Fsp
+    torch.manual_seed(5)
+    B, H, W = 2, 22, 19
+    m, _ = _module_case(kind, cin, cout, (H, W))
+    x = torch.randn(B, cin, H, W, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(m(x))
+
+    def run(direct, plan=None):
+        xi = x.clone().requires_grad_(True)
+        m.weight.grad = torch.full_like(m.weight, 7.0) if direct else None
+        if plan is not None:
+            plan.run()
+        old = (Fsp.DIRECT_GRAD, Fsp.WGRAD_JOIN_LAG)
+        Fsp.DIRECT_GRAD, Fsp.WGRAD_JOIN_LAG = (True, 8) if direct else (False, 0)
+        try:
+            y = m(xi)
+            y.backward(gy)
+            Fsp.join_deferred_wgrad()
+        finally:
+            Fsp.DIRECT_GRAD, Fsp.WGRAD_JOIN_LAG = old
+            Fsp.reset_deferred()
+        torch.cuda.synchronize()
+        return y.detach().clone(), xi.grad.clone(), m.weight.grad.clone()
+
+    a = run(False)
+    b = run(True)
+    plan = Conv3x3Packs(torch.nn.Sequential(m))
+    assert len(plan.convs) == 1
+    c = run(True, plan)
+    assert m._packs_ahead is None                                      # consumed
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w)

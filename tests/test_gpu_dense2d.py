@@ -194,3 +194,50 @@ def test_conv3x3_direct_deferred_gradients_equal_the_plain_path(cin, cout, bias)
             assert torch.equal(a, b_), float((a - b_).abs().max())
         else:   # padded output channels: the direct path is not taken, autograd ADDS to the pre-set .grad
             torch.testing.assert_close(b_, a + 7.0, rtol=1e-6, atol=1e-6)
+
+
+def test_batchnorm_into_a_column_block_and_from_a_gradient_block_is_bit_identical():
+    """pcd_bn_forward_ld / pcd_bn_backward_ld: y written into a column block of a wider matrix, dy read from a column
+    block of a wider gradient -- bit-identical to the dense calls (same kernels, same summation order)."""
+    from com_amd import ops
+    torch.manual_seed(3)
+    n, c, wide = 5000, 64, 192
+    x = torch.randn(n, c, device=DEV).bfloat16()
+    g, b = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+    y0, m0, s0 = ops.bn_forward(x, None, g, b, 1e-3, 0.01, True, None, None, True)
+    buf = torch.full((n, wide), 7.0, device=DEV).bfloat16()
+    y1, m1, s1 = ops.bn_forward(x, None, g, b, 1e-3, 0.01, True, None, None, True, out=buf[:, 64:128])
+    assert y1.data_ptr() == buf[:, 64:128].data_ptr()
+    assert torch.equal(buf[:, 64:128], y0) and torch.equal(m0, m1) and torch.equal(s0, s1)
+    assert bool((buf[:, :64] == 7).all()) and bool((buf[:, 128:] == 7).all())
+    dyw = torch.randn(n, wide, device=DEV).bfloat16()
+    r0 = ops.bn_backward(dyw[:, 64:128].contiguous(), x, None, g, m0, s0, True, True, False, beta=b)
+    r1 = ops.bn_backward(dyw[:, 64:128], x, None, g, m0, s0, True, True, False, beta=b)
+    for u, v in zip(r0, r1):
+        assert (u is None and v is None) or torch.equal(u, v)
+
+
+def test_bev_backbone_without_the_cat_pass_is_bit_identical_to_torch_cat():
+    from com_amd.hotpath import dense2d
+    torch.manual_seed(4)
+    bb = dense2d.BaseBEVBackbone(dense2d.CENTERPOINT_BACKBONE_2D, 256).to(DEV).train()
+    x = (torch.randn(2, 256, 40, 36, device=DEV) * (torch.rand(2, 1, 40, 36, device=DEV) < 0.2)).bfloat16()
+    x = x.contiguous(memory_format=torch.channels_last)
+    gy = None
+    res = []
+    for share in (False, True):
+        bb.SHARE_CAT = share
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        for p in bb.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = bb({"spatial_features": xi})["spatial_features_2d"]
+        assert y.shape == (2, 512, 40, 36) and y.is_contiguous(memory_format=torch.channels_last)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        res.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in bb.parameters()])
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
