@@ -69,6 +69,7 @@ PROTOTYPES = {
     "pcd_conv2d_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pcd_conv2d_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_conv2d_3x3_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "pcd_conv2d_3x3_nhwc_ld": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "pcd_conv2d_planes_nhwc": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
@@ -177,7 +178,7 @@ class PcdWgradReduceJob(ctypes.Structure):
     """include/pcd_ops.h: struct PcdWgradReduceJob."""
     _fields_ = [("workspace", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("kvol", ctypes.c_int),
                 ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("pmax", ctypes.c_int), ("splits", ctypes.c_int),
-                ("layout", ctypes.c_int)]
+                ("layout", ctypes.c_int), ("cout_write", ctypes.c_int)]
 
 
 WGRAD_MAX_JOBS = 32

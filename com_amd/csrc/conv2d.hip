@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const 
                                                              int cin, const uint4 *__restrict__ wp, int cout,
                                                              const float *__restrict__ bias,
                                                              unsigned short *__restrict__ y, unsigned x_bytes,
-                                                             unsigned w_bytes) {
+                                                             unsigned w_bytes, int x_cs, int y_cs) {
+    // x_cs / y_cs: channels per pixel of the buffers x / y live in (>= cin / cout: a channel block of a wider map)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *in_s = smem;                       // [2][IN_BYTES]
     char *w_s = smem + 2 * IN_BYTES;         // [WB][W_BYTES]
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const 
         const int py = pix / HT, px = pix - py * HT;
         const int gy = y0 + py - 1, gx = x0 + px - 1;
         const bool ok = p < HT * HT * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        in_off[it] = ok ? (unsigned)((((size_t)b * H + gy) * W + gx) * cin * 2 + piece * 16) : 0xFFFFFFF0u;
+        in_off[it] = ok ? (unsigned)((((size_t)b * H + gy) * W + gx) * x_cs * 2 + piece * 16) : 0xFFFFFFF0u;
     }
     u32x4 in_r[6], w_r[9];
     auto load_chunk = [&](int cc) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const 
             o[mb * 2] = lo0 | (hi0 << 16);
             o[mb * 2 + 1] = lo1 | (hi1 << 16);
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(y + (((size_t)b * H + gy) * W + gx) * cout + c0);
+        uint4 *dst = reinterpret_cast<uint4 *>(y + (((size_t)b * H + gy) * W + gx) * y_cs + c0);
         dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
         dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
@@ -484,13 +485,13 @@ extern "C" int pcd_conv2d_pack_weights_batched(const void *table, int n, int tot
     return PCD_OK;
 }
 
-extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w,
-                                   int cout, const float *bias, void *y, void *stream) {
+extern "C" int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin,
+                                      const void *packed_w, int cout, const float *bias, void *y, int y_cs, void *stream) {
     PCD_ENTER();
     if (batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0) return PCD_ERR_INVALID_ARG;
-    if (!x || !packed_w || !y) return PCD_ERR_INVALID_ARG;
+    if (!x || !packed_w || !y || x_cs < cin || y_cs < cout || x_cs % 8 || y_cs % 8) return PCD_ERR_INVALID_ARG;
     if (cin % 32 || cout % 16) return PCD_ERR_UNSUPPORTED;
-    const double xb = (double)batch * height * width * cin * 2;
+    const double xb = ((double)batch * height * width - 1) * x_cs * 2 + (double)cin * 2;
     if (xb >= 4294966000.0) return PCD_ERR_UNSUPPORTED;
     const size_t wb_bytes = (size_t)((cout + 63) / 64) * (cin / 32) * W_BYTES;   // bytes of the pack the kernel reads
     static const int wb = getenv("PCD_CONV2D_WB") ? atoi(getenv("PCD_CONV2D_WB")) : 1;   // (1: 28-35 % of the MFMA peak, 2: 21-27 %)
@@ -509,13 +510,20 @@ extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int wid
     if (wb == 1)
         conv2d_3x3_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
                                                                      (const uint4 *)packed_w, cout, bias,
-                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes);
+                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes,
+                                                                     x_cs, y_cs);
     else
         conv2d_3x3_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
                                                                      (const uint4 *)packed_w, cout, bias,
-                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes);
+                                                                     (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes,
+                                                                     x_cs, y_cs);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
+}
+
+extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w,
+                                   int cout, const float *bias, void *y, void *stream) {
+    return pcd_conv2d_3x3_nhwc_ld(x, cin, batch, height, width, cin, packed_w, cout, bias, y, cout, stream);
 }
 
 

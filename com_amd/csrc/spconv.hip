@@ -2659,7 +2659,10 @@ constexpr int WGRAD_OS_ROWS = 1024;     // output rows per workgroup (= per slab
 template <int V>   // V = 4: four consecutive elements per thread (16-byte loads), n % 4 == 0;  V = 1: scalar
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int splits, size_t n,
                                                   float *__restrict__ dw, unsigned block, float *lds,
-                                                  int tr_k = 0, int tr_cin = 0) {
+                                                  int tr_k = 0, int tr_cin = 0, size_t stride = 0) {
+    // n = elements to reduce and write (a PREFIX of every slab when only the first output channels are real),
+    // stride = elements between two slabs (0: n)
+    if (stride == 0) stride = n;
     float(*part)[32][V] = reinterpret_cast<float(*)[32][V]>(lds);   // [8][32][V]
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t e = ((size_t)block * 32 + el) * V;
@@ -2668,10 +2671,10 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab
     for (int j = 0; j < V; ++j) s[j] = 0.0f;
     auto ld = [&](int q, float (&v)[V]) {
         if (V == 4) {
-            float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)q * n + e);
+            float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)q * stride + e);
             v[0] = t.x; v[1 % V] = t.y; v[2 % V] = t.z; v[3 % V] = t.w;
         } else {
-            v[0] = slab[(size_t)q * n + e];
+            v[0] = slab[(size_t)q * stride + e];
         }
     };
     if (e < n) {
@@ -2735,7 +2738,7 @@ struct RedJobs {
     struct {
         const float *slab;
         float *dw;
-        unsigned long long n;
+        unsigned long long n, stride;
         int splits, vec;
         unsigned first_block;
         int tr_k, tr_cin;        // > 0: write [cout][cin][K]
@@ -2753,10 +2756,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
         wgrad_tiles_reduce_body(J.job[j].slab, (int)J.job[j].n, J.job[j].dw, block, J.job[j].tr_k);
     else if (J.job[j].vec)
         wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
-                             J.job[j].tr_k, J.job[j].tr_cin);
+                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride);
     else
         wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
-                             J.job[j].tr_k, J.job[j].tr_cin);
+                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride);
 }
 
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
@@ -3154,12 +3157,14 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
     unsigned blocks = 0;
     for (int i = 0; i < n_jobs; ++i) {
         const PcdWgradReduceJob &q = jobs_host[i];
-        if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight || (q.layout != 0 && q.layout != 1))
+        if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight || (q.layout != 0 && q.layout != 1) ||
+            q.cout_write < 0 || q.cout_write > q.cout)
             return PCD_ERR_INVALID_ARG;
         if (q.pmax == 0 && q.splits <= 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
         if (!q.workspace) return PCD_ERR_WORKSPACE;
         int splits, per;
         if (q.splits <= 0 && wgrad128_use(q.cin, q.cout)) {
+            if (q.cout_write > 0 && q.cout_write != q.cout) return PCD_ERR_UNSUPPORTED;
             auto &d = J.job[J.n_jobs++];
             d.slab = (const float *)q.workspace;
             d.dw = q.dweight;
@@ -3174,12 +3179,14 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
         }
         wgrad_plan(q.pmax, q.cin, q.cout, &splits, &per);
         if (q.splits > 0) splits = q.splits;          // slabs written by pcd_sparse_conv_wgrad_os
-        const size_t n = (size_t)q.cout * q.kvol * q.cin;
-        const bool vec = (n & 3) == 0 && (((uintptr_t)q.dweight | (uintptr_t)q.workspace) & 15u) == 0;
+        const size_t stride = (size_t)q.cout * q.kvol * q.cin;
+        const size_t n = q.cout_write > 0 ? (size_t)q.cout_write * q.kvol * q.cin : stride;   // real rows = a slab prefix
+        const bool vec = (n & 3) == 0 && (stride & 3) == 0 && (((uintptr_t)q.dweight | (uintptr_t)q.workspace) & 15u) == 0;
         auto &d = J.job[J.n_jobs++];
         d.slab = (const float *)q.workspace;
         d.dw = q.dweight;
         d.n = n;
+        d.stride = stride;
         d.splits = splits;
         d.vec = vec ? 1 : 0;
         d.first_block = blocks;

@@ -195,20 +195,23 @@ class _Conv3x3Function(torch.autograd.Function):
 
         def wgrad(direct):
             pairs, num = _dense_pairs(B, H, W, xn.device)
-            if direct:
+            if direct:   # (zero-padded output channels: only the real rows of the slabs are reduced into .grad)
                 ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9, out=wp.grad,
-                          defer=Fsp._WGRAD_JOBS, conv2d_layout=True)
+                          defer=Fsp._WGRAD_JOBS, conv2d_layout=True, cout_write=cout if cp != cout else 0)
                 return None
             dwk = ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9)  # [cp, 9, cin] f32
             return dwk[:cout].permute(0, 2, 1).reshape(cout, cin, 3, 3).to(weight.dtype)
 
         def bsum(direct):
-            if direct:
+            if direct and cp == cout:
                 ops.col_sum(dyn.reshape(-1, cp), out=bp.grad)
+                return None
+            if direct:
+                bp.grad.copy_(ops.col_sum(dyn.reshape(-1, cp))[:cout])
                 return None
             return ops.col_sum(dyn.reshape(-1, cp))[:cout]   # fp32 column sums in a fixed order
 
-        dx, dw, db = _scheduled_backward(ctx.needs_input_grad[0], want_w, want_b, wp, bp, cp == cout, dgrad, wgrad, bsum,
+        dx, dw, db = _scheduled_backward(ctx.needs_input_grad[0], want_w, want_b, wp, bp, True, dgrad, wgrad, bsum,
                                          (xn, dyn))
         return dx, dw, db, None, None
 

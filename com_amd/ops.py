@@ -823,7 +823,7 @@ WGRAD_OS = True      # 16-output-channel layers: output-stationary kernel over n
 
 
 def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None, n_out_dev=None, rb=None,
-          conv2d_layout=False):
+          conv2d_layout=False, x_block=False, cout_write=0):
     """dW [Cout, K, Cin] f32 from bf16 x [n_in, cin_pad] and dy [n_out, cout]; written straight into `out`
     (e.g. the parameter's .grad) when given.  `defer` (a list): only the MFMA kernel runs now, into a slab buffer of
     its own; the slab reduction is appended to the list as a job for wgrad_reduce_batched (one launch for all).
@@ -831,17 +831,28 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     `rb` (instead of pairs / pair_num / nbr_out): a Rulebook -- its pairs are only touched (and, for a SubM rulebook
     built without them, only then derived) when the pair-based kernel is the one that runs.
     `conv2d_layout` (needs `defer`): the deferred reduction writes dW as [Cout, Cin, K] -- the memory layout of an
-    nn.Conv2d weight [Cout, Cin, 3, 3] -- so `out` can be that parameter's .grad."""
+    nn.Conv2d weight [Cout, Cin, 3, 3] -- so `out` can be that parameter's .grad.
+    `x_block`: x is a column block [n, cin] of a wider row-major matrix (row stride x.stride(0)), pair kernels only.
+    `cout_write` (needs `defer` + `out`): dy carries zero-padded output channels; only the first cout_write rows of dW are
+    reduced and written (`out` = a [cout_write, ...] gradient)."""
     assert not conv2d_layout or defer is not None
     n_in_dev = None
     if rb is not None:
         nbr_out, n_out_dev, n_in_dev = rb.nbr_out, rb.n_out_dev, rb.n_in_dev
     _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert dy.is_contiguous()
+    if x_block:
+        assert x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.shape[1] == cin and nbr_out is None \
+            and rb is None and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0
+        x_ld = x.stride(0)
+    else:
+        assert x.is_contiguous()
+        x_ld = x.shape[1]
     cout = dy.shape[1]
     lib = L.lib()
-    dw = out if _usable_out(out, cout * kvol * cin) else \
+    assert cout_write == 0 or (defer is not None and _usable_out(out, cout_write * kvol * cin) and nbr_out is None)
+    dw = out if _usable_out(out, (cout_write or cout) * kvol * cin) else \
         torch.empty((cout, kvol, cin), dtype=torch.float32, device=x.device)
     os_splits = 0
     if WGRAD_OS and nbr_out is not None and nbr_out.is_contiguous() and nbr_out.shape[1] >= dy.shape[0]:
@@ -890,11 +901,11 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     kname = "wgrad128_kernel" if (cin == 128 and cout == 128 and x.shape[1] == 128) else \
         f"wgrad_kernel<{blocks(cin)}, {blocks(cout)}>"
     with _Timed(f"{kname} {x.shape[1]}x{cout} K={kvol}", meta):
-        L.check(lib.pcd_sparse_conv_wgrad_v2(L.ptr(x), x.shape[0], L.ptr(n_in_dev), x.shape[1], cin, L.ptr(dy),
+        L.check(lib.pcd_sparse_conv_wgrad_v2(L.ptr(x), x.shape[0], L.ptr(n_in_dev), x_ld, cin, L.ptr(dy),
                                              dy.shape[0], cout, L.ptr(pairs), L.ptr(pair_num), kvol, pmax, L.ptr(dw),
                                              L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_sparse_conv_wgrad_v2")
     if defer is not None:
-        defer.append((ws, dw, kvol, cin, cout, pmax, 0, 1 if conv2d_layout else 0))
+        defer.append((ws, dw, kvol, cin, cout, pmax, 0, 1 if conv2d_layout else 0, cout_write))
         return dw
     L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, pmax, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
             "pcd_sparse_conv_wgrad_reduce")
@@ -957,19 +968,36 @@ def conv2d_pack_weight(weight, mode=0):
     return packed
 
 
-def conv2d_3x3_nhwc(x, packed_w, cout, bias=None):
+def _pixel_block(t):
+    """channels per pixel of the buffer a [B, H, W, C] channel block lives in (C for a plain contiguous map)."""
+    B, H, W, C = t.shape
+    cs = t.stride(2) if W > 1 else (t.stride(1) // W if H > 1 else C)
+    assert t.stride(3) == 1 and cs >= C and cs % 8 == 0 and t.data_ptr() % 16 == 0 and \
+        (W == 1 or t.stride(2) == cs) and (H == 1 or t.stride(1) == W * cs) and (B == 1 or t.stride(0) == H * W * cs), \
+        "need a channels-last map or a channel block of one"
+    return cs
+
+
+def conv2d_3x3_nhwc(x, packed_w, cout, bias=None, out=None):
     """y = conv2d(x, w, bias, stride 1, padding 1) for x [B, H, W, cin] bf16 contiguous (= channels_last storage of an
-    NCHW tensor); returns [B, H, W, cout] bf16.  Data gradient: conv2d_3x3_nhwc(dy, pack(w, 1), cin)."""
+    NCHW tensor); returns [B, H, W, cout] bf16.  Data gradient: conv2d_3x3_nhwc(dy, pack(w, 1), cin).
+    x may be a CHANNEL BLOCK of a wider map (x[..., a:a + cin] of a contiguous [B, H, W, C]) and `out` one to write into."""
     _require_cuda(x, packed_w)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    assert x.dtype == torch.bfloat16 and x.dim() == 4
     B, H, W, cin = x.shape
-    y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    x_cs = _pixel_block(x)
+    if out is None:
+        y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    else:
+        assert out.shape == (B, H, W, cout) and out.dtype == torch.bfloat16 and out.device == x.device
+        y = out
+    y_cs = _pixel_block(y)
     b = bias.detach().float().contiguous() if bias is not None else None
     with _Timed(f"conv2d_3x3_kernel {cin}->{cout} {H}x{W}",
                 lambda: dict(bytes=(x.numel() + y.numel()) * 2 + 9 * cin * cout * 2, flops=2 * 9 * B * H * W * cin * cout,
                              rows=B * H * W, pairs=0)):
-        L.check(L.lib().pcd_conv2d_3x3_nhwc(L.ptr(x), B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
-                                            L.stream_ptr()), "pcd_conv2d_3x3_nhwc")
+        L.check(L.lib().pcd_conv2d_3x3_nhwc_ld(L.ptr(x), x_cs, B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
+                                               y_cs, L.stream_ptr()), "pcd_conv2d_3x3_nhwc_ld")
     return y
 
 
@@ -1031,7 +1059,7 @@ def wgrad_reduce_batched(jobs):
         for j, job in enumerate(chunk):
             ws, dw, kvol, cin, cout, pmax = job[:6]
             arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax, job[6] if len(job) > 6 else 0,
-                                         job[7] if len(job) > 7 else 0)
+                                         job[7] if len(job) > 7 else 0, job[8] if len(job) > 8 else 0)
         L.check(L.lib().pcd_sparse_conv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk),
                                                              L.stream_ptr()), "pcd_sparse_conv_wgrad_reduce_batched")
 

@@ -359,6 +359,9 @@ typedef struct PcdWgradReduceJob {
     int splits;              /* 0: as planned by pcd_sparse_conv_wgrad; > 0: slabs written by pcd_sparse_conv_wgrad_os */
     int layout;              /* of dweight: 0 = [cout][K][cin] (spconv weights), 1 = [cout][cin][K] (nn.Conv2d weights
                               * [cout, cin, 3, 3]: the dense 3x3 convs of the BEV stack write straight into .grad) */
+    int cout_write;          /* 0 = cout; else only the first cout_write output channels are reduced and written (dweight
+                              * holds cout_write rows): convs run with zero-padded output channels (the 1-3 channel
+                              * final convs of the head towers, padded to 32) */
 } PcdWgradReduceJob;
 int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream);
 /* Output-stationary form for layers with 16 output channels (cin_pad 8 or 16, 3x3x3): walks the OUTPUT rows, reads dY in
@@ -747,6 +750,11 @@ int pcd_conv2d_pack_weight(const float *weight, int cin, int cout, int mode, voi
 int pcd_conv2d_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w, int cout,
                         const float *bias, void *y, void *stream);
+/* the same conv on CHANNEL BLOCKS of wider maps: x_cs / y_cs = channels per pixel of the buffers x / y point into
+ * (>= cin / cout, multiples of 8): the five branches of a SeparateHead (center_head.py:11-46) read their 64 channels of
+ * one 320-channel activation and their data gradients fill its gradient block by block -- no slice copies, no adds */
+int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin, const void *packed_w,
+                           int cout, const float *bias, void *y, int y_cs, void *stream);
 /* The other three layers of BaseBEVBackbone (base_bev_backbone.py:36-75; MIOpen in the reference), forward and data
  * gradient, as per-parity-plane stencils on the same tiles.  pack modes (pcd_conv2d_pack_weight / _packed_weight_bytes /
  * the batched table take them too; cin / cout are the LAYER's channel counts, the weight is the torch parameter):

@@ -190,10 +190,8 @@ def test_conv3x3_direct_deferred_gradients_equal_the_plain_path(cin, cout, bias)
     dx1, g1 = run(True)
     assert torch.equal(dx0, dx1)
     for a, b_, p in zip(g0, g1, m.parameters()):
-        if cout % 32 == 0:
-            assert torch.equal(a, b_), float((a - b_).abs().max())
-        else:   # padded output channels: the direct path is not taken, autograd ADDS to the pre-set .grad
-            torch.testing.assert_close(b_, a + 7.0, rtol=1e-6, atol=1e-6)
+        # (cout = 3 runs with output channels zero-padded to 32: the deferred reduction writes only the real rows)
+        assert torch.equal(a, b_), float((a - b_).abs().max())
 
 
 def test_batchnorm_into_a_column_block_and_from_a_gradient_block_is_bit_identical():
