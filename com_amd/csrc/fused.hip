@@ -90,7 +90,7 @@ static bool aligned16(const void *a, const void *b = nullptr, const void *c = nu
 template <int N, int NACC>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c, int pcs,
                                                    float *partial /*[gridDim.x][NACC][c]*/, float *lds) {
-    if (pcs <= 64) {
+    if (pcs <= 64 && (pcs & (pcs - 1)) == 0 && blockDim.x == 256) {
         for (int off = pcs; off < 64; off <<= 1) {
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
@@ -110,22 +110,25 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][N], int c,
                 ((lds[item] + lds[NACC * c + item]) + lds[2 * NACC * c + item]) + lds[3 * NACC * c + item];
         return;
     }
-    // lds: [256][NACC*N]
+    // general form (pcs > 64, or a piece count that is no power of two: the block then has (256 / pcs) * pcs threads)
+    // lds: [blockDim][NACC*N]
+    const int BT = (int)blockDim.x;
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int j = 0; j < N; ++j) lds[threadIdx.x * (NACC * N) + a * N + j] = acc[a][j];
     __syncthreads();
-    for (int item = threadIdx.x; item < NACC * c; item += 256) {
+    for (int item = threadIdx.x; item < NACC * c; item += BT) {
         int a = item / c, ch = item - a * c;
         int piece = ch / N, j = ch - piece * N;
         float s = 0.0f;
-        for (int t = piece; t < 256; t += pcs) s += lds[t * (NACC * N) + a * N + j];
+        for (int t = piece; t < BT; t += pcs) s += lds[t * (NACC * N) + a * N + j];
         partial[((size_t)blockIdx.x * NACC + a) * c + ch] = s;
     }
 }
 static size_t bn_reduce_lds_bytes(int c, int N) {
-    return (c / N <= 64 ? (size_t)4 * 2 * c : (size_t)256 * 2 * N) * sizeof(float);
+    const int pcs = c / N;
+    return ((pcs <= 64 && (pcs & (pcs - 1)) == 0) ? (size_t)4 * 2 * c : (size_t)256 * 2 * N) * sizeof(float);
 }
 
 template <typename T>
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T *__restrict__ x, 
     for (int j = 0; j < N; ++j) acc[0][j] = acc[1][j] = 0.0f;
     // 4 pieces in flight per thread: with 2 workgroups per CU a thread's 4-5 pieces otherwise cost one full memory
     // latency EACH (the same accumulation order as the plain loop, so results do not change)
-    const size_t S = (size_t)gridDim.x * 256;
-    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t S = (size_t)gridDim.x * blockDim.x;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; e + 3 * S < total; e += 4 * S) {
         float v[4][N];
 #pragma unroll
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
-    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
+    const int piece = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
     if (fin.mid) {
         // training: finish the batch statistics here (see bn_mid_kernel); workgroup 0 also publishes them
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
         float *sc_s = (float *)(tot + 2 * c), *sh_s = sc_s + c;
         mid_totals(fin.mid, c, tot);
         const int n = eff_rows(n_dev, n_cap);
-        for (int ch = threadIdx.x; ch < c; ch += 256) {
+        for (int ch = threadIdx.x; ch < c; ch += (int)blockDim.x) {
             const double s = tot[ch], ss = tot[c + ch];
             double mean = n > 0 ? s / n : 0.0;
             double var = n > 0 ? ss / n - mean * mean : 0.0;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     }
     // y may be a column block of a wider matrix (row stride y_ld elements): row = e / pcs advances by a whole number
     // of rows per grid stride
-    const size_t e0 = (size_t)blockIdx.x * 256 + threadIdx.x, S = (size_t)gridDim.x * 256;
+    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
     size_t ye = (e0 / pcs) * (size_t)(y_ld / N) + piece;
     const size_t ystep = (S / pcs) * (size_t)(y_ld / N);
     for (size_t e = e0; e < total; e += S, ye += ystep) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pcs = c / N;
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
-    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
+    const int piece = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % pcs);
     float mu[N], is[N], sc[N], sh[N], gmv[N], btv[N];
     load_params<N>(mean, piece * N, vec, mu);
     load_params<N>(invstd, piece * N, vec, is);
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
         }
     };
     // two rows of loads (4-6 x 16 bytes) in flight per thread, same accumulation order as the plain loop
-    const size_t S = (size_t)gridDim.x * 256;
-    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t S = (size_t)gridDim.x * blockDim.x;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t de = (e / pcs) * (size_t)(dy_ld / N) + piece;               // dy: row stride dy_ld elements
     const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
     for (; e + S < total; e += 2 * S, de += 2 * dstep) {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     const int pcs = c / N;
     const int n = eff_rows(n_dev, n_cap);
     const size_t total = (size_t)n * pcs;
-    const int piece = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % pcs);
+    const int piece = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % pcs);
     float mu[N], is[N], gm[N], sh[N], k1[N], k2[N], gmv[N], btv[N];
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
     const bool mask_from_x = relu && y == nullptr;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         double *tot = (double *)dyn_lds;
         float *fs = (float *)(tot + 2 * c);
         mid_totals(mid, c, tot);
-        for (int t = threadIdx.x; t < 2 * c; t += 256) {
+        for (int t = threadIdx.x; t < 2 * c; t += (int)blockDim.x) {
             const float v = (float)tot[t];
             fs[t] = v;
             if (blockIdx.x == 0) (t < c ? dbeta[t] : dgamma[t - c]) = v;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     float cs[1][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) cs[0][j] = 0.0f;
-    const size_t e0 = (size_t)blockIdx.x * 256 + threadIdx.x, S = (size_t)gridDim.x * 256;
+    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
     size_t de = (e0 / pcs) * (size_t)(dy_ld / N) + piece;              // dy: row stride dy_ld elements
     const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
     for (size_t e = e0; e < total; e += S, de += dstep) {
@@ -605,11 +608,15 @@ static int grid_for(size_t pieces, int pcs, int max_blocks = MAX_BLOCKS) {
     return (int)blocks;
 }
 
+// threads per block of the streaming passes: a multiple of the pieces per row, so that a thread keeps ONE piece
+// (column group) over its whole grid-stride loop
+static int bn_threads(int pcs) { return 256 / pcs * pcs; }
+
 static bool shape_ok(int c, int dtype) {
     int N = dtype == PCD_F32 ? 4 : 8;
     if (c % N) return false;
     int pcs = c / N;
-    return pcs >= 1 && pcs <= 256 && (256 % pcs) == 0 && c <= 1024;
+    return pcs >= 1 && pcs <= 256 && c <= 1024;   // (256 % pcs != 0: blocks of (256 / pcs) * pcs threads, see bn_threads)
 }
 
 struct BnWs {
@@ -661,9 +668,9 @@ extern "C" int pcd_bn_forward_ld(const void *x, const void *residual, int dtype,
         if (ext_partial)   // the conv epilogue already took the sums (PcdBnReduce mode 1)
             ;
         else if (dtype == PCD_F32)
-            bn_stats_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
+            bn_stats_kernel<float><<<grid, bn_threads(c / N), bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
         else
-            bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c,
+            bn_stats_kernel<unsigned short><<<grid, bn_threads(c / N), bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c,
                                                                   L.partial);
         const float *part = ext_partial ? ext_partial : L.partial;
         const int prow = ext_partial ? ext_rows : grid;
@@ -693,10 +700,10 @@ extern "C" int pcd_bn_forward_ld(const void *x, const void *residual, int dtype,
         }
         const size_t lds = training ? bn_mid_lds_bytes(c) : 0;
         if (dtype == PCD_F32)
-            bn_apply_kernel<float><<<agrid, 256, lds, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
+            bn_apply_kernel<float><<<agrid, bn_threads(pcs), lds, st>>>((const float *)x, (const float *)residual, n, n_dev, c,
                                                            L.scale, L.shift, relu, (float *)y, 1, fin, y_ld);
         else
-            bn_apply_kernel<unsigned short><<<agrid, 256, lds, st>>>(
+            bn_apply_kernel<unsigned short><<<agrid, bn_threads(pcs), lds, st>>>(
                 (const unsigned short *)x, (const unsigned short *)residual, n, n_dev, c, L.scale, L.shift, relu,
                 (unsigned short *)y, 1, fin, y_ld);
     }
@@ -737,9 +744,9 @@ extern "C" int pcd_col_sum(const void *x, int dtype, int n, int c, float *out, c
     const int N = dtype == PCD_F32 ? 4 : 8;
     int grid = grid_for((size_t)n * (c / N), c / N);
     if (dtype == PCD_F32)
-        bn_stats_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
+        bn_stats_kernel<float><<<grid, bn_threads(c / N), bn_reduce_lds_bytes(c, 4), st>>>((const float *)x, n, n_dev, c, L.partial);
     else
-        bn_stats_kernel<unsigned short><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c, L.partial);
+        bn_stats_kernel<unsigned short><<<grid, bn_threads(c / N), bn_reduce_lds_bytes(c, 8), st>>>((const unsigned short *)x, n, n_dev, c, L.partial);
     col_sum_finalize_kernel<<<1, 1024, 0, st>>>(L.partial, grid, c, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -785,23 +792,23 @@ extern "C" int pcd_bn_backward_ld(const void *dy, int dy_ld, const void *x, cons
     };
     if (dtype == PCD_F32) {
         if (!ext_partial)
-            bn_bwd_reduce_kernel<float><<<grid, 256, bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
+            bn_bwd_reduce_kernel<float><<<grid, bn_threads(pcs), bn_reduce_lds_bytes(c, 4), st>>>((const float *)dy, (const float *)x,
                                                           (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                                                           save_invstd, relu, L.partial, vec, dy_ld);
         finalize();
         if (n > 0)
-            bn_bwd_apply_kernel<float><<<agrid, 256, alds, st>>>(
+            bn_bwd_apply_kernel<float><<<agrid, bn_threads(pcs), alds, st>>>(
                 (const float *)dy, (const float *)x, (const float *)y, n, n_dev, c, gamma, beta, save_mean,
                 save_invstd, dgamma, dbeta, relu, training, (float *)dx, (float *)dresidual, vec, mid, colsum_partial,
                 dy_ld);
     } else {
         typedef unsigned short B;
         if (!ext_partial)
-            bn_bwd_reduce_kernel<B><<<grid, 256, bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
+            bn_bwd_reduce_kernel<B><<<grid, bn_threads(pcs), bn_reduce_lds_bytes(c, 8), st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                       gamma, beta, save_mean, save_invstd, relu, L.partial, vec, dy_ld);
         finalize();
         if (n > 0)
-            bn_bwd_apply_kernel<B><<<agrid, 256, alds, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
+            bn_bwd_apply_kernel<B><<<agrid, bn_threads(pcs), alds, st>>>((const B *)dy, (const B *)x, (const B *)y, n, n_dev, c,
                                                             gamma, beta, save_mean, save_invstd, dgamma, dbeta,
                                                             relu, training, (B *)dx, (B *)dresidual, vec, mid, colsum_partial,
                                                             dy_ld);

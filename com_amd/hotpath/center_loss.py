@@ -8,6 +8,14 @@ the stream, so the whole loss is capturable in a hipGraph behind `assign_targets
 import torch
 
 
+
+
+def _like(t):
+    """an uninitialised tensor with EXACTLY t's strides (torch.empty_like densifies a non-dense view, e.g. the 1-3 real
+    channels of a prediction map that was computed with zero-padded channels)."""
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
 def sigmoid_clamped(x):
     """center_head.py:226-228"""
     return torch.clamp(x.sigmoid(), min=1e-4, max=1 - 1e-4)
@@ -130,8 +138,8 @@ class _FusedHeadLoss(torch.autograd.Function):
         hm, heatmap, inds, masks, target_boxes, code_weights, out, *regs = ctx.saved_tensors
         B, C, H, W = hm.shape
         lib = L.lib()
-        d_hm = torch.empty_like(hm)                      # (same strides: the kernels address gradients like the inputs)
-        d_regs = [torch.empty_like(r) for r in regs]
+        d_hm = _like(hm)                      # (same strides: the kernels address gradients like the inputs)
+        d_regs = [_like(r) for r in regs]
         assert d_hm.stride() == hm.stride() and all(d.stride() == r.stride() for d, r in zip(d_regs, regs))
         g = g_loss.detach().to(torch.float32).reshape(1).contiguous()
 

@@ -17,6 +17,14 @@ import torch
 from .. import _lib as L
 
 
+
+
+def _like(t):
+    """an uninitialised tensor with EXACTLY t's strides (torch.empty_like densifies a non-dense view, e.g. the 1-3 real
+    channels of a prediction map that was computed with zero-padded channels)."""
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
 def _dev(t, what):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise L.PcdError(f"{what} needs a HIP device tensor (there is no CPU fallback)")
@@ -154,8 +162,8 @@ class _ComHeadLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_out):
         hm, heatmap, inds, box_mask, target_boxes, code_weights, out, *regs = ctx.saved_tensors
         B, C, H, W = hm.shape
-        d_hm = torch.empty_like(hm)
-        d_regs = [torch.empty_like(r) for r in regs]
+        d_hm = _like(hm)
+        d_regs = [_like(r) for r in regs]
         assert d_hm.stride() == hm.stride() and all(d.stride() == r.stride() for d, r in zip(d_regs, regs))
         g = g_loss.detach().to(torch.float32).reshape(1).contiguous()
 

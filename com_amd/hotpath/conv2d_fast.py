@@ -113,16 +113,19 @@ def _scheduled_backward(need_dx, want_w, want_b, wp, bp, direct_ok, dgrad, wgrad
         side = Fsp._side_stream(keep[0].device)
         side.wait_event(ready)
 
-    def direct(p):
-        return (Fsp.DIRECT_GRAD and direct_ok and p is not None and p.grad is not None
-                and p.grad.dtype == torch.float32 and p.grad.is_contiguous())
+    def direct(ps):          # (wp / bp: one parameter or a list of them -- all or none)
+        ps = ps if isinstance(ps, (list, tuple)) else [ps]
+        return len(ps) > 0 and all(Fsp.DIRECT_GRAD and direct_ok and p is not None and p.grad is not None
+                                   and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in ps)
     direct_w, direct_b = want_w and direct(wp), want_b and direct(bp)
     deferred = (Fsp.WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not want_w)
                 and (direct_b or not want_b))
     if direct_w and deferred:
-        Fsp._claim_direct(wp, "w")
+        for p in (wp if isinstance(wp, (list, tuple)) else [wp]):
+            Fsp._claim_direct(p, "w")
     if direct_b and deferred:
-        Fsp._claim_direct(bp, "b")
+        for p in (bp if isinstance(bp, (list, tuple)) else [bp]):
+            Fsp._claim_direct(p, "b")
     with torch.cuda.stream(side) if side is not None else Fsp._NullCtx():
         if ops.STAMPS is not None:
             Fsp._STAMP_SEQ[0] += 1
@@ -142,8 +145,9 @@ def _scheduled_backward(need_dx, want_w, want_b, wp, bp, direct_ok, dgrad, wgrad
     elif side is not None:
         cur.wait_stream(side)
         for t in (dw, db):
-            if t is not None:
-                t.record_stream(cur)
+            for u in (t if isinstance(t, (list, tuple)) else [t]):
+                if u is not None:
+                    u.record_stream(cur)
     return dx, dw, db
 
 
@@ -235,13 +239,17 @@ class Conv3x3(nn.Conv2d):
             x = x.to(torch.bfloat16)
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
+        pf, pd = self._take_packs()
+        return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
+
+    def _take_packs(self):
         pf = pd = None
         ahead = getattr(self, "_packs_ahead", None)
         if ahead is not None:                        # Conv3x3Packs.run() since the last weight update: use them ONCE
             self._packs_ahead = None
             if ahead[2] == self.weight._version:     # (an in-place change since run() -- load_state_dict, broadcast,
                 pf, pd = ahead[0], ahead[1]          #  a manual edit -- bumps the version: pack again from the weights)
-        return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
+        return pf, pd
 
 
 class _ConvPlanesFunction(torch.autograd.Function):
@@ -366,6 +374,110 @@ class UpConvT(_PlaneConvMixin, nn.ConvTranspose2d):
         return _ConvPlanesFunction.apply(_plane_input(x), self.weight, pf, pd, self.MODE_F)
 
 
+class _BranchConvsFunction(torch.autograd.Function):
+    """The LAST 3x3 convs (64 -> 1..3 channels, bias) of all branches of a SeparateHead (center_head.py:21-24) on the
+    channel blocks of ONE shared activation a [B, 64 n, H, W]: branch i reads channels [64 i, 64 i + 64) in place, its data
+    gradient fills that block of da -- no slice copies forward, no zero-filled slice gradients and no adds backward.
+    Outputs are the first cout_i channels of maps computed with zero-padded output channels (views, pixel stride 32).
+    metas[i] = (pack_f, pack_d) made ahead or (None, None); wb = w_0, b_0, w_1, b_1, ..."""
+
+    @staticmethod
+    def forward(ctx, a, width, metas, *wb):
+        an = a.detach().permute(0, 2, 3, 1)
+        assert an.is_contiguous() and an.shape[3] == width * (len(wb) // 2)
+        outs, packs_d = [], []
+        for i in range(len(wb) // 2):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            cout = w.shape[0]
+            cp = _pad32(cout)
+            bp = torch.nn.functional.pad(b.detach().float(), (0, cp - cout)) if b is not None else None
+            pf = metas[i][0] if metas[i][0] is not None else ops.conv2d_pack_weight(w, 0)
+            y = ops.conv2d_3x3_nhwc(an[..., width * i:width * (i + 1)], pf, cp, bp)
+            outs.append(y[..., :cout].permute(0, 3, 1, 2))
+            packs_d.append(metas[i][1])
+        ctx.save_for_backward(an, *[wb[2 * i] for i in range(len(wb) // 2)])
+        ctx.width, ctx.packs_d = width, packs_d
+        ctx.w_params = [wb[2 * i] if isinstance(wb[2 * i], nn.Parameter) else None for i in range(len(wb) // 2)]
+        ctx.b_params = [wb[2 * i + 1] if isinstance(wb[2 * i + 1], nn.Parameter) else None for i in range(len(wb) // 2)]
+        ctx.has_bias = [wb[2 * i + 1] is not None for i in range(len(wb) // 2)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        an, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        from ..spconv import functional as Fsp
+        B, H, W, C = an.shape
+        n, width = len(ws), ctx.width
+        cps = [_pad32(w.shape[0]) for w in ws]
+        # the output gradients, zero-padded to the channel count the kernels contract over: ONE fill + n copies
+        pad = torch.zeros((sum(cps) * B * H * W,), dtype=torch.bfloat16, device=an.device)
+        dyp, off = [], 0
+        for i in range(n):
+            t = pad[off:off + cps[i] * B * H * W].view(B, H, W, cps[i])
+            off += cps[i] * B * H * W
+            if dys[i] is not None:
+                t[..., :ws[i].shape[0]].copy_(dys[i].permute(0, 2, 3, 1))
+            dyp.append(t)
+        live = [i for i in range(n) if dys[i] is not None]
+        want_w = any(ctx.needs_input_grad[3 + 2 * i] for i in live)
+        want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i] for i in live)
+
+        def dgrad():
+            da = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=an.device)
+            for i in range(n):
+                blk = da[..., width * i:width * (i + 1)]
+                if dys[i] is None:
+                    blk.zero_()
+                    continue
+                pd = ctx.packs_d[i] if ctx.packs_d[i] is not None else ops.conv2d_pack_weight(ws[i], 1)
+                ops.conv2d_3x3_nhwc(dyp[i], pd, width, out=blk)
+            return da.permute(0, 3, 1, 2)
+
+        def wgrad(direct):
+            pairs, num = _dense_pairs(B, H, W, an.device)
+            a2 = an.reshape(-1, C)
+            res = []
+            for i in range(n):
+                if dys[i] is None or not ctx.needs_input_grad[3 + 2 * i]:
+                    res.append(None)
+                    continue
+                cout = ws[i].shape[0]
+                xb = a2[:, width * i:width * (i + 1)]
+                if direct:
+                    ops.wgrad(xb, width, dyp[i].reshape(-1, cps[i]), pairs, num, 9, out=ctx.w_params[i].grad,
+                              defer=Fsp._WGRAD_JOBS, conv2d_layout=True, cout_write=cout if cps[i] != cout else 0,
+                              x_block=True)
+                    res.append(None)
+                else:
+                    dwk = ops.wgrad(xb, width, dyp[i].reshape(-1, cps[i]), pairs, num, 9, x_block=True)
+                    res.append(dwk[:cout].permute(0, 2, 1).reshape(cout, width, 3, 3).to(ws[i].dtype))
+            return res
+
+        def bsum(direct):
+            res = []
+            for i in range(n):
+                if dys[i] is None or not (ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]):
+                    res.append(None)
+                    continue
+                cs = ops.col_sum(dyp[i].reshape(-1, cps[i]))[:ws[i].shape[0]]
+                if direct:
+                    ctx.b_params[i].grad.copy_(cs)
+                    res.append(None)
+                else:
+                    res.append(cs)
+            return res
+
+        wps = [ctx.w_params[i] for i in live if ctx.needs_input_grad[3 + 2 * i]]
+        bps = [ctx.b_params[i] for i in live if ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]]
+        dx, dws, dbs = _scheduled_backward(ctx.needs_input_grad[0], want_w, want_b, wps, bps, True, dgrad, wgrad, bsum,
+                                           (an, pad))
+        grads = [dx, None, None]
+        for i in range(n):
+            grads.append(dws[i] if dws is not None else None)
+            grads.append(dbs[i] if dbs is not None else None)
+        return tuple(grads)
+
+
 class Conv3x3Packs:
     """Forward + data-gradient packs of all Conv3x3 modules of a model in ONE launch (pcd_conv2d_pack_weights_batched)
     into persistent buffers -- call `run()` right after every optimizer step (the weights do not change again before
@@ -378,7 +490,12 @@ class Conv3x3Packs:
         import ctypes  # noqa: F401
         from .. import _lib as L
         self.convs, self.modes = [], []
+        extra = []
         for m in model.modules():
+            hook = getattr(m, "_pack_extra_convs", None)       # (SeparateHead: its batched first-stage conv, if any)
+            if callable(hook):
+                extra += list(hook())
+        for m in list(model.modules()) + extra:
             if not (hasattr(m, "weight") and m.weight is not None and m.weight.is_cuda and m.weight.dtype == torch.float32):
                 continue
             if isinstance(m, Conv3x3) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \

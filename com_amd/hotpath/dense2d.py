@@ -142,8 +142,138 @@ class SeparateHead(nn.Module):
                             nn.init.constant_(m.bias, 0)
             self.__setattr__(cur_name, fc)
 
+    # ---- batched execution -----------------------------------------------------------------------------------
+    # All branches have the shape conv3x3(C -> C) + BatchNorm + ReLU + conv3x3(C -> k).  When their first-stage
+    # parameters (and .grad buffers) lie back to back in memory -- bench.py orders its flat parameter / gradient
+    # buffers that way (`batched_param_order`), `flatten_branches_()` does it for a stand-alone module -- the n first
+    # convs run as ONE conv C -> n C and the n BatchNorms as ONE over n C channels (per-channel arithmetic: identical
+    # results), through un-registered modules whose parameters ALIAS the branches' own; the last convs then read their
+    # channel block of that activation in place (_BranchConvsFunction).  5 + 15 + 5 launches become 1 + 3 + 5 forward,
+    # and the backward loses its 5 zero-filled slice gradients, 4 adds and 15 BatchNorm launches.  State-dict keys,
+    # optimizers and checkpoints see only the branches' own parameters.
+    BATCHED = True
+
+    def _branches(self):
+        names = list(self.sep_head_dict)
+        return names, [self.__getattr__(n) for n in names]
+
+    def _batchable(self):
+        names, seqs = self._branches()
+        ok = len(seqs) > 1 and all(
+            isinstance(q, nn.Sequential) and len(q) == 2 and isinstance(q[0], nn.Sequential) and len(q[0]) == 3
+            and isinstance(q[0][0], Conv3x3) and isinstance(q[0][1], BatchNormReLU2d) and isinstance(q[1], Conv3x3)
+            and q[0][1].relu and q[0][1].affine and q[0][1].track_running_stats for q in seqs)
+        if not ok:
+            return False
+        c = seqs[0][0][0].in_channels
+        return c % 32 == 0 and all(q[0][0].in_channels == c and q[0][0].out_channels == c and q[1].in_channels == c
+                                   and (q[0][0].bias is None) == (seqs[0][0][0].bias is None)
+                                   and q[0][1].eps == seqs[0][0][1].eps and q[0][1].momentum == seqs[0][0][1].momentum
+                                   for q in seqs)
+
+    @staticmethod
+    def _adjacent(ts):
+        return all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and all(
+            ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * 4 for i in range(len(ts) - 1))
+
+    @staticmethod
+    def _wide(ts, lead):
+        t0 = ts[0]
+        shape = (lead,) + tuple(t0.shape[1:])
+        return t0.detach().as_strided(shape, torch.empty(shape, device="meta").stride(), t0.storage_offset())
+
+    def flatten_branches_(self):
+        """Move the first-stage parameters and BatchNorm buffers of the branches into shared flat storage (each stays its
+        own nn.Parameter / buffer: a view), so that the batched path applies.  Call it after .to(device) and before the
+        optimizer is built; bench.py gets the same layout from its flat buckets instead."""
+        if not self._batchable():
+            return self
+        _, seqs = self._branches()
+        with torch.no_grad():
+            for pick in (lambda q: q[0][0].weight, lambda q: q[0][0].bias, lambda q: q[0][1].weight,
+                         lambda q: q[0][1].bias, lambda q: q[0][1].running_mean, lambda q: q[0][1].running_var):
+                ts = [pick(q) for q in seqs]
+                if ts[0] is None or self._adjacent(ts):
+                    continue
+                flat = torch.cat([t.detach().reshape(-1).float() for t in ts])
+                off = 0
+                for t in ts:
+                    t.data = flat[off:off + t.numel()].view_as(t)
+                    off += t.numel()
+        return self
+
+    def _wide_modules(self):
+        """(conv, bn) over all branches, aliasing their parameters -- or None when the layout does not allow it."""
+        if not (self.BATCHED and conv2d_fast.ENABLED) or not self._batchable():
+            return None
+        names, seqs = self._branches()
+        n, c = len(seqs), seqs[0][0][0].in_channels
+        groups = [[q[0][0].weight for q in seqs], [q[0][1].weight for q in seqs], [q[0][1].bias for q in seqs]]
+        if seqs[0][0][0].bias is not None:
+            groups.append([q[0][0].bias for q in seqs])
+        stats = [[q[0][1].running_mean for q in seqs], [q[0][1].running_var for q in seqs]]
+        if not all(self._adjacent(g) for g in groups):
+            return None
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for g in groups for p in g)
+        if want_grad:
+            # the gradients must be writable in place as ONE tensor per group too (pre-allocated, back to back)
+            if not all(all(p.requires_grad and p.grad is not None for p in g) and self._adjacent([p.grad for p in g])
+                       for g in groups):
+                return None
+        if not all(self._adjacent(g) for g in stats):
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self.flatten_branches_()                           # (buffers only move here: the parameters are adjacent)
+            stats = [[q[0][1].running_mean for q in seqs], [q[0][1].running_var for q in seqs]]
+        key = tuple(t.data_ptr() for g in groups + stats for t in g) + \
+            tuple(p.grad.data_ptr() if (want_grad and p.grad is not None) else 0 for g in groups for p in g) + (want_grad,)
+        cache = self.__dict__.get("_wide_cache")
+        if cache is not None and cache[0] == key:
+            conv, bn = cache[1]
+        else:
+            dev = groups[0][0].device
+            has_bias = len(groups) == 4
+            conv = Conv3x3(c, n * c, 3, stride=1, padding=1, bias=has_bias).to(dev)
+            bn0 = seqs[0][0][1]
+            bn = BatchNormReLU2d(n * c, eps=bn0.eps, momentum=bn0.momentum, relu=True).to(dev)
+            bn._defer_nbt = True                               # (the branches' own counters are the ones that count)
+
+            def alias(ps, lead):
+                w = nn.Parameter(self._wide(ps, lead), requires_grad=want_grad)
+                if want_grad:
+                    w.grad = self._wide([p.grad for p in ps], lead)
+                return w
+            conv.weight = alias(groups[0], n * c)
+            bn.weight, bn.bias = alias(groups[1], n * c), alias(groups[2], n * c)
+            if has_bias:
+                conv.bias = alias(groups[3], n * c)
+            bn.running_mean, bn.running_var = self._wide(stats[0], n * c), self._wide(stats[1], n * c)
+            self.__dict__["_wide_cache"] = (key, (conv, bn))
+        conv.train(self.training)
+        bn.train(self.training)
+        return conv, bn
+
+    def _pack_extra_convs(self):
+        """Conv3x3Packs: the batched first-stage conv gets its packs made ahead like every other conv."""
+        wm = self._wide_modules()
+        return [wm[0]] if wm is not None else []
+
     def forward(self, x):
-        return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+        wm = None
+        if x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
+                                                        and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+            wm = self._wide_modules()
+        if wm is None:
+            return {name: self.__getattr__(name)(x) for name in self.sep_head_dict}
+        names, seqs = self._branches()
+        conv, bn = wm
+        a = bn(conv(x))                                        # [B, n C, H, W], all branches' first stage
+        metas, wb = [], []
+        for q in seqs:
+            metas.append(q[1]._take_packs())
+            wb += [q[1].weight, q[1].bias]
+        outs = conv2d_fast._BranchConvsFunction.apply(a, conv.in_channels, metas, *wb)
+        return dict(zip(names, outs))
 
 
 class CenterHeadTowers(nn.Module):
@@ -180,3 +310,22 @@ CENTERPOINT_HEAD = dict(SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=True, NUM_H
                         SEPARATE_HEAD_CFG=dict(HEAD_ORDER=['center', 'center_z', 'dim', 'rot'], HEAD_DICT={
                             'center': {'out_channels': 2, 'num_conv': 2}, 'center_z': {'out_channels': 1, 'num_conv': 2},
                             'dim': {'out_channels': 3, 'num_conv': 2}, 'rot': {'out_channels': 2, 'num_conv': 2}}))
+
+
+def batched_param_order(model):
+    """model.parameters() reordered so that the first-stage parameters of every SeparateHead's branches are consecutive
+    per kind (conv weights, conv biases, BatchNorm weights, BatchNorm biases): a flat parameter / gradient buffer laid out
+    in this order (com_amd.dist.FlatGradBucket) gives the heads their batched path."""
+    params = list(model.parameters())
+    grouped, taken = [], set()
+    for m in model.modules():
+        if isinstance(m, SeparateHead) and m.BATCHED and m._batchable():
+            _, seqs = m._branches()
+            for pick in (lambda q: q[0][0].weight, lambda q: q[0][0].bias, lambda q: q[0][1].weight,
+                         lambda q: q[0][1].bias):
+                for q in seqs:
+                    p = pick(q)
+                    if p is not None and id(p) not in taken:
+                        taken.add(id(p))
+                        grouped.append(p)
+    return [p for p in params if id(p) not in taken] + grouped

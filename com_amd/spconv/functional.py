@@ -460,7 +460,7 @@ def _fusable(bn, x):
     if c % piece or c > 1024:
         return False
     pcs = c // piece
-    return (256 % pcs) == 0 and (bn.running_mean is not None or bn.training)
+    return pcs <= 256 and (bn.running_mean is not None or bn.training)
 
 
 def batch_norm_act(bn, x, residual=None, relu=True, n_dev=None, out=None):
