@@ -437,6 +437,144 @@ __global__ __launch_bounds__(256, 2) void conv2d_planes_kernel(const unsigned sh
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the dense 3x3 conv: dW[co][ky][kx][ci] = sum over pixels dy[p][co] * x[p + (ky - 1, kx - 1)][ci].
+// (The sparse pair kernels of spconv.hip did this over dense pair lists: 9 gathers of the same x rows + two index loads
+//  per pair.)  Here a workgroup owns a 64 (cin) x CO (cout) chunk of ALL 9 taps for its share of 4 x 32 pixel tiles:
+// the x halo tile (6 x 34 pixels) and the dy tile are staged ONCE per tile, the contraction index of
+// v_mfma_f32_16x16x32_bf16 is the pixel (32 consecutive pixels of a tile row per step), so both operands come out of LDS
+// through the transposing ds_read_b64_tr_b16 exactly as in wgrad_kernel.  Wave w owns cin block w (16 channels) x all CO
+// x 9 taps = 9 x NBW accumulators that live in registers over all of the workgroup's tiles; per step it reads 9 A
+// fragments (the tap shifts are LDS row offsets) + NBW B fragments for 9 NBW MFMAs.  The next tile's global loads are
+// in flight during the MFMAs.  Output: one slab [cout][9][cin] per split (fixed order -> deterministic), reduced by the
+// sparse path's batched slab reduction (PcdWgradReduceJob.splits / layout / cout_write).
+constexpr int WG_TH = 4, WG_TW = 32, WG_HH = WG_TH + 2, WG_HW = WG_TW + 2;
+constexpr int WG_XS = 80;                                     // LDS pixel stride of x (elements): 64 channels + 16 pad
+template <int CO> struct WgYs { static constexpr int value = ((CO / 16) % 2 == 0) ? CO + 16 : CO; };
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+typedef __attribute__((ext_vector_type(8))) short s16x8_;
+
+template <int NBW>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const unsigned short *__restrict__ x, int x_cs,
+                                                              const unsigned short *__restrict__ dy, int B, int H, int W,
+                                                              int cin, int cout, int n_splits, int n_chunks,
+                                                              int n_co_chunks, float *__restrict__ slab,
+                                                              unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int CO = NBW * 16, YS = WgYs<CO>::value;
+    constexpr int XP = WG_HH * WG_HW * 8, YP = WG_TH * WG_TW * (CO / 8);        // 16-byte pieces per tile
+    constexpr int XI = (XP + 255) / 256, YI = (YP + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short *xs = (unsigned short *)smem;                               // [HH * HW][XS]
+    unsigned short *ys = xs + WG_HH * WG_HW * WG_XS;                            // [TH * TW][YS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, t = lane & 15;
+    const int trow = 4 * g + (t >> 2);                       // contraction row this lane addresses (and trow + 16)
+    // (split, chunk) items in contiguous runs per XCD, the chunks of one split next to each other: the workgroups that
+    // read the same pixels share an L2
+    const int items = n_splits * n_chunks;
+    const int per_xcd = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    const int split = item / n_chunks, chunk = item - split * n_chunks;
+    const int ci0 = (chunk / n_co_chunks) * 64, co0 = (chunk % n_co_chunks) * CO;
+    const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
+    const int n_tiles = B * tiles_y * tiles_x;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)dy_bytes, 0x00020000);
+
+    f32x4 acc[9][NBW];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[k][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 xr[XI], yr[YI];
+    auto load_tile = [&](int tile) {
+        int q = tile;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p >> 3, piece = p & 7;
+            const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
+            const int gy = ty * WG_TH + hy - 1, gx = tx * WG_TW + hx - 1;
+            const bool ok = p < XP && tile < n_tiles && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const unsigned off = ok ? (unsigned)((((size_t)b * H + gy) * W + gx) * x_cs * 2 + (ci0 + piece * 8) * 2)
+                                    : 0xFFFFFFF0u;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < YI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p / (CO / 8), piece = p - pix * (CO / 8);
+            const int py = pix / WG_TW, px = pix - py * WG_TW;
+            const int gy = ty * WG_TH + py, gx = tx * WG_TW + px;
+            const bool ok = p < YP && tile < n_tiles && gy < H && gx < W;
+            const unsigned off = ok ? (unsigned)((((size_t)b * H + gy) * W + gx) * cout * 2 + (co0 + piece * 8) * 2)
+                                    : 0xFFFFFFF0u;
+            yr[it] = __builtin_amdgcn_raw_buffer_load_b128(yrs, off, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            if (p < XP) *reinterpret_cast<u32x4 *>(xs + (p >> 3) * WG_XS + (p & 7) * 8) = xr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < YI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p / (CO / 8), piece = p - pix * (CO / 8);
+            if (p < YP) *reinterpret_cast<u32x4 *>(ys + pix * YS + piece * 8) = yr[it];
+        }
+    };
+    typedef s16x4_ __attribute__((address_space(3))) * lds_tr_ptr;
+    auto frag = [&](const unsigned short *a0, int hi_off) -> bf16x8 {
+        s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a0));
+        s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a0 + hi_off));
+        s16x8_ cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, cat);
+    };
+
+    int tile = split;
+    load_tile(tile);
+    for (; tile < n_tiles; tile += n_splits) {
+        store_tile();
+        __syncthreads();
+        load_tile(tile + n_splits);                          // (beyond the last tile: every offset out of range, no traffic)
+#pragma unroll 1
+        for (int s = 0; s < WG_TH; ++s) {
+            bf16x8 bfr[NBW];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                bfr[nb] = frag(ys + (s * WG_TW + trow) * YS + nb * 16 + (t & 3) * 4, 16 * YS);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int ky = k / 3, kx = k % 3;
+                const bf16x8 af = frag(xs + ((s + ky) * WG_HW + trow + kx) * WG_XS + wave * 16 + (t & 3) * 4, 16 * WG_XS);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+                    acc[k][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[nb], acc[k][nb], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // everyone is done reading this tile
+    }
+    // lane (g, t) of block nb holds dW[co = nb * 16 + t][ci = 16 wave + 4 g .. + 3] of every tap
+    float *sl = slab + (size_t)split * cout * 9 * cin;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int co = co0 + nb * 16 + t, ci = ci0 + wave * 16 + 4 * g;
+            *reinterpret_cast<float4 *>(sl + ((size_t)co * 9 + k) * cin + ci) =
+                make_float4(acc[k][nb][0], acc[k][nb][1], acc[k][nb][2], acc[k][nb][3]);
+        }
+}
+
 }  // namespace
 
 static int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -577,4 +715,48 @@ extern "C" int pcd_conv2d_planes_nhwc(int pack_mode, const void *x, int batch, i
         if (ho != hi || wo != wi) return PCD_ERR_INVALID_ARG;
         return launch_planes<K_K1, false>(x, batch, hi, wi, cin, packed_w, cout, bias, y, ho, wo, st);
     }
+}
+
+
+// splits (= slabs of [cout][9][cin] f32 the reduction has to sum) pcd_conv2d_wgrad_3x3_nhwc writes; 0 = shape not covered
+extern "C" int pcd_conv2d_wgrad_3x3_splits(int batch, int height, int width, int cin, int cout) {
+    if (batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 32) return 0;
+    const int tiles = batch * ((height + WG_TH - 1) / WG_TH) * ((width + WG_TW - 1) / WG_TW);
+    const int chunks = (cin / 64) * (cout % 64 == 0 ? cout / 64 : cout / 32);
+    static const int target = getenv("PCD_CONV2D_WG_BLOCKS") ? atoi(getenv("PCD_CONV2D_WG_BLOCKS")) : 512;
+    int splits = (target + chunks - 1) / chunks;            // about two workgroups per CU ...
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    // ... with an equal number of tiles each where that is close (188 x 188 x 4: 1152 tiles)
+    const int per = (tiles + splits - 1) / splits;
+    return (tiles + per - 1) / per;
+}
+
+extern "C" int pcd_conv2d_wgrad_3x3_nhwc(const void *x, int x_cs, const void *dy, int batch, int height, int width, int cin,
+                                         int cout, void *slabs, size_t slab_bytes, void *stream) {
+    PCD_ENTER();
+    const int splits = pcd_conv2d_wgrad_3x3_splits(batch, height, width, cin, cout);
+    if (splits <= 0) return PCD_ERR_UNSUPPORTED;
+    if (!x || !dy || !slabs || x_cs < cin || x_cs % 8) return PCD_ERR_INVALID_ARG;
+    if (slab_bytes < (size_t)splits * cout * 9 * cin * sizeof(float)) return PCD_ERR_WORKSPACE;
+    const double xb = ((double)batch * height * width - 1) * x_cs * 2 + (double)cin * 2;
+    const double yb = (double)batch * height * width * cout * 2;
+    if (xb >= 4294966000.0 || yb >= 4294966000.0) return PCD_ERR_UNSUPPORTED;
+    const bool wide = cout % 64 == 0;
+    const int n_co = wide ? cout / 64 : cout / 32, chunks = (cin / 64) * n_co;
+    const int grid = (splits * chunks + 7) / 8 * 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (wide) {
+        const size_t lds = (size_t)(WG_HH * WG_HW * WG_XS + WG_TH * WG_TW * WgYs<64>::value) * 2;
+        conv2d_wgrad_kernel<4><<<grid, 256, lds, st>>>((const unsigned short *)x, x_cs, (const unsigned short *)dy, batch,
+                                                     height, width, cin, cout, splits, chunks, n_co, (float *)slabs,
+                                                     (unsigned)xb, (unsigned)yb);
+    } else {
+        const size_t lds = (size_t)(WG_HH * WG_HW * WG_XS + WG_TH * WG_TW * WgYs<32>::value) * 2;
+        conv2d_wgrad_kernel<2><<<grid, 256, lds, st>>>((const unsigned short *)x, x_cs, (const unsigned short *)dy, batch,
+                                                     height, width, cin, cout, splits, chunks, n_co, (float *)slabs,
+                                                     (unsigned)xb, (unsigned)yb);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
 }

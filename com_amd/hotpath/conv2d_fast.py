@@ -198,6 +198,11 @@ class _Conv3x3Function(torch.autograd.Function):
             return ops.conv2d_3x3_nhwc(dyn, pd, cin).permute(0, 3, 1, 2)
 
         def wgrad(direct):
+            if ops.conv2d_wgrad_splits(B, H, W, cin, cp) > 0:      # the dense kernel (no pair lists)
+                if direct:
+                    ops.conv2d_wgrad(xn, dyn, cout, out=wp.grad, defer=Fsp._WGRAD_JOBS)
+                    return None
+                return ops.conv2d_wgrad(xn, dyn, cout).to(weight.dtype)
             pairs, num = _dense_pairs(B, H, W, xn.device)
             if direct:   # (zero-padded output channels: only the real rows of the slabs are reduced into .grad)
                 ops.wgrad(xn.reshape(-1, cin), cin, dyn.reshape(-1, cp), pairs, num, 9, out=wp.grad,
@@ -442,6 +447,14 @@ class _BranchConvsFunction(torch.autograd.Function):
                     res.append(None)
                     continue
                 cout = ws[i].shape[0]
+                if ops.conv2d_wgrad_splits(B, H, W, width, cps[i]) > 0:
+                    xblk = an[..., width * i:width * (i + 1)]
+                    if direct:
+                        ops.conv2d_wgrad(xblk, dyp[i], cout, out=ctx.w_params[i].grad, defer=Fsp._WGRAD_JOBS)
+                        res.append(None)
+                    else:
+                        res.append(ops.conv2d_wgrad(xblk, dyp[i], cout).to(ws[i].dtype))
+                    continue
                 xb = a2[:, width * i:width * (i + 1)]
                 if direct:
                     ops.wgrad(xb, width, dyp[i].reshape(-1, cps[i]), pairs, num, 9, out=ctx.w_params[i].grad,

@@ -1001,6 +1001,42 @@ def conv2d_3x3_nhwc(x, packed_w, cout, bias=None, out=None):
     return y
 
 
+CONV2D_WGRAD = True      # dense 3x3 weight gradients through conv2d_wgrad_kernel (False: the sparse pair kernels)
+
+
+def conv2d_wgrad_splits(B, H, W, cin, cout_padded):
+    return L.lib().pcd_conv2d_wgrad_3x3_splits(B, H, W, cin, cout_padded) if CONV2D_WGRAD else 0
+
+
+def conv2d_wgrad(x, dy, cout=None, out=None, defer=None):
+    """dW of the dense 3x3 / stride 1 / padding 1 conv in the nn.Conv2d layout [cout, cin, 3, 3] (f32): x [B, H, W, cin]
+    bf16 (may be a channel block of a wider map), dy [B, H, W, cp] bf16 contiguous with cp >= cout (zero-padded output
+    channels).  `defer` (list): only the MFMA kernel runs now, the slab reduction joins the batched one; `out`: the
+    tensor to write (e.g. the parameter's .grad).  Caller checks conv2d_wgrad_splits(...) > 0 first."""
+    _require_cuda(x, dy)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.dim() == 4
+    B, H, W, cin = x.shape
+    cp = dy.shape[3]
+    cout = cp if cout is None else cout
+    lib = L.lib()
+    splits = lib.pcd_conv2d_wgrad_3x3_splits(B, H, W, cin, cp)
+    assert splits > 0
+    x_cs = _pixel_block(x)
+    slab = torch.empty((splits * cp * 9 * cin,), dtype=torch.float32, device=x.device)
+    dw = out if _usable_out(out, cout * 9 * cin) else torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    with _Timed(f"conv2d_wgrad_kernel {cin}x{cp} {H}x{W}",
+                lambda: dict(bytes=(x.numel() + dy.numel()) * 2 + slab.numel() * 4, flops=2 * 9 * B * H * W * cin * cp,
+                             rows=B * H * W, pairs=0)):
+        L.check(lib.pcd_conv2d_wgrad_3x3_nhwc(L.ptr(x), x_cs, L.ptr(dy), B, H, W, cin, cp, L.ptr(slab), slab.numel() * 4,
+                                              L.stream_ptr()), "pcd_conv2d_wgrad_3x3_nhwc")
+    job = (slab, dw, 9, cin, cp, 1, splits, 1, cout if cout != cp else 0)
+    if defer is not None:
+        defer.append(job)
+    else:
+        wgrad_reduce_batched([job])
+    return dw
+
+
 def conv2d_planes_nhwc(mode, x, packed_w, cout, out_hw, bias=None):
     """The stride-2 conv / transposed convs of BaseBEVBackbone on channels-last bf16 maps (pack modes 2..7 of
     pcd_conv2d_planes_nhwc): x [B, hi, wi, cin] -> [B, ho, wo, cout]; `cout` = channels of the result."""

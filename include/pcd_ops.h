@@ -755,6 +755,14 @@ int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin
  * one 320-channel activation and their data gradients fill its gradient block by block -- no slice copies, no adds */
 int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin, const void *packed_w,
                            int cout, const float *bias, void *y, int y_cs, void *stream);
+/* Weight gradient of that conv without pair lists: x [b][h][w][cin] (pixel stride x_cs channels), dy [b][h][w][cout]
+ * contiguous, cin % 64 == 0, cout % 32 == 0 (zero-padded output channels allowed).  Writes
+ * pcd_conv2d_wgrad_3x3_splits(..) slabs [cout][9][cin] f32 into `slabs`; finish with
+ * pcd_sparse_conv_wgrad_reduce_batched (job.kvol = 9, job.splits = that count, job.pmax = 1, layout 1 for an
+ * nn.Conv2d .grad, cout_write for padded convs).  0 splits / PCD_ERR_UNSUPPORTED: shape not covered (use the pair form). */
+int pcd_conv2d_wgrad_3x3_splits(int batch, int height, int width, int cin, int cout);
+int pcd_conv2d_wgrad_3x3_nhwc(const void *x, int x_cs, const void *dy, int batch, int height, int width, int cin, int cout,
+                              void *slabs, size_t slab_bytes, void *stream);
 /* The other three layers of BaseBEVBackbone (base_bev_backbone.py:36-75; MIOpen in the reference), forward and data
  * gradient, as per-parity-plane stencils on the same tiles.  pack modes (pcd_conv2d_pack_weight / _packed_weight_bytes /
  * the batched table take them too; cin / cout are the LAYER's channel counts, the weight is the torch parameter):
