@@ -723,8 +723,11 @@ extern "C" int pcd_conv2d_wgrad_3x3_splits(int batch, int height, int width, int
     if (batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 32) return 0;
     const int tiles = batch * ((height + WG_TH - 1) / WG_TH) * ((width + WG_TW - 1) / WG_TW);
     const int chunks = (cin / 64) * (cout % 64 == 0 ? cout / 64 : cout / 32);
-    static const int target = getenv("PCD_CONV2D_WG_BLOCKS") ? atoi(getenv("PCD_CONV2D_WG_BLOCKS")) : 512;
-    int splits = (target + chunks - 1) / chunks;            // about two workgroups per CU ...
+    static const int target = getenv("PCD_CONV2D_WG_BLOCKS") ? atoi(getenv("PCD_CONV2D_WG_BLOCKS")) : 128;
+    // about 128 workgroups per launch: measured in the full step (tools/exp_wgblocks.sh) 64 / 96 / 128 / 192 / 256 / 512 /
+    // 1024 -> 8.75 / 8.11 / 7.86 / 7.89 / 7.96 / 8.21 / 8.50 ms -- the kernel runs BESIDE the data-gradient chain: fewer, longer
+    // workgroups leave that chain half of the CUs and write fewer slabs
+    int splits = (target + chunks - 1) / chunks;
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     // ... with an equal number of tiles each where that is close (188 x 188 x 4: 1152 tiles)
