@@ -704,7 +704,7 @@ def main():
         if ops.STAMPS is not None and bd["spatial_features"].requires_grad:
             bd["spatial_features"].register_hook(lambda g: ops.stamp("dense_bwd_end"))
         if args.dense_head:
-            # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, MIOpen), then the REAL CenterHead step of the
+            # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, conv2d.hip kernels), then the REAL CenterHead step of the
             # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
             # and get_loss = focal(hm) + L1(boxes) (center_head.py:163-262) without its host round trips
             preds = model.dense_head(model.backbone_2d(bd))["pred_dicts"]

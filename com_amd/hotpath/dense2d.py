@@ -1,10 +1,10 @@
 """Dense BEV stack behind the hot path: the 2D backbone and the convolutional towers of the
 centre head -- pcdet/models/backbones_2d/base_bev_backbone.py:6-112 and
 pcdet/models/dense_heads/center_head.py:11-46,75-99 -- with the reference's constructor arguments, module / state-dict
-names and `data_dict` keys.  The arithmetic is dense conv2d / BatchNorm2d, i.e. library code (MIOpen); what this
-module adds is the MI355X execution form: bf16 autocast + torch.channels_last end to end, fed by the channels-last
+names and `data_dict` keys.  Execution form: bf16 autocast + torch.channels_last end to end, fed by the channels-last
 BEV scatter (`HeightCompression` with CHANNELS_LAST) so that no layout conversion sits between the sparse backbone
-and the first convolution.  Target assignment, losses and box decoding of CenterHead (center_head.py:100-369) stay
+and the first convolution; every conv / transposed conv / BatchNorm of the stack runs on the hand-written kernels of
+conv2d.hip / fused.hip (hotpath/conv2d_fast.py), fp32 inputs outside an autocast region on torch's own.  Target assignment, losses and box decoding of CenterHead (center_head.py:100-369) stay
 with the reference's Python (out of scope)."""
 import copy
 
