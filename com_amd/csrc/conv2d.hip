@@ -11,6 +11,7 @@
 // CONSECUTIVE output channels of its pixel: two 16-byte stores).  The data gradient is the same kernel on weights
 // packed transposed and rotated (mode 1).
 #include "common.h"
+#include "bn_mid.h"
 #include <type_traits>
 
 namespace {
@@ -82,12 +83,77 @@ __global__ __launch_bounds__(256) void conv2d_pack_batched_kernel(const long lon
                           (unsigned short *)row[1], e);
 }
 
+
+// BatchNorm sums in the conv's epilogue (PcdBnReduce, see spconv.hip: the same two modes for the dense maps).  A
+// workgroup covers 256 pixels x 64 channels: partial row `tile` (= blockIdx.x) has 2 x c_total columns, of which this
+// workgroup writes [cg * 64, cg * 64 + 64) of both halves; with `mid` the workgroup that completes a group of rows (every
+// row needs all gridDim.y channel groups: expect = rows of the group x gridDim.y arrivals) folds it.
+struct DenseBn {
+    int mode, relu;
+    const unsigned short *x, *y;     // mode 2: BatchNorm input / output (= this conv's forward input), [pixels][c_total]
+    const float *mean, *invstd;
+    float *partial;
+    double *mid;
+    int *counters;
+};
+
+// sums s[j] / q[j] of the lane's 16 channels (c0 + j) over its pixels -> partial row; all threads of the workgroup
+__device__ __forceinline__ void dense_bn_publish(const DenseBn &bn, float (&sv)[16], float (&qv)[16], int c_total, int cg,
+                                                 int g, int m, int wave, char *smem) {
+    float *red = reinterpret_cast<float *>(smem);          // [4 waves][2][64]; the tile buffers are free now
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        sv[j] = row16_sum(sv[j]);
+        qv[j] = row16_sum(qv[j]);
+    }
+    __syncthreads();
+    if (m == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            red[(wave * 2 + 0) * 64 + g * 16 + j] = sv[j];
+            red[(wave * 2 + 1) * 64 + g * 16 + j] = qv[j];
+        }
+    }
+    __syncthreads();
+    const int tile = blockIdx.x, nrows = gridDim.x;
+    float *dst = bn.partial + (size_t)tile * 2 * c_total;
+    if (threadIdx.x < 128) {
+        const int half = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        const float v = ((red[(0 * 2 + half) * 64 + ch] + red[(1 * 2 + half) * 64 + ch]) + red[(2 * 2 + half) * 64 + ch]) +
+                        red[(3 * 2 + half) * 64 + ch];
+        if (cg * 64 + ch < c_total) {
+            float *d = dst + half * c_total + cg * 64 + ch;
+            if (bn.mid) __hip_atomic_store(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *d = v;
+        }
+    }
+    if (!bn.mid) return;
+    __shared__ int last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row piece has reached the coherence point ...
+    __syncthreads();
+    const int r = tile & (BN_MID_ROWS - 1);
+    if (tile == 0 && cg == 0)                              // fewer tiles than groups: the empty groups' rows are zero
+        for (int e = nrows * 2 * c_total + threadIdx.x; e < BN_MID_ROWS * 2 * c_total; e += blockDim.x) bn.mid[e] = 0.0;
+    if (threadIdx.x == 0) {                                // ... before this workgroup counts as arrived
+        int *cnt = bn.counters + r * BN_COUNTER_STRIDE;
+        const int expect = ((nrows - r + BN_MID_ROWS - 1) / BN_MID_ROWS) * (int)gridDim.y;
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == expect - 1;
+        if (last_s) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last_s) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        bn_mid_row(bn.partial, nrows, c_total, r, bn.mid, reinterpret_cast<double *>(smem));
+    }
+}
+
 template <int WB>   // weight stage buffers: 2 = double buffered (113 KB LDS, 1 workgroup / CU); 1 = single (77 KB, 2 / CU)
 __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const unsigned short *__restrict__ x, int B, int H, int W,
                                                              int cin, const uint4 *__restrict__ wp, int cout,
                                                              const float *__restrict__ bias,
                                                              unsigned short *__restrict__ y, unsigned x_bytes,
-                                                             unsigned w_bytes, int x_cs, int y_cs) {
+                                                             unsigned w_bytes, int x_cs, int y_cs, DenseBn bn) {
     // x_cs / y_cs: channels per pixel of the buffers x / y live in (>= cin / cout: a channel block of a wider map)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *in_s = smem;                       // [2][IN_BYTES]
@@ -181,23 +247,72 @@ __global__ __launch_bounds__(256, WB == 2 ? 1 : 2) void conv2d_3x3_kernel(const 
     float bv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bv[j] = (bias && c0 + j < cout) ? bias[c0 + j] : 0.0f;
+    float sv[16], qv[16], mu[16], is[16];
+    if (bn.mode) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sv[j] = qv[j] = 0.0f;
+            mu[j] = (bn.mode == 2 && c0 + j < cout) ? bn.mean[c0 + j] : 0.0f;
+            is[j] = (bn.mode == 2 && c0 + j < cout) ? bn.invstd[c0 + j] : 0.0f;
+        }
+    }
+    // (with BatchNorm sums: all four rows are rounded and summed FIRST, the partial row is published, and only then the
+    //  tile is stored -- the publication waits for its own stores (s_waitcnt vmcnt(0)), which must not include the 32 KB
+    //  of output stores: that cost 8 us per launch)
+    u32 o[4][8];
+    bool live[4];
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
         const int gy = y0 + wave * 4 + pb, gx = x0 + m;
-        if (gy >= H || gx >= W || c0 >= cout) continue;
-        u32 o[8];
+        live[pb] = !(gy >= H || gx >= W || c0 >= cout);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const u32 lo0 = f32_to_bf16_bits(acc[mb][pb][0] + bv[mb * 4 + 0]);
             const u32 hi0 = f32_to_bf16_bits(acc[mb][pb][1] + bv[mb * 4 + 1]);
             const u32 lo1 = f32_to_bf16_bits(acc[mb][pb][2] + bv[mb * 4 + 2]);
             const u32 hi1 = f32_to_bf16_bits(acc[mb][pb][3] + bv[mb * 4 + 3]);
-            o[mb * 2] = lo0 | (hi0 << 16);
-            o[mb * 2 + 1] = lo1 | (hi1 << 16);
+            o[pb][mb * 2] = lo0 | (hi0 << 16);
+            o[pb][mb * 2 + 1] = lo1 | (hi1 << 16);
         }
+        if (!live[pb] || !bn.mode) continue;
+        const size_t pix = ((size_t)b * H + gy) * W + gx;
+        if (bn.mode == 1) {            // statistics of the outputs AS STORED (bf16)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = __uint_as_float((j & 1) ? (o[pb][j >> 1] & 0xffff0000u) : (o[pb][j >> 1] << 16));
+                sv[j] += v;
+                qv[j] += v * v;
+            }
+        } else {                       // this output is dy of a BatchNorm(+ReLU): sum dz, sum dz * xhat
+            const uint4 *xp = reinterpret_cast<const uint4 *>(bn.x + pix * cout + c0);
+            const uint4 x0v = xp[0], x1v = xp[1];
+            const u32 xw[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
+            u32 yw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (bn.relu) {
+                const uint4 *yp = reinterpret_cast<const uint4 *>(bn.y + pix * cout + c0);
+                const uint4 y0v = yp[0], y1v = yp[1];
+                yw[0] = y0v.x; yw[1] = y0v.y; yw[2] = y0v.z; yw[3] = y0v.w;
+                yw[4] = y1v.x; yw[5] = y1v.y; yw[6] = y1v.z; yw[7] = y1v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = __uint_as_float((j & 1) ? (o[pb][j >> 1] & 0xffff0000u) : (o[pb][j >> 1] << 16));
+                const float xv = __uint_as_float((j & 1) ? (xw[j >> 1] & 0xffff0000u) : (xw[j >> 1] << 16));
+                const float yv = __uint_as_float((j & 1) ? (yw[j >> 1] & 0xffff0000u) : (yw[j >> 1] << 16));
+                const float dz = (bn.relu && !(yv > 0.0f)) ? 0.0f : v;
+                sv[j] += dz;
+                qv[j] += dz * (xv - mu[j]) * is[j];
+            }
+        }
+    }
+    if (bn.mode) dense_bn_publish(bn, sv, qv, cout, cg, g, m, wave, smem);
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        if (!live[pb]) continue;
+        const int gy = y0 + wave * 4 + pb, gx = x0 + m;
         uint4 *dst = reinterpret_cast<uint4 *>(y + (((size_t)b * H + gy) * W + gx) * y_cs + c0);
-        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        dst[0] = make_uint4(o[pb][0], o[pb][1], o[pb][2], o[pb][3]);
+        dst[1] = make_uint4(o[pb][4], o[pb][5], o[pb][6], o[pb][7]);
     }
 }
 
@@ -623,9 +738,32 @@ extern "C" int pcd_conv2d_pack_weights_batched(const void *table, int n, int tot
     return PCD_OK;
 }
 
-extern "C" int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin,
-                                      const void *packed_w, int cout, const float *bias, void *y, int y_cs, void *stream) {
+extern "C" int pcd_conv2d_3x3_tiles(int batch, int height, int width) {
+    if (batch <= 0 || height <= 0 || width <= 0) return PCD_ERR_INVALID_ARG;
+    return batch * ((height + TP - 1) / TP) * ((width + TP - 1) / TP);
+}
+
+extern "C" int pcd_conv2d_3x3_nhwc_bn(const void *x, int x_cs, int batch, int height, int width, int cin,
+                                      const void *packed_w, int cout, const float *bias, void *y, int y_cs,
+                                      const PcdBnReduce *bnr, void *stream) {
     PCD_ENTER();
+    DenseBn bn = {};
+    if (bnr && bnr->mode) {
+        if (bnr->mode != 1 && bnr->mode != 2) return PCD_ERR_INVALID_ARG;
+        if (!bnr->partial || bnr->partial_rows != pcd_conv2d_3x3_tiles(batch, height, width) || y_cs != cout)
+            return PCD_ERR_INVALID_ARG;
+        if (bnr->mode == 2 && (!bnr->x || !bnr->mean || !bnr->invstd || (bnr->relu && !bnr->y))) return PCD_ERR_INVALID_ARG;
+        if ((bnr->mid != nullptr) != (bnr->counters != nullptr)) return PCD_ERR_INVALID_ARG;
+        bn.mode = bnr->mode;
+        bn.relu = bnr->relu;
+        bn.x = (const unsigned short *)bnr->x;
+        bn.y = (const unsigned short *)bnr->y;
+        bn.mean = bnr->mean;
+        bn.invstd = bnr->invstd;
+        bn.partial = bnr->partial;
+        bn.mid = bnr->mid;
+        bn.counters = bnr->counters;
+    }
     if (batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0) return PCD_ERR_INVALID_ARG;
     if (!x || !packed_w || !y || x_cs < cin || y_cs < cout || x_cs % 8 || y_cs % 8) return PCD_ERR_INVALID_ARG;
     if (cin % 32 || cout % 16) return PCD_ERR_UNSUPPORTED;
@@ -649,19 +787,24 @@ extern "C" int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int he
         conv2d_3x3_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
                                                                      (const uint4 *)packed_w, cout, bias,
                                                                      (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes,
-                                                                     x_cs, y_cs);
+                                                                     x_cs, y_cs, bn);
     else
         conv2d_3x3_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>((const unsigned short *)x, batch, height, width, cin,
                                                                      (const uint4 *)packed_w, cout, bias,
                                                                      (unsigned short *)y, (unsigned)xb, (unsigned)wb_bytes,
-                                                                     x_cs, y_cs);
+                                                                     x_cs, y_cs, bn);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
 
+extern "C" int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin,
+                                      const void *packed_w, int cout, const float *bias, void *y, int y_cs, void *stream) {
+    return pcd_conv2d_3x3_nhwc_bn(x, x_cs, batch, height, width, cin, packed_w, cout, bias, y, y_cs, nullptr, stream);
+}
+
 extern "C" int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin, const void *packed_w,
                                    int cout, const float *bias, void *y, void *stream) {
-    return pcd_conv2d_3x3_nhwc_ld(x, cin, batch, height, width, cin, packed_w, cout, bias, y, cout, stream);
+    return pcd_conv2d_3x3_nhwc_bn(x, cin, batch, height, width, cin, packed_w, cout, bias, y, cout, nullptr, stream);
 }
 
 

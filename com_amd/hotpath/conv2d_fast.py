@@ -14,6 +14,11 @@ import torch.nn as nn
 from .. import ops
 
 ENABLED = True
+# BatchNorm sums in the dense convs' epilogues (PcdBnReduce modes 1 / 2 of pcd_conv2d_3x3_nhwc_bn): bit 0 = forward
+# statistics, bit 1 = backward reductions on the data-gradient launch.  Measured in the full step
+# (tools/exp_dense_bn_epi.sh, 2 x 80 replays): off 7.84, forward 7.79, backward 7.89, both 7.86 ms -- the backward form
+# re-reads the BatchNorm's input and output tile in the data-gradient epilogue and loses; only the forward one is on.
+DENSE_BN_EPILOGUE = int(os.environ.get('PCD_DENSE_BN_EPI', '1'))
 _PAIRS = {}
 
 
@@ -157,8 +162,11 @@ class _Conv3x3Function(torch.autograd.Function):
     pack_f / pack_d: packs made ahead (Conv3x3Packs), or None: packed here."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pack_f, pack_d):
+    def forward(ctx, x, weight, bias, pack_f, pack_d, bn_follows=False, bn_link=None):
         # x: [B, C, H, W] bf16, channels_last storage
+        # bn_follows: a training-mode BatchNorm consumes the output -> its statistics are taken in this launch's epilogue
+        # bn_link: x IS the output of a fused BatchNorm -> its backward reductions ride on our data-gradient launch
+        from ..spconv import functional as Fsp
         xn = x.detach().permute(0, 2, 3, 1)
         assert xn.is_contiguous()
         cout = weight.shape[0]
@@ -168,14 +176,19 @@ class _Conv3x3Function(torch.autograd.Function):
             b = torch.nn.functional.pad(b, (0, cp - cout))
         if pack_f is None:
             pack_f = ops.conv2d_pack_weight(weight, 0)
-        y = ops.conv2d_3x3_nhwc(xn, pack_f, cp, b)
+        stats = ops.BnReduce(1) if (bn_follows and Fsp.FUSE_BN_REDUCTIONS and cp == cout and (DENSE_BN_EPILOGUE & 1)) else None
+        y = ops.conv2d_3x3_nhwc(xn, pack_f, cp, b, bn_reduce=stats)
         if cp != cout:
             y = y[..., :cout].contiguous()
         ctx.save_for_backward(xn, weight, pack_d)
         ctx.has_bias, ctx.cout = bias is not None, cout
         ctx.weight_param = weight if isinstance(weight, nn.Parameter) else None
         ctx.bias_param = bias if isinstance(bias, nn.Parameter) else None
-        return y.permute(0, 3, 1, 2)
+        ctx.bn_link = bn_link if (Fsp.FUSE_BN_REDUCTIONS and (DENSE_BN_EPILOGUE & 2)) else None
+        out = y.permute(0, 3, 1, 2)
+        if stats is not None and stats.partial is not None:
+            out._pcd_stats = stats
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -195,7 +208,14 @@ class _Conv3x3Function(torch.autograd.Function):
 
         def dgrad():
             pd = pack_d if pack_d is not None else ops.conv2d_pack_weight(weight, 1)
-            return ops.conv2d_3x3_nhwc(dyn, pd, cin).permute(0, 3, 1, 2)
+            link, red = ctx.bn_link, None
+            if link is not None and link.x.shape == (B * H * W, cin):
+                red = ops.BnReduce(2, relu=link.relu, x=link.x, y=xn.reshape(-1, cin) if link.relu else None,
+                                   mean=link.mean, invstd=link.invstd)
+            dxn = ops.conv2d_3x3_nhwc(dyn, pd, cin, bn_reduce=red)
+            if red is not None and red.partial is not None:
+                link.result = (dxn.view(-1, cin), red.partial, red.rows)
+            return dxn.permute(0, 3, 1, 2)
 
         def wgrad(direct):
             if ops.conv2d_wgrad_splits(B, H, W, cin, cp) > 0:      # the dense kernel (no pair lists)
@@ -222,7 +242,7 @@ class _Conv3x3Function(torch.autograd.Function):
 
         dx, dw, db = _scheduled_backward(ctx.needs_input_grad[0], want_w, want_b, wp, bp, True, dgrad, wgrad, bsum,
                                          (xn, dyn))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class Conv3x3(nn.Conv2d):
@@ -237,15 +257,19 @@ class Conv3x3(nn.Conv2d):
                 and x.shape[0] * x.shape[2] * x.shape[3] * max(self.in_channels, _pad32(self.out_channels)) * 2
                 < 2 ** 32 - 4096)
 
+    bn_follows = False   # set by the owner when a BatchNormReLU2d consumes the output (dense2d.py)
+
     def forward(self, x):
         if not self._fast(x):
             return super().forward(x)
+        link = getattr(x, "_pcd_bn_link", None)
         if x.dtype != torch.bfloat16:
-            x = x.to(torch.bfloat16)
+            x, link = x.to(torch.bfloat16), None
         if not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)
+            x, link = x.contiguous(memory_format=torch.channels_last), None
         pf, pd = self._take_packs()
-        return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd)
+        follows = bool(self.bn_follows and self.training and torch.is_grad_enabled())
+        return _Conv3x3Function.apply(x, self.weight, self.bias, pf, pd, follows, link)
 
     def _take_packs(self):
         pf = pd = None
@@ -577,9 +601,16 @@ class BatchNormReLU2d(nn.BatchNorm2d):
                     out_rows = out.permute(0, 2, 3, 1).reshape(B * H * W, C)
                     if out_rows.data_ptr() != out.data_ptr() or out_rows.stride(1) != 1:
                         out_rows = None                                   # (reshape had to copy: not a column block)
+                st = getattr(x, "_pcd_stats", None)           # the conv in front took the statistics in its epilogue
+                if st is not None:
+                    rows._pcd_stats = st
                 y = Fsp.batch_norm_act(self, rows, None, self.relu, out=out_rows)
                 self.wrote_out = out_rows is not None
-                return y.view(B, H, W, C).permute(0, 3, 1, 2)
+                res = y.view(B, H, W, C).permute(0, 3, 1, 2)
+                link = getattr(y, "_pcd_bn_link", None)       # ... and the conv behind can take the backward reductions
+                if link is not None:
+                    res._pcd_bn_link = link
+                return res
         if getattr(self, "_defer_nbt", False) and self.training and self.num_batches_tracked is not None:
             self.num_batches_tracked.sub_(1)         # bump_bn_counters() already counted this call
         y = super().forward(x)

@@ -60,6 +60,9 @@ class BaseBEVBackbone(nn.Module):
             for _ in range(layer_nums[idx]):
                 layers += [Conv3x3(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
                            bn(num_filters[idx]), nn.Identity()]
+            for a, b_ in zip(layers[:-1], layers[1:]):
+                if isinstance(a, Conv3x3) and isinstance(b_, BatchNormReLU2d):
+                    a.bn_follows = True                      # its epilogue takes the BatchNorm statistics
             self.blocks.append(nn.Sequential(*layers))
             if upsample_strides:
                 stride = upsample_strides[idx]
@@ -130,6 +133,7 @@ class SeparateHead(nn.Module):
             for _ in range(spec['num_conv'] - 1):
                 fc.append(nn.Sequential(Conv3x3(input_channels, input_channels, 3, stride=1, padding=1, bias=use_bias),
                                         BatchNormReLU2d(input_channels, relu=True), nn.Identity()))
+                fc[-1][0].bn_follows = True
             fc.append(Conv3x3(input_channels, spec['out_channels'], 3, stride=1, padding=1, bias=True))
             fc = nn.Sequential(*fc)
             if 'hm' in cur_name:
@@ -234,6 +238,7 @@ class SeparateHead(nn.Module):
             dev = groups[0][0].device
             has_bias = len(groups) == 4
             conv = Conv3x3(c, n * c, 3, stride=1, padding=1, bias=has_bias).to(dev)
+            conv.bn_follows = True
             bn0 = seqs[0][0][1]
             bn = BatchNormReLU2d(n * c, eps=bn0.eps, momentum=bn0.momentum, relu=True).to(dev)
             bn._defer_nbt = True                               # (the branches' own counters are the ones that count)
@@ -288,6 +293,7 @@ class CenterHeadTowers(nn.Module):
         use_bias = bool(_get(model_cfg, 'USE_BIAS_BEFORE_NORM', False))
         self.shared_conv = nn.Sequential(Conv3x3(input_channels, shared, 3, stride=1, padding=1, bias=use_bias),
                                          BatchNormReLU2d(shared, relu=True), nn.Identity())
+        self.shared_conv[0].bn_follows = True
         head_cfg = _get(model_cfg, 'SEPARATE_HEAD_CFG')
         self.heads_list = nn.ModuleList()
         for names in class_names_each_head:

@@ -673,6 +673,21 @@ class BnReduce:
                     return False
         return True
 
+    def usable_dense(self, pixels, c):
+        """conv2d_3x3_nhwc: the dense maps [pixels, c] behind mode 2 must be plain contiguous bf16 matrices."""
+        if self.mode == 2:
+            for t in (self.x, self.y if self.relu else None):
+                if t is None:
+                    if t is self.x:
+                        return False
+                    continue
+                if t.dtype != torch.bfloat16 or tuple(t.shape) != (pixels, c) or not t.is_contiguous():
+                    return False
+            for t in (self.mean, self.invstd):
+                if t is None or t.dtype != torch.float32 or t.numel() != c:
+                    return False
+        return True
+
     def _struct(self, tiles, c_out, device):
         self.partial = torch.empty((max(tiles, 1), 2, c_out), dtype=torch.float32, device=device)
         self.rows = tiles
@@ -978,10 +993,11 @@ def _pixel_block(t):
     return cs
 
 
-def conv2d_3x3_nhwc(x, packed_w, cout, bias=None, out=None):
+def conv2d_3x3_nhwc(x, packed_w, cout, bias=None, out=None, bn_reduce=None):
     """y = conv2d(x, w, bias, stride 1, padding 1) for x [B, H, W, cin] bf16 contiguous (= channels_last storage of an
     NCHW tensor); returns [B, H, W, cout] bf16.  Data gradient: conv2d_3x3_nhwc(dy, pack(w, 1), cin).
-    x may be a CHANNEL BLOCK of a wider map (x[..., a:a + cin] of a contiguous [B, H, W, C]) and `out` one to write into."""
+    x may be a CHANNEL BLOCK of a wider map (x[..., a:a + cin] of a contiguous [B, H, W, C]) and `out` one to write into.
+    bn_reduce (BnReduce): the launch also takes the BatchNorm sums of its output tile (plain output map only)."""
     _require_cuda(x, packed_w)
     assert x.dtype == torch.bfloat16 and x.dim() == 4
     B, H, W, cin = x.shape
@@ -996,8 +1012,14 @@ def conv2d_3x3_nhwc(x, packed_w, cout, bias=None, out=None):
     with _Timed(f"conv2d_3x3_kernel {cin}->{cout} {H}x{W}",
                 lambda: dict(bytes=(x.numel() + y.numel()) * 2 + 9 * cin * cout * 2, flops=2 * 9 * B * H * W * cin * cout,
                              rows=B * H * W, pairs=0)):
-        L.check(L.lib().pcd_conv2d_3x3_nhwc_ld(L.ptr(x), x_cs, B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
-                                               y_cs, L.stream_ptr()), "pcd_conv2d_3x3_nhwc_ld")
+        bnr = keep = None
+        if bn_reduce is not None and y_cs == cout and bn_reduce.usable_dense(B * H * W, cout):
+            keep = bnr = bn_reduce._struct(L.lib().pcd_conv2d_3x3_tiles(B, H, W), cout, x.device)
+        elif bn_reduce is not None:
+            bn_reduce.partial, bn_reduce.rows = None, 0
+        L.check(L.lib().pcd_conv2d_3x3_nhwc_bn(L.ptr(x), x_cs, B, H, W, cin, L.ptr(packed_w), cout, L.ptr(b), L.ptr(y),
+                                               y_cs, _byref(bnr), L.stream_ptr()), "pcd_conv2d_3x3_nhwc_bn")
+        del keep
     return y
 
 

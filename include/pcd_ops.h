@@ -755,6 +755,13 @@ int pcd_conv2d_3x3_nhwc(const void *x, int batch, int height, int width, int cin
  * one 320-channel activation and their data gradients fill its gradient block by block -- no slice copies, no adds */
 int pcd_conv2d_3x3_nhwc_ld(const void *x, int x_cs, int batch, int height, int width, int cin, const void *packed_w,
                            int cout, const float *bias, void *y, int y_cs, void *stream);
+/* ... and with the BatchNorm sums of the sparse path's PcdBnReduce taken in its epilogue (y_cs == cout required): mode 1 on
+ * the forward launch for the BatchNorm behind the conv, mode 2 on the data-gradient launch for the BatchNorm whose output
+ * was the conv's input (x / y = that BatchNorm's input / output as [pixels][cout] bf16).  partial_rows must equal
+ * pcd_conv2d_3x3_tiles(batch, height, width); hand partial / mid to pcd_bn_forward / _backward as ext_partial. */
+int pcd_conv2d_3x3_tiles(int batch, int height, int width);
+int pcd_conv2d_3x3_nhwc_bn(const void *x, int x_cs, int batch, int height, int width, int cin, const void *packed_w,
+                           int cout, const float *bias, void *y, int y_cs, const PcdBnReduce *bn_reduce, void *stream);
 /* Weight gradient of that conv without pair lists: x [b][h][w][cin] (pixel stride x_cs channels), dy [b][h][w][cout]
  * contiguous, cin % 64 == 0, cout % 32 == 0 (zero-padded output channels allowed).  Writes
  * pcd_conv2d_wgrad_3x3_splits(..) slabs [cout][9][cin] f32 into `slabs`; finish with
