@@ -506,6 +506,8 @@ extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, c
     if (!workspace || workspace_bytes < pcd_stack_fps_coop_workspace_bytes(B)) return PCD_ERR_WORKSPACE;
     int G = 256 / B;
     if (G > FPS_COOP_MAXG) G = FPS_COOP_MAXG;
+    static const int g_env = getenv("PCD_FPS_G") ? atoi(getenv("PCD_FPS_G")) : 0;   // (experiments: workgroups per frame)
+    if (g_env >= 2 && g_env <= G) G = g_env;
     if (G < 2) return PCD_ERR_UNSUPPORTED;
     const int slice_cap = pcd_div_up(max_cnt_host, G);
     const size_t lds = (size_t)slice_cap * 16;

@@ -73,12 +73,13 @@ class _RulebookPrefetcher:
     def __init__(self, units, x0, side):
         self.units, self.t, self.side, self.next = units, x0, side, 0
 
-    def advance(self):
+    def advance(self, inline=False):
+        """inline: build the unit on the CURRENT stream (no event: its consumers are ordered behind it anyway)."""
         if self.next >= len(self.units):
             return
         unit = self.units[self.next]
         self.next += 1
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(torch.cuda.current_stream() if inline else self.side):
             t = self.t
             built = []
             for conv in unit:
@@ -89,11 +90,14 @@ class _RulebookPrefetcher:
                     t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
                                          num_rows=rb.n_out_dev)
             self.t = t
-            if built:
+            if built and not inline:
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 for rb in built:
                     rb.ready_event = ev
+            from .. import ops
+            if ops.STAMPS is not None:
+                ops.stamp(f"rb_unit{self.next - 1}")
 
 
 class _BackboneBase(nn.Module):
@@ -125,6 +129,7 @@ class _BackboneBase(nn.Module):
                 torch._foreach_add_(counters, 1)
 
     prefetch_rulebooks = True
+    first_unit_inline = __import__("os").environ.get("PCD_RB_INLINE0", "0") == "1"   # measured: see _prefetch_rulebooks
     prefetch_depth = 2          # rulebook units issued before the first conv; each unit's first consumer issues one more
 
     def _prefetch_rulebooks(self, x0):
@@ -150,6 +155,14 @@ class _BackboneBase(nn.Module):
         x0.indice_dict["__prefetcher__"] = pf
         depth = max(1, int(self.prefetch_depth))
         side.wait_stream(cur)
+        if self.first_unit_inline:
+            # (experiment, off) the level-1 rulebook on the MAIN stream.  Device-clock stamps show the first conv of the step
+            # starting 210-260 us into the forward although its rulebook is ready at 24 us (the hipGraph executor runs it
+            # behind the next unit's kernels); built inline it finishes at 63 us and the forward ends 84 us earlier -- but
+            # the rulebook units, now beside the gather kernels from the start, finish 90-200 us later and the step is the
+            # same: 3.44 vs 3.42 ms without stamps (tools/exp_rb_inline.sh)
+            pf.advance(inline=True)
+            depth -= 1
         for _ in range(depth):
             pf.advance()
         if getattr(self, "_packed_ahead", False):              # pack_after_update() ran since the last update
@@ -203,6 +216,8 @@ class _BackboneBase(nn.Module):
         from .. import ops
         x0 = self._input_tensor(batch_dict)
         ops.stamp("fwd_begin")
+        if ops.STAMPS is not None:
+            ops.STAMPS["conv_seq"] = 0
         self._prefetch_rulebooks(x0)
         x = self.conv_input(x0)
         ops.stamp("conv_input")

@@ -180,11 +180,18 @@ class SparseConvolution(SparseModule):
             cur.wait_event(ev)                      # built on the prefetch stream: order this stream after it ONCE
             rb.joined_stream = cur.cuda_stream
             first_use = True
+        from .. import ops as _ops
+        dbg = _ops.STAMPS is not None and _ops.STAMPS.get("conv_seq", 99) < 3
+        if dbg:
+            _ops.stamp(f"cv{_ops.STAMPS['conv_seq']}_a")
         fp8 = getattr(self, "fp8_train", None)
         if fp8 is not None and not (self.training and torch.is_grad_enabled()):
             fp8 = None                                  # (the fp8-forward training form; inference has Fp8Backbone)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad,
                                 passthrough, **({"fp8": fp8} if fp8 is not None else {}))
+        if dbg:
+            _ops.stamp(f"cv{_ops.STAMPS['conv_seq']}_b")
+            _ops.STAMPS["conv_seq"] += 1
         ident = None
         if passthrough:
             feats, ident = feats
