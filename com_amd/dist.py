@@ -292,3 +292,47 @@ def max_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _gpu_local_cpus(device_index):
+    import os
+    p = torch.cuda.get_device_properties(device_index)
+    bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    text = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+    cpus = set()
+    for part in text.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus |= set(range(int(a), int(b) + 1))
+        elif part.strip():
+            cpus.add(int(part))
+    return cpus
+
+
+def bind_to_gpu_numa(device_index, n_local=1):
+    """Restrict this process to CPUs local to its GPU's PCIe root (sysfs `local_cpulist` of the device), so that the
+    launch thread and the pinned staging buffers it allocates sit on the GPU's NUMA node; with n_local > 1 ranks on the
+    node, the ranks whose GPUs share a NUMA node split that node's cores between them (rank = device index).  Call it
+    right after torch.cuda.set_device(), before allocating pinned memory.  Returns the CPU set, or None when nothing was
+    changed (no sysfs entry, PCD_NO_AFFINITY=1, one NUMA node, or nothing left after intersecting with the current mask)."""
+    import os
+    if os.environ.get("PCD_NO_AFFINITY"):
+        return None
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        local = _gpu_local_cpus(device_index)
+        mine = sorted(local & allowed)
+        if not mine:
+            return None
+        if n_local > 1:
+            peers = [j for j in range(n_local) if _gpu_local_cpus(j) == local]
+            per = len(mine) // len(peers)
+            if per >= 1:
+                k = peers.index(device_index)
+                mine = mine[k * per:(k + 1) * per]
+        if set(mine) == allowed:
+            return None
+        os.sched_setaffinity(0, set(mine))
+        return set(mine)
+    except Exception:
+        return None
