@@ -568,6 +568,9 @@ def main():
     # (opt-in, PCD_BIND_GPU_NUMA=1: launch thread + pinned staging buffers on the GPU's own NUMA node.  Measured on a
     #  2-socket gpurun box: the HBM-resident loop is unchanged (3.39 ms) and the H2D-inclusive loop gets SLOWER when bound to
     #  the node sysfs reports as local -- 4.8 vs 3.47 ms per step -- so it is off)
+    if os.environ.get("PCD_BIND_CPUS"):                      # experiments: "a-b" CPU range for this process
+        a_, b_ = os.environ["PCD_BIND_CPUS"].split("-")
+        os.sched_setaffinity(0, set(range(int(a_), int(b_) + 1)))
     if os.environ.get("PCD_BIND_GPU_NUMA") and not os.environ.get("PCD_DIST_ONE_GPU"):
         cdist.bind_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     rccl_world1 = world == 1 and bool(os.environ.get("PCD_RCCL_WORLD1"))
