@@ -61,11 +61,38 @@ class StackSAModuleMSG(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
                 nn.init.constant_(m.bias, 0)
 
+    ROWS_MLP = True   # the shared MLPs as plain GEMMs over [M * nsample, C] rows (False: the reference's Conv2d form)
+
+    @staticmethod
+    def _mlp_rows(mlp, x):
+        """The reference's Conv2d(1x1) + BatchNorm2d + ReLU stack (pointnet2_modules.py StackSAModuleMSG) applied to
+        [rows, C]: a 1 x 1 conv over (1, C, M, nsample) IS a matrix product over the M * nsample positions -- run it as one
+        (rocBLAS GEMM, rows contiguous) instead of through MIOpen's NCHW path (its layout transposes were a quarter of the
+        set-abstraction time).  Same parameters / buffers (training mode updates the running statistics)."""
+        for m in mlp:
+            if isinstance(m, nn.Conv2d):
+                x = F.linear(x, m.weight.view(m.out_channels, m.in_channels), m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                if m.training and m.num_batches_tracked is not None:
+                    m.num_batches_tracked.add_(1)
+                x = F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training or m.running_mean is None,
+                                 m.momentum if m.momentum is not None else 0.1, m.eps)
+            elif isinstance(m, nn.ReLU):
+                x = F.relu(x)
+            else:
+                raise NotImplementedError(type(m))
+        return x
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, return_idx=False):
         outs, idxs = [], []
         for grouper, mlp in zip(self.groupers, self.mlps):
             new_features, ball_idxs = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)   # (M, C, nsample)
             idxs.append(ball_idxs)
+            if self.ROWS_MLP and self.pool_method in ('max_pool', 'avg_pool'):
+                M, C, ns = new_features.shape
+                rows = self._mlp_rows(mlp, new_features.permute(0, 2, 1).reshape(M * ns, C)).view(M, ns, -1)
+                outs.append(rows.amax(dim=1) if self.pool_method == 'max_pool' else rows.mean(dim=1))
+                continue
             new_features = mlp(new_features.permute(1, 0, 2).unsqueeze(0))                               # (1, C', M, nsample)
             if self.pool_method == 'max_pool':
                 new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
