@@ -948,13 +948,76 @@ def g13():
          iou_dd=O.ref_boxes_iou_bev_cpu(d, d))
 
 
+def g16():
+    """The dense BEV stack by the REFERENCE's own modules: `BaseBEVBackbone` (pcdet/models/backbones_2d/
+    base_bev_backbone.py:6-112, imported as it stands) followed by the conv towers of CenterHead -- `shared_conv` built as
+    center_head.py:75-83 builds it and the reference's `SeparateHead` class (center_head.py:11-46, extracted from the file:
+    the module itself pulls in the compiled iou3d extension) -- at reduced widths, same structure as centerpoint.yaml
+    (LAYER_NUMS [2, 2], strides [1, 2], k = stride deconvs, five two-conv branches, USE_BIAS_BEFORE_NORM).  Training-mode
+    forward on a sparse-looking BEV map + backward of a fixed linear functional, float32 on the CPU.  Stored: the complete
+    state dicts BEFORE the step (what `load_state_dict(strict=True)` of the drop-in modules must accept), the input, all
+    outputs, the BatchNorm running statistics AFTER the step, the input gradient and four parameter gradients."""
+    import ast
+    import textwrap
+    import torch.nn as nn
+    bb_mod = ref_module("pcdet/models/backbones_2d", "base_bev_backbone", "refbev")
+    src = open(os.path.join(REF, "pcdet/models/dense_heads/center_head.py")).read()
+    ns = {"torch": torch, "nn": nn, "kaiming_normal_": torch.nn.init.kaiming_normal_}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == "SeparateHead":
+            exec(compile(textwrap.dedent(ast.get_source_segment(src, node)), "center_head.SeparateHead", "exec"), ns)
+    SeparateHead = ns["SeparateHead"]
+    torch.manual_seed(16)
+    cfg = _AttrDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[32, 64], UPSAMPLE_STRIDES=[1, 2],
+                    NUM_UPSAMPLE_FILTERS=[32, 32])
+    bb = bb_mod.BaseBEVBackbone(cfg, 64).train()
+    shared = nn.Sequential(nn.Conv2d(bb.num_bev_features, 64, 3, stride=1, padding=1, bias=True), nn.BatchNorm2d(64),
+                           nn.ReLU()).train()                                        # center_head.py:75-83
+    head_dict = {"center": dict(out_channels=2, num_conv=2), "center_z": dict(out_channels=1, num_conv=2),
+                 "dim": dict(out_channels=3, num_conv=2), "rot": dict(out_channels=2, num_conv=2),
+                 "hm": dict(out_channels=3, num_conv=2)}
+    head = SeparateHead(64, head_dict, init_bias=-2.19, use_bias=True).train()       # center_head.py:85-97
+    with torch.no_grad():                    # non-trivial BatchNorm parameters (the constructors leave them at 1 / 0)
+        for m in list(bb.modules()) + list(shared.modules()) + list(head.modules()):
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.2)
+    arrays = {}
+    for prefix, mod in (("bb.", bb), ("shared.", shared), ("head.", head)):
+        for k, v in mod.state_dict().items():
+            arrays["sd:" + prefix + k] = v.detach().numpy().copy()
+    B, H, W = 2, 24, 20
+    x = (torch.randn(B, 64, H, W) * (torch.rand(B, 1, H, W) < 0.3)).requires_grad_(True)
+    d = bb({"spatial_features": x})
+    f2d = d["spatial_features_2d"]
+    preds = head(shared(f2d))
+    ws = {k: torch.randn_like(v) for k, v in preds.items()}
+    loss = sum((preds[k] * ws[k]).sum() for k in preds)
+    loss.backward()
+    arrays.update(x=x.detach().numpy(), spatial_features_2d=f2d.detach().numpy(), dx=x.grad.numpy())
+    for k in preds:
+        arrays["pred:" + k] = preds[k].detach().numpy()
+        arrays["w:" + k] = ws[k].numpy()
+    for prefix, mod in (("bb.", bb), ("shared.", shared), ("head.", head)):
+        for k, v in mod.state_dict().items():
+            if "running_" in k:
+                arrays["after:" + prefix + k] = v.detach().numpy().copy()
+    named = dict(bb.named_parameters())
+    for k in ("blocks.0.1.weight", "blocks.1.1.weight", "deblocks.0.0.weight", "deblocks.1.0.weight"):
+        arrays["grad:bb." + k] = named[k].grad.numpy()
+    arrays["grad:head.hm.1.weight"] = dict(head.named_parameters())["hm.1.weight"].grad.numpy()
+    arrays["grad:head.dim.0.0.weight"] = dict(head.named_parameters())["dim.0.0.weight"].grad.numpy()
+    assert f2d.shape == (B, 64, H, W) and preds["hm"].shape == (B, 3, H, W)
+    save("g16_dense_stack", **arrays)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
