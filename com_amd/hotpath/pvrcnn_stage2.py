@@ -208,11 +208,11 @@ class VoxelSetAbstraction(nn.Module):
 
 
 def rotate_points_along_z(points, angle):
-    """pcdet/utils/common_utils.py:32-57: points [B, N, 3], angle [B]."""
+    """pcdet/utils/common_utils.py:35-57: points [B, N, 3 + C], angle [B]; the extra channels pass through."""
     cosa, sina = torch.cos(angle), torch.sin(angle)
     zeros, ones = angle.new_zeros(points.shape[0]), angle.new_ones(points.shape[0])
     rot = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
-    return torch.matmul(points[:, :, 0:3], rot)
+    return torch.cat((torch.matmul(points[:, :, 0:3], rot), points[:, :, 3:]), dim=-1)
 
 
 def roi_grid_points(rois, grid_size):

@@ -1011,13 +1011,62 @@ def g16():
     save("g16_dense_stack", **arrays)
 
 
+def g17():
+    """Host geometry of PV-RCNN's second stage by the REFERENCE's own functions, extracted from the files as they stand
+    (the modules pull in compiled extensions / SharedArray): pcdet/utils/common_utils.py `rotate_points_along_z` (:35-54),
+    `get_voxel_centers` (:66-82), voxel_set_abstraction.py `bilinear_interpolate_torch` (:11-44) and pvrcnn_head.py `get_global_grid_points_of_roi`
+    / `get_dense_grid_points` (:111-132)."""
+    import ast
+    import textwrap
+    csrc = open(os.path.join(REF, "pcdet/utils/common_utils.py")).read()
+    cns = {"torch": torch, "np": np}
+    for node in ast.parse(csrc).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("rotate_points_along_z", "get_voxel_centers",
+                                                               "bilinear_interpolate_torch", "check_numpy_to_torch"):
+            exec(compile(textwrap.dedent(ast.get_source_segment(csrc, node)), "common_utils." + node.name, "exec"), cns)
+    vsrc = open(os.path.join(REF, "pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py")).read()
+    for node in ast.parse(vsrc).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "bilinear_interpolate_torch":     # :11-44
+            exec(compile(textwrap.dedent(ast.get_source_segment(vsrc, node)), "voxel_set_abstraction." + node.name, "exec"), cns)
+    common_utils = types.SimpleNamespace(**{k: v for k, v in cns.items() if callable(v)})
+    hsrc = open(os.path.join(REF, "pcdet/models/roi_heads/pvrcnn_head.py")).read()
+    hns = {"torch": torch, "common_utils": common_utils}
+    for node in ast.parse(hsrc).body:
+        if isinstance(node, ast.ClassDef) and node.name == "PVRCNNHead":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name in ("get_global_grid_points_of_roi", "get_dense_grid_points"):
+                    seg = ast.get_source_segment(hsrc, fn)
+                    exec(compile(textwrap.dedent(seg), "pvrcnn_head." + fn.name, "exec"), hns)
+    holder = types.SimpleNamespace()
+    holder.get_dense_grid_points = hns["get_dense_grid_points"]
+    rng = np.random.default_rng(17)
+    rois = np.zeros((2, 9, 7), np.float32)
+    rois[..., 0:2] = rng.uniform(-60, 60, (2, 9, 2))
+    rois[..., 2] = rng.uniform(-1, 2, (2, 9))
+    rois[..., 3:6] = rng.uniform(0.5, 10, (2, 9, 3))
+    rois[..., 6] = rng.uniform(-np.pi, np.pi, (2, 9))
+    glob, local = hns["get_global_grid_points_of_roi"](holder, torch.from_numpy(rois), 6)
+    coords = torch.from_numpy(rng.integers(0, 40, (50, 3)).astype(np.int32))
+    centers = cns["get_voxel_centers"](coords, 4, list(synth.WAYMO_VOXEL), list(synth.WAYMO_RANGE))
+    im = torch.from_numpy(rng.standard_normal((23, 31, 5)).astype(np.float32))
+    bx = torch.from_numpy(rng.uniform(-2, 33, 64).astype(np.float32))
+    by = torch.from_numpy(rng.uniform(-2, 25, 64).astype(np.float32))
+    inter = cns["bilinear_interpolate_torch"](im, bx, by)
+    pts = torch.from_numpy(rng.standard_normal((4, 11, 5)).astype(np.float32))
+    ang = torch.from_numpy(rng.uniform(-np.pi, np.pi, 4).astype(np.float32))
+    rot = cns["rotate_points_along_z"](pts, ang)
+    save("g17_stage2_geometry", rois=rois, grid_global=glob.numpy(), grid_local=local.numpy(), coords=coords.numpy(),
+         centers=centers.numpy(), im=im.numpy(), bx=bx.numpy(), by=by.numpy(), interp=inter.numpy(), pts=pts.numpy(),
+         ang=ang.numpy(), rot=rot.numpy())
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])           # e.g. `make_golden.py g6`: regenerate just that fixture, keep the rest
     mpath = os.path.join(HERE, "MANIFEST.json")
     if only and os.path.exists(mpath):
         with open(mpath) as f:
             manifest.update(json.load(f))
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()
     with open(mpath, "w") as f:
