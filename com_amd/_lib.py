@@ -74,6 +74,8 @@ PROTOTYPES = {
     "pcd_conv2d_wgrad_3x3_nhwc": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pcd_conv2d_3x3_tiles": (_i, [_i, _i, _i]),
     "pcd_conv2d_3x3_nhwc_bn": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "pcd_conv2d_wgrad_planes_splits": (_i, [_i, _i, _i, _i, _i, _i]),
+    "pcd_conv2d_wgrad_planes_nhwc": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pcd_conv2d_planes_nhwc": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),

@@ -690,6 +690,169 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const unsigned sho
         }
 }
 
+
+// Weight gradients of the plane operators (pcd_conv2d_planes_nhwc): the same tile / transposing-read machinery as
+// conv2d_wgrad_kernel with the A operand taken from the FINE map plane by plane (stride-2 pixel addressing, the plane's
+// 1 / 2 / 4 taps as LDS row offsets) and the B operand from the coarse map, staged once per tile:
+//   C3S2  A = x (fine), B = dy (coarse)               -> slabs [cout][9][cin]
+//   K2S2  A = dy (fine), B = x (coarse)                -> slabs [cin][4][cout]   (the ConvTranspose2d parameter's layout)
+//   K1    A = dy, B = x, one plane, one tap            -> slabs [cin][1][cout]
+template <int KIND, int NBW>
+__global__ __launch_bounds__(256, KIND == K_C3S2 ? 1 : 2) void conv2d_wgrad_planes_kernel(
+    const unsigned short *__restrict__ xa, int Ha, int Wa, int ca, const unsigned short *__restrict__ xb, int B, int Hc,
+    int Wc, int cb, int n_splits, int n_chunks, int n_cb_chunks, float *__restrict__ slab, unsigned a_bytes,
+    unsigned b_bytes) {
+    constexpr int NP = pl_count<KIND>(), ST = pl_step<KIND>(), NT = taps_total<KIND>(), KW = kernel_w<KIND>();
+    constexpr int HL = KIND == K_C3S2 ? 1 : 0;                                   // halo (low and high side)
+    constexpr int AH = WG_TH + 2 * HL, AW = WG_TW + 2 * HL;
+    constexpr int CO = NBW * 16, YS = WgYs<CO>::value;
+    constexpr int XP = AH * AW * 8, YP = WG_TH * WG_TW * (CO / 8);
+    constexpr int XI = (XP + 255) / 256, YI = (YP + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short *xs = (unsigned short *)smem;                               // [AH * AW][XS]   one plane of the A tile
+    unsigned short *ys = xs + AH * AW * WG_XS;                                  // [TH * TW][YS]   the B tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, t = lane & 15;
+    const int trow = 4 * g + (t >> 2);
+    const int items = n_splits * n_chunks;
+    const int per_xcd = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    const int split = item / n_chunks, chunk = item - split * n_chunks;
+    const int ca0 = (chunk / n_cb_chunks) * 64, cb0 = (chunk % n_cb_chunks) * CO;
+    const int tiles_x = (Wc + WG_TW - 1) / WG_TW, tiles_y = (Hc + WG_TH - 1) / WG_TH;
+    const int n_tiles = B * tiles_y * tiles_x;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)xa, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)b_bytes, 0x00020000);
+
+    f32x4 acc[NT][NBW];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[k][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 xr[XI], yr[YI];
+    auto load_a = [&](int tile, int plane) {
+        int q = tile;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+        const int py = plane >> 1, px = plane & 1;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p >> 3, piece = p & 7;
+            const int hy = pix / AW, hx = pix - hy * AW;
+            const int gy = (ty * WG_TH + hy - HL) * ST + py, gx = (tx * WG_TW + hx - HL) * ST + px;
+            const bool ok = p < XP && tile < n_tiles && gy >= 0 && gy < Ha && gx >= 0 && gx < Wa;
+            const unsigned off = ok ? (unsigned)((((size_t)b * Ha + gy) * Wa + gx) * ca * 2 + (ca0 + piece * 8) * 2)
+                                    : 0xFFFFFFF0u;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(ars, off, 0, 0);
+        }
+    };
+    auto load_b = [&](int tile) {
+        int q = tile;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+#pragma unroll
+        for (int it = 0; it < YI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p / (CO / 8), piece = p - pix * (CO / 8);
+            const int qy = pix / WG_TW, qx = pix - qy * WG_TW;
+            const int gy = ty * WG_TH + qy, gx = tx * WG_TW + qx;
+            const bool ok = p < YP && tile < n_tiles && gy < Hc && gx < Wc;
+            const unsigned off = ok ? (unsigned)((((size_t)b * Hc + gy) * Wc + gx) * cb * 2 + (cb0 + piece * 8) * 2)
+                                    : 0xFFFFFFF0u;
+            yr[it] = __builtin_amdgcn_raw_buffer_load_b128(brs, off, 0, 0);
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            if (p < XP) *reinterpret_cast<u32x4 *>(xs + (p >> 3) * WG_XS + (p & 7) * 8) = xr[it];
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int it = 0; it < YI; ++it) {
+            const int p = it * 256 + threadIdx.x;
+            const int pix = p / (CO / 8), piece = p - pix * (CO / 8);
+            if (p < YP) *reinterpret_cast<u32x4 *>(ys + pix * YS + piece * 8) = yr[it];
+        }
+    };
+    typedef s16x4_ __attribute__((address_space(3))) * lds_tr_ptr;
+    auto frag = [&](const unsigned short *a0, int hi_off) -> bf16x8 {
+        s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a0));
+        s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a0 + hi_off));
+        s16x8_ cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, cat);
+    };
+    auto mma_plane = [&](auto plane_c) {
+        constexpr int P = decltype(plane_c)::value;
+        constexpr int py = P >> 1, px = P & 1, ny = ax_n<KIND>(py), nx = ax_n<KIND>(px), base = pl_base<KIND>(P);
+#pragma unroll 1
+        for (int s = 0; s < WG_TH; ++s) {
+            bf16x8 bfr[NBW];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                bfr[nb] = frag(ys + (s * WG_TW + trow) * YS + nb * 16 + (t & 3) * 4, 16 * YS);
+#pragma unroll
+            for (int ty_ = 0; ty_ < ny; ++ty_)
+#pragma unroll
+                for (int tx_ = 0; tx_ < nx; ++tx_) {
+                    const int dy = ax_d<KIND, true>(py, ty_), dx = ax_d<KIND, true>(px, tx_);
+                    const bf16x8 af = frag(xs + ((s + HL + dy) * AW + trow + HL + dx) * WG_XS + wave * 16 + (t & 3) * 4,
+                                           16 * WG_XS);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb)
+                        acc[base + ty_ * nx + tx_][nb] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[nb], acc[base + ty_ * nx + tx_][nb], 0, 0, 0);
+                }
+        }
+    };
+
+    int tile = split;
+    load_a(tile, 0);
+    load_b(tile);
+    for (; tile < n_tiles; tile += n_splits) {
+#pragma unroll 1
+        for (int plane = 0; plane < NP; ++plane) {
+            store_a();
+            if (plane == 0) store_b();
+            __syncthreads();
+            if (plane + 1 < NP) {
+                load_a(tile, plane + 1);
+            } else {
+                load_a(tile + n_splits, 0);                  // (beyond the last tile: all offsets out of range)
+                load_b(tile + n_splits);
+            }
+            if (NP == 1 || plane == 0) mma_plane(std::integral_constant<int, 0>{});
+            else if (plane == 1) mma_plane(std::integral_constant<int, 1>{});
+            else if (plane == 2) mma_plane(std::integral_constant<int, 2>{});
+            else mma_plane(std::integral_constant<int, 3>{});
+            __syncthreads();
+        }
+    }
+    // slab [cb][KH * KW][ca]: lane (g, t) of block nb holds rows cb0 + nb * 16 + t, columns ca0 + 16 wave + 4 g .. + 3
+    float *sl = slab + (size_t)split * cb * (KW * KW) * ca;
+#pragma unroll
+    for (int P = 0; P < NP; ++P) {
+        const int py = P >> 1, px = P & 1, nx = ax_n<KIND>(px);
+#pragma unroll
+        for (int tt = 0; tt < pl_taps<KIND>(P); ++tt) {
+            const int kop = ax_k<KIND>(py, tt / nx) * KW + ax_k<KIND>(px, tt % nx);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int rb = cb0 + nb * 16 + t, cacol = ca0 + wave * 16 + 4 * g;
+                const f32x4 v = acc[pl_base<KIND>(P) + tt][nb];
+                *reinterpret_cast<float4 *>(sl + ((size_t)rb * (KW * KW) + kop) * ca + cacol) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -903,6 +1066,64 @@ extern "C" int pcd_conv2d_wgrad_3x3_nhwc(const void *x, int x_cs, const void *dy
                                                      height, width, cin, cout, splits, chunks, n_co, (float *)slabs,
                                                      (unsigned)xb, (unsigned)yb);
     }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+
+// Weight gradient of the plane operators (forward pack modes 2 / 4 / 6 of pcd_conv2d_planes_nhwc).  `fine` / `coarse`: the
+// two maps of the layer ([b][hf][wf][cf] and [b][hc][wc][cc] bf16, contiguous) -- mode 2: x / dy; modes 4, 6: dy / x.
+// Slabs [cc][k * k][cf] f32 (finish with pcd_sparse_conv_wgrad_reduce_batched: kvol = k * k, cin = cf, cout = cc, layout 1
+// gives the torch parameter's layout for all three: Conv2d [cout][cin][3][3], ConvTranspose2d [cin][cout][k][k]).
+extern "C" int pcd_conv2d_wgrad_planes_splits(int mode, int batch, int hc, int wc, int cf, int cc) {
+    if ((mode != 2 && mode != 4 && mode != 6) || batch <= 0 || hc <= 0 || wc <= 0 || cf <= 0 || cc <= 0 || cf % 64 || cc % 32)
+        return 0;
+    // mode 2 (stride-2 conv: 9 accumulator sets + 4 plane stagings per tile, one workgroup per CU) measures SLOWER than the
+    // pair kernels over dense pair lists (99-152 vs 80 us, tools/exp_wgrad_planes.py): not offered unless asked for
+    static const int mode2 = getenv("PCD_CONV2D_WGP_MODE2") ? atoi(getenv("PCD_CONV2D_WGP_MODE2")) : 0;
+    if (mode == 2 && !mode2) return 0;
+    const int tiles = batch * ((hc + WG_TH - 1) / WG_TH) * ((wc + WG_TW - 1) / WG_TW);
+    const int chunks = (cf / 64) * (cc % 64 == 0 ? cc / 64 : cc / 32);
+    static const int target = getenv("PCD_CONV2D_WGP_BLOCKS") ? atoi(getenv("PCD_CONV2D_WGP_BLOCKS")) : 512;
+    int splits = (target + chunks - 1) / chunks;
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    const int per = (tiles + splits - 1) / splits;
+    return (tiles + per - 1) / per;
+}
+
+template <int KIND, int NBW>
+static void launch_wgrad_planes(const void *fine, int hf, int wf, int cf, const void *coarse, int batch, int hc, int wc, int cc,
+                                int splits, void *slabs, hipStream_t st) {
+    constexpr int HL = KIND == K_C3S2 ? 1 : 0;
+    const int n_cc = cc / (NBW * 16), chunks = (cf / 64) * n_cc;
+    const int grid = (splits * chunks + 7) / 8 * 8;
+    const size_t lds = (size_t)((WG_TH + 2 * HL) * (WG_TW + 2 * HL) * WG_XS + WG_TH * WG_TW * WgYs<NBW * 16>::value) * 2;
+    conv2d_wgrad_planes_kernel<KIND, NBW><<<grid, 256, lds, st>>>(
+        (const unsigned short *)fine, hf, wf, cf, (const unsigned short *)coarse, batch, hc, wc, cc, splits, chunks, n_cc,
+        (float *)slabs, (unsigned)((size_t)batch * hf * wf * cf * 2), (unsigned)((size_t)batch * hc * wc * cc * 2));
+}
+
+extern "C" int pcd_conv2d_wgrad_planes_nhwc(int mode, const void *fine, int hf, int wf, int cf, const void *coarse, int batch,
+                                            int hc, int wc, int cc, void *slabs, size_t slab_bytes, void *stream) {
+    PCD_ENTER();
+    const int splits = pcd_conv2d_wgrad_planes_splits(mode, batch, hc, wc, cf, cc);
+    if (splits <= 0) return PCD_ERR_UNSUPPORTED;
+    if (!fine || !coarse || !slabs) return PCD_ERR_INVALID_ARG;
+    const int kk = mode == 2 ? 9 : (mode == 4 ? 4 : 1);
+    if (mode == 2 ? (hc != (hf - 1) / 2 + 1 || wc != (wf - 1) / 2 + 1)
+                  : (mode == 4 ? (hf != 2 * hc || wf != 2 * wc) : (hf != hc || wf != wc)))
+        return PCD_ERR_INVALID_ARG;
+    if (slab_bytes < (size_t)splits * cc * kk * cf * sizeof(float)) return PCD_ERR_WORKSPACE;
+    if ((double)batch * hf * wf * cf * 2 >= 4294966000.0 || (double)batch * hc * wc * cc * 2 >= 4294966000.0)
+        return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = cc % 64 == 0;
+#define PCD_WGP(K)                                                                                                      \
+    if (wide) launch_wgrad_planes<K, 4>(fine, hf, wf, cf, coarse, batch, hc, wc, cc, splits, slabs, st);                \
+    else launch_wgrad_planes<K, 2>(fine, hf, wf, cf, coarse, batch, hc, wc, cc, splits, slabs, st);
+    if (mode == 2) { PCD_WGP(K_C3S2) } else if (mode == 4) { PCD_WGP(K_K2S2) } else { PCD_WGP(K_K1) }
+#undef PCD_WGP
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -320,6 +320,12 @@ class _ConvPlanesFunction(torch.autograd.Function):
             return ops.conv2d_planes_nhwc(mode_f + 1, dyn, pd, cin, (H, W)).permute(0, 3, 1, 2)
 
         def wgrad(direct):
+            fine, coarse = (xn, dyn) if mode_f == 2 else (dyn, xn)
+            if ops.conv2d_wgrad_planes_splits(mode_f, B, coarse.shape[1], coarse.shape[2], fine.shape[3], coarse.shape[3]) > 0:
+                if direct:                                        # the dense kernel (no pair lists)
+                    ops.conv2d_wgrad_planes(mode_f, fine, coarse, out=wp.grad, defer=Fsp._WGRAD_JOBS)
+                    return None
+                return ops.conv2d_wgrad_planes(mode_f, fine, coarse).to(weight.dtype)
             pairs, num = _plane_pairs(mode_f, B, H, W, xn.device)
             if mode_f == 2:       # gathered rows = x (contraction c = cin), accumulated rows = dy (o = cout)
                 a, ca, b_, cb = xn.reshape(-1, cin), cin, dyn.reshape(-1, cout), cout

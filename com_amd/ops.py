@@ -1059,6 +1059,43 @@ def conv2d_wgrad(x, dy, cout=None, out=None, defer=None):
     return dw
 
 
+# Dense weight-gradient kernels for the plane operators (stride-2 conv, deconvs): built, bit-checked against the pair
+# kernels -- and NOT faster in the step (tools/exp_wgp_blocks.sh: 7.81-7.85 vs 7.79 ms with the pair kernels; isolated the
+# k = stride deconvs gain, 31 / 60 vs 76 us at 512 workgroups, the stride-2 conv loses, 99 vs 80 us): off unless asked for.
+CONV2D_WGRAD_PLANES = _os.environ.get("PCD_CONV2D_WGP", "0") == "1"
+
+
+def conv2d_wgrad_planes_splits(mode_f, B, hc, wc, cf, cc):
+    return L.lib().pcd_conv2d_wgrad_planes_splits(mode_f, B, hc, wc, cf, cc) if (CONV2D_WGRAD and CONV2D_WGRAD_PLANES) else 0
+
+
+def conv2d_wgrad_planes(mode_f, fine, coarse, out=None, defer=None):
+    """dW of the plane operators in the torch parameter's layout (f32): mode 2 (Conv2d 3 / stride 2): fine = x, coarse = dy
+    -> [cout, cin, 3, 3]; modes 4 / 6 (ConvTranspose2d k = stride = 2 / 1): fine = dy, coarse = x -> [cin, cout, k, k].
+    Both maps [B, h, w, c] bf16 contiguous.  Caller checks conv2d_wgrad_planes_splits(...) > 0 first."""
+    _require_cuda(fine, coarse)
+    assert fine.dtype == torch.bfloat16 and coarse.dtype == torch.bfloat16 and fine.is_contiguous() and coarse.is_contiguous()
+    B, hf, wf, cf = fine.shape
+    _, hc, wc, cc = coarse.shape
+    k = {2: 3, 4: 2, 6: 1}[mode_f]
+    lib = L.lib()
+    splits = lib.pcd_conv2d_wgrad_planes_splits(mode_f, B, hc, wc, cf, cc)
+    assert splits > 0
+    slab = torch.empty((splits * cc * k * k * cf,), dtype=torch.float32, device=fine.device)
+    dw = out if _usable_out(out, cc * k * k * cf) else torch.empty((cc, cf, k, k), dtype=torch.float32, device=fine.device)
+    with _Timed(f"conv2d_wgrad_planes_kernel<{mode_f}> {cf}x{cc} {hc}x{wc}",
+                lambda: dict(bytes=(fine.numel() + coarse.numel()) * 2 + slab.numel() * 4,
+                             flops=2 * k * k * B * hc * wc * cf * cc, rows=B * hc * wc, pairs=0)):
+        L.check(lib.pcd_conv2d_wgrad_planes_nhwc(mode_f, L.ptr(fine), hf, wf, cf, L.ptr(coarse), B, hc, wc, cc, L.ptr(slab),
+                                                 slab.numel() * 4, L.stream_ptr()), "pcd_conv2d_wgrad_planes_nhwc")
+    job = (slab, dw, k * k, cf, cc, 1, splits, 1, 0)
+    if defer is not None:
+        defer.append(job)
+    else:
+        wgrad_reduce_batched([job])
+    return dw
+
+
 def conv2d_planes_nhwc(mode, x, packed_w, cout, out_hw, bias=None):
     """The stride-2 conv / transposed convs of BaseBEVBackbone on channels-last bf16 maps (pack modes 2..7 of
     pcd_conv2d_planes_nhwc): x [B, hi, wi, cin] -> [B, ho, wo, cout]; `cout` = channels of the result."""

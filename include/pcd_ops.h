@@ -770,6 +770,12 @@ int pcd_conv2d_3x3_nhwc_bn(const void *x, int x_cs, int batch, int height, int w
 int pcd_conv2d_wgrad_3x3_splits(int batch, int height, int width, int cin, int cout);
 int pcd_conv2d_wgrad_3x3_nhwc(const void *x, int x_cs, const void *dy, int batch, int height, int width, int cin, int cout,
                               void *slabs, size_t slab_bytes, void *stream);
+/* ... and of the plane operators below (forward pack modes 2 / 4 / 6): `fine` / `coarse` = the layer's two maps (mode 2: x / dy;
+ * modes 4, 6: dy / x), contiguous bf16; slabs [cc][k * k][cf] f32 -> pcd_sparse_conv_wgrad_reduce_batched (kvol = k * k,
+ * cin = cf, cout = cc, layout 1 = the torch parameter's layout for Conv2d AND ConvTranspose2d).  cf % 64 == 0, cc % 32 == 0. */
+int pcd_conv2d_wgrad_planes_splits(int mode, int batch, int hc, int wc, int cf, int cc);
+int pcd_conv2d_wgrad_planes_nhwc(int mode, const void *fine, int hf, int wf, int cf, const void *coarse, int batch, int hc,
+                                 int wc, int cc, void *slabs, size_t slab_bytes, void *stream);
 /* The other three layers of BaseBEVBackbone (base_bev_backbone.py:36-75; MIOpen in the reference), forward and data
  * gradient, as per-parity-plane stencils on the same tiles.  pack modes (pcd_conv2d_pack_weight / _packed_weight_bytes /
  * the batched table take them too; cin / cout are the LAYER's channel counts, the weight is the torch parameter):

@@ -182,3 +182,29 @@ def test_dense_wgrad_kernel_equals_the_pair_kernels_and_torch(cin, cout, hw, blo
     assert float((got - old).abs().max()) <= 1e-4 * float(old.abs().max())
     again = ops.conv2d_wgrad(x, dy, cout)
     assert torch.equal(got, again)                                         # fixed summation order
+
+
+@pytest.mark.parametrize("mode,cin,cout,hw", [(4, 256, 256, (24, 26)), (6, 128, 256, (40, 33)), (4, 64, 128, (9, 31)), (6, 64, 64, (5, 70))])
+def test_plane_weight_gradient_kernels_equal_the_pair_kernels(mode, cin, cout, hw):
+    """conv2d_wgrad_planes_kernel (off by default: not faster in the step) against the pair kernels over dense pair lists
+    it would replace, in the ConvTranspose2d parameter's layout; deterministic."""
+    from com_amd import ops
+    from com_amd.hotpath.conv2d_fast import _plane_pairs
+    torch.manual_seed(mode * 100 + cin)
+    B, (H, W) = 2, hw
+    k = 2 if mode == 4 else 1
+    x = torch.randn(B, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, k * H, k * W, cout, device=DEV).bfloat16()
+    old = ops.CONV2D_WGRAD_PLANES
+    ops.CONV2D_WGRAD_PLANES = True
+    try:
+        assert ops.conv2d_wgrad_planes_splits(mode, B, H, W, cout, cin) > 0
+        got = ops.conv2d_wgrad_planes(mode, dy, x)
+        again = ops.conv2d_wgrad_planes(mode, dy, x)
+    finally:
+        ops.CONV2D_WGRAD_PLANES = old
+    assert got.shape == (cin, cout, k, k) and torch.equal(got, again)
+    pairs, num = _plane_pairs(mode, B, H, W, x.device)
+    ref = ops.wgrad(dy.reshape(-1, cout), cout, x.reshape(-1, cin), pairs, num, k * k)            # [cin, K, cout]
+    ref = ref.permute(0, 2, 1).reshape(cin, cout, k, k)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
