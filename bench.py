@@ -388,47 +388,101 @@ class ResidentSource:
 class H2DSource:
     """a3 inside the step (dataset.py:252-259 + load_data_to_gpu, pcdet/models/__init__.py:23-34): the collated
     points of every batch start in PINNED HOST memory and are copied host -> device on a copy stream, two batches
-    ahead, overlapped with the compute of the steps in between; the consumer waits on the batch's event only."""
+    ahead, overlapped with the compute of the steps in between; the consumer waits on the batch's event only.
+    This loop is BIMODAL on the gpurun boxes: the same command gives 3.45 or 4.0-4.8 ms per step (PCD_BENCH_DEBUG=1 prints
+    where the launching thread's time goes: replaying the step's hipGraph costs it 1.5 ms, the rest of the slow mode is spent
+    in `get()` waiting for the slot's copy, although a 15.4 MB copy takes 0.29 ms on the GPU clock beside the step).
+    Neither binding the process to either socket's cores, nor a helper thread that enqueues the copies (PCD_H2D_THREAD=1),
+    nor more slots (PCD_H2D_DEPTH) removes the slow mode; the HBM-resident `value` never shows it."""
 
     def __init__(self, batches, dev):
+        import queue
+        import threading
         self.host = [(p.cpu().pin_memory(), o.cpu().pin_memory()) for p, o in batches]
-        self.stage = [(torch.empty_like(batches[0][0]), torch.empty_like(batches[0][1])) for _ in range(2)]
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.depth = D = max(2, int(os.environ.get('PCD_H2D_DEPTH', '2')))   # batches in flight ahead of the consumer
+        self.stage = [(torch.empty_like(batches[0][0]), torch.empty_like(batches[0][1])) for _ in range(D)]
+        self.ready = [torch.cuda.Event() for _ in range(D)]
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream())
+        self.dev = dev
         self.issued = self.taken = 0
-        for _ in range(2):
-            self._issue()
+        self.copy_events = []
+        self.threaded = bool(os.environ.get('PCD_H2D_THREAD'))
+        self.jobs, self.done = queue.Queue(), [threading.Event() for _ in range(D)]
+        self.error = None
+        if self.threaded:
+            self.worker = threading.Thread(target=self._work, daemon=True)
+            self.worker.start()
+        for _ in range(D):
+            self._issue(None)
 
-    def _issue(self):
-        k = self.issued
-        self.issued += 1
+    def _copy(self, k, after):
         hp, ho = self.host[k % len(self.host)]
         with torch.cuda.stream(self.stream):
-            self.stage[k % 2][0].copy_(hp, non_blocking=True)       # 15.4 MB host -> device
-            self.stage[k % 2][1].copy_(ho, non_blocking=True)
-            self.ready[k % 2].record(self.stream)
+            if after is not None:
+                self.stream.wait_event(after)                # the consumer's reads of this slot's previous batch
+            timed = os.environ.get('PCD_BENCH_DEBUG') and k >= 8 and len(self.copy_events) < 24
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+            self.stage[k % self.depth][0].copy_(hp, non_blocking=True)       # 15.4 MB host -> device
+            self.stage[k % self.depth][1].copy_(ho, non_blocking=True)
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(self.stream)
+                self.copy_events.append((e0, e1))
+            self.ready[k % self.depth].record(self.stream)
+
+    def _work(self):
+        torch.cuda.set_device(self.dev)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            k, after = job
+            try:
+                self._copy(k, after)
+            except Exception as exc:                        # surfaced by the next get()
+                self.error = exc
+            self.done[k % self.depth].set()
+
+    def _issue(self, after):
+        k = self.issued
+        self.issued += 1
+        if self.threaded:
+            self.done[k % self.depth].clear()
+            self.jobs.put((k, after))
+        else:
+            self._copy(k, after)
 
     def get(self, j):
         """Next batch in sequence (batches alternate; `j` is the consumer's step counter, informational)."""
         k = self.taken
         self.taken += 1
-        assert self.issued == k + 2, "one release() per get()"
+        assert self.issued == k + self.depth, "one release() per get()"
+        if self.threaded:
+            self.done[k % self.depth].wait()                          # the helper thread has enqueued this slot's copies
+            if self.error is not None:
+                raise self.error
         if os.environ.get('PCD_H2D_STREAM_WAIT'):
-            torch.cuda.current_stream().wait_event(self.ready[k % 2])
+            torch.cuda.current_stream().wait_event(self.ready[k % self.depth])
         else:
             # the copy was issued two steps ago: the HOST waits for it (it has long finished; this only keeps the
             # host from running more than two steps ahead) instead of putting a cross-queue barrier in front of
             # every step on the compute stream
-            self.ready[k % 2].synchronize()
-        return self.stage[k % 2]
+            self.ready[k % self.depth].synchronize()
+        return self.stage[k % self.depth]
 
     def release(self, j):
         """The consumer's reads of the batch just taken have been issued on the current stream: refill its slot."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self.stream.wait_event(ev)
-        self._issue()
+        self._issue(ev)
+
+    def close(self):
+        if self.threaded:
+            self.jobs.put(None)
+            self.worker.join(timeout=10)
 
 
 def measure_stage2(B, dev):
@@ -845,7 +899,21 @@ def main():
                 plan.arm()                                   # sticky overflow check of every replay, inside the graph
                 ops.stamp("step_end")
 
+            HT = state.setdefault("host_times", [0.0] * 5) if os.environ.get('PCD_BENCH_DEBUG') else None
+
             def run_step(i, source=resident):
+                if HT is not None:                           # where the launching thread's time goes (debug only)
+                    t = [time.perf_counter()]
+                    pts, offs = source.get(i + 1); t.append(time.perf_counter())
+                    schedule()
+                    s_pts.copy_(pts, non_blocking=True)
+                    s_offs.copy_(offs, non_blocking=True); t.append(time.perf_counter())
+                    source.release(i + 1); t.append(time.perf_counter())
+                    g_all.replay(); t.append(time.perf_counter())
+                    for q in range(4):
+                        HT[q] += t[q + 1] - t[q]
+                    HT[4] += 1
+                    return
                 pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
                 schedule()
                 s_pts.copy_(pts, non_blocking=True)          # device -> device
@@ -984,13 +1052,26 @@ def main():
     if not args.no_h2d:
         try:
             src = H2DSource(batches, dev)
-            el, _ = timed_loop(run_step, args.steps, src, use_graph)
+            el, h2d_host = timed_loop(run_step, args.steps, src, use_graph)
+            if os.environ.get('PCD_BENCH_DEBUG') and state.get("host_times"):
+                ht = state["host_times"]
+                print("[bench] launching thread, ms per step (all loops so far): get %.3f  d2d copies %.3f  release %.3f  "
+                      "graph replay %.3f" % tuple(1e3 * v / max(ht[4], 1) for v in ht[:4]), file=sys.stderr)
+            if os.environ.get('PCD_BENCH_DEBUG') and src.copy_events:
+                torch.cuda.synchronize()
+                cms = sorted(a.elapsed_time(b) for a, b in src.copy_events)
+                print(f"[bench] h2d copies on the GPU clock (15.4 MB each, beside the step): median {cms[len(cms) // 2]:.3f} ms, "
+                      f"max {cms[-1]:.3f} ms", file=sys.stderr)
+            if os.environ.get('PCD_BENCH_DEBUG'):
+                print(f"[bench] h2d loop: host issue {1e3 * h2d_host / max(args.steps, 1):.3f} ms/step, "
+                      f"wall {1e3 * el / max(args.steps, 1):.3f} ms/step", file=sys.stderr)
+            src.close()
             el = cdist.max_over_ranks(el, dev)
             h2d = {"value": round(world * B * args.steps / el, 3), "unit": "frames/s",
                    "ms_per_step": round(1e3 * el / max(args.steps, 1), 4),
                    "what": "same timed loop, points of every batch copied from PINNED HOST memory on a copy stream two "
-                           "batches ahead (15.4 MB / step / GPU), overlapped with compute; `value` above is the "
-                           "HBM-resident figure the contract asks for"}
+                           "batches ahead (15.4 MB / step / GPU), overlapped with compute; "
+                           "`value` above is the HBM-resident figure the contract asks for"}
             if use_graph:
                 plan.check()
         except Exception as exc:
