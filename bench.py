@@ -393,7 +393,10 @@ class H2DSource:
     where the launching thread's time goes: replaying the step's hipGraph costs it 1.5 ms, the rest of the slow mode is spent
     in `get()` waiting for the slot's copy, although a 15.4 MB copy takes 0.29 ms on the GPU clock beside the step).
     Neither binding the process to either socket's cores, nor a helper thread that enqueues the copies (PCD_H2D_THREAD=1),
-    nor more slots (PCD_H2D_DEPTH) removes the slow mode; the HBM-resident `value` never shows it."""
+    nor more slots (PCD_H2D_DEPTH) removes the slow mode; the HBM-resident `value` never shows it.  In BOTH modes the launching
+    thread spends its time waiting in `get()` (2.6 vs 3.8 ms per step) and 0.5 ms replaying the graph: the loop is GPU-bound,
+    the replayed step itself runs longer in the slow mode; a HIGH-priority copy stream (PCD_H2D_PRIO=-1) makes every run
+    slow (6.6-7.7 ms) -- how the copy queue is arbitrated against the graph's queues decides, not the 0.29 ms copy."""
 
     def __init__(self, batches, dev):
         import queue
@@ -402,7 +405,7 @@ class H2DSource:
         self.depth = D = max(2, int(os.environ.get('PCD_H2D_DEPTH', '2')))   # batches in flight ahead of the consumer
         self.stage = [(torch.empty_like(batches[0][0]), torch.empty_like(batches[0][1])) for _ in range(D)]
         self.ready = [torch.cuda.Event() for _ in range(D)]
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('PCD_H2D_PRIO', '0')))
         self.stream.wait_stream(torch.cuda.current_stream())
         self.dev = dev
         self.issued = self.taken = 0
@@ -1052,10 +1055,12 @@ def main():
     if not args.no_h2d:
         try:
             src = H2DSource(batches, dev)
+            if state.get("host_times"):
+                state["host_times"][:] = [0.0] * 5               # (debug split: this loop only)
             el, h2d_host = timed_loop(run_step, args.steps, src, use_graph)
             if os.environ.get('PCD_BENCH_DEBUG') and state.get("host_times"):
                 ht = state["host_times"]
-                print("[bench] launching thread, ms per step (all loops so far): get %.3f  d2d copies %.3f  release %.3f  "
+                print("[bench] launching thread in the h2d loop, ms per step: get %.3f  d2d copies %.3f  release %.3f  "
                       "graph replay %.3f" % tuple(1e3 * v / max(ht[4], 1) for v in ht[:4]), file=sys.stderr)
             if os.environ.get('PCD_BENCH_DEBUG') and src.copy_events:
                 torch.cuda.synchronize()
