@@ -65,6 +65,8 @@ PROTOTYPES = {
     "pcd_rulebook_conv_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp,
                                      _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_debug_stamp": (_i, [_vp, _vp]),
+    "pcd_pull_from_host": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp]),
+    "pcd_counter_add": (_i, [_vp, _i, _vp]),
     "pcd_conv2d_packed_weight_bytes": (_sz, [_i, _i, _i]),
     "pcd_conv2d_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pcd_conv2d_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),

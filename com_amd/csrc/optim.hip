@@ -260,3 +260,48 @@ extern "C" int pcd_debug_stamp(uint64_t *slot, void *stream) {
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// (a3) Host -> device inside the captured step without a copy engine, a second stream or the host: the collated points
+// of every batch sit in PINNED host memory (device-visible under HIP's unified addressing); a kernel of the step's own
+// graph reads slot (*counter % n_slots) of a device-side table of those host pointers over PCIe and writes the staging
+// buffer the step's voxeliser reads.  A replayed graph cannot change its arguments, the table + counter can: every replay
+// pulls the next batch.  (The copy-stream form of the same thing was bimodal on the gpurun boxes, 3.5 vs 4.2-4.8 ms per
+// step: how the copy queue is arbitrated against the queues the hipGraph executor uses; bench.py H2DSource.)
+namespace {
+__global__ __launch_bounds__(256) void pull_host_kernel(const unsigned long long *__restrict__ table, int n_slots,
+                                                        const int32_t *__restrict__ counter, uint4 *__restrict__ dst,
+                                                        size_t n16) {
+    const int slot = (int)((unsigned)(*counter) % (unsigned)n_slots);
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(table[slot]);
+    const size_t S = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * S < n16; i += 4 * S) {                 // 4 x 16 bytes in flight per thread: PCIe reads are latency-bound
+        const uint4 a = src[i], b = src[i + S], c = src[i + 2 * S], d = src[i + 3 * S];
+        dst[i] = a; dst[i + S] = b; dst[i + 2 * S] = c; dst[i + 3 * S] = d;
+    }
+    for (; i < n16; i += S) dst[i] = src[i];
+}
+__global__ void counter_add_kernel(int32_t *counter, int delta) { *counter += delta; }
+}  // namespace
+
+extern "C" int pcd_pull_from_host(const void *host_ptr_table_dev, int n_slots, const int32_t *counter_dev, void *dst,
+                                  size_t bytes, int workgroups, void *stream) {
+    PCD_ENTER();
+    if (!host_ptr_table_dev || n_slots <= 0 || !counter_dev || !dst || (bytes & 15) || ((uintptr_t)dst & 15))
+        return PCD_ERR_INVALID_ARG;
+    if (bytes == 0) return PCD_OK;
+    if (workgroups <= 0) workgroups = 64;
+    pull_host_kernel<<<workgroups, 256, 0, (hipStream_t)stream>>>((const unsigned long long *)host_ptr_table_dev, n_slots,
+                                                                 counter_dev, (uint4 *)dst, bytes / 16);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_counter_add(int32_t *counter_dev, int delta, void *stream) {
+    PCD_ENTER();
+    if (!counter_dev) return PCD_ERR_INVALID_ARG;
+    counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter_dev, delta);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

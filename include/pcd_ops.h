@@ -788,6 +788,15 @@ int pcd_conv2d_wgrad_planes_nhwc(int mode, const void *fine, int hf, int wf, int
 int pcd_conv2d_planes_nhwc(int pack_mode, const void *x, int batch, int hi, int wi, int cin, const void *packed_w,
                            int cout, const float *bias, void *y, int ho, int wo, void *stream);
 
+/* (a3, dataset.py:252-259 + pcdet/models/__init__.py:23-34: collate + .cuda()) the host -> device hop INSIDE a captured step:
+ * `host_ptr_table_dev` = n_slots device-side entries holding the addresses of PINNED host buffers (each >= bytes); the kernel
+ * copies buffer (*counter_dev % n_slots) into dst over PCIe.  No copy engine, no second stream, no host call per step: a
+ * replayed hipGraph pulls a different batch every time because the counter (pcd_counter_add, also a graph node) moves.
+ * bytes % 16 == 0, dst 16-byte aligned; `workgroups` <= 0: 64. */
+int pcd_pull_from_host(const void *host_ptr_table_dev, int n_slots, const int32_t *counter_dev, void *dst, size_t bytes,
+                       int workgroups, void *stream);
+int pcd_counter_add(int32_t *counter_dev, int delta, void *stream);
+
 /* <a, b> of two bf16 vectors (fp32 products, fp64 partial sums) -> out[0], and y = bf16(a * scale_dev[0]): forward and
  * backward of a fixed linear functional of the BEV map -- bench.py's stand-in for the dense head's loss when only the
  * sparse hot path is timed (no reference counterpart).  n % 8 == 0, 16-byte aligned. */
