@@ -92,3 +92,36 @@ def test_linear_functional_loss_kernels_match_torch():
     assert abs(float(loss) - float(want)) <= 1e-5 * float((x.detach().double() * w.double()).abs().sum())
     (loss * 3.0).backward()
     torch.testing.assert_close(x.grad.float(), (w.float() * 3.0).to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+def test_pull_from_pinned_host_inside_a_replayed_graph():
+    """pcd_pull_from_host + pcd_counter_add: a captured graph whose kernel copies slot (counter % n) of a table of PINNED host
+    buffers into a device buffer and then moves the counter -- every replay delivers the next buffer, no host call between."""
+    import torch
+    from com_amd import _lib as L
+    lib = L.lib()
+    n, words = 3, 4096 + 4                                   # (not a multiple of the grid stride: exercises the tail loop)
+    host = [torch.arange(words, dtype=torch.int32).mul_(k + 1).pin_memory() for k in range(n)]
+    table = torch.tensor([h.data_ptr() for h in host], dtype=torch.int64, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(words, dtype=torch.int32, device="cuda")
+
+    def step():
+        L.check(lib.pcd_pull_from_host(L.ptr(table), n, L.ptr(counter), L.ptr(dst), words * 4, 3, L.stream_ptr()), "pull")
+        L.check(lib.pcd_counter_add(L.ptr(counter), 1, L.stream_ptr()), "counter")
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), host[0]) and int(counter) == 1
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    for k in range(1, 8):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dst.cpu(), host[k % n]), k
+    assert int(counter) == 8
+    assert lib.pcd_pull_from_host(L.ptr(table), n, L.ptr(counter), L.ptr(dst), words * 4 + 2, 0, L.stream_ptr()) != 0
