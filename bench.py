@@ -930,6 +930,11 @@ def main():
             # first).  Two graph boundaries per step less than the N > 1 form.
             vox_out = voxelize(s_pts, s_offs)
             torch.cuda.synchronize()
+            shift = int(os.environ.get('PCD_GRAPH_STREAM_SHIFT', '0'))   # (experiment: streams created before the graph's own)
+            state["shift_streams"] = [torch.cuda.Stream() for _ in range(shift)]
+            for st_ in state["shift_streams"]:
+                with torch.cuda.stream(st_):
+                    torch.zeros(1, device=dev)
             g_all = torch.cuda.CUDAGraph()
             pull_stream = torch.cuda.Stream() if pull is not None else None
             with torch.cuda.graph(g_all):
