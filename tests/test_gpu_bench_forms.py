@@ -95,3 +95,23 @@ def test_config5_fp8_forward_training_step_captures_at_300k_points(tmp_path):
     res16, st16 = _bench(tmp_path, "cfg5_bf16", ["--gpus", "1", "--config5"], env={"PCD_CONFIG5_BF16": "1"})
     assert st8["param_sha256"] != st16["param_sha256"]                      # the fp8 forward really ran
     assert abs(st8["param_sum"] - st16["param_sum"]) <= 2e-2 * abs(st16["param_sum"])
+
+
+@pytest.mark.timeout(1200)
+def test_h2d_inclusive_leg_runs_in_both_forms(tmp_path):
+    """The a3 leg of the bench (points of every batch arriving from pinned host memory inside the step): the copy-stream
+    form with its trial-based stream choice, and the opt-in form where a kernel of the step's own graph pulls the batch over
+    PCIe (pcd_pull_from_host) -- both must run the captured step to the end (sticky overflow flag checked) and report a
+    rate of the order of the resident one."""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCD_H2D_PULL"):
+        e.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "2", "--no-cpu-baseline",
+           "--no-roofline", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--distinct-batches", "3", "--gpus", "1"]
+    for env, form in (({"PCD_H2D_CANDIDATES": "2"}, "copy stream"), ({"PCD_H2D_PULL": "1"}, "pulled by a kernel")):
+        r = subprocess.run(cmd, env={**e, **env}, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "H2D-inclusive loop failed" not in r.stderr, r.stderr[-2000:]
+        res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        h = res["h2d_inclusive"]
+        assert form in h["form"] and 0.3 * res["value"] < h["value"] < 1.2 * res["value"], h
