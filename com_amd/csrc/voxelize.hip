@@ -561,7 +561,10 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
                               int32_t *coords, int32_t *num_points, float *mean_f32,
                               void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
                               void *workspace, size_t workspace_bytes, void *stream, bool key_order,
-                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth) {
+                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth, int phase = 0) {
+    // phase (key order, <= VOX_FOLD_FRAMES frames only): 0 = the whole chain; 1 = the part that touches only the workspace
+    // (hash insert + first-flag scan); 2 = the rest (bitmap, ranks, emit), on the SAME workspace, untouched in between.
+    // A training loop can issue phase 1 for the next batch beside the current step and keep only phase 2 in its tail.
     PCD_ENTER();
     if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
         !frame_offsets || !range_host || !vsize_host || !coords || !num_points || !voxel_counts)
@@ -606,13 +609,14 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n_points, 256);
     const bool fast_sorted = key_order && n_points > 0 && batch <= VOX_FOLD_FRAMES;
-    if (key_order && n_points > 0)
+    if (phase != 0 && (phase < 0 || phase > 2 || !fast_sorted)) return PCD_ERR_UNSUPPORTED;
+    if (key_order && n_points > 0 && phase != 1)
         pcd_fill(bitmap, 0, nw * sizeof(u32), st);
     // (forking this fill onto a helper stream beside the insert pass -- event fork / join inside the call -- crashed
     //  the HIP runtime when the call was captured into a graph from a stream that had itself joined the capture)
     // one memset to 0xFF sets both sentinels (empty key, no candidate)
-    pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
-    if (n_points > 0) {
+    if (phase != 2) pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
+    if (n_points > 0 && phase != 2) {
         vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                               frame_offsets, batch, G, max_points, L, keys, best,
                                               tcap - 1, pt_slot);
@@ -631,9 +635,15 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         // instead of scan spines, the per-frame table folded into the mark kernel
         FirstFlag ff{pt_slot, best, L, rank};
         const int spined = nb > VOX_DIRECT_BLOCKS;
-        scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
-        if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
-        vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
+        if (phase != 2) {
+            scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
+            if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+            vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
+        }
+        if (phase == 1) {
+            PCD_RETURN_IF_LAUNCH_FAILED();
+            return PCD_OK;
+        }
         vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
                                                    G, rank, max_voxels, cap, frame_rank0, frame_base, voxel_counts,
                                                    bitmap);
@@ -710,6 +720,22 @@ extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int p
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
                               true, rank_bitmap, rank_prefix, key_depth);
+}
+
+extern "C" int pcd_voxelize_hard_sorted_phase(int phase, const float *points, int n_points, int point_stride,
+                                              int feat_offset, int num_features, const int32_t *frame_offsets,
+                                              int batch, const float *range_host, const float *vsize_host,
+                                              int max_points, int max_voxels, int cap, float *voxels,
+                                              int32_t *coords, int32_t *num_points, float *mean_f32,
+                                              void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
+                                              int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
+                                              void *workspace, size_t workspace_bytes, void *stream) {
+    if ((rank_bitmap != nullptr) != (rank_prefix != nullptr) || key_depth < 0 || phase < 0 || phase > 2)
+        return PCD_ERR_INVALID_ARG;
+    return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
+                              range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
+                              mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
+                              true, rank_bitmap, rank_prefix, key_depth, phase);
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

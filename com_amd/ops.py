@@ -202,7 +202,7 @@ def grid_size(point_cloud_range, voxel_size):
 # ---------------------------------------------------------------------------------------------
 def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
                   feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None,
-                  row_order="first", key_depth=0):
+                  row_order="first", key_depth=0, phase=0):
     """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
     rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
     voxel_features, voxel_features_bf16, counts (host list per frame)).
@@ -211,8 +211,12 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     `row_order`: "first" = the reference's first-appearance voxel ids; "key" = the same voxels numbered by ascending
     (b, z, y, x) (pcd_voxelize_hard_sorted: spatially coherent rows for the sparse convs); the result then carries
     `rank`, the coordinate -> row map (RankMap) the level-1 SubM rulebook is built from -- laid out for a grid of
-    `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1)."""
+    `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1).
+    `phase` (static-shape mode with `out`, key order): 1 = only the half of the chain that touches the call's workspace
+    (hash insert + first-flag scan), 2 = the rest; the workspace then belongs to `out` (no other op may use it between
+    the two calls).  0 = everything."""
     assert row_order in ("first", "key")
+    assert phase == 0 or (row_order == "key" and out is not None)
     _require_cuda(points)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
     dev = points.device
@@ -238,6 +242,12 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         ws_bytes = lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch)
         entry = lib.pcd_voxelize_hard
     ws = _ws(ws_bytes, dev)
+    if out is not None and static and row_order == "key":
+        # a workspace of the result's own: phase 1 / phase 2 calls share it across other launches
+        own = out.get("_own_ws")
+        if own is None or own.numel() < ws_bytes:
+            own = out["_own_ws"] = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        ws = own
     def buf(key, shape, dtype, want=True):
         if not want:
             return None
@@ -266,7 +276,10 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
 
     with _Timed("voxelize_hard", meta):
         extra = (int(key_depth), L.ptr(rank_bm), L.ptr(rank_px)) if row_order == "key" else ()
-        L.check(entry(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
+        head = ()
+        if phase:
+            entry, head = lib.pcd_voxelize_hard_sorted_phase, (int(phase),)
+        L.check(entry(*head, L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
                       L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
                       max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
                       L.ptr(mean16), mean_bf16_stride, L.ptr(counts), *extra, L.ptr(ws), ws.numel(),
@@ -276,10 +289,11 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]
-        PLAN.record("voxels", num_rows, cap)
+        if phase != 1:
+            PLAN.record("voxels", num_rows, cap)
         return dict(voxels=voxels, coords=coords, num_points=nump, voxel_features=mean,
                     voxel_features_bf16=mean16, counts=counts, num_rows=num_rows, rank_bitmap=rank_bm,
-                    rank_prefix=rank_px,
+                    rank_prefix=rank_px, _own_ws=(out or {}).get("_own_ws"),
                     rank=RankMap(None, rank_bm, rank_px, coords, [gz, gy, gx], 4) if rank_bm is not None else None)
     host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
     m = host_counts[-1]

@@ -109,6 +109,17 @@ int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride
                              int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
                              int32_t *voxel_counts, int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* The same call in two halves for a training loop that wants the voxelisation of the NEXT batch off its tail: phase 1 = the
+ * part that touches only `workspace` (hash insert + first-flag scan: ~half of the chain), phase 2 = the rest (bitmap, ranks,
+ * emit) on the SAME workspace, which nothing may touch in between; phase 0 = the whole call.  Key order with at most 8
+ * frames only (PCD_ERR_UNSUPPORTED otherwise).  Results are identical to the one-call form. */
+int pcd_voxelize_hard_sorted_phase(int phase, const float *points, int n_points, int point_stride, int feat_offset,
+                             int num_features, const int32_t *frame_offsets, int batch,
+                             const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
+                             int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
+                             int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
+                             int32_t *voxel_counts, int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
 int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
