@@ -785,13 +785,13 @@ def main():
             com_facade = torch.from_numpy(np.where(valid, rs.integers(0, 4, valid.shape), 0).astype(np.float32)).to(dev)
             com_epoch = 5
 
-    def voxelize(pts, offs, out=None, phase=0):
+    def voxelize(pts, offs, out=None):
         """hard voxelisation + fused MeanVFE of one batch (what the reference's DataLoader workers do on the CPU)"""
         bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
         bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
                                                 synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True,
                                                 out=out["_result"] if out is not None else None,
-                                                row_order=ROW_ORDER, phase=phase)
+                                                row_order=ROW_ORDER)
         bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B,
                "_result": bd["voxelize_result"]}
         if "voxel_num_rows" in bd:
@@ -924,54 +924,6 @@ def main():
         # DataLoader workers, asynchronously to the training step); it owns its memory pool because it runs
         # concurrently with the optimizer graph.  Every timed step still contains exactly one voxelisation.
         vox_stream = torch.cuda.Stream()
-        if world == 1 and os.environ.get('PCD_SPLIT_TAIL') and pull is None and ROW_ORDER == "key" \
-                and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1:
-            # (experiment) the first half of the next batch's voxelisation (hash insert + first-flag scan: it touches only
-            # the voxeliser's own workspace) runs EAGERLY on a stream of its own beside forward + backward; the step is two
-            # graphs: forward+backward | clip+Adam beside the second half of the voxelisation.  (One graph cannot host it:
-            # the hipGraph executor keeps two branches concurrent and the step uses two everywhere.)
-            vox_out = voxelize(s_pts, s_offs)
-            voxelize(s_pts, s_offs, out=vox_out)             # (allocates the result's own workspace outside any capture)
-            torch.cuda.synchronize()
-            g_fb, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb):
-                train_from_voxels(vox_out)
-            with torch.cuda.graph(g_tail, pool=g_fb.pool()):
-                cur = torch.cuda.current_stream()
-                vox_stream.wait_stream(cur)
-                with torch.cuda.stream(vox_stream):
-                    voxelize(s_pts, s_offs, out=vox_out, phase=2)
-                opt_step()
-                cur.wait_stream(vox_stream)
-                plan.arm()
-            state['skip_streams'] = [torch.cuda.Stream() for _ in range(int(os.environ.get('PCD_SPLIT_STREAM_SKIP', '0')))]
-            a_stream = torch.cuda.Stream()
-            ev_copy, ev_a, ev_tail = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-
-            def run_step(i, source=resident):
-                cur = torch.cuda.current_stream()
-                pts, offs = source.get(i + 1)
-                schedule()
-                s_pts.copy_(pts, non_blocking=True)          # (after the previous tail: its emit pass read s_pts)
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(i + 1)
-                ev_copy.record(cur)
-                with torch.cuda.stream(a_stream):
-                    a_stream.wait_event(ev_copy)
-                    voxelize(s_pts, s_offs, out=vox_out, phase=1)
-                    ev_a.record(a_stream)
-                g_fb.replay()
-                cur.wait_event(ev_a)
-                g_tail.replay()
-
-            def prime(source):
-                pts, offs = source.get(0)
-                s_pts.copy_(pts, non_blocking=True)
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(0)
-                voxelize(s_pts, s_offs, out=vox_out)
-            state["prime"] = prime
-            return run_step
         if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1:   # (the switches exercise the N > 1 form on one GPU)
             # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
             # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads

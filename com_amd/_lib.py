@@ -32,9 +32,7 @@ PROTOTYPES = {
     "pcd_voxelize_hard_sorted_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp, _i]),
     "pcd_voxelize_hard_sorted_rank_words": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
     "pcd_voxelize_hard_sorted": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                                      _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
-    "pcd_voxelize_hard_sorted_phase": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                                            _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+                                      _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_mean_vfe": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -57,15 +55,15 @@ PROTOTYPES = {
     "pcd_rulebook_subm_pairs_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_pairs": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
-                                      _vp]),
+                                      _vp, _i]),
     "pcd_rulebook_subm_ranked4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
-                                       _vp]),
+                                       _vp, _i]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
-                                    _vp, _sz, _vp]),
+                                    _vp, _sz, _vp, _i]),
     "pcd_rulebook_conv_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp,
-                                     _i, _vp, _vp, _vp, _sz, _vp]),
+                                     _i, _vp, _vp, _vp, _sz, _vp, _i]),
     "pcd_debug_stamp": (_i, [_vp, _vp]),
     "pcd_pull_from_host": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp]),
     "pcd_counter_add": (_i, [_vp, _i, _vp]),
@@ -161,6 +159,7 @@ PROTOTYPES = {
     "pcd_pfn_relu_pool": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_pfn_relu_pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_boxes_overlap_bev": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
+    "pcd_boxes_iou_bev_host": (_i, [_vp, _i, _vp, _i, _vp]),
     "pcd_nms_workspace_bytes": (_sz, [_i]),
     "pcd_nms_bev": (_i, [_vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_bn_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -21,24 +21,26 @@ namespace {
 
 constexpr float IOU_EPS = 1e-8f;        // iou3d_nms_kernel.cu:14
 
+// (the geometry is __host__ __device__: pcd_boxes_iou_bev_host below runs the SAME code on the host, where cosf / sinf /
+//  atan2f are the C library's -- the functions the reference's iou3d_cpu.cpp calls)
 struct P2 {
     float x, y;
 };
-__device__ __forceinline__ P2 mk(float x, float y) { P2 p; p.x = x; p.y = y; return p; }
-__device__ __forceinline__ float cross2(const P2 &a, const P2 &b) { return a.x * b.y - a.y * b.x; }
+__host__ __device__ __forceinline__ P2 mk(float x, float y) { P2 p; p.x = x; p.y = y; return p; }
+__host__ __device__ __forceinline__ float cross2(const P2 &a, const P2 &b) { return a.x * b.y - a.y * b.x; }
 // (p1 - p0) x (p2 - p0)
-__device__ __forceinline__ float cross3(const P2 &p1, const P2 &p2, const P2 &p0) {
+__host__ __device__ __forceinline__ float cross3(const P2 &p1, const P2 &p2, const P2 &p0) {
     return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
 }
 
 // bounding boxes of the two segments overlap (iou3d_nms_kernel.cu:43-49)
-__device__ __forceinline__ bool seg_boxes_touch(const P2 &p1, const P2 &p2, const P2 &q1, const P2 &q2) {
+__host__ __device__ __forceinline__ bool seg_boxes_touch(const P2 &p1, const P2 &p2, const P2 &q1, const P2 &q2) {
     return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
            fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
 }
 
 // point inside the rotated rectangle, with the reference's 1e-2 margin (iou3d_nms_kernel.cu:51-61)
-__device__ __forceinline__ bool in_box2d(const float *box, const P2 &p) {
+__host__ __device__ __forceinline__ bool in_box2d(const float *box, const P2 &p) {
     const float MARGIN = 1e-2f;
     const float cx = box[0], cy = box[1];
     const float c = cosf(-box[6]), s = sinf(-box[6]);
@@ -48,7 +50,7 @@ __device__ __forceinline__ bool in_box2d(const float *box, const P2 &p) {
 }
 
 // proper intersection of segments p0-p1 and q0-q1 (iou3d_nms_kernel.cu:63-92)
-__device__ __forceinline__ bool seg_intersection(const P2 &p1, const P2 &p0, const P2 &q1, const P2 &q0, P2 &ans) {
+__host__ __device__ __forceinline__ bool seg_intersection(const P2 &p1, const P2 &p0, const P2 &q1, const P2 &q0, P2 &ans) {
     if (!seg_boxes_touch(p0, p1, q0, q1)) return false;
     const float s1 = cross3(q0, p1, p0);
     const float s2 = cross3(p1, q1, p0);
@@ -69,7 +71,7 @@ __device__ __forceinline__ bool seg_intersection(const P2 &p1, const P2 &p0, con
     return true;
 }
 
-__device__ __forceinline__ void corners_of(const float *box, P2 (&c)[5]) {
+__host__ __device__ __forceinline__ void corners_of(const float *box, P2 (&c)[5]) {
     const float hx = box[3] / 2, hy = box[4] / 2;
     const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
     const float ca = cosf(box[6]), sa = sinf(box[6]);
@@ -83,7 +85,7 @@ __device__ __forceinline__ void corners_of(const float *box, P2 (&c)[5]) {
 }
 
 // area of the intersection polygon of two rotated rectangles (iou3d_nms_kernel.cu:104-223)
-__device__ float overlap_bev(const float *a, const float *b) {
+__host__ __device__ inline float overlap_bev(const float *a, const float *b) {
     P2 ca[5], cb[5];
     corners_of(a, ca);
     corners_of(b, cb);
@@ -131,7 +133,7 @@ __device__ float overlap_bev(const float *a, const float *b) {
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float iou_bev_dev(const float *a, const float *b) {     // iou3d_nms_kernel.cu:225-234
+__host__ __device__ __forceinline__ float iou_bev_dev(const float *a, const float *b) {     // iou3d_nms_kernel.cu:225-234
     const float sa = a[3] * a[4], sb = b[3] * b[4];
     const float so = overlap_bev(a, b);
     return so / fmaxf(sa + sb - so, IOU_EPS);
@@ -222,6 +224,20 @@ extern "C" int pcd_boxes_overlap_bev(const float *boxes_a, int num_a, const floa
     else
         pairwise_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(boxes_a, num_a, boxes_b, num_b, out);
     PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// Host-side variant (boxes_bev_iou_cpu, iou3d_nms_utils.py:12-28 -> src/iou3d_cpu.cpp:232-252): what COMAug's database
+// sampler calls per frame for its collision test (datasets/augmentor/database_sampler_v2.py:600-601) inside DataLoader
+// workers.  HOST pointers, no stream, no GPU work: the same geometry code as the kernels above, compiled for the host.
+extern "C" int pcd_boxes_iou_bev_host(const float *boxes_a_host, int num_a, const float *boxes_b_host, int num_b,
+                                      float *out_host) {
+    if (num_a < 0 || num_b < 0) return PCD_ERR_INVALID_ARG;
+    if (num_a == 0 || num_b == 0) return PCD_OK;
+    if (!boxes_a_host || !boxes_b_host || !out_host) return PCD_ERR_INVALID_ARG;
+    for (int i = 0; i < num_a; ++i)
+        for (int j = 0; j < num_b; ++j)
+            out_host[(size_t)i * num_b + j] = iou_bev_dev(boxes_a_host + (size_t)i * 7, boxes_b_host + (size_t)j * 7);
     return PCD_OK;
 }
 

@@ -28,12 +28,17 @@ struct ConvGeom {
     int pd, ph, pw;
     int dd, dh, dw;
     int K;
+    int order;          // PCD_ROWS_ZYX / PCD_ROWS_YXZ: the linear key that numbers the rows of a bitmap-ranked level
 };
 
 constexpr u64 SLOT_EMPTY = ~0ull;
 
 __device__ __forceinline__ u32 lin_key(int b, int z, int y, int x, int D, int H, int W) {
     return (((u32)b * D + z) * H + y) * W + x;
+}
+// key of a bitmap-ranked level in the given row order (pcd_ops.h: PCD_ROWS_*)
+__device__ __forceinline__ u32 ord_key(int order, int b, int z, int y, int x, int D, int H, int W) {
+    return order == PCD_ROWS_YXZ ? (((u32)b * H + y) * W + x) * D + z : (((u32)b * D + z) * H + y) * W + x;
 }
 
 __global__ __launch_bounds__(256) void hash_insert_kernel(const int4 *__restrict__ idx, int n,
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) void blk_probe_kernel(const int4 *__restrict__
 // PW = words per prefix entry: 1 (the strided builds' maps: one prefix per bitmap word) or 4 (the key-ordered voxeliser's
 // map of the level-1 grid, pcd_voxelize_hard_sorted: one prefix per 16-byte group, the rank adds the set bits of the
 // group's words in front -- a quarter of the prefix memory for a grid of 371 M cells).
-template <int KD, int KH, int KW, int PW>
+template <int KD, int KH, int KW, int PW, int ORDER = PCD_ROWS_ZYX>
 __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
                                                         const u32 *__restrict__ bitmap,
@@ -302,14 +307,17 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
     const bool live = o < eff_rows(n_dev, n);
     const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
     const int wave = o >> 6;
-    if (KW == 3 && G.dw == 1) {
-        // The three x-neighbours of a (dz, dy) line are three CONSECUTIVE keys: one fetch of the bitmap (the word / group of
-        // key - 1 and, across a word boundary, its successor) and ONE prefix serve all three -- the prefix sums are
-        // cumulative, so rank(key) = prefix(first word) + set bits in front of the key within the fetched run.  A third of
-        // the probe loads of the per-offset form below (which remains for dilated kernels).
+    if (ORDER == PCD_ROWS_ZYX ? (KW == 3 && G.dw == 1) : (KD == 3 && G.dd == 1)) {
+        // The three neighbours along the key's FASTEST axis (x in ZYX order, z in YXZ order) of a line are three
+        // CONSECUTIVE keys: one fetch of the bitmap (the word / group of key - 1 and, across a word boundary, its
+        // successor) and ONE prefix serve all three -- the prefix sums are cumulative, so rank(key) = prefix(first word)
+        // + set bits in front of the key within the fetched run.  A third of the probe loads of the per-offset form below
+        // (which remains for dilated kernels).  Lines: (dz, dy) in ZYX order, (dy, dx) in YXZ order.
+        constexpr int NL = ORDER == PCD_ROWS_ZYX ? KD * KH : KH * KW;     // lines
+        constexpr int LG = ORDER == PCD_ROWS_ZYX ? KH : KW;               // lines per group of the PW = 4 form
 #pragma unroll
-        for (int l0 = 0; l0 < KD * KH; l0 += (PW == 1 ? KD * KH : KH)) {
-            constexpr int LB = PW == 1 ? KD * KH : KH;       // lines whose loads are in flight together
+        for (int l0 = 0; l0 < NL; l0 += (PW == 1 ? NL : LG)) {
+            constexpr int LB = PW == 1 ? NL : LG;            // lines whose loads are in flight together
             u64 run[LB];
             int pre[LB];
             int p0[LB];
@@ -317,14 +325,23 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
 #pragma unroll
             for (int ll = 0; ll < LB; ++ll) {
                 const int l = l0 + ll;
-                const int a = l / KH, bq = l % KH;
-                const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh;
-                const bool ok = live && z >= 0 && z < G.D && y >= 0 && y < G.H;
+                bool ok;
+                u32 keyc;
+                if (ORDER == PCD_ROWS_ZYX) {
+                    const int a = l / KH, bq = l % KH;
+                    const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh;
+                    ok = live && z >= 0 && z < G.D && y >= 0 && y < G.H;
+                    keyc = ok ? lin_key(c.x, z, y, c.w, G.D, G.H, G.W) : 1u;            // key of (z, y, x)
+                } else {
+                    const int bq = l / KW, cq = l % KW;
+                    const int y = c.z + (bq - KH / 2) * G.dh, x = c.w + (cq - KW / 2) * G.dw;
+                    ok = live && y >= 0 && y < G.H && x >= 0 && x < G.W;
+                    keyc = ok ? ord_key(PCD_ROWS_YXZ, c.x, c.y, y, x, G.D, G.H, G.W) : 1u;   // key of (y, x, z)
+                }
                 line_ok[ll] = ok;
-                const u32 keyc = ok ? lin_key(c.x, z, y, c.w, G.D, G.H, G.W) : 1u;      // key of (z, y, x)
-                const u32 key0 = keyc == 0u ? 0u : keyc - 1u;                           // key of x - 1 (x = 0: not probed)
+                const u32 key0 = keyc == 0u ? 0u : keyc - 1u;                           // key of the -1 step (at 0: not probed)
                 const u32 w0 = key0 >> 5;
-                p0[ll] = (int)(keyc - 1u - (w0 << 5));                                  // bit of x - 1 in the run (-1 at key 0)
+                p0[ll] = (int)(keyc - 1u - (w0 << 5));                                  // bit of the -1 step in the run (-1 at key 0)
                 if (PW == 1) {
                     const u32 lo = bitmap[w0], hi = bitmap[w0 + 1];     // (the maps are padded by one word)
                     pre[ll] = prefix[w0];
@@ -342,12 +359,15 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
 #pragma unroll
             for (int ll = 0; ll < LB; ++ll)
 #pragma unroll
-                for (int cq = 0; cq < 3; ++cq) {
-                    const int k = (l0 + ll) * 3 + cq;
-                    const int x = c.w + cq - 1;
+                for (int f = 0; f < 3; ++f) {
+                    const int l = l0 + ll;
+                    // f = index along the fastest axis; k = (a * KH + bq) * KW + cq in both orders
+                    const int k = ORDER == PCD_ROWS_ZYX ? l * 3 + f : (f * KH + l / KW) * KW + l % KW;
+                    const int t = (ORDER == PCD_ROWS_ZYX ? c.w : c.y) + f - 1;
+                    const int tmax = ORDER == PCD_ROWS_ZYX ? G.W : G.D;
                     int r = -1;
-                    if (line_ok[ll] && x >= 0 && x < G.W) {
-                        const int p = p0[ll] + cq;
+                    if (line_ok[ll] && t >= 0 && t < tmax) {
+                        const int p = p0[ll] + f;
                         if ((run[ll] >> p) & 1ull) {
                             r = pre[ll] + __popcll(run[ll] & ((1ull << p) - 1ull));
                             if (r >= n) r = -1;
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(256) void subm_rank_kernel(const int4 *__restrict__
             const int a = k / (KH * KW), bq = (k / KW) % KH, cq = k % KW;
             const int z = c.y + (a - KD / 2) * G.dd, y = c.z + (bq - KH / 2) * G.dh, x = c.w + (cq - KW / 2) * G.dw;
             const bool inb = live && z >= 0 && z < G.D && y >= 0 && y < G.H && x >= 0 && x < G.W;
-            const u32 key = inb ? lin_key(c.x, z, y, x, G.D, G.H, G.W) : 0u;
+            const u32 key = inb ? ord_key(ORDER, c.x, z, y, x, G.D, G.H, G.W) : 0u;
             inside[kk] = inb;
             const u32 sh = key & 31;
             if (PW == 1) {
@@ -475,7 +495,7 @@ __device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int b
     int ox = G.sw == 2 ? (tx >> 1) : (G.sw == 1 ? tx : tx / G.sw);
     if (oz * G.sd != tz || oy * G.sh != ty || ox * G.sw != tx) return false;
     if (oz >= G.Do || oy >= G.Ho || ox >= G.Wo) return false;
-    key = lin_key(c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
+    key = ord_key(G.order, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
     return true;
 }
 
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__
                 if (ox < 0) continue;
                 // one BYTE per output cell: plain stores of the same value need no atomics (about 8 inputs mark
                 // each cell; the 32-bit-word bitmap this replaced cost one memory-side atomic per mark)
-                bytemap[lin_key(c.x, oz, oy, ox, G.Do, G.Ho, G.Wo)] = 1;
+                bytemap[ord_key(G.order, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo)] = 1;
             }
         }
     }
@@ -725,12 +745,22 @@ __global__ __launch_bounds__(256) void conv_scan_emit_kernel(const u32 *__restri
                     const int bpos = __ffs(bits) - 1;
                     bits &= bits - 1;
                     const u32 key = ((u32)(w0 + j) << 5) + bpos;
-                    const int x = key % G.Wo;
-                    u32 t = key / G.Wo;
-                    const int y = t % G.Ho;
-                    t /= G.Ho;
-                    const int z = t % G.Do;
-                    const int bq = t / G.Do;
+                    int x, y, z, bq;
+                    if (G.order == PCD_ROWS_YXZ) {
+                        z = key % G.Do;
+                        u32 t = key / G.Do;
+                        x = t % G.Wo;
+                        t /= G.Wo;
+                        y = t % G.Ho;
+                        bq = t / G.Ho;
+                    } else {
+                        x = key % G.Wo;
+                        u32 t = key / G.Wo;
+                        y = t % G.Ho;
+                        t /= G.Ho;
+                        z = t % G.Do;
+                        bq = t / G.Do;
+                    }
                     if (r < S.n_out) reinterpret_cast<int4 *>(S.out_indices)[r] = make_int4(bq, z, y, x);
                     ++r;
                 }
@@ -906,6 +936,7 @@ static int make_geom(const int *shape, const int *ks, const int *st, const int *
     pcd_conv_out_shape(shape, ks, st, pd, dl, out);
     G.Do = out[0]; G.Ho = out[1]; G.Wo = out[2];
     if (G.K > 343) return PCD_ERR_UNSUPPORTED;
+    G.order = PCD_ROWS_ZYX;
     return PCD_OK;
 }
 
@@ -1152,9 +1183,10 @@ static int subm_ranked_impl(const int32_t *indices, int n, int batch, const int 
                            const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                            const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                            int pad_pairs, const int32_t *n_dev, void *workspace,
-                           size_t workspace_bytes, void *stream, int prefix_words) {
+                           size_t workspace_bytes, void *stream, int prefix_words, int row_order) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !shape_host || !ksize_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
     const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
     ConvGeom G;
@@ -1175,12 +1207,19 @@ static int subm_ranked_impl(const int32_t *indices, int n, int batch, const int 
     int *totals = ws.take<int>(G.K);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n, 256);
-    if (prefix_words == 4)
-        subm_rank_kernel<3, 3, 3, 4><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
-                                                        pairs ? wave_cnt : nullptr, nwaves);
-    else
-        subm_rank_kernel<3, 3, 3, 1><<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, G, bitmap, prefix, nbr,
-                                                        pairs ? wave_cnt : nullptr, nwaves);
+    int *wc = pairs ? wave_cnt : nullptr;
+    const int4 *idx4 = (const int4 *)indices;
+    if (row_order == PCD_ROWS_YXZ) {
+        if (prefix_words == 4)
+            subm_rank_kernel<3, 3, 3, 4, PCD_ROWS_YXZ><<<nb, 256, 0, st>>>(idx4, n, n_dev, G, bitmap, prefix, nbr, wc, nwaves);
+        else
+            subm_rank_kernel<3, 3, 3, 1, PCD_ROWS_YXZ><<<nb, 256, 0, st>>>(idx4, n, n_dev, G, bitmap, prefix, nbr, wc, nwaves);
+    } else {
+        if (prefix_words == 4)
+            subm_rank_kernel<3, 3, 3, 4><<<nb, 256, 0, st>>>(idx4, n, n_dev, G, bitmap, prefix, nbr, wc, nwaves);
+        else
+            subm_rank_kernel<3, 3, 3, 1><<<nb, 256, 0, st>>>(idx4, n, n_dev, G, bitmap, prefix, nbr, wc, nwaves);
+    }
     if (pairs) {
         scan_rows_kernel<<<G.K, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
@@ -1194,18 +1233,18 @@ extern "C" int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch
                                         const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                                         const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                                         int pad_pairs, const int32_t *n_dev, void *workspace,
-                                        size_t workspace_bytes, void *stream) {
+                                        size_t workspace_bytes, void *stream, int row_order) {
     return subm_ranked_impl(indices, n, batch, shape_host, ksize_host, dil_host, bitmap, prefix, nbr, pairs, pair_num,
-                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 1);
+                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 1, row_order);
 }
 
 extern "C" int pcd_rulebook_subm_ranked4(const int32_t *indices, int n, int batch, const int *shape_host,
                                          const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                                          const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                                          int pad_pairs, const int32_t *n_dev, void *workspace,
-                                         size_t workspace_bytes, void *stream) {
+                                         size_t workspace_bytes, void *stream, int row_order) {
     return subm_ranked_impl(indices, n, batch, shape_host, ksize_host, dil_host, bitmap, prefix, nbr, pairs, pair_num,
-                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 4);
+                            pad_pairs, n_dev, workspace, workspace_bytes, stream, 4, row_order);
 }
 
 extern "C" int pcd_rulebook_conv_rank_layout(int n, int batch, const int *in_shape_host, const int *ksize_host,
@@ -1323,15 +1362,17 @@ extern "C" int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch,
                                        const int *in_shape_host, const int *ksize_host,
                                        const int *stride_host, const int *pad_host,
                                        const int *dil_host, int32_t *n_out_dev, const int32_t *n_dev,
-                                       void *workspace, size_t workspace_bytes, void *stream) {
+                                       void *workspace, size_t workspace_bytes, void *stream, int row_order) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
+    if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
         return PCD_ERR_INVALID_ARG;
     ConvGeom G;
     int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
     if (rc != PCD_OK) return rc;
     if (G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return PCD_ERR_INVALID_ARG;
+    G.order = row_order;
     ConvWs L;
     rc = conv_ws_layout(workspace, workspace_bytes, n, batch, G, L, nullptr);
     if (rc != PCD_OK) return rc;
@@ -1349,15 +1390,17 @@ extern "C" int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch,
                                       const int *dil_host, int n_out, int32_t *out_indices,
                                       int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs,
                                       int32_t *pair_num, int pad_pairs, const int32_t *n_dev,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
+                                      void *workspace, size_t workspace_bytes, void *stream, int row_order) {
     PCD_ENTER();
     if (n < 0 || batch <= 0 || n_out < 0) return PCD_ERR_INVALID_ARG;
+    if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host)
         return PCD_ERR_INVALID_ARG;
     if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
     ConvGeom G;
     int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
     if (rc != PCD_OK) return rc;
+    G.order = row_order;
     ConvWs L;
     rc = conv_ws_layout(workspace, workspace_bytes, n, batch, G, L, nullptr);
     if (rc != PCD_OK) return rc;
@@ -1384,9 +1427,11 @@ extern "C" int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch,
                                        const int *dil_host, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices,
                                        int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
                                        int pad_pairs, int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev,
-                                       const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream) {
+                                       const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream,
+                                       int row_order) {
     PCD_ENTER();
     if (n <= 0 || batch <= 0 || n_out_cap <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
+    if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !dil_host) return PCD_ERR_INVALID_ARG;
     if (!indices || !out_indices || !nbr_in || !nbr_out) return PCD_ERR_INVALID_ARG;
     if ((pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
@@ -1394,6 +1439,7 @@ extern "C" int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch,
     int rc = make_geom(in_shape_host, ksize_host, stride_host, pad_host, dil_host, G);
     if (rc != PCD_OK) return rc;
     if (G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return PCD_ERR_INVALID_ARG;
+    G.order = row_order;
     ClsOut C = {G.sd * G.sh * G.sw, cls_tile, vcap, perm, vstart_dev};
     const bool classes = perm != nullptr;
     if (classes) {

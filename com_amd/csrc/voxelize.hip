@@ -27,6 +27,7 @@ struct VoxGeom {
     float v0, v1, v2;
     int gx, gy, gz;
     int kz;   // z extent of the KEY space of the key-ordered form (>= gz: the backbones' sparse_shape has gz + 1 planes)
+    int order;   // key-ordered form: PCD_ROWS_ZYX = rows by (b, z, y, x); PCD_ROWS_YXZ = rows by (b, y, x, z), z fastest
 };
 
 __device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &G, int &cx, int &cy,
@@ -173,6 +174,7 @@ __global__ void vox_frames_kernel(const int32_t *offs, int batch, const int *ran
 // voxels share chunks) took the mark kernel from 18 to 62 us.
 
 __device__ __forceinline__ u32 vox_key_u32(const VoxGeom &G, int b, int cz, int cy, int cx) {
+    if (G.order == PCD_ROWS_YXZ) return (((u32)b * G.gy + cy) * G.gx + cx) * G.kz + cz;
     return (((u32)b * G.kz + cz) * G.gy + cy) * G.gx + cx;
 }
 
@@ -495,6 +497,7 @@ static VoxGeom make_geom(const float *range, const float *vs) {
     }
     G.gx = g[0]; G.gy = g[1]; G.gz = g[2];
     G.kz = G.gz;
+    G.order = PCD_ROWS_ZYX;
     return G;
 }
 
@@ -547,6 +550,7 @@ extern "C" size_t pcd_voxelize_hard_workspace_bytes(int n_points, int max_points
 extern "C" size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
                                                            const float *range_host, const float *vsize_host,
                                                            int key_depth) {
+    // (the key space has the same size in both row orders)
     if (!range_host || !vsize_host) return 0;
     VoxGeom G = make_geom(range_host, vsize_host);
     if (key_depth > 0 && key_depth < G.gz) return 0;
@@ -561,11 +565,9 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
                               int32_t *coords, int32_t *num_points, float *mean_f32,
                               void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
                               void *workspace, size_t workspace_bytes, void *stream, bool key_order,
-                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth, int phase = 0) {
-    // phase (key order, <= VOX_FOLD_FRAMES frames only): 0 = the whole chain; 1 = the part that touches only the workspace
-    // (hash insert + first-flag scan); 2 = the rest (bitmap, ranks, emit), on the SAME workspace, untouched in between.
-    // A training loop can issue phase 1 for the next batch beside the current step and keep only phase 2 in its tail.
+                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth, int row_order) {
     PCD_ENTER();
+    if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
         !frame_offsets || !range_host || !vsize_host || !coords || !num_points || !voxel_counts)
         return PCD_ERR_INVALID_ARG;
@@ -579,6 +581,7 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         if (key_depth < G.gz) return PCD_ERR_INVALID_ARG;
         G.kz = key_depth;
     }
+    G.order = row_order;
     if ((double)batch * G.gx * G.gy * G.gz >= 1.8e19) return PCD_ERR_KEYSPACE;
     size_t nw = 0, nc = 0;
     if (key_order && !sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
@@ -609,14 +612,13 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n_points, 256);
     const bool fast_sorted = key_order && n_points > 0 && batch <= VOX_FOLD_FRAMES;
-    if (phase != 0 && (phase < 0 || phase > 2 || !fast_sorted)) return PCD_ERR_UNSUPPORTED;
-    if (key_order && n_points > 0 && phase != 1)
+    if (key_order && n_points > 0)
         pcd_fill(bitmap, 0, nw * sizeof(u32), st);
     // (forking this fill onto a helper stream beside the insert pass -- event fork / join inside the call -- crashed
     //  the HIP runtime when the call was captured into a graph from a stream that had itself joined the capture)
     // one memset to 0xFF sets both sentinels (empty key, no candidate)
-    if (phase != 2) pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
-    if (n_points > 0 && phase != 2) {
+    pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
+    if (n_points > 0) {
         vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                               frame_offsets, batch, G, max_points, L, keys, best,
                                               tcap - 1, pt_slot);
@@ -635,15 +637,9 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         // instead of scan spines, the per-frame table folded into the mark kernel
         FirstFlag ff{pt_slot, best, L, rank};
         const int spined = nb > VOX_DIRECT_BLOCKS;
-        if (phase != 2) {
-            scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
-            if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
-            vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
-        }
-        if (phase == 1) {
-            PCD_RETURN_IF_LAUNCH_FAILED();
-            return PCD_OK;
-        }
+        scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
+        if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+        vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
         vox_sorted_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch,
                                                    G, rank, max_voxels, cap, frame_rank0, frame_base, voxel_counts,
                                                    bitmap);
@@ -691,7 +687,7 @@ extern "C" int pcd_voxelize_hard(const float *points, int n_points, int point_st
     return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
-                              false, nullptr, nullptr, 0);
+                              false, nullptr, nullptr, 0, PCD_ROWS_ZYX);
 }
 
 extern "C" int pcd_voxelize_hard_sorted_rank_words(int batch, const float *range_host, const float *vsize_host,
@@ -713,29 +709,14 @@ extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int p
                                         int max_points, int max_voxels, int cap, float *voxels,
                                         int32_t *coords, int32_t *num_points, float *mean_f32,
                                         void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
-                                        int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
+                                        int key_depth, int row_order, uint32_t *rank_bitmap,
+                                        int32_t *rank_prefix, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
     if ((rank_bitmap != nullptr) != (rank_prefix != nullptr) || key_depth < 0) return PCD_ERR_INVALID_ARG;
     return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
-                              true, rank_bitmap, rank_prefix, key_depth);
-}
-
-extern "C" int pcd_voxelize_hard_sorted_phase(int phase, const float *points, int n_points, int point_stride,
-                                              int feat_offset, int num_features, const int32_t *frame_offsets,
-                                              int batch, const float *range_host, const float *vsize_host,
-                                              int max_points, int max_voxels, int cap, float *voxels,
-                                              int32_t *coords, int32_t *num_points, float *mean_f32,
-                                              void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
-                                              int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
-                                              void *workspace, size_t workspace_bytes, void *stream) {
-    if ((rank_bitmap != nullptr) != (rank_prefix != nullptr) || key_depth < 0 || phase < 0 || phase > 2)
-        return PCD_ERR_INVALID_ARG;
-    return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
-                              range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
-                              mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
-                              true, rank_bitmap, rank_prefix, key_depth, phase);
+                              true, rank_bitmap, rank_prefix, key_depth, row_order);
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

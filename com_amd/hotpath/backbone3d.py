@@ -115,6 +115,7 @@ class _BackboneBase(nn.Module):
         if rank is not None and rank.indices is x.indices and list(rank.shape) == list(x.spatial_shape):
             # key-ordered voxel rows: the voxeliser's bitmap ranks ARE the row ids -> level-1 SubM without a hash table
             x.indice_dict[("__rank__", x.indices.data_ptr())] = rank
+            x.indice_dict["__row_order__"] = rank.order      # the strided builds number their rows the same way
         return x
 
     def _bump_bn_counters(self):

@@ -1,12 +1,35 @@
 """Rotated BEV IoU / 3D IoU / NMS with the function names and signatures of the reference's
 pcdet/ops/iou3d_nms/iou3d_nms_utils.py:31-116, over the HIP kernels of com_amd/csrc/iou3d.hip.
 
-Boxes are (N, 7) float32 device tensors (x, y, z, dx, dy, dz, heading).  `boxes_bev_iou_cpu` (the reference's
-host-side variant for the GT-sampling augmentor, iou3d_nms_utils.py:12-28) is a CPU data-loader function and is
-not part of this GPU hot path."""
+Boxes are (N, 7) float32 device tensors (x, y, z, dx, dy, dz, heading).  `boxes_bev_iou_cpu` is the reference's
+host-side variant for the GT-sampling augmentor (iou3d_nms_utils.py:12-28; COMAug calls it per frame,
+database_sampler_v2.py:600-601): numpy arrays / CPU tensors in, the library's host entry point
+pcd_boxes_iou_bev_host underneath (no GPU call: usable inside forked DataLoader workers)."""
+import ctypes
+
+import numpy as np
 import torch
 
 from . import _lib as L
+
+
+def boxes_bev_iou_cpu(boxes_a, boxes_b):
+    """iou3d_nms_utils.py:12-28: (N, 7), (M, 7) CPU boxes -> (N, M) BEV IoU; numpy in -> numpy out, tensor in -> tensor out
+    (the reference's check_numpy_to_torch convention).  Bit-identical to the reference's iou3d_cpu.cpp (fixture G13)."""
+    is_numpy = isinstance(boxes_a, np.ndarray)
+    a = np.ascontiguousarray(boxes_a if isinstance(boxes_a, np.ndarray) else _cpu_array(boxes_a), dtype=np.float32)
+    b = np.ascontiguousarray(boxes_b if isinstance(boxes_b, np.ndarray) else _cpu_array(boxes_b), dtype=np.float32)
+    assert a.ndim == 2 and b.ndim == 2 and a.shape[1] == 7 and b.shape[1] == 7
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    L.check(L.lib().pcd_boxes_iou_bev_host(a.ctypes.data_as(ctypes.c_void_p), a.shape[0],
+                                           b.ctypes.data_as(ctypes.c_void_p), b.shape[0],
+                                           out.ctypes.data_as(ctypes.c_void_p)), "pcd_boxes_iou_bev_host")
+    return out if is_numpy else torch.from_numpy(out)
+
+
+def _cpu_array(t):
+    assert not t.is_cuda, 'Only support CPU tensors'          # (the reference's own assertion, iou3d_nms_utils.py:22)
+    return t.detach().float().numpy()
 
 
 def _boxes(t):

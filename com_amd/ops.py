@@ -194,6 +194,11 @@ def pow2_ge8(c):
     return p
 
 
+# row orders of key-numbered levels (pcd_ops.h: PCD_ROWS_ZYX / PCD_ROWS_YXZ)
+ROWS_ZYX, ROWS_YXZ = 0, 1
+ROW_ORDERS = {"first": ROWS_ZYX, "key": ROWS_ZYX, "zyx": ROWS_ZYX, "yxz": ROWS_YXZ}
+
+
 def grid_size(point_cloud_range, voxel_size):
     """pcdet/datasets/processor/data_processor.py:127-128"""
     return [int(round((point_cloud_range[j + 3] - point_cloud_range[j]) / voxel_size[j])) for j in range(3)]
@@ -202,7 +207,7 @@ def grid_size(point_cloud_range, voxel_size):
 # ---------------------------------------------------------------------------------------------
 def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
                   feat_offset=0, num_features=None, want_voxels=True, want_mean=True, mean_bf16_stride=0, out=None,
-                  row_order="first", key_depth=0, phase=0):
+                  row_order="first", key_depth=0):
     """Batched hard voxelisation (+ fused MeanVFE).  `points` [n, stride] f32 on device, frame b =
     rows [frame_offsets[b], frame_offsets[b+1]).  Returns dict(voxels, coords [M,4], num_points,
     voxel_features, voxel_features_bf16, counts (host list per frame)).
@@ -211,12 +216,10 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     `row_order`: "first" = the reference's first-appearance voxel ids; "key" = the same voxels numbered by ascending
     (b, z, y, x) (pcd_voxelize_hard_sorted: spatially coherent rows for the sparse convs); the result then carries
     `rank`, the coordinate -> row map (RankMap) the level-1 SubM rulebook is built from -- laid out for a grid of
-    `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1).
-    `phase` (static-shape mode with `out`, key order): 1 = only the half of the chain that touches the call's workspace
-    (hash insert + first-flag scan), 2 = the rest; the workspace then belongs to `out` (no other op may use it between
-    the two calls).  0 = everything."""
-    assert row_order in ("first", "key")
-    assert phase == 0 or (row_order == "key" and out is not None)
+    `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1).  "yxz" = the same with the rows numbered
+    by ascending (b, y, x, z) -- z fastest, PCD_ROWS_YXZ: the order the window gather-GEMM wants."""
+    assert row_order in ("first", "key", "yxz")
+    keyed = row_order in ("key", "yxz")
     _require_cuda(points)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
     dev = points.device
@@ -232,7 +235,7 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     if static:
         cap = min(cap, PLAN.cap("voxels"))
     lib = L.lib()
-    if row_order == "key":
+    if keyed:
         ws_bytes = lib.pcd_voxelize_hard_sorted_workspace_bytes(n, max_points, batch, L.host_f32(point_cloud_range),
                                                                 L.host_f32(voxel_size), int(key_depth))
         if ws_bytes == 0:
@@ -242,12 +245,6 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         ws_bytes = lib.pcd_voxelize_hard_workspace_bytes(n, max_points, batch)
         entry = lib.pcd_voxelize_hard
     ws = _ws(ws_bytes, dev)
-    if out is not None and static and row_order == "key":
-        # a workspace of the result's own: phase 1 / phase 2 calls share it across other launches
-        own = out.get("_own_ws")
-        if own is None or own.numel() < ws_bytes:
-            own = out["_own_ws"] = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        ws = own
     def buf(key, shape, dtype, want=True):
         if not want:
             return None
@@ -263,7 +260,7 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     mean16 = buf("voxel_features_bf16", (cap, mean_bf16_stride), torch.bfloat16, bool(mean_bf16_stride))
     counts = buf("counts", (batch + 1,), torch.int32)
     rank_bm = rank_px = None
-    if row_order == "key":        # the coordinate -> row map of the output: kept for the level-1 SubM rulebook
+    if keyed:                     # the coordinate -> row map of the output: kept for the level-1 SubM rulebook
         nbw, npw = ctypes.c_size_t(), ctypes.c_size_t()
         L.check(lib.pcd_voxelize_hard_sorted_rank_words(batch, L.host_f32(point_cloud_range), L.host_f32(voxel_size),
                                                         int(key_depth), ctypes.byref(nbw), ctypes.byref(npw)),
@@ -275,11 +272,8 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         return dict(bytes=24 * n + 36 * m_ + (104 * m_ if want_voxels else 0), flops=0, rows=m_, pairs=0)
 
     with _Timed("voxelize_hard", meta):
-        extra = (int(key_depth), L.ptr(rank_bm), L.ptr(rank_px)) if row_order == "key" else ()
-        head = ()
-        if phase:
-            entry, head = lib.pcd_voxelize_hard_sorted_phase, (int(phase),)
-        L.check(entry(*head, L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
+        extra = (int(key_depth), ROW_ORDERS[row_order], L.ptr(rank_bm), L.ptr(rank_px)) if keyed else ()
+        L.check(entry(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
                       L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
                       max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
                       L.ptr(mean16), mean_bf16_stride, L.ptr(counts), *extra, L.ptr(ws), ws.numel(),
@@ -289,12 +283,12 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]
-        if phase != 1:
-            PLAN.record("voxels", num_rows, cap)
+        PLAN.record("voxels", num_rows, cap)
         return dict(voxels=voxels, coords=coords, num_points=nump, voxel_features=mean,
                     voxel_features_bf16=mean16, counts=counts, num_rows=num_rows, rank_bitmap=rank_bm,
-                    rank_prefix=rank_px, _own_ws=(out or {}).get("_own_ws"),
-                    rank=RankMap(None, rank_bm, rank_px, coords, [gz, gy, gx], 4) if rank_bm is not None else None)
+                    rank_prefix=rank_px,
+                    rank=RankMap(None, rank_bm, rank_px, coords, [gz, gy, gx], 4, ROW_ORDERS[row_order])
+                    if rank_bm is not None else None)
     host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
     m = host_counts[-1]
     if PLAN is not None:
@@ -303,7 +297,8 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     return dict(num_rows=None,voxels=voxels[:m] if want_voxels else None, coords=coords_m, num_points=nump[:m],
                 voxel_features=mean[:m] if want_mean else None,
                 voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1],
-                rank=RankMap(None, rank_bm, rank_px, coords_m, [gz, gy, gx], 4) if rank_bm is not None else None)
+                rank=RankMap(None, rank_bm, rank_px, coords_m, [gz, gy, gx], 4, ROW_ORDERS[row_order])
+                if rank_bm is not None else None)
 
 
 def mean_vfe(voxels, num_points):
@@ -429,6 +424,7 @@ class Rulebook:
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.rank = None          # RankMap of the output level (strided builds only)
+        self.order = None         # ROWS_* of the output rows when they are key-numbered (strided / rank-map builds)
         self.classes = None       # (perm, vstart, vcap): input rows grouped by stride-parity class (strided, training)
 
     def _lazy_pairs(self):
@@ -483,9 +479,10 @@ class RankMap:
     + exclusive popcount prefix (row id = rank of the linear key).  Views into the build's workspace, which this
     object keeps alive.  `indices` is the out_indices tensor the ranks refer to."""
 
-    def __init__(self, ws, bitmap, prefix, indices, shape, prefix_words=1):
+    def __init__(self, ws, bitmap, prefix, indices, shape, prefix_words=1, order=ROWS_ZYX):
         self.ws, self.bitmap, self.prefix, self.indices, self.shape = ws, bitmap, prefix, indices, list(shape)
         self.prefix_words = prefix_words      # 1: one prefix per bitmap word; 4: pcd_voxelize_hard_sorted's map
+        self.order = order                    # ROWS_ZYX / ROWS_YXZ: the linear key the ranks were taken over
 
     def matches(self, indices, shape, ks):
         return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
@@ -516,19 +513,24 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
             L.check(entry(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
                           L.host_i32(dl), L.ptr(rank.bitmap), L.ptr(rank.prefix), L.ptr(nbr),
                           L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev),
-                          L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm_ranked")
+                          L.ptr(ws), ws.numel(), L.stream_ptr(), int(rank.order)), "pcd_rulebook_subm_ranked")
     else:
         ws = _ws(lib.pcd_rulebook_subm_workspace_bytes(n, K), dev)
         with _Timed("rulebook_subm", meta):
             L.check(lib.pcd_rulebook_subm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.host_i32(ks),
                                           L.host_i32(dl), L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs),
                                           L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_subm")
-    return Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
-                    [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
+    rb = Rulebook(True, K, n, n, nbr, None, pairs, pair_num, indices, shp, ks, [1, 1, 1],
+                  [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
+    if rank is not None and rank.matches(indices, shp, ks):
+        rb.order = rank.order
+    return rb
 
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
-                  pad_pairs=False, n_dev=None, plan_key=None):
+                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX):
+    """`order`: how the OUTPUT rows are numbered (ROWS_ZYX: ascending (b, z, y, x), spconv's sorted order; ROWS_YXZ:
+    ascending (b, y, x, z)); the input rows may come in any order."""
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -575,12 +577,14 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
             L.check(lib.pcd_rulebook_conv_build(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(n_out_dev),
                                                 L.ptr(out_indices), L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs),
                                                 L.ptr(pair_num), int(pad_pairs), CLS_TILE, L.ptr(perm), vcap,
-                                                L.ptr(vstart), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                                L.ptr(vstart), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr(),
+                                                int(order)),
                     "pcd_rulebook_conv_build")
     else:
         with _Timed("rulebook_conv_count", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
             L.check(lib.pcd_rulebook_conv_count(L.ptr(indices), n, batch_size, *args, L.ptr(n_out_dev), L.ptr(n_dev),
-                                                L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_rulebook_conv_count")
+                                                L.ptr(ws), ws.numel(), L.stream_ptr(), int(order)),
+                    "pcd_rulebook_conv_count")
         if static:
             n_out = PLAN.cap(plan_key)         # capacity; the real count stays in n_out_dev (no host sync)
             PLAN.record(plan_key, n_out_dev, n_out)
@@ -592,7 +596,8 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
         with _Timed("rulebook_conv_fill", meta):
             L.check(lib.pcd_rulebook_conv_fill(L.ptr(indices), n, batch_size, *args, n_out, L.ptr(out_indices),
                                                L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num),
-                                               int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                               int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr(),
+                                               int(order)),
                     "pcd_rulebook_conv_fill")
     rb = Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st,
                   pd, dl, n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
@@ -603,7 +608,8 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
                                               ctypes.byref(nwords)), "pcd_rulebook_conv_rank_layout")
     nw = int(nwords.value)
     rb.rank = RankMap(ws, ws[boff.value:boff.value + 4 * nw].view(torch.int32),
-                      ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape)
+                      ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape, 1, order)
+    rb.order = order
     if classes is not None:
         rb.classes = classes
     elif want_pairs and ncls <= 8:

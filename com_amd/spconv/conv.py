@@ -150,7 +150,9 @@ class SparseConvolution(SparseModule):
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, n_dev=x.num_rows,
                                    want_pairs=self._needs_backward(x),   # (pair lists / parity classes: backward only)
-                                   plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)))
+                                   plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)),
+                                   # the chain's row order (set by the backbone from the voxeliser's rank map)
+                                   order=x.indice_dict.get("__row_order__", ops.ROWS_ZYX))
             out_idx, out_shape = rb.out_indices, rb.out_shape
             if rb.rank is not None:
                 x.indice_dict[("__rank__", out_idx.data_ptr())] = rb.rank

@@ -43,6 +43,17 @@ extern "C" {
 #define PCD_F32 0
 #define PCD_BF16 1
 
+/* Row order of a sparse level whose rows are numbered by a linear coordinate key (the key-ordered voxeliser, the strided
+ * rulebook builds and the rank-map SubM builds take it as `row_order`).  Every consumer of the path is invariant to the
+ * order (spconv itself numbers GPU-built levels by hash / atomics order); the VOXEL SETS and, through the row permutation,
+ * the rulebooks are identical in both.
+ *   PCD_ROWS_ZYX  key = ((b*D + z)*H + y)*W + x   x fastest -- spconv's / torch.unique's sorted order
+ *   PCD_ROWS_YXZ  key = ((b*H + y)*W + x)*D + z   z fastest: the voxels of a BEV column are consecutive rows and the 27
+ *                 neighbours of a run of rows lie in three short runs of rows (BEV rows y-1, y, y+1) -- what the window
+ *                 gather-GEMM (pcd_sparse_conv_subm_window) stages in LDS */
+#define PCD_ROWS_ZYX 0
+#define PCD_ROWS_YXZ 1
+
 /* ---- library info -------------------------------------------------------------------------- */
 int pcd_version(void);                    /* 10000*major + 100*minor + patch */
 const char *pcd_error_string(int code);
@@ -94,9 +105,10 @@ int pcd_voxelize_hard(const float *points, int n_points, int point_stride, int f
  *   that receive the coordinate -> row map of the output -- bit (key) of rank_bitmap set for every kept voxel,
  *   rank_prefix[g] = number of set bits in front of the 128-bit group g -- the map pcd_rulebook_subm_ranked4 builds the
  *   level-1 SubM rulebook from (no hash table).  NULL: the map lives in the workspace and dies with the call.
- *   key_depth: z extent of the key space, key = ((b * key_depth + z) * gy + y) * gx + x; 0 = gz.  The 3D backbones use
+ *   key_depth: z extent D of the key space (PCD_ROWS_* above with H = gy, W = gx); 0 = gz.  The 3D backbones use
  *   sparse_shape = grid_size[::-1] + [1, 0, 0] (spconv_backbone.py:87,187): pass gz + 1 so that the map has the layout
- *   the rulebook of that shape addresses.  The row ORDER does not depend on it. */
+ *   the rulebook of that shape addresses.  The row ORDER does not depend on it.
+ *   row_order: PCD_ROWS_ZYX / PCD_ROWS_YXZ. */
 size_t pcd_voxelize_hard_sorted_workspace_bytes(int n_points, int max_points, int batch,
                                                 const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
                                                 int key_depth);
@@ -107,20 +119,8 @@ int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride
                              const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
                              int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
                              int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
-                             int32_t *voxel_counts, int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
-                             void *workspace, size_t workspace_bytes, void *stream);
-/* The same call in two halves for a training loop that wants the voxelisation of the NEXT batch off its tail: phase 1 = the
- * part that touches only `workspace` (hash insert + first-flag scan: ~half of the chain), phase 2 = the rest (bitmap, ranks,
- * emit) on the SAME workspace, which nothing may touch in between; phase 0 = the whole call.  Key order with at most 8
- * frames only (PCD_ERR_UNSUPPORTED otherwise).  Results are identical to the one-call form. */
-int pcd_voxelize_hard_sorted_phase(int phase, const float *points, int n_points, int point_stride, int feat_offset,
-                             int num_features, const int32_t *frame_offsets, int batch,
-                             const float *range_host /*[6]*/, const float *vsize_host /*[3]*/,
-                             int max_points, int max_voxels, int cap, float *voxels, int32_t *coords,
-                             int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
-                             int32_t *voxel_counts, int key_depth, uint32_t *rank_bitmap, int32_t *rank_prefix,
-                             void *workspace, size_t workspace_bytes, void *stream);
-
+                             int32_t *voxel_counts, int key_depth, int row_order, uint32_t *rank_bitmap,
+                             int32_t *rank_prefix, void *workspace, size_t workspace_bytes, void *stream);
 /* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
 int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
                  int num_features, float *out, void *stream);
@@ -176,8 +176,8 @@ int pcd_rulebook_subm(const int32_t *indices, int n, int batch, const int *shape
  * (a9) SparseConv3d (strided) rulebook -- replaces get_indice_pairs(subm=False) behind
  *      spconv.SparseConv3d (spconv_backbone.py:14-15,205-229).  Two phases because the number of
  *      output rows is data dependent:
- *   phase 1 `_count`: marks the active output cells, ranks them (sorted by linear key
- *           ((b*D+z)*H+y)*W+x) and writes n_out to n_out_dev[0]; state lives in `workspace`.
+ *   phase 1 `_count`: marks the active output cells, ranks them (sorted by the linear key of
+ *           `row_order`, PCD_ROWS_*) and writes n_out to n_out_dev[0]; state lives in `workspace`.
  *   phase 2 `_fill` : (after the caller read n_out and allocated) emits
  *           out_indices [n_out][4], nbr_in [K][n] (output row fed by input i, or -1),
  *           nbr_out [K][n_out] (input row feeding output o, or -1),
@@ -193,12 +193,13 @@ int pcd_conv_out_shape(const int *in_shape_host, const int *ksize_host, const in
 int pcd_rulebook_conv_count(const int32_t *indices, int n, int batch, const int *in_shape_host,
                             const int *ksize_host, const int *stride_host, const int *pad_host,
                             const int *dil_host, int32_t *n_out_dev, const int32_t *n_dev, void *workspace,
-                            size_t workspace_bytes, void *stream);
+                            size_t workspace_bytes, void *stream, int row_order);
 int pcd_rulebook_conv_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
                            const int *ksize_host, const int *stride_host, const int *pad_host,
                            const int *dil_host, int n_out, int32_t *out_indices, int32_t *nbr_in,
                            int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
-                           const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+                           const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream,
+                           int row_order);
 
 /* Both phases (+ the parity classes of pcd_rulebook_conv_classes when perm != NULL) in ONE call for callers that
  * bound the number of output rows on the host (`n_out_cap`: buffers are sized for it, rows beyond it are dropped and
@@ -212,7 +213,7 @@ int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch, const int 
                             const int *dil_host, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices,
                             int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                             int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            void *workspace, size_t workspace_bytes, void *stream, int row_order);
 
 /* indice_pairs / indice_pair_num of a SubM rulebook from its nbr table [kvol][n] alone -- for rulebooks built with
  * pairs == NULL (the forward and the output-stationary kernels only need nbr) whose pairs are wanted later. */
@@ -238,12 +239,12 @@ int pcd_rulebook_subm_ranked4(const int32_t *indices, int n, int batch, const in
                               const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                               const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                               int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
-                              void *stream);
+                              void *stream, int row_order);
 int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int *shape_host,
                              const int *ksize_host, const int *dil_host, const uint32_t *bitmap,
                              const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                              int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             void *stream, int row_order);
 
 /* Optional per-channel reductions of the OUTPUT tile in the epilogue of pcd_sparse_conv_gather_gemm /
  * pcd_sparse_conv_dgrad_classes (bf16 outputs only; NULL or mode 0 = off).  The BatchNorm1d that follows every conv of
@@ -706,7 +707,14 @@ int pcd_pfn_relu_pool_backward(const float *grad_out, const float *x, const int3
  *                nms_normal_gpu).  keep = int64[num_boxes] receives the kept indices in ascending order,
  *                *num_keep_dev (device int32) their number; both stay on the device (the reference returns the
  *                count through a host loop over a mask it copies back).  workspace: pcd_nms_workspace_bytes(n).
+ *   pcd_boxes_iou_bev_host: the reference's CPU variant boxes_iou_bev_cpu (iou3d_nms_utils.py:12-28 ->
+ *                src/iou3d_cpu.cpp:232-252), called by COMAug's database sampler per frame inside DataLoader workers
+ *                (datasets/augmentor/database_sampler_v2.py:600-601).  HOST pointers, synchronous, touches no GPU state
+ *                (safe in forked workers); out_host = [num_a][num_b] f32 IoU.  Same float arithmetic as the reference
+ *                file, bit for bit (fixture G13).
  * ============================================================================================ */
+int pcd_boxes_iou_bev_host(const float *boxes_a_host, int num_a, const float *boxes_b_host, int num_b,
+                           float *out_host);
 int pcd_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b, float *out, int want_iou,
                           void *stream);
 size_t pcd_nms_workspace_bytes(int num_boxes);

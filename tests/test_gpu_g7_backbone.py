@@ -83,19 +83,22 @@ def _reset_bn(net):
             m.running_var.fill_(1.0)
 
 
-def _key_order(idx):
+def _key_order(idx, mode=True):
+    if mode == "yxz":                                # (b, y, x, z): z fastest (PCD_ROWS_YXZ)
+        return np.lexsort((idx[:, 1], idx[:, 3], idx[:, 2], idx[:, 0]))
     return np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))
 
 
 def _check_against_g7(g, net, bd, sf, loss, n_real=None, key_order=False):
     """n_real: not None when the tensors are padded to capacities (static-shape mode).
     key_order: the voxeliser numbered its rows by (b, z, y, x) (pcd_voxelize_hard_sorted, what bench.py runs): the
-    fixture's level-1 rows are compared in that order (deeper levels are key-ordered in both)."""
+    fixture's level-1 rows are compared in that order (deeper levels are key-ordered in both).  "yxz": the whole chain
+    numbers its rows by (b, y, x, z) (PCD_ROWS_YXZ) -- every level of the fixture is compared through that permutation."""
     report, fails = {}, []
     coords = bd["voxel_coords"]
     m = g["coords"].shape[0] if n_real is not None else coords.shape[0]
     np.testing.assert_array_equal(coords[:m].cpu().numpy(),
-                                  g["coords"][_key_order(g["coords"])] if key_order else g["coords"])
+                                  g["coords"][_key_order(g["coords"], key_order)] if key_order else g["coords"])
     taps = dict(bd["multi_scale_3d_features"])
     taps["out"] = bd["encoded_spconv_tensor"]
     for name, t in taps.items():
@@ -105,8 +108,8 @@ def _check_against_g7(g, net, bd, sf, loss, n_real=None, key_order=False):
             assert t.indices.shape[0] == n, (name, t.indices.shape, n)
         else:
             assert int(t.num_rows.item()) == n and t.indices.shape[0] >= n
-        order = _key_order(want_idx) if key_order else np.arange(n)
-        if name != "x_conv1":
+        order = _key_order(want_idx, key_order) if key_order else np.arange(n)
+        if name != "x_conv1" and key_order != "yxz":
             assert np.array_equal(order, np.arange(n))      # rows of strided convs are key-ordered already
         np.testing.assert_array_equal(t.indices[:n].cpu().numpy(), want_idx[order])   # bit-exact row set AND order
         assert list(t.spatial_shape) == list(g["shape_" + name])
@@ -115,7 +118,7 @@ def _check_against_g7(g, net, bd, sf, loss, n_real=None, key_order=False):
         e_hip, e_emu = _rel(f, exact), _rel(emul, exact)
         report[name] = (round(e_hip, 5), round(e_emu, 5), round(_rel(f, emul), 5))
         fails += [(name, e_hip, e_emu)] if e_hip > NOISE_FACTOR * e_emu else []
-    o1 = _key_order(g["idx_x_conv1"]) if key_order else np.arange(g["idx_x_conv1"].shape[0])
+    o1 = _key_order(g["idx_x_conv1"], key_order) if key_order else np.arange(g["idx_x_conv1"].shape[0])
     if _rel(taps["x_conv1"].features[:g["idx_x_conv1"].shape[0]].detach().float().cpu().numpy(),
             g["bf16_x_conv1"][o1]) > FIRST_TAP_TOL:
         fails.append(("x_conv1 vs bf16 chain", report["x_conv1"]))
@@ -181,6 +184,20 @@ def test_g7_key_ordered_voxel_rows_end_to_end(golden):
     torch.cuda.synchronize()
     rep = _check_against_g7(g, net, bd, sf.detach(), loss.detach(), key_order=True)
     print("G7 key-ordered rows:", rep)
+
+
+def test_g7_yxz_rows_end_to_end(golden):
+    """The whole chain in the z-fastest row order (PCD_ROWS_YXZ: voxeliser, every strided build, every rank-map SubM
+    rulebook): the same voxel sets at every level -- compared with the fixture through the row permutation, bit-exact --
+    and the same features / BEV map / loss / gradients within the same bounds."""
+    g = golden("g7_backbone")
+    net, bev = _build()
+    pts, offs = _inputs(g)
+    proj = torch.from_numpy(P7.loss_projection(P7.BATCH * 256 * 12 * 12)).to(DEV).view(P7.BATCH, 256, 12, 12)
+    bd, sf, loss = _step(net, bev, pts, offs, proj, row_order="yxz")
+    torch.cuda.synchronize()
+    rep = _check_against_g7(g, net, bd, sf.detach(), loss.detach(), key_order="yxz")
+    print("G7 yxz rows:", rep)
 
 
 def test_g7_fp32_exact_path_end_to_end_within_1e3(golden):

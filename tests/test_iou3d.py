@@ -89,6 +89,24 @@ def test_oracle_iou_is_bit_identical_to_the_reference_fixture_g13():
     assert (g["iou_ab"] > 0).mean() > 0.1 and g["iou_ab"].size >= 10000
 
 
+def test_product_boxes_bev_iou_cpu_is_bit_identical_to_the_reference_fixture_g13():
+    """com_amd.iou3d_nms.boxes_bev_iou_cpu (the library's HOST entry point pcd_boxes_iou_bev_host -- product code, no
+    oracle involved) against the outputs of the reference's compiled iou3d_cpu.cpp (G13): bit for bit; numpy in ->
+    numpy out, CPU tensor in -> tensor out (iou3d_nms_utils.py:12-28); the COMAug call pattern
+    (database_sampler_v2.py:600-603: an empty second operand)."""
+    import torch
+    from com_amd import iou3d_nms
+    g = _g13()
+    got = iou3d_nms.boxes_bev_iou_cpu(g["boxes_a"], g["boxes_b"])
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32
+    np.testing.assert_array_equal(got, g["iou_ab"])
+    got_t = iou3d_nms.boxes_bev_iou_cpu(torch.from_numpy(g["boxes_d"]), torch.from_numpy(g["boxes_d"]))
+    assert torch.is_tensor(got_t)
+    np.testing.assert_array_equal(got_t.numpy(), g["iou_dd"])
+    assert iou3d_nms.boxes_bev_iou_cpu(g["boxes_a"][:5], g["boxes_b"][:0]).shape == (5, 0)
+    assert iou3d_nms.boxes_bev_iou_cpu(g["boxes_a"][3:9, 0:7], np.ascontiguousarray(g["boxes_b"][::7])).shape[0] == 6
+
+
 @pytest.mark.skipif(not O.ref_iou3d_available(), reason="oracle/_ref/libiou3d_ref.so not built (needs /root/reference)")
 def test_oracle_iou_against_the_compiled_reference_on_fresh_boxes():
     rng = np.random.default_rng(131)
