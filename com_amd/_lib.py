@@ -26,6 +26,8 @@ PROTOTYPES = {
     "pcd_build_arch": (ctypes.c_char_p, []),
     "pcd_last_hip_error_string": (ctypes.c_char_p, []),
     "pcd_set_last_hip_error": (None, [_i]),
+    "pcd_set_option": (_i, [ctypes.c_char_p, _i]),
+    "pcd_get_option": (_i, [ctypes.c_char_p, _vp]),
     "pcd_voxelize_hard_workspace_bytes": (_sz, [_i, _i, _i]),
     "pcd_voxelize_hard": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                _i, _vp, _vp, _sz, _vp]),
@@ -249,7 +251,23 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        # experiment scripts pass tuning options through the environment: PCD_OPT_<KEY>=<int> -> pcd_set_option (the
+        # library itself reads no environment variable)
+        for k, v in os.environ.items():
+            if k.startswith("PCD_OPT_"):
+                if handle.pcd_set_option(k[8:].lower().encode(), int(v)) != 0:
+                    raise PcdError(f"unknown tuning option {k}")
     return _lib
+
+
+def set_option(key, value):
+    check(lib().pcd_set_option(key.encode(), int(value)), f"pcd_set_option({key})")
+
+
+def get_option(key):
+    v = ctypes.c_int(0)
+    check(lib().pcd_get_option(key.encode(), ctypes.byref(v)), f"pcd_get_option({key})")
+    return int(v.value)
 
 
 def check(code, what):

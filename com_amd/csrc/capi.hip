@@ -38,3 +38,36 @@ extern "C" int pcd_stream_capture_id(void *stream, unsigned long long *id_out) {
     *id_out = st == hipStreamCaptureStatusActive ? (id ? id : 1ull) : 0ull;
     return PCD_OK;
 }
+
+// ---- tuning options (pcd_ops.h) ----------------------------------------------------------------------------------
+#include <string.h>
+namespace {
+struct OptRow {
+    const char *key;
+    int value;
+};
+OptRow g_opts[PCD_OPT_COUNT] = {
+    {"gg_resident_kb", 32}, {"ggw", 1}, {"gg1", 1}, {"subm_window", 1}, {"wg128", 1}, {"wg128_chunks", 512},
+    {"wg_rows", 6144}, {"conv2d_wb", 1}, {"conv2d_wg_blocks", 128}, {"conv2d_wgp_mode2", 0}, {"conv2d_wgp_blocks", 512},
+    {"fps_g", 0}, {"gg_dbg", 0}, {"ggw_dbg", 0}, {"win_dbg", 0},
+};
+}  // namespace
+int pcd_opt(int which) { return g_opts[which].value; }
+extern "C" int pcd_set_option(const char *key, int value) {
+    if (!key) return PCD_ERR_INVALID_ARG;
+    for (int i = 0; i < PCD_OPT_COUNT; ++i)
+        if (strcmp(key, g_opts[i].key) == 0) {
+            g_opts[i].value = value;
+            return PCD_OK;
+        }
+    return PCD_ERR_INVALID_ARG;
+}
+extern "C" int pcd_get_option(const char *key, int *value_out) {
+    if (!key || !value_out) return PCD_ERR_INVALID_ARG;
+    for (int i = 0; i < PCD_OPT_COUNT; ++i)
+        if (strcmp(key, g_opts[i].key) == 0) {
+            *value_out = g_opts[i].value;
+            return PCD_OK;
+        }
+    return PCD_ERR_INVALID_ARG;
+}

@@ -933,7 +933,7 @@ extern "C" int pcd_conv2d_3x3_nhwc_bn(const void *x, int x_cs, int batch, int he
     const double xb = ((double)batch * height * width - 1) * x_cs * 2 + (double)cin * 2;
     if (xb >= 4294966000.0) return PCD_ERR_UNSUPPORTED;
     const size_t wb_bytes = (size_t)((cout + 63) / 64) * (cin / 32) * W_BYTES;   // bytes of the pack the kernel reads
-    static const int wb = getenv("PCD_CONV2D_WB") ? atoi(getenv("PCD_CONV2D_WB")) : 1;   // (1: 28-35 % of the MFMA peak, 2: 21-27 %)
+    const int wb = pcd_opt(PCD_OPT_CONV2D_WB);   // (1: 28-35 % of the MFMA peak, 2: 21-27 %)
     const size_t lds = 2 * (size_t)IN_BYTES + (size_t)(wb == 1 ? 1 : 2) * (size_t)W_BYTES;
     static bool raised = false;
     if (!raised) {
@@ -1029,7 +1029,7 @@ extern "C" int pcd_conv2d_wgrad_3x3_splits(int batch, int height, int width, int
     if (batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || cin % 64 || cout % 32) return 0;
     const int tiles = batch * ((height + WG_TH - 1) / WG_TH) * ((width + WG_TW - 1) / WG_TW);
     const int chunks = (cin / 64) * (cout % 64 == 0 ? cout / 64 : cout / 32);
-    static const int target = getenv("PCD_CONV2D_WG_BLOCKS") ? atoi(getenv("PCD_CONV2D_WG_BLOCKS")) : 128;
+    const int target = pcd_opt(PCD_OPT_CONV2D_WG_BLOCKS);
     // about 128 workgroups per launch: measured in the full step (tools/exp_wgblocks.sh) 64 / 96 / 128 / 192 / 256 / 512 /
     // 1024 -> 8.75 / 8.11 / 7.86 / 7.89 / 7.96 / 8.21 / 8.50 ms -- the kernel runs BESIDE the data-gradient chain: fewer, longer
     // workgroups leave that chain half of the CUs and write fewer slabs
@@ -1080,11 +1080,11 @@ extern "C" int pcd_conv2d_wgrad_planes_splits(int mode, int batch, int hc, int w
         return 0;
     // mode 2 (stride-2 conv: 9 accumulator sets + 4 plane stagings per tile, one workgroup per CU) measures SLOWER than the
     // pair kernels over dense pair lists (99-152 vs 80 us, tools/exp_wgrad_planes.py): not offered unless asked for
-    static const int mode2 = getenv("PCD_CONV2D_WGP_MODE2") ? atoi(getenv("PCD_CONV2D_WGP_MODE2")) : 0;
+    const int mode2 = pcd_opt(PCD_OPT_CONV2D_WGP_MODE2);
     if (mode == 2 && !mode2) return 0;
     const int tiles = batch * ((hc + WG_TH - 1) / WG_TH) * ((wc + WG_TW - 1) / WG_TW);
     const int chunks = (cf / 64) * (cc % 64 == 0 ? cc / 64 : cc / 32);
-    static const int target = getenv("PCD_CONV2D_WGP_BLOCKS") ? atoi(getenv("PCD_CONV2D_WGP_BLOCKS")) : 512;
+    const int target = pcd_opt(PCD_OPT_CONV2D_WGP_BLOCKS);
     int splits = (target + chunks - 1) / chunks;
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;

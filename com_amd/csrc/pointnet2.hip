@@ -188,8 +188,8 @@ __global__ __launch_bounds__(1024) void stack_fps_kernel(const float *__restrict
 // local farthest point, publishes (distance, index) and meets the others at a per-frame barrier (a monotonic
 // arrival counter, agent scope); every workgroup then reduces the G candidates itself.  The argmax key is the TOTAL
 // order fps_better (distance, then the reference tree's bit-reversed thread id, then the index), so the selected points
-// are the reference's whatever the partition.  All B x G workgroups must be resident at once (the host keeps
-// B x G <= 256 with one workgroup per CU); the spin is bounded and raises `err` instead of hanging the device.
+// are the reference's whatever the partition.  All B x G workgroups must be resident at once (the host sizes G from the
+// device's CU count and the occupancy query); the spin is bounded and raises `err` instead of hanging the device.
 constexpr int FPS_COOP_MAXG = 64;
 
 __global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ xyz_cnt,
@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__rest
     __shared__ float wd[4];
     __shared__ int wk[4];
     __shared__ int old_s;
-    const int b = blockIdx.x / G, gi = blockIdx.x - b * G;
+    // frame -> workgroups: blockIdx = gi * B + b.  Workgroup i runs on XCD i % 8 (observed; speed only), so a frame's G
+    // workgroups sit on the XCDs {b, b + B, ..} mod 8 -- two of the eight at B = 4, one at B = 8 -- instead of all eight:
+    // most of the per-iteration candidate exchange stays inside one XCD's L2.
+    const int Bf = (int)gridDim.x / G;
+    const int b = blockIdx.x % Bf, gi = blockIdx.x / Bf;
     int start = 0, ostart = 0;
     for (int k = 0; k < b; ++k) {
         start += xyz_cnt[k];
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void stack_fps_coop_kernel(const float *__rest
         }
         __syncthreads();
         old = old_s;
-        if (*err) return;                                               // (uniform enough: everyone leaves within an iteration)
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (everyone leaves within an iteration)
     }
 }
 
@@ -504,27 +508,37 @@ extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, c
     PCD_ENTER();
     if (B <= 0 || !xyz || !xyz_batch_cnt || !idxs || !num_sampled_points || max_cnt_host <= 0) return PCD_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < pcd_stack_fps_coop_workspace_bytes(B)) return PCD_ERR_WORKSPACE;
-    int G = 256 / B;
+    // All B x G workgroups spin on each other: they must be CO-RESIDENT.  G comes from the device the call runs on -- its
+    // CU count and what the occupancy query admits per CU for this kernel's LDS footprint -- never from a constant; one
+    // workgroup per CU is the design point (the slice of a frame lives in LDS), and a quarter of the CUs is left to whatever
+    // else the caller has in flight on other streams.  (The spin is bounded: if residency still fails, `err` is raised and
+    // the caller re-runs the one-workgroup kernel.)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return PCD_ERR_LAUNCH;
+    int G = cus / B;
     if (G > FPS_COOP_MAXG) G = FPS_COOP_MAXG;
-    static const int g_env = getenv("PCD_FPS_G") ? atoi(getenv("PCD_FPS_G")) : 0;   // (experiments: workgroups per frame)
-    if (g_env >= 2 && g_env <= G) G = g_env;
+    const int g_opt = pcd_opt(PCD_OPT_FPS_G);   // (experiments: workgroups per frame)
+    if (g_opt >= 2 && g_opt <= G) G = g_opt;
     if (G < 2) return PCD_ERR_UNSUPPORTED;
     const int slice_cap = pcd_div_up(max_cnt_host, G);
     const size_t lds = (size_t)slice_cap * 16;
     if (lds > 96 * 1024 || max_cnt_host > (1 << 20)) return PCD_ERR_UNSUPPORTED;   // (one workgroup per CU; 20-bit indices)
+    if (lds > 64 * 1024 &&      // per call: the attribute is per device and the call is idempotent (no process-wide cache)
+        hipFuncSetAttribute((const void *)stack_fps_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PCD_ERR_LAUNCH;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stack_fps_coop_kernel, 256, lds) != hipSuccess)
+        return PCD_ERR_LAUNCH;
+    if (per_cu < 1 || (long long)B * G > (long long)cus * (per_cu < 8 ? per_cu : 8))
+        return PCD_ERR_UNSUPPORTED;            // the grid cannot be resident at once on this device
     hipStream_t st = (hipStream_t)stream;
     char *w = (char *)workspace;
     unsigned long long *cand = (unsigned long long *)w;
     unsigned *counters = (unsigned *)(w + ws_piece((size_t)B * 2 * FPS_COOP_MAXG, sizeof(unsigned long long)));
     int *err = (int *)((char *)counters + ws_piece((size_t)B * 32, sizeof(unsigned)));
     pcd_fill(workspace, 0, pcd_stack_fps_coop_workspace_bytes(B), st);   // candidate tags 0 (no iteration has tag 0 before j = 4096), err = 0
-    static size_t raised = 0;
-    if (raised < lds) {
-        if (hipFuncSetAttribute((const void *)stack_fps_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return PCD_ERR_LAUNCH;
-        raised = lds;
-    }
     stack_fps_coop_kernel<<<B * G, 256, lds, st>>>(xyz, xyz_batch_cnt, idxs, num_sampled_points, G, slice_cap, cand, counters,
                                                   err);
     PN2_CHECK_LAUNCH();

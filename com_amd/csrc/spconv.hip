@@ -18,8 +18,6 @@
 // gfx950 transpose read ds_read_b64_tr_b16 (the contraction index = pair index is the slow axis of
 // both row-major tiles).  Waves of a workgroup split the pair range, are reduced through LDS in a
 // fixed order, written to per-split slabs and summed by a second kernel: deterministic, no atomics.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -637,7 +635,7 @@ static int launch_gg(const void *x, int c_in, int cshift, const void *wp, const 
     size_t wbytes = SG > 0 ? (size_t)2 * SG * NB * 64 * sizeof(uint4) : (size_t)nsteps * NB * 64 * sizeof(uint4);
     size_t lds = wbytes + (size_t)(K + 1) * ROWS * sizeof(int) + (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
-    static const int dbg = getenv("PCD_GG_DBG") ? atoi(getenv("PCD_GG_DBG")) : 0;  // ablation switches
+    const int dbg = pcd_opt(PCD_OPT_GG_DBG);   // ablation switches (0 in production)
     auto kb = gather_gemm_kernel<NB, MI, G, SG, true, WN>;
     auto kf = gather_gemm_kernel<NB, MI, G, SG, false, WN>;
     if (lds > 64 * 1024) {
@@ -930,7 +928,7 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
     const size_t lds = (size_t)R * (2 * NB * 1024) + (size_t)4 * R * (MI * 2048) + (size_t)(K + 1) * ROWS * sizeof(int) +
                        (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
-    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;   // ablation switches
+    const int dbg = pcd_opt(PCD_OPT_GGW_DBG);   // ablation switches (0 in production)
     auto kb = ggw_kernel<NB, SOFF, MI, R, true>;
     auto kf = ggw_kernel<NB, SOFF, MI, R, false>;
     if (lds > 64 * 1024) {
@@ -949,942 +947,6 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
     else
         kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
                                    n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// WINDOW gather-GEMM for SubM 3x3x3 layers with C_in = 64 over KEY-ORDERED rows (rows numbered by ascending (b, z, y, x),
-// which every level of the hot path is): the inputs a tile of consecutive output rows needs at the 9 offsets that share
-// dz are (almost always) ONE contiguous run of input rows -- the lines (z + dz, y - 1 .. y + 1) are neighbours in row
-// space -- about 1.2-1.5 x the tile.  So instead of 27 gathers per output row (27 x 128 B through the texture-address
-// unit, the bound of gather_gemm_kernel / ggw_kernel) the loader waves DMA three WINDOWS of contiguous rows into LDS once
-// per tile (coalesced 1-KiB instructions, 1.75 x ROWS rows each, XOR-swizzled like ggw's gather image) and the consumers
-// address their MFMA operands through the rulebook tile: operand row = nbr - window_lo.  A missing neighbour reads a
-// zero row; a neighbour outside its window (rows of a tile that straddles a frame / z boundary, very long lines) is
-// loaded straight from global memory by the lanes concerned (exec-masked, rare).  Weights stream through the same ring
-// of stages as in ggw_kernel -- they are now the larger part of the DMA traffic.
-// Same operands, same MFMA sequence per output element (offsets ascending) as the other two kernels -> bit-identical.
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int NB, int MI, int R, bool OUT_BF16>
-__global__ __launch_bounds__(512, (MI == 1 ? 4 : 1)) void ggwin_kernel(
-    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
-    int n_in, void *__restrict__ yv, unsigned x_bytes, unsigned w_bytes, const void *__restrict__ addend, BnRed bn,
-    int dbg) {
-    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
-    constexpr int K = 27, GRP = 9;
-    constexpr int ROWS = 64 * MI;
-    constexpr int WCAP = (ROWS * 3 / 2 + 31) / 32 * 32;    // window rows (multiple of 4 loaders x 8 rows)
-    constexpr int WIN_B = WCAP * 128;                      // bytes per window
-    constexpr int WINI = WCAP / 32;                        // window DMA instructions per loader and window
-    constexpr int WFR = 2 * NB;                            // 1-KiB weight fragments per stage
-    constexpr int WPW = WFR / 4;                           // ... per loader
-    constexpr int W_STAGE = WFR * 1024;
-    constexpr int c_out = NB * 16;
-    static_assert(R % 2 == 0 && (R - 2) * WPW < 64, "ring depth: even (slot parity = operand register set), vmcnt field");
-    const int n_out = eff_rows(n_out_dev, n_out_cap);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *wring = smem;                                    // [R][W_STAGE]
-    char *win = smem + R * W_STAGE;                        // [3][WCAP][128 B]
-    char *zero_row = win + 3 * WIN_B;                      // 128 B of zeros (missing neighbours)
-    int *nbr_s = (int *)(zero_row + 128);                  // [K + 1][ROWS]
-    int *bounds = nbr_s + (K + 1) * ROWS;                  // [3] window lo
-    float *red_s = (float *)(bounds + 8);                  // [4][2][c_out], only with bn.mode
-
-    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;
-    const int lane = threadIdx.x & 63;
-    const int rl = lane & 15, g = lane >> 4;
-    const int tile = xcd_tile(n_out, ROWS);
-    const int r0wg = tile * ROWS;
-    if (r0wg >= n_out) {
-        if (bn.mode) bnred_zero_row(bn, tile, c_out);
-        return;
-    }
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
-    const int wrow0 = wave * (MI * 16);
-    constexpr int T = K;                                   // stages (one per offset: C_in = 64 = 2 contraction steps)
-    constexpr int NIT = (T + R - 1) / R * R;               // steps of both roles (stages >= T are no-ops)
-
-    if (loader) {
-        // ------------------------------------------------------------------------------------------- loader
-        if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
-        auto fire = [&](int stage, auto slot_tag) {
-            constexpr int SLOT = decltype(slot_tag)::value;
-#pragma unroll
-            for (int f = 0; f < WPW; ++f) {
-                const int frag = wave + 4 * f;
-                const unsigned off = (stage < T && !(dbg & 2))
-                                         ? (unsigned)stage * (unsigned)W_STAGE + (unsigned)lane * 16u + (unsigned)frag * 1024u
-                                         : 0xFFFFFFF0u;
-                glds16(wrsrc, wring + SLOT * W_STAGE + frag * 1024, off);
-            }
-        };
-        // the weights of the first R - 1 stages go out at once: they need nothing from the rulebook tile and their
-        // memory latency then runs beside the consumers' staging of that tile
-        static_for<0, R - 1>([&](auto j) { fire(decltype(j)::value, j); });
-        if (threadIdx.x >= 256 && threadIdx.x < 288) reinterpret_cast<int *>(zero_row)[threadIdx.x - 256] = 0;
-        __builtin_amdgcn_s_barrier();                      // (1) bounds[] initialised by the consumers
-        __builtin_amdgcn_s_barrier();                      // (2) nbr_s complete, per-wave minima merged into bounds[]
-        // windows: instruction j of loader w moves window rows 32 j + 8 w + (lane >> 3), piece (lane & 7) ^ ((row >> 1) & 7)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int lo = bounds[q];
-            const int wlo_q = lo == 0x7fffffff ? 0 : (lo & ~1);
-#pragma unroll
-            for (int j = 0; j < WINI; ++j) {
-                const int wr = 32 * j + 8 * wave + (lane >> 3);
-                const int src = wlo_q + wr;
-                const unsigned piece = (unsigned)(lane & 7) ^ ((unsigned)(wr >> 1) & 7u);
-                unsigned off = (unsigned)src * 128u + piece * 16u;
-                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;                    // beyond the last row: zeros
-                glds16(xrsrc, win + q * WIN_B + (32 * j + 8 * wave) * 128, off);
-            }
-        }
-        // The consumers read the operands of stage t + 1 while they run the MFMAs of stage t: barrier P publishes the
-        // windows and stage 0; barrier t publishes stage t + 1 and frees the slot of stage t (whose reads the consumers
-        // completed before arriving) for stage t + R.  Before barrier t only the R - 2 stages t + 2 .. t + R - 1 may be
-        // in flight.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // windows (issued last) + every stage fired so far
-        __builtin_amdgcn_s_barrier();                      // barrier P
-        fire(R - 1, std::integral_constant<int, R - 1>{});
-        for (int t = 0; t < NIT; t += R)
-            static_for<0, R>([&](auto j) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * WPW) : "memory");
-                __builtin_amdgcn_s_barrier();
-                fire(t + decltype(j)::value + R, j);
-            });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        f32x4 none[MI][NB];
-        int norows[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) norows[mi] = -1;
-        gg_epilogue<MI, NB, OUT_BF16>(none, norows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s, true);
-        return;
-    }
-
-    // ----------------------------------------------------------------------------------------------- consumer
-    {   // rulebook tile -> LDS (k-major, coalesced), row K = -1; per-thread minimum of the three dz groups on the way
-        const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
-        constexpr int CT = 256;
-        if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;
-        int lo_t[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-        const int total = K * ROWS;
-        for (int base = threadIdx.x; base < total + ROWS; base += 4 * CT) {
-            int v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * CT;
-                const int k = idx / ROWS, r = idx - k * ROWS;
-                const int row = r0wg + r;
-                const int krow = flip ? (K - 1 - k) : k;
-                const bool ok = idx < total && row < n_out;
-                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
-                if (!ok) v[u] = -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * CT;
-                if (idx < total + ROWS) nbr_s[idx] = v[u];
-                if (idx < total && v[u] >= 0) {
-                    const int grp = idx / (GRP * ROWS);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (q == grp) lo_t[q] = min(lo_t[q], v[u]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // (1)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            int lo = lo_t[q];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o));
-            if (lane == 0) atomicMin(bounds + q, lo);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // (2)
-    }
-    int wlo[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int lo = bounds[q];
-        wlo[q] = lo == 0x7fffffff ? 0 : (lo & ~1);         // even: the swizzle of a row depends on (window row >> 1)
-    }
-    f32x4 acc[MI][NB];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // neighbour indices of the lane's MI rows at a stage (row rl of every 16-row block), read two stages ahead
-    auto idx_of = [&](int stage, int (&out)[MI]) {
-        const int k = stage < K ? stage : K;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) out[mi] = nbr_s[k * ROWS + wrow0 + mi * 16 + rl];
-    };
-    // operand registers: two sets (stage parity), so that the LDS reads of stage t + 1 overlap the MFMAs of stage t
-    bf16x8 xa[2][2][MI], bw[2][2][NB];
-    bool have[2] = {false, false};
-    auto fetch = [&](auto slot_tag, int stage, const int (&ix)[MI]) {
-        constexpr int SLOT = decltype(slot_tag)::value;
-        constexpr int SET = SLOT & 1;                             // R is even: slot parity = stage parity
-        bool any = false;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) any = any || ix[mi] >= 0;
-        have[SET] = __builtin_amdgcn_ballot_w64(any) != 0ull && stage < T && !(dbg & 4);
-        if (!have[SET]) return;                                   // no neighbour at this offset: no reads, no MFMAs
-        const int q = stage / GRP;
-        const int lo = q == 0 ? wlo[0] : (q == 1 ? wlo[1] : wlo[2]);
-        const char *wbase = win + q * WIN_B;
-        const char *wb = wring + SLOT * W_STAGE;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int w = ix[mi] - lo;
-            const bool inside = ix[mi] >= 0 && (unsigned)w < (unsigned)WCAP;
-            const char *rowp = inside ? wbase + w * 128 : zero_row;
-            const unsigned swz = inside ? (unsigned)(w >> 1) & 7u : 0u;
-#pragma unroll
-            for (int cs = 0; cs < 2; ++cs)
-                xa[SET][cs][mi] = *reinterpret_cast<const bf16x8 *>(rowp + (((unsigned)(cs * 4 + g) ^ swz) << 4));
-        }
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                bw[SET][cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int w = ix[mi] - lo;
-            if (ix[mi] >= 0 && (unsigned)w >= (unsigned)WCAP) {    // rare: straight from global memory (L2)
-                const bf16x8 *src = reinterpret_cast<const bf16x8 *>(x + (size_t)ix[mi] * 64);
-                xa[SET][0][mi] = src[g];
-                xa[SET][1][mi] = src[4 + g];
-            }
-        }
-    };
-    auto mfmas = [&](auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-        if (!have[SET]) return;
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[SET][cs][nb], xa[SET][cs][mi], acc[mi][nb], 0, 0, 0);
-    };
-    int ixe[MI], ixo[MI];                                           // indices of the next even / odd stage
-    idx_of(0, ixe);
-    idx_of(1, ixo);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // barrier P: windows + stage 0 published
-    fetch(std::integral_constant<int, 0>{}, 0, ixe);
-    idx_of(2, ixe);
-    // step t: (reads of stage t complete) barrier t -> stage t + 1 published; fetch stage t + 1 (other set); MFMAs of t
-    for (int t = 0; t < NIT; t += R)
-        static_for<0, R>([&](auto j) {
-            constexpr int J = decltype(j)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if constexpr ((J & 1) == 0) {
-                fetch(std::integral_constant<int, (J + 1) % R>{}, t + J + 1, ixo);
-                idx_of(t + J + 3, ixo);
-            } else {
-                fetch(std::integral_constant<int, (J + 1) % R>{}, t + J + 1, ixe);
-                idx_of(t + J + 3, ixe);
-            }
-            mfmas(std::integral_constant<int, J & 1>{});
-        });
-
-    int rows[MI];
-    const int tile_row = wrow0 + rl;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = r0wg + tile_row + mi * 16;
-        rows[mi] = row < n_out ? row : -1;
-    }
-    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
-}
-
-template <int NB, int MI>
-static int launch_ggwin(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
-                        int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
-                        unsigned w_bytes, hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
-    constexpr int R = MI == 1 ? 4 : 8, K = 27;
-    constexpr int ROWS = 64 * MI;
-    constexpr int WCAP = (ROWS * 3 / 2 + 31) / 32 * 32;
-    int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;
-    if (tiles_only) {
-        *tiles_only = grid;
-        return PCD_OK;
-    }
-    BnRed bn;
-    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
-    const size_t lds = (size_t)R * (2 * NB * 1024) + (size_t)3 * WCAP * 128 + 128 + (size_t)(K + 1) * ROWS * sizeof(int) + 32 +
-                       (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
-    if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
-    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
-    auto kb = ggwin_kernel<NB, MI, R, true>;
-    auto kf = ggwin_kernel<NB, MI, R, false>;
-    if (lds > 64 * 1024) {
-        static size_t raised[2] = {0, 0};
-        const int which = y_dtype == PCD_BF16 ? 0 : 1;
-        if (raised[which] < lds) {
-            if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess)
-                return PCD_ERR_LAUNCH;
-            raised[which] = lds;
-        }
-    }
-    if (y_dtype == PCD_BF16)
-        kb<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                   n_out_dev, n_in, y, x_bytes, w_bytes, addend, bn, dbg);
-    else
-        kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                   n_out_dev, n_in, y, x_bytes, w_bytes, addend, bn, dbg);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// REGISTER-RESIDENT-WEIGHT window gather-GEMM: SubM 3x3x3, 64 -> 64, key-ordered rows.  What the experiments with
-// ggwin_kernel showed (tools/exp_win.py): with the gathers replaced by windows the weight stream (221 KB per tile, one
-// barrier per 8 KB stage, ~3.7 k clk of DMA latency per stage to hide) and the per-tile prologue (rulebook tile ->
-// window bounds -> window DMA: two dependent memory latencies) are what is left, and at one workgroup per CU nothing
-// hides them.  Here:
-//   * wave w of a 4-wave workgroup owns output channel block w (16 channels) of ALL rows of a tile and keeps its
-//     27 x 2 weight fragments in REGISTERS (216 VGPRs; one wave per SIMD, 512 registers) for the whole launch: no
-//     weight traffic, no stage barriers in the offset loop (27 offsets fully unrolled);
-//   * a workgroup is PERSISTENT over a contiguous run of <= SMAX 64-row tiles: the rulebook run is staged once (one
-//     latency), all window bounds come from it at once, and the three windows of tile s + 1 are DMA'd into the second
-//     LDS buffer while tile s is computed -- two barriers per tile, no exposed latency after the first tile;
-//   * operands: LDS window reads through the rulebook tile (as ggwin_kernel), fetched one offset ahead of the MFMAs.
-// LDS traffic: every wave reads all 64 rows' fragments (8 KiB per offset and wave) for 8 MFMAs -> LDS-bound at ~2x the
-// MFMA time, i.e. up to half of the matrix peak.  Same operands and the same MFMA sequence per output element as the
-// other kernels (offsets ascending, the two contraction steps in order) -> bit-identical conv outputs.
-constexpr int GGR_ROWS = 64;          // rows per tile
-constexpr int GGR_WCAP = 96;          // window rows (1.5 x)
-constexpr int GGR_SMAX = 8;           // tiles per workgroup (LDS: operand-address table of the run)
-constexpr int GGR_SCRATCH = 8192;     // head of the dynamic LDS: bnred_publish's scratch / column sums
-constexpr int GGR_WBUF = 3 * GGR_WCAP * 128 + 256;   // three windows + a row of zeros (+ pad: 256-byte multiple)
-
-typedef __attribute__((address_space(3))) const bf16x8 *lds_frag_ptr;
-typedef __attribute__((address_space(3))) const int *lds_int_ptr;
-
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256, 1) void ggreg_kernel(
-    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
-    int n_in, void *__restrict__ yv, unsigned x_bytes, const void *__restrict__ addend, BnRed bn, int bn_rows, int dbg) {
-    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
-    constexpr int K = 27, GRP = 9, NB = 4, c_out = 64;
-    constexpr int ROWS = GGR_ROWS, WCAP = GGR_WCAP, SMAX = GGR_SMAX;
-    constexpr int WIN_B = WCAP * 128, WBUF = GGR_WBUF;
-    constexpr unsigned ZREL = 3 * WIN_B;                   // the zero row of a window buffer ((ZREL >> 8) & 7 == 0: no swizzle)
-    static_assert(((ZREL >> 8) & 7u) == 0 && ((WIN_B >> 8) & 7) == 0 && (WBUF & 255) == 0, "swizzle bits of the window layout");
-    constexpr int WINI = 3 * WCAP / 32;                    // window DMA instructions per wave and tile (9)
-    const int n_out = eff_rows(n_out_dev, n_out_cap);
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    float *red_s = (float *)smem;                          // [2][c_out] (inside the scratch head)
-    int *bounds = (int *)(smem + GGR_SCRATCH);             // [SMAX][4]
-    int *tab_s = bounds + SMAX * 4;                        // [K][SMAX * ROWS]: operand offsets relative to the window buffer
-    char *win = (char *)(tab_s + K * SMAX * ROWS);         // [2][WBUF]
-    // 32-bit LDS addresses (generic pointers cost a 64-bit add and an address-space test per operand read)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const unsigned tab_a = lds0 + (unsigned)((char *)tab_s - smem), win_a = lds0 + (unsigned)(win - smem);
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int rl = lane & 15, g = lane >> 4;
-    // tiles of this workgroup: the n_sub real tiles are dealt to the workgroups in contiguous runs of `per`, XCD by XCD
-    const int n_sub = (n_out + ROWS - 1) / ROWS;
-    const int nwg = gridDim.x;
-    const int per = (n_sub + nwg - 1) / nwg;               // <= SMAX (the grid is sized from the capacity)
-    const int chunk = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
-    const int t0 = chunk * per;
-    const int nt = max(0, min(per, n_sub - t0));
-    // the BatchNorm partial rows beyond the real tiles are zeroed by their round-robin owners (every row published once)
-    auto zero_surplus = [&]() {
-        if (!bn.mode) return;
-        for (int t = n_sub + (int)blockIdx.x; t < bn_rows; t += nwg)
-            bnred_publish(bn, t, c_out, [](int) { return 0.0f; }, bn_rows);
-    };
-    if (nt == 0) {
-        zero_surplus();
-        return;
-    }
-    // ---- weights -> registers: fragment (cs, nb = wave) of every offset (packed order: ((k * 2 + cs) * NB + nb) * 64 + lane)
-    bf16x8 bw[K][2];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs) {
-            const uint4 v = wp[((size_t)(k * 2 + cs) * NB + wave) * 64 + lane];
-            bw[k][cs] = __builtin_bit_cast(bf16x8, v);
-        }
-    // ---- rulebook run -> operand-address table.  Wave w takes the tiles s = w, w + 4, ..; its 64 lanes are the tile's 64
-    // rows (one coalesced 256-byte load per offset).  Per dz group: minimum of the valid indices (lane-local over the 9
-    // offsets + one wave reduction) = window start; table entry = byte offset of the neighbour's row inside the window
-    // buffer, ZREL (a row of zeros) for a missing neighbour, -(index + 2) for a neighbour outside its window.
-    const int r0 = t0 * ROWS;
-    if (threadIdx.x < 64) {                                 // the zero rows of both window buffers
-        reinterpret_cast<int *>(win + ZREL)[threadIdx.x & 31] = 0;
-        reinterpret_cast<int *>(win + WBUF + ZREL)[threadIdx.x & 31] = 0;
-    }
-    {
-        const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
-        for (int sb = wave; sb < nt; sb += 4) {
-            const int row = r0 + sb * ROWS + lane;
-            const bool ok = row < n_out;
-            int v[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int krow = flip ? (K - 1 - k) : k;
-                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
-                v[k] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                int lo = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int t = ok ? v[q * GRP + j] : -1;
-                    lo = t >= 0 ? min(lo, t) : lo;
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o));
-                lo = lo == 0x7fffffff ? 0 : (lo & ~1);       // even: the swizzle of a row depends on (window row >> 1)
-                if (lane == 0) bounds[sb * 4 + q] = lo;
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int t = ok ? v[q * GRP + j] : -1;
-                    const int w = t - lo;
-                    int e = (int)ZREL;
-                    if (t >= 0) e = (unsigned)w < (unsigned)WCAP ? q * WIN_B + w * 128 : -(t + 2);
-                    tab_s[(q * GRP + j) * (SMAX * ROWS) + sb * ROWS + lane] = e;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
-    // windows of tile s -> buffer s & 1: instruction j of wave w moves rows 32 j' + 8 w + (lane >> 3) of window q (j = 3 q + j')
-    auto fire_windows = [&](int s) {
-        char *dst = win + (s & 1) * WBUF;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int wlo = bounds[s * 4 + q];
-#pragma unroll
-            for (int j = 0; j < WCAP / 32; ++j) {
-                const int wr = 32 * j + 8 * wave + (lane >> 3);
-                const int src = wlo + wr;
-                const unsigned piece = (unsigned)(lane & 7) ^ ((unsigned)(wr >> 1) & 7u);
-                unsigned off = (unsigned)src * 128u + piece * 16u;
-                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;
-                glds16(xrsrc, dst + q * WIN_B + (32 * j + 8 * wave) * 128, off);
-            }
-        }
-    };
-    fire_windows(0);
-    const unsigned g4 = (unsigned)g << 4;
-    for (int s = 0; s < nt; ++s) {
-        // (A) every wave has finished tile s - 1: its window buffer may be refilled for tile s + 1
-        if (s > 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (s + 1 < nt) {
-            fire_windows(s + 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WINI) : "memory");     // windows of tile s landed (s + 1 in flight)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                       // (B) every wave's share of the windows of tile s is in LDS
-        const unsigned wb_a = win_a + (unsigned)(s & 1) * (unsigned)WBUF;
-        f32x4 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const unsigned trow_a = tab_a + (unsigned)(s * ROWS + rl) * 4u;     // + (k * SMAX * ROWS + rb * 16) * 4
-        bf16x8 xa[2][4][2];                                 // [set][row block][contraction step]
-        int ev[2][4];
-        auto load_tab = [&](int k, int (&o)[4]) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-                o[rb] = *(lds_int_ptr)(trow_a + (unsigned)(k * (SMAX * ROWS) + rb * 16) * 4u);
-        };
-        auto fetch = [&](const int (&e)[4], bf16x8 (&dst)[4][2]) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                unsigned v = e[rb] < 0 ? ZREL : (unsigned)e[rb];
-                if (dbg & 8) v = (unsigned)(rb * 16 + rl) * 128u;            // ablation: consecutive rows (conflict-free pattern)
-                const unsigned swz4 = (v >> 4) & 0x70u;                      // ((window row >> 1) & 7) << 4
-                const unsigned a0 = wb_a + v + (g4 ^ swz4);
-                dst[rb][0] = *(lds_frag_ptr)a0;
-                dst[rb][1] = *(lds_frag_ptr)(a0 ^ 64u);                      // piece 4 + g: bit 6 of the in-row offset
-            }
-            // rare: a neighbour outside its window comes straight from global memory (one wave-uniform test per offset)
-            if (__builtin_amdgcn_ballot_w64((e[0] | e[1] | e[2] | e[3]) < 0) != 0ull) {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-                    if (e[rb] < 0) {
-                        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(x + (size_t)(-(e[rb] + 2)) * 64);
-                        dst[rb][0] = src[g];
-                        dst[rb][1] = src[4 + g];
-                    }
-            }
-        };
-        load_tab(0, ev[0]);
-        load_tab(1, ev[1]);
-        fetch(ev[0], xa[0]);
-        if (dbg & 16) fetch(ev[1], xa[1]);                                   // ablation: operands fetched once per tile
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k + 1 < K && !(dbg & 16)) fetch(ev[(k + 1) & 1], xa[(k + 1) & 1]);
-            if (k + 2 < K && !(dbg & 16)) load_tab(k + 2, ev[k & 1]);
-            if (!(dbg & 4)) {
-#pragma unroll
-                for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb)
-                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[k][cs], xa[k & 1][rb][cs], acc[rb], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) acc[rb][0] += (float)xa[k & 1][rb][0][0] + (float)xa[k & 1][rb][1][0];   // keep the reads alive
-            }
-        }
-        // ---- epilogue of tile s: lane (g, rl) holds channels g * 16 + wave * 4 .. + 3 of rows rb * 16 + rl
-        const int tile = t0 + s;
-        const int col = g * 16 + wave * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const float4 t = *reinterpret_cast<const float4 *>(bias + col);
-            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-        }
-        float bs[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int row = tile * ROWS + rb * 16 + rl;
-            if (row >= n_out) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[rb][j] + (bias ? bv[j] : 0.0f);
-            const size_t at = (size_t)row * c_out + col;
-            if (OUT_BF16) {
-                if (addend) {
-                    const uint2 t = *reinterpret_cast<const uint2 *>((const unsigned short *)addend + at);
-                    v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
-                    v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
-                }
-                const u32 o0 = (u32)f32_to_bf16_bits(v[0]) | ((u32)f32_to_bf16_bits(v[1]) << 16);
-                const u32 o1 = (u32)f32_to_bf16_bits(v[2]) | ((u32)f32_to_bf16_bits(v[3]) << 16);
-                *reinterpret_cast<uint2 *>((unsigned short *)yv + at) = make_uint2(o0, o1);
-                if (bn.mode) {
-                    const float d[4] = {__uint_as_float(o0 << 16), __uint_as_float(o0 & 0xffff0000u),
-                                        __uint_as_float(o1 << 16), __uint_as_float(o1 & 0xffff0000u)};
-                    if (bn.mode == 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            bs[j] += d[j];
-                            bq[j] += d[j] * d[j];
-                        }
-                    } else {
-                        const uint2 tx = *reinterpret_cast<const uint2 *>(bn.x + at);
-                        const float xv[4] = {__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u),
-                                             __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u)};
-                        float tv[4] = {1.f, 1.f, 1.f, 1.f};
-                        if (bn.relu) {
-                            const uint2 ty = *reinterpret_cast<const uint2 *>(bn.y + at);
-                            tv[0] = __uint_as_float(ty.x << 16); tv[1] = __uint_as_float(ty.x & 0xffff0000u);
-                            tv[2] = __uint_as_float(ty.y << 16); tv[3] = __uint_as_float(ty.y & 0xffff0000u);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float dz = (bn.relu && !(tv[j] > 0.0f)) ? 0.0f : d[j];
-                            bs[j] += dz;
-                            bq[j] += dz * xv[j];
-                        }
-                    }
-                }
-            } else {
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (addend) {
-                    const float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + at);
-                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                }
-                *reinterpret_cast<float4 *>((float *)yv + at) = o;
-            }
-        }
-        if (OUT_BF16 && bn.mode) {
-            if (bn.mode == 2) {
-                const float4 mu = *reinterpret_cast<const float4 *>(bn.mean + col);
-                const float4 is = *reinterpret_cast<const float4 *>(bn.invstd + col);
-                bq[0] = (bq[0] - mu.x * bs[0]) * is.x; bq[1] = (bq[1] - mu.y * bs[1]) * is.y;
-                bq[2] = (bq[2] - mu.z * bs[2]) * is.z; bq[3] = (bq[3] - mu.w * bs[3]) * is.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bs[j] = row16_sum(bs[j]);
-                bq[j] = row16_sum(bq[j]);
-            }
-            if (rl == 0) {
-                *reinterpret_cast<float4 *>(red_s + col) = make_float4(bs[0], bs[1], bs[2], bs[3]);
-                *reinterpret_cast<float4 *>(red_s + c_out + col) = make_float4(bq[0], bq[1], bq[2], bq[3]);
-            }
-            __syncthreads();
-            float mine = threadIdx.x < 2 * c_out ? red_s[threadIdx.x] : 0.0f;
-            __syncthreads();                                 // (red_s lies inside bnred_publish's scratch)
-            bnred_publish(bn, tile, c_out, [&](int) { return mine; }, bn_rows);
-        }
-    }
-    zero_surplus();
-}
-
-// ---------------------------------------------------------------------------------------------
-// WAVE-LEVEL window gather-GEMM: SubM 3x3x3, 32 -> 32, key-ordered rows.  The lesson of ggwin / ggreg (one wave per SIMD
-// cannot hide a per-tile serial section) turned around: every WAVE is its own pipeline -- it owns 32-row tiles, DMAs its
-// own three windows (48 rows x 64 B each) into a private LDS area, waits only for its own DMAs (no workgroup barrier in
-// the loop) and computes the 27 offsets from LDS; the 54 KB of packed weights are resident in LDS for the whole
-// (persistent) workgroup.  8 waves per CU run these pipelines out of phase, which is what hides the latencies.
-constexpr int GWV_ROWS = 32, GWV_WCAP = 48, GWV_WAVES = 8;
-constexpr int GWV_WIN_B = GWV_WCAP * 64;                   // bytes per window (64-byte rows)
-constexpr int GWV_QSTRIDE = GWV_WIN_B + 256;               // a zero row (window row -1) in front of every window, 256-byte aligned
-constexpr int GWV_WAVE_B = 3 * GWV_QSTRIDE;                // a wave's three windows (9984 B)
-constexpr int GWV_W_BYTES = 27 * 2 * 1024;                 // packed weights: 27 offsets x 2 channel blocks x 1 KiB
-
-template <bool OUT_BF16>
-__global__ __launch_bounds__(64 * GWV_WAVES, 2) void ggwave_kernel(
-    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
-    int n_in, void *__restrict__ yv, unsigned x_bytes, const void *__restrict__ addend, BnRed bn, int dbg) {
-    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
-    constexpr int K = 27, GRP = 9, c_out = 32, ROWS = GWV_ROWS, WCAP = GWV_WCAP, WIN_B = GWV_WIN_B;
-    const int n_out = eff_rows(n_out_dev, n_out_cap);
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    char *wlds = smem + GGR_SCRATCH;                        // [27][2][64 lanes][16 B]
-    char *wins = wlds + GWV_W_BYTES;                        // [waves][GWV_WAVE_B]
-    float *red_s = (float *)smem;                           // [waves][2][c_out] inside the scratch head (end of kernel only)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int rl = lane & 15, g = lane >> 4;
-    // weights -> LDS once (lane-linear image of the packed fragments)
-    for (int e = threadIdx.x; e < GWV_W_BYTES / 16; e += 64 * GWV_WAVES)
-        reinterpret_cast<uint4 *>(wlds)[e] = wp[e];
-    char *mywin = wins + wave * GWV_WAVE_B;
-    // window q of this wave: rows 0 .. WCAP - 1 at mywin + q * QSTRIDE + 256; the 64 bytes in front of row 0 are zeros
-    // ("window row -1" = a missing neighbour: no select in the operand address)
-    if (lane < 48) reinterpret_cast<int *>(mywin + (lane >> 4) * GWV_QSTRIDE + 192)[lane & 15] = 0;
-    __syncthreads();
-    const unsigned w_a = lds0 + (unsigned)(wlds - smem) + (unsigned)lane * 16u;
-    const unsigned win_a = lds0 + (unsigned)(mywin - smem) + 256u;                 // row 0 of window 0
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
-    // tiles: contiguous runs per wave, XCD by XCD (workgroup b runs on XCD b % 8)
-    const int n_tiles = (n_out + ROWS - 1) / ROWS;
-    const int nwv = gridDim.x * GWV_WAVES;
-    const int chunk = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * GWV_WAVES + wave;
-    const int per = (n_tiles + nwv - 1) / nwv;
-    const int t_begin = min(n_tiles, chunk * per), t_end = min(n_tiles, t_begin + per);
-    float bs[8], bq[8];                                     // BatchNorm column sums of this wave (channels g * 8 .. + 7)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bs[j] = bq[j] = 0.0f;
-    const int col = g * 8;
-    float bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[col + j] : 0.0f;
-    // minimum / maximum over the 16 lanes of a DPP row (every row of 16 lanes holds all 32 rows of the tile: no cross-row step)
-    auto row16_min = [](int v) {
-        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
-        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
-        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));     // row_ror:4
-        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));     // row_ror:8
-        return v;
-    };
-
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const int row0 = tile * ROWS;
-        // neighbour indices in FRAGMENT mapping: ix[k][mi] = nbr[k][row0 + mi * 16 + rl] (the 4 lane groups load the same words)
-        int ix[K][2];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int krow = flip ? (K - 1 - k) : k;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int row = row0 + mi * 16 + rl;
-                const unsigned off = row < n_out ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
-                const int v = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
-                ix[k][mi] = row < n_out ? v : -1;
-            }
-        }
-        // window starts (multiples of 4) and whether every neighbour lies inside its window
-        int wlo[3];
-        bool fits = true;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            int lo = 0x7fffffff, nhi = 0x7fffffff;           // nhi = -(max valid index) - 1 (so that one kind of reduction serves)
-#pragma unroll
-            for (int j = 0; j < GRP; ++j)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int t = ix[q * GRP + j][mi];
-                    lo = min(lo, t >= 0 ? t : 0x7fffffff);
-                    nhi = min(nhi, ~t);                       // ~t = -t - 1; t = -1 -> 0 (index "-1"), harmless
-                }
-            lo = row16_min(lo);
-            nhi = row16_min(nhi);
-            wlo[q] = lo == 0x7fffffff ? 0 : (lo & ~3);
-            fits = fits && (~nhi - wlo[q] < WCAP);
-        }
-        // windows -> the wave's LDS area: instruction j moves rows 16 j + (lane >> 2), 16-byte piece (lane & 3) ^ ((row >> 2) & 3)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the previous tile's operand reads are done)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int j = 0; j < WCAP / 16; ++j) {
-                const int wr = 16 * j + (lane >> 2);
-                const int src = wlo[q] + wr;
-                const unsigned piece = (unsigned)(lane & 3) ^ ((unsigned)(wr >> 2) & 3u);
-                unsigned off = (unsigned)src * 64u + piece * 16u;
-                if (src >= n_in || (dbg & 1)) off = 0xFFFFFF00u;
-                glds16(xrsrc, mywin + q * GWV_QSTRIDE + 256 + 16 * j * 64, off);
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's own DMAs: no barrier, nobody else reads them
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (__builtin_amdgcn_ballot_w64(!fits) == 0ull) {
-            // FAST path (every neighbour inside its window): operand address = 7 integer instructions, no selects --
-            // window row w = max(index - lo, -1) (row -1 = zeros), byte = w * 64 + ((g ^ ((w >> 2) & 3)) << 4)
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int q = k / GRP;
-                bf16x8 xa[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int w = max(ix[k][mi] - wlo[q], -1);
-                    const unsigned p = ((unsigned)g ^ ((unsigned)(w >> 2) & 3u)) << 4;
-                    xa[mi] = *(lds_frag_ptr)(win_a + (unsigned)(q * GWV_QSTRIDE) + (unsigned)(w * 64) + p);
-                }
-                if (!(dbg & 4)) {
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        const bf16x8 bw = *(lds_frag_ptr)(w_a + (unsigned)((k * 2 + nb) * 1024));
-#pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
-                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, xa[mi], acc[mi][nb], 0, 0, 0);
-                    }
-                } else {
-                    acc[0][0][0] += (float)xa[0][0] + (float)xa[1][0];
-                }
-            }
-        } else {
-            // rare (a tile straddling a frame / z boundary, very long lines): operands straight from global memory
-#pragma unroll 1
-            for (int k = 0; k < K; ++k) {
-                int i0 = 0, i1 = 0;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk)
-                    if (kk == k) {
-                        i0 = ix[kk][0];
-                        i1 = ix[kk][1];
-                    }
-                const bf16x8 zero = {};
-                bf16x8 xa[2];
-                xa[0] = i0 >= 0 ? reinterpret_cast<const bf16x8 *>(x + (size_t)i0 * 32)[g] : zero;
-                xa[1] = i1 >= 0 ? reinterpret_cast<const bf16x8 *>(x + (size_t)i1 * 32)[g] : zero;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const bf16x8 bw = *(lds_frag_ptr)(w_a + (unsigned)((k * 2 + nb) * 1024));
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, xa[mi], acc[mi][nb], 0, 0, 0);
-                }
-            }
-        }
-        // epilogue: lane (g, rl) holds channels g * 8 + nb * 4 + j of rows mi * 16 + rl (Q = 2 interleave of the packs)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = row0 + mi * 16 + rl;
-            if (row >= n_out) continue;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = acc[mi][j >> 2][j & 3] + bv[j];
-            const size_t at = (size_t)row * c_out + col;
-            if (OUT_BF16) {
-                if (addend) {
-                    const uint4 t = *reinterpret_cast<const uint4 *>((const unsigned short *)addend + at);
-                    const u32 tw[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[2 * j] += __uint_as_float(tw[j] << 16);
-                        v[2 * j + 1] += __uint_as_float(tw[j] & 0xffff0000u);
-                    }
-                }
-                u32 o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
-                *reinterpret_cast<uint4 *>((unsigned short *)yv + at) = make_uint4(o[0], o[1], o[2], o[3]);
-                if (bn.mode) {
-                    float d[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        d[2 * j] = __uint_as_float(o[j] << 16);
-                        d[2 * j + 1] = __uint_as_float(o[j] & 0xffff0000u);
-                    }
-                    if (bn.mode == 1) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            bs[j] += d[j];
-                            bq[j] += d[j] * d[j];
-                        }
-                    } else {
-                        const uint4 tx = *reinterpret_cast<const uint4 *>(bn.x + at);
-                        const u32 xw[4] = {tx.x, tx.y, tx.z, tx.w};
-                        u32 yw[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-                        if (bn.relu) {
-                            const uint4 ty = *reinterpret_cast<const uint4 *>(bn.y + at);
-                            yw[0] = ty.x; yw[1] = ty.y; yw[2] = ty.z; yw[3] = ty.w;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float xv = (j & 1) ? __uint_as_float(xw[j >> 1] & 0xffff0000u) : __uint_as_float(xw[j >> 1] << 16);
-                            const float tv = (j & 1) ? __uint_as_float(yw[j >> 1] & 0xffff0000u) : __uint_as_float(yw[j >> 1] << 16);
-                            const float dz = (bn.relu && !(tv > 0.0f)) ? 0.0f : d[j];
-                            bs[j] += dz;
-                            bq[j] += dz * xv;
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    float4 o = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-                    if (addend) {
-                        const float4 ad = *reinterpret_cast<const float4 *>((const float *)addend + at + 4 * u);
-                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                    }
-                    *reinterpret_cast<float4 *>((float *)yv + at + 4 * u) = o;
-                }
-            }
-        }
-    }
-    if (OUT_BF16 && bn.mode) {          // ONE partial row per workgroup: the waves' sums over all their tiles
-        if (bn.mode == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bq[j] = (bq[j] - bn.mean[col + j] * bs[j]) * bn.invstd[col + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bs[j] = row16_sum(bs[j]);
-            bq[j] = row16_sum(bq[j]);
-        }
-        __syncthreads();                 // (the scratch head is free: every wave has left its loop)
-        if (rl == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red_s[(wave * 2 + 0) * c_out + col + j] = bs[j];
-                red_s[(wave * 2 + 1) * c_out + col + j] = bq[j];
-            }
-        }
-        __syncthreads();
-        float mine = 0.0f;
-        if (threadIdx.x < 2 * c_out)
-            for (int w = 0; w < GWV_WAVES; ++w) mine += red_s[(w * 2 + (threadIdx.x / c_out)) * c_out + (threadIdx.x % c_out)];
-        __syncthreads();
-        bnred_publish(bn, (int)blockIdx.x, c_out, [&](int) { return mine; });
-    }
-}
-
-static int ggwave_grid() { return 256; }                   // one persistent workgroup (8 independent waves) per CU
-
-static int launch_ggwave(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
-                         int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
-                         hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
-    const int grid = ggwave_grid();
-    if (tiles_only) {
-        *tiles_only = grid;
-        return PCD_OK;
-    }
-    BnRed bn;
-    if (int rc = make_bnred(bnr, y_dtype, 32, grid, &bn)) return rc;
-    const size_t lds = (size_t)GGR_SCRATCH + GWV_W_BYTES + (size_t)GWV_WAVES * GWV_WAVE_B;
-    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
-    auto kb = ggwave_kernel<true>;
-    auto kf = ggwave_kernel<false>;
-    static size_t raised[2] = {0, 0};
-    const int which = y_dtype == PCD_BF16 ? 0 : 1;
-    if (raised[which] < lds) {
-        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PCD_ERR_LAUNCH;
-        raised[which] = lds;
-    }
-    if (y_dtype == PCD_BF16)
-        kb<<<grid, 64 * GWV_WAVES, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                              n_out_dev, n_in, y, x_bytes, addend, bn, dbg);
-    else
-        kf<<<grid, 64 * GWV_WAVES, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                              n_out_dev, n_in, y, x_bytes, addend, bn, dbg);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
-
-// grid of the persistent kernel for a capacity of n_out rows: one workgroup per CU unless its run would exceed SMAX tiles
-static int ggreg_grid(int n_out) {
-    const int n_sub = pcd_div_up(n_out, GGR_ROWS);
-    int grid = 256;
-    if (pcd_div_up(n_sub, grid) > GGR_SMAX) grid = pcd_div_up(pcd_div_up(n_sub, GGR_SMAX), 8) * 8;
-    return grid;
-}
-static int ggreg_bn_rows(int n_out) { return pcd_div_up(pcd_div_up(n_out, GGR_ROWS), 8) * 8; }
-
-static int launch_ggreg(const void *x, int n_in, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
-                        int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
-                        hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
-    const int bn_rows = ggreg_bn_rows(n_out);
-    if (tiles_only) {
-        *tiles_only = bn_rows;
-        return PCD_OK;
-    }
-    const int grid = ggreg_grid(n_out);
-    BnRed bn;
-    if (int rc = make_bnred(bnr, y_dtype, 64, bn_rows, &bn)) return rc;
-    const size_t lds = (size_t)GGR_SCRATCH + GGR_SMAX * 16 + (size_t)27 * GGR_SMAX * GGR_ROWS * sizeof(int) +
-                       (size_t)2 * GGR_WBUF + 256;
-    static const int dbg = getenv("PCD_GGW_DBG") ? atoi(getenv("PCD_GGW_DBG")) : 0;
-    auto kb = ggreg_kernel<true>;
-    auto kf = ggreg_kernel<false>;
-    static size_t raised[2] = {0, 0};
-    const int which = y_dtype == PCD_BF16 ? 0 : 1;
-    if (raised[which] < lds) {
-        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PCD_ERR_LAUNCH;
-        raised[which] = lds;
-    }
-    if (y_dtype == PCD_BF16)
-        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                   n_out_dev, n_in, y, x_bytes, addend, bn, bn_rows, dbg);
-    else
-        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out,
-                                   n_out_dev, n_in, y, x_bytes, addend, bn, bn_rows, dbg);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -2707,25 +1769,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
 // (layers that are cut into >= 4 channel chunks already have 4x the workgroups: twice the rows per split there,
 // measured 79 -> 72 us at 128 x 128 channels)
-static bool wgrad128_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("PCD_WG128");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool wgrad128_enabled() { return pcd_opt(PCD_OPT_WG128) != 0; }
 static int wgrad128_chunks() {   // equal-pair chunks of wgrad128_kernel: two workgroups per CU
     // (768 = three per CU was the isolated optimum; in the step 512 wins by 0.6 % -- 3.424 vs 3.447 ms, 384 / 640: 3.436 /
     //  3.451 -- a third less tile traffic for the reduction: 512 x 64 KiB per layer)
-    static int v = 0;
-    if (v == 0) {
-        const char *e = getenv("PCD_WG128_NB");
-        v = e ? atoi(e) : 512;
-        if (v < 8) v = 8;
-        v = (v + 7) / 8 * 8;
-    }
-    return v;
+    int v = pcd_opt(PCD_OPT_WG128_CHUNKS);
+    if (v < 8) v = 8;
+    return (v + 7) / 8 * 8;
 }
 static bool wgrad128_use(int cin, int cout) { return cin == 128 && cout == 128 && wgrad128_enabled(); }
 
@@ -2733,7 +1783,7 @@ static void wgrad_plan(int pmax, int cin, int cout, int *splits, int *rows_per_s
     const int chunks = pcd_div_up(cin, 64) * pcd_div_up(cout, 64);
     // input rows per split (x 2 for layers cut into >= 4 channel chunks): 6144 measured best in the step (3.420 ms;
     // 3072 / 4096 / 5120 / 7168 / 8192: 3.450 / 3.432 / 3.430 / 3.429 / 3.425) -- fewer, larger slabs to reduce
-    static const int scale = getenv("PCD_WG_ROWS") && atoi(getenv("PCD_WG_ROWS")) >= 256 ? atoi(getenv("PCD_WG_ROWS")) : 6144;
+    const int scale = pcd_opt(PCD_OPT_WG_ROWS) >= 256 ? pcd_opt(PCD_OPT_WG_ROWS) : 6144;
     int s = pcd_div_up(pmax > 0 ? pmax : 1, chunks >= 4 ? 2 * scale : scale);
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -2829,7 +1879,7 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     //   else                    -> double-buffered stages of SG steps
     // Narrow layers (NB 1/2, 300k+ rows): short look-ahead, many waves per SIMD.
     const size_t wbytes = (size_t)nsteps * (c_out / 16) * 1024;
-    static const size_t resident_kb = getenv("PCD_GG_RESIDENT_KB") ? (size_t)atoi(getenv("PCD_GG_RESIDENT_KB")) : 32;
+    const size_t resident_kb = (size_t)pcd_opt(PCD_OPT_GG_RESIDENT_KB);
     const bool resident = wbytes <= resident_kb * 1024;
     // Wide layers: a contraction step lasts one memory latency (~3.7k clk measured at 128 channels: the gathers
     // and the weight stage are fetched one step ahead of ~256 clk of MFMA work), so two steps of look-ahead with
@@ -2839,43 +1889,15 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // (B = 1 / 2: 432 / 676 -> 457 / 712 frames/s without that rule).
     // Wide layers (C_in = 64 / 128, C_out = 64 / 128): the LDS-DMA kernel (ggw_kernel).  Rows per workgroup follow the
     // row count so that the tiles of the LARGEST layers of a level fill the 256 CUs in whole rounds.
-    static const int ggw_mode = getenv("PCD_GGW") ? atoi(getenv("PCD_GGW")) : 1;
+    const int ggw_mode = pcd_opt(PCD_OPT_GGW);
     // (C_in = 64: measured equal to the fragment-loading kernel, 55 us at 115 k rows -- both at the texture-address
     //  limit of one 1-KiB instruction per ~32 clk; only PCD_GGW >= 2 routes it here)
     const bool is_dgrad = dir_hint >= 0 ? dir_hint != 0 : (flip_k || (bnr && bnr->mode == 2));
-    // SubM 3x3x3, 32 -> 32 (n_in == n_out): the wave-level window kernel (PCD_GGWAVE=1)
-    static const int ggwave_mode = getenv("PCD_GGWAVE") ? atoi(getenv("PCD_GGWAVE")) : 0;
-    if (ggwave_mode && c_in == 32 && c_out == 32 && kvol == 27 && n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
-        if (tiles_only && tiles_only[0] == -12345) {
-            tiles_only[0] = 3;
-            return PCD_OK;
-        }
-        return launch_ggwave(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype,
-                             x_bytes, st, addend, bnr, tiles_only);
-    }
-    // SubM 3x3x3, 64 -> 64 (n_in == n_out): the window kernel (PCD_GGWIN=0 turns it off, =3 uses 48 rows per wave)
-    static const int ggwin_mode = getenv("PCD_GGWIN") ? atoi(getenv("PCD_GGWIN")) : 0;
-    if (tiles_only && tiles_only[0] == -12345 && ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 &&
-        n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
-        tiles_only[0] = 2;
-        return PCD_OK;
-    }
     if (tiles_only && tiles_only[0] == -12345) {       // variant query (pcd_sparse_conv_gather_gemm_variant)
-        static const int m = getenv("PCD_GGW") ? atoi(getenv("PCD_GGW")) : 1;
+        const int m = pcd_opt(PCD_OPT_GGW);
         tiles_only[0] = (m && (c_in == 128 || (c_in == 64 && m >= 2 && m <= 4)) && (c_out == 64 || c_out == 128) &&
                          x_bytes <= 0xFFFF0000u && !(is_dgrad && m == 6)) ? 1 : 0;
         return PCD_OK;
-    }
-    if (ggwin_mode && c_in == 64 && c_out == 64 && kvol == 27 && n_rows_in == n_rows_out && x_bytes <= 0xFFFF0000u) {
-        const unsigned w_bytes = (unsigned)wbytes;
-        if (ggwin_mode >= 4)
-            return launch_ggreg(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
-                                y_dtype, x_bytes, st, addend, bnr, tiles_only);
-        if (ggwin_mode == 3)
-            return launch_ggwin<4, 1>(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
-                                      y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only);
-        return launch_ggwin<4, 2>(x, n_rows_in, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y,
-                                  y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only);
     }
     // PCD_GGW: 0 = off, 1 = on (default), 2..4 = on with MI rows-per-wave forced (also for C_in = 64), 6 = forward only
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
@@ -2896,7 +1918,7 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
             // 16 channels (level 1).  With key-ordered voxel rows (pcd_voxelize_hard_sorted) 32 rows per wave and one
             // step of look-ahead win: whole step 3.46 -> 3.42 ms (<1,2,2,0> 3.43, <1,4,*,0> 3.47-3.48, <1,1,1/4,0> 3.46);
             // rows in first-appearance order preferred <1,1,2,0> (PCD_GG1=0).
-            static const int v1 = getenv("PCD_GG1") ? atoi(getenv("PCD_GG1")) : 1;
+            const int v1 = pcd_opt(PCD_OPT_GG1);
             if (resident) return v1 ? launch_gg<1, 2, 1, 0>(GG_ARGS) : launch_gg<1, 1, 2, 0>(GG_ARGS);
             return launch_gg<1, 1, 2, 4>(GG_ARGS);
         }

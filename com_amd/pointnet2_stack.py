@@ -90,6 +90,7 @@ class QueryAndGroup(nn.Module):
 
 
 COOP_FPS_MIN_POINTS = 16384     # frames at least this large take the cooperative kernel
+COOP_FPS_TIMEOUTS = 0           # times the cooperative kernel gave up and the one-workgroup kernel redid the call
 FPS_CHECK_ERR = True            # read the barrier-timeout flag back (one host sync; FPS is an eager op)
 
 
@@ -114,10 +115,13 @@ class StackFarthestPointSampling(Function):
             rc = lib.pcd_stack_farthest_point_sampling_coop(B, L.ptr(xyz.float()), L.ptr(cnt), L.ptr(out), L.ptr(npoint),
                                                             max_cnt, L.ptr(ws), ws.numel(), L.stream_ptr())
             if rc == 0:
-                if FPS_CHECK_ERR and int(ws[-256:].view(torch.int32)[0].item()) != 0:
-                    raise L.PcdError("cooperative FPS: a workgroup of a frame was not resident (barrier timed out)")
-                return out
-            if rc != -2:                                       # PCD_ERR_UNSUPPORTED: too many frames / slice too large
+                if not (FPS_CHECK_ERR and int(ws[-256:].view(torch.int32)[0].item()) != 0):
+                    return out
+                # a workgroup of a frame was not resident (another stream held CUs): the bounded spin gave up -- the
+                # one-workgroup-per-frame kernel below computes the same indices
+                global COOP_FPS_TIMEOUTS
+                COOP_FPS_TIMEOUTS += 1
+            elif rc != -2:                                       # PCD_ERR_UNSUPPORTED: too many frames / slice too large
                 L.check(rc, "pcd_stack_farthest_point_sampling_coop")
         temp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
         L.check(lib.pcd_stack_farthest_point_sampling(B, L.ptr(xyz.float()), L.ptr(temp), L.ptr(cnt),

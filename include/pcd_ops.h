@@ -65,6 +65,24 @@ void pcd_set_last_hip_error(int code);    /* internal use */
  * per-graph resources; no reference counterpart: the reference has no graph capture) */
 int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
 
+/* ---- tuning options --------------------------------------------------------------------------
+ * Integer knobs of the kernel dispatch (tile shapes, kernel variants, ablation switches).  They select between
+ * implementations that produce the same results; the defaults are the measured optima and nothing in the product sets them.
+ * Explicit and inspectable (no environment reads anywhere in the library): pcd_set_option returns PCD_ERR_INVALID_ARG for an
+ * unknown key.  Process-wide, not synchronised: set them before the first call that uses them.  (No reference counterpart.)
+ *   "gg_resident_kb" 32   packed weight up to this size stays resident in LDS in gather_gemm_kernel
+ *   "ggw" 1               LDS-DMA gather-GEMM for C_in = 128 (0 off, 2..4: rows-per-wave forced also for C_in = 64, 6: forward only)
+ *   "gg1" 1               16-channel gather-GEMM variant (1: 32 rows per wave)
+ *   "subm_window" 1       window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows (0: generic kernels)
+ *   "wg128" 1             equal-pair weight-gradient kernel at 128 x 128 channels
+ *   "wg128_chunks" 512    its workgroup count
+ *   "wg_rows" 6144        row-range split of the generic weight-gradient kernel
+ *   "conv2d_wb" 1, "conv2d_wg_blocks" 128, "conv2d_wgp_mode2" 0, "conv2d_wgp_blocks" 512   dense 3x3 conv variants
+ *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
+ *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only) */
+int pcd_set_option(const char *key, int value);
+int pcd_get_option(const char *key, int *value_out);
+
 /* ============================================================================================
  * (a1) hard voxelisation -- replaces spconv.utils.VoxelGeneratorV2.generate /
  *      Point2VoxelCPU3d.point_to_voxel as called from
