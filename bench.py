@@ -715,9 +715,10 @@ def main():
     # the side-stream weight-gradient chain is joined once, at the end of the backward pass (a lag >= the number of
     # convs; lag 1 measured 0.5 % slower: every join is an edge that orders a main-chain kernel behind a weight gradient)
     Fsp.WGRAD_JOIN_LAG = int(os.environ.get('PCD_WGRAD_LAG', '32'))
-    # voxel rows in (b, z, y, x) key order (pcd_voxelize_hard_sorted: the same voxels as the reference's voxeliser, numbered
-    # like torch.unique / spconv's strided convs number theirs); PCD_ROW_ORDER=first = first-appearance ids
-    ROW_ORDER = os.environ.get('PCD_ROW_ORDER', 'key')
+    # voxel rows numbered by (b, y, x, z) -- z fastest, PCD_ROWS_YXZ: the same voxels as the reference's voxeliser (the caps are
+    # decided by first appearance), every level of the chain numbered the same way, the 64-channel SubM layers through the
+    # window gather-GEMM; PCD_ROW_ORDER=key = (b, z, y, x) (torch.unique / spconv's sorted order), first = first-appearance ids
+    ROW_ORDER = os.environ.get('PCD_ROW_ORDER', 'yxz')
     Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
     ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
     Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket

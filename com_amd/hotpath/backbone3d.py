@@ -197,7 +197,8 @@ class _BackboneBase(nn.Module):
             todo.append((conv, 0))
             if self.training and conv.in_channels >= 16:
                 todo.append((conv, 1))
-        wm = [(c.weight.detach(), m) for c, m in todo]
+        # (layers that run through the window kernel -- decided by their last forward -- get that kernel's layout: modes 2 / 3)
+        wm = [(c.weight.detach(), m + (2 if c.use_window else 0)) for c, m in todo]
         if not all(w.dtype == torch.float32 and w.is_contiguous() for w, _ in wm):
             for conv in self._conv_list:
                 conv.prepack(dgrad=self.training)
@@ -210,7 +211,7 @@ class _BackboneBase(nn.Module):
         for (conv, mode), buf in zip(todo, packed):
             got.setdefault(conv, [None, None])[mode] = buf
         for conv, (f, d) in got.items():
-            conv.adopt_packs(f, d)
+            conv.adopt_packs(f, d)        # (stamped with the conv's current use_window: a later change of mind repacks)
 
     def _run(self, batch_dict):
         self._bump_bn_counters()

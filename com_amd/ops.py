@@ -786,23 +786,34 @@ class PackPlan:
     weights still live at the addresses the table was built with."""
 
     def __init__(self, weights_modes):
+        """modes 0 / 1: forward / data-gradient pack of the generic kernels; 2 / 3: the same for the window kernel
+        (pack_weight_window) -- those go through a second launch (pcd_subm_window_pack_weights_batched)."""
         lib = L.lib()
         self.keys = tuple((w.data_ptr(), m) for w, m in weights_modes)
         self.packed = []
-        rows, first = [], 0
+        rows, first, wrows, wfirst = [], 0, [], 0
         for w, mode in weights_modes:
             _require_cuda(w)
             assert w.dtype == torch.float32 and w.is_contiguous()
             cout, cin = w.shape[0], w.shape[-1]
             K = w.numel() // (cout * cin)
-            nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
-            buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+            if mode >= 2:
+                nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cin, cout))
+                assert nbytes > 0 and K == 27
+                buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+                wrows.append([w.data_ptr(), buf.data_ptr(), cin, mode - 2, wfirst, 0, 0, 0])
+                wfirst += (nbytes // 2 + 255) // 256
+            else:
+                nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
+                buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+                rows.append([w.data_ptr(), buf.data_ptr(), K, cin, cout, mode, first, 0])
+                first += (nbytes // 2 + 255) // 256
             self.packed.append(buf)
-            rows.append([w.data_ptr(), buf.data_ptr(), K, cin, cout, mode, first, 0])
-            first += (nbytes // 2 + 255) // 256
-        self.total_blocks = first
-        self.n = len(rows)
-        self.table = torch.tensor(rows, dtype=torch.int64).to(weights_modes[0][0].device) if rows else None
+        self.total_blocks, self.win_blocks = first, wfirst
+        self.n, self.nw = len(rows), len(wrows)
+        dev = weights_modes[0][0].device if weights_modes else None
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+        self.wtable = torch.tensor(wrows, dtype=torch.int64).to(dev) if wrows else None
 
     def valid_for(self, weights_modes):
         return self.keys == tuple((w.data_ptr(), m) for w, m in weights_modes)
@@ -811,6 +822,9 @@ class PackPlan:
         if self.n:
             L.check(L.lib().pcd_pack_weights_batched(L.ptr(self.table), self.n, self.total_blocks, L.stream_ptr()),
                     "pcd_pack_weights_batched")
+        if self.nw:
+            L.check(L.lib().pcd_subm_window_pack_weights_batched(L.ptr(self.wtable), self.nw, self.win_blocks,
+                                                                 L.stream_ptr()), "pcd_subm_window_pack_weights_batched")
         return self.packed
 
 
@@ -846,6 +860,72 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
                                                     L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),
                                                     L.ptr(addend), _byref(bnr), L.stream_ptr()),
                 "pcd_sparse_conv_gather_gemm")
+    return y
+
+
+# ---- window gather-GEMM for SubM 3x3x3 layers over z-fastest rows (spconv_win.hip) ----------------------------------
+def subm_window_tile_rows(c_in, c_out):
+    """Rows per tile of the window kernel for these widths; 0 = none."""
+    return int(L.lib().pcd_subm_window_tile_rows(int(c_in), int(c_out)))
+
+
+def subm_window_plan(rb, c_in, c_out):
+    """The three runs of neighbour rows of every tile of `rb` (a SubM 3x3x3 Rulebook), cached on the rulebook per tile
+    size: every conv of the indice_key, forward and backward, shares it."""
+    T = subm_window_tile_rows(c_in, c_out)
+    assert T > 0 and rb.subm and rb.kvol == 27
+    cache = rb.__dict__.setdefault("_win_plans", {})
+    if T not in cache:
+        lib = L.lib()
+        n = rb.nbr_out.shape[1]
+        plan = torch.empty((max(int(lib.pcd_subm_window_plan_bytes(n, int(c_in), int(c_out))), 32),), dtype=torch.uint8,
+                           device=rb.nbr_out.device)
+        L.check(lib.pcd_subm_window_plan(L.ptr(rb.nbr_out), n, n, L.ptr(rb.n_out_dev), int(c_in), int(c_out), L.ptr(plan),
+                                         L.stream_ptr()), "pcd_subm_window_plan")
+        cache[T] = plan
+    return cache[T]
+
+
+def pack_weight_window(weight, mode, out=None):
+    """weight [Cout, 3, 3, 3, Cin] f32 -> the window kernel's register-resident slices (mode 0 forward, 1 dgrad)."""
+    _require_cuda(weight)
+    w = weight.detach().contiguous().float()
+    cout, cin = w.shape[0], w.shape[-1]
+    lib = L.lib()
+    nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cin, cout))
+    assert nbytes > 0 and w.numel() == cout * 27 * cin
+    packed = out if (out is not None and out.numel() == nbytes // 2 and out.device == w.device) else \
+        torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    L.check(lib.pcd_subm_window_pack_weight(L.ptr(w), cin, cout, int(mode), L.ptr(packed), L.stream_ptr()),
+            "pcd_subm_window_pack_weight")
+    return packed
+
+
+def subm_window(x, packed_w, bias, rb, flip_k, c_out, addend=None, bn_reduce=None):
+    """gather_gemm over the SubM rulebook `rb` through the window kernel: y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o]).
+    x, y bf16 [n, c]; packed_w from pack_weight_window."""
+    _require_cuda(x, packed_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and rb.subm and rb.kvol == 27
+    n, c_in = x.shape
+    assert n == rb.nbr_out.shape[1]
+    plan = subm_window_plan(rb, c_in, c_out)
+    y = torch.empty((n, c_out), dtype=torch.bfloat16, device=x.device)
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == y.dtype and addend.is_contiguous() and addend.is_cuda
+
+    def meta():
+        pairs = int((rb.nbr_out >= 0).sum().item())
+        return dict(bytes=(n * c_in + n * c_out) * 2 + 8 * pairs + 27 * c_in * c_out * 2, flops=2 * pairs * c_in * c_out,
+                    rows=n, pairs=pairs)
+
+    bnr = None
+    if bn_reduce is not None:
+        bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows()), c_out, x.device)
+    with _Timed(f"subm_win_kernel<{c_in}> {c_in}->{c_out} K=27", meta):
+        L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
+                                                    rb.nbr_out.shape[1], int(bool(flip_k)), L.ptr(rb.n_out_dev), L.ptr(plan),
+                                                    c_out, L.ptr(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
+                "pcd_sparse_conv_subm_window")
     return y
 
 

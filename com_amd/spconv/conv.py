@@ -50,6 +50,27 @@ class SparseConvolution(SparseModule):
         self._packed_d = None
         self._packed_d_version = None
         self._fresh_f = self._fresh_d = False
+        # window gather-GEMM (spconv_win.hip): SubM 3x3x3 layers whose widths have a window kernel take it when the chain's
+        # rows are numbered z-fastest (ops.ROWS_YXZ; decided per forward from the rulebook) -- their packs are then in that
+        # kernel's layout
+        self.use_window = False
+
+    def window_capable(self):
+        """A window kernel exists for this layer (and the "subm_window" option admits it: bit 0 = 64 channels, bit 1 = 32)."""
+        if not (self.subm and tuple(self.kernel_size) == (3, 3, 3) and tuple(self.dilation) == (1, 1, 1)
+                and self.in_channels == self.out_channels):
+            return False
+        from .. import _lib as L
+        opt = L.get_option("subm_window")
+        bit = {64: 1, 32: 2}.get(self.in_channels, 0)
+        return bool(opt & bit) and ops.subm_window_tile_rows(self.in_channels, self.out_channels) > 0
+
+    def set_window(self, on):
+        on = bool(on)
+        if on != self.use_window:                  # the packs are in the other kernel's layout: drop them
+            self.use_window = on
+            self._packed_version = self._packed_d_version = None
+            self._fresh_f = self._fresh_d = False
 
     def reset_parameters(self):
         # spconv 2.x default init: kaiming_uniform_(a=sqrt(5)), bias ~ U(+-1/sqrt(fan_in))  (SURVEY.md A.5)
@@ -73,18 +94,23 @@ class SparseConvolution(SparseModule):
     # it, the forward / backward consumes it; in eval mode the pack is cached per (version, pointer) and
     # train()/eval() switches drop the cache.
     def _key(self):
-        return (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        return (self.weight._version, self.weight.data_ptr(), self.weight.device, self.use_window)
+
+    def _pack(self, mode, out):
+        if self.use_window:
+            return ops.pack_weight_window(self.weight, mode, out=out)
+        return ops.pack_weight(self.weight, mode, out=out)
 
     def _packed_fwd(self):
         if self._packed is None or self._packed_version != self._key() or (self.training and not self._fresh_f):
-            self._packed = ops.pack_weight(self.weight, 0, out=self._packed)
+            self._packed = self._pack(0, self._packed)
             self._packed_version = self._key()
         self._fresh_f = False
         return self._packed
 
     def _packed_dgrad(self):
         if self._packed_d is None or self._packed_d_version != self._key() or (self.training and not self._fresh_d):
-            self._packed_d = ops.pack_weight(self.weight, 1, out=self._packed_d)
+            self._packed_d = self._pack(1, self._packed_d)
             self._packed_d_version = self._key()
         self._fresh_d = False
         return self._packed_d
@@ -189,8 +215,13 @@ class SparseConvolution(SparseModule):
         fp8 = getattr(self, "fp8_train", None)
         if fp8 is not None and not (self.training and torch.is_grad_enabled()):
             fp8 = None                                  # (the fp8-forward training form; inference has Fp8Backbone)
+        # window kernel: SubM rulebook over z-fastest rows, bf16 features (decided here -- the packs follow the decision)
+        win = (fp8 is None and rb.subm and getattr(rb, "order", None) == ops.ROWS_YXZ and input.features.is_cuda
+               and input.features.dtype == torch.bfloat16 and input.features.shape[1] == self.in_channels
+               and self.window_capable())
+        self.set_window(win)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad,
-                                passthrough, **({"fp8": fp8} if fp8 is not None else {}))
+                                passthrough, **({"fp8": fp8} if fp8 is not None else {}), window=win)
         if dbg:
             _ops.stamp(f"cv{_ops.STAMPS['conv_seq']}_b")
             _ops.STAMPS["conv_seq"] += 1

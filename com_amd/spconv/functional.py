@@ -114,8 +114,10 @@ class SparseConvFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None):
-        """passthrough=True also returns `features` itself as a second output (the identity branch of a residual
+    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False):
+        """window=True: `packed_fwd` / `packed_dgrad` are window-kernel packs (ops.pack_weight_window) and `rb` is a SubM
+        3x3x3 rulebook over z-fastest rows: forward and data gradient run through ops.subm_window.
+        passthrough=True also returns `features` itself as a second output (the identity branch of a residual
         block): backward then receives the gradients of BOTH branches in one call and adds the identity gradient
         inside the dgrad kernel's epilogue instead of through a separate elementwise kernel."""
         cout, cin = weight.shape[0], weight.shape[-1]
@@ -133,6 +135,9 @@ class SparseConvFunction(Function):
             # input (straight-through: the quantisation is treated as the identity).  No BatchNorm sums in this epilogue.
             y = fp8.forward(x, b, rb, cout, out_dtype)
             stats = None
+        elif window:
+            assert out_dtype == torch.bfloat16 and rb.subm
+            y = ops.subm_window(x, packed_fwd, b, rb, False, cout, bn_reduce=stats)
         else:
             y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
                                 n_dev=rb.n_out_dev, bn_reduce=stats)
@@ -158,6 +163,7 @@ class SparseConvFunction(Function):
         ctx.weight_param = weight if isinstance(weight, torch.nn.Parameter) else None
         ctx.in_dtype = features.dtype
         ctx.passthrough = passthrough
+        ctx.window = bool(window) and fp8 is None
         ctx.save_for_backward(x, weight)
         if passthrough:
             return y, features.view_as(features)
@@ -168,7 +174,7 @@ class SparseConvFunction(Function):
         x, weight = ctx.saved_tensors
         rb = ctx.rb
         if dy is None:                               # only the identity branch received a gradient
-            return (d_ident, None, None, None, None, None, None, None)
+            return (d_ident, None, None, None, None, None, None, None, None)
         dy16 = _to_bf16_padded(dy, ctx.cout)
         dx = dw = db = None
         # dgrad and wgrad only share their inputs: at B = 4 neither fills the chip (1-4 waves per SIMD), so the
@@ -200,7 +206,10 @@ class SparseConvFunction(Function):
                                    invstd=link.invstd)
                 if not red.usable(ctx.cin_pad, ctx.in_dtype):
                     red = None
-            if rb.subm:
+            if rb.subm and ctx.window and ctx.in_dtype == torch.bfloat16:
+                dxp = ops.subm_window(dy16, packed_d, None, rb, True, ctx.cin_pad, addend=add, bn_reduce=red)
+            elif rb.subm:
+                assert not ctx.window, "window packs cannot feed the generic kernel"
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red)
             elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
@@ -270,7 +279,7 @@ class SparseConvFunction(Function):
                     t.record_stream(cur)
         if dx is None and d_ident is not None:
             dx = d_ident
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class BevDenseFunction(Function):
@@ -352,10 +361,10 @@ class SparseConvExactFunction(Function):
         return (dx, dw, db, None, None)
 
 
-def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None):
+def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False):
     if EXACT_FP32 and features.dtype == torch.float32:
         return SparseConvExactFunction.apply(features, weight, bias, rb, passthrough)
-    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough, fp8)
+    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough, fp8, window)
 
 
 class _ColsumLink:

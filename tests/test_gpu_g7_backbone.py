@@ -367,9 +367,9 @@ def test_g7_every_op_in_situ_forward_and_backward(golden):
     convs, bns = [], []
     orig_conv, orig_bn = Fsp.sparse_conv, Fsp.batch_norm_act
 
-    def conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False):
+    def conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, **kw):
         rec = dict(w=weight, b=bias, rb=rb, x=features.detach(), passthrough=passthrough)
-        out = orig_conv(_tap(features, rec, "dx"), weight, bias, rb, packed_fwd, packed_dgrad, passthrough)
+        out = orig_conv(_tap(features, rec, "dx"), weight, bias, rb, packed_fwd, packed_dgrad, passthrough, **kw)
         y = out[0] if passthrough else out
         rec["y"] = y.detach()
         if y.requires_grad:

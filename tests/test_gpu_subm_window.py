@@ -1,0 +1,195 @@
+"""Window gather-GEMM (com_amd/csrc/spconv_win.hip, pcd_sparse_conv_subm_window) -- forward and data gradient of SubM 3x3x3
+layers over z-fastest rows -- against the CPU oracle (oracle/pcd_oracle.c: spconv's gather-GEMM-scatter) on
+the same bf16-rounded operands, against the generic HIP kernel, and through the module / autograd path.
+
+Tolerance: the kernel accumulates in fp32 in its own order and rounds once to bf16, the oracle accumulates in fp32 in pair
+order: outputs agree to one bf16 ulp (2^-8 relative) on the rare elements whose fp32 sums straddle a rounding boundary --
+the bound below is 2^-7 of the value + 2^-7 of the layer's RMS (north_star: 1e-3 relative on bf16 features is the L2 figure,
+checked separately)."""
+import numpy as np
+import pytest
+import torch
+
+from com_amd.utils import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from com_amd import ops
+    return ops
+
+
+def _level(n_frames, lvl, order="yxz", frame0=0, beams=64, azim=2500):
+    """(indices tensor, rank map, shape) of level `lvl` (1..4) of the Waymo chain, rows numbered in `order`."""
+    from com_amd.hotpath import collate_points
+    ops = _ops()
+    frames = [synth.synth_cloud(frame0 + f, beams, azim) for f in range(n_frames)]
+    pts, offs = collate_points(frames, DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
+                            want_voxels=False, row_order=order, key_depth=41)
+    idx, rank, shape = res["coords"], res["rank"], [41, 1504, 1504]
+    for k, s, p in [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1))][:lvl - 1]:
+        rb = ops.rulebook_conv(idx, n_frames, shape, k, s, p, want_pairs=False, order=ops.ROW_ORDERS[order])
+        idx, rank, shape = rb.out_indices, rb.rank, rb.out_shape
+    return idx, rank, shape
+
+
+def _bf16(a):
+    return torch.from_numpy(a).to(torch.bfloat16)
+
+
+def _oracle_fwd(x16, w, bias, idx_np, shape, flip):
+    """y = bias + sum_k x[nbr[k'][o]] W_k in fp32 on the bf16-rounded operands (oracle conv over the SubM rulebook)."""
+    rb_o = O.rulebook_subm(idx_np, tuple(shape))
+    wk = O.weight_from_spconv2(w)                              # [K, cin, cout]
+    if flip:                                                   # data gradient: dx[i] = sum_k W_k^T dy[nbr[26 - k][i]]
+        wk = np.ascontiguousarray(wk[::-1].transpose(0, 2, 1))
+    return O.conv_fwd(x16.float().numpy(), O.bf16_round(wk), bias, rb_o, threads=8)
+
+
+def _close(y, ref, what):
+    y, ref = y.float().cpu().numpy(), np.asarray(ref, np.float32)
+    rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    err = np.abs(y - ref)
+    bound = 2.0 ** -7 * np.abs(ref) + 2.0 ** -7 * rms
+    assert (err <= bound).all(), (what, float(err.max()), rms, int((err > bound).sum()))
+    rel = float(np.linalg.norm((y - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+    assert rel < 3e-3, (what, rel)                             # bf16 output rounding alone is ~1.7e-3 relative L2
+    return rel
+
+
+@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2)])
+def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
+    ops = _ops()
+    idx, rank, shape = _level(1, lvl, beams=32 if lvl == 2 else 64, azim=1250 if lvl == 2 else 2500)
+    n = idx.shape[0]
+    assert n > 5000
+    rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False)
+    assert rb.order == ops.ROWS_YXZ
+    g = torch.Generator().manual_seed(ch)
+    w = torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))
+    bias = torch.randn(ch, generator=g) * 0.1
+    x = _bf16(torch.randn(n, ch, generator=g).numpy())
+    add = _bf16(torch.randn(n, ch, generator=g).numpy())
+    wd = w.to(DEV)
+    idx_np = idx.cpu().numpy()
+    # forward (+ bias)
+    y = ops.subm_window(x.to(DEV), ops.pack_weight_window(wd, 0), bias.to(DEV), rb, False, ch)
+    ref = _oracle_fwd(x, w.numpy(), bias.numpy(), idx_np, shape, False)
+    _close(y, ref, "forward")
+    # data gradient (+ addend): the k-flipped view with W^T
+    dx = ops.subm_window(x.to(DEV), ops.pack_weight_window(wd, 1), None, rb, True, ch, addend=add.to(DEV))
+    ref = _oracle_fwd(x, w.numpy(), None, idx_np, shape, True) + add.float().numpy()
+    _close(dx, ref, "dgrad")
+    # ... and the generic kernel on the same operands: identical except for elements on a rounding boundary
+    y0 = ops.gather_gemm(x.to(DEV), ops.pack_weight(wd, 0), bias.to(DEV), rb.nbr_out, 27, False, n, ch, torch.bfloat16)
+    d = (y0.float() - y.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(y0.float().abs().max())
+
+
+def test_window_batchnorm_sums_match_the_generic_kernels():
+    """PcdBnReduce in the window kernel's epilogue: mode 1 (sum y, sum y^2 of the rounded outputs) and mode 2 (sum dz, sum
+    dz * xhat with the ReLU mask) against sums taken from the kernel's own output in float64, and against the generic kernel."""
+    ops = _ops()
+    idx, rank, shape = _level(1, 3)
+    n, ch = idx.shape[0], 64
+    rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False)
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))).to(DEV)
+    x = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
+    bnx = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
+    bny = torch.relu(torch.randn(n, ch, generator=g)).to(DEV).to(torch.bfloat16)
+    mean = (torch.randn(ch, generator=g) * 0.3).to(DEV)
+    invstd = (torch.rand(ch, generator=g) + 0.5).to(DEV)
+    old = ops.BN_FUSED_MID
+    try:
+        for fused_mid in (False, True):
+            ops.BN_FUSED_MID = fused_mid
+            st = ops.BnReduce(1)
+            y = ops.subm_window(x, ops.pack_weight_window(w, 0), None, rb, False, ch, bn_reduce=st)
+            torch.cuda.synchronize()
+            got = st.partial.double().sum(0)
+            want = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)])
+            assert float(((got - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-5
+            for relu in (False, True):
+                red = ops.BnReduce(2, relu, x=bnx, y=bny if relu else None, mean=mean, invstd=invstd)
+                assert red.usable(ch, torch.bfloat16)
+                dx = ops.subm_window(x, ops.pack_weight_window(w, 1), None, rb, True, ch, bn_reduce=red)
+                torch.cuda.synchronize()
+                dz = dx.double() * ((bny.double() > 0) if relu else 1.0)
+                want = torch.stack([dz.sum(0), (dz * (bnx.double() - mean.double()) * invstd.double()).sum(0)])
+                got = red.partial.double().sum(0)
+                assert float(((got - want).abs() / want.abs().clamp_min(1.0)).max()) < 2e-5, (fused_mid, relu)
+    finally:
+        ops.BN_FUSED_MID = old
+
+
+def test_window_multi_pass_tiles_device_row_count_and_tiny_inputs():
+    """Rows NOT numbered z-fastest (first-appearance order: every run is far longer than the window) take the multi-pass
+    path -- same results as the generic kernel up to rounding ties; a capacity above the real row count with the count in
+    device memory; fewer rows than one tile."""
+    ops = _ops()
+    from com_amd.hotpath import collate_points
+    pts, offs = collate_points([synth.synth_cloud(2, 16, 250)], DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
+                            want_voxels=False)                   # first-appearance rows
+    idx = res["coords"]
+    n, ch = idx.shape[0], 64
+    assert 1000 < n < 6000
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))).to(DEV)
+    for rows in (n, 37):
+        ii = idx[:rows].contiguous()
+        rb = ops.rulebook_subm(ii, 1, [41, 1504, 1504], want_pairs=False)
+        x = torch.randn(rows, ch, generator=g).to(DEV).to(torch.bfloat16)
+        y1 = ops.subm_window(x, ops.pack_weight_window(w, 0), None, rb, False, ch)
+        y0 = ops.gather_gemm(x, ops.pack_weight(w, 0), None, rb.nbr_out, 27, False, rows, ch, torch.bfloat16)
+        d = (y0.float() - y1.float()).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(y0.float().abs().max()) and float((d > 0).float().mean()) < 5e-3
+    # capacity > rows, count on the device: rows beyond the count are neither read nor written
+    cap = 4096
+    assert cap > n - 500
+    rows = n - 500 if n - 500 < cap else cap - 100
+    big = torch.full((cap, 4), 7, dtype=torch.int32, device=DEV)
+    big[:rows] = idx[:rows]
+    n_dev = torch.tensor([rows], dtype=torch.int32, device=DEV)
+    rb = ops.rulebook_subm(big, 1, [41, 1504, 1504], want_pairs=False, n_dev=n_dev)
+    x = torch.randn(cap, ch, generator=g).to(DEV).to(torch.bfloat16)
+    y1 = ops.subm_window(x, ops.pack_weight_window(w, 0), None, rb, False, ch)
+    y0 = ops.gather_gemm(x, ops.pack_weight(w, 0), None, rb.nbr_out, 27, False, cap, ch, torch.bfloat16, n_dev=n_dev)
+    d = (y0[:rows].float() - y1[:rows].float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * float(y0[:rows].float().abs().max())
+
+
+def test_submconv3d_module_takes_the_window_kernel_on_yxz_rows_and_matches_the_generic_path():
+    """spconv.SubMConv3d (64 -> 64, bias) forward + backward through autograd on a z-fastest level: the layer routes itself to
+    the window kernel (use_window), and outputs / input gradient / weight gradient / bias gradient agree with the same layer
+    forced onto the generic kernels (option subm_window = 0)."""
+    from com_amd import spconv, _lib as L
+    ops = _ops()
+    idx, rank, shape = _level(1, 3)
+    n, ch = idx.shape[0], 64
+    torch.manual_seed(4)
+    conv = spconv.SubMConv3d(ch, ch, 3, padding=1, bias=True, indice_key="k").to(DEV)
+    feats = torch.randn(n, ch, device=DEV).to(torch.bfloat16)
+    gout = torch.randn(n, ch, device=DEV).to(torch.bfloat16)
+    outs = {}
+    for opt in (1, 0):
+        L.set_option("subm_window", opt)
+        try:
+            x = spconv.SparseConvTensor(feats.clone().requires_grad_(True), idx, shape, 1)
+            x.indice_dict[("__rank__", idx.data_ptr())] = rank
+            x.indice_dict["__row_order__"] = rank.order
+            conv.zero_grad()
+            y = conv(x)
+            assert conv.use_window == bool(opt)
+            y.features.backward(gout)
+            outs[opt] = (y.features.detach().float(), x.features.grad.float(), conv.weight.grad.clone(), conv.bias.grad.clone())
+        finally:
+            L.set_option("subm_window", 1)
+    for a, b, what in zip(outs[1], outs[0], ("y", "dx", "dw", "db")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2.0 ** -6 * scale, what

@@ -59,7 +59,8 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     pts, offs = hotpath.collate_points(frames, dev)
     res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1,
                             num_features=5, want_voxels=False,
-                            row_order=os.environ.get('PCD_ROW_ORDER', 'key'), key_depth=41)   # (what bench.py runs)
+                            row_order=os.environ.get('PCD_ROW_ORDER', 'yxz'), key_depth=41)   # (what bench.py runs)
+    ORDER = ops.ROW_ORDERS[os.environ.get('PCD_ROW_ORDER', 'yxz')]
     idx, shape = res['coords'], [41, 1504, 1504]
     rows = []
     tot_bytes = tot_t = tot_g = 0.0
@@ -68,10 +69,10 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     for lvl, geo in enumerate(geos):
         if geo is not None:
             n_in = idx.shape[0]
-            rbc, t = timed(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2]))
+            rbc, t = timed(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], order=ORDER))
             P = int(rbc.pair_num.sum())
             by = 16 * n_in + 8 * P + 16 * rbc.out_indices.shape[0]
-            tg = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl)),
+            tg = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER),
                              ("conv", lvl), int(rbc.out_indices.shape[0]))
             rows.append(dict(kind="strided", level=lvl + 1, n_in=n_in, n_out=int(rbc.out_indices.shape[0]), pairs=P,
                              us=round(t * 1e6, 1), graph_us=round(tg * 1e6, 1), alg_MB=round(by / 1e6, 1),
