@@ -72,9 +72,15 @@ def parse():
     ap.add_argument("--no-regime", action="store_true", help="skip the rulebook bandwidth-regime child run (B = 4 and B = 32)")
     ap.add_argument("--no-stage2", action="store_true", help="skip the PV-RCNN stage-2 (config 4) secondary figure")
     ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
+    ap.add_argument("--no-n-gt-1", action="store_true", help="skip the two child runs that measure the N > 1 execution form on one GPU")
+    ap.add_argument("--light", action="store_true", help="only the timed loop: every --no-* switch at once (experiment scripts)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU plumbing test of the launcher / result assembly: gloo ranks, no GPU work")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.light:
+        a.no_cpu_baseline = a.no_roofline = a.no_h2d = a.no_ragged = a.no_stage2 = a.no_full_model = a.no_fp8 = True
+        a.no_regime = a.no_n_gt_1 = True
+    return a
 
 
 class HotPath(torch.nn.Module):
@@ -129,7 +135,11 @@ def _rocprof_avg_us(kernel):
     import glob
     import re
     m = re.match(r"(\w+)<NB=(\d+)>", kernel)
-    pat = re.compile(re.escape(m.group(1)) + r"<" + m.group(2) + r",") if m else re.compile(re.escape(kernel.split(" ")[0]) + r"[<(]")
+    mw = re.match(r"subm_win_kernel<(\d+)>", kernel)
+    if mw:
+        pat = re.compile(r"subm_win_kernel<.*WinCfg<" + mw.group(1) + r",")
+    else:
+        pat = re.compile(re.escape(m.group(1)) + r"<" + m.group(2) + r",") if m else re.compile(re.escape(kernel.split(" ")[0]) + r"[<(]")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_eager.txt")),
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     for path in reversed(files):
@@ -217,7 +227,7 @@ def measure_roofline(step_fn, ms_per_step):
     groups = _profiled_groups(step_fn)
     if not groups:
         return None
-    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "ggw", "wgrad"))}
+    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "ggw", "wgrad", "subm_win"))}
     name, g = max(conv_like.items() or groups.items(), key=lambda kv: kv[1]["ms"])
     out = _group_roofline(name, g)
     traffic, source = _pmc_traffic(name)
@@ -225,8 +235,12 @@ def measure_roofline(step_fn, ms_per_step):
     out["traffic_source"] = source
     out["event_overhead_us"] = round(1e3 * EVENT_OVERHEAD_MS[0], 2)      # (already subtracted per launch)
     rp, rp_src = _rocprof_avg_us(name)
-    if rp is not None:           # the profiler's figure for the same kernel (another box, another run): both are reported
+    if rp is not None:           # the profiler's figure for the same kernel (another box, another run): both are reported,
+        # named, at the top level: `frac` = HIP events of THIS run (they bracket a launch on the stream and read ~10 % longer
+        # than the profiler's kernel duration), `frac_rocprof` = the same algorithmic work over the committed profile's average
         out["rocprof"] = {"avg_launch_us": rp, "frac": round(out["frac"] * out["avg_launch_us"] / rp, 4), "source": rp_src}
+        out["frac_rocprof"] = out["rocprof"]["frac"]
+        out["frac_source"] = "HIP events in this run (avg_launch_us); frac_rocprof: " + rp_src
     total_ms = sum(v["ms"] for v in groups.values())
     out["kernels"] = [_group_roofline(k, v) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
                       if v["ms"] >= 0.02 * total_ms]
@@ -260,27 +274,59 @@ def measure_cpu_baseline():
     fp32, compiled -O3 -march=native) on the host's cores, timed on ONE WHOLE synthetic frame, unsampled: voxelise,
     MeanVFE, all 9 rulebooks, all 21 convs of VoxelResBackBone8x (spconv_backbone.py:191-232) forward + backward,
     21 BatchNorm+ReLU fwd+bwd (torch-CPU), BEV dense + its gradient.  value = 1 / median of 3 whole-frame passes.
-    The conv arithmetic and BN run on `cores` threads (OpenMP over the pairs of a kernel offset / torch intra-op);
-    voxelisation, rulebooks and the BEV scatter are sequential algorithms and run on one core.  One single-core
-    pass is timed too (`single_core_value`)."""
+    The conv arithmetic and BN run on `cores` threads (OpenMP over the pairs of a kernel offset / torch intra-op).  The
+    rulebook builders' per-offset loops can run on threads too (orc_set_rulebook_threads): they are timed once sequentially
+    and once on min(cores, 27) threads and the faster setting is used and reported (`rulebook_threads`; hash probes bound by
+    memory latency -- on the 8-core build container threads LOSE: 0.07 s vs 0.10-0.13 s for the level-1 SubM build).
+    Voxelisation (first-appearance order: sequential by definition) and the BEV scatter run on one core.  One single-core
+    pass is timed too (`single_core_value`).  `cores` = min(host cores, 64) is a cap, not a measured optimum: the baseline
+    is a reported figure, never the target (`host_cores_available` says what the box had)."""
     from oracle import oracle as O          # cpu_baseline leg only
     mt = max(1, min(os.cpu_count() or 1, 64))
+    RB_THREADS[0] = _pick_rulebook_threads(O, min(mt, 27))
     passes = [_cpu_frame(O, mt) for _ in range(3)]
     passes.sort(key=lambda t: t[0])
     per_frame, parts = passes[1]
     st_total = _cpu_frame(O, 1)[0] if mt > 1 else per_frame
     return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": mt, "kind": "port",
             "host_cores_available": os.cpu_count(), "single_core_value": round(1.0 / st_total, 4),
+            "rulebook_threads": RB_THREADS[0],
             "passes_s": [round(t[0], 3) for t in passes],
             "sample": "1 whole synthetic 160k-pt frame (unsampled), fp32 C oracle (spconv native gather-GEMM-scatter): "
                       "voxelize + MeanVFE + 9 rulebooks + all 21 VoxelResBackBone8x convs fwd+bwd + 21 BN/ReLU fwd+bwd "
-                      f"(torch-CPU) + BEV dense fwd+bwd; median of 3 passes; conv and BN on {mt} threads, the rest on "
-                      "1; " + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
+                      f"(torch-CPU) + BEV dense fwd+bwd; median of 3 passes; conv and BN on {mt} threads, rulebooks on "
+                      f"{RB_THREADS[0]} (the faster of 1 / {min(mt, 27)}), the rest on 1; " + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
                       + f"; all on one core: {st_total:.2f}s per frame"}
+
+
+RB_THREADS = [1]
+
+
+def _pick_rulebook_threads(O, cand):
+    """1 or `cand`: whichever builds the level-1 SubM rulebook of a frame faster (median of 3)."""
+    if cand <= 1:
+        return 1
+    pts = synth.synth_cloud(0)
+    _, c, _ = O.voxelize_hard(pts, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS)
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    best = (None, 1)
+    for th in (1, cand):
+        O.set_rulebook_threads(th)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.rulebook_subm(idx, (41, 1504, 1504))
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[1]
+        if best[0] is None or med < best[0]:
+            best = (med, th)
+    O.set_rulebook_threads(1)
+    return best[1]
 
 
 def _cpu_frame(O, threads):
     torch.set_num_threads(threads)
+    O.set_rulebook_threads(RB_THREADS[0] if threads > 1 else 1)
     rng = np.random.default_rng(0)
     t_total = {}
     if threads > 1:      # start the OpenMP thread pool outside the timed region
@@ -613,7 +659,7 @@ def measure_regime():
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def measure_full_model(args, flags=("--dense-head", "--com"), what=None):
+def measure_full_model(args, flags=("--dense-head", "--com"), what=None, extra_env=None):
     """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
     run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
     loops have finished; the child is a new process, nothing is exec'ed over this one.  (`fp8_config5` reuses this
@@ -621,10 +667,12 @@ def measure_full_model(args, flags=("--dense-head", "--com"), what=None):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), *flags, "--gpus", "1", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-regime"]
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-regime",
+           "--no-n-gt-1"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env.update(extra_env or {})
     try:
         t0 = time.perf_counter()
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -655,6 +703,7 @@ def main():
               f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)",
               file=sys.stderr)
         sys.exit(2)
+    cdist.apply_rank_affinity()                              # (opt-in pinning of launch_local_ranks, before any GPU call)
     if args.selftest_launch:
         return selftest_launch(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -1126,6 +1175,7 @@ def main():
         try:
             one_graph = use_graph and world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1
             h2d_form = "copy stream"
+            trial_ms = []
             if one_graph and os.environ.get('PCD_H2D_PULL'):
                 # (opt-in) the step's own graph pulls the next batch from pinned host memory (PullSource): no copy stream, no
                 # events, nothing bimodal -- but the hipGraph executor runs the extra branch IN SERIES with the step (it keeps
@@ -1176,6 +1226,9 @@ def main():
             el = cdist.max_over_ranks(el, dev)
             h2d = {"value": round(world * B * args.steps / el, 3), "unit": "frames/s",
                    "ms_per_step": round(1e3 * el / max(args.steps, 1), 4), "form": h2d_form,
+                   # what a user gets WITHOUT trying streams: the first stream created (8-step trial), beside the best-of-N
+                   "first_stream_ms_per_step": (trial_ms[0] if (not os.environ.get('PCD_H2D_PULL') and trial_ms) else None),
+                   "worst_stream_ms_per_step": (max(trial_ms) if (not os.environ.get('PCD_H2D_PULL') and trial_ms) else None),
                    "what": "same timed loop, points of every batch arriving from PINNED HOST memory inside the step (15.4 MB "
                            "/ step / GPU) on a copy stream two batches ahead, overlapped with compute; `value` above is the "
                            "HBM-resident figure the contract asks for"}
@@ -1302,6 +1355,25 @@ def main():
             what="child run `bench.py --config5`: BASELINE config 5 as a TRAINING step -- SECOND's VoxelBackBone8x on "
                  "300k-point clouds, fp8 (e4m3, v_mfma_f32_16x16x32_fp8_fp8) forward convs with static per-tensor scales, "
                  "batch-statistics BatchNorm, bf16 backward; one hipGraph per step")
+    if rank == 0 and world == 1 and not args.no_n_gt_1 and not args.dense_head and not args.config5 \
+            and not os.environ.get("PCD_FORCE_3GRAPH") and not os.environ.get("PCD_RCCL_WORLD1"):
+        # what N > 1 GPUs run, measured on this one GPU: the three-graph form (voxelise | forward + backward | all-reduce of
+        # the flat gradient bucket, then clip + Adam) with a real RCCL communicator of ONE rank, and the same form without
+        # the collective -- the difference is what the exchange step costs a rank before any byte crosses xGMI
+        a = measure_full_model(args, flags=(), what="three-graph form + dist.all_reduce over a one-rank RCCL communicator",
+                               extra_env={"PCD_RCCL_WORLD1": "1"})
+        b = measure_full_model(args, flags=(), what="three-graph form, no collective", extra_env={"PCD_FORCE_3GRAPH": "1"})
+        if "error" in a or "error" in b:
+            result["n_gt_1_form"] = {"error": a.get("error") or b.get("error")}
+        else:
+            result["n_gt_1_form"] = {
+                "ms_per_step": a["ms_per_step"], "ms_per_step_no_collective": b["ms_per_step"],
+                "ms_allreduce_exposed": round(a["ms_per_step"] - b["ms_per_step"], 4),
+                "ms_per_step_one_graph": result["ms_per_step"], "bucket_MB": round(bucket.flat.numel() * 4 / 1e6, 2),
+                "what": "the N > 1 execution form on ONE GPU (child runs): voxelise | forward+backward | all-reduce | clip+Adam "
+                        "as three graphs around the collective; a one-rank RCCL all-reduce moves no bytes, so "
+                        "ms_allreduce_exposed is the launch / synchronisation cost of the exchange step only -- the wire "
+                        "time of 2 (N-1)/N x bucket over xGMI comes on top at N > 1 (DESIGN.md section 6)"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -639,6 +639,7 @@ extern "C" int pcd_com_loss_forward(const void *hm, int hm_dtype, const long lon
     if ((double)batch * (num_classes > CHL_MAX_DIM ? num_classes : CHL_MAX_DIM) * height * width >= 2147483647.0)
         return PCD_ERR_UNSUPPORTED;
     if (num_max_objs > CHL_MAX_OBJS) return PCD_ERR_UNSUPPORTED;
+    if (batch > COM_BLOCKS) return PCD_ERR_UNSUPPORTED;   // (the regression sums take one workgroup per frame of a fixed grid)
     ComCur cur = com_cur(cur_host, radius_map_cols == 5);
     if (cur.conf_c * cur.conf_g > 512) return PCD_ERR_UNSUPPORTED;
     if (cur.conf_c > 0 && (!conf_all || !num_all)) return PCD_ERR_INVALID_ARG;

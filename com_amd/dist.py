@@ -242,26 +242,25 @@ def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):
             s.bind(("127.0.0.1", 0))
             master_port = s.getsockname()[1]
     procs = []
-    # per-rank CPU affinity: the host cores are dealt to the ranks in contiguous blocks (rank r launches and polls from
-    # its own cores; with 8 ranks on one node the launch threads otherwise migrate across sockets); PCD_NO_AFFINITY=1 skips
+    # Per-rank CPU affinity is OPT-IN (PCD_RANK_AFFINITY=1): contiguous blocks of the allowed cores ignore NUMA and SMT
+    # numbering (where logical CPUs N/2.. are the hyperthreads of 0..N/2-1 the upper ranks would land on the lower ranks'
+    # siblings), and binding to the GPU-local node measured slower for the H2D loop on the gpurun boxes.  The child applies it
+    # to itself at start-up (PCD_PIN_CPUS, read by apply_rank_affinity()) -- no preexec_fn: that hook runs between fork and
+    # exec of a multi-threaded parent (torch is loaded here), which Python documents as unsafe.
     try:
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:
         cores = []
-    per = len(cores) // n if (cores and not os.environ.get("PCD_NO_AFFINITY")) else 0
-
-    def pin(r):
-        if per < 1:
-            return None
-        mine = set(cores[r * per:(r + 1) * per])
-        return lambda: os.sched_setaffinity(0, mine)
+    per = len(cores) // n if (cores and os.environ.get("PCD_RANK_AFFINITY") == "1") else 0
 
     for r in range(n):
         e = dict(os.environ if env is None else env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(master_port)})
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr, preexec_fn=pin(r)))
+        if per >= 1:
+            e["PCD_PIN_CPUS"] = ",".join(str(c) for c in cores[r * per:(r + 1) * per])
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
     t0 = time.time()
     codes = [None] * n
     try:
@@ -283,6 +282,17 @@ def launch_local_ranks(n, argv, env=None, master_port=None, timeout=None):
                     codes[i] = p.wait()
                 codes[i] = codes[i] if codes[i] not in (None, 0) else -15
     return codes
+
+
+def apply_rank_affinity():
+    """Child side of launch_local_ranks' opt-in pinning: bind this process to the cores listed in PCD_PIN_CPUS (call it
+    first thing in the rank's main, before anything touches the GPU)."""
+    spec = os.environ.get("PCD_PIN_CPUS")
+    if spec:
+        try:
+            os.sched_setaffinity(0, {int(c) for c in spec.split(",") if c})
+        except (AttributeError, OSError, ValueError):
+            pass
 
 
 def max_over_ranks(value, device="cpu"):

@@ -632,8 +632,9 @@ CLS_TILE = 256
 import os as _os
 BN_FUSED_MID = _os.environ.get("PCD_BN_FUSED_MID", "1") != "0"   # fold the BatchNorm "mid" reduction into the conv launches
 _BN_COUNTER_POOL = {}     # device -> [int32 zeros [slots * 16], next slot]     (eager launches)
-_BN_CAPTURE_BLOCK = {}    # device -> [capture id, int32 zeros, next slot]      (launches recorded into ONE hipGraph)
+_BN_CAPTURE_BLOCK = {}    # (device, stream) -> [capture id, int32 zeros, next slot]   (launches recorded into a hipGraph)
 _BN_SLOTS = 1024
+_BN_CAPTURE_SLOTS = 128    # slots per captured block (a training step takes ~45 on its main stream; a full block -> a new one)
 
 
 def _capture_id():
@@ -647,20 +648,26 @@ def _bn_counters(device):
     """16 zeroed int32 counters (one per 128-byte line) for one conv launch with a fused mid reduction.  The kernels
     return them to zero.  Eager launches take slots round-robin from a pool zeroed once (1024 slots: far more launches
     than are ever in flight on one device).  Launches recorded into a hipGraph NEVER share a slot with anything else:
-    every capture owns blocks allocated inside it (its private memory pool; zeroed by ONE memset node per block), slots
-    are handed out once per capture -- so eager launches, a second graph or a re-capture running concurrently on
-    another stream cannot bump a captured launch's counters."""
-    key = str(device)
+    every (capture, STREAM) pair owns blocks allocated inside the capture (its private memory pool) and zeroed by a memset
+    node recorded on that very stream -- so the memset is ordered in front of every launch that takes a slot of the block
+    whatever the fork / join structure of the captured streams is (one block per capture, zeroed on the stream that
+    happened to ask first, left the launches of the other branches without a dependency on that memset: on replay it could
+    have run during one of their reductions).  Slots are handed out once per capture -- eager launches, a second graph or a
+    re-capture running concurrently on another stream cannot bump a captured launch's counters."""
     per = L.BN_MID_ROWS * L.BN_COUNTER_STRIDE
     cid = _capture_id() if torch.cuda.is_current_stream_capturing() else 0
     if cid:
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
         blk = _BN_CAPTURE_BLOCK.get(key)
-        if blk is None or blk[0] != cid or blk[2] >= _BN_SLOTS:
-            blk = _BN_CAPTURE_BLOCK[key] = [cid, torch.zeros((_BN_SLOTS * per,), dtype=torch.int32, device=device), 0]
+        if blk is None or blk[0] != cid or blk[2] >= _BN_CAPTURE_SLOTS:
+            for k in [k for k, b in _BN_CAPTURE_BLOCK.items() if b[0] != cid]:
+                del _BN_CAPTURE_BLOCK[k]               # blocks of finished captures live on in their graphs' pools
+            blk = _BN_CAPTURE_BLOCK[key] = [cid, torch.zeros((_BN_CAPTURE_SLOTS * per,), dtype=torch.int32, device=device), 0]
         slot = blk[2]
         blk[2] += 1
         return blk[1][slot * per:(slot + 1) * per]
-    _BN_CAPTURE_BLOCK.pop(key, None)               # (drop the reference: the block lives as long as its graph's pool)
+    _BN_CAPTURE_BLOCK.clear()                          # (drop the references: the blocks live as long as their graph's pool)
+    key = str(device)
     ent = _BN_COUNTER_POOL.get(key)
     if ent is None:
         ent = _BN_COUNTER_POOL[key] = [torch.zeros((_BN_SLOTS * per,), dtype=torch.int32, device=device), 0]

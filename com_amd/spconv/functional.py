@@ -462,6 +462,13 @@ def _fusable(bn, x):
     import torch.nn as nn
     if not isinstance(bn, nn.modules.batchnorm._BatchNorm) or not x.is_cuda or x.dim() != 2:   # (1d; 2d via hotpath.conv2d_fast)
         return False
+    if isinstance(bn, nn.SyncBatchNorm) and bn.training:
+        # --sync_bn (tools/train.py:34,134-135: convert_sync_batchnorm): statistics over ALL ranks.  The fused kernels take
+        # per-rank statistics only, so a SyncBatchNorm in training mode goes through torch's own module (its all_gather of
+        # the per-rank sums included) -- correct, unfused, eager only; in eval mode it is an ordinary BatchNorm.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
     if x.dtype not in (torch.float32, torch.bfloat16):
         return False
     c = x.shape[1]

@@ -173,6 +173,11 @@ def conv_out_shape(in_shape, ksize, stride, padding, dilation):
     return out
 
 
+def set_rulebook_threads(t):
+    """Threads of the per-offset loops of rulebook_subm / rulebook_conv (results do not depend on it; bench.py's CPU baseline)."""
+    lib().orc_set_rulebook_threads(int(t))
+
+
 def rulebook_subm(indices, spatial_shape, ksize=3, dilation=1):
     indices = _i32(indices)
     n = indices.shape[0]

@@ -237,6 +237,12 @@ static inline int64_t orc_lin(int b, int z, int y, int x, const int shape[3]) {
     return (((int64_t)b * shape[0] + z) * shape[1] + y) * shape[2] + x;
 }
 
+/* Threads of the per-offset loops of the two rulebook builders (bench.py's multi-core CPU baseline; 1 = sequential, the
+ * default).  The offsets are independent once the coordinate map is built: every k writes its own rows of pairs / nbr_out /
+ * nbr_in / pair_num, so the tables are identical for any thread count. */
+static int orc_rb_threads = 1;
+void orc_set_rulebook_threads(int t) { orc_rb_threads = t > 1 ? t : 1; }
+
 int orc_rulebook_subm(const int32_t *indices, int n, const int shape[3], const int ksize[3],
                       const int dil[3], int32_t *pairs, int32_t *pair_num, int32_t *nbr_out,
                       int32_t *nbr_in) {
@@ -257,6 +263,7 @@ int orc_rulebook_subm(const int32_t *indices, int n, const int shape[3], const i
     for (size_t q = 0; q < (size_t)K * n; ++q) nbr_out[q] = -1;
     if (nbr_in)
         for (size_t q = 0; q < (size_t)K * n; ++q) nbr_in[q] = -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_rb_threads) if (orc_rb_threads > 1)
     for (int k = 0; k < K; ++k) {
         int kd = k / (ksize[1] * ksize[2]), kh = (k / ksize[2]) % ksize[1], kw = k % ksize[2];
         int cnt = 0;
@@ -361,6 +368,7 @@ int orc_rulebook_conv(const int32_t *indices, int n, const int in_shape[3], cons
     for (size_t q = 0; q < (size_t)K * out_cap; ++q) nbr_out[q] = -1;
     if (nbr_in)
         for (size_t q = 0; q < (size_t)K * n; ++q) nbr_in[q] = -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_rb_threads) if (orc_rb_threads > 1)
     for (int k = 0; k < K; ++k) {
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
