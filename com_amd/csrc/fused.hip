@@ -22,6 +22,9 @@ struct Piece;  // 16-byte piece of a row
 template <>
 struct Piece<float> {
     static constexpr int N = 4;
+    typedef float4 Raw;
+    __device__ static Raw raw(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    __device__ static void decode(const Raw &r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
     __device__ static void load(const float *p, float (&v)[4]) {
         float4 r = *reinterpret_cast<const float4 *>(p);
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
@@ -34,8 +37,11 @@ struct Piece<float> {
 template <>
 struct Piece<unsigned short> {
     static constexpr int N = 8;
-    __device__ static void load(const unsigned short *p, float (&v)[8]) {
-        uint4 r = *reinterpret_cast<const uint4 *>(p);
+    typedef uint4 Raw;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    __device__ static Raw raw(const unsigned short *p) { return *reinterpret_cast<const uint4 *>(p); }
+    __device__ static void decode(const Raw &r, float (&v)[8]) {
         u32 w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -43,14 +49,18 @@ struct Piece<unsigned short> {
             v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
         }
     }
+    __device__ static void load(const unsigned short *p, float (&v)[8]) { decode(raw(p), v); }
+    // v_cvt_pk_bf16_f32: round to nearest even, two values per instruction (= f32_to_bf16_bits for every finite value)
+    __device__ static u32 pack2(float a, float b) {
+        return __builtin_bit_cast(u32, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+    }
     __device__ static void store(unsigned short *p, const float (&v)[8]) {
         u32 w[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            w[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) w[j] = pack2(v[2 * j], v[2 * j + 1]);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    __device__ static float stored(float v) { return __uint_as_float((u32)f32_to_bf16_bits(v) << 16); }
+    __device__ static float stored(float v) { return __uint_as_float(pack2(v, 0.0f) << 16); }
 };
 
 // A thread's N per-channel parameters.  16-byte loads when the arrays allow it (`vec`, decided on the host from the
@@ -340,6 +350,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
+    // The first two pieces of this thread are requested BEFORE the statistics prologue below (16 dependent L2 reads per
+    // column + a barrier: ~2 us in which nothing streamed -- a fifth of the launch at 4 pieces per thread).
+    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
+    typename Piece<T>::Raw px[2], pr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const size_t e = e0 + u * S < total ? e0 + u * S : 0;          // (beyond the end: any valid piece, unused)
+        px[u] = Piece<T>::raw(x + e * N);
+        if (res) pr[u] = Piece<T>::raw(res + e * N);
+    }
     if (fin.mid) {
         // training: finish the batch statistics here (see bn_mid_kernel); workgroup 0 also publishes them
         double *tot = (double *)dyn_lds;
@@ -378,13 +398,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     }
     // y may be a column block of a wider matrix (row stride y_ld elements): row = e / pcs advances by a whole number
     // of rows per grid stride
-    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
     size_t ye = (e0 / pcs) * (size_t)(y_ld / N) + piece;
     const size_t ystep = (S / pcs) * (size_t)(y_ld / N);
-    for (size_t e = e0; e < total; e += S, ye += ystep) {
+    auto finish = [&](const typename Piece<T>::Raw &xr, const typename Piece<T>::Raw &rr, size_t yat) {
         float v[N], r[N];
-        Piece<T>::load(x + e * N, v);
-        if (res) Piece<T>::load(res + e * N, r);
+        Piece<T>::decode(xr, v);
+        if (res) Piece<T>::decode(rr, r);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float o = v[j] * sc[j] + sh[j];
@@ -392,7 +411,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
             if (relu) o = o > 0.0f ? o : 0.0f;
             v[j] = o;
         }
-        Piece<T>::store(y + ye * N, v);
+        Piece<T>::store(y + yat * N, v);
+    };
+    size_t e = e0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u, e += S, ye += ystep)
+        if (e < total) finish(px[u], pr[u], ye);
+    for (; e < total; e += S, ye += ystep) {
+        const typename Piece<T>::Raw xr = Piece<T>::raw(x + e * N);
+        typename Piece<T>::Raw rr = xr;
+        if (res) rr = Piece<T>::raw(res + e * N);
+        finish(xr, rr, ye);
     }
 }
 
@@ -496,6 +525,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     float mu[N], is[N], gm[N], sh[N], k1[N], k2[N], gmv[N], btv[N];
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
     const bool mask_from_x = relu && y == nullptr;
+    // the first two pieces of this thread are requested BEFORE the reduction prologue below (see bn_apply_kernel)
+    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
+    size_t de = (e0 / pcs) * (size_t)(dy_ld / N) + piece;              // dy: row stride dy_ld elements
+    const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
+    typename Piece<T>::Raw pg[2], px[2], py[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bool in = e0 + u * S < total;
+        pg[u] = Piece<T>::raw(dy + (in ? de + u * dstep : 0) * N);
+        px[u] = Piece<T>::raw(x + (in ? e0 + u * S : 0) * N);
+        if (relu && !mask_from_x) py[u] = Piece<T>::raw(y + (in ? e0 + u * S : 0) * N);
+    }
     load_params<N>(mean, piece * N, vec, mu);
     load_params<N>(invstd, piece * N, vec, is);
     if (gamma) load_params<N>(gamma, piece * N, vec, gmv); else fill_params<N>(1.0f, gmv);
@@ -535,14 +576,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     float cs[1][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) cs[0][j] = 0.0f;
-    const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
-    size_t de = (e0 / pcs) * (size_t)(dy_ld / N) + piece;              // dy: row stride dy_ld elements
-    const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
-    for (size_t e = e0; e < total; e += S, de += dstep) {
+    auto finish = [&](const typename Piece<T>::Raw &gr, const typename Piece<T>::Raw &xr, const typename Piece<T>::Raw &yr,
+                      size_t e) {
         float g[N], xv[N], yv[N], o[N];
-        Piece<T>::load(dy + de * N, g);
-        Piece<T>::load(x + e * N, xv);
-        if (relu && !mask_from_x) Piece<T>::load(y + e * N, yv);
+        Piece<T>::decode(gr, g);
+        Piece<T>::decode(xr, xv);
+        if (relu && !mask_from_x) Piece<T>::decode(yr, yv);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float t = mask_from_x ? xv[j] * gm[j] + sh[j] : yv[j];
@@ -554,6 +593,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         }
         Piece<T>::store(dx + e * N, o);
         if (dres) Piece<T>::store(dres + e * N, g);
+    };
+    size_t e = e0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u, e += S, de += dstep)
+        if (e < total) finish(pg[u], px[u], py[u], e);
+    for (; e < total; e += S, de += dstep) {
+        const typename Piece<T>::Raw gr = Piece<T>::raw(dy + de * N), xr = Piece<T>::raw(x + e * N);
+        typename Piece<T>::Raw yr = xr;
+        if (relu && !mask_from_x) yr = Piece<T>::raw(y + e * N);
+        finish(gr, xr, yr, e);
     }
     if (colsum_partial) {
         __syncthreads();      // the prologue's use of the dynamic LDS is over

@@ -485,6 +485,7 @@ static void launch_pairs_fill(const int32_t *tbl, int n, const int32_t *n_dev, i
 
 // ---------------------------------------------------------------------------------------------
 // strided conv
+template <int ORD>
 __device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int bq, int cq, u32 &key) {
     int tz = c.y + G.pd - a * G.dd;
     int ty = c.z + G.ph - bq * G.dh;
@@ -495,7 +496,7 @@ __device__ __forceinline__ bool out_cell(const ConvGeom &G, int4 c, int a, int b
     int ox = G.sw == 2 ? (tx >> 1) : (G.sw == 1 ? tx : tx / G.sw);
     if (oz * G.sd != tz || oy * G.sh != ty || ox * G.sw != tx) return false;
     if (oz >= G.Do || oy >= G.Ho || ox >= G.Wo) return false;
-    key = ord_key(G.order, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
+    key = ord_key(ORD, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo);
     return true;
 }
 
@@ -530,6 +531,7 @@ __device__ __forceinline__ void block_class_counts(int cls, int ncls, int *cnt /
 }
 
 // blk_cnt != NULL: the launch also counts the rows of every parity class (ncls of them) per block
+template <int ORD>
 __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
                                                         unsigned char *__restrict__ bytemap, int ncls,
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int4 *__restrict__
                 if (ox < 0) continue;
                 // one BYTE per output cell: plain stores of the same value need no atomics (about 8 inputs mark
                 // each cell; the 32-bit-word bitmap this replaced cost one memory-side atomic per mark)
-                bytemap[ord_key(G.order, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo)] = 1;
+                bytemap[ord_key(ORD, c.x, oz, oy, ox, G.Do, G.Ho, G.Wo)] = 1;
             }
         }
     }
@@ -786,6 +788,7 @@ __device__ __forceinline__ void publish_wave_count(int *__restrict__ wave_cnt, i
 }
 
 // perm != NULL: the launch also writes the parity-class permutation of the input rows (blk_off from class_offsets)
+template <int ORD>
 __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__ idx, int n,
                                                         const int32_t *n_dev, ConvGeom G,
                                                         const u32 *__restrict__ bitmap,
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256) void conv_fill_kernel(const int4 *__restrict__
             for (int cq = 0; cq < G.kw; ++cq, ++k) {
                 int o = -1;
                 u32 key;
-                if (live && out_cell(G, c, a, bq, cq, key)) {
+                if (live && out_cell<ORD>(G, c, a, bq, cq, key)) {
                     u32 w = key >> 5;
                     o = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
                     if (o < n_out) nbr_out[(size_t)k * n_out + o] = i; else o = -1;
@@ -994,9 +997,14 @@ struct ClsOut {
 static void conv_launch_mark(const int32_t *indices, int n, const int32_t *n_dev, const ConvGeom &G, const ConvWs &L,
                              const ClsOut *C, hipStream_t st) {
     pcd_fill(L.bytemap, 0, L.zero_bytes, st);
-    if (n > 0)
-        conv_mark_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap,
-                                                             C ? C->ncls : 0, C ? L.blk_cnt : nullptr);
+    if (n > 0) {
+        if (G.order == PCD_ROWS_YXZ)
+            conv_mark_kernel<PCD_ROWS_YXZ><<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap,
+                                                                               C ? C->ncls : 0, C ? L.blk_cnt : nullptr);
+        else
+            conv_mark_kernel<PCD_ROWS_ZYX><<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bytemap,
+                                                                               C ? C->ncls : 0, C ? L.blk_cnt : nullptr);
+    }
     conv_pack_sum_kernel<<<L.nblk, 256, 0, st>>>((const uint4 *)L.bytemap, L.nwords, L.bitmap, L.bsums, L.super,
                                                  L.nblk <= CONV_DIRECT_BLOCKS);
 }
@@ -1034,10 +1042,14 @@ static void conv_launch_scan(int n, const ConvGeom &G, const ConvWs &L, int32_t 
 static void conv_launch_fill(const int32_t *indices, int n, const int32_t *n_dev, const ConvGeom &G, const ConvWs &L,
                              int n_out, int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
                              int pad_pairs, const ClsOut *C, hipStream_t st) {
-    conv_fill_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix,
-                                                         n_out, nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr,
-                                                         L.nwaves, L.wsuper, L.nws, C ? C->ncls : 0, L.blk_cnt,
-                                                         C ? C->perm : nullptr);
+    if (G.order == PCD_ROWS_YXZ)
+        conv_fill_kernel<PCD_ROWS_YXZ><<<pcd_div_up(n, 256), 256, 0, st>>>(
+            (const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix, n_out, nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr,
+            L.nwaves, L.wsuper, L.nws, C ? C->ncls : 0, L.blk_cnt, C ? C->perm : nullptr);
+    else
+        conv_fill_kernel<PCD_ROWS_ZYX><<<pcd_div_up(n, 256), 256, 0, st>>>(
+            (const int4 *)indices, n, n_dev, G, L.bitmap, L.prefix, n_out, nbr_in, nbr_out, pairs ? L.wave_cnt : nullptr,
+            L.nwaves, L.wsuper, L.nws, C ? C->ncls : 0, L.blk_cnt, C ? C->perm : nullptr);
     if (pairs) {
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)G.K * 2 * n * sizeof(int32_t), st);
         launch_pairs_fill_super(nbr_in, n, n_dev, G.K, 0, L.wave_cnt, L.nwaves, L.wsuper, L.nws, pairs, pair_num, st);
