@@ -629,8 +629,37 @@ def measure_stage2(B, dev):
             S2.sample_keypoints(bd["points"], bd["point_frame_counts"], 4096)
             e1.record()
             torch.cuda.synchronize()
+        # the same stage in the metric's direction: training-mode modules, forward + backward (gradients into every MLP /
+        # BatchNorm parameter and back into the backbone's x_conv3 / x_conv4 features and the BEV map through the grouping
+        # kernels' gradient, pcd_group_points_stack_grad; tests/test_gpu_stage2.py checks them against a torch restatement)
+        vsa.train()
+        pool.train()
+        ms_feats = {}
+        for name, t in bd["multi_scale_3d_features"].items():
+            ms_feats[name] = t.replace_feature(t.features.detach().float().clone().requires_grad_(True))
+        bdt = dict(bd)
+        bdt["multi_scale_3d_features"] = ms_feats
+        bdt["spatial_features"] = bd["spatial_features"].detach().float().clone().requires_grad_(True)
+
+        def run_train():
+            for q in list(vsa.parameters()) + list(pool.parameters()):
+                q.grad = None
+            out = vsa(dict(bdt))
+            out["point_cls_scores"] = scores
+            pooled = pool(out)
+            (pooled * pooled).mean().backward()
+        for _ in range(2):
+            run_train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run_train()
+        torch.cuda.synchronize()
+        ms_train = 1e3 * (time.perf_counter() - t0) / n
         return {"ms_per_batch": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "frames": B,
                 "fps_4096_keypoints_ms": round(e0.elapsed_time(e1), 3),
+                "stage2_train": {"ms_per_batch": round(ms_train, 3), "frames_per_s": round(B / ms_train * 1e3, 1),
+                                 "what": "the same stage in training mode, forward + backward (eager launches)"},
                 "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points (cooperative kernel: 64 "
                         "workgroups per frame) + set abstraction over raw points, x_conv3, x_conv4 + BEV + RoI-grid pooling "
                         "128 RoIs x 216 points/frame"}

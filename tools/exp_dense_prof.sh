@@ -1,6 +1,6 @@
 # kernel time by name inside ONE replayed step of bench.py --dense-head (last step of the trace)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/pdh; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pdh -o r -- python3 bench.py --dense-head --com --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-h2d --no-ragged --no-stage2 --no-full-model --no-fp8 --no-regime > gpurun_out/dh_bench.log 2>&1
+rm -rf /tmp/pdh; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pdh -o r -- python3 bench.py --dense-head --com --steps 5 --warmup 2 --light > gpurun_out/dh_bench.log 2>&1
 DB=$(find /tmp/pdh -name "*.db" | head -1)
 python tools/timeline.py $DB gpurun_out/dh_seq.txt | head -12
 python - <<'PY'
