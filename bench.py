@@ -107,7 +107,7 @@ class HotPath(torch.nn.Module):
         return bd["spatial_features"], bd
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel):
@@ -115,7 +115,7 @@ def _pmc_traffic(kernel):
     (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE) -- PMC counters cannot be read from inside the timed
     process.  Returns (bytes or None, source description incl. the git blob hash of the file that was read)."""
     import hashlib
-    for rel in (TRAFFIC_FILE, os.path.join("profiles", "r02_pmc_traffic.json")):
+    for rel in (TRAFFIC_FILE, os.path.join("profiles", "r03_pmc_traffic.json")):
         path = os.path.join(ROOT, rel)
         try:
             data = open(path, "rb").read()
@@ -123,7 +123,9 @@ def _pmc_traffic(kernel):
         except Exception:
             continue
         blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()[:12]
-        hit = [v for name, v in k.items() if name == kernel or name.startswith(kernel + "<") or name.startswith(kernel + " ")]
+        # (the summary keeps the template arguments only where several instantiations of a kernel run in the step)
+        hit = [v for name, v in k.items() if name == kernel or name.startswith(kernel + "<") or name.startswith(kernel + " ")
+               or kernel.startswith(name + "<")]
         val = hit[0]["hbm_bytes_per_launch_corrected"] if hit else None
         return val, f"{rel}@{blob} (offline rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
     return None, None
