@@ -41,15 +41,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #ifndef WIN_VARIANT
 #define WIN_VARIANT 0
 #endif
-__device__ __forceinline__ void win_glds16(u32x4 rsrc, char *lds_dst_wave_uniform, unsigned voffset) {
-    typedef __attribute__((address_space(3))) char *lds_ptr_t;
-#if WIN_VARIANT & 1
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((u64)rsrc[1] << 32) | rsrc[0]), 0, (int)rsrc[2], (int)rsrc[3]),
-                                             (lds_ptr_t)lds_dst_wave_uniform, 16, voffset, 0, 0, 0);
-    return;
-#endif
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)lds_dst_wave_uniform);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voffset), "s"(rsrc)
+// (the destination is an LDS byte ADDRESS, wave-uniform: a generic pointer would be null-checked on its way to address space 3)
+__device__ __forceinline__ void win_glds16(u32x4 rsrc, unsigned lds_addr_wave_uniform, unsigned voffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr_wave_uniform), "v"(voffset), "s"(rsrc)
                  : "memory", "m0");
 }
 __device__ __forceinline__ u32x4 win_rsrc(const void *base, unsigned bytes) {
@@ -70,13 +64,22 @@ constexpr int WIN_THREADS = 512;
 constexpr int WIN_GRID = 256;            // one persistent workgroup per CU; also the number of BatchNorm partial rows
 constexpr int WIN_SCRATCH = 8192;        // head of the dynamic LDS: bnred_publish's scratch
 constexpr int WIN_PLAN_CAP = 64;         // tiles whose plans are staged in LDS at a time
+// Plan buffer: [entries: WIN_GRID x 64 B][prefix: ntiles x i32, padded to 32 B][headers: ntiles x 32 B][tables: ntiles x TABB]
+//   entry[w] = {first tile, end tile, 0, 0, header of the first tile (8 ints), 0 ..} of workgroup w (in XCD-major order): one
+//   scalar load at kernel entry gives a workgroup its share AND what it needs to start the first DMAs.
+constexpr int WIN_ENTRY_BYTES = 64;
+__host__ __device__ constexpr size_t win_prefix_off() { return (size_t)WIN_GRID * WIN_ENTRY_BYTES; }
+__host__ __device__ constexpr size_t win_hdr_off(int ntiles) { return win_prefix_off() + ((size_t)ntiles * 4 + 31) / 32 * 32; }
+__host__ __device__ constexpr size_t win_tab_off(int ntiles) { return win_hdr_off(ntiles) + (size_t)ntiles * 32; }
 
 // Wave roles: wave = (cb, rg, oq) -- output-channel block of 32, group of row blocks, slice of the 27 offsets.
 template <int CIN_, int NCB_, int NRG_, int NOQ_, int T_, int R_>
 struct WinCfg {
     static constexpr int CIN = CIN_, NCB = NCB_, NRG = NRG_, NOQ = NOQ_, T = T_, R = R_;
     static_assert(NCB * NRG * NOQ == 8, "8 waves");
-    static constexpr int COUT = 32 * NCB;
+    static constexpr int COUT = CIN;                     // square layers only; a wave's MFMA block spans 32 output channels (the
+    static_assert(32 * NCB >= COUT, "channel blocks");   //  upper 16 are zero weights at 16 channels: LDS reads bound that layer, not MFMAs)
+    static constexpr int QN = COUT >= 32 ? 4 : COUT / 8; // live 4-register groups of a lane's 32 x 32 accumulator block
     static constexpr int ROWB = CIN * 2;                 // bytes per feature row
     static constexpr int S = ROWB / 16;                  // 16-byte slots per row
     static constexpr int P = ROWB >= 256 ? 1 : 256 / ROWB;   // rows per 256 bytes of LDS (one sweep of the 64 banks)
@@ -88,13 +91,23 @@ struct WinCfg {
     static constexpr int Z0 = 16;                        // LDS row index of the first window row (row 0 = zeros); 16: one swizzle period
     static constexpr int WINROWS = 3 * R;
     static constexpr int WINB = WINROWS * ROWB;
-    static constexpr int TABROWS = 28;                   // table rows: 27 offsets + a row of zeros (the padding offset of the last slice)
-    static_assert(NOQ * OPW <= TABROWS, "slices");
-    static constexpr int TABN = TABROWS * T;
-    static constexpr int TABB = (TABN * 2 + 1023) / 1024 * 1024;   // whole 1-KiB DMA instructions
-    static constexpr int NTABI = TABB / 1024;            // ... of them (<= 8: one per wave)
-    static_assert(NTABI <= 8, "table pieces");
-    static_assert(R / RPI == 16, "two window instructions per run and wave");
+    // Table of a tile (in the plan and, DMA'd verbatim, in LDS): 64 bytes = 32 u16 entries per tile row; offset k = oq OPW + j is
+    // entry oq SLICE + j (slices padded to whole 16-byte pieces, padding = 0 = the zero row), and the four 16-byte pieces of row r
+    // are stored at piece ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 phase touches hit 64 distinct banks.
+    static constexpr int SLICE = 32 / NOQ;               // entries per slice
+    static_assert(SLICE >= OPW && SLICE % 8 == 0, "slices");
+    static constexpr int SLP = SLICE / 8;                // 16-byte pieces per slice
+    static constexpr int TABB = T * 64;                  // bytes per tile
+    static_assert(TABB % 1024 == 0, "whole 1-KiB DMA instructions");
+    static constexpr int NTABI = TABB / 1024;            // ... of them
+    static constexpr int TSL = (NTABI + 7) / 8;          // table DMA instructions per wave
+    __host__ __device__ static constexpr unsigned tab_pos(unsigned r, unsigned k) {      // u16 index of (tile row r, offset k)
+        const unsigned ei = (k / OPW) * SLICE + k % OPW;
+        return r * 32 + (((ei >> 3) ^ ((r >> 2) & 3)) << 3) + (ei & 7);
+    }
+    static constexpr bool DIRECT = NOQ == 1 && NCB == 1; // a wave owns whole rows: no cross-wave sums, the epilogue runs from registers
+    static constexpr int SPR = (R / RPI + 7) / 8;        // window DMA instructions per run and wave
+    static constexpr int NSLOT = 3 * SPR + TSL;          // prefetch instructions per wave and tile
     static constexpr int REDSTRIDE = COUT * 4 + 16;      // bytes per (slice, row) of partial sums: +16 keeps b128 stores conflict-free
     static constexpr int REDB = NOQ * T * REDSTRIDE;
     static constexpr int EXTRA = REDB > WINB ? (REDB - WINB + 16 * ROWB - 1) / (16 * ROWB) * (16 * ROWB) : 0;   // whole swizzle periods
@@ -102,10 +115,16 @@ struct WinCfg {
     // byte offsets into the dynamic LDS
     static constexpr int ROWBASE = WIN_SCRATCH;          // row index 0 lives here
     static constexpr int WIN0 = ROWBASE + Z0 * ROWB;
-    static constexpr int XTR = WIN0 + WINB;              // the reduction area of buffer 0 = [WIN0, +REDB), of buffer 1 = [XTR, +REDB)
-    static constexpr int WIN1 = XTR + EXTRA;
-    static constexpr int WIN1ROW = Z0 + WINROWS + EXTRA / ROWB;
-    static constexpr int BOFF = WIN1ROW - Z0;            // table values are buffer-0 row indices; buffer 1 = + BOFF (a multiple of 16: same swizzle)
+    static constexpr int XTR = WIN0 + WINB;
+    static constexpr int ZERO1 = XTR + EXTRA;            // Z0 rows of zeros in front of EACH window: entry 0 + BOFF is a zero row too
+    static constexpr int WIN1 = ZERO1 + Z0 * ROWB;
+    static constexpr int WIN1ROW = Z0 + WINROWS + EXTRA / ROWB + Z0;
+    static constexpr int BOFF = WIN1ROW - Z0;            // table values are buffer-0 slots; buffer 1 = + BOFF rows (a multiple of 16: same swizzle)
+    // the reduction area (partial sums of a tile, written over its window): buffer 0 = [WIN0, +REDB); buffer 1 = [WIN1, +REDB) when
+    // that fits the window, else [XTR, +REDB) -- which runs over the second zero rows: they are cleared again (REZERO)
+    static constexpr bool REZERO = EXTRA > 0;
+    static constexpr int RED1 = REZERO ? XTR : WIN1;
+    static_assert(Z0 * ROWB <= WIN_THREADS * 4, "one dword per thread clears the zero rows");
     static_assert(BOFF % 16 == 0 && WINROWS % 16 == 0, "swizzle period");
     static constexpr int TAB0 = WIN1 + WINB;
     static constexpr int PLAN = TAB0 + 2 * TABB;
@@ -113,27 +132,44 @@ struct WinCfg {
     static constexpr int LDS_BYTES = COLS + 2 * COUT * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static constexpr int NL = (27 * T + WIN_THREADS - 1) / WIN_THREADS;   // rulebook entries per thread and tile (multi-pass tiles only)
-    static constexpr size_t plan_bytes(int ntiles) { return (size_t)ntiles * (32 + TABB); }
+    static constexpr size_t plan_bytes(int ntiles) { return win_tab_off(ntiles) + (size_t)ntiles * TABB; }
     static constexpr int CG = COUT / 8;                  // 8-channel groups per row in the tile epilogue
     static_assert(T * CG == WIN_THREADS, "epilogue: one (row, 8 channels) per thread");
     __host__ __device__ static constexpr unsigned swz(unsigned row) { return (row / P) & (S - 1); }
+    static_assert(P * S == 16 && Z0 % 16 == 0 && R % 16 == 0 && (8 * RPI) % 16 == 0, "swizzle period of 16 rows");
 };
 
 using Win64 = WinCfg<64, 2, 1, 4, 64, 128>;      // 64 -> 64: waves = 2 channel blocks x 4 offset slices (7 offsets each)
-using Win32 = WinCfg<32, 1, 4, 2, 128, 256>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
+using Win32 = WinCfg<32, 1, 4, 2, 128, 320>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
+using Win16 = WinCfg<16, 1, 8, 1, 256, 512>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
 
-// ---- plan: the three runs of every tile + its table of LDS row indices -----------------------------------------------
+// c_in -> configuration (square layers): f(Cfg{}) with the matching type, `none` otherwise
+template <class F, class N>
+static inline auto win_dispatch(int c_in, int c_out, F &&f, N none) -> decltype(none) {
+    if (c_in != c_out) return none;
+    switch (c_in) {
+        case 64: return f(Win64{});
+        case 32: return f(Win32{});
+        case 16: return f(Win16{});
+        default: return none;
+    }
+}
+
+// ---- plan: the three runs of every tile + its table of LDS operand slots --------------------------------------------
 // header[tile] = {lo0, n0, lo1, n1, lo2, n2, passes, 0}: run g = rows [lo_g, lo_g + n_g) = min .. max of the valid entries of the
-// nine table rows k with (k / 3) % 3 == g (dy = g - 1) over the tile's rows; passes = max_g ceil(n_g / R), >= 1.
-// table[tile][28][T] u16 (behind the headers, TABB bytes per tile): LDS row of the operand of (offset k, row r) in window
-// buffer 0 = Z0 + g R + (nbr[k][r] - lo_g) for neighbours inside the first R rows of their run, 0 (the zero row) otherwise
-// (missing neighbour, row beyond n, the part of an over-long run that a later pass covers); row 27 = zeros.  The kernel
-// DMAs a tile's table straight into LDS -- nothing is converted on the fly.  The k-flipped view of the data gradient
-// reads table row 26 - k for offset k (same windows).  One wave per tile.
-template <int T>
+// nine rulebook rows k with (k / 3) % 3 == g (dy = g - 1) over the tile's rows; passes = max_g ceil(n_g / R), >= 1.
+// table[tile] (behind the headers, TABB bytes per tile, layout WinCfg::tab_pos): where the operand of (offset k, row r) lies in
+// window buffer 0, as the index of the 16-byte LDS slot that holds the row's first 8 channels:
+//     row = Z0 + g R + (nbr[k][r] - lo_g),   entry = row * S + swz(row)     (S slots per row; slot c of a row is stored at c ^ swz)
+// for neighbours inside the first R rows of their run, 0 (the zero row) otherwise (missing neighbour, row beyond n, the part of
+// an over-long run that a later pass covers).  A reader of channels 8 c .. 8 c + 7 takes slot entry ^ c: two instructions
+// between the table and the LDS address.  The kernel DMAs a tile's table straight into LDS.  The data gradient reads the SAME
+// table: its k flip is in the packed weights (win_pack_one).  One wave per tile.
+template <class C>
 __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict__ nbr, int nbr_stride, int n_cap,
-                                                       const int32_t *__restrict__ n_dev, int R, int Z0, int tabb,
-                                                       int4 *__restrict__ plan, int ntiles_cap) {
+                                                       const int32_t *__restrict__ n_dev, char *__restrict__ plan_base, int ntiles_cap) {
+    constexpr int T = C::T, R = C::R;
+    int4 *plan = (int4 *)(plan_base + win_hdr_off(ntiles_cap));
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles_cap) return;
     const int lane = threadIdx.x & 63;
@@ -174,23 +210,90 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
         plan[(size_t)tile * 2] = make_int4(lo[0], nn[0], lo[1], nn[1]);
         plan[(size_t)tile * 2 + 1] = make_int4(lo[2], nn[2], passes, 0);
     }
-    unsigned short *tab = (unsigned short *)((char *)plan + (size_t)ntiles_cap * 32 + (size_t)tile * tabb);
+    char *tab = plan_base + win_tab_off(ntiles_cap) + (size_t)tile * C::TABB;
 #pragma unroll
     for (int u = 0; u < T / 64; ++u) {
+        const unsigned r = (unsigned)(u * 64 + lane);
+        u32 w[16];                                   // the row's 32 entries
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = 0u;
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
             const int g = (k / 3) % 3;
             const unsigned rel = (unsigned)(v[u][k] - lo[g]);
-            tab[k * T + u * 64 + lane] = (v[u][k] >= 0 && rel < (unsigned)R) ? (unsigned short)(Z0 + g * R + (int)rel) : (unsigned short)0;
+            const unsigned row = (unsigned)(C::Z0 + g * R) + rel;
+            const unsigned e = (v[u][k] >= 0 && rel < (unsigned)R) ? row * C::S + C::swz(row) : 0u;
+            const int ei = (k / C::OPW) * C::SLICE + k % C::OPW;
+            w[ei >> 1] |= e << (16 * (ei & 1));
         }
-        tab[27 * T + u * 64 + lane] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint4 *>(tab + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+    }
+}
+
+// ---- shares: the tiles dealt to the WIN_GRID persistent workgroups in contiguous runs of EQUAL COST ------------------------
+// A multi-pass tile (a run longer than the window: frame borders, walls) costs its workgroup about 2.5 ordinary tiles; with equal
+// tile COUNTS the launch lasted as long as the few workgroups that own two of them (measured: 54 k clk against 31 k for the
+// typical workgroup at 16 channels).  cost = 2 + 5 (passes - 1); share w = tiles whose inclusive cost prefix lies in
+// (total w / G, total (w + 1) / G].  Static (a function of the rulebook only): the BatchNorm partial rows stay reproducible.
+// One workgroup.
+template <class C>
+__global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan_base, int n_cap, const int32_t *__restrict__ n_dev,
+                                                         int ntiles_cap) {
+    __shared__ int scan[1024];
+    __shared__ int bnd[WIN_GRID + 1];
+    const int tid = threadIdx.x;
+    const int n = eff_rows(n_dev, n_cap);
+    const int nt = (n + C::T - 1) / C::T;
+    const int4 *hdr = (const int4 *)(plan_base + win_hdr_off(ntiles_cap));
+    int *prefix = (int *)(plan_base + win_prefix_off());
+    const int per = (nt + 1023) / 1024;
+    const int t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
+    int sum = 0;
+    for (int t = t0; t < t1; ++t) sum += 2 + 5 * (hdr[(size_t)t * 2 + 1].z - 1);
+    scan[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int run = scan[tid] - sum;
+    for (int t = t0; t < t1; ++t) {
+        run += 2 + 5 * (hdr[(size_t)t * 2 + 1].z - 1);
+        prefix[t] = run;
+    }
+    const long long total = scan[1023];
+    __threadfence_block();
+    __syncthreads();
+    for (int j = tid; j <= WIN_GRID; j += 1024) {
+        const long long target = total * j / WIN_GRID;
+        int lo = 0, hi = nt;                          // number of tiles with prefix <= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
+        }
+        bnd[j] = j == WIN_GRID ? nt : lo;
+    }
+    __syncthreads();
+    for (int w = tid; w < WIN_GRID; w += 1024) {
+        const int tb = bnd[w], te = bnd[w + 1];
+        int4 *e = (int4 *)(plan_base + (size_t)w * WIN_ENTRY_BYTES);
+        const int4 z = make_int4(0, 0, 0, 0);
+        e[0] = make_int4(tb, te, 0, 0);
+        e[1] = tb < te ? hdr[(size_t)tb * 2] : z;
+        e[2] = tb < te ? hdr[(size_t)tb * 2 + 1] : z;
+        e[3] = z;
     }
 }
 
 // ---- weight pack: every wave's slice contiguous, MFMA 32x32x16 A-operand order --------------------------------------
 // packed[(((cb * NOQ + oq) * OPW + j) * KS + ks) * 64 + lane][e] = W_k[c_out = 32 cb + lane % 32][c_in = 16 ks + 8 (lane / 32) + e],
 // k = oq * OPW + j (zeros for k >= 27).  mode 0: forward, weight [c_out][K][c_in]; mode 1: data gradient -- the contraction runs
-// over the forward's OUTPUT channels: W_k[co][ci] := weight[ci][k][co] (the k flip is in the rulebook view, like pcd_pack_weight).
+// over the forward's OUTPUT channels and the k-flipped rulebook view, dx[i] = sum_k dy[nbr[26 - k][i]] W_k^T = sum_k' dy[nbr[k'][i]]
+// W_{26-k'}^T: the flip goes into the pack, W_k[co][ci] := weight[ci][26 - k][co], and the launch reads the table as it is.
 template <class C>
 __device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mode, size_t e, unsigned short *out) {
     const int j8 = (int)(e & 7), lane = (int)((e >> 3) & 63);
@@ -203,19 +306,23 @@ __device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mo
     const int k = oq * C::OPW + j;
     const int co = 32 * cb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j8;
     float v = 0.0f;
-    if (k < 27) v = mode == 0 ? w[((size_t)co * 27 + k) * C::CIN + ci] : w[((size_t)ci * 27 + k) * C::COUT + co];
+    if (k < 27 && co < C::COUT) v = mode == 0 ? w[((size_t)co * 27 + k) * C::CIN + ci] : w[((size_t)ci * 27 + (26 - k)) * C::COUT + co];
     out[e] = f32_to_bf16_bits(v);
 }
 template <class C>
 constexpr size_t win_pack_elems() { return (size_t)C::NCB * C::NOQ * C::OPW * C::KS * 512; }
 
-__global__ __launch_bounds__(256) void win_pack_kernel(const float *__restrict__ w, int cin, int mode, unsigned short *out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void win_pack_any(const float *__restrict__ w, int cin, int mode, size_t e, unsigned short *out) {
     if (cin == 64) {
         if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out);
-    } else {
+    } else if (cin == 32) {
         if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out);
+    } else {
+        if (e < win_pack_elems<Win16>()) win_pack_one<Win16>(w, mode, e, out);
     }
+}
+__global__ __launch_bounds__(256) void win_pack_kernel(const float *__restrict__ w, int cin, int mode, unsigned short *out) {
+    win_pack_any(w, cin, mode, (size_t)blockIdx.x * 256 + threadIdx.x, out);
 }
 
 // table[i] = {weight ptr, packed ptr, c_in, mode, first block, 0, 0, 0}
@@ -230,11 +337,7 @@ __global__ __launch_bounds__(256) void win_pack_batched_kernel(const long long *
     unsigned short *out = (unsigned short *)row[1];
     const int cin = (int)row[2], mode = (int)row[3];
     const size_t e = ((size_t)blockIdx.x - (size_t)row[4]) * 256 + threadIdx.x;
-    if (cin == 64) {
-        if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out);
-    } else {
-        if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out);
-    }
+    win_pack_any(w, cin, mode, e, out);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
@@ -247,7 +350,7 @@ struct WinPlan {                 // scalars only (an array member sent the struc
 template <class C>
 __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_cap, const int32_t *__restrict__ n_dev,
+    const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, const int32_t *__restrict__ n_dev,
     const int4 *__restrict__ plan_g, unsigned short *__restrict__ y, unsigned x_bytes,
     const unsigned short *__restrict__ addend, BnRed bn, int dbg, unsigned long long *trace) {
     __builtin_amdgcn_s_setprio(3);       // main-chain kernel (see spconv.hip: PCD_MAIN_PRIO)
@@ -263,13 +366,13 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave8 % C::NCB, rg = (wave8 / C::NCB) % C::NRG, oq = wave8 / (C::NCB * C::NRG);
     const int n = eff_rows(n_dev, n_cap);
-    const int nt = (n + T - 1) / T;
-    // tiles of this workgroup: every XCD (workgroup b runs on XCD b % 8 -- speed only) gets a contiguous eighth of the real
-    // tiles, its workgroups contiguous shares of that: neighbouring tiles' windows overlap, they share the XCD's L2
-    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;
-    const int tpx = (nt + 7) >> 3;
-    const int x0 = min(nt, xcd * tpx), nx = min(nt, x0 + tpx) - x0;
-    const int t_begin = x0 + (int)((long long)nx * jw / wpx), t_end = x0 + (int)((long long)nx * (jw + 1) / wpx);
+    // tiles of this workgroup: share w of win_split_kernel, w in XCD-major order (workgroup b runs on XCD b % 8 -- speed only):
+    // every XCD gets a contiguous run of tiles -- neighbouring tiles' windows overlap, they share the XCD's L2
+    const int ntiles_cap = (n_cap + T - 1) / T;
+    const int4 *entry = (const int4 *)((const char *)plan_g + (size_t)((blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3)) * WIN_ENTRY_BYTES);
+    const int4 ent0 = entry[0], ent1 = entry[1], ent2 = entry[2];
+    const int t_begin = __builtin_amdgcn_readfirstlane(ent0.x), t_end = __builtin_amdgcn_readfirstlane(ent0.y);
+    const int4 *hdr_g = (const int4 *)((const char *)plan_g + win_hdr_off(ntiles_cap));
 
     float *cols = (float *)(smem + C::COLS);
     if (t_begin >= t_end) {              // no tile: the BatchNorm row of this workgroup is zero
@@ -289,8 +392,12 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     // bias and (BatchNorm mode 2) mean of the epilogue: LDS copies (zeros without a bias) in the area of the final BatchNorm row
     for (int e = tid; e < 2 * COUT; e += WIN_THREADS)
         cols[e] = e < COUT ? (bias ? bias[e] : 0.0f) : (bn.mode == 2 ? bn.mean[e - COUT] : 0.0f);
-    // the zero row
-    for (int e = tid; e < C::Z0 * ROWB / 4; e += WIN_THREADS) ((int *)(smem + C::ROWBASE))[e] = 0;
+    // the zero rows in front of both windows
+    auto clear_zero1 = [&]() {
+        if (tid < C::Z0 * ROWB / 4) ((int *)(smem + C::ZERO1))[tid] = 0;
+    };
+    if (tid < C::Z0 * ROWB / 4) ((int *)(smem + C::ROWBASE))[tid] = 0;
+    clear_zero1();
 
     const u32x4 xdma = win_rsrc(x, x_bytes);
     const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -304,6 +411,17 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     for (int e = 0; e < 8; ++e) bs[e] = bq[e] = 0.0f;
 
     const int4 *plan_s = (const int4 *)(smem + C::PLAN);
+    auto make_plan = [](const int4 a, const int4 b) {
+        WinPlan p;
+        p.lo0 = __builtin_amdgcn_readfirstlane(a.x);
+        p.n0 = __builtin_amdgcn_readfirstlane(a.y);
+        p.lo1 = __builtin_amdgcn_readfirstlane(a.z);
+        p.n1 = __builtin_amdgcn_readfirstlane(a.w);
+        p.lo2 = __builtin_amdgcn_readfirstlane(b.x);
+        p.n2 = __builtin_amdgcn_readfirstlane(b.y);
+        p.passes = __builtin_amdgcn_readfirstlane(b.z);
+        return p;
+    };
     auto get_plan = [&](int t, int chunk0) {
         const int4 a = plan_s[(t - chunk0) * 2], b = plan_s[(t - chunk0) * 2 + 1];
         WinPlan p;
@@ -316,36 +434,36 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         p.passes = __builtin_amdgcn_readfirstlane(b.z);
         return p;
     };
-    const int ntiles_cap = (n_cap + T - 1) / T;
-    const u32x4 tdma = win_rsrc((const char *)plan_g + (size_t)ntiles_cap * 32, (unsigned)((size_t)ntiles_cap * C::TABB));
+    const u32x4 tdma = win_rsrc((const char *)plan_g + win_tab_off(ntiles_cap), (unsigned)((size_t)ntiles_cap * C::TABB));
+    typedef __attribute__((address_space(3))) char *lds_ptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);      // LDS address of smem[0]
 
     // The prefetch of a tile is NSLOT VMEM instructions per wave, issued one at a time BETWEEN the MFMA steps of the previous
     // tile (a 1-KiB instruction occupies the CU's texture-address unit for ~34 clk and the in-order wave behind it: issued as one
     // burst after the barrier, the 40-80 instructions of a tile cost every wave 1.8 k clk before its first MFMA and skewed the
     // waves by another 3 k clk -- measured with pcd_subm_window_set_trace).
-    //   slots 0..5: window pieces -- run g = s / 2, 1-KiB instruction wave8 + 8 (s % 2) of the run (R / RPI = 16 of them at most)
-    //   slot  6   : piece wave8 of the tile's table (NTABI pieces; table row k of the flipped view = stored row 26 - k)
-    constexpr int NSLOT = 7;
+    //   slots 0 .. 3 SPR - 1: window pieces -- run g = s / SPR, 1-KiB instruction wave8 + 8 (s % SPR) of the run
+    //   slots 3 SPR ..      : 1-KiB piece wave8 + 8 (s - 3 SPR) of the tile's table (NTABI pieces)
+    constexpr int NSLOT = C::NSLOT, SPR = C::SPR;
+    // The lane part of every DMA address is computed once: a wave's window pieces all start a multiple of 16 rows (one swizzle
+    // period) + (wave8 RPI) % 16 into their buffer; a table piece is 1 KiB of the tile's table as it lies in the plan.
+    const unsigned wlane = (unsigned)(lane / C::S) * (unsigned)ROWB +
+                           (((unsigned)(lane % C::S) ^ C::swz((unsigned)(lane / C::S + (wave8 * C::RPI) % 16))) << 4);
     auto issue_slot = [&](const WinPlan p, int tile, int buf, int pass, int slot) {
         if (dbg & 1) return;
-        if (slot < 6) {
-            const int g = slot >> 1, i = wave8 + 8 * (slot & 1);
+        if (slot < 3 * SPR) {
+            const int g = slot / SPR, i = wave8 + 8 * (slot % SPR);
             const int cnt = min(R, p.cnt(g) - pass * R);
             if (i * C::RPI < cnt) {
+                // (whole pieces: the rows past the end of the run are rows of x nobody refers to, or lie beyond the buffer)
                 const int wrow = (buf ? C::WIN1ROW : C::Z0) + g * R + i * C::RPI;          // first LDS row of the piece (wave-uniform)
-                const int r_in = i * C::RPI + lane / C::S;
-                const unsigned chunk = (unsigned)(lane % C::S) ^ C::swz((unsigned)(wrow + lane / C::S));
-                const unsigned off = r_in < cnt ? (unsigned)(p.lo(g) + pass * R + r_in) * (unsigned)ROWB + chunk * 16u : 0xFFFFFF00u;
-                win_glds16(xdma, smem + C::ROWBASE + (size_t)wrow * ROWB, off);
+                const unsigned sbase = (unsigned)(p.lo(g) + pass * R + i * C::RPI) * (unsigned)ROWB;
+                win_glds16(xdma, lds0 + (unsigned)(C::ROWBASE + wrow * ROWB), sbase + wlane);
             }
-        } else if (wave8 < C::NTABI && pass == 0) {
-            constexpr int PPR = T * 2 / 16;                      // 16-byte pieces per table row
-            const int trow = wave8 * (64 / PPR) + lane / PPR;
-            const int src = trow < 27 ? (flip ? 26 - trow : trow) : 27;
-            const unsigned off = trow < C::TABROWS
-                                     ? (unsigned)tile * (unsigned)C::TABB + (unsigned)(src * T * 2) + (unsigned)(lane % PPR) * 16u
-                                     : 0xFFFFFF00u;
-            win_glds16(tdma, smem + C::TAB0 + buf * C::TABB + wave8 * 1024, off);
+        } else if (wave8 + 8 * (slot - 3 * SPR) < C::NTABI && pass == 0) {
+            const int piece = wave8 + 8 * (slot - 3 * SPR);
+            win_glds16(tdma, lds0 + (unsigned)(C::TAB0 + buf * C::TABB + piece * 1024),
+                       (unsigned)tile * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
         }
     };
 
@@ -362,8 +480,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         for (int u = 0; u < C::NL; ++u) {
             const int e = tq + u * WIN_THREADS;
             const int k = e / T, r = e - k * T;
-            const int src = flip ? 26 - k : k;
-            const unsigned off = e < 27 * T ? ((unsigned)src * (unsigned)nbr_stride + (unsigned)(t * T + r)) * 4u : 0xFFFFFFF0u;
+            const unsigned off = e < 27 * T ? ((unsigned)k * (unsigned)nbr_stride + (unsigned)(t * T + r)) * 4u : 0xFFFFFFF0u;
             nv[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
         }
     };
@@ -374,7 +491,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         for (int u = 0; u < C::NL; ++u) {
             const int e = tq + u * WIN_THREADS;
             const int k = e / T, r = e - k * T;
-            const int g = ((flip ? 26 - k : k) / 3) % 3;          // group of the STORED row the view's offset k reads
+            const int g = (k / 3) % 3;
             const int lo = p.lo(g) + pass * R;
             const int v = nv[u];
             const unsigned rel = (unsigned)(v - lo);
@@ -382,7 +499,8 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             //  wait for the load here and does not carry "maybe still in flight" registers into the MFMA loop, where it would
             //  protect their reuse with an s_waitcnt vmcnt(0) that also waits for the prefetch of the next tile)
             const bool ok = (e < 27 * T) & (v >= 0) & (t * T + r < n) & (rel < (unsigned)R);
-            if (e < 27 * T) tab[e] = ok ? (unsigned short)(C::Z0 + g * R + (int)rel) : (unsigned short)0;
+            const unsigned row = (unsigned)(C::Z0 + g * R) + rel;
+            if (e < 27 * T) tab[C::tab_pos((unsigned)r, (unsigned)k)] = ok ? (unsigned short)(row * C::S + C::swz(row)) : (unsigned short)0;
         }
     };
 
@@ -399,25 +517,43 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             return;
         }
         const char *rowbase = smem + C::ROWBASE;
-        const unsigned short *tabw =
-            (const unsigned short *)(smem + C::TAB0 + buf * C::TABB) + (oq * OPW) * T + rg * RBW * 32 + (lane & 31);
         const unsigned half = (unsigned)lane >> 5;
-        const unsigned boff = buf ? (unsigned)C::BOFF : 0u;
-        constexpr int NSTEP = OPW * RBW;
-        constexpr int PF_FIRST = 3;      // first step followed by a prefetch slot
-        static_assert(NSTEP >= PF_FIRST + NSLOT, "a prefetch slot per step");
-        bf16x8 fr[2][KS];
-        unsigned idxs[NSTEP];            // all table entries of the tile up front: no table read (and its wait) between steps
+        const unsigned boff = buf ? (unsigned)(C::BOFF * ROWB) : 0u;     // table entries are slots of buffer 0; (a multiple of 128)
+        // a step = KS * SO MFMAs: SO offsets are paired at narrow layers so that a step always has >= 4 fragments in flight
+        constexpr int SO = KS >= 4 ? 1 : 4 / KS;
+        constexpr int NJ = (OPW + SO - 1) / SO;          // offset groups of this wave's slice
+        constexpr int NSTEP = NJ * RBW;
+        constexpr int PF_FIRST = C::DIRECT ? 0 : NSTEP >= 10 ? 3 : 1;    // first step followed by prefetch slots (DIRECT: no barrier
+                                                                          // to wait for -- as early as possible, the loop is short)
+        constexpr int SPS = (NSLOT + (NSTEP - PF_FIRST) - 1) / (NSTEP - PF_FIRST);   // slots per step
+        static_assert(NSTEP > PF_FIRST, "steps");
+        bf16x8 fr[2][SO * KS];
+        // this lane's table entries (its row of every row block, the wave's slice of the offsets): SLP 16-byte reads per block
+        u32x4 tq[RBW][C::SLP];
 #pragma unroll
-        for (int step = 0; step < NSTEP; ++step) idxs[step] = tabw[(step / RBW) * T + (step % RBW) * 32];
-        auto fetch = [&](int step, bf16x8 (&dst)[KS]) {
-            // table values are rows of buffer 0 (0 = the zero row); buffer 1 lies BOFF rows (whole swizzle periods) further
-            const unsigned idx = idxs[step] ? idxs[step] + boff : 0u;
-            // slot of contraction step ks = (2 ks + half) ^ swz(row) = (half ^ swz) ^ 2 ks: one XOR with a constant per step
-            const unsigned a0 = idx * (unsigned)ROWB + ((C::swz(idx) ^ half) << 4);
+        for (int rbw = 0; rbw < RBW; ++rbw) {
+            const unsigned r = (unsigned)((rg * RBW + rbw) * 32) + ((unsigned)lane & 31u);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                dst[ks] = *reinterpret_cast<const bf16x8 *>(rowbase + (a0 ^ ((unsigned)ks << 5)));
+            for (int c = 0; c < C::SLP; ++c)
+                tq[rbw][c] = *reinterpret_cast<const u32x4 *>(smem + C::TAB0 + buf * C::TABB + r * 64 +
+                                                              (((unsigned)(oq * C::SLP + c) ^ ((r >> 2) & 3u)) << 4));
+        }
+        auto fetch = [&](int step, bf16x8 (&dst)[SO * KS]) {
+            const int jg = step / RBW, rbw = step % RBW;
+#pragma unroll
+            for (int o = 0; o < SO; ++o) {
+                const int j = jg * SO + o;
+                if (j >= OPW) continue;
+                // entry = slot of the row's first 8 channels in buffer 0 (0 = the zero row in front of it); buffer 1 lies BOFF rows
+                // (whole swizzle periods) further and has its own zero rows.  Slot of contraction step ks = (2 ks + half) ^
+                // swz(row) = entry ^ half ^ 2 ks: one XOR with a constant per step.
+                const u32 w = tq[rbw][j / 8][(j % 8) / 2];
+                const unsigned e = (j & 1) ? w >> 16 : w & 0xffffu;
+                const unsigned a0 = ((e ^ half) << 4) + boff;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    dst[o * KS + ks] = *reinterpret_cast<const bf16x8 *>(rowbase + (a0 ^ ((unsigned)ks << 5)));
+            }
         };
         fetch(0, fr[0]);
 #pragma unroll
@@ -425,16 +561,26 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             if (step + 1 < NSTEP) fetch(step + 1, fr[(step + 1) & 1]);
             // (the scheduler, short of registers, sinks the reads back to one per MFMA unless told not to)
             __builtin_amdgcn_sched_barrier(0);
-            const int j = step / RBW, rbw = step % RBW;
+            const int jg = step / RBW, rbw = step % RBW;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                acc[rbw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][ks], fr[step & 1][ks], acc[rbw], 0, 0, 0);
+            for (int o = 0; o < SO; ++o)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if (jg * SO + o < OPW)
+                        acc[rbw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[jg * SO + o][ks], fr[step & 1][o * KS + ks], acc[rbw], 0, 0, 0);
             if (PF) {
                 // B1, inside the loop: the prefetch overwrites the area the PREVIOUS tile's epilogue read its partial sums from, so
                 // every wave must have left that epilogue -- but nothing before the first slot needs the barrier: the waves run
                 // their first steps as they arrive and meet here (the skew of the epilogue is absorbed by MFMA work)
-                if (step == PF_FIRST - 1) WIN_BARRIER();
-                if (step >= PF_FIRST && step < PF_FIRST + NSLOT) issue_slot(pn, tnext, buf ^ 1, 0, step - PF_FIRST);
+                // (DIRECT: no epilogue reads LDS, the barrier at the end of every tile covers the reuse of the buffers)
+                if (!C::DIRECT && step == PF_FIRST - 1) {
+                    WIN_BARRIER();
+                    // (the previous tile's partial sums ran over the zero rows of buffer 1: clear them for the next tile)
+                    if (C::REZERO && buf == 0) clear_zero1();
+                }
+#pragma unroll
+                for (int q = 0; q < SPS; ++q)
+                    if (step >= PF_FIRST && (step - PF_FIRST) * SPS + q < NSLOT) issue_slot(pn, tnext, buf ^ 1, 0, (step - PF_FIRST) * SPS + q);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -446,14 +592,16 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     for (int chunk0 = t_begin; chunk0 < t_end; chunk0 += WIN_PLAN_CAP) {
         const int chunk1 = min(t_end, chunk0 + WIN_PLAN_CAP);
         __syncthreads();
-        for (int e = tid; e < (chunk1 - chunk0) * 2; e += WIN_THREADS) ((int4 *)(smem + C::PLAN))[e] = plan_g[(size_t)chunk0 * 2 + e];
-        __syncthreads();
-        {   // prologue: tile chunk0 into buffer 0
-            const WinPlan p0 = get_plan(chunk0, chunk0);
+        {   // prologue: tile chunk0 into buffer 0 -- its header came with the workgroup's entry (first chunk) or is read from the
+            // plan here (wave-uniform loads): the DMAs start before the chunk's plans are staged in LDS
+            if (C::REZERO) clear_zero1();
+            const bool first = chunk0 == t_begin;
+            const WinPlan p0 = make_plan(first ? ent1 : hdr_g[(size_t)chunk0 * 2], first ? ent2 : hdr_g[(size_t)chunk0 * 2 + 1]);
             for (int q = 0; q < NSLOT; ++q) issue_slot(p0, chunk0, 0, 0, q);
+            for (int e = tid; e < (chunk1 - chunk0) * 2; e += WIN_THREADS) ((int4 *)(smem + C::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp();                         // (trace slot 1: weights + first window have landed)
-            WIN_BARRIER();
+            __syncthreads();
         }
         for (int t = chunk0; t < chunk1; ++t) {
             const int buf = (t - chunk0) & 1;
@@ -469,67 +617,33 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             for (int rbw = 0; rbw < RBW; ++rbw)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rbw][i] = 0.0f;
-            stamp();
-            if (more) compute(buf, PF1{}, pn, t + 1); else compute(buf, PF0{}, pn, t);
-            stamp();
-            for (int pass = 1; pass < p.passes; ++pass) {
-                // a run longer than the window: next chunk of every run into the same buffer (slow path, rare)
-                int nv2[C::NL];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WIN_BARRIER();
-                for (int q = 0; q < 6; ++q) issue_slot(p, t, buf, pass, q);
-                load_nbr(t, nv2);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                build_tab(t, p, nv2, buf, pass);
-                WIN_BARRIER();
-                compute(buf, PF0{}, p, t);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window + table of t + 1 landed (this wave's part)
-            stamp();
-            // the epilogue's operands (this thread's row and 8 channels): in flight across the two barriers below
-            const int te = fresh(tid);
-            const int erow = te / C::CG, ecg = te % C::CG;
-            const int orow = t * T + erow;
-            const bool olive = orow < n;
-            const size_t oelem = (size_t)orow * COUT + ecg * 8;
-            const unsigned ooff = olive ? (unsigned)oelem * 2u : 0xFFFFFFF0u;
-            // (rows beyond n read row n - 1: unconditional loads, no select that would wait for them here; the launch-uniform
-            //  branches leave the registers undefined when the operand does not exist -- they are only read under the same test)
-            const size_t lelem = olive ? oelem : (size_t)(n - 1) * COUT + ecg * 8;
+            // the epilogue's operands of this thread's (row, 8 channels).  (Rows beyond n read row n - 1: unconditional loads, no
+            // select that would wait for them; the launch-uniform branches leave the registers undefined when the operand does
+            // not exist -- they are only read under the same test.)
             uint4 av, xv, yv;
-            if (addend) av = *reinterpret_cast<const uint4 *>(addend + lelem);
-            if (bn.mode == 2) {
-                xv = *reinterpret_cast<const uint4 *>(bn.x + lelem);
-                if (bn.relu) yv = *reinterpret_cast<const uint4 *>(bn.y + lelem);
-            }
-            WIN_BARRIER();                               // B2: every wave is done reading window buf -> it becomes the reduction area
-            stamp();
-            char *red = smem + (buf ? C::XTR : C::WIN0);
-            if (!(dbg & 8)) {   // partial sums: lane (n = lane & 31, h = lane >> 5) holds rows (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block
-                const int h = lane >> 5;
-#pragma unroll
-                for (int rbw = 0; rbw < RBW; ++rbw) {
-                    const int row = (rg * RBW + rbw) * 32 + (lane & 31);
-                    char *dst = red + (size_t)(oq * T + row) * C::REDSTRIDE + (cb * 32 + 4 * h) * 4;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        *reinterpret_cast<f32x4 *>(dst + q4 * 32) =
-                            (f32x4){acc[rbw][q4 * 4], acc[rbw][q4 * 4 + 1], acc[rbw][q4 * 4 + 2], acc[rbw][q4 * 4 + 3]};
+            int erow, ecg;
+            auto load_operands = [&]() {
+                const int te = fresh(tid);
+                if (C::DIRECT) {         // the lane's row of the wave's block, channels 8 (lane / 32) .. + 7 (after the half swap below)
+                    erow = rg * 32 + (te & 31);
+                    ecg = (te & 63) >> 5;
+                } else {
+                    erow = te / C::CG;
+                    ecg = te % C::CG;
                 }
-            }
-            WIN_BARRIER();                               // B3
-            stamp();
-            if (!(dbg & 8)) {   // tile epilogue: sum the slices in order, + bias (+ addend), one rounding, whole lines out, BatchNorm sums
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-#pragma unroll
-                for (int q = 0; q < C::NOQ; ++q) {
-                    const char *src = red + (size_t)(q * T + erow) * C::REDSTRIDE + ecg * 32;
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 16);
-                    v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
-                    v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+                const int orow = t * T + erow;
+                const size_t lelem = (size_t)(orow < n ? orow : n - 1) * COUT + ecg * 8;
+                if (addend) av = *reinterpret_cast<const uint4 *>(addend + lelem);
+                if (bn.mode == 2) {
+                    xv = *reinterpret_cast<const uint4 *>(bn.x + lelem);
+                    if (bn.relu) yv = *reinterpret_cast<const uint4 *>(bn.y + lelem);
                 }
+            };
+            // v[8] = the fp32 sums of (erow, channels 8 ecg ..): + bias (+ addend), one rounding, 16 bytes out, BatchNorm sums
+            auto finish = [&](float (&v)[8]) {
+                const int orow = t * T + erow;
+                const bool olive = orow < n;
+                const unsigned ooff = olive ? (unsigned)((size_t)orow * COUT + ecg * 8) * 2u : 0xFFFFFFF0u;
                 {
                     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(cols + ecg * 8),
                                 b1 = *reinterpret_cast<const f32x4 *>(cols + ecg * 8 + 4);
@@ -577,6 +691,77 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                         }
                     }
                 }
+            };
+            if (C::DIRECT) load_operands();              // (in flight across the MFMA loop)
+            stamp();
+            if (more) compute(buf, PF1{}, pn, t + 1); else compute(buf, PF0{}, pn, t);
+            stamp();
+            for (int pass = 1; pass < p.passes; ++pass) {
+                // a run longer than the window: next chunk of every run into the same buffer (slow path, rare)
+                int nv2[C::NL];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WIN_BARRIER();
+                for (int q = 0; q < 3 * SPR; ++q) issue_slot(p, t, buf, pass, q);
+                load_nbr(t, nv2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                build_tab(t, p, nv2, buf, pass);
+                WIN_BARRIER();
+                compute(buf, PF0{}, p, t);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window + table of t + 1 landed (this wave's part)
+            stamp();
+            if (C::DIRECT) {
+                // One barrier per tile: everybody's share of tile t + 1 has landed and everybody is done reading buffer buf (the
+                // prefetch of tile t + 2 may overwrite it).  The wave's 32 x 32 block holds, per lane (row n = lane & 31, h =
+                // lane >> 5), channels 4 h .. + 3 in registers 0-3 and 8 + 4 h .. + 3 in 4-7 (16 live channels): the halves
+                // exchange registers 4-7 / 0-3 (v_permlane32_swap), after which lane (n, h) holds channels 8 h .. 8 h + 7.
+                WIN_BARRIER();
+                stamp();
+                stamp();
+                if (!(dbg & 8)) {
+                    static_assert(!C::DIRECT || (RBW == 1 && COUT == 16), "direct epilogue: one row block per wave, 16 channels");
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][e]), __float_as_uint(acc[0][4 + e]), false, false);
+                        v[e] = __uint_as_float(r[0]);
+                        v[4 + e] = __uint_as_float(r[1]);
+                    }
+                    finish(v);
+                }
+                stamp();
+                continue;
+            }
+            load_operands();                             // in flight across the two barriers below
+            WIN_BARRIER();                               // B2: every wave is done reading window buf -> it becomes the reduction area
+            stamp();
+            char *red = smem + (buf ? C::RED1 : C::WIN0);
+            if (!(dbg & 8)) {   // partial sums: lane (n = lane & 31, h = lane >> 5) holds rows (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block
+                const int h = lane >> 5;
+#pragma unroll
+                for (int rbw = 0; rbw < RBW; ++rbw) {
+                    const int row = (rg * RBW + rbw) * 32 + (lane & 31);
+                    char *dst = red + (size_t)(oq * T + row) * C::REDSTRIDE + (cb * 32 + 4 * h) * 4;
+#pragma unroll
+                    for (int q4 = 0; q4 < C::QN; ++q4)
+                        *reinterpret_cast<f32x4 *>(dst + q4 * 32) =
+                            (f32x4){acc[rbw][q4 * 4], acc[rbw][q4 * 4 + 1], acc[rbw][q4 * 4 + 2], acc[rbw][q4 * 4 + 3]};
+                }
+            }
+            WIN_BARRIER();                               // B3
+            stamp();
+            if (!(dbg & 8)) {   // tile epilogue: the slices summed in order
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < C::NOQ; ++q) {
+                    const char *src = red + (size_t)(q * T + erow) * C::REDSTRIDE + ecg * 32;
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 16);
+                    v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+                    v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+                }
+                finish(v);
             }
             stamp();
         }
@@ -584,8 +769,9 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     if (bn.mode) {
         // the workgroup's BatchNorm row: column sums over its threads' rows in a fixed order -- rows of a wave by lane
         // exchanges (lanes that differ in the row bits), then the 8 waves through LDS
+        // (a lane's 8-channel group: lane % CG, rows in the higher lane bits; DIRECT: lane / 32, rows in the lower five)
 #pragma unroll
-        for (int d = C::CG; d < 64; d <<= 1)
+        for (int d = C::DIRECT ? 1 : C::CG; d < (C::DIRECT ? 32 : 64); d <<= 1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 bs[e] += __shfl_xor(bs[e], d, 64);
@@ -593,11 +779,12 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             }
         __syncthreads();
         float *stage = (float *)(smem + C::WIN0);                        // [8 waves][CG][16]
-        if (lane < C::CG) {
+        if (C::DIRECT ? (lane & 31) == 0 : lane < C::CG) {
+            const int cg = C::DIRECT ? lane >> 5 : lane;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                stage[(wave8 * C::CG + lane) * 16 + e] = bs[e];
-                stage[(wave8 * C::CG + lane) * 16 + 8 + e] = bq[e];
+                stage[(wave8 * C::CG + cg) * 16 + e] = bs[e];
+                stage[(wave8 * C::CG + cg) * 16 + 8 + e] = bq[e];
             }
         }
         __syncthreads();
@@ -618,7 +805,7 @@ unsigned long long *g_win_trace = nullptr;     // profiling aid, NULL in product
 
 template <class C>
 static int launch_win(const void *x, int n_rows, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
-                      int flip, const int32_t *n_dev, const void *plan, void *y, const void *addend,
+                      const int32_t *n_dev, const void *plan, void *y, const void *addend,
                       const PcdBnReduce *bnr, hipStream_t st) {
     BnRed bn;
     if (int rc = make_bnred(bnr, PCD_BF16, C::COUT, WIN_GRID, &bn)) return rc;
@@ -627,7 +814,7 @@ static int launch_win(const void *x, int n_rows, const void *wp, const float *bi
     // (set per call: the attribute is per device, the call idempotent)
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
         return PCD_ERR_LAUNCH;
-    k<<<WIN_GRID, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip,
+    k<<<WIN_GRID, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
                                                     n_rows, n_dev, (const int4 *)plan, (unsigned short *)y,
                                                     (unsigned)((size_t)n_rows * C::ROWB), (const unsigned short *)addend, bn,
                                                     pcd_opt(PCD_OPT_WIN_DBG), g_win_trace);
@@ -635,14 +822,15 @@ static int launch_win(const void *x, int n_rows, const void *wp, const float *bi
     return PCD_OK;
 }
 
-static bool win_supported(int c_in, int c_out) { return (c_in == 64 && c_out == 64) || (c_in == 32 && c_out == 32); }
+static bool win_supported(int c_in, int c_out) {
+    return win_dispatch(c_in, c_out, [](auto) { return true; }, false);
+}
 
 }  // namespace
 
 // =============================================================================================
 extern "C" int pcd_subm_window_tile_rows(int c_in, int c_out) {
-    if (!win_supported(c_in, c_out)) return 0;
-    return c_in == 64 ? Win64::T : Win32::T;
+    return win_dispatch(c_in, c_out, [](auto c) { return (int)decltype(c)::T; }, 0);
 }
 
 extern "C" int pcd_subm_window_partial_rows(void) { return WIN_GRID; }
@@ -653,9 +841,9 @@ extern "C" int pcd_subm_window_set_trace(void *buf256_u64) {
 }
 
 extern "C" size_t pcd_subm_window_plan_bytes(int n_cap, int c_in, int c_out) {
-    if (n_cap < 0 || !win_supported(c_in, c_out)) return 0;
+    if (n_cap < 0) return 0;
     const int nc = n_cap > 0 ? n_cap : 1;
-    return c_in == 64 ? Win64::plan_bytes(pcd_div_up(nc, Win64::T)) : Win32::plan_bytes(pcd_div_up(nc, Win32::T));
+    return win_dispatch(c_in, c_out, [&](auto c) { using C = decltype(c); return C::plan_bytes(pcd_div_up(nc, C::T)); }, (size_t)0);
 }
 
 extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_cap, const int32_t *n_dev, int c_in,
@@ -665,22 +853,19 @@ extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_ca
     if (n_cap == 0) return PCD_OK;
     if (!nbr || !plan || nbr_stride < n_cap) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (c_in == 64) {
-        const int nt = pcd_div_up(n_cap, Win64::T);
-        win_plan_kernel<Win64::T><<<pcd_div_up(nt, 4), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, Win64::R, Win64::Z0, Win64::TABB,
-                                                                     (int4 *)plan, nt);
-    } else {
-        const int nt = pcd_div_up(n_cap, Win32::T);
-        win_plan_kernel<Win32::T><<<pcd_div_up(nt, 4), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, Win32::R, Win32::Z0, Win32::TABB,
-                                                                     (int4 *)plan, nt);
-    }
+    win_dispatch(c_in, c_out, [&](auto c) {
+        using C = decltype(c);
+        const int nt = pcd_div_up(n_cap, C::T);
+        win_plan_kernel<C><<<pcd_div_up(nt, 4), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
+        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt);
+        return 0;
+    }, 0);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
 
 extern "C" size_t pcd_subm_window_packed_weight_bytes(int c_in, int c_out) {
-    if (!win_supported(c_in, c_out)) return 0;
-    return (c_in == 64 ? win_pack_elems<Win64>() : win_pack_elems<Win32>()) * 2;
+    return win_dispatch(c_in, c_out, [](auto c) { return win_pack_elems<decltype(c)>() * 2; }, (size_t)0);
 }
 
 extern "C" int pcd_subm_window_pack_weight(const float *weight, int c_in, int c_out, int mode, void *packed, void *stream) {
@@ -703,7 +888,7 @@ extern "C" int pcd_subm_window_pack_weights_batched(const void *table, int n, in
 }
 
 extern "C" int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
-                                           const int32_t *nbr, int nbr_stride, int flip_k, const int32_t *n_rows_dev,
+                                           const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
                                            const void *plan, int c_out, void *y, const void *addend,
                                            const PcdBnReduce *bn_reduce, void *stream) {
     PCD_ENTER();
@@ -711,9 +896,8 @@ extern "C" int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, 
     if (n_rows == 0) return PCD_OK;
     if (!x || !packed_w || !nbr || !plan || !y || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (c_in == 64)
-        return launch_win<Win64>(x, n_rows, packed_w, bias, nbr, nbr_stride, flip_k ? 1 : 0, n_rows_dev, plan, y, addend,
-                                 bn_reduce, st);
-    return launch_win<Win32>(x, n_rows, packed_w, bias, nbr, nbr_stride, flip_k ? 1 : 0, n_rows_dev, plan, y, addend,
-                             bn_reduce, st);
+    return win_dispatch(c_in, c_out, [&](auto c) {
+        return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend,
+                                       bn_reduce, st);
+    }, (int)PCD_ERR_UNSUPPORTED);
 }

@@ -894,7 +894,8 @@ def subm_window_plan(rb, c_in, c_out):
 
 
 def pack_weight_window(weight, mode, out=None):
-    """weight [Cout, 3, 3, 3, Cin] f32 -> the window kernel's register-resident slices (mode 0 forward, 1 dgrad)."""
+    """weight [Cout, 3, 3, 3, Cin] f32 -> the window kernel's register-resident slices (mode 0 forward, 1 dgrad: transposed,
+    kernel offsets reversed)."""
     _require_cuda(weight)
     w = weight.detach().contiguous().float()
     cout, cin = w.shape[0], w.shape[-1]
@@ -908,9 +909,10 @@ def pack_weight_window(weight, mode, out=None):
     return packed
 
 
-def subm_window(x, packed_w, bias, rb, flip_k, c_out, addend=None, bn_reduce=None):
-    """gather_gemm over the SubM rulebook `rb` through the window kernel: y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o]).
-    x, y bf16 [n, c]; packed_w from pack_weight_window."""
+def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
+    """gather_gemm over the SubM rulebook `rb` through the window kernel: y[o] = bias + sum_k x[nbr[k][o]] @ W[k] (+ addend[o])
+    with packed_w = pack_weight_window(w, 0); the data gradient (k-flipped view, W^T) with pack_weight_window(w, 1) -- the flip
+    is part of that pack.  x, y bf16 [n, c]."""
     _require_cuda(x, packed_w)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and rb.subm and rb.kvol == 27
     n, c_in = x.shape
@@ -930,7 +932,7 @@ def subm_window(x, packed_w, bias, rb, flip_k, c_out, addend=None, bn_reduce=Non
         bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows()), c_out, x.device)
     with _Timed(f"subm_win_kernel<{c_in}> {c_in}->{c_out} K=27", meta):
         L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
-                                                    rb.nbr_out.shape[1], int(bool(flip_k)), L.ptr(rb.n_out_dev), L.ptr(plan),
+                                                    rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
                                                     c_out, L.ptr(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
                 "pcd_sparse_conv_subm_window")
     return y

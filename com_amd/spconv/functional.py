@@ -137,7 +137,7 @@ class SparseConvFunction(Function):
             stats = None
         elif window:
             assert out_dtype == torch.bfloat16 and rb.subm
-            y = ops.subm_window(x, packed_fwd, b, rb, False, cout, bn_reduce=stats)
+            y = ops.subm_window(x, packed_fwd, b, rb, cout, bn_reduce=stats)
         else:
             y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
                                 n_dev=rb.n_out_dev, bn_reduce=stats)
@@ -207,7 +207,7 @@ class SparseConvFunction(Function):
                 if not red.usable(ctx.cin_pad, ctx.in_dtype):
                     red = None
             if rb.subm and ctx.window and ctx.in_dtype == torch.bfloat16:
-                dxp = ops.subm_window(dy16, packed_d, None, rb, True, ctx.cin_pad, addend=add, bn_reduce=red)
+                dxp = ops.subm_window(dy16, packed_d, None, rb, ctx.cin_pad, addend=add, bn_reduce=red)
             elif rb.subm:
                 assert not ctx.window, "window packs cannot feed the generic kernel"
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,

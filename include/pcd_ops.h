@@ -847,17 +847,20 @@ int pcd_debug_stamp(uint64_t *slot, void *stream);
 
 /* ============================================================================================
  * (a8) SubMConv3d arithmetic over z-fastest rows: the WINDOW gather-GEMM (spconv_win.hip) -- forward and data gradient of
- *      spconv.SubMConv3d (spconv_backbone.py:12,38-45) for 3x3x3 kernels with c_in == c_out in {32, 64}, bf16 features.
- * Same operation as pcd_sparse_conv_gather_gemm on a SubM neighbour table (y[o] = bias + sum_k W_k x[nbr[k'][o]] (+ addend),
- * k' = flip_k ? 26 - k : k); results agree up to the fp32 summation order.  It is FAST when the rows are numbered
+ *      spconv.SubMConv3d (spconv_backbone.py:12,38-45) for 3x3x3 kernels with c_in == c_out in {16, 32, 64}, bf16 features.
+ * Same operation as pcd_sparse_conv_gather_gemm on a SubM neighbour table: y[o] = bias + sum_k W_k x[nbr[k][o]] (+ addend)
+ * with weights packed in mode 0; with weights packed in mode 1 the data gradient dx[i] = sum_k W_k^T dy[nbr[26 - k][i]]
+ * (+ addend) -- the k flip of the rulebook view is folded into that pack, the launch has no flip argument.  Results agree
+ * with the generic kernels up to the fp32 summation order.  It is FAST when the rows are numbered
  * PCD_ROWS_YXZ (the 27 neighbours of a tile of consecutive rows then lie in three short runs of rows that are staged in LDS
  * once per tile) and correct, only slow, for any other numbering.
  *   pcd_subm_window_tile_rows      rows per tile T of the (c_in, c_out) kernel; 0 = no window kernel for these widths
- *   pcd_subm_window_plan           per tile of T rows the three runs of neighbour rows + the tile's table of LDS operand rows
- *                                  (u16 [28][T]): plan = pcd_subm_window_plan_bytes(n, c_in, c_out) bytes, built once per rulebook
+ *   pcd_subm_window_plan           per tile of T rows the three runs of neighbour rows + the tile's table of LDS operand slots
+ *                                  (u16, 32 per row): plan = pcd_subm_window_plan_bytes(n, c_in, c_out) bytes, built once per rulebook
  *                                  (every conv of the indice_key, forward and backward, uses it)
  *   pcd_subm_window_pack_weight    weight [c_out][27][c_in] f32 -> the kernel's register-resident slices (mode 0 forward,
- *                                  1 data gradient), pcd_subm_window_packed_weight_bytes bytes; _batched: table rows of 8 x i64
+ *                                  1 data gradient: transposed, offsets reversed), pcd_subm_window_packed_weight_bytes bytes;
+ *                                  _batched: table rows of 8 x i64
  *                                  {weight ptr, packed ptr, c_in, mode, first 256-thread block, 0, 0, 0}
  *   pcd_subm_window_partial_rows   rows of PcdBnReduce.partial the launch writes (one per persistent workgroup)
  * ============================================================================================ */
@@ -874,7 +877,7 @@ size_t pcd_subm_window_packed_weight_bytes(int c_in, int c_out);
 int pcd_subm_window_pack_weight(const float *weight, int c_in, int c_out, int mode, void *packed, void *stream);
 int pcd_subm_window_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
-                                const int32_t *nbr, int nbr_stride, int flip_k, const int32_t *n_rows_dev,
+                                const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
                                 const void *plan, int c_out, void *y, const void *addend,
                                 const PcdBnReduce *bn_reduce, void *stream);
 

@@ -19,7 +19,7 @@ pts, offs = hotpath.collate_points(frames, dev)
 res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
                         want_voxels=False, row_order="yxz", key_depth=41)
 idx, rank, shape = res["coords"], res["rank"], [41, 1504, 1504]
-levels = {}
+levels = {1: (idx, rank, shape, 16)}
 chain = [((3, 3, 3), (2, 2, 2), (1, 1, 1), 32), ((3, 3, 3), (2, 2, 2), (1, 1, 1), 64), ((3, 3, 3), (2, 2, 2), (0, 1, 1), 128)]
 lvl = 1
 for k, s, p, ch in chain:
@@ -44,7 +44,7 @@ def timeit(fn, iters=30):
 
 
 want = sys.argv[1] if len(sys.argv) > 1 else "23"
-for lvl in (2, 3):
+for lvl in (1, 2, 3):
     if str(lvl) not in want:
         continue
     idx, rank, shape, ch = levels[lvl]
@@ -58,14 +58,32 @@ for lvl in (2, 3):
     pf, pd = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
     wf, wd = ops.pack_weight_window(w, 0), ops.pack_weight_window(w, 1)
     pairs = int((rb.nbr_out >= 0).sum().item())
+    T = ops.subm_window_tile_rows(ch, ch)
+    nt = (n + T - 1) // T
+    off = 256 * 64 + (nt * 4 + 31) // 32 * 32                     # (spconv_win.hip: win_hdr_off)
+    pl = ops.subm_window_plan(rb, ch, ch)
+    hdr = pl[off:off + nt * 32].view(torch.int32).view(nt, 8).cpu().numpy()
+    ent = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()
+    share = ent[:, 1] - ent[:, 0]
+    print(f"level {lvl}: shares of the 256 workgroups: tiles min {share.min()} median {int(np.median(share))} max {share.max()}")
+    runs = hdr[:, [1, 3, 5]]
+    print(f"level {lvl}: {nt} tiles of {T} rows; passes histogram {np.bincount(hdr[:, 6]).tolist()}; run length median "
+          f"{int(np.median(runs))} p90 {int(np.percentile(runs, 90))} p99 {int(np.percentile(runs, 99))} max {int(runs.max())}; "
+          f"multi-pass tiles: {np.nonzero(hdr[:, 6] > 1)[0][:24].tolist()}")
+    if os.environ.get("WIN_HDR"):
+        ic = idx.cpu().numpy()
+        for tt in np.nonzero(hdr[:, 6] > 1)[0][:6]:
+            rows = ic[tt * T:(tt + 1) * T]
+            print(f"   tile {tt}: header {hdr[tt].tolist()}; rows {tt * T}..: b {rows[:, 0].min()}-{rows[:, 0].max()} "
+                  f"z {rows[:, 1].min()}-{rows[:, 1].max()} y {rows[:, 2].min()}-{rows[:, 2].max()} x {rows[:, 3].min()}-{rows[:, 3].max()}")
     for name, flip, pk, pw, b_, a_ in (("fwd", False, pf, wf, bias, None), ("dgrad+addend", True, pd, wd, None, add)):
         y0 = ops.gather_gemm(x, pk, b_, rb.nbr_out, 27, flip, n, ch, torch.bfloat16, addend=a_)
-        y1 = ops.subm_window(x, pw, b_, rb, flip, ch, addend=a_)
+        y1 = ops.subm_window(x, pw, b_, rb, ch, addend=a_)
         torch.cuda.synchronize()
         d = (y0.float() - y1.float()).abs()
         scale = y0.float().abs().max().item()
         t_gen = timeit(lambda: ops.gather_gemm(x, pk, b_, rb.nbr_out, 27, flip, n, ch, torch.bfloat16, addend=a_))
-        t_win = timeit(lambda: ops.subm_window(x, pw, b_, rb, flip, ch, addend=a_))
+        t_win = timeit(lambda: ops.subm_window(x, pw, b_, rb, ch, addend=a_))
         fl = 2.0 * pairs * ch * ch
         print(f"level {lvl} {ch}->{ch} rows {n} pairs {pairs} {name}: max|diff| {d.max().item():.4g} (scale {scale:.3g}, "
               f"mismatching elements {(d > 0).float().mean().item():.4f}) generic {t_gen:.1f} us, window {t_win:.1f} us "
@@ -74,7 +92,7 @@ for lvl in (2, 3):
     st0, st1 = ops.BnReduce(1), ops.BnReduce(1)
     ops.BN_FUSED_MID = False
     y0 = ops.gather_gemm(x, pf, bias, rb.nbr_out, 27, False, n, ch, torch.bfloat16, bn_reduce=st0)
-    y1 = ops.subm_window(x, wf, bias, rb, False, ch, bn_reduce=st1)
+    y1 = ops.subm_window(x, wf, bias, rb, ch, bn_reduce=st1)
     torch.cuda.synchronize()
     s0, s1 = st0.partial.double().sum(0), st1.partial.double().sum(0)
     ref = torch.stack([y1.double().sum(0), (y1.double() ** 2).sum(0)])
@@ -92,9 +110,9 @@ if os.environ.get("WIN_TRACE"):
     wf = ops.pack_weight_window(w, 0)
     tr = torch.zeros(256, dtype=torch.int64, device=dev)
     for _ in range(3):
-        ops.subm_window(x, wf, None, rb, False, ch)
+        ops.subm_window(x, wf, None, rb, ch)
     L.lib().pcd_subm_window_set_trace(L.ptr(tr))
-    ops.subm_window(x, wf, None, rb, False, ch)
+    ops.subm_window(x, wf, None, rb, ch)
     torch.cuda.synchronize()
     L.lib().pcd_subm_window_set_trace(None)
     t = tr.cpu().numpy()
