@@ -137,9 +137,9 @@ def _rocprof_avg_us(kernel):
     import glob
     import re
     m = re.match(r"(\w+)<NB=(\d+)>", kernel)
-    mw = re.match(r"subm_win_kernel<(\d+)>", kernel)
+    mw = re.match(r"(subm_win_kernel|subm_wgrad_win_kernel)<(\d+)>", kernel)
     if mw:
-        pat = re.compile(r"subm_win_kernel<.*WinCfg<" + mw.group(1) + r",")
+        pat = re.compile(mw.group(1) + r"<.*WinCfg<" + mw.group(2) + r",")
     else:
         pat = re.compile(re.escape(m.group(1)) + r"<" + m.group(2) + r",") if m else re.compile(re.escape(kernel.split(" ")[0]) + r"[<(]")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_eager.txt")),
@@ -229,7 +229,7 @@ def measure_roofline(step_fn, ms_per_step):
     groups = _profiled_groups(step_fn)
     if not groups:
         return None
-    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "ggw", "wgrad", "subm_win"))}
+    conv_like = {k: v for k, v in groups.items() if k.startswith(("gather_gemm", "ggw", "wgrad", "subm_win", "subm_wgrad"))}
     name, g = max(conv_like.items() or groups.items(), key=lambda kv: kv[1]["ms"])
     out = _group_roofline(name, g)
     traffic, source = _pmc_traffic(name)

@@ -43,7 +43,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #endif
 // (the destination is an LDS byte ADDRESS, wave-uniform: a generic pointer would be null-checked on its way to address space 3)
 __device__ __forceinline__ void win_glds16(u32x4 rsrc, unsigned lds_addr_wave_uniform, unsigned voffset) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr_wave_uniform), "v"(voffset), "s"(rsrc)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr_wave_uniform)), "v"(voffset), "s"(rsrc)
                  : "memory", "m0");
 }
 __device__ __forceinline__ u32x4 win_rsrc(const void *base, unsigned bytes) {
@@ -67,8 +67,11 @@ constexpr int WIN_PLAN_CAP = 64;         // tiles whose plans are staged in LDS 
 // Plan buffer: [entries: WIN_GRID x 64 B][prefix: ntiles x i32, padded to 32 B][headers: ntiles x 32 B][tables: ntiles x TABB]
 //   entry[w] = {first tile, end tile, 0, 0, header of the first tile (8 ints), 0 ..} of workgroup w (in XCD-major order): one
 //   scalar load at kernel entry gives a workgroup its share AND what it needs to start the first DMAs.
+//   wshare[s] = {first tile, end tile} of share s of the weight-gradient kernel (WIN_WG_SHARES shares, 1 KiB reserved)
 constexpr int WIN_ENTRY_BYTES = 64;
-__host__ __device__ constexpr size_t win_prefix_off() { return (size_t)WIN_GRID * WIN_ENTRY_BYTES; }
+constexpr int WIN_WG_SHARES = 80;        // weight gradient: 8 XCDs x 10 shares, three workgroups (one per run) each
+__host__ __device__ constexpr size_t win_wshare_off() { return (size_t)WIN_GRID * WIN_ENTRY_BYTES; }
+__host__ __device__ constexpr size_t win_prefix_off() { return win_wshare_off() + 1024; }
 __host__ __device__ constexpr size_t win_hdr_off(int ntiles) { return win_prefix_off() + ((size_t)ntiles * 4 + 31) / 32 * 32; }
 __host__ __device__ constexpr size_t win_tab_off(int ntiles) { return win_hdr_off(ntiles) + (size_t)ntiles * 32; }
 
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
                                                          int ntiles_cap) {
     __shared__ int scan[1024];
     __shared__ int bnd[WIN_GRID + 1];
+    __shared__ int bndw[WIN_WG_SHARES + 1];
     const int tid = threadIdx.x;
     const int n = eff_rows(n_dev, n_cap);
     const int nt = (n + C::T - 1) / C::T;
@@ -277,6 +281,15 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         }
         bnd[j] = j == WIN_GRID ? nt : lo;
     }
+    for (int j = tid; j <= WIN_WG_SHARES; j += 1024) {
+        const long long target = total * j / WIN_WG_SHARES;
+        int lo = 0, hi = nt;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
+        }
+        bndw[j] = j == WIN_WG_SHARES ? nt : lo;
+    }
     __syncthreads();
     for (int w = tid; w < WIN_GRID; w += 1024) {
         const int tb = bnd[w], te = bnd[w + 1];
@@ -287,6 +300,8 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         e[2] = tb < te ? hdr[(size_t)tb * 2 + 1] : z;
         e[3] = z;
     }
+    for (int w = tid; w < WIN_WG_SHARES; w += 1024)
+        ((int2 *)(plan_base + win_wshare_off()))[w] = make_int2(bndw[w], bndw[w + 1]);
 }
 
 // ---- weight pack: every wave's slice contiguous, MFMA 32x32x16 A-operand order --------------------------------------
@@ -340,6 +355,8 @@ __global__ __launch_bounds__(256) void win_pack_batched_kernel(const long long *
     win_pack_any(w, cin, mode, e, out);
 }
 
+unsigned long long *g_win_trace = nullptr;     // profiling aid, NULL in production (pcd_subm_window_set_trace)
+
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 struct WinPlan {                 // scalars only (an array member sent the struct to scratch memory)
     int lo0, lo1, lo2, n0, n1, n2, passes;
@@ -380,9 +397,15 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         return;
     }
 
-    // this wave's weights: OPW offsets x KS steps, 4 VGPRs each, resident for the whole launch
+    // this wave's weights: OPW offsets x KS steps, 4 VGPRs each, resident for the whole launch.  Where several waves hold the SAME
+    // slice (NRG > 1: 8 copies at 16 channels, 4 at 32) the packed weights go to LDS once (into window buffer 1, free until the first
+    // prefetch) and the waves fill their registers from there: 27 / 56 one-KiB instructions through the CU's texture-address unit
+    // instead of 216 / 224 -- a third of a 16-channel launch's DMA work otherwise, all of it ahead of the first tile.
     bf16x8 wreg[OPW][KS];
-    {
+    constexpr bool STAGEW = C::NRG > 1;
+    constexpr int NWP = C::NCB * C::NOQ * OPW * KS;      // KiB of packed weights
+    static_assert(!STAGEW || NWP * 1024 <= C::WINB, "staged weights fit window buffer 1");
+    if (!STAGEW) {
         const uint4 *wsrc = wp + (size_t)((cb * C::NOQ + oq) * OPW) * KS * 64 + lane;
 #pragma unroll
         for (int j = 0; j < OPW; ++j)
@@ -437,6 +460,11 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const u32x4 tdma = win_rsrc((const char *)plan_g + win_tab_off(ntiles_cap), (unsigned)((size_t)ntiles_cap * C::TABB));
     typedef __attribute__((address_space(3))) char *lds_ptr_t;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);      // LDS address of smem[0]
+    if (STAGEW) {
+        const u32x4 wdma = win_rsrc(wp, (unsigned)(NWP * 1024));
+        for (int pc = wave8; pc < NWP; pc += 8)
+            win_glds16(wdma, lds0 + (unsigned)(C::WIN1 + pc * 1024), (unsigned)(pc * 1024) + (unsigned)lane * 16u);
+    }
 
     // The prefetch of a tile is NSLOT VMEM instructions per wave, issued one at a time BETWEEN the MFMA steps of the previous
     // tile (a 1-KiB instruction occupies the CU's texture-address unit for ~34 clk and the in-order wave behind it: issued as one
@@ -602,6 +630,14 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp();                         // (trace slot 1: weights + first window have landed)
             __syncthreads();
+            if (STAGEW && first) {
+                const char *wl = smem + C::WIN1 + ((cb * C::NOQ + oq) * OPW * KS) * 1024 + lane * 16;
+#pragma unroll
+                for (int j = 0; j < OPW; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) wreg[j][ks] = *reinterpret_cast<const bf16x8 *>(wl + (j * KS + ks) * 1024);
+                __syncthreads();             // (the first prefetch overwrites the staging area)
+            }
         }
         for (int t = chunk0; t < chunk1; ++t) {
             const int buf = (t - chunk0) & 1;
@@ -801,7 +837,6 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     stamp();                                 // (last trace slot: kernel exit)
 }
 
-unsigned long long *g_win_trace = nullptr;     // profiling aid, NULL in production (pcd_subm_window_set_trace)
 
 template <class C>
 static int launch_win(const void *x, int n_rows, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
@@ -818,6 +853,357 @@ static int launch_win(const void *x, int n_rows, const void *wp, const float *bi
                                                     n_rows, n_dev, (const int4 *)plan, (unsigned short *)y,
                                                     (unsigned)((size_t)n_rows * C::ROWB), (const unsigned short *)addend, bn,
                                                     pcd_opt(PCD_OPT_WIN_DBG), g_win_trace);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+
+// ---- weight gradient over the same tiles ------------------------------------------------------------------------------
+// dW_k[ci][co] = sum over rows r of x[nbr[k][r]][ci] dy[r][co], k = 0..26, for the SubM layers the window kernel serves.
+// The 27 accumulators of a layer do not fit one workgroup at 64 channels, and the offsets of one run (dy = g - 1: the nine k
+// with (k / 3) % 3 == g) only need THAT run in LDS: a workgroup = (share of the tiles, run g) keeps nine C x C accumulators in
+// registers for its whole share, streams per tile the run's window (the forward's DMA, one run of three), the tile's rows of
+// dy and the tile's slot table through double-buffered LDS, and builds both MFMA operands with the transposing LDS read
+// (ds_read_b64_tr_b16: the contraction index = tile row is the slow axis of both row-major operands), x rows found through
+// the table.  No pair lists, no gathers from global memory, dy read three times (once per run), x once.
+//   waves: (block group, row-step split): C = 16: 8 waves split the 32-row steps of a tile; 32: 4 blocks x 2; 64: 8 groups of
+//   2 blocks.  16x16x32 MFMA, A = x^T (ci x rows), B = dy (rows x co), as in wgrad_kernel (spconv.hip).
+// Every (share, run) workgroup writes its nine offsets of slab[share][co][k][ci] (f32): WIN_WG_SHARES slabs that the batched
+// fixed-order reduction (pcd_sparse_conv_wgrad_reduce_batched, `splits` = WIN_WG_SHARES) sums: deterministic, no atomics.
+// Workgroup b -> XCD b % 8 takes shares 10 (b % 8) .. + 9, all three runs of a share on the same XCD (they read the same
+// rows of dy and the same table through its L2); 2 of the 32 workgroups of an XCD idle.
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <class C>
+struct WgCfg {
+    static constexpr int CIN = C::CIN, T = C::T, R = C::R, ROWB = C::ROWB, S = C::S;
+    static constexpr int MB = CIN / 16, NB = CIN / 16;
+    // wave = (mb, oh, rs): a 16-channel block of c_in, one of NOH parts of the run's nine offsets, one of RS interleaved subsets of
+    // the tile's 32-row steps; it owns ALL output-channel blocks of those: every x operand is read from LDS by one wave only
+    static constexpr int NOH = MB >= 4 ? 2 : 1;
+    static constexpr int NO = (9 + NOH - 1) / NOH;                 // offsets per wave
+    static constexpr int NG = MB * NOH;
+    static constexpr int RS = 8 / NG;
+    static constexpr int NSTEP = T / 32;
+    static_assert(NG * RS == 8 && NSTEP % RS == 0, "wave roles");
+    static constexpr int SPRW = (R / C::RPI + 7) / 8;              // window DMA instructions per wave and tile
+    static_assert(T * ROWB == 8192, "dy tile: one 1-KiB DMA instruction per wave");
+    // A tile's compute is short (~1 k clk) against the latency of its DMAs: a ring of NBUF stages, filled NBUF - 1 tiles ahead.
+    // LDS: [Z0 zero rows][NBUF windows of R rows][NBUF dy tiles][NBUF tables][plans]
+    static constexpr int NBUF = 3;
+    static constexpr int WIN0 = C::Z0 * ROWB;
+    static constexpr int DY0 = (C::Z0 + NBUF * R) * ROWB;
+    static constexpr int TAB0 = DY0 + NBUF * T * ROWB;
+    static constexpr int PLAN = TAB0 + NBUF * C::TABB;
+    static constexpr int LDS_BYTES = PLAN + WIN_PLAN_CAP * 32;
+    static constexpr int REDB = (RS - 1) * NG * NO * NB * 1024;    // final cross-wave sums, over the windows
+    static_assert(REDB <= PLAN && LDS_BYTES <= 160 * 1024, "LDS");
+    static constexpr int NL = (9 * T + WIN_THREADS - 1) / WIN_THREADS;
+};
+
+template <class C, int G>
+__device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                               const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, int n,
+                                               const char *__restrict__ plan_g, float *__restrict__ slab, unsigned x_bytes,
+                                               unsigned dy_bytes, int share, char *smem, unsigned long long *trace) {
+    using W = WgCfg<C>;
+    int trace_at = 0;
+    auto stamp = [&]() {
+        if (trace && blockIdx.x == 0 && threadIdx.x == 0 && trace_at < 256) trace[trace_at++] = __builtin_readcyclecounter();
+    };
+    stamp();
+    const unsigned long long t_entry = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;     // (100 MHz, the same clock on every CU)
+    constexpr int T = C::T, R = C::R, ROWB = C::ROWB, S = C::S, CIN = C::CIN, NB = W::NB, NO = W::NO;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 % W::NG, rs = wave8 / W::NG;
+    const int mb = grp % W::MB, oh = grp / W::MB;
+    const int ntiles_cap = (n_cap + T - 1) / T;
+    const int2 sh = ((const int2 *)(plan_g + win_wshare_off()))[share];
+    const int t_begin = __builtin_amdgcn_readfirstlane(sh.x), t_end = __builtin_amdgcn_readfirstlane(sh.y);
+    const int4 *hdr_g = (const int4 *)(plan_g + win_hdr_off(ntiles_cap));
+
+    f32x4 acc[NO][NB];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[o][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (tid < C::Z0 * ROWB / 4) ((int *)smem)[tid] = 0;           // the zero rows (entry 0)
+    // (dy: the REAL rows only -- with a capacity above the row count the rows behind it hold whatever the allocation held, and
+    //  0 x NaN is NaN: beyond num_records the DMA delivers zeros)
+    (void)dy_bytes;
+    const u32x4 xdma = win_rsrc(x, x_bytes), ydma = win_rsrc(dy, (unsigned)n * (unsigned)ROWB);
+    const u32x4 tdma = win_rsrc(plan_g + win_tab_off(ntiles_cap), (unsigned)((size_t)ntiles_cap * C::TABB));
+    typedef __attribute__((address_space(3))) char *lds_ptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);
+    // lane part of the row DMAs (window pieces and the dy piece of a wave start (wave8 RPI) % 16 rows into a swizzle period)
+    const unsigned wlane = (unsigned)(lane / S) * (unsigned)ROWB +
+                           (((unsigned)(lane % S) ^ C::swz((unsigned)(lane / S + (wave8 * C::RPI) % 16))) << 4);
+    // MFMA operand roles of the lane (as in wgrad_kernel): contraction index 8 g4 + j <-> tile row (j < 4 ? 4 g4 + j : 16 + 4 g4
+    // + j - 4) of the 32-row step; the lane supplies the address of 4 bf16 (8 bytes) of row trow, columns 4 (t & 3) .. + 3 of the
+    // 16-channel block
+    const int g4 = lane >> 4, t16 = lane & 15;
+    const int trow = 4 * g4 + (t16 >> 2);
+    const unsigned sub = (unsigned)(t16 & 1) * 8u;
+    const unsigned csel = (unsigned)(2 * mb + ((t16 & 3) >> 1));               // 16-byte slot of the lane's x columns
+
+    struct Run { int lo, cnt; };
+    auto run_of = [&](const int4 a, const int4 b) {
+        Run r;
+        r.lo = __builtin_amdgcn_readfirstlane(G == 0 ? a.x : G == 1 ? a.z : b.x);
+        r.cnt = __builtin_amdgcn_readfirstlane(G == 0 ? a.y : G == 1 ? a.w : b.y);
+        return r;
+    };
+    const int4 *plan_s = (const int4 *)(smem + W::PLAN);
+    // A stage's DMAs are NSL instructions per wave: slots 0 .. SPRW - 1 window pieces, SPRW the wave's dy piece, then its table
+    // pieces.  issue_slot returns 1 if the slot had an instruction (wave-uniform: the counted waits below need the sum).
+    constexpr int NSL = W::SPRW + 1 + C::TSL;
+    auto issue_slot = [&](const Run p, int tile, int buf, int pass, int slot) -> int {
+        if (slot < W::SPRW) {
+            const int i = wave8 + 8 * slot;
+            if (i * C::RPI >= min(R, p.cnt - pass * R)) return 0;
+            win_glds16(xdma, lds0 + (unsigned)(W::WIN0 + (buf * R + i * C::RPI) * ROWB),
+                       (unsigned)(p.lo + pass * R + i * C::RPI) * (unsigned)ROWB + wlane);
+            return 1;
+        }
+        if (pass != 0) return 0;
+        if (slot == W::SPRW) {
+            win_glds16(ydma, lds0 + (unsigned)(W::DY0 + buf * T * ROWB + wave8 * 1024),
+                       (unsigned)(tile * T + wave8 * C::RPI) * (unsigned)ROWB + wlane);
+            return 1;
+        }
+        const int piece = wave8 + 8 * (slot - W::SPRW - 1);
+        if (piece >= C::NTABI) return 0;
+        win_glds16(tdma, lds0 + (unsigned)(W::TAB0 + buf * C::TABB + piece * 1024),
+                   (unsigned)tile * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
+        return 1;
+    };
+    auto issue = [&](const Run p, int tile, int buf, int pass) {
+        int issued = 0;
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) issued += issue_slot(p, tile, buf, pass, q);
+        return issued;
+    };
+    // s_waitcnt vmcnt(k), k wave-uniform: at most k of this wave's vector-memory operations still in flight
+    auto wait_vm = [](int k) {
+        switch (k) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
+    };
+    // OH (the wave's part of the offsets) is a template argument: the table entry of an offset is picked by compile-time indices
+    // (pf: the DMAs of tile `tn` into stage `bn` are issued one at a time between the offsets of the wave's first step -- as one
+    //  burst at the top of the tile the 8 waves queued ~40 instructions at the CU's texture-address unit, ~1.3 k clk in which
+    //  nobody computed; *pf_count receives their number)
+    auto compute_oh = [&](int buf, auto oh_tag, bool pf, const Run pn, int tn, int bn, int *pf_count) {
+        constexpr int OH = decltype(oh_tag)::value;
+        const char *tab = smem + W::TAB0 + buf * C::TABB;
+        const char *dyb = smem + W::DY0 + buf * T * ROWB;
+        // table entries are slots of the FORWARD's buffer 0 (row Z0 + G R + rel); here the run lies at row Z0 + buf R + rel
+        const unsigned adj = (unsigned)((buf - G) * R * S);
+        const unsigned q4 = (unsigned)(t16 & 3);
+        for (int s = rs; s < W::NSTEP; s += W::RS) {
+            const unsigned r_lo = (unsigned)(s * 32 + trow), r_hi = r_lo + 16u;
+            // the four lanes of a quad supply addresses in the same two tile rows: each reads ONE 16-byte piece of the row's 64
+            // table bytes, entries are handed round the quad by DPP (a quarter of the LDS traffic of four private copies)
+            const u32x4 tl = *reinterpret_cast<const u32x4 *>(tab + r_lo * 64 + ((q4 ^ ((r_lo >> 2) & 3u)) << 4));
+            const u32x4 th = *reinterpret_cast<const u32x4 *>(tab + r_hi * 64 + ((q4 ^ ((r_hi >> 2) & 3u)) << 4));
+            bf16x8 bf[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned dsel = (unsigned)(2 * j) + (q4 >> 1);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(
+                    dyb + r_lo * ROWB + ((dsel ^ C::swz(r_lo)) << 4) + sub));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(
+                    dyb + r_hi * ROWB + ((dsel ^ C::swz(r_hi)) << 4) + sub));
+                bf[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            bf16x8 af[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const int og = OH * NO + o;
+                if (og >= 9) continue;
+                const int k = 9 * (og / 3) + 3 * G + og % 3;
+                const int ei = (k / C::OPW) * C::SLICE + k % C::OPW;
+                const int d = ei / 2;                                  // dword of the row: piece d / 4 (= quad lane), element d % 4
+                u32 w0, w1;
+                switch (d / 4) {                                       // (the DPP control is an immediate)
+                    case 0: w0 = __builtin_amdgcn_mov_dpp(tl[d % 4], 0x00, 0xF, 0xF, true); w1 = __builtin_amdgcn_mov_dpp(th[d % 4], 0x00, 0xF, 0xF, true); break;
+                    case 1: w0 = __builtin_amdgcn_mov_dpp(tl[d % 4], 0x55, 0xF, 0xF, true); w1 = __builtin_amdgcn_mov_dpp(th[d % 4], 0x55, 0xF, 0xF, true); break;
+                    case 2: w0 = __builtin_amdgcn_mov_dpp(tl[d % 4], 0xAA, 0xF, 0xF, true); w1 = __builtin_amdgcn_mov_dpp(th[d % 4], 0xAA, 0xF, 0xF, true); break;
+                    default: w0 = __builtin_amdgcn_mov_dpp(tl[d % 4], 0xFF, 0xF, 0xF, true); w1 = __builtin_amdgcn_mov_dpp(th[d % 4], 0xFF, 0xF, 0xF, true); break;
+                }
+                const unsigned e0 = (ei & 1) ? w0 >> 16 : w0 & 0xffffu, e1 = (ei & 1) ? w1 >> 16 : w1 & 0xffffu;
+                const unsigned q0 = e0 ? e0 + adj : 0u, q1 = e1 ? e1 + adj : 0u;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3))) *)(smem + (((q0 ^ csel) << 4) + sub)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3))) *)(smem + (((q1 ^ csel) << 4) + sub)));
+                af[o] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            static_assert(NSL <= NO, "one prefetch slot per offset");
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                if (pf && s == rs && o < NSL) *pf_count += issue_slot(pn, tn, bn, 0, o);
+                if (OH * NO + o >= 9) continue;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[o][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[o], bf[j], acc[o][j], 0, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](int buf, bool pf, const Run pn, int tn, int bn, int *pf_count) {
+        if (W::NOH == 1 || oh == 0) compute_oh(buf, std::integral_constant<int, 0>{}, pf, pn, tn, bn, pf_count);
+        else compute_oh(buf, std::integral_constant<int, W::NOH - 1>{}, pf, pn, tn, bn, pf_count);
+    };
+
+    static_assert(W::NBUF == 3, "prefetch distance 2 below");
+    for (int chunk0 = t_begin; chunk0 < t_end; chunk0 += WIN_PLAN_CAP) {
+        const int chunk1 = min(t_end, chunk0 + WIN_PLAN_CAP);
+        __syncthreads();
+        int c_next = 0;                      // DMA instructions of this wave in flight for tile t + 2 (after the wait below: t + 1)
+        {
+            // the first two tiles of the chunk: their headers straight from the plan (wave-uniform loads)
+            const Run p0 = run_of(hdr_g[(size_t)chunk0 * 2], hdr_g[(size_t)chunk0 * 2 + 1]);
+            issue(p0, chunk0, 0, 0);
+            if (chunk0 + 1 < chunk1) {
+                const Run p1 = run_of(hdr_g[(size_t)chunk0 * 2 + 2], hdr_g[(size_t)chunk0 * 2 + 3]);
+                c_next = issue(p1, chunk0 + 1, 1, 0);
+            }
+            for (int e = tid; e < (chunk1 - chunk0) * 2; e += WIN_THREADS) ((int4 *)(smem + W::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
+            wait_vm(c_next);                 // (the plan loads are older than nothing here: staged below the barrier anyway)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        int buf = 0;
+        for (int t = chunk0; t < chunk1; ++t) {
+            const Run p = run_of(plan_s[(t - chunk0) * 2], plan_s[(t - chunk0) * 2 + 1]);
+            // tile t + 2 into the stage tile t - 1 left (every wave passed the barrier behind its compute)
+            int c_new = 0;
+            stamp();
+            const bool pf = t + 2 < chunk1;
+            const int tp = pf ? t + 2 : t;
+            const Run pn = run_of(plan_s[(tp - chunk0) * 2], plan_s[(tp - chunk0) * 2 + 1]);
+            stamp();
+            compute(buf, pf, pn, t + 2, buf == 0 ? 2 : buf - 1, &c_new);
+            stamp();
+            for (int pass = 1; pass * R < p.cnt; ++pass) {
+                // the run is longer than the window (rare): its next R rows into the same stage, the nine table columns of
+                // the run rebuilt from the rulebook for that part
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WIN_BARRIER();
+                issue(p, t, buf, pass);
+                unsigned short *tabw = (unsigned short *)(smem + W::TAB0 + buf * C::TABB);
+#pragma unroll
+                for (int u = 0; u < W::NL; ++u) {
+                    const int e = tid + u * WIN_THREADS;
+                    const int o = e / T, r = e - o * T;
+                    const int k = 9 * (o / 3) + 3 * G + o % 3;
+                    if (e < 9 * T) {
+                        const int v = t * T + r < n ? nbr[(size_t)k * nbr_stride + t * T + r] : -1;
+                        const unsigned rel = (unsigned)(v - (p.lo + pass * R));
+                        const unsigned row = (unsigned)(C::Z0 + G * R) + rel;
+                        tabw[C::tab_pos((unsigned)r, (unsigned)k)] =
+                            (v >= 0 && rel < (unsigned)R) ? (unsigned short)(row * S + C::swz(row)) : (unsigned short)0;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WIN_BARRIER();
+                int none = 0;
+                compute(buf, false, p, t, buf, &none);
+                c_new = 0;                   // (everything has been waited for)
+            }
+            wait_vm(c_new);                  // tile t + 1 has landed (this wave's part): only tile t + 2's may be in flight
+            stamp();
+            WIN_BARRIER();                   // ... everybody's, and everybody is done with stage buf
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+
+    // the waves of a group that split the row steps: summed in wave order through LDS
+    stamp();
+    __syncthreads();
+    if (W::RS > 1) {
+        float4 *red = (float4 *)smem;
+        if (rs > 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    red[(((grp * (W::RS - 1) + rs - 1) * NO + o) * NB + j) * 64 + lane] =
+                        make_float4(acc[o][j][0], acc[o][j][1], acc[o][j][2], acc[o][j][3]);
+        }
+        __syncthreads();
+        if (rs == 0) {
+            for (int q = 0; q < W::RS - 1; ++q)
+#pragma unroll
+                for (int o = 0; o < NO; ++o)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float4 v = red[(((grp * (W::RS - 1) + q) * NO + o) * NB + j) * 64 + lane];
+                        acc[o][j][0] += v.x; acc[o][j][1] += v.y; acc[o][j][2] += v.z; acc[o][j][3] += v.w;
+                    }
+        }
+    }
+    if (rs == 0) {
+        // lane (g4, t16) of block (mb, nb) holds dW_k[ci = 16 mb + 4 g4 .. + 3][co = 16 nb + t16]
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int og = oh * NO + o;
+            const int k = 9 * (og / 3) + 3 * G + og % 3;
+            if (og < 9) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int co = 16 * j + t16, ci = 16 * mb + 4 * g4;
+                    *reinterpret_cast<float4 *>(slab + (((size_t)share * CIN + co) * 27 + k) * CIN + ci) =
+                        make_float4(acc[o][j][0], acc[o][j][1], acc[o][j][2], acc[o][j][3]);
+                }
+            }
+        }
+    }
+    stamp();
+    if (trace && threadIdx.x == 0) {         // per-workgroup entry / exit times (trace[256 + b], trace[512 + b])
+        trace[256 + blockIdx.x] = t_entry;
+        trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(WIN_THREADS, 1) void subm_wgrad_win_kernel(
+    const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const int32_t *__restrict__ nbr, int nbr_stride,
+    int n_cap, const int32_t *__restrict__ n_dev, const char *__restrict__ plan_g, float *__restrict__ slab, unsigned x_bytes,
+    unsigned dy_bytes, unsigned long long *trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (j >= 30) return;
+    const int share = xcd * (WIN_WG_SHARES / 8) + j / 3;
+    const int n = eff_rows(n_dev, n_cap);
+    switch (j % 3) {
+        case 0: wgrad_win_body<C, 0>(x, dy, nbr, nbr_stride, n_cap, n, plan_g, slab, x_bytes, dy_bytes, share, smem, trace); break;
+        case 1: wgrad_win_body<C, 1>(x, dy, nbr, nbr_stride, n_cap, n, plan_g, slab, x_bytes, dy_bytes, share, smem, trace); break;
+        default: wgrad_win_body<C, 2>(x, dy, nbr, nbr_stride, n_cap, n, plan_g, slab, x_bytes, dy_bytes, share, smem, trace); break;
+    }
+}
+
+template <class C>
+static int launch_wgrad_win(const void *x, const void *dy, int n_rows, const int32_t *nbr, int nbr_stride, const int32_t *n_dev,
+                            const void *plan, float *slab, hipStream_t st) {
+    using W = WgCfg<C>;
+    if ((double)n_rows * C::ROWB >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
+    auto k = subm_wgrad_win_kernel<C>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES) != hipSuccess)
+        return PCD_ERR_LAUNCH;
+    const unsigned bytes = (unsigned)((size_t)n_rows * C::ROWB);
+    k<<<WIN_GRID, WIN_THREADS, W::LDS_BYTES, st>>>((const unsigned short *)x, (const unsigned short *)dy, nbr, nbr_stride, n_rows,
+                                                   n_dev, (const char *)plan, slab, bytes, bytes, g_win_trace);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -899,5 +1285,25 @@ extern "C" int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, 
     return win_dispatch(c_in, c_out, [&](auto c) {
         return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend,
                                        bn_reduce, st);
+    }, (int)PCD_ERR_UNSUPPORTED);
+}
+
+extern "C" int pcd_subm_window_wgrad_splits(void) { return WIN_WG_SHARES; }
+
+extern "C" int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, int n_rows, int c, const int32_t *nbr,
+                                                 int nbr_stride, const int32_t *n_rows_dev, const void *plan, void *slab,
+                                                 size_t slab_bytes, void *stream) {
+    PCD_ENTER();
+    if (n_rows < 0 || !win_supported(c, c)) return PCD_ERR_UNSUPPORTED;
+    if (!slab || slab_bytes < (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float)) return PCD_ERR_WORKSPACE;
+    if (n_rows == 0) {
+        if (hipMemsetAsync(slab, 0, (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return PCD_ERR_LAUNCH;
+        return PCD_OK;
+    }
+    if (!x || !dy || !nbr || !plan || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return win_dispatch(c, c, [&](auto cfg) {
+        return launch_wgrad_win<decltype(cfg)>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
     }, (int)PCD_ERR_UNSUPPORTED);
 }

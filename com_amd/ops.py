@@ -938,6 +938,36 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     return y
 
 
+def subm_window_wgrad(x, dy, rb, out=None, defer=None):
+    """dW [C, 27, C] f32 of a SubM 3x3x3 layer (c_in == c_out == C) over the window kernel's tiles: x, dy bf16 [n, C].  The
+    kernel leaves pcd_subm_window_wgrad_splits() partial slabs; their fixed-order sum is a job of wgrad_reduce_batched
+    (appended to `defer` when given, run here otherwise)."""
+    _require_cuda(x, dy)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    assert x.shape == dy.shape and rb.subm and rb.kvol == 27 and x.shape[0] == rb.nbr_out.shape[1]
+    n, c = x.shape
+    lib = L.lib()
+    plan = subm_window_plan(rb, c, c)
+    splits = int(lib.pcd_subm_window_wgrad_splits())
+    slab = torch.empty((splits * 27 * c * c * 4,), dtype=torch.uint8, device=x.device)
+    dw = out if _usable_out(out, c * 27 * c) else torch.empty((c, 27, c), dtype=torch.float32, device=x.device)
+
+    def meta():
+        pairs = int((rb.nbr_out >= 0).sum().item())
+        return dict(bytes=2 * n * c * 2 + 8 * pairs + 27 * c * c * 4, flops=2 * pairs * c * c, rows=n, pairs=pairs)
+
+    with _Timed(f"subm_wgrad_win_kernel<{c}> {c}x{c} K=27", meta):
+        L.check(lib.pcd_sparse_conv_subm_window_wgrad(L.ptr(x), L.ptr(dy), n, c, L.ptr(rb.nbr_out), rb.nbr_out.shape[1],
+                                                      L.ptr(rb.n_out_dev), L.ptr(plan), L.ptr(slab), slab.numel(),
+                                                      L.stream_ptr()), "pcd_sparse_conv_subm_window_wgrad")
+    job = (slab, dw, 27, c, c, 0, splits)
+    if defer is not None:
+        defer.append(job)
+    else:
+        wgrad_reduce_batched([job])
+    return dw
+
+
 def _usable_out(out, numel):
     return (out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == numel
             and out.is_cuda)

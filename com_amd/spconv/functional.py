@@ -105,6 +105,12 @@ def _to_bf16_padded(x, c_pad):
     return x.contiguous()
 
 
+def _window_wgrad(c):
+    """The "subm_window_wgrad" option admits the window weight gradient for c channels (bit 0 = 64, bit 1 = 32, bit 2 = 16)."""
+    from .. import _lib as L
+    return bool(L.get_option("subm_window_wgrad") & {64: 1, 32: 2, 16: 4}.get(int(c), 0))
+
+
 class SparseConvFunction(Function):
     """y = indice_conv(features, weight, rulebook) with bf16 MFMA, fp32 accumulate.
 
@@ -243,9 +249,13 @@ class SparseConvFunction(Function):
                     and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             if ctx.needs_input_grad[1]:
-                dwk = ops.wgrad(x, ctx.cin, dy16, None, None, rb.kvol,
-                                out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32
-                                defer=_WGRAD_JOBS if (deferred and direct_w) else None, rb=rb)
+                if ctx.window and rb.subm and ctx.cin == ctx.cout == x.shape[1] and _window_wgrad(ctx.cin):
+                    dwk = ops.subm_window_wgrad(x, dy16, rb, out=weight_p.grad if direct_w else None,
+                                                defer=_WGRAD_JOBS if (deferred and direct_w) else None)
+                else:
+                    dwk = ops.wgrad(x, ctx.cin, dy16, None, None, rb.kvol,
+                                    out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32
+                                    defer=_WGRAD_JOBS if (deferred and direct_w) else None, rb=rb)
                 dw = None if direct_w else dwk.view(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 cl = ctx.colsum_link.result if ctx.colsum_link is not None else None

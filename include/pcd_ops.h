@@ -73,7 +73,10 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "gg_resident_kb" 32   packed weight up to this size stays resident in LDS in gather_gemm_kernel
  *   "ggw" 1               LDS-DMA gather-GEMM for C_in = 128 (0 off, 2..4: rows-per-wave forced also for C_in = 64, 6: forward only)
  *   "gg1" 1               16-channel gather-GEMM variant (1: 32 rows per wave)
- *   "subm_window" 1       window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows (0: generic kernels)
+ *   "subm_window" 7       window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows: bit 0 = 64 channels, bit 1 = 32,
+ *                         bit 2 = 16 (0: generic kernels) -- read by the host-side layer, the C entry points take any width
+ *   "subm_window_wgrad" 6 the same bits for the window weight gradient (pcd_sparse_conv_subm_window_wgrad); 64 channels off:
+ *                         its 80 partial slabs (35 MB per layer) cost the training step more than the kernel saves
  *   "wg128" 1             equal-pair weight-gradient kernel at 128 x 128 channels
  *   "wg128_chunks" 512    its workgroup count
  *   "wg_rows" 6144        row-range split of the generic weight-gradient kernel
@@ -866,7 +869,7 @@ int pcd_debug_stamp(uint64_t *slot, void *stream);
  * ============================================================================================ */
 int pcd_subm_window_tile_rows(int c_in, int c_out);
 int pcd_subm_window_partial_rows(void);
-/* profiling aid: a device buffer of 256 x u64 that receives shader-clock stamps of workgroup 0 at the phase boundaries of its
+/* profiling aid: a device buffer of 1024 x u64 whose first 256 entries receive shader-clock stamps of workgroup 0 at the phase boundaries of its
  * tiles (7 per tile: barrier, prefetch issued, MFMA loop done, prefetch landed, barrier, partial sums written + barrier,
  * epilogue done); NULL (the default) = off.  Process-wide; tools/exp_subm_win.py */
 int pcd_subm_window_set_trace(void *buf256_u64);
@@ -876,6 +879,13 @@ int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_cap, const in
 size_t pcd_subm_window_packed_weight_bytes(int c_in, int c_out);
 int pcd_subm_window_pack_weight(const float *weight, int c_in, int c_out, int mode, void *packed, void *stream);
 int pcd_subm_window_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
+/* Weight gradient over the same tiles: slab[s][c_out][27][c_in] f32 for s < pcd_subm_window_wgrad_splits() partial sums
+ * (slab_bytes >= splits * 27 * c * c * 4), to be summed over s in order -- pcd_sparse_conv_wgrad_reduce_batched with
+ * job.splits = that count does it (same job as pcd_sparse_conv_wgrad_os).  x, dy: bf16 [n_rows][c]; nbr / plan as above. */
+int pcd_subm_window_wgrad_splits(void);
+int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, int n_rows, int c, const int32_t *nbr, int nbr_stride,
+                                      const int32_t *n_rows_dev, const void *plan, void *slab, size_t slab_bytes,
+                                      void *stream);
 int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
                                 const void *plan, int c_out, void *y, const void *addend,

@@ -201,3 +201,61 @@ def test_submconv3d_module_takes_the_window_kernel_on_yxz_rows_and_matches_the_g
     for a, b, what in zip(outs[1], outs[0], ("y", "dx", "dw", "db")):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2.0 ** -6 * scale, what
+
+
+@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1)])
+def test_window_weight_gradient_against_the_generic_kernel_and_float64(ch, lvl):
+    """dW[co][k][ci] = sum_r x[nbr[k][r]][ci] dy[r][co] over the window kernel's tiles (three workgroups per share, one per run,
+    80 partial slabs summed in order): against the pair-list kernel (same bf16 operands, fp32 sums in another order) and against
+    a float64 evaluation of the definition on the rulebook; z-fastest rows and first-appearance rows (multi-pass runs)."""
+    ops = _ops()
+    idx, rank, shape = _level(1, lvl, beams=32 if lvl <= 2 else 64, azim=1250 if lvl <= 2 else 2500)
+    n = idx.shape[0]
+    g = torch.Generator().manual_seed(11 + ch)
+    for case in ("yxz", "first"):
+        if case == "yxz":
+            rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=True)
+        else:
+            perm = torch.randperm(n, generator=g).to(DEV)              # any numbering: runs far longer than the window
+            rb = ops.rulebook_subm(idx[perm].contiguous(), 1, shape, want_pairs=True)
+        m = rb.nbr_out.shape[1]
+        x = torch.randn(m, ch, generator=g).to(DEV).to(torch.bfloat16)
+        dy = torch.randn(m, ch, generator=g).to(DEV).to(torch.bfloat16)
+        dw = ops.subm_window_wgrad(x, dy, rb)
+        ref = ops.wgrad(x, ch, dy, None, None, 27, rb=rb)
+        torch.cuda.synchronize()
+        assert dw.shape == ref.shape == (ch, 27, ch)
+        scale = float(ref.abs().max())
+        assert float((dw - ref).abs().max()) <= 2e-5 * scale * np.sqrt(m / 1000.0 + 1.0), case
+        # float64 definition for a few offsets
+        x64, dy64 = x.double(), dy.double()
+        for k in (0, 4, 13, 22, 26):
+            nb = rb.nbr_out[k].long()
+            ok = nb >= 0
+            want = dy64[ok].t() @ x64[nb[ok]]                            # [co, ci]
+            got = dw[:, k, :].double()
+            assert float((got - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1.0) * np.sqrt(m / 1000.0 + 1.0), (case, k)
+
+
+def test_window_weight_gradient_ignores_the_rows_behind_a_device_side_row_count():
+    """Static-shape mode: buffers of a capacity above the row count (the count lives in device memory); the rows behind it hold
+    garbage -- NaN here -- that must not reach the sums (0 x NaN = NaN)."""
+    ops = _ops()
+    idx, rank, shape = _level(1, 2, beams=32, azim=1250)
+    n, ch = idx.shape[0], 32
+    cap = n + 777
+    big = torch.full((cap, 4), 0, dtype=torch.int32, device=DEV)
+    big[:n] = idx
+    n_dev = torch.tensor([n], dtype=torch.int32, device=DEV)
+    rb = ops.rulebook_subm(big, 1, shape, want_pairs=True, n_dev=n_dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(cap, ch, generator=g).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(cap, ch, generator=g).to(DEV).to(torch.bfloat16)
+    x[n:] = float("nan")
+    dy[n:] = float("nan")
+    dw = ops.subm_window_wgrad(x, dy, rb)
+    rb0 = ops.rulebook_subm(idx, 1, shape, want_pairs=True)
+    ref = ops.wgrad(x[:n].contiguous(), ch, dy[:n].contiguous(), None, None, 27, rb=rb0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dw).all())
+    assert float((dw - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * np.sqrt(n / 1000.0 + 1.0)

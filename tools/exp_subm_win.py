@@ -108,7 +108,7 @@ if os.environ.get("WIN_TRACE"):
     w = (torch.randn(ch, 3, 3, 3, ch) * 0.02).to(dev)
     x = torch.randn(n, ch).to(dev).to(torch.bfloat16)
     wf = ops.pack_weight_window(w, 0)
-    tr = torch.zeros(256, dtype=torch.int64, device=dev)
+    tr = torch.zeros(1024, dtype=torch.int64, device=dev)
     for _ in range(3):
         ops.subm_window(x, wf, None, rb, ch)
     L.lib().pcd_subm_window_set_trace(L.ptr(tr))
@@ -126,3 +126,46 @@ if os.environ.get("WIN_TRACE"):
     for i in range(0, len(t) - 6, 7):
         d = np.diff(t[i:i + 8])
         print("   " + " ".join(f"{int(v):7d}" for v in d))
+
+if os.environ.get("WIN_WGRAD"):
+    for lvl in (1, 2, 3):
+        if str(lvl) not in want:
+            continue
+        idx, rank, shape, ch = levels[lvl]
+        n = idx.shape[0]
+        rb = ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=True)
+        x = torch.randn(n, ch).to(dev).to(torch.bfloat16)
+        dy = torch.randn(n, ch).to(dev).to(torch.bfloat16)
+        d0 = ops.wgrad(x, ch, dy, None, None, 27, rb=rb)
+        d1 = ops.subm_window_wgrad(x, dy, rb)
+        torch.cuda.synchronize()
+        jobs = []
+        t_gen = timeit(lambda: ops.wgrad(x, ch, dy, None, None, 27, rb=rb, defer=jobs))
+        t_win = timeit(lambda: ops.subm_window_wgrad(x, dy, rb, defer=jobs))
+        t_red0 = timeit(lambda: ops.wgrad(x, ch, dy, None, None, 27, rb=rb)) - t_gen
+        t_red1 = timeit(lambda: ops.subm_window_wgrad(x, dy, rb)) - t_win
+        if os.environ.get("WIN_WGRAD") == "2":
+            from com_amd import _lib as L
+            tr = torch.zeros(1024, dtype=torch.int64, device=dev)
+            L.lib().pcd_subm_window_set_trace(L.ptr(tr))
+            ops.subm_window_wgrad(x, dy, rb, defer=jobs)
+            torch.cuda.synchronize()
+            L.lib().pcd_subm_window_set_trace(None)
+            tt = tr.cpu().numpy()
+            ent, ext = tt[256:512], tt[512:768]
+            live = ext > 0
+            t0 = ent[live].min()
+            dur = (ext - ent)[live] * 10e-3
+            print(f"   per workgroup (us): start after the first {np.percentile((ent[live] - t0) * 10e-3, [50, 100]).round(1).tolist()} "
+                  f"(median, max); duration min {dur.min():.1f} median {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f}; "
+                  f"end of the last {((ext[live] - t0) * 10e-3).max():.1f}; longest: block {np.nonzero(live)[0][dur.argmax()]}")
+            tt = tt[:256]
+            tt = tt[tt > 0]
+            print(f"   wgrad workgroup 0: entry -> first tile {int(tt[1] - tt[0])} clk, entry -> exit {int(tt[-1] - tt[0])} clk, "
+                  f"last barrier -> exit {int(tt[-1] - tt[-2])}; per tile (issue | compute | wait | barrier):")
+            body = tt[1:-2]
+            for i in range(0, min(len(body) - 4, 48), 4):
+                d = np.diff(body[i:i + 5])
+                print("      " + " ".join(f"{int(v):6d}" for v in d))
+        print(f"level {lvl} wgrad {ch}x{ch}: max|diff| {(d0 - d1).abs().max().item():.4g} (scale {d0.abs().max().item():.3g}); "
+              f"generic {t_gen:.1f} us (+ reduce {t_red0:.1f}), window {t_win:.1f} us (+ reduce {t_red1:.1f})", flush=True)
