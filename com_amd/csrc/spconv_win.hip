@@ -76,13 +76,17 @@ __host__ __device__ constexpr size_t win_hdr_off(int ntiles) { return win_prefix
 __host__ __device__ constexpr size_t win_tab_off(int ntiles) { return win_hdr_off(ntiles) + (size_t)ntiles * 32; }
 
 // Wave roles: wave = (cb, rg, oq) -- output-channel block of 32, group of row blocks, slice of the 27 offsets.
-template <int CIN_, int NCB_, int NRG_, int NOQ_, int T_, int R_>
+// CQN > 1: the output channels are dealt to CQN workgroups per share of the tiles (128 channels: the weights of 32 output
+// channels fill the registers of a workgroup) -- each loads the same windows and writes its COUTW columns of y.
+template <int CIN_, int NCB_, int NRG_, int NOQ_, int T_, int R_, int CQN_ = 1>
 struct WinCfg {
-    static constexpr int CIN = CIN_, NCB = NCB_, NRG = NRG_, NOQ = NOQ_, T = T_, R = R_;
+    static constexpr int CIN = CIN_, NCB = NCB_, NRG = NRG_, NOQ = NOQ_, T = T_, R = R_, CQN = CQN_;
     static_assert(NCB * NRG * NOQ == 8, "8 waves");
     static constexpr int COUT = CIN;                     // square layers only; a wave's MFMA block spans 32 output channels (the
-    static_assert(32 * NCB >= COUT, "channel blocks");   //  upper 16 are zero weights at 16 channels: LDS reads bound that layer, not MFMAs)
-    static constexpr int QN = COUT >= 32 ? 4 : COUT / 8; // live 4-register groups of a lane's 32 x 32 accumulator block
+    static constexpr int COUTW = COUT / CQN;             //  upper 16 are zero weights at 16 channels: LDS reads bound that layer, not MFMAs)
+    static_assert(32 * NCB >= COUTW && WIN_GRID % CQN == 0, "channel blocks");
+    static constexpr int NCBP = COUT >= 32 ? COUT / 32 : 1;   // 32-channel blocks of the packed weights
+    static constexpr int QN = COUTW >= 32 ? 4 : COUTW / 8;   // live 4-register groups of a lane's 32 x 32 accumulator block
     static constexpr int ROWB = CIN * 2;                 // bytes per feature row
     static constexpr int S = ROWB / 16;                  // 16-byte slots per row
     static constexpr int P = ROWB >= 256 ? 1 : 256 / ROWB;   // rows per 256 bytes of LDS (one sweep of the 64 banks)
@@ -98,8 +102,9 @@ struct WinCfg {
     // entry oq SLICE + j (slices padded to whole 16-byte pieces, padding = 0 = the zero row), and the four 16-byte pieces of row r
     // are stored at piece ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 phase touches hit 64 distinct banks.
     static constexpr int SLICE = 32 / NOQ;               // entries per slice
-    static_assert(SLICE >= OPW && SLICE % 8 == 0, "slices");
-    static constexpr int SLP = SLICE / 8;                // 16-byte pieces per slice
+    static_assert(SLICE >= OPW && (SLICE % 8 == 0 || SLICE == 4), "slices");
+    static constexpr int SLP = SLICE / 8;                // 16-byte pieces per slice (0: half a piece, SLICE == 4)
+    static constexpr int SLD = SLICE / 2;                // dwords per slice
     static constexpr int TABB = T * 64;                  // bytes per tile
     static_assert(TABB % 1024 == 0, "whole 1-KiB DMA instructions");
     static constexpr int NTABI = TABB / 1024;            // ... of them
@@ -111,7 +116,7 @@ struct WinCfg {
     static constexpr bool DIRECT = NOQ == 1 && NCB == 1; // a wave owns whole rows: no cross-wave sums, the epilogue runs from registers
     static constexpr int SPR = (R / RPI + 7) / 8;        // window DMA instructions per run and wave
     static constexpr int NSLOT = 3 * SPR + TSL;          // prefetch instructions per wave and tile
-    static constexpr int REDSTRIDE = COUT * 4 + 16;      // bytes per (slice, row) of partial sums: +16 keeps b128 stores conflict-free
+    static constexpr int REDSTRIDE = COUTW * 4 + 16;     // bytes per (slice, row) of partial sums: +16 keeps b128 stores conflict-free
     static constexpr int REDB = NOQ * T * REDSTRIDE;
     static constexpr int EXTRA = REDB > WINB ? (REDB - WINB + 16 * ROWB - 1) / (16 * ROWB) * (16 * ROWB) : 0;   // whole swizzle periods
     static_assert(WIN_THREADS * 16 * 4 <= WINB + EXTRA, "BatchNorm column staging fits the reduction area");
@@ -127,7 +132,6 @@ struct WinCfg {
     // that fits the window, else [XTR, +REDB) -- which runs over the second zero rows: they are cleared again (REZERO)
     static constexpr bool REZERO = EXTRA > 0;
     static constexpr int RED1 = REZERO ? XTR : WIN1;
-    static_assert(Z0 * ROWB <= WIN_THREADS * 4, "one dword per thread clears the zero rows");
     static_assert(BOFF % 16 == 0 && WINROWS % 16 == 0, "swizzle period");
     static constexpr int TAB0 = WIN1 + WINB;
     static constexpr int PLAN = TAB0 + 2 * TABB;
@@ -136,8 +140,9 @@ struct WinCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static constexpr int NL = (27 * T + WIN_THREADS - 1) / WIN_THREADS;   // rulebook entries per thread and tile (multi-pass tiles only)
     static constexpr size_t plan_bytes(int ntiles) { return win_tab_off(ntiles) + (size_t)ntiles * TABB; }
-    static constexpr int CG = COUT / 8;                  // 8-channel groups per row in the tile epilogue
-    static_assert(T * CG == WIN_THREADS, "epilogue: one (row, 8 channels) per thread");
+    static constexpr int CG = COUTW / 8;                 // 8-channel groups per row in the tile epilogue
+    static constexpr int NEPI = T * CG;                  // epilogue threads: one (row, 8 channels) each
+    static_assert(NEPI <= WIN_THREADS && NEPI % 64 == 0, "epilogue threads");
     __host__ __device__ static constexpr unsigned swz(unsigned row) { return (row / P) & (S - 1); }
     static_assert(P * S == 16 && Z0 % 16 == 0 && R % 16 == 0 && (8 * RPI) % 16 == 0, "swizzle period of 16 rows");
 };
@@ -145,6 +150,7 @@ struct WinCfg {
 using Win64 = WinCfg<64, 2, 1, 4, 64, 128>;      // 64 -> 64: waves = 2 channel blocks x 4 offset slices (7 offsets each)
 using Win32 = WinCfg<32, 1, 4, 2, 128, 320>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
 using Win16 = WinCfg<16, 1, 8, 1, 256, 512>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
+using Win128 = WinCfg<128, 1, 1, 8, 32, 64, 4>;  // 128 -> 128: 4 workgroups x 32 output channels; waves = 8 offset slices (4 each)
 
 // c_in -> configuration (square layers): f(Cfg{}) with the matching type, `none` otherwise
 template <class F, class N>
@@ -154,6 +160,7 @@ static inline auto win_dispatch(int c_in, int c_out, F &&f, N none) -> decltype(
         case 64: return f(Win64{});
         case 32: return f(Win32{});
         case 16: return f(Win16{});
+        case 128: return f(Win128{});
         default: return none;
     }
 }
@@ -172,21 +179,24 @@ template <class C>
 __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict__ nbr, int nbr_stride, int n_cap,
                                                        const int32_t *__restrict__ n_dev, char *__restrict__ plan_base, int ntiles_cap) {
     constexpr int T = C::T, R = C::R;
+    constexpr int TPW = T >= 64 ? 1 : 64 / T;            // tiles per wave (T < 64: every T lanes one tile)
+    constexpr int U = T >= 64 ? T / 64 : 1;              // rows per lane
+    constexpr int LPT = T >= 64 ? 64 : T;                // lanes per tile
     int4 *plan = (int4 *)(plan_base + win_hdr_off(ntiles_cap));
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntiles_cap) return;
-    const int lane = threadIdx.x & 63;
+    const int tile = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + (threadIdx.x & 63) / LPT;
+    if (tile >= ntiles_cap) return;                      // (whole T-lane groups leave: the exchanges below stay inside a group)
+    const int lane = (threadIdx.x & 63) % LPT;
     const int n = eff_rows(n_dev, n_cap);
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-    int v[T / 64][27];
+    int v[U][27];
 #pragma unroll
-    for (int u = 0; u < T / 64; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int row = tile * T + u * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 27; ++k) v[u][k] = row < n ? nbr[(size_t)k * nbr_stride + row] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < T / 64; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
             const int g = (k / 3) % 3;
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
+        for (int d = LPT / 2; d >= 1; d >>= 1) {
             lo[g] = min(lo[g], __shfl_xor(lo[g], d, 64));
             hi[g] = max(hi[g], __shfl_xor(hi[g], d, 64));
         }
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
     }
     char *tab = plan_base + win_tab_off(ntiles_cap) + (size_t)tile * C::TABB;
 #pragma unroll
-    for (int u = 0; u < T / 64; ++u) {
+    for (int u = 0; u < U; ++u) {
         const unsigned r = (unsigned)(u * 64 + lane);
         u32 w[16];                                   // the row's 32 entries
 #pragma unroll
@@ -272,14 +282,15 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
     const long long total = scan[1023];
     __threadfence_block();
     __syncthreads();
-    for (int j = tid; j <= WIN_GRID; j += 1024) {
-        const long long target = total * j / WIN_GRID;
+    constexpr int NSH = WIN_GRID / C::CQN;            // shares of the forward / data-gradient kernel (CQN workgroups each)
+    for (int j = tid; j <= NSH; j += 1024) {
+        const long long target = total * j / NSH;
         int lo = 0, hi = nt;                          // number of tiles with prefix <= target
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
         }
-        bnd[j] = j == WIN_GRID ? nt : lo;
+        bnd[j] = j == NSH ? nt : lo;
     }
     for (int j = tid; j <= WIN_WG_SHARES; j += 1024) {
         const long long target = total * j / WIN_WG_SHARES;
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         bndw[j] = j == WIN_WG_SHARES ? nt : lo;
     }
     __syncthreads();
-    for (int w = tid; w < WIN_GRID; w += 1024) {
+    for (int w = tid; w < NSH; w += 1024) {
         const int tb = bnd[w], te = bnd[w + 1];
         int4 *e = (int4 *)(plan_base + (size_t)w * WIN_ENTRY_BYTES);
         const int4 z = make_int4(0, 0, 0, 0);
@@ -317,7 +328,7 @@ __device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mo
     t /= C::KS;
     const int j = (int)(t % C::OPW);
     t /= C::OPW;
-    const int oq = (int)(t % C::NOQ), cb = (int)(t / C::NOQ);
+    const int oq = (int)(t % C::NOQ), cb = (int)(t / C::NOQ);          // cb < NCBP: (workgroup quarter, block) in the kernel's order
     const int k = oq * C::OPW + j;
     const int co = 32 * cb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j8;
     float v = 0.0f;
@@ -325,13 +336,15 @@ __device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mo
     out[e] = f32_to_bf16_bits(v);
 }
 template <class C>
-constexpr size_t win_pack_elems() { return (size_t)C::NCB * C::NOQ * C::OPW * C::KS * 512; }
+constexpr size_t win_pack_elems() { return (size_t)C::NCBP * C::NOQ * C::OPW * C::KS * 512; }
 
 __device__ __forceinline__ void win_pack_any(const float *__restrict__ w, int cin, int mode, size_t e, unsigned short *out) {
     if (cin == 64) {
         if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out);
     } else if (cin == 32) {
         if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out);
+    } else if (cin == 128) {
+        if (e < win_pack_elems<Win128>()) win_pack_one<Win128>(w, mode, e, out);
     } else {
         if (e < win_pack_elems<Win16>()) win_pack_one<Win16>(w, mode, e, out);
     }
@@ -355,6 +368,7 @@ __global__ __launch_bounds__(256) void win_pack_batched_kernel(const long long *
     win_pack_any(w, cin, mode, e, out);
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 unsigned long long *g_win_trace = nullptr;     // profiling aid, NULL in production (pcd_subm_window_set_trace)
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     auto stamp = [&]() {
         if (trace && blockIdx.x == 0 && threadIdx.x == 0 && trace_at < 256) trace[trace_at++] = __builtin_readcyclecounter();
     };
-    constexpr int T = C::T, R = C::R, ROWB = C::ROWB, COUT = C::COUT, OPW = C::OPW, KS = C::KS, RBW = C::RBW;
+    constexpr int T = C::T, R = C::R, ROWB = C::ROWB, COUT = C::COUT, COUTW = C::COUTW, OPW = C::OPW, KS = C::KS, RBW = C::RBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stamp();                                 // (trace slot 0: kernel entry)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -386,7 +400,9 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     // tiles of this workgroup: share w of win_split_kernel, w in XCD-major order (workgroup b runs on XCD b % 8 -- speed only):
     // every XCD gets a contiguous run of tiles -- neighbouring tiles' windows overlap, they share the XCD's L2
     const int ntiles_cap = (n_cap + T - 1) / T;
-    const int4 *entry = (const int4 *)((const char *)plan_g + (size_t)((blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3)) * WIN_ENTRY_BYTES);
+    const int wxm = (blockIdx.x & 7) * ((int)gridDim.x >> 3) + (blockIdx.x >> 3);          // XCD-major index
+    const int cq = wxm % C::CQN;                         // this workgroup's columns of y: [cq COUTW, + COUTW) (consecutive wxm: same XCD)
+    const int4 *entry = (const int4 *)((const char *)plan_g + (size_t)(wxm / C::CQN) * WIN_ENTRY_BYTES);
     const int4 ent0 = entry[0], ent1 = entry[1], ent2 = entry[2];
     const int t_begin = __builtin_amdgcn_readfirstlane(ent0.x), t_end = __builtin_amdgcn_readfirstlane(ent0.y);
     const int4 *hdr_g = (const int4 *)((const char *)plan_g + win_hdr_off(ntiles_cap));
@@ -406,20 +422,20 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     constexpr int NWP = C::NCB * C::NOQ * OPW * KS;      // KiB of packed weights
     static_assert(!STAGEW || NWP * 1024 <= C::WINB, "staged weights fit window buffer 1");
     if (!STAGEW) {
-        const uint4 *wsrc = wp + (size_t)((cb * C::NOQ + oq) * OPW) * KS * 64 + lane;
+        const uint4 *wsrc = wp + (size_t)(((cq * C::NCB + cb) * C::NOQ + oq) * OPW) * KS * 64 + lane;
 #pragma unroll
         for (int j = 0; j < OPW; ++j)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) wreg[j][ks] = __builtin_bit_cast(bf16x8, wsrc[(j * KS + ks) * 64]);
     }
     // bias and (BatchNorm mode 2) mean of the epilogue: LDS copies (zeros without a bias) in the area of the final BatchNorm row
-    for (int e = tid; e < 2 * COUT; e += WIN_THREADS)
-        cols[e] = e < COUT ? (bias ? bias[e] : 0.0f) : (bn.mode == 2 ? bn.mean[e - COUT] : 0.0f);
+    for (int e = tid; e < 2 * COUTW; e += WIN_THREADS)
+        cols[e] = e < COUTW ? (bias ? bias[cq * COUTW + e] : 0.0f) : (bn.mode == 2 ? bn.mean[cq * COUTW + e - COUTW] : 0.0f);
     // the zero rows in front of both windows
     auto clear_zero1 = [&]() {
-        if (tid < C::Z0 * ROWB / 4) ((int *)(smem + C::ZERO1))[tid] = 0;
+        for (int e = tid; e < C::Z0 * ROWB / 4; e += WIN_THREADS) ((int *)(smem + C::ZERO1))[e] = 0;
     };
-    if (tid < C::Z0 * ROWB / 4) ((int *)(smem + C::ROWBASE))[tid] = 0;
+    for (int e = tid; e < C::Z0 * ROWB / 4; e += WIN_THREADS) ((int *)(smem + C::ROWBASE))[e] = 0;
     clear_zero1();
 
     const u32x4 xdma = win_rsrc(x, x_bytes);
@@ -547,27 +563,37 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         const char *rowbase = smem + C::ROWBASE;
         const unsigned half = (unsigned)lane >> 5;
         const unsigned boff = buf ? (unsigned)(C::BOFF * ROWB) : 0u;     // table entries are slots of buffer 0; (a multiple of 128)
-        // a step = KS * SO MFMAs: SO offsets are paired at narrow layers so that a step always has >= 4 fragments in flight
+        // a step = 4 MFMAs on 4 fragments: SO offsets are paired at narrow layers, a wide contraction (KS > 4) is cut into KH
+        // parts of KSS steps (two register sets of 4 fragments either way)
         constexpr int SO = KS >= 4 ? 1 : 4 / KS;
+        constexpr int KH = KS > 4 ? KS / 4 : 1, KSS = KS / KH;
         constexpr int NJ = (OPW + SO - 1) / SO;          // offset groups of this wave's slice
-        constexpr int NSTEP = NJ * RBW;
+        constexpr int NSTEP = NJ * RBW * KH;
         constexpr int PF_FIRST = C::DIRECT ? 0 : NSTEP >= 10 ? 3 : 1;    // first step followed by prefetch slots (DIRECT: no barrier
                                                                           // to wait for -- as early as possible, the loop is short)
         constexpr int SPS = (NSLOT + (NSTEP - PF_FIRST) - 1) / (NSTEP - PF_FIRST);   // slots per step
         static_assert(NSTEP > PF_FIRST, "steps");
-        bf16x8 fr[2][SO * KS];
+        bf16x8 fr[2][SO * KSS];
         // this lane's table entries (its row of every row block, the wave's slice of the offsets): SLP 16-byte reads per block
-        u32x4 tq[RBW][C::SLP];
+        u32 tq[RBW][C::SLD];
 #pragma unroll
         for (int rbw = 0; rbw < RBW; ++rbw) {
             const unsigned r = (unsigned)((rg * RBW + rbw) * 32) + ((unsigned)lane & 31u);
+            if (C::SLP > 0) {
 #pragma unroll
-            for (int c = 0; c < C::SLP; ++c)
-                tq[rbw][c] = *reinterpret_cast<const u32x4 *>(smem + C::TAB0 + buf * C::TABB + r * 64 +
-                                                              (((unsigned)(oq * C::SLP + c) ^ ((r >> 2) & 3u)) << 4));
+                for (int c = 0; c < C::SLP; ++c) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + C::TAB0 + buf * C::TABB + r * 64 +
+                                                                      (((unsigned)(oq * C::SLP + c) ^ ((r >> 2) & 3u)) << 4));
+                    tq[rbw][4 * c] = v[0]; tq[rbw][4 * c + 1] = v[1]; tq[rbw][4 * c + 2] = v[2]; tq[rbw][4 * c + 3] = v[3];
+                }
+            } else {             // SLICE == 4: half a piece (8 bytes) per slice
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(smem + C::TAB0 + buf * C::TABB + r * 64 +
+                                                                  (((unsigned)(oq >> 1) ^ ((r >> 2) & 3u)) << 4) + (oq & 1) * 8);
+                tq[rbw][0] = v[0]; tq[rbw][1] = v[1];
+            }
         }
-        auto fetch = [&](int step, bf16x8 (&dst)[SO * KS]) {
-            const int jg = step / RBW, rbw = step % RBW;
+        auto fetch = [&](int step, bf16x8 (&dst)[SO * KSS]) {
+            const int jg = step / (RBW * KH), rbw = (step / KH) % RBW, kh = step % KH;
 #pragma unroll
             for (int o = 0; o < SO; ++o) {
                 const int j = jg * SO + o;
@@ -575,12 +601,12 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                 // entry = slot of the row's first 8 channels in buffer 0 (0 = the zero row in front of it); buffer 1 lies BOFF rows
                 // (whole swizzle periods) further and has its own zero rows.  Slot of contraction step ks = (2 ks + half) ^
                 // swz(row) = entry ^ half ^ 2 ks: one XOR with a constant per step.
-                const u32 w = tq[rbw][j / 8][(j % 8) / 2];
+                const u32 w = tq[rbw][j / 2];
                 const unsigned e = (j & 1) ? w >> 16 : w & 0xffffu;
                 const unsigned a0 = ((e ^ half) << 4) + boff;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    dst[o * KS + ks] = *reinterpret_cast<const bf16x8 *>(rowbase + (a0 ^ ((unsigned)ks << 5)));
+                for (int ks = 0; ks < KSS; ++ks)
+                    dst[o * KSS + ks] = *reinterpret_cast<const bf16x8 *>(rowbase + (a0 ^ ((unsigned)(kh * KSS + ks) << 5)));
             }
         };
         fetch(0, fr[0]);
@@ -589,13 +615,14 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             if (step + 1 < NSTEP) fetch(step + 1, fr[(step + 1) & 1]);
             // (the scheduler, short of registers, sinks the reads back to one per MFMA unless told not to)
             __builtin_amdgcn_sched_barrier(0);
-            const int jg = step / RBW, rbw = step % RBW;
+            const int jg = step / (RBW * KH), rbw = (step / KH) % RBW, kh = step % KH;
 #pragma unroll
             for (int o = 0; o < SO; ++o)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KSS; ++ks)
                     if (jg * SO + o < OPW)
-                        acc[rbw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[jg * SO + o][ks], fr[step & 1][o * KS + ks], acc[rbw], 0, 0, 0);
+                        acc[rbw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[jg * SO + o][kh * KSS + ks], fr[step & 1][o * KSS + ks],
+                                                                           acc[rbw], 0, 0, 0);
             if (PF) {
                 // B1, inside the loop: the prefetch overwrites the area the PREVIOUS tile's epilogue read its partial sums from, so
                 // every wave must have left that epilogue -- but nothing before the first slot needs the barrier: the waves run
@@ -664,11 +691,13 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                     erow = rg * 32 + (te & 31);
                     ecg = (te & 63) >> 5;
                 } else {
-                    erow = te / C::CG;
+                    // (NEPI < 512 threads have a row: the others repeat the roles of the first NEPI -- loads of valid addresses,
+                    //  nothing stored)
+                    erow = (te % C::NEPI) / C::CG;
                     ecg = te % C::CG;
                 }
                 const int orow = t * T + erow;
-                const size_t lelem = (size_t)(orow < n ? orow : n - 1) * COUT + ecg * 8;
+                const size_t lelem = (size_t)(orow < n ? orow : n - 1) * COUT + cq * COUTW + ecg * 8;
                 if (addend) av = *reinterpret_cast<const uint4 *>(addend + lelem);
                 if (bn.mode == 2) {
                     xv = *reinterpret_cast<const uint4 *>(bn.x + lelem);
@@ -679,7 +708,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             auto finish = [&](float (&v)[8]) {
                 const int orow = t * T + erow;
                 const bool olive = orow < n;
-                const unsigned ooff = olive ? (unsigned)((size_t)orow * COUT + ecg * 8) * 2u : 0xFFFFFFF0u;
+                const unsigned ooff = olive ? (unsigned)((size_t)orow * COUT + cq * COUTW + ecg * 8) * 2u : 0xFFFFFFF0u;
                 {
                     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(cols + ecg * 8),
                                 b1 = *reinterpret_cast<const f32x4 *>(cols + ecg * 8 + 4);
@@ -707,8 +736,8 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                         if (bn.relu) {
                             yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
                         }
-                        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(cols + COUT + ecg * 8),
-                                    m1 = *reinterpret_cast<const f32x4 *>(cols + COUT + ecg * 8 + 4);
+                        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(cols + COUTW + ecg * 8),
+                                    m1 = *reinterpret_cast<const f32x4 *>(cols + COUTW + ecg * 8 + 4);
                         mu[0] = m0[0]; mu[1] = m0[1]; mu[2] = m0[2]; mu[3] = m0[3];
                         mu[4] = m1[0]; mu[5] = m1[1]; mu[6] = m1[2]; mu[7] = m1[3];
                     }
@@ -786,7 +815,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             }
             WIN_BARRIER();                               // B3
             stamp();
-            if (!(dbg & 8)) {   // tile epilogue: the slices summed in order
+            if (!(dbg & 8) && (C::NEPI == WIN_THREADS || fresh(tid) < C::NEPI)) {   // tile epilogue: the slices summed in order
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.0f;
@@ -824,15 +853,20 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < 2 * COUT; e += WIN_THREADS) {
-            const int which = e / COUT, c = e % COUT;
+        for (int e = tid; e < 2 * COUTW; e += WIN_THREADS) {
+            const int which = e / COUTW, c = e % COUTW;
             float s = 0.0f;
             for (int w = 0; w < 8; ++w) s += stage[(w * C::CG + c / 8) * 16 + which * 8 + (c & 7)];
-            if (which == 1 && bn.mode == 2) s *= bn.invstd[c];
+            if (which == 1 && bn.mode == 2) s *= bn.invstd[cq * COUTW + c];
             cols[e] = s;
         }
         __syncthreads();
-        bnred_publish(bn, blockIdx.x, COUT, [&](int e) { return cols[e]; }, (int)gridDim.x);
+        // (CQN > 1: the workgroup's row of the partial matrix carries its COUTW columns, zeros elsewhere -- the column sums over
+        //  the rows are the same)
+        bnred_publish(bn, blockIdx.x, COUT, [&](int e) {
+            const int which = e / COUT, c = e % COUT - cq * COUTW;
+            return (c >= 0 && c < COUTW) ? cols[which * COUTW + c] : 0.0f;
+        }, (int)gridDim.x);
     }
     stamp();                                 // (last trace slot: kernel exit)
 }
@@ -1242,7 +1276,7 @@ extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_ca
     win_dispatch(c_in, c_out, [&](auto c) {
         using C = decltype(c);
         const int nt = pcd_div_up(n_cap, C::T);
-        win_plan_kernel<C><<<pcd_div_up(nt, 4), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
+        win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
         win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt);
         return 0;
     }, 0);
@@ -1294,7 +1328,7 @@ extern "C" int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, 
                                                  int nbr_stride, const int32_t *n_rows_dev, const void *plan, void *slab,
                                                  size_t slab_bytes, void *stream) {
     PCD_ENTER();
-    if (n_rows < 0 || !win_supported(c, c)) return PCD_ERR_UNSUPPORTED;
+    if (n_rows < 0 || !win_supported(c, c) || c > 64) return PCD_ERR_UNSUPPORTED;
     if (!slab || slab_bytes < (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float)) return PCD_ERR_WORKSPACE;
     if (n_rows == 0) {
         if (hipMemsetAsync(slab, 0, (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float), (hipStream_t)stream) != hipSuccess)
@@ -1303,7 +1337,9 @@ extern "C" int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, 
     }
     if (!x || !dy || !nbr || !plan || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    return win_dispatch(c, c, [&](auto cfg) {
-        return launch_wgrad_win<decltype(cfg)>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
-    }, (int)PCD_ERR_UNSUPPORTED);
+    switch (c) {
+        case 64: return launch_wgrad_win<Win64>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+        case 32: return launch_wgrad_win<Win32>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+        default: return launch_wgrad_win<Win16>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+    }
 }

@@ -56,13 +56,13 @@ class SparseConvolution(SparseModule):
         self.use_window = False
 
     def window_capable(self):
-        """A window kernel exists for this layer (and the "subm_window" option admits it: bit 0 = 64 channels, bit 1 = 32, bit 2 = 16)."""
+        """A window kernel exists for this layer (and the "subm_window" option admits it: bit 0 = 64 channels, bit 1 = 32, bit 2 = 16, bit 3 = 128)."""
         if not (self.subm and tuple(self.kernel_size) == (3, 3, 3) and tuple(self.dilation) == (1, 1, 1)
                 and self.in_channels == self.out_channels):
             return False
         from .. import _lib as L
         opt = L.get_option("subm_window")
-        bit = {64: 1, 32: 2, 16: 4}.get(self.in_channels, 0)
+        bit = {64: 1, 32: 2, 16: 4, 128: 8}.get(self.in_channels, 0)
         return bool(opt & bit) and ops.subm_window_tile_rows(self.in_channels, self.out_channels) > 0
 
     def set_window(self, on):

@@ -61,12 +61,12 @@ def _close(y, ref, what):
     return rel
 
 
-@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1)])
+@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1), (128, 4)])
 def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
     ops = _ops()
     idx, rank, shape = _level(1, lvl, beams=32 if lvl <= 2 else 64, azim=1250 if lvl <= 2 else 2500)
     n = idx.shape[0]
-    assert n > 5000
+    assert n > (5000 if lvl < 4 else 2000)
     rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False)
     assert rb.order == ops.ROWS_YXZ
     g = torch.Generator().manual_seed(ch)
@@ -90,7 +90,7 @@ def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
     assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(y0.float().abs().max())
 
 
-@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1)])
+@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1), (128, 4)])
 def test_window_batchnorm_sums_match_the_generic_kernels(ch, lvl):
     """PcdBnReduce in the window kernel's epilogue: mode 1 (sum y, sum y^2 of the rounded outputs) and mode 2 (sum dz, sum
     dz * xhat with the ReLU mask) against sums taken from the kernel's own output in float64, and against the generic kernel."""
@@ -133,7 +133,7 @@ def test_window_batchnorm_sums_match_the_generic_kernels(ch, lvl):
         ops.BN_FUSED_MID = old
 
 
-@pytest.mark.parametrize("ch", [64, 32, 16])
+@pytest.mark.parametrize("ch", [64, 32, 16, 128])
 def test_window_multi_pass_tiles_device_row_count_and_tiny_inputs(ch):
     """Rows NOT numbered z-fastest (first-appearance order: every run is far longer than the window) take the multi-pass
     path -- same results as the generic kernel up to rounding ties; a capacity above the real row count with the count in

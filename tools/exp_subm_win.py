@@ -44,7 +44,7 @@ def timeit(fn, iters=30):
 
 
 want = sys.argv[1] if len(sys.argv) > 1 else "23"
-for lvl in (1, 2, 3):
+for lvl in (1, 2, 3, 4):
     if str(lvl) not in want:
         continue
     idx, rank, shape, ch = levels[lvl]
