@@ -74,7 +74,9 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "ggw" 1               LDS-DMA gather-GEMM for C_in = 128 (0 off, 2..4: rows-per-wave forced also for C_in = 64, 6: forward only)
  *   "gg1" 1               16-channel gather-GEMM variant (1: 32 rows per wave)
  *   "subm_window" 7       window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows: bit 0 = 64 channels, bit 1 = 32,
- *                         bit 2 = 16 (0: generic kernels) -- read by the host-side layer, the C entry points take any width
+ *                         bit 2 = 16, bit 3 = 128 (off: its dense 27-offset MFMA work makes it slower than the step-skipping
+ *                         generic kernel there, 61.6 vs 49.0 us) (0: generic kernels) -- read by the host-side layer, the C
+ *                         entry points take any of these widths
  *   "subm_window_wgrad" 6 the same bits for the window weight gradient (pcd_sparse_conv_subm_window_wgrad); 64 channels off:
  *                         its 80 partial slabs (35 MB per layer) cost the training step more than the kernel saves
  *   "wg128" 1             equal-pair weight-gradient kernel at 128 x 128 channels
@@ -850,7 +852,7 @@ int pcd_debug_stamp(uint64_t *slot, void *stream);
 
 /* ============================================================================================
  * (a8) SubMConv3d arithmetic over z-fastest rows: the WINDOW gather-GEMM (spconv_win.hip) -- forward and data gradient of
- *      spconv.SubMConv3d (spconv_backbone.py:12,38-45) for 3x3x3 kernels with c_in == c_out in {16, 32, 64}, bf16 features.
+ *      spconv.SubMConv3d (spconv_backbone.py:12,38-45) for 3x3x3 kernels with c_in == c_out in {16, 32, 64, 128}, bf16 features.
  * Same operation as pcd_sparse_conv_gather_gemm on a SubM neighbour table: y[o] = bias + sum_k W_k x[nbr[k][o]] (+ addend)
  * with weights packed in mode 0; with weights packed in mode 1 the data gradient dx[i] = sum_k W_k^T dy[nbr[26 - k][i]]
  * (+ addend) -- the k flip of the rulebook view is folded into that pack, the launch has no flip argument.  Results agree

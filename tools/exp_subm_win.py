@@ -60,12 +60,12 @@ for lvl in (1, 2, 3, 4):
     pairs = int((rb.nbr_out >= 0).sum().item())
     T = ops.subm_window_tile_rows(ch, ch)
     nt = (n + T - 1) // T
-    off = 256 * 64 + (nt * 4 + 31) // 32 * 32                     # (spconv_win.hip: win_hdr_off)
+    off = 256 * 64 + 1024 + (nt * 4 + 31) // 32 * 32              # (spconv_win.hip: win_hdr_off)
     pl = ops.subm_window_plan(rb, ch, ch)
     hdr = pl[off:off + nt * 32].view(torch.int32).view(nt, 8).cpu().numpy()
     ent = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()
-    share = ent[:, 1] - ent[:, 0]
-    print(f"level {lvl}: shares of the 256 workgroups: tiles min {share.min()} median {int(np.median(share))} max {share.max()}")
+    share = (ent[:, 1] - ent[:, 0])[:256 // (4 if ch == 128 else 1)]
+    print(f"level {lvl}: shares of the workgroups: tiles min {share.min()} median {int(np.median(share))} max {share.max()}")
     runs = hdr[:, [1, 3, 5]]
     print(f"level {lvl}: {nt} tiles of {T} rows; passes histogram {np.bincount(hdr[:, 6]).tolist()}; run length median "
           f"{int(np.median(runs))} p90 {int(np.percentile(runs, 90))} p99 {int(np.percentile(runs, 99))} max {int(runs.max())}; "
