@@ -884,6 +884,8 @@ def main():
             last["bd2"] = bd2
         return bd2
 
+    VOX_EARLY = os.environ.get('PCD_VOX_EARLY', '1') != '0'      # one-graph form: see build_graphs
+
     def train_from_voxels(bd2, ev=None):
         """MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into the bucket)"""
         bd = model.map_to_bev_module(model.backbone_3d(model.vfe(dict(bd2))))
@@ -1024,15 +1026,41 @@ def main():
                     pull_stream.wait_stream(cur)
                     with torch.cuda.stream(pull_stream):
                         pull.enqueue(s_pts, s_offs8)
-                train_from_voxels(vox_out)
-                vox_stream.wait_stream(cur)
-                if pull is not None:
-                    vox_stream.wait_stream(pull_stream)
-                with torch.cuda.stream(vox_stream):
-                    ops.stamp("vox_begin")
-                    vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
-                    assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                    ops.stamp("vox_end")
+                def voxelize_next():
+                    vox_stream.wait_stream(torch.cuda.current_stream())
+                    if pull is not None:
+                        vox_stream.wait_stream(pull_stream)
+                    with torch.cuda.stream(vox_stream):
+                        ops.stamp("vox_begin")
+                        vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
+                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                        ops.stamp("vox_end")
+
+                if VOX_EARLY:
+                    # The next batch is voxelised in the MIDDLE of this step's forward pass, on the rulebook stream behind its
+                    # last unit (the last reader of the voxeliser's buffers; the stream is idle from there on), instead of after
+                    # the backward pass, where its 245 us were the tail of the step.  (On a stream of its own, forked there, the
+                    # graph executor serialised the conv chain behind the rulebook chain: 3.70 ms against 3.21.)  What the rest of the
+                    # step still needs of this batch is copied first: the row count and the (bf16, 8-channel) features that
+                    # conv_input's weight gradient reads at the very end.
+                    def early():                         # (called on the rulebook stream, behind its last unit)
+                        if pull is not None:
+                            torch.cuda.current_stream().wait_stream(pull_stream)
+                        ops.stamp("vox_begin")
+                        vox_next = voxelize(s_pts, s_offs, out=vox_out)
+                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                        ops.stamp("vox_end")
+                    bd_in = dict(vox_out)
+                    # (copies by KERNELS: a clone is a memcpy node, and a memcpy node at the head of the graph held the whole
+                    #  conv chain back behind the second rulebook unit)
+                    bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
+                    if "voxel_num_rows" in vox_out:
+                        bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
+                    bd_in["after_rulebooks_hook"] = early
+                    train_from_voxels(bd_in)
+                else:
+                    train_from_voxels(vox_out)
+                    voxelize_next()
                 opt_step()
                 ops.stamp("opt_end")
                 cur.wait_stream(vox_stream)
@@ -1161,7 +1189,8 @@ def main():
 
     if os.environ.get('PCD_STAMPS'):
         # time points inside the replayed graph (device clock, 100 MHz), averaged over the timed steps
-        ops.STAMPS = {"buf": torch.zeros((128,), dtype=torch.int64, device=dev), "names": []}
+        ops.STAMPS = {"buf": torch.zeros((128,), dtype=torch.int64, device=dev), "names": [],
+                      "sparse": os.environ.get('PCD_STAMPS') == 'sparse'}     # (per-layer dgrad / wgrad time points)
         if use_graph:
             run_step = build_graphs()
             state["prime"](resident)

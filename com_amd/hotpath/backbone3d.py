@@ -72,6 +72,7 @@ class SparseBasicBlock(spconv.SparseModule):
 class _RulebookPrefetcher:
     def __init__(self, units, x0, side):
         self.units, self.t, self.side, self.next = units, x0, side, 0
+        self.after_units = x0.indice_dict.pop("__after_units__", None)
 
     def advance(self, inline=False):
         """inline: build the unit on the CURRENT stream (no event: its consumers are ordered behind it anyway)."""
@@ -86,6 +87,7 @@ class _RulebookPrefetcher:
                 rb, out_idx, out_shape = conv._rulebook(t)
                 if getattr(rb, "ready_event", None) is None:
                     built.append(rb)
+                    self._window_plan(conv, rb)
                 if not conv.subm:
                     t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
                                          num_rows=rb.n_out_dev)
@@ -98,6 +100,24 @@ class _RulebookPrefetcher:
             from .. import ops
             if ops.STAMPS is not None:
                 ops.stamp(f"rb_unit{self.next - 1}")
+            if self.next >= len(self.units) and self.after_units is not None:
+                # the last unit is on the stream: nothing issued later reads the voxeliser's outputs (level-1 coordinates, rank
+                # map) -- a caller that recycles those buffers continues HERE, on this stream, idle for the rest of the forward
+                hook, self.after_units = self.after_units, None
+                hook()
+
+
+    @staticmethod
+    def _window_plan(conv, rb):
+        """The window kernel's tile plan of a freshly built SubM rulebook (ops.subm_window_plan caches it on the rulebook),
+        here on the rulebook stream: built by the first conv that uses it, it sat on the main chain (~30 us per level)."""
+        from .. import ops, _lib as L
+        if not (conv.subm and tuple(conv.kernel_size) == (3, 3, 3) and getattr(rb, "order", None) == ops.ROWS_YXZ):
+            return
+        c = conv.out_channels
+        bit = {64: 1, 32: 2, 16: 4, 128: 8}.get(c, 0)
+        if bit and (L.get_option("subm_window") & bit) and ops.subm_window_tile_rows(c, c) > 0:
+            ops.subm_window_plan(rb, c, c)
 
 
 class _BackboneBase(nn.Module):
@@ -220,6 +240,8 @@ class _BackboneBase(nn.Module):
         ops.stamp("fwd_begin")
         if ops.STAMPS is not None:
             ops.STAMPS["conv_seq"] = 0
+        if batch_dict.get('after_rulebooks_hook', None) is not None:
+            x0.indice_dict["__after_units__"] = batch_dict['after_rulebooks_hook']
         self._prefetch_rulebooks(x0)
         x = self.conv_input(x0)
         ops.stamp("conv_input")

@@ -167,6 +167,10 @@ class SparseConvolution(SparseModule):
                 # without indice_pairs (derived on demand if some other consumer asks for them)
                 lazy = ops.WGRAD_OS and self.out_channels == 16 and self.in_channels <= 16 \
                     and tuple(self.kernel_size) == (3, 3, 3)
+                # ... and so are the layers whose weight gradient runs over the window kernel's tiles
+                if not lazy and self.window_capable() and x.indice_dict.get("__row_order__", ops.ROWS_ZYX) == ops.ROWS_YXZ:
+                    from .functional import _window_wgrad
+                    lazy = _window_wgrad(self.in_channels)
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
                                        self.dilation, n_dev=x.num_rows, rank=rank,
                                        want_pairs=self._needs_backward(x) and not lazy)   # (inference never needs them)

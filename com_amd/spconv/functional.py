@@ -31,6 +31,7 @@ _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not 
 
 _COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
 _WGRAD_JOBS = []    # [(slab, dW, kvol, cin, cout, pmax)] of deferred slab reductions: one launch at the join
+_SP_SEQ = [0]       # diagnostics (ops.STAMPS["sparse"]): running index of the sparse conv layers in backward order
 _STAMP_SEQ = [0]    # diagnostics (ops.STAMPS): running index of the dense weight-gradient launches of a step
 _DIRECT_WRITTEN = set()   # ids of the parameters whose .grad a kernel has OVERWRITTEN since the last join (DIRECT_GRAD)
 
@@ -61,6 +62,7 @@ def join_deferred_wgrad():
     deferred bias gradients with one launch on that stream).  Ends the step for the DIRECT_GRAD bookkeeping."""
     _DIRECT_WRITTEN.clear()
     _STAMP_SEQ[0] = 0
+    _SP_SEQ[0] = 0
     if _COLSUM_JOBS or _WGRAD_JOBS:
         side = _side_stream((_COLSUM_JOBS or _WGRAD_JOBS)[0][0].device)
         with torch.cuda.stream(side):
@@ -247,7 +249,12 @@ class SparseConvFunction(Function):
         keep_partial = None
         deferred = (WGRAD_JOIN_LAG > 0 and side is not None and (direct_w or not ctx.needs_input_grad[1])
                     and (direct_b or not (ctx.has_bias and ctx.needs_input_grad[2])))
+        if ops.STAMPS is not None and ops.STAMPS.get("sparse"):
+            _SP_SEQ[0] += 1
+            ops.stamp(f"dg{_SP_SEQ[0]}e")                 # main stream: the data gradient of layer (backward order) is behind us
         with torch.cuda.stream(side) if side is not None else _NullCtx():
+            if ops.STAMPS is not None and ops.STAMPS.get("sparse"):
+                ops.stamp(f"wg{_SP_SEQ[0]}s")             # side stream: its weight gradient starts
             if ctx.needs_input_grad[1]:
                 if ctx.window and rb.subm and ctx.cin == ctx.cout == x.shape[1] and _window_wgrad(ctx.cin):
                     dwk = ops.subm_window_wgrad(x, dy16, rb, out=weight_p.grad if direct_w else None,
