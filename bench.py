@@ -1018,54 +1018,67 @@ def main():
             for st_ in state["shift_streams"]:
                 with torch.cuda.stream(st_):
                     torch.zeros(1, device=dev)
-            g_all = torch.cuda.CUDAGraph()
-            pull_stream = torch.cuda.Stream() if pull is not None else None
-            with torch.cuda.graph(g_all):
-                cur = torch.cuda.current_stream()
-                if pull is not None:                         # a branch of its own from the first node of the step
-                    pull_stream.wait_stream(cur)
-                    with torch.cuda.stream(pull_stream):
-                        pull.enqueue(s_pts, s_offs8)
-                def voxelize_next():
-                    vox_stream.wait_stream(torch.cuda.current_stream())
-                    if pull is not None:
-                        vox_stream.wait_stream(pull_stream)
-                    with torch.cuda.stream(vox_stream):
-                        ops.stamp("vox_begin")
-                        vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
-                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                        ops.stamp("vox_end")
-
-                if VOX_EARLY:
-                    # The next batch is voxelised in the MIDDLE of this step's forward pass, on the rulebook stream behind its
-                    # last unit (the last reader of the voxeliser's buffers; the stream is idle from there on), instead of after
-                    # the backward pass, where its 245 us were the tail of the step.  (On a stream of its own, forked there, the
-                    # graph executor serialised the conv chain behind the rulebook chain: 3.70 ms against 3.21.)  What the rest of the
-                    # step still needs of this batch is copied first: the row count and the (bf16, 8-channel) features that
-                    # conv_input's weight gradient reads at the very end.
-                    def early():                         # (called on the rulebook stream, behind its last unit)
+            def capture_step():
+                g_all = torch.cuda.CUDAGraph()
+                pull_stream = torch.cuda.Stream() if pull is not None else None
+                with torch.cuda.graph(g_all):
+                    cur = torch.cuda.current_stream()
+                    if pull is not None:                         # a branch of its own from the first node of the step
+                        pull_stream.wait_stream(cur)
+                        with torch.cuda.stream(pull_stream):
+                            pull.enqueue(s_pts, s_offs8)
+                    def voxelize_next():
+                        vox_stream.wait_stream(torch.cuda.current_stream())
                         if pull is not None:
-                            torch.cuda.current_stream().wait_stream(pull_stream)
-                        ops.stamp("vox_begin")
-                        vox_next = voxelize(s_pts, s_offs, out=vox_out)
-                        assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                        ops.stamp("vox_end")
-                    bd_in = dict(vox_out)
-                    # (copies by KERNELS: a clone is a memcpy node, and a memcpy node at the head of the graph held the whole
-                    #  conv chain back behind the second rulebook unit)
-                    bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
-                    if "voxel_num_rows" in vox_out:
-                        bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
-                    bd_in["after_rulebooks_hook"] = early
-                    train_from_voxels(bd_in)
-                else:
-                    train_from_voxels(vox_out)
-                    voxelize_next()
-                opt_step()
-                ops.stamp("opt_end")
-                cur.wait_stream(vox_stream)
-                plan.arm()                                   # sticky overflow check of every replay, inside the graph
-                ops.stamp("step_end")
+                            vox_stream.wait_stream(pull_stream)
+                        with torch.cuda.stream(vox_stream):
+                            ops.stamp("vox_begin")
+                            vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
+                            assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                            ops.stamp("vox_end")
+
+                    if VOX_EARLY:
+                        # The next batch is voxelised in the MIDDLE of this step's forward pass, on the rulebook stream behind its
+                        # last unit (the last reader of the voxeliser's buffers; the stream is idle from there on), instead of after
+                        # the backward pass, where its 245 us were the tail of the step.  (On a stream of its own, forked there, the
+                        # graph executor serialised the conv chain behind the rulebook chain: 3.70 ms against 3.21.)  What the rest of the
+                        # step still needs of this batch is copied first: the row count and the (bf16, 8-channel) features that
+                        # conv_input's weight gradient reads at the very end.
+                        def early():                         # (called on the rulebook stream, behind its last unit)
+                            if pull is not None:
+                                torch.cuda.current_stream().wait_stream(pull_stream)
+                            ops.stamp("vox_begin")
+                            vox_next = voxelize(s_pts, s_offs, out=vox_out)
+                            assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                            ops.stamp("vox_end")
+                        bd_in = dict(vox_out)
+                        # (copies by KERNELS: a clone is a memcpy node, and a memcpy node at the head of the graph held the whole
+                        #  conv chain back behind the second rulebook unit)
+                        bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
+                        if "voxel_num_rows" in vox_out:
+                            bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
+                        bd_in["after_rulebooks_hook"] = early
+                        train_from_voxels(bd_in)
+                    else:
+                        train_from_voxels(vox_out)
+                        voxelize_next()
+                    opt_step()
+                    ops.stamp("opt_end")
+                    cur.wait_stream(vox_stream)
+                    plan.arm()                                   # sticky overflow check of every replay, inside the graph
+                    ops.stamp("step_end")
+                return g_all
+
+            # (PCD_GRAPH_TWIN=1, experiment: two instantiations of the same step, replayed alternately -- does the host enqueue
+            #  one while the other runs?)
+            graphs = [capture_step() for _ in range(2 if os.environ.get('PCD_GRAPH_TWIN') == '1' else 1)]
+            g_turn = [0]
+
+            class _Alt:
+                def replay(self_):
+                    graphs[g_turn[0] % len(graphs)].replay()
+                    g_turn[0] += 1
+            g_all = _Alt()
 
             HT = state.setdefault("host_times", [0.0] * 5) if os.environ.get('PCD_BENCH_DEBUG') else None
 

@@ -151,7 +151,8 @@ class _BackboneBase(nn.Module):
 
     prefetch_rulebooks = True
     first_unit_inline = __import__("os").environ.get("PCD_RB_INLINE0", "0") == "1"   # measured: see _prefetch_rulebooks
-    prefetch_depth = 2          # rulebook units issued before the first conv; each unit's first consumer issues one more
+    # rulebook units issued before the first conv; each unit's first consumer issues one more
+    prefetch_depth = int(__import__("os").environ.get("PCD_RB_DEPTH", "2"))
 
     def _prefetch_rulebooks(self, x0):
         """All 9 rulebooks depend only on the voxel coordinates, not on features: they are built on a second HIP

@@ -31,6 +31,8 @@ _PENDING = []   # [(event, tensors kept alive)] of weight-gradient launches not 
 
 _COLSUM_JOBS = []   # [(partial, rows, bias.grad)] of deferred bias gradients: one launch at the join
 _WGRAD_JOBS = []    # [(slab, dW, kvol, cin, cout, pmax)] of deferred slab reductions: one launch at the join
+WGRAD_FLUSH_BYTES = 32 << 20     # deferred slab reductions are flushed whenever this many slab bytes have piled up (0: once, at the join)
+_WGRAD_KEEP = []
 _SP_SEQ = [0]       # diagnostics (ops.STAMPS["sparse"]): running index of the sparse conv layers in backward order
 _STAMP_SEQ = [0]    # diagnostics (ops.STAMPS): running index of the dense weight-gradient launches of a step
 _DIRECT_WRITTEN = set()   # ids of the parameters whose .grad a kernel has OVERWRITTEN since the last join (DIRECT_GRAD)
@@ -41,6 +43,7 @@ def reset_deferred():
     hold raw pointers into tensors of the aborted step).  join_deferred_wgrad() is the normal end of a step."""
     _COLSUM_JOBS.clear()
     _WGRAD_JOBS.clear()
+    _WGRAD_KEEP.clear()
     _PENDING.clear()
     _DIRECT_WRITTEN.clear()
 
@@ -76,8 +79,10 @@ def join_deferred_wgrad():
         torch.cuda.current_stream().wait_event(ev)
         _COLSUM_JOBS.clear()
         _WGRAD_JOBS.clear()
+        _WGRAD_KEEP.clear()
         _PENDING.clear()
         return
+    _WGRAD_KEEP.clear()
     if _PENDING:
         torch.cuda.current_stream().wait_event(_PENDING[-1][0])
         _PENDING.clear()
@@ -280,6 +285,12 @@ class SparseConvFunction(Function):
                     ctx.colsum_link.result = None
                 if direct_b:
                     db = None
+            if deferred and WGRAD_FLUSH_BYTES > 0 and sum(j[0].numel() for j in _WGRAD_JOBS) >= WGRAD_FLUSH_BYTES:
+                # the slabs collected so far are summed NOW, on this (side) stream, in the middle of the backward pass: one
+                # reduction of every layer at the very end read ~170 MB of 128-channel tiles on the step's critical tail
+                ops.wgrad_reduce_batched(_WGRAD_JOBS)
+                _WGRAD_KEEP.extend(_WGRAD_JOBS)          # (buffers stay referenced until the step's join)
+                del _WGRAD_JOBS[:]
             if deferred:
                 ev = torch.cuda.Event()
                 ev.record(side)
