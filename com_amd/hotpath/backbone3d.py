@@ -70,17 +70,21 @@ class SparseBasicBlock(spconv.SparseModule):
 
 
 class _RulebookPrefetcher:
+    event_per_rulebook = __import__("os").environ.get("PCD_RB_EVENT_EACH", "0") == "1"   # (measured: no difference)
+
     def __init__(self, units, x0, side):
         self.units, self.t, self.side, self.next = units, x0, side, 0
         self.after_units = x0.indice_dict.pop("__after_units__", None)
 
-    def advance(self, inline=False):
-        """inline: build the unit on the CURRENT stream (no event: its consumers are ordered behind it anyway)."""
+    def advance(self, inline=False, stream=None):
+        """inline: build the unit on the CURRENT stream (no event: its consumers are ordered behind it anyway);
+        stream: build it on that stream instead of the prefetcher's own."""
         if self.next >= len(self.units):
             return
         unit = self.units[self.next]
         self.next += 1
-        with torch.cuda.stream(torch.cuda.current_stream() if inline else self.side):
+        side = stream if stream is not None else self.side
+        with torch.cuda.stream(torch.cuda.current_stream() if inline else side):
             t = self.t
             built = []
             for conv in unit:
@@ -88,13 +92,18 @@ class _RulebookPrefetcher:
                 if getattr(rb, "ready_event", None) is None:
                     built.append(rb)
                     self._window_plan(conv, rb)
+                    if not inline and self.event_per_rulebook:
+                        # the strided conv that opens a level waits for ITS rulebook only, not for the SubM rulebook (+ window
+                        # plan) of the level behind it in the same unit
+                        rb.ready_event = torch.cuda.Event()
+                        rb.ready_event.record(side)
                 if not conv.subm:
                     t = SparseConvTensor(t.features, out_idx, out_shape, t.batch_size, indice_dict=t.indice_dict,
                                          num_rows=rb.n_out_dev)
             self.t = t
-            if built and not inline:
+            if built and not inline and not self.event_per_rulebook:
                 ev = torch.cuda.Event()
-                ev.record(self.side)
+                ev.record(side)
                 for rb in built:
                     rb.ready_event = ev
             from .. import ops
@@ -151,6 +160,7 @@ class _BackboneBase(nn.Module):
 
     prefetch_rulebooks = True
     first_unit_inline = __import__("os").environ.get("PCD_RB_INLINE0", "0") == "1"   # measured: see _prefetch_rulebooks
+    unit0_own_stream = __import__("os").environ.get("PCD_RB_UNIT0_STREAM", "1") == "1"
     # rulebook units issued before the first conv; each unit's first consumer issues one more
     prefetch_depth = int(__import__("os").environ.get("PCD_RB_DEPTH", "2"))
 
@@ -184,6 +194,16 @@ class _BackboneBase(nn.Module):
             # the rulebook units, now beside the gather kernels from the start, finish 90-200 us later and the step is the
             # same: 3.44 vs 3.42 ms without stamps (tools/exp_rb_inline.sh)
             pf.advance(inline=True)
+            depth -= 1
+        if self.unit0_own_stream and not self.first_unit_inline:
+            # The level-1 SubM rulebook (unit 0: all the first conv waits for) on a short branch of its own; the other units do
+            # not read it (unit 1 = the strided build over the level-1 coordinates), so they fork from the main stream too.  As
+            # children of unit 0's last node they held the first conv back: the graph executor ran it behind the whole of unit 1
+            # (first conv at 0.27 ms with its rulebook ready at 0.06).
+            u0 = Fsp._side_stream(dev, "rulebook0")
+            u0.wait_stream(cur)
+            pf.advance(stream=u0)
+            pf.unit0_stream = u0
             depth -= 1
         for _ in range(depth):
             pf.advance()
@@ -256,8 +276,11 @@ class _BackboneBase(nn.Module):
         ops.stamp("conv4")
         out = self.conv_out(x_conv4)
         ops.stamp("conv_out")
-        if "__prefetcher__" in x0.indice_dict:                 # every unit was consumed; join the stream anyway
-            torch.cuda.current_stream().wait_stream(x0.indice_dict.pop("__prefetcher__").side)
+        if "__prefetcher__" in x0.indice_dict:                 # every unit was consumed; join the stream(s) anyway
+            pf = x0.indice_dict.pop("__prefetcher__")
+            torch.cuda.current_stream().wait_stream(pf.side)
+            if getattr(pf, "unit0_stream", None) is not None:
+                torch.cuda.current_stream().wait_stream(pf.unit0_stream)
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {
             'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3, 'x_conv4': x_conv4}})
