@@ -1021,7 +1021,10 @@ def main():
             def capture_step():
                 g_all = torch.cuda.CUDAGraph()
                 pull_stream = torch.cuda.Stream() if pull is not None else None
-                with torch.cuda.graph(g_all):
+                # (PCD_GRAPH_PRIO=1, experiment: capture on a high-priority stream -- do the main chain's persistent kernels get
+                #  the CUs ahead of the side streams' workgroups?)
+                cap_stream = torch.cuda.Stream(priority=-1) if os.environ.get('PCD_GRAPH_PRIO') == '1' else None
+                with torch.cuda.graph(g_all, **({"stream": cap_stream} if cap_stream is not None else {})):
                     cur = torch.cuda.current_stream()
                     if pull is not None:                         # a branch of its own from the first node of the step
                         pull_stream.wait_stream(cur)
