@@ -1207,6 +1207,8 @@ def main():
         # time points inside the replayed graph (device clock, 100 MHz), averaged over the timed steps
         ops.STAMPS = {"buf": torch.zeros((128,), dtype=torch.int64, device=dev), "names": [],
                       "sparse": os.environ.get('PCD_STAMPS') == 'sparse'}     # (per-layer dgrad / wgrad time points)
+        if os.environ.get('PCD_STAMPS') == 'few':
+            ops.STAMPS["only"] = {"fwd_begin", "conv1", "conv2", "conv3", "conv4", "loss_end", "bwd_end", "step_end"}
         if use_graph:
             run_step = build_graphs()
             state["prime"](resident)

@@ -114,6 +114,9 @@ struct WinCfg {
         return r * 32 + (((ei >> 3) ^ ((r >> 2) & 3)) << 3) + (ei & 7);
     }
     static constexpr bool DIRECT = NOQ == 1 && NCB == 1; // a wave owns whole rows: no cross-wave sums, the epilogue runs from registers
+    // what a further pass over a tile costs, in quarters of a tile's time (measured per workgroup, tools/exp_subm_win.py
+    // WIN_BALANCE: 2.84 / 1.32 / 0.94 tiles at 16 / 32 / 64 channels)
+    static constexpr int PASS_COST = CIN <= 16 ? 11 : CIN <= 32 ? 5 : 4;
     static constexpr int SPR = (R / RPI + 7) / 8;        // window DMA instructions per run and wave
     static constexpr int NSLOT = 3 * SPR + TSL;          // prefetch instructions per wave and tile
     static constexpr int REDSTRIDE = COUTW * 4 + 16;     // bytes per (slice, row) of partial sums: +16 keeps b128 stores conflict-free
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
 // ---- shares: the tiles dealt to the WIN_GRID persistent workgroups in contiguous runs of EQUAL COST ------------------------
 // A multi-pass tile (a run longer than the window: frame borders, walls) costs its workgroup about 2.5 ordinary tiles; with equal
 // tile COUNTS the launch lasted as long as the few workgroups that own two of them (measured: 54 k clk against 31 k for the
-// typical workgroup at 16 channels).  cost = 2 + 5 (passes - 1); share w = tiles whose inclusive cost prefix lies in
+// typical workgroup at 16 channels).  cost = 4 + PASS_COST (passes - 1), fitted per width; share w = tiles whose inclusive cost prefix lies in
 // (total w / G, total (w + 1) / G].  Static (a function of the rulebook only): the BatchNorm partial rows stay reproducible.
 // One workgroup.
 template <class C>
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
     const int per = (nt + 1023) / 1024;
     const int t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
     int sum = 0;
-    for (int t = t0; t < t1; ++t) sum += 2 + 5 * (hdr[(size_t)t * 2 + 1].z - 1);
+    for (int t = t0; t < t1; ++t) sum += 4 + C::PASS_COST * (hdr[(size_t)t * 2 + 1].z - 1);
     scan[tid] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
     }
     int run = scan[tid] - sum;
     for (int t = t0; t < t1; ++t) {
-        run += 2 + 5 * (hdr[(size_t)t * 2 + 1].z - 1);
+        run += 4 + C::PASS_COST * (hdr[(size_t)t * 2 + 1].z - 1);
         prefix[t] = run;
     }
     const long long total = scan[1023];
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     constexpr int T = C::T, R = C::R, ROWB = C::ROWB, COUT = C::COUT, COUTW = C::COUTW, OPW = C::OPW, KS = C::KS, RBW = C::RBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stamp();                                 // (trace slot 0: kernel entry)
+    if (trace && threadIdx.x == 0) trace[256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // (per-workgroup entry time, 100 MHz)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave8 % C::NCB, rg = (wave8 / C::NCB) % C::NRG, oq = wave8 / (C::NCB * C::NRG);
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         }, (int)gridDim.x);
     }
     stamp();                                 // (last trace slot: kernel exit)
+    if (trace && threadIdx.x == 0) trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 

@@ -70,6 +70,9 @@ def stamp(name):
     hipGraph capture -- every replay refreshes the slot."""
     if STAMPS is None:
         return
+    only = STAMPS.get("only")
+    if only is not None and name not in only:      # (every stamp is a kernel node of the graph: few of them perturb less)
+        return
     names = STAMPS["names"]
     if name not in names:
         names.append(name)

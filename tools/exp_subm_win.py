@@ -169,3 +169,85 @@ if os.environ.get("WIN_WGRAD"):
                 print("      " + " ".join(f"{int(v):6d}" for v in d))
         print(f"level {lvl} wgrad {ch}x{ch}: max|diff| {(d0 - d1).abs().max().item():.4g} (scale {d0.abs().max().item():.3g}); "
               f"generic {t_gen:.1f} us (+ reduce {t_red0:.1f}), window {t_win:.1f} us (+ reduce {t_red1:.1f})", flush=True)
+
+if os.environ.get("WIN_CONTEND"):
+    # how a window launch starts while another stream keeps the chip busy: per-workgroup entry / exit times
+    from com_amd import _lib as L
+    lvl = int(os.environ["WIN_CONTEND"])
+    idx, rank, shape, ch = levels[lvl]
+    n = idx.shape[0]
+    rb = ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=False)
+    w = (torch.randn(ch, 3, 3, 3, ch) * 0.02).to(dev)
+    x = torch.randn(n, ch).to(dev).to(torch.bfloat16)
+    wf = ops.pack_weight_window(w, 0)
+    # the competitor: the pair-based weight gradient of the 128-channel level (what runs beside the level-1 dgrads in the step)
+    i4, r4, s4, c4 = levels[4]
+    rb4 = ops.rulebook_subm(i4, B, s4, rank=r4, want_pairs=True)
+    x4 = torch.randn(i4.shape[0], c4).to(dev).to(torch.bfloat16)
+    d4 = torch.randn(i4.shape[0], c4).to(dev).to(torch.bfloat16)
+    side = torch.cuda.Stream()
+    tr = torch.zeros(1024, dtype=torch.int64, device=dev)
+    for contend in (False, True):
+        for _ in range(3):
+            ops.subm_window(x, wf, None, rb, ch)
+        torch.cuda.synchronize()
+        L.lib().pcd_subm_window_set_trace(L.ptr(tr))
+        if contend:
+            with torch.cuda.stream(side):
+                jobs = []
+                for _ in range(4):
+                    ops.wgrad(x4, c4, d4, None, None, 27, rb=rb4, defer=jobs)
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        ops.subm_window(x, wf, None, rb, ch)
+        t1.record()
+        torch.cuda.synchronize()
+        L.lib().pcd_subm_window_set_trace(None)
+        tt = tr.cpu().numpy()
+        ent, ext = tt[256:512], tt[512:768]
+        live = ext > 0
+        tz = ent[live].min()
+        st = (ent[live] - tz) * 10e-3
+        dur = (ext - ent)[live] * 10e-3
+        print(f"level {lvl} window launch {'beside 4 wgrad128 launches' if contend else 'alone'}: {t0.elapsed_time(t1) * 1e3:.1f} us; "
+              f"workgroup start after the first: median {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f} us; "
+              f"duration median {np.median(dur):.1f} max {dur.max():.1f}; last exit {((ext[live] - tz) * 10e-3).max():.1f} us")
+        tr.zero_()
+
+if os.environ.get("WIN_BALANCE"):
+    # per-workgroup duration against its share: least squares  dur = a + b tiles + c extra passes
+    from com_amd import _lib as L
+    for lvl in (1, 2, 3):
+        idx, rank, shape, ch = levels[lvl]
+        n = idx.shape[0]
+        rb = ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=False)
+        w = (torch.randn(ch, 3, 3, 3, ch) * 0.02).to(dev)
+        x = torch.randn(n, ch).to(dev).to(torch.bfloat16)
+        wf = ops.pack_weight_window(w, 0)
+        T = ops.subm_window_tile_rows(ch, ch)
+        nt = (n + T - 1) // T
+        pl = ops.subm_window_plan(rb, ch, ch)
+        off = 256 * 64 + 1024 + (nt * 4 + 31) // 32 * 32
+        hdr = pl[off:off + nt * 32].view(torch.int32).view(nt, 8).cpu().numpy()
+        ent_tab = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()
+        tr = torch.zeros(1024, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            ops.subm_window(x, wf, None, rb, ch)
+        torch.cuda.synchronize()
+        L.lib().pcd_subm_window_set_trace(L.ptr(tr))
+        ops.subm_window(x, wf, None, rb, ch)
+        torch.cuda.synchronize()
+        L.lib().pcd_subm_window_set_trace(None)
+        tt = tr.cpu().numpy()
+        dur = (tt[512:768] - tt[256:512]) * 10e-3
+        # workgroup b -> XCD-major index
+        rowsA = []
+        for b in range(256):
+            wxm = (b & 7) * 32 + (b >> 3)
+            tb, te = ent_tab[wxm, 0], ent_tab[wxm, 1]
+            extra = int((hdr[tb:te, 6] - 1).sum())
+            rowsA.append((1.0, te - tb, extra, dur[b]))
+        A = np.array(rowsA)
+        coef, *_ = np.linalg.lstsq(A[:, :3], A[:, 3], rcond=None)
+        print(f"level {lvl}: dur = {coef[0]:.2f} + {coef[1]:.2f} tiles + {coef[2]:.2f} extra passes (us); extra pass = {coef[2] / coef[1]:.2f} tiles; "
+              f"dur median {np.median(dur):.1f} max {dur.max():.1f}; tiles {A[:, 1].min():.0f}-{A[:, 1].max():.0f}, extra 0-{A[:, 2].max():.0f}")
