@@ -9,7 +9,8 @@
 // each, 94-99 % of the tiles within 2 T (profiles/r04_win_stats.txt; in (b, z, y, x) order 76-86 % of the tiles overflow).  So:
 //   * the three runs are DMA'd into LDS once per tile as contiguous 1-KiB instructions (3.3 x T rows instead of 27 x T
 //     gathered rows), XOR-swizzled on the source side like ggw_kernel's gather image; tile t + 1 is fetched during tile t;
-//   * the rulebook tile nbr[27][T] becomes a table of LDS row indices (0 = a row of zeros for missing neighbours);
+//   * the rulebook tile nbr[27][T] becomes a table of LDS operand slots (64 B per row, built once per rulebook; 0 = a row of
+//     zeros for missing neighbours): two VALU instructions from a table entry to an operand address;
 //   * the packed weights never move: every wave keeps ITS slice of them in registers for the whole launch (a persistent
 //     workgroup per CU, 8 waves x ~110 VGPRs = the 221 KB of a 64 -> 64 layer's 27 offsets).  The slices partition the
 //     (offset, output-channel block) space, so the waves that share an output block hold partial sums; these meet in LDS once
@@ -20,6 +21,9 @@
 // Runs longer than the window (rare; any row order at all is still correct, only slow) are processed in several passes over
 // chunks of the run: a neighbour lies in exactly one chunk, the other passes read the zero row for it.
 // Results equal gather_gemm_kernel's up to the fp32 summation order (offsets are summed per wave slice, then across slices).
+// The data gradient runs through the same launch with the mode-1 weight pack (transposed, offsets reversed: the k flip of the
+// rulebook view lives in the pack).  The WEIGHT gradient of these layers runs over the same tiles: subm_wgrad_win_kernel below.
+// Widths: 16 / 32 / 64 (and 128, slower than ggw_kernel: off) -- WinCfg instances; tile shares of equal cost: win_split_kernel.
 #include <type_traits>
 
 #include "common.h"
@@ -38,9 +42,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // in front of the next ds_read of the same wave -- here that is the first operand read of the MFMA loop, i.e. every wave would
 // wait for the prefetch of the NEXT tile before computing the current one (seen in the ISA: the prefetch overlapped nothing).
 // The waits are placed by hand (vmcnt(0) + barrier before a window is read).
-#ifndef WIN_VARIANT
-#define WIN_VARIANT 0
-#endif
 // (the destination is an LDS byte ADDRESS, wave-uniform: a generic pointer would be null-checked on its way to address space 3)
 __device__ __forceinline__ void win_glds16(u32x4 rsrc, unsigned lds_addr_wave_uniform, unsigned voffset) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr_wave_uniform)), "v"(voffset), "s"(rsrc)
