@@ -63,7 +63,8 @@ __device__ __forceinline__ u32x4 win_rsrc(const void *base, unsigned bytes) {
 
 constexpr int WIN_THREADS = 512;
 constexpr int WIN_GRID = 256;            // one persistent workgroup per CU; also the number of BatchNorm partial rows
-constexpr int WIN_SCRATCH = 8192;        // head of the dynamic LDS: bnred_publish's scratch
+constexpr int WIN_SCRATCH = 0;           // (bnred_publish's 8 KiB of scratch at the head of the dynamic LDS are the zero rows and the
+                                         //  first window: dead by then)
 constexpr int WIN_PLAN_CAP = 64;         // tiles whose plans are staged in LDS at a time
 // Plan buffer: [entries: WIN_GRID x 64 B][prefix: ntiles x i32, padded to 32 B][headers: ntiles x 32 B][tables: ntiles x TABB]
 //   entry[w] = {first tile, end tile, 0, 0, header of the first tile (8 ints), 0 ..} of workgroup w (in XCD-major order): one
@@ -153,7 +154,7 @@ struct WinCfg {
 
 using Win64 = WinCfg<64, 2, 1, 4, 64, 128>;      // 64 -> 64: waves = 2 channel blocks x 4 offset slices (7 offsets each)
 using Win32 = WinCfg<32, 1, 4, 2, 128, 320>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
-using Win16 = WinCfg<16, 1, 8, 1, 256, 512>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
+using Win16 = WinCfg<16, 1, 8, 1, 256, 640>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
 using Win128 = WinCfg<128, 1, 1, 8, 32, 64, 4>;  // 128 -> 128: 4 workgroups x 32 output channels; waves = 8 offset slices (4 each)
 
 // c_in -> configuration (square layers): f(Cfg{}) with the matching type, `none` otherwise
