@@ -1390,7 +1390,7 @@ def main():
                    "optimizer": "adam_onecycle (decoupled wd 0.01, betas (OneCycle MOMS, 0.99), clip 10)",
                    "dense_head": bool(args.dense_head), "com_head": bool(args.com),
                    "distinct_batches": n_batches, "recaptures": recaptures[0],
-                   "execution": ("hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)" if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
+                   "execution": (("hipGraph replay (one graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream, then clip+Adam)" if os.environ.get('PCD_VOX_EARLY', '1') != '0' else "hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)") if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
                                 if use_graph else "eager launches"},
     }
     if h2d is not None:
