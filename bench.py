@@ -1433,6 +1433,13 @@ def main():
             what="child run `bench.py --config5`: BASELINE config 5 as a TRAINING step -- SECOND's VoxelBackBone8x on "
                  "300k-point clouds, fp8 (e4m3, v_mfma_f32_16x16x32_fp8_fp8) forward convs with static per-tensor scales, "
                  "batch-statistics BatchNorm, bf16 backward; one hipGraph per step")
+        if isinstance(result["fp8_config5"], dict) and "value" in result["fp8_config5"]:
+            # the SAME workload with bf16 forward convs (window kernels where they apply): what the fp8 forward is worth
+            ref = measure_full_model(args, flags=("--config5",), what="the same child run with bf16 forward convs",
+                                     extra_env={"PCD_CONFIG5_BF16": "1"})
+            if isinstance(ref, dict) and "value" in ref:
+                result["fp8_config5"]["bf16_same_workload"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"]}
+                result["fp8_config5"]["fp8_over_bf16"] = round(result["fp8_config5"]["value"] / ref["value"], 4)
     if rank == 0 and world == 1 and not args.no_n_gt_1 and not args.dense_head and not args.config5 \
             and not os.environ.get("PCD_FORCE_3GRAPH") and not os.environ.get("PCD_RCCL_WORLD1"):
         # what N > 1 GPUs run, measured on this one GPU: the three-graph form (voxelise | forward + backward | all-reduce of
