@@ -115,11 +115,32 @@ __global__ __launch_bounds__(256) void group_points_grad_tiled_kernel(int B, int
     batch_of(idx_cnt, B, m, &start, feat_cnt);
     const float *src = grad_out + (size_t)m * C * nsample;
     for (int e = threadIdx.x; e < C * nsample; e += 256) gp_tile[(e / nsample) * (nsample + 1) + e % nsample] = src[e];
+    __shared__ int first[64];
     if ((int)threadIdx.x < nsample) rows[threadIdx.x] = start + idx[(size_t)m * nsample + threadIdx.x];
+    __syncthreads();
+    // a ball with fewer than nsample neighbours repeats its first index in the remaining slots (ball_query): the gradients of
+    // equal indices are added up in LDS first, one atomic per DISTINCT point and channel leaves the workgroup
+    if ((int)threadIdx.x < nsample) {
+        int f = threadIdx.x;
+        for (int s2 = 0; s2 < (int)threadIdx.x; ++s2)
+            if (rows[s2] == rows[threadIdx.x]) {
+                f = s2;
+                break;
+            }
+        first[threadIdx.x] = f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float *row = gp_tile + c * (nsample + 1);
+        for (int s = 1; s < nsample; ++s) {
+            const int f = first[s];
+            if (f != s) row[f] += row[s];
+        }
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < C * nsample; e += 256) {
         const int s = e / C, c = e - s * C;
-        atomicAdd(grad_features + (size_t)rows[s] * C + c, gp_tile[c * (nsample + 1) + s]);
+        if (first[s] == s) atomicAdd(grad_features + (size_t)rows[s] * C + c, gp_tile[c * (nsample + 1) + s]);
     }
 }
 
