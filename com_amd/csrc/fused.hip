@@ -16,6 +16,14 @@ namespace {
 
 constexpr int MAX_BLOCKS = 512;       // blocks of the reduction passes (= rows of the partial buffer)
 constexpr int MAX_APPLY_BLOCKS = 2048; // blocks of the streaming apply passes
+// 16-byte pieces every thread of an apply pass requests BEFORE anything else (the grid gives a thread >= BN_PPT = 4 pieces).
+// Measured in the training step, same box, alternating builds: 2 in flight 3.138 ms, all 4 in flight 3.148, twice the
+// workgroups with 2 pieces each 3.22 -- these passes run beside the weight-gradient stream, more of them in flight at once
+// takes from it what it gives them.
+#ifndef BN_PF_VALUE
+#define BN_PF_VALUE 2
+#endif
+constexpr int BN_PF = BN_PF_VALUE;
 
 template <typename T>
 struct Piece;  // 16-byte piece of a row
@@ -350,12 +358,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     const size_t total = (size_t)eff_rows(n_dev, n_cap) * pcs;
     const int piece = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % pcs);  // fixed: strides are multiples of pcs
     float sc[N], sh[N];
-    // The first two pieces of this thread are requested BEFORE the statistics prologue below (16 dependent L2 reads per
+    // The first BN_PF pieces of this thread are requested BEFORE the statistics prologue below (16 dependent L2 reads per
     // column + a barrier: ~2 us in which nothing streamed -- a fifth of the launch at 4 pieces per thread).
     const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
-    typename Piece<T>::Raw px[2], pr[2];
+    typename Piece<T>::Raw px[BN_PF], pr[BN_PF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < BN_PF; ++u) {
         const size_t e = e0 + u * S < total ? e0 + u * S : 0;          // (beyond the end: any valid piece, unused)
         px[u] = Piece<T>::raw(x + e * N);
         if (res) pr[u] = Piece<T>::raw(res + e * N);
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ x, 
     };
     size_t e = e0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u, e += S, ye += ystep)
+    for (int u = 0; u < BN_PF; ++u, e += S, ye += ystep)
         if (e < total) finish(px[u], pr[u], ye);
     for (; e < total; e += S, ye += ystep) {
         const typename Piece<T>::Raw xr = Piece<T>::raw(x + e * N);
@@ -525,13 +533,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     float mu[N], is[N], gm[N], sh[N], k1[N], k2[N], gmv[N], btv[N];
     const float inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
     const bool mask_from_x = relu && y == nullptr;
-    // the first two pieces of this thread are requested BEFORE the reduction prologue below (see bn_apply_kernel)
+    // the first BN_PF pieces of this thread are requested BEFORE the reduction prologue below (see bn_apply_kernel)
     const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, S = (size_t)gridDim.x * blockDim.x;
     size_t de = (e0 / pcs) * (size_t)(dy_ld / N) + piece;              // dy: row stride dy_ld elements
     const size_t dstep = (S / pcs) * (size_t)(dy_ld / N);
-    typename Piece<T>::Raw pg[2], px[2], py[2];
+    typename Piece<T>::Raw pg[BN_PF], px[BN_PF], py[BN_PF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < BN_PF; ++u) {
         const bool in = e0 + u * S < total;
         pg[u] = Piece<T>::raw(dy + (in ? de + u * dstep : 0) * N);
         px[u] = Piece<T>::raw(x + (in ? e0 + u * S : 0) * N);
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     };
     size_t e = e0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u, e += S, de += dstep)
+    for (int u = 0; u < BN_PF; ++u, e += S, de += dstep)
         if (e < total) finish(pg[u], px[u], py[u], e);
     for (; e < total; e += S, de += dstep) {
         const typename Piece<T>::Raw gr = Piece<T>::raw(dy + de * N), xr = Piece<T>::raw(x + e * N);
@@ -651,7 +659,10 @@ __global__ __launch_bounds__(1024) void col_rows_finalize_kernel(ColJobs jobs) {
 static int grid_for(size_t pieces, int pcs, int max_blocks = MAX_BLOCKS) {
     (void)pcs;
     if (max_blocks == MAX_BLOCKS) return MAX_BLOCKS;
-    size_t blocks = (pieces + 1023) / 1024;  // streaming apply passes: >= 4 pieces per thread
+#ifndef BN_PPT
+#define BN_PPT 4
+#endif
+    size_t blocks = (pieces + 256 * BN_PPT - 1) / (256 * BN_PPT);  // streaming apply passes: >= BN_PPT pieces per thread
     if (blocks > (size_t)max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
