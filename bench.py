@@ -631,6 +631,20 @@ def measure_stage2(B, dev):
             S2.sample_keypoints(bd["points"], bd["point_frame_counts"], 4096)
             e1.record()
             torch.cuda.synchronize()
+            # the reference's other sampler (SAMPLE_METHOD 'SPC', PV-RCNN++): points around the proposals, then SectorFPS
+            # (6 azimuth sectors as one stacked FPS) -- per frame, as VoxelSetAbstraction.get_sampled_points loops
+            xyz_all, fr = bd["points"][:, 1:4].contiguous(), bd["points"][:, 0].long()
+            per_frame = [xyz_all[fr == b].contiguous() for b in range(B)]
+
+            def run_spc():
+                return [S2.sectorized_proposal_centric_sampling(bd["rois"][b], per_frame[b], 4096, 1.6, 6) for b in range(B)]
+            run_spc()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            kp_spc = run_spc()
+            torch.cuda.synchronize()
+            ms_spc = 1e3 * (time.perf_counter() - t1)
+            n_spc = [int(k.shape[0]) for k in kp_spc]
         # the same stage in the metric's direction: training-mode modules, forward + backward (gradients into every MLP /
         # BatchNorm parameter and back into the backbone's x_conv3 / x_conv4 features and the BEV map through the grouping
         # kernels' gradient, pcd_group_points_stack_grad; tests/test_gpu_stage2.py checks them against a torch restatement)
@@ -660,6 +674,9 @@ def measure_stage2(B, dev):
         ms_train = 1e3 * (time.perf_counter() - t0) / n
         return {"ms_per_batch": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "frames": B,
                 "fps_4096_keypoints_ms": round(e0.elapsed_time(e1), 3),
+                "spc_sampling": {"ms_per_batch": round(ms_spc, 3), "keypoints_per_frame": n_spc,
+                                 "what": "SAMPLE_METHOD SPC instead of FPS: RoI-centric point filter (radius 1.6 m) + SectorFPS over 6 "
+                                         "sectors, 4096 keypoints asked per frame (not what the timed stage uses)"},
                 "stage2_train": {"ms_per_batch": round(ms_train, 3), "frames_per_s": round(B / ms_train * 1e3, 1),
                                  "what": "the same stage in training mode, forward + backward (eager launches)"},
                 "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points (cooperative kernel: 64 "

@@ -5,6 +5,7 @@ natives of com_amd.pointnet2_stack with the reference's module names and dataflo
                                 HIP; the shared 1x1-conv MLPs + max-pool stay torch, as in the reference)
   * `get_voxel_centers`         pcdet/utils/common_utils.py:66-82
   * `sample_keypoints`          VoxelSetAbstraction.get_sampled_points, FPS branch
+  * `sectorized_proposal_centric_sampling` (+ `sample_points_with_roi`, `sector_fps`)   its SPC branch (PV-RCNN++)
                                 (pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:236-263): farthest point sampling of
                                 NUM_KEYPOINTS raw points per frame
   * `VoxelSetAbstraction`       the same file :340-420 for FEATURES_SOURCE in {bev, raw_points, x_conv1..4}
@@ -113,6 +114,49 @@ def sample_keypoints(points, frame_counts, num_keypoints):
     idx = P.stack_farthest_point_sample(xyz, frame_counts, num_keypoints)
     kp = points[idx.long(), 0:4]
     return kp, idx
+
+
+def sample_points_with_roi(rois, points, sample_radius_with_roi, num_max_points_of_part=200000):
+    """voxel_set_abstraction.py:45-75: keep a point when its NEAREST proposal centre is closer than that proposal's half
+    diagonal + `sample_radius_with_roi`.  rois [M, 7+], points [N, 3] -> (kept points -- the first point alone when none
+    qualifies, as the reference -- , mask [N]).  The N x M distances are taken `num_max_points_of_part` points at a time."""
+    centres, half_diag = rois[:, 0:3], (rois[:, 3:6] / 2).norm(dim=-1)
+    keep = torch.zeros((points.shape[0],), dtype=torch.bool, device=points.device)
+    for lo in range(0, points.shape[0], num_max_points_of_part):
+        chunk = points[lo:lo + num_max_points_of_part]
+        nearest, which = (chunk[:, None, :] - centres[None, :, :]).norm(dim=-1).min(dim=-1)
+        keep[lo:lo + chunk.shape[0]] = nearest < half_diag[which] + sample_radius_with_roi
+    return (points[keep] if bool(keep.any()) else points[:1]), keep
+
+
+def sector_fps(points, num_sampled_points, num_sectors):
+    """voxel_set_abstraction.py:78-121 (SectorFPS of PV-RCNN++): azimuth sectors of 2 pi / num_sectors; a non-empty sector with
+    n_k of the N points gets min(n_k, ceil(n_k / N * num_sampled_points)) samples, and ONE stacked farthest point sampling runs
+    over the sectors as its batch -- `num_sectors` short dependent chains instead of one long one.
+    points [N, 3] -> sampled points [N_out, 3], sector after sector (N_out >= num_sampled_points by the ceilings)."""
+    import math
+    width = math.pi * 2 / num_sectors
+    sector = ((torch.atan2(points[:, 1], points[:, 0]) + math.pi) / width).floor().clamp(min=0, max=num_sectors)
+    # (angle == 2 pi lands in "sector num_sectors", which the reference's loop over range(num_sectors) never visits)
+    order = torch.argsort(sector, stable=True)
+    sizes = torch.bincount(sector.long(), minlength=num_sectors + 1)[:num_sectors].tolist()
+    order = order[:sum(sizes)]
+    sizes = [n for n in sizes if n > 0]
+    if sizes:
+        quota = [min(n, math.ceil(n / points.shape[0] * num_sampled_points)) for n in sizes]
+        xyz = points[order].contiguous()
+    else:                                                  # (the reference's fallback: everything as one sector)
+        sizes, quota, xyz = [points.shape[0]], [num_sampled_points], points.contiguous()
+    cnt = torch.tensor(sizes, device=points.device, dtype=torch.int32)
+    return xyz[P.stack_farthest_point_sample(xyz, cnt, quota).long()]
+
+
+def sectorized_proposal_centric_sampling(roi_boxes, points, num_keypoints, sample_radius_with_roi, num_sectors,
+                                         num_points_of_each_sample_part=200000):
+    """VoxelSetAbstraction.sectorized_proposal_centric_sampling (voxel_set_abstraction.py:205-225), SAMPLE_METHOD 'SPC':
+    keep the points around the proposals, then SectorFPS.  One frame: roi_boxes [M, 7+], points [N, 3]."""
+    sampled, _ = sample_points_with_roi(roi_boxes, points, sample_radius_with_roi, num_points_of_each_sample_part)
+    return sector_fps(sampled, num_keypoints, num_sectors)
 
 
 def bilinear_interpolate_torch(im, x, y):

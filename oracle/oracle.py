@@ -434,6 +434,36 @@ def stack_fps(xyz, xyz_cnt, npoint):
     return np.array(out, np.int32)
 
 
+def sample_points_with_roi(rois, points, sample_radius_with_roi):
+    """voxel_set_abstraction.py:45-75 -> boolean mask of the points kept (float32 arithmetic as torch's)."""
+    rois, points = _f32(rois), _f32(points)
+    d = points[:, None, :] - rois[None, :, 0:3]
+    dist = np.sqrt((d * d).sum(-1, dtype=np.float32), dtype=np.float32)
+    j = dist.argmin(-1)
+    half = (rois[j, 3:6] / np.float32(2)).astype(np.float32)
+    roi_max_dim = np.sqrt((half * half).sum(-1, dtype=np.float32), dtype=np.float32)
+    return dist[np.arange(len(points)), j] < roi_max_dim + np.float32(sample_radius_with_roi)
+
+
+def sector_fps(points, sector_idx, num_sampled_points, num_sectors):
+    """voxel_set_abstraction.py:78-121 given every point's sector index (the reference: floor((atan2(y, x) + pi) / (2 pi /
+    num_sectors)) clamped to [0, num_sectors]): grouping by sector, ceil-share sample counts, stacked FPS -> sampled points."""
+    import math
+    points = _f32(points)
+    groups, cnts, nsamp = [], [], []
+    for k in range(num_sectors):
+        m = sector_idx == k
+        cur = int(m.sum())
+        if cur > 0:
+            groups.append(points[m])
+            cnts.append(cur)
+            nsamp.append(min(cur, math.ceil(cur / points.shape[0] * num_sampled_points)))
+    if not cnts:
+        groups, cnts, nsamp = [points], [len(points)], [num_sampled_points]
+    xyz = np.concatenate(groups, 0)
+    return xyz[stack_fps(xyz, cnts, nsamp)]
+
+
 def three_nn_stack(unknown, unknown_cnt, known, known_cnt):
     """interpolate_gpu.cu:16-76 -> (squared distances [N, 3], global indices [N, 3])."""
     unknown, known = _f32(unknown), _f32(known)
