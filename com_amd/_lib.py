@@ -261,17 +261,20 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
         # experiment scripts pass tuning options through the environment: PCD_OPT_<KEY>=<int> -> pcd_set_option (the
-        # library itself reads no environment variable)
+        # library itself reads no environment variable).  Applied BEFORE the handle is published: a mistyped option fails
+        # every call, not just the first.
         for k, v in os.environ.items():
             if k.startswith("PCD_OPT_"):
                 if handle.pcd_set_option(k[8:].lower().encode(), int(v)) != 0:
                     raise PcdError(f"unknown tuning option {k}")
+        _lib = handle
     return _lib
 
 
 def set_option(key, value):
+    """PROCESS-WIDE (one table per loaded library, read at launch time without synchronisation): set options before
+    the first launch, not from concurrent threads; tests restore what they change (tests/conftest.py::pcd_option)."""
     check(lib().pcd_set_option(key.encode(), int(value)), f"pcd_set_option({key})")
 
 

@@ -532,10 +532,10 @@ extern "C" int pcd_group_points_stack_grad(int B, int M, int C, int nsample, con
     if (nsample <= 64 && tile_bytes <= 48 * 1024) {
         group_points_grad_tiled_kernel<<<(unsigned)M, 256, tile_bytes, (hipStream_t)stream>>>(
             B, M, C, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features_zeroed);
-        PN2_CHECK_LAUNCH();
+    } else {          // (balls of more than 64 samples / tiles beyond 48 KB: one atomic per element)
+        group_points_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+            B, M, C, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features_zeroed);
     }
-    group_points_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        B, M, C, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features_zeroed);
     PN2_CHECK_LAUNCH();
 }
 
@@ -570,7 +570,7 @@ extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, c
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return PCD_ERR_LAUNCH;
-    int G = cus / B;
+    int G = (cus - cus / 4) / B;                 // three quarters of the CUs
     if (G > FPS_COOP_MAXG) G = FPS_COOP_MAXG;
     const int g_opt = pcd_opt(PCD_OPT_FPS_G);   // (experiments: workgroups per frame)
     if (g_opt >= 2 && g_opt <= G) G = g_opt;

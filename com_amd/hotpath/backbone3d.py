@@ -113,6 +113,12 @@ class _RulebookPrefetcher:
                 # the last unit is on the stream: nothing issued later reads the voxeliser's outputs (level-1 coordinates, rank
                 # map) -- a caller that recycles those buffers continues HERE, on this stream, idle for the rest of the forward
                 hook, self.after_units = self.after_units, None
+                u0 = getattr(self, "unit0_stream", None)
+                if u0 is not None and u0 is not side:
+                    # unit 0 (the level-1 SubM rulebook) reads the voxeliser's coordinates and rank map on ITS OWN stream: the
+                    # hook may overwrite them, so this stream is ordered behind unit 0's reads first (in a captured graph
+                    # nothing else puts an edge between the two branches)
+                    side.wait_stream(u0)
                 hook()
 
 

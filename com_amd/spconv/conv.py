@@ -115,6 +115,14 @@ class SparseConvolution(SparseModule):
         self._fresh_d = False
         return self._packed_d
 
+    def _packed_dgrad_for(self, window):
+        """The dgrad pack in the layout the FORWARD that asks for it decided on (`window`): the cached pack follows the
+        module's CURRENT decision, which another forward may have changed before this one's backward runs (an eval pass in
+        fp32, another row order, the fp8 toggle) -- then pack afresh in the layout the saved context needs."""
+        if bool(window) == self.use_window:
+            return self._packed_dgrad()
+        return ops.pack_weight_window(self.weight, 1) if window else ops.pack_weight(self.weight, 1)
+
     def prepack(self, dgrad=True):
         """Pack the weights for forward (and dgrad) now -- e.g. on a side stream at the start of a step, so the
         ~40 small pack kernels of a backbone leave the critical path; the next forward / backward consumes
@@ -224,8 +232,8 @@ class SparseConvolution(SparseModule):
                and input.features.dtype == torch.bfloat16 and input.features.shape[1] == self.in_channels
                and self.window_capable())
         self.set_window(win)
-        feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(), self._packed_dgrad,
-                                passthrough, **({"fp8": fp8} if fp8 is not None else {}), window=win)
+        feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(),
+                                lambda w=win: self._packed_dgrad_for(w), passthrough, **({"fp8": fp8} if fp8 is not None else {}), window=win)
         if dbg:
             _ops.stamp(f"cv{_ops.STAMPS['conv_seq']}_b")
             _ops.STAMPS["conv_seq"] += 1

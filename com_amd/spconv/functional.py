@@ -208,7 +208,11 @@ class SparseConvFunction(Function):
             if ctx.cin_pad % 16 != 0:
                 raise RuntimeError("dgrad needs >= 16 input channels (the 5-channel input layer never "
                                    "requires an input gradient)")
-            packed_d = ctx.packed_dgrad() if ctx.packed_dgrad is not None else ops.pack_weight(weight, 1)
+            # (the pack's layout is bound to THIS forward's window decision: conv._packed_dgrad_for)
+            if ctx.packed_dgrad is not None:
+                packed_d = ctx.packed_dgrad()
+            else:
+                packed_d = ops.pack_weight_window(weight, 1) if ctx.window else ops.pack_weight(weight, 1)
             add = None
             if d_ident is not None and ctx.cin_pad == ctx.in_cols and d_ident.dtype == ctx.in_dtype:
                 add = d_ident.contiguous()           # fused: dx = dgrad + identity-branch gradient

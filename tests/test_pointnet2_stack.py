@@ -53,6 +53,15 @@ def test_gpu_ball_query_group_and_gradient():
     gref = np.zeros((2000, 9), np.float64)
     np.add.at(gref, (idx.cpu().numpy() + starts[:, None]).reshape(-1), w.cpu().numpy().transpose(0, 2, 1).reshape(-1, 9))
     np.testing.assert_allclose(feats.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)
+    # balls of more than 64 samples take the one-atomic-per-element gradient kernel (the tiled one holds <= 64): same sums
+    feats2 = feats.detach().clone().requires_grad_(True)
+    idx2, _ = P.ball_query(4.0, 80, txyz, tc, tnew, tn)
+    out2 = P.grouping_operation(feats2, tc, idx2, tn)                   # (160, 9, 80)
+    w2 = torch.randn_like(out2)
+    (out2 * w2).sum().backward()
+    gref2 = np.zeros((2000, 9), np.float64)
+    np.add.at(gref2, (idx2.cpu().numpy() + starts[:, None]).reshape(-1), w2.cpu().numpy().transpose(0, 2, 1).reshape(-1, 9))
+    np.testing.assert_allclose(feats2.grad.cpu().numpy(), gref2, rtol=1e-4, atol=1e-4)
     qg = P.QueryAndGroup(2.5, 32, use_xyz=True)
     nf, _ = qg(txyz, tc, tnew, tn, feats.detach())
     assert nf.shape == (160, 12, 32)
