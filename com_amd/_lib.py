@@ -71,6 +71,17 @@ PROTOTYPES = {
                                       _vp, _i]),
     "pcd_rulebook_subm_ranked4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
                                        _vp, _i]),
+    "pcd_colmap_bytes": (_sz, [_i, _vp, _i]),
+    "pcd_colmap_from_rows_workspace_bytes": (_sz, [_i, _vp]),
+    "pcd_colmap_from_rows": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "pcd_rulebook_subm_cm_workspace_bytes": (_sz, [_i]),
+    "pcd_rulebook_subm_cm": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_cm_workspace_bytes": (_sz, [_i, _i, _vp, _vp, _vp, _vp]),
+    "pcd_rulebook_conv_cm_count": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_cm_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,
+                                       _vp, _i, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_cm_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
+                                        _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,

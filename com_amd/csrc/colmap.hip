@@ -1,0 +1,907 @@
+// Column-map rulebook builds for levels whose rows are numbered z-fastest (PCD_ROWS_YXZ) -- O(rows) + O(BEV cells / 32)
+// instead of O(volume of the key space).
+//
+// Replaces the same spconv get_indice_pairs calls as rulebook.hip (pcdet/models/backbones_3d/spconv_backbone.py:12-15,
+// 199-229; definitions SURVEY.md A.4).  In (b, y, x, z) order the rows of one BEV cell -- a COLUMN -- are consecutive and
+// ordered by z, so the coordinate -> row map of a level needs no bitmap over its (b, y, x, z) key space (371 M cells at
+// level 1 of a 4-frame Waymo batch):
+//     cw[word]  = { occupancy bits of 32 BEV cells (b, y, x), number of occupied cells in front of the word }     8 B
+//     cr[col]   = { z mask lo, z mask hi, first row of the column, rows of the column }                           16 B
+//     row(b, z, y, x) = cr[col].start + popcount(zmask & below(z)),  col = cw[key >> 5].prefix + popcount(bits below)
+// 2.3 MB + 16 B per column at level 1 (L2-resident) against 46 MB + 11.6 MB for the flat bitmap and its prefixes.
+//
+// A strided conv's OUTPUT map follows from the input map alone: output column (b, oy, ox) exists iff one of its kh x kw
+// input columns does; its z mask is the OR of their masks shifted by the padding, smeared over the kd kernel taps and
+// (stride 2) compressed to the even bits.  One thread per output BEV cell; two passes (count, emit) around block sums.
+// No atomics, no zero-fill of a map of the output volume, no scatter: every table entry is written exactly once by the
+// thread that owns its row.
+#include "rulebook_common.h"
+
+namespace {
+
+constexpr int CM_CELLS_PER_BLOCK = 2048;              // 4 waves x 8 groups of 64 cells
+constexpr int CM_GROUPS_PER_BLOCK = CM_CELLS_PER_BLOCK / 64;
+// block sums are added up by the consuming block up to "cm_direct_blocks" blocks (4096: 16 loads per thread), a spine launch beyond
+static inline bool cm_spined(int nblk) { return nblk > pcd_opt(PCD_OPT_CM_DIRECT_BLOCKS); }
+
+struct CmBuf {            // a level's column map inside ONE caller-owned buffer (pcd_colmap_bytes)
+    uint2 *cw;            // [nwords + 2]
+    uint4 *cr;            // [ncol_cap + 1]
+    int *ncols;           // [4]: columns, rows (diagnostics)
+    size_t nwords;        // whole groups of 64 cells: 2 words per group
+    int ncol_cap;
+    int cells;
+};
+
+bool cm_carve(void *p, size_t bytes, int batch, int H, int W, int n_cap, CmBuf &B, size_t *need) {
+    const double cells = (double)batch * H * W;
+    if (batch <= 0 || H <= 0 || W <= 0 || cells >= 2147483647.0 - 4096.0) return false;
+    B.cells = (int)cells;
+    B.nwords = (size_t)pcd_div_up(B.cells, 64) * 2;
+    B.ncol_cap = n_cap < B.cells ? (n_cap > 0 ? n_cap : 1) : B.cells;
+    WsCarver ws(p, bytes);
+    B.cw = ws.take<uint2>(B.nwords + 2);
+    B.cr = ws.take<uint4>((size_t)B.ncol_cap + 1);
+    B.ncols = ws.take<int>(4);
+    if (need) *need = ws.off;
+    return p == nullptr || ws.ok;
+}
+
+// ---- lookups ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 bev_key(int b, int y, int x, int H, int W) { return ((u32)b * H + y) * W + x; }
+
+// column index of a BEV cell given its word, or -1
+__device__ __forceinline__ int cm_col(uint2 w, u32 key, int ncol_cap) {
+    const u32 bit = key & 31u;
+    if (!((w.x >> bit) & 1u)) return -1;
+    const int col = (int)w.y + __popc(w.x & ((1u << bit) - 1u));
+    return col < ncol_cap ? col : -1;
+}
+
+__device__ __forceinline__ int cm_row(u64 zm, int start, int z) {
+    return ((zm >> z) & 1ull) ? start + __popcll(zm & ((1ull << z) - 1ull)) : -1;
+}
+
+// ---- level 1: the map of a row set given in (b, y, x, z) order -----------------------------------------------
+__device__ __forceinline__ bool same_column(int4 a, int4 c) { return a.x == c.x && a.z == c.z && a.w == c.w; }
+
+__global__ __launch_bounds__(256) void cm_rows_mark_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                           int H, int W, u32 *__restrict__ bits) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= eff_rows(n_dev, n)) return;
+    const int4 c = idx[i];
+    if (i > 0 && same_column(idx[i - 1], c)) return;
+    const u32 key = bev_key(c.x, c.z, c.w, H, W);
+    // the heads of a wave are in ascending key order: lanes that share a word with the head in front of them hand their bit
+    // down; one atomic per (wave, word)
+    u32 word = key >> 5, mine = 1u << (key & 31u);
+    atomicOr(bits + word, mine);
+}
+
+// words -> block sums of set bits (1024 words per block)
+__global__ __launch_bounds__(256) void cm_words_count_kernel(const u32 *__restrict__ bits, int nwords, int *__restrict__ bsums) {
+    __shared__ int lds[4];
+    const int w0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    int c = 0;
+    if (w0 + 3 < nwords) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(bits + w0);
+        c = __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (w0 + j < nwords) c += __popc(bits[w0 + j]);
+    }
+    const int t = block_sum(c, lds);
+    if (threadIdx.x == 0) bsums[blockIdx.x] = t;
+}
+
+// sum of bsums[0 .. blk) by the block itself, or bsums[blk] when a spine launch left exclusive prefixes there
+__device__ __forceinline__ int cm_base(const int *__restrict__ bsums, int blk, int spined, int *lds) {
+    if (spined) return bsums[blk];
+    int acc = 0;
+    for (int j = threadIdx.x; j < blk; j += 256) acc += bsums[j];
+    return block_sum(acc, lds);
+}
+
+__global__ __launch_bounds__(256) void cm_words_prefix_kernel(const u32 *__restrict__ bits, int nwords, int nblk,
+                                                              const int *__restrict__ bsums, int spined,
+                                                              uint2 *__restrict__ cw, int *__restrict__ ncols) {
+    __shared__ int lds[4];
+    const int base = cm_base(bsums, blockIdx.x, spined, lds);
+    if (blockIdx.x == 0 && ncols) {
+        int t = 0;
+        if (spined) t = bsums[nblk];
+        else {
+            for (int j = threadIdx.x; j < nblk; j += 256) t += bsums[j];
+            t = block_sum(t, lds);
+        }
+        if (threadIdx.x == 0) ncols[0] = t;
+    }
+    const int w0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    u32 b[4] = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < 4; ++j)
+        if (w0 + j < nwords) b[j] = bits[w0 + j];
+    const int c0 = __popc(b[0]), c1 = __popc(b[1]), c2 = __popc(b[2]), c3 = __popc(b[3]);
+    int total;
+    const int ex = base + block_exclusive_scan(c0 + c1 + c2 + c3, lds, total);
+    const int pre[4] = {ex, ex + c0, ex + c0 + c1, ex + c0 + c1 + c2};
+    for (int j = 0; j < 4; ++j)
+        if (w0 + j < nwords) cw[w0 + j] = make_uint2(b[j], (u32)pre[j]);
+}
+
+// head rows write their column's record: z mask and length from the rows that follow
+__global__ __launch_bounds__(256) void cm_rows_fill_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                           int H, int W, const uint2 *__restrict__ cw,
+                                                           uint4 *__restrict__ cr, int ncol_cap, int *__restrict__ ncols) {
+    const int nn = eff_rows(n_dev, n);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && ncols) ncols[1] = nn;
+    if (i >= nn) return;
+    const int4 c = idx[i];
+    if (i > 0 && same_column(idx[i - 1], c)) return;
+    const u32 key = bev_key(c.x, c.z, c.w, H, W);
+    const int col = cm_col(cw[key >> 5], key, ncol_cap);
+    if (col < 0) return;
+    u64 zm = 1ull << c.y;
+    int cnt = 1;
+    for (int j = i + 1; j < nn; ++j) {
+        const int4 d = idx[j];
+        if (!same_column(d, c)) break;
+        zm |= 1ull << d.y;
+        ++cnt;
+    }
+    cr[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)i, (u32)cnt);
+}
+
+// ---- SubM 3x3x3 from the map ---------------------------------------------------------------------------------
+// One thread per row: the nine columns (dy, dx) of its neighbourhood, each looked up once (word, then record) and serving
+// the three z-neighbours.  Neighbouring rows of a wave share columns: the loads hit the same few lines.
+__global__ __launch_bounds__(256) void cm_subm_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
+                                                      int D, int H, int W, const uint2 *__restrict__ cw,
+                                                      const uint4 *__restrict__ cr, int ncol_cap,
+                                                      int32_t *__restrict__ nbr, int *__restrict__ wave_cnt, int nwaves) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int nn = eff_rows(n_dev, n);
+    const bool live = o < nn;
+    const int4 c = live ? idx[o] : make_int4(0, 0, 0, 0);
+    const int wave = o >> 6;
+    uint2 w[9];
+    u32 key[9];
+    bool in[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int y = c.z + q / 3 - 1, x = c.w + q % 3 - 1;
+        in[q] = live && y >= 0 && y < H && x >= 0 && x < W;
+        key[q] = in[q] ? bev_key(c.x, y, x, H, W) : 0u;
+        w[q] = cw[key[q] >> 5];
+    }
+    uint4 r[9];
+    bool hit[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int col = in[q] ? cm_col(w[q], key[q], ncol_cap) : -1;
+        hit[q] = col >= 0;
+        r[q] = cr[hit[q] ? col : 0];
+    }
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int k = dz * 9 + q;
+            const int z = c.y + dz - 1;
+            int row = -1;
+            if (hit[q] && z >= 0 && z < D) {
+                row = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, z);
+                if (row >= nn) row = -1;
+            }
+            if (k == 13 && live) row = o;
+            if (live) nbr[(size_t)k * n + o] = row;
+            if (wave_cnt) {
+                const u64 m = __ballot(row >= 0);
+                if (lane_id() == 0 && wave < nwaves) wave_cnt[(size_t)k * nwaves + wave] = __popcll(m);
+            }
+        }
+}
+
+// ---- strided conv from the input map --------------------------------------------------------------------------
+struct CmGeom {
+    int D, H, W, Do, Ho, Wo;
+    int kd, sd, sh, sw, pd, ph, pw;
+    int cells;            // batch * Ho * Wo
+    int ncol_cap_in, ncol_cap_out;
+};
+
+__device__ __forceinline__ u32 compress_even(u64 t) {
+    t &= 0x5555555555555555ull;
+    t = (t | (t >> 1)) & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+    t = (t | (t >> 8)) & 0x0000ffff0000ffffull;
+    t = (t | (t >> 16)) & 0x00000000ffffffffull;
+    return (u32)t;
+}
+
+// z mask of the output column fed by the OR `m` of its input columns' masks:  out bit oz = OR_kz m[oz * sd - pd + kz]
+__device__ __forceinline__ u64 squash_z(u64 m, const CmGeom &G) {
+    const u64 m1 = m << G.pd;
+    u64 t = m1;
+    for (int kz = 1; kz < G.kd; ++kz) t |= m1 >> kz;
+    const u64 o = G.sd == 2 ? (u64)compress_even(t) : t;
+    return o & ((1ull << G.Do) - 1ull);
+}
+
+// OR of the z masks of the KH x KW input columns of output cell (b, oy, ox) (0 = the output column does not exist)
+template <int KH, int KW>
+__device__ __forceinline__ u64 in_union(const CmGeom &G, const uint2 *__restrict__ cw, const uint4 *__restrict__ cr, int b,
+                                        int oy, int ox) {
+    uint2 w[KH * KW];
+    u32 key[KH * KW];
+    bool in[KH * KW];
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        const int y = oy * G.sh - G.ph + q / KW, x = ox * G.sw - G.pw + q % KW;
+        in[q] = y >= 0 && y < G.H && x >= 0 && x < G.W;
+        key[q] = in[q] ? bev_key(b, y, x, G.H, G.W) : 0u;
+        w[q] = cw[key[q] >> 5];
+    }
+    u64 m = 0;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        in[q] = in[q] && ((w[q].x >> (key[q] & 31u)) & 1u);
+        any = any || in[q];
+    }
+    if (!any) return 0;
+    uint4 r[KH * KW];
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        const int col = in[q] ? cm_col(w[q], key[q], G.ncol_cap_in) : -1;
+        in[q] = col >= 0;
+        r[q] = cr[in[q] ? col : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q)
+        if (in[q]) m |= (u64)r[q].x | ((u64)r[q].y << 32);
+    return m;
+}
+
+struct CmConvSide {         // by-products of the count launch
+    int *zero;              // words to zero (wsuper of the pair lists), spread over the cell blocks
+    int zero_words;
+    const int4 *idx;        // parity classes: extra blocks count the classes of 256 input rows each
+    int n;
+    const int32_t *n_dev;
+    int ncls;
+    int *blk_cnt;
+    int pd, ph, pw;
+};
+
+// pass 1: per group of 64 output cells { occupancy bits, rows }, per block { columns, rows }
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void cm_conv_count_kernel(CmGeom G, int ncellblk, const uint2 *__restrict__ cw,
+                                                            const uint4 *__restrict__ cr, uint4 *__restrict__ ginfo,
+                                                            int2 *__restrict__ bsums, CmConvSide S) {
+    __shared__ int lds[4];
+    __shared__ int ccnt[CLS_MAX];
+    if ((int)blockIdx.x >= ncellblk) {
+        const int i = ((int)blockIdx.x - ncellblk) * 256 + threadIdx.x;
+        int cls = -1;
+        if (i < eff_rows(S.n_dev, S.n)) cls = row_class(S.idx[i], S.pd, S.ph, S.pw, G.sd, G.sh, G.sw);
+        // (block_class_counts indexes blk_cnt by blockIdx.x / gridDim.x: shift the pointer so that the class blocks count from 0)
+        if (threadIdx.x < CLS_MAX) ccnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int q = 0; q < S.ncls; ++q) {
+            const u64 m = __ballot(cls == q);
+            if (lane_id() == 0 && m) atomicAdd(&ccnt[q], __popcll(m));
+        }
+        __syncthreads();
+        const int nclsblk = (int)gridDim.x - ncellblk;
+        if ((int)threadIdx.x < S.ncls) S.blk_cnt[(size_t)threadIdx.x * nclsblk + ((int)blockIdx.x - ncellblk)] = ccnt[threadIdx.x];
+        return;
+    }
+    if (S.zero) {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < S.zero_words; e += ncellblk * 256) S.zero[e] = 0;
+    }
+    const int wave = threadIdx.x >> 6;
+    int ncols = 0, nrows = 0;
+    for (int it = 0; it < CM_GROUPS_PER_BLOCK / 4; ++it) {
+        const int cell = blockIdx.x * CM_CELLS_PER_BLOCK + (wave * (CM_GROUPS_PER_BLOCK / 4) + it) * 64 + lane_id();
+        u64 zm = 0;
+        if (cell < G.cells) {
+            const int ox = cell % G.Wo, t = cell / G.Wo;
+            const u64 m = in_union<KH, KW>(G, cw, cr, t / G.Ho, t % G.Ho, ox);
+            if (m) zm = squash_z(m, G);
+        }
+        const u64 bits = __ballot(zm != 0);
+        int rows = __popcll(zm);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rows += __shfl_xor(rows, d, 64);
+        if (lane_id() == 0) {
+            if (cell < G.cells) ginfo[cell >> 6] = make_uint4((u32)bits, (u32)(bits >> 32), (u32)rows, 0u);
+            ncols += __popcll(bits);
+            nrows += rows;
+        }
+    }
+    const int tc = block_sum(ncols, lds);
+    const int tr = block_sum(nrows, lds);
+    if (threadIdx.x == 0) bsums[blockIdx.x] = make_int2(tc, tr);
+}
+
+// exclusive scan of the block sums (only beyond "cm_direct_blocks" blocks): one block, in place, totals -> bsums[nblk]
+__global__ __launch_bounds__(256) void cm_spine2_kernel(int2 *bsums, int nblk) {
+    __shared__ int lds[4];
+    __shared__ int2 carry_s;
+    if (threadIdx.x == 0) carry_s = make_int2(0, 0);
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int2 v = i < nblk ? bsums[i] : make_int2(0, 0);
+        int tc, tr;
+        const int ec = block_exclusive_scan(v.x, lds, tc);
+        const int er = block_exclusive_scan(v.y, lds, tr);
+        const int2 carry = carry_s;
+        if (i < nblk) bsums[i] = make_int2(carry.x + ec, carry.y + er);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = make_int2(carry.x + tc, carry.y + tr);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsums[nblk] = carry_s;
+}
+
+__device__ __forceinline__ int2 cm_base2(const int2 *__restrict__ bsums, int blk, int spined, int *lds) {
+    if (spined) return bsums[blk];
+    int ac = 0, ar = 0;
+    for (int j = threadIdx.x; j < blk; j += 256) {
+        const int2 v = bsums[j];
+        ac += v.x;
+        ar += v.y;
+    }
+    const int tc = block_sum(ac, lds);
+    const int tr = block_sum(ar, lds);
+    return make_int2(tc, tr);
+}
+
+// totals only (the two-phase API: the host reads n_out before it allocates the outputs)
+__global__ __launch_bounds__(256) void cm_total_kernel(const int2 *__restrict__ bsums, int nblk, int spined,
+                                                       int *__restrict__ n_out_dev) {
+    __shared__ int lds[4];
+    const int2 t = cm_base2(bsums, nblk, spined, lds);
+    if (threadIdx.x == 0) *n_out_dev = t.y;
+}
+
+struct CmEmitSide {
+    void *fill_a;           // 0xFF fill (perm of the parity classes), spread over the cell blocks
+    size_t fill_a_bytes;
+    int *blk_cnt;           // parity classes: one extra block turns the counts into offsets
+    int cls_nblk, ncls, cls_tile;
+    int *vstart;
+};
+
+// pass 2: the output map (words, column records), the output coordinates, the row count
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellblk, const uint2 *__restrict__ cw,
+                                                           const uint4 *__restrict__ cr, const uint4 *__restrict__ ginfo,
+                                                           const int2 *__restrict__ bsums, int spined,
+                                                           uint2 *__restrict__ cw_out, uint4 *__restrict__ cr_out,
+                                                           int *__restrict__ ncols_out, int32_t *__restrict__ out_indices,
+                                                           int n_out, int *__restrict__ n_out_dev, CmEmitSide S) {
+    __shared__ int lds[4];
+    __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
+    __shared__ int2 gbase[CM_GROUPS_PER_BLOCK];
+    if ((int)blockIdx.x >= ncellblk) {
+        class_offsets(S.blk_cnt, S.cls_nblk, S.ncls, S.cls_tile, S.vstart, ctot, cstart);
+        return;
+    }
+    if (S.fill_a) fill_ff(S.fill_a, S.fill_a_bytes, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)ncellblk * 256);
+    const int2 base = cm_base2(bsums, blockIdx.x, spined, lds);
+    if (blockIdx.x == 0 && (n_out_dev || ncols_out)) {
+        const int2 t = cm_base2(bsums, ncellblk, spined, lds);
+        if (threadIdx.x == 0) {
+            if (n_out_dev) *n_out_dev = t.y;
+            if (ncols_out) {
+                ncols_out[0] = t.x;
+                ncols_out[1] = t.y;
+            }
+        }
+    }
+    const int g0 = blockIdx.x * CM_GROUPS_PER_BLOCK;
+    const int ngroups = (G.cells + 63) >> 6;
+    if (threadIdx.x < 64) {            // one wave: exclusive scan over the block's groups
+        const int g = g0 + threadIdx.x;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x < CM_GROUPS_PER_BLOCK && g < ngroups) q = ginfo[g];
+        const int c = __popc(q.x) + __popc(q.y), r = (int)q.z;
+        const int ic = wave_inclusive_scan(c), ir = wave_inclusive_scan(r);
+        if (threadIdx.x < CM_GROUPS_PER_BLOCK) gbase[threadIdx.x] = make_int2(base.x + ic - c, base.y + ir - r);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const u64 lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+    for (int it = 0; it < CM_GROUPS_PER_BLOCK / 4; ++it) {
+        const int gl = wave * (CM_GROUPS_PER_BLOCK / 4) + it;
+        const int g = g0 + gl;
+        if (g >= ngroups) break;
+        const uint4 q = ginfo[g];
+        const u64 bits = (u64)q.x | ((u64)q.y << 32);
+        const int2 gb = gbase[gl];
+        if (lane_id() == 0) {
+            cw_out[2 * g] = make_uint2(q.x, (u32)gb.x);
+            cw_out[2 * g + 1] = make_uint2(q.y, (u32)(gb.x + __popc(q.x)));
+        }
+        if (!bits) continue;
+        const int cell = g * 64 + lane_id();
+        const bool set = (bits >> lane_id()) & 1ull;
+        u64 zm = 0;
+        int b = 0, oy = 0, ox = 0;
+        if (set) {
+            ox = cell % G.Wo;
+            const int t = cell / G.Wo;
+            oy = t % G.Ho;
+            b = t / G.Ho;
+            zm = squash_z(in_union<KH, KW>(G, cw, cr, b, oy, ox), G);
+        }
+        const int cnt = __popcll(zm);
+        const int start = gb.y + wave_inclusive_scan(cnt) - cnt;
+        if (set) {
+            const int col = gb.x + __popcll(bits & lt);
+            if (col < G.ncol_cap_out) cr_out[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)start, (u32)cnt);
+            if (out_indices) {
+                int r = start;
+                u64 m = zm;
+                while (m) {
+                    const int z = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                    if (r < n_out) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(b, z, oy, ox);
+                    ++r;
+                }
+            }
+        }
+    }
+}
+
+struct CmTablesSide {
+    int *wave_cnt;          // pair lists: hits per (offset, wave of 64 input rows) ...
+    int nwaves;
+    int *wsuper;            // ... and per 64 waves (zeroed by the count launch)
+    int nws;
+    int ncls;               // parity classes: permutation of the input rows
+    const int *blk_off;
+    int32_t *perm;
+};
+
+// pass 3: both neighbour tables.  Blocks [0, nb_out): one thread per OUTPUT row -> nbr_out[k][o] from the input map;
+// blocks [nb_out, nb_out + nb_in): one thread per INPUT row -> nbr_in[k][i] from the output map (+ pair counts, classes).
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_out, const int4 *__restrict__ idx, int n,
+                                                             const int32_t *n_dev, const int4 *__restrict__ out_idx, int n_out,
+                                                             const int32_t *n_out_dev, const uint2 *__restrict__ cw,
+                                                             const uint4 *__restrict__ cr, const uint2 *__restrict__ cw_out,
+                                                             const uint4 *__restrict__ cr_out, int32_t *__restrict__ nbr_in,
+                                                             int32_t *__restrict__ nbr_out, CmTablesSide S) {
+    constexpr int K = KD * KH * KW;
+    const int nn_in = eff_rows(n_dev, n), nn_out = eff_rows(n_out_dev, n_out);
+    if ((int)blockIdx.x < nb_out) {
+        const int o = blockIdx.x * 256 + threadIdx.x;
+        if (o >= n_out) return;
+        const bool live = o < nn_out;
+        const int4 c = live ? out_idx[o] : make_int4(0, 0, 0, 0);
+        uint2 w[KH * KW];
+        u32 key[KH * KW];
+        bool in[KH * KW];
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q) {
+            const int y = c.z * G.sh - G.ph + q / KW, x = c.w * G.sw - G.pw + q % KW;
+            in[q] = live && y >= 0 && y < G.H && x >= 0 && x < G.W;
+            key[q] = in[q] ? bev_key(c.x, y, x, G.H, G.W) : 0u;
+            w[q] = cw[key[q] >> 5];
+        }
+        uint4 r[KH * KW];
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q) {
+            const int col = in[q] ? cm_col(w[q], key[q], G.ncol_cap_in) : -1;
+            in[q] = col >= 0;
+            r[q] = cr[in[q] ? col : 0];
+        }
+#pragma unroll
+        for (int a = 0; a < KD; ++a)
+#pragma unroll
+            for (int q = 0; q < KH * KW; ++q) {
+                const int z = c.y * G.sd - G.pd + a;
+                int row = -1;
+                if (in[q] && z >= 0 && z < G.D) {
+                    row = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, z);
+                    if (row >= nn_in) row = -1;
+                }
+                nbr_out[(size_t)(a * KH * KW + q) * n_out + o] = row;
+            }
+        return;
+    }
+    __shared__ int wcnt[4][CLS_MAX];
+    __shared__ int blk_sum[K];
+    const int blk = (int)blockIdx.x - nb_out;
+    const int i = blk * 256 + threadIdx.x;
+    const bool live = i < nn_in;
+    const int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
+    const int wave = i >> 6;
+    if (S.wave_cnt) {
+        for (int q = threadIdx.x; q < K; q += 256) blk_sum[q] = 0;
+        __syncthreads();
+    }
+    if (S.perm) {
+        const int cls = live ? row_class(c, G.pd, G.ph, G.pw, G.sd, G.sh, G.sw) : -1;
+        const int wv = threadIdx.x >> 6;
+        const u64 lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+        int rank = 0;
+        for (int q = 0; q < S.ncls; ++q) {
+            const u64 m = __ballot(cls == q);
+            if (cls == q) rank = __popcll(m & lt);
+            if (lane_id() == 0) wcnt[wv][q] = __popcll(m);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int before = 0;
+            for (int ww = 0; ww < wv; ++ww) before += wcnt[ww][cls];
+            const int nclsblk = (int)gridDim.x - nb_out;
+            S.perm[S.blk_off[(size_t)cls * nclsblk + blk] + before + rank] = i;
+        }
+    }
+    // output columns reached through (ky, kx): oy = (y + ph - ky) / sh where that is a whole, in-range number
+    uint2 w[KH * KW];
+    u32 key[KH * KW];
+    bool in[KH * KW];
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        const int oy = axis_out(c.z, G.ph, 1, G.sh, q / KW, G.Ho), ox = axis_out(c.w, G.pw, 1, G.sw, q % KW, G.Wo);
+        in[q] = live && oy >= 0 && ox >= 0;
+        key[q] = in[q] ? bev_key(c.x, oy, ox, G.Ho, G.Wo) : 0u;
+        w[q] = cw_out[key[q] >> 5];
+    }
+    uint4 r[KH * KW];
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        const int col = in[q] ? cm_col(w[q], key[q], G.ncol_cap_out) : -1;
+        in[q] = col >= 0;
+        r[q] = cr_out[in[q] ? col : 0];
+    }
+#pragma unroll
+    for (int a = 0; a < KD; ++a) {
+        const int oz = axis_out(c.y, G.pd, 1, G.sd, a, G.Do);
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q) {
+            const int k = a * KH * KW + q;
+            int row = -1;
+            if (in[q] && oz >= 0) {
+                row = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, oz);
+                if (row >= nn_out) row = -1;
+            }
+            if (live) nbr_in[(size_t)k * n + i] = row;
+            if (S.wave_cnt) publish_wave_count(S.wave_cnt, blk_sum, k, wave, S.nwaves, row >= 0);
+        }
+    }
+    if (S.wave_cnt) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < K; q += 256)
+            if (blk_sum[q]) atomicAdd(&S.wsuper[(size_t)q * S.nws + (blk >> 4)], blk_sum[q]);
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+struct CmConvWs {
+    uint4 *ginfo;
+    int2 *bsums;
+    int *wsuper, *wave_cnt, *blk_cnt;
+    int ngroups, ncellblk, nwaves, nws, nclsblk;
+};
+
+bool cm_geom(const int *shape, const int *ks, const int *st, const int *pd, const int *dl, int batch, ConvGeom &G, CmGeom &C) {
+    if (make_geom(shape, ks, st, pd, dl, G) != PCD_OK) return false;
+    if (G.dd != 1 || G.dh != 1 || G.dw != 1) return false;
+    if (!((G.kd == 3 && G.kh == 3 && G.kw == 3) || (G.kd == 3 && G.kh == 1 && G.kw == 1))) return false;
+    if (G.sd < 1 || G.sd > 2 || G.sh < 1 || G.sh > 2 || G.sw < 1 || G.sw > 2) return false;
+    if (G.D + G.pd > 62 || G.Do > 62 || G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return false;
+    const double cells = (double)batch * G.Ho * G.Wo, cells_in = (double)batch * G.H * G.W;
+    if (cells >= 2147483647.0 - 4096.0 || cells_in >= 2147483647.0 - 4096.0) return false;
+    C.D = G.D; C.H = G.H; C.W = G.W; C.Do = G.Do; C.Ho = G.Ho; C.Wo = G.Wo;
+    C.kd = G.kd; C.sd = G.sd; C.sh = G.sh; C.sw = G.sw; C.pd = G.pd; C.ph = G.ph; C.pw = G.pw;
+    C.cells = (int)cells;
+    return true;
+}
+
+bool cm_conv_ws(void *p, size_t bytes, int n, const ConvGeom &G, const CmGeom &C, CmConvWs &L, size_t *need) {
+    L.ngroups = pcd_div_up(C.cells, 64);
+    L.ncellblk = pcd_div_up(C.cells, CM_CELLS_PER_BLOCK);
+    L.nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    L.nws = pcd_div_up(L.nwaves, 64);
+    L.nclsblk = pcd_div_up(n > 0 ? n : 1, 256);
+    WsCarver ws(p, bytes);
+    L.ginfo = ws.take<uint4>((size_t)L.ngroups + 1);
+    L.bsums = ws.take<int2>((size_t)L.ncellblk + 2);
+    L.wsuper = ws.take<int>((size_t)G.K * L.nws);
+    L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
+    L.blk_cnt = ws.take<int>((size_t)CLS_MAX * L.nclsblk);
+    if (need) *need = ws.off;
+    return p == nullptr || ws.ok;
+}
+
+template <int KH, int KW>
+void cm_launch_count(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmConvSide &S, int cls_blocks, hipStream_t st) {
+    cm_conv_count_kernel<KH, KW><<<L.ncellblk + cls_blocks, 256, 0, st>>>(C, L.ncellblk, in.cw, in.cr, L.ginfo, L.bsums, S);
+    if (cm_spined(L.ncellblk)) cm_spine2_kernel<<<1, 256, 0, st>>>(L.bsums, L.ncellblk);
+}
+
+template <int KH, int KW>
+void cm_launch_emit(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmBuf &out, int32_t *out_indices, int n_out,
+                    int32_t *n_out_dev, const CmEmitSide &S, hipStream_t st) {
+    cm_conv_emit_kernel<KH, KW><<<L.ncellblk + (S.blk_cnt ? 1 : 0), 256, 0, st>>>(
+        C, L.ncellblk, in.cw, in.cr, L.ginfo, L.bsums, cm_spined(L.ncellblk), out.cw, out.cr, out.ncols, out_indices,
+        n_out, n_out_dev, S);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" size_t pcd_colmap_bytes(int batch, const int *shape_host, int n_cap) {
+    if (!shape_host) return 0;
+    CmBuf B;
+    size_t need = 0;
+    if (!cm_carve(nullptr, 0, batch, shape_host[1], shape_host[2], n_cap, B, &need)) return 0;
+    return need;
+}
+
+extern "C" size_t pcd_colmap_from_rows_workspace_bytes(int batch, const int *shape_host) {
+    if (!shape_host) return 0;
+    CmBuf B;
+    if (!cm_carve(nullptr, 0, batch, shape_host[1], shape_host[2], 1, B, nullptr)) return 0;
+    return ws_piece(B.nwords + 4, sizeof(u32)) + ws_piece(pcd_div_up((int)B.nwords, 1024) + 2, sizeof(int));
+}
+
+extern "C" int pcd_colmap_from_rows(const int32_t *indices, int n, const int32_t *n_dev, int batch, const int *shape_host,
+                                    void *colmap, size_t colmap_bytes, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !shape_host || !colmap || (n > 0 && !indices)) return PCD_ERR_INVALID_ARG;
+    if (shape_host[0] <= 0 || shape_host[0] > 62) return PCD_ERR_UNSUPPORTED;
+    CmBuf B;
+    if (!cm_carve(colmap, colmap_bytes, batch, shape_host[1], shape_host[2], n, B, nullptr)) return PCD_ERR_WORKSPACE;
+    const int nwords = (int)B.nwords, nblk = pcd_div_up(nwords, 1024);
+    WsCarver ws(workspace, workspace_bytes);
+    u32 *bits = ws.take<u32>(B.nwords + 4);
+    int *bsums = ws.take<int>(nblk + 2);
+    if (!ws.ok) return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = shape_host[1], W = shape_host[2];
+    pcd_fill(bits, 0, (B.nwords + 4) * sizeof(u32), st);
+    const int nb = pcd_div_up(n > 0 ? n : 1, 256);
+    if (n > 0) cm_rows_mark_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, W, bits);
+    cm_words_count_kernel<<<nblk, 256, 0, st>>>(bits, nwords, bsums);
+    const int spined = cm_spined(nblk);
+    if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nblk, nullptr);
+    cm_words_prefix_kernel<<<nblk, 256, 0, st>>>(bits, nwords, nblk, bsums, spined, B.cw, B.ncols);
+    if (n > 0)
+        cm_rows_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, W, B.cw, B.cr, B.ncol_cap, B.ncols);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_rulebook_subm_cm_workspace_bytes(int n) {
+    if (n < 0) return 0;
+    const int nwaves = pcd_div_up(n > 0 ? n : 1, 64);
+    return 2 * ws_piece((size_t)27 * nwaves, sizeof(int)) + ws_piece(27, sizeof(int));
+}
+
+extern "C" int pcd_rulebook_subm_cm(const int32_t *indices, int n, int batch, const int *shape_host, const void *colmap,
+                                    size_t colmap_bytes, int colmap_cap, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                                    int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !shape_host || !colmap) return PCD_ERR_INVALID_ARG;
+    if (n > 0 && (pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    if (shape_host[0] <= 0 || shape_host[0] > 62) return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (pair_num) pcd_fill(pair_num, 0, 27 * sizeof(int32_t), st);
+        return PCD_OK;
+    }
+    if (!indices || !nbr) return PCD_ERR_INVALID_ARG;
+    CmBuf B;
+    if (!cm_carve(const_cast<void *>(colmap), colmap_bytes, batch, shape_host[1], shape_host[2], colmap_cap, B, nullptr))
+        return PCD_ERR_WORKSPACE;
+    const int nwaves = pcd_div_up(n, 64);
+    WsCarver ws(workspace, workspace_bytes);
+    int *wave_cnt = ws.take<int>((size_t)27 * nwaves);
+    int *wave_off = ws.take<int>((size_t)27 * nwaves);
+    int *totals = ws.take<int>(27);
+    if (pairs && !ws.ok) return PCD_ERR_WORKSPACE;
+    cm_subm_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, shape_host[0], shape_host[1],
+                                                       shape_host[2], B.cw, B.cr, B.ncol_cap, nbr,
+                                                       pairs ? wave_cnt : nullptr, nwaves);
+    if (pairs) {
+        scan_rows_kernel<<<27, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)27 * 2 * n * sizeof(int32_t), st);
+        launch_pairs_fill(nbr, n, n_dev, 27, 1, wave_off, nwaves, pairs, st);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_rulebook_conv_cm_workspace_bytes(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                                                       const int *stride_host, const int *pad_host) {
+    if (n < 0 || batch <= 0 || !in_shape_host || !ksize_host || !stride_host || !pad_host) return 0;
+    const int one[3] = {1, 1, 1};
+    ConvGeom G;
+    CmGeom C;
+    if (!cm_geom(in_shape_host, ksize_host, stride_host, pad_host, one, batch, G, C)) return 0;
+    CmConvWs L;
+    size_t need = 0;
+    cm_conv_ws(nullptr, 0, n, G, C, L, &need);
+    return need;
+}
+
+namespace {
+
+struct CmConvCall {
+    ConvGeom G;
+    CmGeom C;
+    CmConvWs L;
+    CmBuf in, out;
+};
+
+int cm_conv_setup(int n, int batch, const int *in_shape_host, const int *ksize_host, const int *stride_host,
+                  const int *pad_host, const void *in_colmap, size_t in_colmap_bytes, int in_cap, void *out_colmap,
+                  size_t out_colmap_bytes, int out_cap, void *workspace, size_t workspace_bytes, CmConvCall &X) {
+    const int one[3] = {1, 1, 1};
+    if (!in_shape_host || !ksize_host || !stride_host || !pad_host || !in_colmap) return PCD_ERR_INVALID_ARG;
+    if (!cm_geom(in_shape_host, ksize_host, stride_host, pad_host, one, batch, X.G, X.C)) return PCD_ERR_UNSUPPORTED;
+    if (!cm_carve(const_cast<void *>(in_colmap), in_colmap_bytes, batch, X.G.H, X.G.W, in_cap, X.in, nullptr))
+        return PCD_ERR_WORKSPACE;
+    X.out = CmBuf{};
+    if (out_colmap && !cm_carve(out_colmap, out_colmap_bytes, batch, X.G.Ho, X.G.Wo, out_cap, X.out, nullptr))
+        return PCD_ERR_WORKSPACE;
+    X.C.ncol_cap_in = X.in.ncol_cap;
+    X.C.ncol_cap_out = out_colmap ? X.out.ncol_cap : 0;
+    if (!cm_conv_ws(workspace, workspace_bytes, n, X.G, X.C, X.L, nullptr) || !workspace) return PCD_ERR_WORKSPACE;
+    return PCD_OK;
+}
+
+void cm_count(const CmConvCall &X, const CmConvSide &S, int cls_blocks, hipStream_t st) {
+    if (X.G.kh == 3) cm_launch_count<3, 3>(X.C, X.L, X.in, S, cls_blocks, st);
+    else cm_launch_count<1, 1>(X.C, X.L, X.in, S, cls_blocks, st);
+}
+
+void cm_emit(const CmConvCall &X, int32_t *out_indices, int n_out, int32_t *n_out_dev, const CmEmitSide &S, hipStream_t st) {
+    if (X.G.kh == 3) cm_launch_emit<3, 3>(X.C, X.L, X.in, X.out, out_indices, n_out, n_out_dev, S, st);
+    else cm_launch_emit<1, 1>(X.C, X.L, X.in, X.out, out_indices, n_out, n_out_dev, S, st);
+}
+
+void cm_tables(const CmConvCall &X, const int32_t *indices, int n, const int32_t *n_dev, const int32_t *out_indices, int n_out,
+               const int32_t *n_out_dev, int32_t *nbr_in, int32_t *nbr_out, const CmTablesSide &S, hipStream_t st) {
+    const int nb_out = pcd_div_up(n_out, 256), nb_in = pcd_div_up(n, 256);
+    if (X.G.kh == 3)
+        cm_conv_tables_kernel<3, 3, 3><<<nb_out + nb_in, 256, 0, st>>>(X.C, nb_out, (const int4 *)indices, n, n_dev,
+                                                                       (const int4 *)out_indices, n_out, n_out_dev, X.in.cw,
+                                                                       X.in.cr, X.out.cw, X.out.cr, nbr_in, nbr_out, S);
+    else
+        cm_conv_tables_kernel<3, 1, 1><<<nb_out + nb_in, 256, 0, st>>>(X.C, nb_out, (const int4 *)indices, n, n_dev,
+                                                                       (const int4 *)out_indices, n_out, n_out_dev, X.in.cw,
+                                                                       X.in.cr, X.out.cw, X.out.cr, nbr_in, nbr_out, S);
+}
+
+}  // namespace
+
+extern "C" int pcd_rulebook_conv_cm_count(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                                          const int *stride_host, const int *pad_host, const void *in_colmap,
+                                          size_t in_colmap_bytes, int in_cap, int32_t *n_out_dev, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (n < 0 || batch <= 0 || !n_out_dev) return PCD_ERR_INVALID_ARG;
+    CmConvCall X;
+    int rc = cm_conv_setup(n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes, in_cap,
+                           nullptr, 0, 0, workspace, workspace_bytes, X);
+    if (rc != PCD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    CmConvSide S = {};
+    cm_count(X, S, 0, st);
+    cm_total_kernel<<<1, 256, 0, st>>>(X.L.bsums, X.L.ncellblk, cm_spined(X.L.ncellblk), n_out_dev);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// count (+ class counts) -> emit (+ class offsets) -> tables (+ class permutation) -> pair lists: four launches.
+// `counted`: pcd_rulebook_conv_cm_count ran over the same workspace (the two-phase API): the count launch is skipped.
+static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const int *in_shape_host, const int *ksize_host,
+                              const int *stride_host, const int *pad_host, const void *in_colmap, size_t in_colmap_bytes,
+                              int in_cap, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices, void *out_colmap,
+                              size_t out_colmap_bytes, int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
+                              int pad_pairs, int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
+                              void *workspace, size_t workspace_bytes, void *stream, bool counted) {
+    PCD_ENTER();
+    if (n <= 0 || batch <= 0 || n_out_cap <= 0) return PCD_ERR_INVALID_ARG;
+    if (!indices || !out_indices || !nbr_in || !nbr_out || !out_colmap) return PCD_ERR_INVALID_ARG;
+    if ((pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
+    CmConvCall X;
+    int rc = cm_conv_setup(n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes, in_cap,
+                           out_colmap, out_colmap_bytes, n_out_cap, workspace, workspace_bytes, X);
+    if (rc != PCD_OK) return rc;
+    const int ncls = X.G.sd * X.G.sh * X.G.sw;
+    const bool classes = perm != nullptr;
+    if (classes) {
+        if (ncls > CLS_MAX) return PCD_ERR_UNSUPPORTED;
+        if (cls_tile <= 0 || !vstart_dev || vcap < (n + cls_tile - 1) / cls_tile * cls_tile + ncls * cls_tile)
+            return PCD_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const CmConvWs &L = X.L;
+    if (!counted) {
+        CmConvSide S = {};
+        if (pairs) {
+            S.zero = L.wsuper;
+            S.zero_words = X.G.K * L.nws;
+        }
+        if (classes) {
+            S.idx = (const int4 *)indices;
+            S.n = n;
+            S.n_dev = n_dev;
+            S.ncls = ncls;
+            S.blk_cnt = L.blk_cnt;
+            S.pd = X.G.pd; S.ph = X.G.ph; S.pw = X.G.pw;
+        }
+        cm_count(X, S, classes ? L.nclsblk : 0, st);
+    } else {
+        if (pairs) pcd_fill(L.wsuper, 0, (size_t)X.G.K * L.nws * sizeof(int), st);
+        if (classes) return PCD_ERR_INVALID_ARG;      // (the two-phase API builds its classes with pcd_rulebook_conv_classes)
+    }
+    CmEmitSide E = {};
+    if (classes) {
+        E.fill_a = perm;
+        E.fill_a_bytes = (size_t)vcap * sizeof(int32_t);
+        E.blk_cnt = L.blk_cnt;
+        E.cls_nblk = L.nclsblk;
+        E.ncls = ncls;
+        E.cls_tile = cls_tile;
+        E.vstart = vstart_dev;
+    }
+    cm_emit(X, out_indices, n_out_cap, n_out_dev, E, st);
+    CmTablesSide T = {};
+    if (pairs) {
+        T.wave_cnt = L.wave_cnt;
+        T.nwaves = L.nwaves;
+        T.wsuper = L.wsuper;
+        T.nws = L.nws;
+    }
+    if (classes) {
+        T.ncls = ncls;
+        T.blk_off = L.blk_cnt;
+        T.perm = perm;
+    }
+    cm_tables(X, indices, n, n_dev, out_indices, n_out_cap, n_out_dev, nbr_in, nbr_out, T, st);
+    if (pairs) {
+        if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)X.G.K * 2 * n * sizeof(int32_t), st);
+        launch_pairs_fill_super(nbr_in, n, n_dev, X.G.K, 0, L.wave_cnt, L.nwaves, L.wsuper, L.nws, pairs, pair_num, st);
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_rulebook_conv_cm_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                                         const int *ksize_host, const int *stride_host, const int *pad_host,
+                                         const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out,
+                                         int32_t *out_indices, void *out_colmap, size_t out_colmap_bytes, int32_t *nbr_in,
+                                         int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                                         const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream) {
+    return cm_conv_build_impl(indices, n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes,
+                              in_cap, n_out, nullptr, out_indices, out_colmap, out_colmap_bytes, nbr_in, nbr_out, pairs,
+                              pair_num, pad_pairs, 0, nullptr, 0, nullptr, n_dev, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int pcd_rulebook_conv_cm_build(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                                          const int *ksize_host, const int *stride_host, const int *pad_host,
+                                          const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out_cap,
+                                          int32_t *n_out_dev, int32_t *out_indices, void *out_colmap, size_t out_colmap_bytes,
+                                          int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                                          int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (!n_out_dev) return PCD_ERR_INVALID_ARG;
+    return cm_conv_build_impl(indices, n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes,
+                              in_cap, n_out_cap, n_out_dev, out_indices, out_colmap, out_colmap_bytes, nbr_in, nbr_out, pairs,
+                              pair_num, pad_pairs, cls_tile, perm, vcap, vstart_dev, n_dev, workspace, workspace_bytes, stream,
+                              false);
+}

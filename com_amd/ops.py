@@ -197,6 +197,8 @@ def pow2_ge8(c):
     return p
 
 
+USE_COLUMN_MAPS = True      # z-fastest chains build their rulebooks from column maps (colmap.hip); False: flat key-space bitmaps
+
 # row orders of key-numbered levels (pcd_ops.h: PCD_ROWS_ZYX / PCD_ROWS_YXZ)
 ROWS_ZYX, ROWS_YXZ = 0, 1
 ROW_ORDERS = {"first": ROWS_ZYX, "key": ROWS_ZYX, "zyx": ROWS_ZYX, "yxz": ROWS_YXZ}
@@ -283,15 +285,26 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
                       L.stream_ptr()), "pcd_voxelize_hard")
     gz, gy, gx = grid_size(point_cloud_range, voxel_size)[::-1]
     gz = max(gz, int(key_depth))
+
+    def rank_of(rows, n_dev):
+        """the coordinate -> row map handed to the level-1 rulebook builds: z-fastest rows get a ColumnMap (O(rows) to
+        build, 2 MB to probe), (b, z, y, x) rows keep the voxeliser's flat bitmap"""
+        if rank_bm is None:
+            return None
+        if row_order == "yxz" and USE_COLUMN_MAPS and gz <= 62 and rows.shape[0] > 0:
+            prev = out.get("rank") if (out is not None and static) else None
+            cm = colmap_from_rows(rows, batch, [gz, gy, gx], n_dev=n_dev,
+                                  out=prev if isinstance(prev, ColumnMap) else None)
+            return cm
+        return RankMap(None, rank_bm, rank_px, rows, [gz, gy, gx], 4, ROW_ORDERS[row_order])
+
     if static:
         # no read-back: outputs stay at capacity, the row count stays on the device
         num_rows = counts[batch:batch + 1]
         PLAN.record("voxels", num_rows, cap)
         return dict(voxels=voxels, coords=coords, num_points=nump, voxel_features=mean,
                     voxel_features_bf16=mean16, counts=counts, num_rows=num_rows, rank_bitmap=rank_bm,
-                    rank_prefix=rank_px,
-                    rank=RankMap(None, rank_bm, rank_px, coords, [gz, gy, gx], 4, ROW_ORDERS[row_order])
-                    if rank_bm is not None else None)
+                    rank_prefix=rank_px, rank=rank_of(coords, num_rows))
     host_counts = counts.tolist()          # the one host sync: data-dependent number of voxels
     m = host_counts[-1]
     if PLAN is not None:
@@ -300,8 +313,7 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     return dict(num_rows=None,voxels=voxels[:m] if want_voxels else None, coords=coords_m, num_points=nump[:m],
                 voxel_features=mean[:m] if want_mean else None,
                 voxel_features_bf16=mean16[:m] if mean16 is not None else None, counts=host_counts[:-1],
-                rank=RankMap(None, rank_bm, rank_px, coords_m, [gz, gy, gx], 4, ROW_ORDERS[row_order])
-                if rank_bm is not None else None)
+                rank=rank_of(coords_m, None))
 
 
 def mean_vfe(voxels, num_points):
@@ -491,6 +503,43 @@ class RankMap:
         return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
 
 
+class ColumnMap:
+    """Coordinate -> row map of a level whose rows are numbered z-fastest (ROWS_YXZ): BEV occupancy words + one record per
+    occupied BEV cell (z mask, first row) in ONE device buffer (include/pcd_ops.h: "Column maps").  `cap` is the row capacity
+    the buffer was laid out for; `indices` the coordinate tensor the rows refer to."""
+    order = ROWS_YXZ
+
+    def __init__(self, buf, cap, indices, shape, batch_size):
+        self.buf, self.cap, self.indices, self.shape, self.batch_size = buf, int(cap), indices, list(shape), int(batch_size)
+
+    def matches(self, indices, shape, ks):
+        return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
+
+    def serves(self, indices, shape, batch_size):
+        return indices is self.indices and list(shape) == self.shape and int(batch_size) == self.batch_size
+
+
+def colmap_from_rows(indices, batch_size, spatial_shape, n_dev=None, out=None):
+    """ColumnMap of rows given in (b, y, x, z) order (level 1: the key-ordered voxeliser's output).  `out`: a ColumnMap of the
+    same geometry whose buffer is written again (static buffers)."""
+    _require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
+    lib = L.lib()
+    shp = _triple(spatial_shape)
+    n, dev = indices.shape[0], indices.device
+    nbytes = lib.pcd_colmap_bytes(batch_size, L.host_i32(shp), max(n, 1))
+    if nbytes == 0:
+        raise L.PcdError("pcd_colmap_bytes: BEV plane too large")
+    if out is not None and out.buf.numel() == nbytes and out.cap == max(n, 1) and out.buf.device == dev:
+        buf = out.buf
+    else:
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    ws = _ws(lib.pcd_colmap_from_rows_workspace_bytes(batch_size, L.host_i32(shp)), dev)
+    L.check(lib.pcd_colmap_from_rows(L.ptr(indices), n, L.ptr(n_dev), batch_size, L.host_i32(shp), L.ptr(buf), buf.numel(),
+                                     L.ptr(ws), ws.numel(), L.stream_ptr()), "pcd_colmap_from_rows")
+    return ColumnMap(buf, max(n, 1), indices, shp, batch_size)
+
+
 def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False,
                   n_dev=None, rank=None):
     """`rank`: the RankMap of the strided build whose out_indices these `indices` are -- the rulebook is then
@@ -509,7 +558,14 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
         p_ = int((nbr >= 0).sum().item())
         return dict(bytes=16 * n + 8 * p_, flops=0, rows=n, pairs=p_)
 
-    if rank is not None and rank.matches(indices, shp, ks):
+    if isinstance(rank, ColumnMap) and rank.matches(indices, shp, ks) and dl == [1, 1, 1]:
+        ws = _ws(lib.pcd_rulebook_subm_cm_workspace_bytes(n), dev)
+        with _Timed("rulebook_subm_cm", meta):
+            L.check(lib.pcd_rulebook_subm_cm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.ptr(rank.buf),
+                                             rank.buf.numel(), rank.cap, L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num),
+                                             int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_rulebook_subm_cm")
+    elif isinstance(rank, RankMap) and rank.matches(indices, shp, ks):
         ws = _ws(lib.pcd_rulebook_subm_ranked_workspace_bytes(n, K), dev)
         with _Timed("rulebook_subm_ranked", meta):
             entry = lib.pcd_rulebook_subm_ranked4 if rank.prefix_words == 4 else lib.pcd_rulebook_subm_ranked
@@ -527,13 +583,16 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
                   [k // 2 for k in ks], dl, n_in_dev=n_dev, n_out_dev=n_dev)
     if rank is not None and rank.matches(indices, shp, ks):
         rb.order = rank.order
+        rb.rank = rank
     return rb
 
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
-                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX):
+                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX, in_rank=None):
     """`order`: how the OUTPUT rows are numbered (ROWS_ZYX: ascending (b, z, y, x), spconv's sorted order; ROWS_YXZ:
-    ascending (b, y, x, z)); the input rows may come in any order."""
+    ascending (b, y, x, z)); the input rows may come in any order.
+    `in_rank`: the ColumnMap of the INPUT level (rows in ROWS_YXZ order): the build then derives the output level's map from
+    it (pcd_rulebook_conv_cm_*: no map over the output volume, no atomics) -- same outputs; rb.rank is the output's map."""
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -544,6 +603,12 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     lib = L.lib()
     args = (L.host_i32(shp), L.host_i32(ks), L.host_i32(st), L.host_i32(pd), L.host_i32(dl))
     out_shape = conv_out_shape(shp, ks, st, pd, dl)
+    if isinstance(in_rank, ColumnMap) and order == ROWS_YXZ and n > 0 and dl == [1, 1, 1] \
+            and in_rank.serves(indices, shp, batch_size):
+        rb = _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank,
+                               out_shape)
+        if rb is not None:
+            return rb
     wsb = lib.pcd_rulebook_conv_workspace_bytes(n, batch_size, *args)
     if wsb == 0:
         raise L.PcdError("pcd_rulebook_conv: bad geometry or key space too large")
@@ -630,6 +695,90 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 
 
 CLS_TILE = 256
+
+
+def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank, out_shape):
+    """rulebook_conv through the column maps (None: geometry outside what pcd_rulebook_conv_cm_* covers)."""
+    lib = L.lib()
+    dev = indices.device
+    n = indices.shape[0]
+    K = ks[0] * ks[1] * ks[2]
+    geo = (L.host_i32(shp), L.host_i32(ks), L.host_i32(st), L.host_i32(pd))
+    wsb = lib.pcd_rulebook_conv_cm_workspace_bytes(n, batch_size, *geo)
+    if wsb == 0:
+        return None
+    ws = _ws(wsb, dev)
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    static = PLAN is not None and PLAN.active
+    ncls = st[0] * st[1] * st[2]
+    inmap = (L.ptr(in_rank.buf), in_rank.buf.numel(), in_rank.cap)
+
+    def outputs(n_out):
+        cmb = lib.pcd_colmap_bytes(batch_size, L.host_i32(out_shape), max(n_out, 1))
+        return (torch.empty((n_out, 4), dtype=torch.int32, device=dev),
+                torch.empty((K, n), dtype=torch.int32, device=dev),
+                torch.empty((K, n_out), dtype=torch.int32, device=dev),
+                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None,
+                torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None,
+                torch.empty((cmb,), dtype=torch.uint8, device=dev))
+
+    def meta():                                  # SURVEY 8d: read 16 N_in, write 8 P + 16 N_out
+        p_ = int((nbr_in >= 0).sum().item())
+        return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
+
+    classes = None
+    if static:
+        n_out = PLAN.cap(plan_key)
+        PLAN.record(plan_key, n_out_dev, n_out)
+        out_indices, nbr_in, nbr_out, pairs, pair_num, cmap = outputs(n_out)
+        perm = vstart = None
+        vcap = 0
+        if want_pairs and ncls <= 8:
+            vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
+            perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
+            vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
+            classes = (perm, vstart, vcap)
+        with _Timed("rulebook_conv_build", meta):
+            L.check(lib.pcd_rulebook_conv_cm_build(L.ptr(indices), n, batch_size, *geo, *inmap, n_out, L.ptr(n_out_dev),
+                                                   L.ptr(out_indices), L.ptr(cmap), cmap.numel(), L.ptr(nbr_in),
+                                                   L.ptr(nbr_out), L.ptr(pairs), L.ptr(pair_num), int(pad_pairs), CLS_TILE,
+                                                   L.ptr(perm), vcap, L.ptr(vstart), L.ptr(n_dev), L.ptr(ws), ws.numel(),
+                                                   L.stream_ptr()), "pcd_rulebook_conv_cm_build")
+    else:
+        with _Timed("rulebook_conv_count", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
+            L.check(lib.pcd_rulebook_conv_cm_count(n, batch_size, *geo, *inmap, L.ptr(n_out_dev), L.ptr(ws), ws.numel(),
+                                                   L.stream_ptr()), "pcd_rulebook_conv_cm_count")
+        n_out = int(n_out_dev.item())          # host sync: data-dependent number of output rows
+        if PLAN is not None and plan_key is not None:
+            PLAN.observe(plan_key, n_out)
+        out_indices, nbr_in, nbr_out, pairs, pair_num, cmap = outputs(n_out)
+        if n_out > 0:
+            with _Timed("rulebook_conv_fill", meta):
+                L.check(lib.pcd_rulebook_conv_cm_fill(L.ptr(indices), n, batch_size, *geo, *inmap, n_out, L.ptr(out_indices),
+                                                      L.ptr(cmap), cmap.numel(), L.ptr(nbr_in), L.ptr(nbr_out), L.ptr(pairs),
+                                                      L.ptr(pair_num), int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(),
+                                                      L.stream_ptr()), "pcd_rulebook_conv_cm_fill")
+        else:
+            nbr_in.fill_(-1)
+            if pair_num is not None:
+                pair_num.zero_()
+    rb = Rulebook(False, K, n, n_out, nbr_out, nbr_in, pairs, pair_num, out_indices, out_shape, ks, st, pd, dl,
+                  n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
+    rb.rank = ColumnMap(cmap, max(n_out, 1), out_indices, out_shape, batch_size) if n_out > 0 else None
+    rb.order = ROWS_YXZ
+    if classes is not None:
+        rb.classes = classes
+    elif want_pairs and ncls <= 8:
+        vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
+        perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
+        vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
+        cws = _ws(lib.pcd_rulebook_conv_classes_workspace_bytes(n), dev)
+        with _Timed("rulebook_conv_classes", lambda: dict(bytes=0, flops=0, rows=n, pairs=0)):
+            L.check(lib.pcd_rulebook_conv_classes(L.ptr(indices), n, L.host_i32(st), L.host_i32(pd), CLS_TILE,
+                                                  L.ptr(perm), vcap, L.ptr(vstart), L.ptr(n_dev), L.ptr(cws),
+                                                  cws.numel(), L.stream_ptr()), "pcd_rulebook_conv_classes")
+        rb.classes = (perm, vstart, vcap)
+    return rb
 
 
 import os as _os

@@ -190,7 +190,9 @@ class SparseConvolution(SparseModule):
                                    want_pairs=self._needs_backward(x),   # (pair lists / parity classes: backward only)
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)),
                                    # the chain's row order (set by the backbone from the voxeliser's rank map)
-                                   order=x.indice_dict.get("__row_order__", ops.ROWS_ZYX))
+                                   order=x.indice_dict.get("__row_order__", ops.ROWS_ZYX),
+                                   # (z-fastest chains: the input level's column map -> the output level's)
+                                   in_rank=x.indice_dict.get(("__rank__", x.indices.data_ptr()), None))
             out_idx, out_shape = rb.out_indices, rb.out_shape
             if rb.rank is not None:
                 x.indice_dict[("__rank__", out_idx.data_ptr())] = rb.rank

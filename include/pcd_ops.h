@@ -84,7 +84,9 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "wg_rows" 6144        row-range split of the generic weight-gradient kernel
  *   "conv2d_wb" 1, "conv2d_wg_blocks" 128, "conv2d_wgp_mode2" 0, "conv2d_wgp_blocks" 512   dense 3x3 conv variants
  *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
- *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only) */
+ *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only)
+ *   "cm_direct_blocks" 4096   column-map builds: up to this many scan blocks add up the block sums themselves, beyond it a
+ *                             spine launch runs (tests lower it to reach the spine path on small inputs) */
 int pcd_set_option(const char *key, int value);
 int pcd_get_option(const char *key, int *value_out);
 
@@ -268,6 +270,54 @@ int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int
                              const int32_t *prefix, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
                              int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
                              void *stream, int row_order);
+
+/* ---- Column maps: the coordinate -> row map of a level whose rows are numbered z-fastest (PCD_ROWS_YXZ) ----------
+ * In (b, y, x, z) order the rows of one BEV cell (a COLUMN) are consecutive and ordered by z, so a level's map is
+ *     words  [B*H*W / 32]: { occupancy bits of 32 BEV cells, occupied cells in front of the word }       (8 bytes each)
+ *     columns [<= rows]   : { z mask (64 bits), first row, rows }                                        (16 bytes each)
+ * -- O(BEV area / 32) + O(rows) bytes instead of a bitmap over the (b, y, x, z) key space (371 M cells at level 1 of a
+ * 4-frame Waymo batch).  The map lives in ONE caller-owned buffer of pcd_colmap_bytes(batch, shape (D, H, W), n_cap)
+ * bytes (n_cap = row capacity of the level = column capacity; the same n_cap must be passed wherever the buffer is read).
+ * D <= 62; the builds below cover dilation 1, kernels 3x3x3 and (3,1,1), strides 1 / 2 per axis (every conv of
+ * pcdet/models/backbones_3d/spconv_backbone.py:69-293) and return PCD_ERR_UNSUPPORTED otherwise (0 from the
+ * _workspace_bytes query): callers then take pcd_rulebook_conv_* / pcd_rulebook_subm.
+ *   pcd_colmap_from_rows: the map of a row set given in (b, y, x, z) order (level 1: the key-ordered voxeliser's output).
+ *   pcd_rulebook_subm_cm: pcd_rulebook_subm's outputs (bit for bit) for a 3x3x3 SubM conv (spconv_backbone.py:12-13) from
+ *       the level's map: nine column lookups per row serve the 27 offsets; no hash table, no atomics.
+ *   pcd_rulebook_conv_cm_{count,fill,build}: pcd_rulebook_conv_{count,fill,build}'s outputs for a strided conv
+ *       (spconv_backbone.py:14-15,205-229) with row_order PCD_ROWS_YXZ, from the INPUT level's map; additionally writes
+ *       the OUTPUT level's map (out_colmap, sized for n_out / n_out_cap rows).  An output column exists iff one of its
+ *       kh x kw input columns does; its z mask is the OR of theirs, shifted by the padding, smeared over the kd taps and
+ *       compressed by the stride: one thread per output BEV cell, no atomics, no map of the output volume.  Launches:
+ *       count (+ class counts) -> emit map + coordinates (+ class offsets) -> both neighbour tables (+ class
+ *       permutation) -> pair lists.  _count / _fill share one untouched workspace (the host reads n_out in between). */
+size_t pcd_colmap_bytes(int batch, const int *shape_host, int n_cap);
+size_t pcd_colmap_from_rows_workspace_bytes(int batch, const int *shape_host);
+int pcd_colmap_from_rows(const int32_t *indices, int n, const int32_t *n_dev, int batch, const int *shape_host,
+                         void *colmap, size_t colmap_bytes, void *workspace, size_t workspace_bytes, void *stream);
+size_t pcd_rulebook_subm_cm_workspace_bytes(int n);
+int pcd_rulebook_subm_cm(const int32_t *indices, int n, int batch, const int *shape_host, const void *colmap,
+                         size_t colmap_bytes, int colmap_cap, int32_t *nbr, int32_t *pairs, int32_t *pair_num,
+                         int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+size_t pcd_rulebook_conv_cm_workspace_bytes(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                                            const int *stride_host, const int *pad_host);
+int pcd_rulebook_conv_cm_count(int n, int batch, const int *in_shape_host, const int *ksize_host,
+                               const int *stride_host, const int *pad_host, const void *in_colmap,
+                               size_t in_colmap_bytes, int in_cap, int32_t *n_out_dev, void *workspace,
+                               size_t workspace_bytes, void *stream);
+int pcd_rulebook_conv_cm_fill(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                              const int *ksize_host, const int *stride_host, const int *pad_host,
+                              const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out,
+                              int32_t *out_indices, void *out_colmap, size_t out_colmap_bytes, int32_t *nbr_in,
+                              int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                              const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+int pcd_rulebook_conv_cm_build(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                               const int *ksize_host, const int *stride_host, const int *pad_host,
+                               const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out_cap,
+                               int32_t *n_out_dev, int32_t *out_indices, void *out_colmap, size_t out_colmap_bytes,
+                               int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                               int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* Optional per-channel reductions of the OUTPUT tile in the epilogue of pcd_sparse_conv_gather_gemm /
  * pcd_sparse_conv_dgrad_classes (bf16 outputs only; NULL or mode 0 = off).  The BatchNorm1d that follows every conv of
