@@ -908,6 +908,10 @@ def main():
         bd = model.map_to_bev_module(model.backbone_3d(model.vfe(dict(bd2))))
         if ops.STAMPS is not None and bd["spatial_features"].requires_grad:
             bd["spatial_features"].register_hook(lambda g: ops.stamp("dense_bwd_end"))
+        if bd2.get("at_backward_start") is not None and bd["spatial_features"].requires_grad:
+            # (experiment PCD_VOX_AT=bwd: the next batch is voxelised beside the START of the backward pass)
+            hook_ = bd2["at_backward_start"]
+            bd["spatial_features"].register_hook(lambda g: (hook_(), None)[1])
         if args.dense_head:
             # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, conv2d.hip kernels), then the REAL CenterHead step of the
             # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
@@ -1057,7 +1061,14 @@ def main():
                             assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
                             ops.stamp("vox_end")
 
-                    if VOX_EARLY:
+                    if os.environ.get('PCD_VOX_AT') == 'bwd':
+                        bd_in = dict(vox_out)
+                        bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
+                        if "voxel_num_rows" in vox_out:
+                            bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
+                        bd_in["at_backward_start"] = voxelize_next
+                        train_from_voxels(bd_in)
+                    elif VOX_EARLY:
                         # The next batch is voxelised in the MIDDLE of this step's forward pass, on the rulebook stream behind its
                         # last unit (the last reader of the voxeliser's buffers; the stream is idle from there on), instead of after
                         # the backward pass, where its 245 us were the tail of the step.  (On a stream of its own, forked there, the

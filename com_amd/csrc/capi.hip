@@ -71,3 +71,36 @@ extern "C" int pcd_get_option(const char *key, int *value_out) {
         }
     return PCD_ERR_INVALID_ARG;
 }
+
+// ---- diagnostics for tools/exp_cu_mask.py -----------------------------------------------------------------------------
+// A stream restricted to the compute units whose bits are set in cu_mask (hipExtStreamCreateWithCUMask), and a kernel that
+// keeps `blocks` workgroups of 1024 threads busy for `ticks` ticks of the 100 MHz device clock: how long a launch of 256 of
+// them takes says how many CUs it was given -- eagerly, and when the launch is replayed as a hipGraph kernel node.
+static __global__ __launch_bounds__(1024) void debug_spin_kernel(unsigned long long ticks, unsigned *xcc_seen) {
+    const unsigned long long t0 = wall_clock64();
+    if (xcc_seen && threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        atomicOr(xcc_seen, 1u << (xcc & 15u));
+    }
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+extern "C" int pcd_debug_stream_create_cu_mask(const uint32_t *cu_mask, int words, void **stream_out) {
+    if (!cu_mask || words <= 0 || !stream_out) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask);
+    if (e != hipSuccess) {
+        pcd_set_last_hip_error((int)e);
+        return PCD_ERR_LAUNCH;
+    }
+    *stream_out = (void *)st;
+    return PCD_OK;
+}
+extern "C" int pcd_debug_spin(int blocks, unsigned long long ticks, uint32_t *xcc_seen, void *stream) {
+    PCD_ENTER();
+    if (blocks <= 0) return PCD_ERR_INVALID_ARG;
+    debug_spin_kernel<<<blocks, 1024, 0, (hipStream_t)stream>>>(ticks, xcc_seen);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

@@ -12,15 +12,22 @@
 //
 // A strided conv's OUTPUT map follows from the input map alone: output column (b, oy, ox) exists iff one of its kh x kw
 // input columns does; its z mask is the OR of their masks shifted by the padding, smeared over the kd kernel taps and
-// (stride 2) compressed to the even bits.  One thread per output BEV cell; two passes (count, emit) around block sums.
-// No atomics, no zero-fill of a map of the output volume, no scatter: every table entry is written exactly once by the
-// thread that owns its row.
+// (stride 2) compressed to the even bits.  BEV keys use a row pitch rounded up to 32 cells, so a word never straddles two BEV
+// rows and the OCCUPANCY of 32 output cells is a few shifts over 4 input words per kernel row (one lane per output word);
+// the occupied cells of a wave's 64 words (5-10 % of the cells) are then compacted so that every lane gathers the z masks of
+// ONE occupied cell.  Two passes (count, emit) around per-wave sums.  No atomics, no zero-fill of a map of the output
+// volume, no scatter: every table entry is written exactly once by the thread that owns its row.
 #include "rulebook_common.h"
 
 namespace {
 
-constexpr int CM_CELLS_PER_BLOCK = 2048;              // 4 waves x 8 groups of 64 cells
-constexpr int CM_GROUPS_PER_BLOCK = CM_CELLS_PER_BLOCK / 64;
+// A wave takes 2^wshift output words (32 BEV cells each), one per lane: 64 at the large levels, fewer where that would leave
+// too few waves to hide the gathers' latency (level 5 of a 4-frame batch is 4.5 k words in all).
+static inline int cm_wshift(int nwords_out) {
+    int s = 6;
+    while (s > 2 && (nwords_out >> s) < 2048) --s;
+    return s;
+}
 // block sums are added up by the consuming block up to "cm_direct_blocks" blocks (4096: 16 loads per thread), a spine launch beyond
 static inline bool cm_spined(int nblk) { return nblk > pcd_opt(PCD_OPT_CM_DIRECT_BLOCKS); }
 
@@ -28,17 +35,21 @@ struct CmBuf {            // a level's column map inside ONE caller-owned buffer
     uint2 *cw;            // [nwords + 2]
     uint4 *cr;            // [ncol_cap + 1]
     int *ncols;           // [4]: columns, rows (diagnostics)
-    size_t nwords;        // whole groups of 64 cells: 2 words per group
+    size_t nwords;        // batch * H * pitch / 32
     int ncol_cap;
-    int cells;
+    int pitch;            // BEV row pitch in cells: W rounded up to 32
 };
 
+static inline int cm_pitch(int W) { return (W + 31) & ~31; }
+
 bool cm_carve(void *p, size_t bytes, int batch, int H, int W, int n_cap, CmBuf &B, size_t *need) {
-    const double cells = (double)batch * H * W;
-    if (batch <= 0 || H <= 0 || W <= 0 || cells >= 2147483647.0 - 4096.0) return false;
-    B.cells = (int)cells;
-    B.nwords = (size_t)pcd_div_up(B.cells, 64) * 2;
-    B.ncol_cap = n_cap < B.cells ? (n_cap > 0 ? n_cap : 1) : B.cells;
+    if (batch <= 0 || H <= 0 || W <= 0) return false;
+    B.pitch = cm_pitch(W);
+    const double cells = (double)batch * H * B.pitch;
+    if (cells >= 2147483647.0 - 4096.0) return false;
+    B.nwords = (size_t)cells / 32;
+    const int real = batch * H * W;
+    B.ncol_cap = n_cap < real ? (n_cap > 0 ? n_cap : 1) : real;
     WsCarver ws(p, bytes);
     B.cw = ws.take<uint2>(B.nwords + 2);
     B.cr = ws.take<uint4>((size_t)B.ncol_cap + 1);
@@ -48,7 +59,7 @@ bool cm_carve(void *p, size_t bytes, int batch, int H, int W, int n_cap, CmBuf &
 }
 
 // ---- lookups ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 bev_key(int b, int y, int x, int H, int W) { return ((u32)b * H + y) * W + x; }
+__device__ __forceinline__ u32 bev_key(int b, int y, int x, int H, int pitch) { return ((u32)b * H + y) * pitch + x; }
 
 // column index of a BEV cell given its word, or -1
 __device__ __forceinline__ int cm_col(uint2 w, u32 key, int ncol_cap) {
@@ -66,16 +77,13 @@ __device__ __forceinline__ int cm_row(u64 zm, int start, int z) {
 __device__ __forceinline__ bool same_column(int4 a, int4 c) { return a.x == c.x && a.z == c.z && a.w == c.w; }
 
 __global__ __launch_bounds__(256) void cm_rows_mark_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
-                                                           int H, int W, u32 *__restrict__ bits) {
+                                                           int H, int P, u32 *__restrict__ bits) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= eff_rows(n_dev, n)) return;
     const int4 c = idx[i];
     if (i > 0 && same_column(idx[i - 1], c)) return;
-    const u32 key = bev_key(c.x, c.z, c.w, H, W);
-    // the heads of a wave are in ascending key order: lanes that share a word with the head in front of them hand their bit
-    // down; one atomic per (wave, word)
-    u32 word = key >> 5, mine = 1u << (key & 31u);
-    atomicOr(bits + word, mine);
+    const u32 key = bev_key(c.x, c.z, c.w, H, P);
+    atomicOr(bits + (key >> 5), 1u << (key & 31u));      // one per column (a third of the rows), no return value
 }
 
 // words -> block sums of set bits (1024 words per block)
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void cm_words_prefix_kernel(const u32 *__restr
 
 // head rows write their column's record: z mask and length from the rows that follow
 __global__ __launch_bounds__(256) void cm_rows_fill_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
-                                                           int H, int W, const uint2 *__restrict__ cw,
+                                                           int H, int P, const uint2 *__restrict__ cw,
                                                            uint4 *__restrict__ cr, int ncol_cap, int *__restrict__ ncols) {
     const int nn = eff_rows(n_dev, n);
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void cm_rows_fill_kernel(const int4 *__restric
     if (i >= nn) return;
     const int4 c = idx[i];
     if (i > 0 && same_column(idx[i - 1], c)) return;
-    const u32 key = bev_key(c.x, c.z, c.w, H, W);
+    const u32 key = bev_key(c.x, c.z, c.w, H, P);
     const int col = cm_col(cw[key >> 5], key, ncol_cap);
     if (col < 0) return;
     u64 zm = 1ull << c.y;
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void cm_rows_fill_kernel(const int4 *__restric
 // One thread per row: the nine columns (dy, dx) of its neighbourhood, each looked up once (word, then record) and serving
 // the three z-neighbours.  Neighbouring rows of a wave share columns: the loads hit the same few lines.
 __global__ __launch_bounds__(256) void cm_subm_kernel(const int4 *__restrict__ idx, int n, const int32_t *n_dev,
-                                                      int D, int H, int W, const uint2 *__restrict__ cw,
+                                                      int D, int H, int W, int P, const uint2 *__restrict__ cw,
                                                       const uint4 *__restrict__ cr, int ncol_cap,
                                                       int32_t *__restrict__ nbr, int *__restrict__ wave_cnt, int nwaves) {
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(256) void cm_subm_kernel(const int4 *__restrict__ i
     for (int q = 0; q < 9; ++q) {
         const int y = c.z + q / 3 - 1, x = c.w + q % 3 - 1;
         in[q] = live && y >= 0 && y < H && x >= 0 && x < W;
-        key[q] = in[q] ? bev_key(c.x, y, x, H, W) : 0u;
+        key[q] = in[q] ? bev_key(c.x, y, x, H, P) : 0u;
         w[q] = cw[key[q] >> 5];
     }
     uint4 r[9];
@@ -206,7 +214,9 @@ __global__ __launch_bounds__(256) void cm_subm_kernel(const int4 *__restrict__ i
 struct CmGeom {
     int D, H, W, Do, Ho, Wo;
     int kd, sd, sh, sw, pd, ph, pw;
-    int cells;            // batch * Ho * Wo
+    int P, Po;            // BEV row pitches (cells) of the input / output map
+    int nwords_out;       // batch * Ho * Po / 32
+    int wshift;           // log2(output words per wave)
     int ncol_cap_in, ncol_cap_out;
 };
 
@@ -240,7 +250,7 @@ __device__ __forceinline__ u64 in_union(const CmGeom &G, const uint2 *__restrict
     for (int q = 0; q < KH * KW; ++q) {
         const int y = oy * G.sh - G.ph + q / KW, x = ox * G.sw - G.pw + q % KW;
         in[q] = y >= 0 && y < G.H && x >= 0 && x < G.W;
-        key[q] = in[q] ? bev_key(b, y, x, G.H, G.W) : 0u;
+        key[q] = in[q] ? bev_key(b, y, x, G.H, G.P) : 0u;
         w[q] = cw[key[q] >> 5];
     }
     u64 m = 0;
@@ -275,18 +285,88 @@ struct CmConvSide {         // by-products of the count launch
     int pd, ph, pw;
 };
 
-// pass 1: per group of 64 output cells { occupancy bits, rows }, per block { columns, rows }
+// Occupancy of the 32 output cells (b, oy, 32 xb ..) from the input map's words alone: per kernel row the four input words
+// around input word xb * sw, as a 128-bit window; out bit j = OR_kx window[32 + j * sw - pw + kx].
+template <int KH, int KW>
+__device__ __forceinline__ u32 out_occupancy(const CmGeom &G, const uint2 *__restrict__ cw, int b, int oy, int xb) {
+    const int wpr = G.P >> 5, wb = xb * G.sw;
+    u32 w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+        const int y = oy * G.sh - G.ph + ky;
+        if (y < 0 || y >= G.H) continue;
+        const uint2 *row = cw + (size_t)(b * G.H + y) * wpr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wi = wb - 1 + j;
+            if (wi >= 0 && wi < wpr) w[j] |= row[wi].x;
+        }
+    }
+    const u64 lo = (u64)w[0] | ((u64)w[1] << 32), hi = (u64)w[2] | ((u64)w[3] << 32);
+    u64 t = 0;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+        const int sh = 32 - G.pw + kx;                    // 0 < sh < 64 (pw <= 31)
+        t |= (lo >> sh) | (hi << (64 - sh));
+    }
+    u32 occ = G.sw == 2 ? compress_even(t) : (u32)t;
+    const int valid = G.Wo - (xb << 5);                   // cells of the word inside the row
+    if (valid < 32) occ &= (1u << (valid > 0 ? valid : 0)) - 1u;
+    return occ;
+}
+
+// position of the k-th (0-based) set bit of v (k < popcount(v))
+__device__ __forceinline__ int kth_set_bit(u32 v, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int half = 16; half >= 1; half >>= 1) {
+        const int c = __popc(v & ((1u << half) - 1u));
+        if (k >= c) {
+            k -= c;
+            v >>= half;
+            pos += half;
+        }
+    }
+    return pos;
+}
+
+// The occupied cells of a wave's 64 words, one per lane and round: lane `idx - base` of round `base` takes the idx-th
+// occupied cell in cell order (word = last one whose exclusive count is <= idx, bit = the (idx - count)-th set one).
+struct CmWaveCells {
+    u32 *occ_s;           // LDS [64]: occupancy word of every lane
+    int *excl_s;          // LDS [64]: occupied cells in front of the word, inside the wave
+    int total;
+};
+__device__ __forceinline__ CmWaveCells cm_wave_cells(u32 occ, u32 *occ_s, int *excl_s) {
+    const int c = __popc(occ);
+    const int inc = wave_inclusive_scan(c);
+    occ_s[lane_id()] = occ;
+    excl_s[lane_id()] = inc - c;
+    __syncthreads();                                      // (every wave of a cell block gets here; orders the LDS writes)
+    CmWaveCells Wc = {occ_s, excl_s, __shfl(inc, 63)};
+    return Wc;
+}
+__device__ __forceinline__ void cm_wave_cell(const CmWaveCells &Wc, int idx, int &word_lane, int &bit) {
+    int lo = 0;                                           // largest l with excl_s[l] <= idx
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1)
+        if (Wc.excl_s[lo + step] <= idx) lo += step;      // (lo + step <= 63)
+    word_lane = lo;
+    bit = kth_set_bit(Wc.occ_s[lo], idx - Wc.excl_s[lo]);
+}
+
+// pass 1: { occupied cells, rows } per wave of 64 output words
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void cm_conv_count_kernel(CmGeom G, int ncellblk, const uint2 *__restrict__ cw,
-                                                            const uint4 *__restrict__ cr, uint4 *__restrict__ ginfo,
-                                                            int2 *__restrict__ bsums, CmConvSide S) {
-    __shared__ int lds[4];
+                                                            const uint4 *__restrict__ cr, int2 *__restrict__ bsums,
+                                                            CmConvSide S) {
     __shared__ int ccnt[CLS_MAX];
+    __shared__ u32 occ_s[4][64];
+    __shared__ int excl_s[4][64];
     if ((int)blockIdx.x >= ncellblk) {
         const int i = ((int)blockIdx.x - ncellblk) * 256 + threadIdx.x;
         int cls = -1;
         if (i < eff_rows(S.n_dev, S.n)) cls = row_class(S.idx[i], S.pd, S.ph, S.pw, G.sd, G.sh, G.sw);
-        // (block_class_counts indexes blk_cnt by blockIdx.x / gridDim.x: shift the pointer so that the class blocks count from 0)
         if (threadIdx.x < CLS_MAX) ccnt[threadIdx.x] = 0;
         __syncthreads();
         for (int q = 0; q < S.ncls; ++q) {
@@ -302,55 +382,56 @@ __global__ __launch_bounds__(256) void cm_conv_count_kernel(CmGeom G, int ncellb
         for (int e = blockIdx.x * 256 + threadIdx.x; e < S.zero_words; e += ncellblk * 256) S.zero[e] = 0;
     }
     const int wave = threadIdx.x >> 6;
-    int ncols = 0, nrows = 0;
-    for (int it = 0; it < CM_GROUPS_PER_BLOCK / 4; ++it) {
-        const int cell = blockIdx.x * CM_CELLS_PER_BLOCK + (wave * (CM_GROUPS_PER_BLOCK / 4) + it) * 64 + lane_id();
-        u64 zm = 0;
-        if (cell < G.cells) {
-            const int ox = cell % G.Wo, t = cell / G.Wo;
-            const u64 m = in_union<KH, KW>(G, cw, cr, t / G.Ho, t % G.Ho, ox);
-            if (m) zm = squash_z(m, G);
-        }
-        const u64 bits = __ballot(zm != 0);
-        int rows = __popcll(zm);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rows += __shfl_xor(rows, d, 64);
-        if (lane_id() == 0) {
-            if (cell < G.cells) ginfo[cell >> 6] = make_uint4((u32)bits, (u32)(bits >> 32), (u32)rows, 0u);
-            ncols += __popcll(bits);
-            nrows += rows;
+    const int word0 = (blockIdx.x * 4 + wave) << G.wshift, word = word0 + lane_id();
+    const int wpr = G.Po >> 5;
+    u32 occ = 0;
+    if (lane_id() < (1 << G.wshift) && word < G.nwords_out) {
+        const int t = word / wpr;
+        occ = out_occupancy<KH, KW>(G, cw, t / G.Ho, t % G.Ho, word % wpr);
+    }
+    const CmWaveCells Wc = cm_wave_cells(occ, occ_s[wave], excl_s[wave]);
+    int rows = 0;
+    for (int base = 0; base < Wc.total; base += 64) {
+        const int idx = base + lane_id();
+        if (idx < Wc.total) {
+            int wl, bit;
+            cm_wave_cell(Wc, idx, wl, bit);
+            const int wd = word0 + wl, t = wd / wpr;
+            const u64 m = in_union<KH, KW>(G, cw, cr, t / G.Ho, t % G.Ho, ((wd % wpr) << 5) + bit);
+            rows += __popcll(squash_z(m, G));
         }
     }
-    const int tc = block_sum(ncols, lds);
-    const int tr = block_sum(nrows, lds);
-    if (threadIdx.x == 0) bsums[blockIdx.x] = make_int2(tc, tr);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rows += __shfl_xor(rows, d, 64);
+    if (lane_id() == 0) bsums[blockIdx.x * 4 + wave] = make_int2(Wc.total, rows);
 }
 
-// exclusive scan of the block sums (only beyond "cm_direct_blocks" blocks): one block, in place, totals -> bsums[nblk]
-__global__ __launch_bounds__(256) void cm_spine2_kernel(int2 *bsums, int nblk) {
+// exclusive scan of the wave sums (only beyond "cm_direct_blocks" entries): one block, in place, totals -> bsums[nent]
+__global__ __launch_bounds__(256) void cm_spine2_kernel(int2 *bsums, int nent) {
     __shared__ int lds[4];
     __shared__ int2 carry_s;
     if (threadIdx.x == 0) carry_s = make_int2(0, 0);
     __syncthreads();
-    for (int base = 0; base < nblk; base += 256) {
+    for (int base = 0; base < nent; base += 256) {
         const int i = base + threadIdx.x;
-        const int2 v = i < nblk ? bsums[i] : make_int2(0, 0);
+        const int2 v = i < nent ? bsums[i] : make_int2(0, 0);
         int tc, tr;
         const int ec = block_exclusive_scan(v.x, lds, tc);
         const int er = block_exclusive_scan(v.y, lds, tr);
         const int2 carry = carry_s;
-        if (i < nblk) bsums[i] = make_int2(carry.x + ec, carry.y + er);
+        if (i < nent) bsums[i] = make_int2(carry.x + ec, carry.y + er);
         __syncthreads();
         if (threadIdx.x == 0) carry_s = make_int2(carry.x + tc, carry.y + tr);
         __syncthreads();
     }
-    if (threadIdx.x == 0) bsums[nblk] = carry_s;
+    if (threadIdx.x == 0) bsums[nent] = carry_s;
 }
 
-__device__ __forceinline__ int2 cm_base2(const int2 *__restrict__ bsums, int blk, int spined, int *lds) {
-    if (spined) return bsums[blk];
+// sum of entries [0, ent) (by the block itself, or read from the spine's exclusive prefixes)
+__device__ __forceinline__ int2 cm_base2(const int2 *__restrict__ bsums, int ent, int spined, int *lds) {
+    if (spined) return bsums[ent];
     int ac = 0, ar = 0;
-    for (int j = threadIdx.x; j < blk; j += 256) {
+    for (int j = threadIdx.x; j < ent; j += 256) {
         const int2 v = bsums[j];
         ac += v.x;
         ar += v.y;
@@ -361,10 +442,10 @@ __device__ __forceinline__ int2 cm_base2(const int2 *__restrict__ bsums, int blk
 }
 
 // totals only (the two-phase API: the host reads n_out before it allocates the outputs)
-__global__ __launch_bounds__(256) void cm_total_kernel(const int2 *__restrict__ bsums, int nblk, int spined,
+__global__ __launch_bounds__(256) void cm_total_kernel(const int2 *__restrict__ bsums, int nent, int spined,
                                                        int *__restrict__ n_out_dev) {
     __shared__ int lds[4];
-    const int2 t = cm_base2(bsums, nblk, spined, lds);
+    const int2 t = cm_base2(bsums, nent, spined, lds);
     if (threadIdx.x == 0) *n_out_dev = t.y;
 }
 
@@ -379,22 +460,23 @@ struct CmEmitSide {
 // pass 2: the output map (words, column records), the output coordinates, the row count
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellblk, const uint2 *__restrict__ cw,
-                                                           const uint4 *__restrict__ cr, const uint4 *__restrict__ ginfo,
-                                                           const int2 *__restrict__ bsums, int spined,
-                                                           uint2 *__restrict__ cw_out, uint4 *__restrict__ cr_out,
+                                                           const uint4 *__restrict__ cr, const int2 *__restrict__ bsums,
+                                                           int spined, uint2 *__restrict__ cw_out, uint4 *__restrict__ cr_out,
                                                            int *__restrict__ ncols_out, int32_t *__restrict__ out_indices,
                                                            int n_out, int *__restrict__ n_out_dev, CmEmitSide S) {
     __shared__ int lds[4];
     __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
-    __shared__ int2 gbase[CM_GROUPS_PER_BLOCK];
+    __shared__ u32 occ_s[4][64];
+    __shared__ int excl_s[4][64];
     if ((int)blockIdx.x >= ncellblk) {
         class_offsets(S.blk_cnt, S.cls_nblk, S.ncls, S.cls_tile, S.vstart, ctot, cstart);
         return;
     }
     if (S.fill_a) fill_ff(S.fill_a, S.fill_a_bytes, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)ncellblk * 256);
-    const int2 base = cm_base2(bsums, blockIdx.x, spined, lds);
+    const int wave = threadIdx.x >> 6;
+    int2 base = cm_base2(bsums, blockIdx.x * 4, spined, lds);
     if (blockIdx.x == 0 && (n_out_dev || ncols_out)) {
-        const int2 t = cm_base2(bsums, ncellblk, spined, lds);
+        const int2 t = cm_base2(bsums, ncellblk * 4, spined, lds);
         if (threadIdx.x == 0) {
             if (n_out_dev) *n_out_dev = t.y;
             if (ncols_out) {
@@ -403,46 +485,45 @@ __global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellbl
             }
         }
     }
-    const int g0 = blockIdx.x * CM_GROUPS_PER_BLOCK;
-    const int ngroups = (G.cells + 63) >> 6;
-    if (threadIdx.x < 64) {            // one wave: exclusive scan over the block's groups
-        const int g = g0 + threadIdx.x;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (threadIdx.x < CM_GROUPS_PER_BLOCK && g < ngroups) q = ginfo[g];
-        const int c = __popc(q.x) + __popc(q.y), r = (int)q.z;
-        const int ic = wave_inclusive_scan(c), ir = wave_inclusive_scan(r);
-        if (threadIdx.x < CM_GROUPS_PER_BLOCK) gbase[threadIdx.x] = make_int2(base.x + ic - c, base.y + ir - r);
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6;
-    const u64 lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
-    for (int it = 0; it < CM_GROUPS_PER_BLOCK / 4; ++it) {
-        const int gl = wave * (CM_GROUPS_PER_BLOCK / 4) + it;
-        const int g = g0 + gl;
-        if (g >= ngroups) break;
-        const uint4 q = ginfo[g];
-        const u64 bits = (u64)q.x | ((u64)q.y << 32);
-        const int2 gb = gbase[gl];
-        if (lane_id() == 0) {
-            cw_out[2 * g] = make_uint2(q.x, (u32)gb.x);
-            cw_out[2 * g + 1] = make_uint2(q.y, (u32)(gb.x + __popc(q.x)));
+    if (spined) {
+        base = bsums[blockIdx.x * 4 + wave];
+    } else {
+        for (int wv = 0; wv < wave; ++wv) {
+            const int2 v = bsums[blockIdx.x * 4 + wv];
+            base.x += v.x;
+            base.y += v.y;
         }
-        if (!bits) continue;
-        const int cell = g * 64 + lane_id();
-        const bool set = (bits >> lane_id()) & 1ull;
+    }
+    const int word0 = (blockIdx.x * 4 + wave) << G.wshift, word = word0 + lane_id();
+    const int wpr = G.Po >> 5;
+    const bool mine = lane_id() < (1 << G.wshift) && word < G.nwords_out;
+    u32 occ = 0;
+    if (mine) {
+        const int t = word / wpr;
+        occ = out_occupancy<KH, KW>(G, cw, t / G.Ho, t % G.Ho, word % wpr);
+    }
+    const CmWaveCells Wc = cm_wave_cells(occ, occ_s[wave], excl_s[wave]);
+    if (mine) cw_out[word] = make_uint2(occ, (u32)(base.x + excl_s[wave][lane_id()]));
+    int row0 = base.y;
+    for (int b0 = 0; b0 < Wc.total; b0 += 64) {
+        const int idx = b0 + lane_id();
         u64 zm = 0;
         int b = 0, oy = 0, ox = 0;
-        if (set) {
-            ox = cell % G.Wo;
-            const int t = cell / G.Wo;
-            oy = t % G.Ho;
+        if (idx < Wc.total) {
+            int wl, bit;
+            cm_wave_cell(Wc, idx, wl, bit);
+            const int wd = word0 + wl, t = wd / wpr;
             b = t / G.Ho;
+            oy = t % G.Ho;
+            ox = ((wd % wpr) << 5) + bit;
             zm = squash_z(in_union<KH, KW>(G, cw, cr, b, oy, ox), G);
         }
         const int cnt = __popcll(zm);
-        const int start = gb.y + wave_inclusive_scan(cnt) - cnt;
-        if (set) {
-            const int col = gb.x + __popcll(bits & lt);
+        const int inc = wave_inclusive_scan(cnt);
+        const int start = row0 + inc - cnt;
+        row0 += __shfl(inc, 63);
+        if (idx < Wc.total) {
+            const int col = base.x + idx;
             if (col < G.ncol_cap_out) cr_out[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)start, (u32)cnt);
             if (out_indices) {
                 int r = start;
@@ -491,7 +572,7 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
         for (int q = 0; q < KH * KW; ++q) {
             const int y = c.z * G.sh - G.ph + q / KW, x = c.w * G.sw - G.pw + q % KW;
             in[q] = live && y >= 0 && y < G.H && x >= 0 && x < G.W;
-            key[q] = in[q] ? bev_key(c.x, y, x, G.H, G.W) : 0u;
+            key[q] = in[q] ? bev_key(c.x, y, x, G.H, G.P) : 0u;
             w[q] = cw[key[q] >> 5];
         }
         uint4 r[KH * KW];
@@ -552,7 +633,7 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
     for (int q = 0; q < KH * KW; ++q) {
         const int oy = axis_out(c.z, G.ph, 1, G.sh, q / KW, G.Ho), ox = axis_out(c.w, G.pw, 1, G.sw, q % KW, G.Wo);
         in[q] = live && oy >= 0 && ox >= 0;
-        key[q] = in[q] ? bev_key(c.x, oy, ox, G.Ho, G.Wo) : 0u;
+        key[q] = in[q] ? bev_key(c.x, oy, ox, G.Ho, G.Po) : 0u;
         w[q] = cw_out[key[q] >> 5];
     }
     uint4 r[KH * KW];
@@ -586,10 +667,9 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
 
 // ---- host side -------------------------------------------------------------------------------------------------
 struct CmConvWs {
-    uint4 *ginfo;
-    int2 *bsums;
+    int2 *bsums;            // per wave of 64 output words: { occupied cells, rows }
     int *wsuper, *wave_cnt, *blk_cnt;
-    int ngroups, ncellblk, nwaves, nws, nclsblk;
+    int ncellblk, nwaves, nws, nclsblk;
 };
 
 bool cm_geom(const int *shape, const int *ks, const int *st, const int *pd, const int *dl, int batch, ConvGeom &G, CmGeom &C) {
@@ -598,23 +678,25 @@ bool cm_geom(const int *shape, const int *ks, const int *st, const int *pd, cons
     if (!((G.kd == 3 && G.kh == 3 && G.kw == 3) || (G.kd == 3 && G.kh == 1 && G.kw == 1))) return false;
     if (G.sd < 1 || G.sd > 2 || G.sh < 1 || G.sh > 2 || G.sw < 1 || G.sw > 2) return false;
     if (G.D + G.pd > 62 || G.Do > 62 || G.Do <= 0 || G.Ho <= 0 || G.Wo <= 0) return false;
-    const double cells = (double)batch * G.Ho * G.Wo, cells_in = (double)batch * G.H * G.W;
+    if (G.pw > 31) return false;
+    C.P = cm_pitch(G.W);
+    C.Po = cm_pitch(G.Wo);
+    const double cells = (double)batch * G.Ho * C.Po, cells_in = (double)batch * G.H * C.P;
     if (cells >= 2147483647.0 - 4096.0 || cells_in >= 2147483647.0 - 4096.0) return false;
     C.D = G.D; C.H = G.H; C.W = G.W; C.Do = G.Do; C.Ho = G.Ho; C.Wo = G.Wo;
     C.kd = G.kd; C.sd = G.sd; C.sh = G.sh; C.sw = G.sw; C.pd = G.pd; C.ph = G.ph; C.pw = G.pw;
-    C.cells = (int)cells;
+    C.nwords_out = (int)(cells / 32);
+    C.wshift = cm_wshift(C.nwords_out);
     return true;
 }
 
 bool cm_conv_ws(void *p, size_t bytes, int n, const ConvGeom &G, const CmGeom &C, CmConvWs &L, size_t *need) {
-    L.ngroups = pcd_div_up(C.cells, 64);
-    L.ncellblk = pcd_div_up(C.cells, CM_CELLS_PER_BLOCK);
+    L.ncellblk = pcd_div_up(pcd_div_up(C.nwords_out, 1 << C.wshift), 4);
     L.nwaves = pcd_div_up(n > 0 ? n : 1, 64);
     L.nws = pcd_div_up(L.nwaves, 64);
     L.nclsblk = pcd_div_up(n > 0 ? n : 1, 256);
     WsCarver ws(p, bytes);
-    L.ginfo = ws.take<uint4>((size_t)L.ngroups + 1);
-    L.bsums = ws.take<int2>((size_t)L.ncellblk + 2);
+    L.bsums = ws.take<int2>((size_t)L.ncellblk * 4 + 2);
     L.wsuper = ws.take<int>((size_t)G.K * L.nws);
     L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
     L.blk_cnt = ws.take<int>((size_t)CLS_MAX * L.nclsblk);
@@ -624,16 +706,16 @@ bool cm_conv_ws(void *p, size_t bytes, int n, const ConvGeom &G, const CmGeom &C
 
 template <int KH, int KW>
 void cm_launch_count(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmConvSide &S, int cls_blocks, hipStream_t st) {
-    cm_conv_count_kernel<KH, KW><<<L.ncellblk + cls_blocks, 256, 0, st>>>(C, L.ncellblk, in.cw, in.cr, L.ginfo, L.bsums, S);
-    if (cm_spined(L.ncellblk)) cm_spine2_kernel<<<1, 256, 0, st>>>(L.bsums, L.ncellblk);
+    cm_conv_count_kernel<KH, KW><<<L.ncellblk + cls_blocks, 256, 0, st>>>(C, L.ncellblk, in.cw, in.cr, L.bsums, S);
+    if (cm_spined(L.ncellblk * 4)) cm_spine2_kernel<<<1, 256, 0, st>>>(L.bsums, L.ncellblk * 4);
 }
 
 template <int KH, int KW>
 void cm_launch_emit(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmBuf &out, int32_t *out_indices, int n_out,
                     int32_t *n_out_dev, const CmEmitSide &S, hipStream_t st) {
     cm_conv_emit_kernel<KH, KW><<<L.ncellblk + (S.blk_cnt ? 1 : 0), 256, 0, st>>>(
-        C, L.ncellblk, in.cw, in.cr, L.ginfo, L.bsums, cm_spined(L.ncellblk), out.cw, out.cr, out.ncols, out_indices,
-        n_out, n_out_dev, S);
+        C, L.ncellblk, in.cw, in.cr, L.bsums, cm_spined(L.ncellblk * 4), out.cw, out.cr, out.ncols, out_indices, n_out,
+        n_out_dev, S);
 }
 
 }  // namespace
@@ -668,16 +750,16 @@ extern "C" int pcd_colmap_from_rows(const int32_t *indices, int n, const int32_t
     int *bsums = ws.take<int>(nblk + 2);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int H = shape_host[1], W = shape_host[2];
+    const int H = shape_host[1], P = B.pitch;
     pcd_fill(bits, 0, (B.nwords + 4) * sizeof(u32), st);
     const int nb = pcd_div_up(n > 0 ? n : 1, 256);
-    if (n > 0) cm_rows_mark_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, W, bits);
+    if (n > 0) cm_rows_mark_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, P, bits);
     cm_words_count_kernel<<<nblk, 256, 0, st>>>(bits, nwords, bsums);
     const int spined = cm_spined(nblk);
     if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nblk, nullptr);
     cm_words_prefix_kernel<<<nblk, 256, 0, st>>>(bits, nwords, nblk, bsums, spined, B.cw, B.ncols);
     if (n > 0)
-        cm_rows_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, W, B.cw, B.cr, B.ncol_cap, B.ncols);
+        cm_rows_fill_kernel<<<nb, 256, 0, st>>>((const int4 *)indices, n, n_dev, H, P, B.cw, B.cr, B.ncol_cap, B.ncols);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -712,7 +794,7 @@ extern "C" int pcd_rulebook_subm_cm(const int32_t *indices, int n, int batch, co
     int *totals = ws.take<int>(27);
     if (pairs && !ws.ok) return PCD_ERR_WORKSPACE;
     cm_subm_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>((const int4 *)indices, n, n_dev, shape_host[0], shape_host[1],
-                                                       shape_host[2], B.cw, B.cr, B.ncol_cap, nbr,
+                                                       shape_host[2], B.pitch, B.cw, B.cr, B.ncol_cap, nbr,
                                                        pairs ? wave_cnt : nullptr, nwaves);
     if (pairs) {
         scan_rows_kernel<<<27, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
@@ -800,7 +882,7 @@ extern "C" int pcd_rulebook_conv_cm_count(int n, int batch, const int *in_shape_
     hipStream_t st = (hipStream_t)stream;
     CmConvSide S = {};
     cm_count(X, S, 0, st);
-    cm_total_kernel<<<1, 256, 0, st>>>(X.L.bsums, X.L.ncellblk, cm_spined(X.L.ncellblk), n_out_dev);
+    cm_total_kernel<<<1, 256, 0, st>>>(X.L.bsums, X.L.ncellblk * 4, cm_spined(X.L.ncellblk * 4), n_out_dev);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -186,20 +186,26 @@ __global__ __launch_bounds__(256) void pairs_fill_super_kernel(const int32_t *__
                                                                const int *__restrict__ wave_cnt, int nwaves,
                                                                const int *__restrict__ wsuper, int nws,
                                                                int32_t *__restrict__ pairs,
-                                                               int32_t *__restrict__ pair_num) {
+                                                               int32_t *__restrict__ pair_num, int scanned) {
+    // scanned: wsuper holds exclusive prefixes already (a scan launch ran: beyond PAIRS_SUPER_SCAN groups every block
+    // adding up the groups in front of it -- K x sb loads -- was most of this kernel's time) and pair_num is written
     __shared__ int off_s[343][4];
     const int w = threadIdx.x >> 6, lane = lane_id();
     const int wave0 = blockIdx.x * 4, sb = wave0 >> 6, m = wave0 & 63;   // m <= 60: the block's 4 waves share a group
     for (int kr = w; kr < K; kr += 4) {
         int acc = 0;
-        for (int i = lane; i < sb; i += 64) acc += wsuper[(size_t)kr * nws + i];
+        if (scanned) {
+            acc = lane == 0 ? wsuper[(size_t)kr * nws + sb] : 0;
+        } else {
+            for (int i = lane; i < sb; i += 64) acc += wsuper[(size_t)kr * nws + i];
+        }
         const int wi = (sb << 6) + lane;
         const int c = (wi < nwaves && lane < m + 4) ? wave_cnt[(size_t)kr * nwaves + wi] : 0;
         const int inc = wave_inclusive_scan(c);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (lane >= m && lane < m + 4) off_s[kr][lane - m] = acc + inc - c;
-        if (blockIdx.x == 0 && pair_num) {
+        if (blockIdx.x == 0 && pair_num && !scanned) {
             int t = 0;
             for (int i = lane; i < nws; i += 64) t += wsuper[(size_t)kr * nws + i];
 #pragma unroll
@@ -243,16 +249,20 @@ __global__ __launch_bounds__(256) void pairs_fill_super_kernel(const int32_t *__
     }
 }
 
+constexpr int PAIRS_SUPER_SCAN = 256;
 static void launch_pairs_fill_super(const int32_t *tbl, int n, const int32_t *n_dev, int K, int flip,
                                     const int *wave_cnt, int nwaves, const int *wsuper, int nws, int32_t *pairs,
                                     int32_t *pair_num, hipStream_t st) {
     int nb = pcd_div_up(n, 256);
+    const int scanned = nws > PAIRS_SUPER_SCAN;
+    // (in place: every thread of scan_rows_kernel reads its 8 entries before it writes them)
+    if (scanned) scan_rows_kernel<<<K, 256, 0, st>>>(wsuper, const_cast<int *>(wsuper), nws, nullptr, pair_num, flip);
     if (K == 27)
         pairs_fill_super_kernel<27><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_cnt, nwaves, wsuper, nws, pairs,
-                                                        pair_num);
+                                                        pair_num, scanned);
     else
         pairs_fill_super_kernel<0><<<nb, 256, 0, st>>>(tbl, n, n_dev, K, flip, wave_cnt, nwaves, wsuper, nws, pairs,
-                                                       pair_num);
+                                                       pair_num, scanned);
 }
 
 static int make_geom(const int *shape, const int *ks, const int *st, const int *pd, const int *dl,

@@ -899,6 +899,12 @@ int pcd_scale_bf16(const void *a, const float *scale_dev, size_t n, void *y, voi
 /* Diagnostics: the device clock (100 MHz) into slot[0] at this point of the stream -- a time point inside a replayed
  * hipGraph, which events cannot give and a profiler perturbs (tools/exp_stamps.py).  No reference counterpart. */
 int pcd_debug_stamp(uint64_t *slot, void *stream);
+/* Diagnostics (tools/exp_cu_mask.py): a stream restricted to the compute units of `cu_mask` (hipExtStreamCreateWithCUMask;
+ * the caller owns it), and a launch of `blocks` 1024-thread workgroups that each stay busy for `ticks` ticks of the 100 MHz
+ * clock (xcc_seen, optional: bit x set when a workgroup ran on XCD x) -- the duration of 256 of them tells how many CUs the
+ * launch was given, eagerly and as a replayed hipGraph node.  No reference counterpart. */
+int pcd_debug_stream_create_cu_mask(const uint32_t *cu_mask, int words, void **stream_out);
+int pcd_debug_spin(int blocks, unsigned long long ticks, uint32_t *xcc_seen, void *stream);
 
 /* ============================================================================================
  * (a8) SubMConv3d arithmetic over z-fastest rows: the WINDOW gather-GEMM (spconv_win.hip) -- forward and data gradient of
