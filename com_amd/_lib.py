@@ -63,6 +63,7 @@ PROTOTYPES = {
     "pcd_subm_window_wgrad_splits": (_i, []),
     "pcd_sparse_conv_subm_window_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_subm_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pcd_sparse_conv_subm_window_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_pairs_workspace_bytes": (_sz, [_i, _i]),

@@ -62,7 +62,15 @@ __device__ __forceinline__ u32x4 win_rsrc(const void *base, unsigned bytes) {
     } while (0)
 
 constexpr int WIN_THREADS = 512;
-constexpr int WIN_GRID = 256;            // one persistent workgroup per CU; also the number of BatchNorm partial rows
+constexpr int WIN_GRID = 256;            // (at most) one persistent workgroup per CU; also the number of BatchNorm partial rows
+// workgroups of a forward / data-gradient launch = shares of its plan: option "subm_window_grid" (a multiple of 8, <= WIN_GRID;
+// fewer than the CU count leaves CUs to the kernels of the other streams -- a 512-thread, 230-VGPR workgroup starts only on
+// an EMPTY CU)
+static inline int win_grid() {
+    int g = pcd_opt(PCD_OPT_SUBM_WINDOW_GRID);
+    g = g / 8 * 8;
+    return g < 8 ? 8 : g > WIN_GRID ? WIN_GRID : g;
+}
 constexpr int WIN_SCRATCH = 0;           // (bnred_publish's 8 KiB of scratch at the head of the dynamic LDS are the zero rows and the
                                          //  first window: dead by then)
 constexpr int WIN_PLAN_CAP = 64;         // tiles whose plans are staged in LDS at a time
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
 // One workgroup.
 template <class C>
 __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan_base, int n_cap, const int32_t *__restrict__ n_dev,
-                                                         int ntiles_cap) {
+                                                         int ntiles_cap, int grid) {
     __shared__ int scan[1024];
     __shared__ int bnd[WIN_GRID + 1];
     __shared__ int bndw[WIN_WG_SHARES + 1];
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
     const long long total = scan[1023];
     __threadfence_block();
     __syncthreads();
-    constexpr int NSH = WIN_GRID / C::CQN;            // shares of the forward / data-gradient kernel (CQN workgroups each)
+    const int NSH = grid / C::CQN;                    // shares of the forward / data-gradient kernel (CQN workgroups each)
     for (int j = tid; j <= NSH; j += 1024) {
         const long long target = total * j / NSH;
         int lo = 0, hi = nt;                          // number of tiles with prefix <= target
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
     const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, const int32_t *__restrict__ n_dev,
     const int4 *__restrict__ plan_g, unsigned short *__restrict__ y, unsigned x_bytes,
-    const unsigned short *__restrict__ addend, BnRed bn, int dbg, unsigned long long *trace) {
+    const unsigned short *__restrict__ addend, BnRed bn, int dbg, unsigned long long *trace, float *__restrict__ y_f32) {
     __builtin_amdgcn_s_setprio(3);       // main-chain kernel (see spconv.hip: PCD_MAIN_PRIO)
     // profiling aid (pcd_subm_window_set_trace): shader-clock stamps of workgroup 0 / wave 0 at the phase boundaries of its tiles
     int trace_at = 0;
@@ -729,6 +737,11 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                         v[2 * e + 1] += __uint_as_float(aw[e] & 0xffff0000u);
                     }
                 }
+                if (y_f32 && olive) {      // (parity aid: the fp32 sums the rounding below starts from, pcd_sparse_conv_subm_window_f32)
+                    float *d = y_f32 + (size_t)orow * COUT + cq * COUTW + ecg * 8;
+                    *reinterpret_cast<f32x4 *>(d) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(d + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                }
                 u32x4 o;      // v_cvt_pk_bf16_f32: round to nearest even, two values per instruction (= f32_to_bf16_bits for finite values)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -882,18 +895,19 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
 template <class C>
 static int launch_win(const void *x, int n_rows, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
                       const int32_t *n_dev, const void *plan, void *y, const void *addend,
-                      const PcdBnReduce *bnr, hipStream_t st) {
+                      const PcdBnReduce *bnr, hipStream_t st, float *y_f32 = nullptr) {
     BnRed bn;
-    if (int rc = make_bnred(bnr, PCD_BF16, C::COUT, WIN_GRID, &bn)) return rc;
+    const int grid = win_grid();
+    if (int rc = make_bnred(bnr, PCD_BF16, C::COUT, grid, &bn)) return rc;
     if ((double)n_rows * C::ROWB >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
     auto k = subm_win_kernel<C>;
     // (set per call: the attribute is per device, the call idempotent)
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
         return PCD_ERR_LAUNCH;
-    k<<<WIN_GRID, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
+    k<<<grid, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
                                                     n_rows, n_dev, (const int4 *)plan, (unsigned short *)y,
                                                     (unsigned)((size_t)n_rows * C::ROWB), (const unsigned short *)addend, bn,
-                                                    pcd_opt(PCD_OPT_WIN_DBG), g_win_trace);
+                                                    pcd_opt(PCD_OPT_WIN_DBG), g_win_trace, y_f32);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -1260,7 +1274,7 @@ extern "C" int pcd_subm_window_tile_rows(int c_in, int c_out) {
     return win_dispatch(c_in, c_out, [](auto c) { return (int)decltype(c)::T; }, 0);
 }
 
-extern "C" int pcd_subm_window_partial_rows(void) { return WIN_GRID; }
+extern "C" int pcd_subm_window_partial_rows(void) { return win_grid(); }
 
 extern "C" int pcd_subm_window_set_trace(void *buf256_u64) {
     g_win_trace = (unsigned long long *)buf256_u64;
@@ -1284,7 +1298,7 @@ extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_ca
         using C = decltype(c);
         const int nt = pcd_div_up(n_cap, C::T);
         win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
-        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt);
+        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid());
         return 0;
     }, 0);
     PCD_RETURN_IF_LAUNCH_FAILED();
@@ -1326,6 +1340,22 @@ extern "C" int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, 
     return win_dispatch(c_in, c_out, [&](auto c) {
         return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend,
                                        bn_reduce, st);
+    }, (int)PCD_ERR_UNSUPPORTED);
+}
+
+// the same launch, additionally writing the fp32 sums (bias and addend included) every bf16 output is rounded from
+extern "C" int pcd_sparse_conv_subm_window_f32(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
+                                               const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
+                                               const void *plan, int c_out, void *y, float *y_f32, const void *addend,
+                                               void *stream) {
+    PCD_ENTER();
+    if (n_rows < 0 || !win_supported(c_in, c_out)) return PCD_ERR_UNSUPPORTED;
+    if (n_rows == 0) return PCD_OK;
+    if (!x || !packed_w || !nbr || !plan || !y || !y_f32 || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return win_dispatch(c_in, c_out, [&](auto c) {
+        return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend, nullptr,
+                                       st, y_f32);
     }, (int)PCD_ERR_UNSUPPORTED);
 }
 

@@ -1061,6 +1061,21 @@ def pack_weight_window(weight, mode, out=None):
     return packed
 
 
+def subm_window_f32(x, packed_w, bias, rb, c_out, addend=None):
+    """subm_window that also returns the fp32 sums its bf16 outputs are rounded from: (y bf16, y_f32) -- parity tests only."""
+    _require_cuda(x, packed_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and rb.subm and rb.kvol == 27
+    n, c_in = x.shape
+    plan = subm_window_plan(rb, c_in, c_out)
+    y = torch.empty((n, c_out), dtype=torch.bfloat16, device=x.device)
+    y32 = torch.zeros((n, c_out), dtype=torch.float32, device=x.device)
+    L.check(L.lib().pcd_sparse_conv_subm_window_f32(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
+                                                    rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan), c_out, L.ptr(y),
+                                                    L.ptr(y32), L.ptr(addend), L.stream_ptr()),
+            "pcd_sparse_conv_subm_window_f32")
+    return y, y32
+
+
 def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     """gather_gemm over the SubM rulebook `rb` through the window kernel: y[o] = bias + sum_k x[nbr[k][o]] @ W[k] (+ addend[o])
     with packed_w = pack_weight_window(w, 0); the data gradient (k-flipped view, W^T) with pack_weight_window(w, 1) -- the flip

@@ -948,6 +948,12 @@ int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, const void 
                                 const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
                                 const void *plan, int c_out, void *y, const void *addend,
                                 const PcdBnReduce *bn_reduce, void *stream);
+/* The same launch that ALSO writes y_f32 [n_rows][c_out]: the fp32 sums (bias and addend included) every bf16 output is
+ * rounded from -- what the parity tests compare with the oracle at the 1e-3 bar of BASELINE.json (the bf16 rounding of y
+ * alone is 2^-9 relative per element).  Not used by the training step. */
+int pcd_sparse_conv_subm_window_f32(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
+                                    const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev, const void *plan,
+                                    int c_out, void *y, float *y_f32, const void *addend, void *stream);
 
 #ifdef __cplusplus
 }

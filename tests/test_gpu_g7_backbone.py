@@ -32,8 +32,10 @@ import g7_params as P7  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 OP_TOL = 1e-3            # relative L2 of ONE op's output vs fp64 on its own inputs (+ bf16 rounding)
-NOISE_FACTOR = 1.3       # err(HIP, exact) <= NOISE_FACTOR * err(bf16-emulating fp64 chain, exact)
-GRAD_NOISE_FACTOR = 1.75 # same for a parameter-gradient tensor (one noise realisation each; scatter +-40 %)
+NOISE_FACTOR = 1.1       # err(HIP, exact) <= NOISE_FACTOR * err(bf16-emulating fp64 chain, exact)   (measured: 1.000-1.0005)
+GRAD_NOISE_FACTOR = 1.6  # same for a parameter-gradient tensor: one noise realisation each -- the worst ratio over the 62 tensors
+                         # of the six runs of this file is 1.29-1.42 (round 5; 1.75 until round 4)
+GRAD_MIN_COS = 0.85      # cosine of a parameter gradient with the exact chain's (measured minimum 0.875)
 FIRST_TAP_TOL = 2e-3     # x_conv1 vs the bf16-emulating chain directly (10 ops deep: not yet decorrelated)
 
 
@@ -150,7 +152,7 @@ def _check_against_g7(g, net, bd, sf, loss, n_real=None, key_order=False):
         cos = float(np.dot(got.astype(np.float64), ex) / (np.linalg.norm(got) * np.linalg.norm(ex) + 1e-30))
         grads[name] = (round(e_hip, 4), round(e_emu, 4), round(cos, 4))
         # one noise realisation per tensor: the ratio of two such errors scatters by +-40 % (measured)
-        fails += [(name, "grad", e_hip, e_emu, cos)] if (e_hip > GRAD_NOISE_FACTOR * e_emu + 0.01 or cos < 0.8) else []
+        fails += [(name, "grad", e_hip, e_emu, cos)] if (e_hip > GRAD_NOISE_FACTOR * e_emu + 0.01 or cos < GRAD_MIN_COS) else []
     for name, b in net.named_buffers():
         if name.endswith("running_mean") or name.endswith("running_var"):
             want = g["exact_" + name.replace(".", "__")]

@@ -15,6 +15,10 @@ from com_amd import hotpath, ops
 from com_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
+# two bf16 chains with different rounding points (the stock layer graph rounds after every module, the fused one once per
+# conv + BN): bars = 2 x what was measured (round 5: see the [seam1] lines the test prints)
+# measured 5.2e-3 / 7.8e-3 / 1.05e-2 / 1.31e-2 / 1.53e-2 (3e-2 / 4e-2 until round 4)
+TAP_TOL = {"x_conv1": 1.1e-2, "x_conv2": 1.6e-2, "x_conv3": 2.1e-2, "x_conv4": 2.7e-2, "out": 3.1e-2}
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
@@ -53,9 +57,11 @@ def test_stock_model_file_over_seam1_matches_the_fused_backbone():
     for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
         a, b = bs["multi_scale_3d_features"][k], bf["multi_scale_3d_features"][k]
         assert torch.equal(a.indices, b.indices)
-        assert _rel(a.features, b.features) < 3e-2, (k, _rel(a.features, b.features))
+        print(f"[seam1] {k}: rel L2 stock vs fused {_rel(a.features, b.features):.4g}")
+        assert _rel(a.features, b.features) < TAP_TOL[k], (k, _rel(a.features, b.features))
     assert torch.equal(bs["encoded_spconv_tensor"].indices, bf["encoded_spconv_tensor"].indices)
-    assert _rel(bs["encoded_spconv_tensor"].features, bf["encoded_spconv_tensor"].features) < 4e-2
+    print(f"[seam1] out: rel L2 stock vs fused {_rel(bs['encoded_spconv_tensor'].features, bf['encoded_spconv_tensor'].features):.4g}")
+    assert _rel(bs["encoded_spconv_tensor"].features, bf["encoded_spconv_tensor"].features) < TAP_TOL["out"]
     worst = 0.0
     for (n, p), (_, q) in zip(stock.named_parameters(), fused.named_parameters()):
         if p.grad is None or q.grad is None or float(q.grad.norm()) == 0:

@@ -61,6 +61,19 @@ def _close(y, ref, what):
     return rel
 
 
+def _close_f32(y32, ref, what):
+    """fp32 sums vs the oracle's fp32 sums on the same bf16 operands: 1e-3 relative (north_star) per element -- against
+    |ref| + rms / 10 so that sums that cancel to ~0 are not held to their own size -- and 1e-4 in relative L2."""
+    y, ref = y32.float().cpu().numpy(), np.asarray(ref, np.float32)
+    rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    err = np.abs(y - ref)
+    bound = 1e-3 * (np.abs(ref) + 0.1 * rms)
+    assert (err <= bound).all(), (what, float(err.max()), rms, int((err > bound).sum()))
+    rel = float(np.linalg.norm((y - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+    assert rel < 1e-4, (what, rel)
+    return rel
+
+
 @pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1), (128, 4)])
 def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
     ops = _ops()
@@ -80,10 +93,18 @@ def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
     y = ops.subm_window(x.to(DEV), ops.pack_weight_window(wd, 0), bias.to(DEV), rb, ch)
     ref = _oracle_fwd(x, w.numpy(), bias.numpy(), idx_np, shape, False)
     _close(y, ref, "forward")
+    # ... and the fp32 sums those outputs are rounded from, at the bar BASELINE.json states (1e-3 relative; measured ~1e-6:
+    # fp32 accumulation in another order), element by element; y is exactly their round-to-nearest-even
+    y2, y32 = ops.subm_window_f32(x.to(DEV), ops.pack_weight_window(wd, 0), bias.to(DEV), rb, ch)
+    assert torch.equal(y2, y) and torch.equal(y32.to(torch.bfloat16), y)
+    _close_f32(y32, ref, "forward fp32 sums")
     # data gradient (+ addend): the k-flipped view with W^T
     dx = ops.subm_window(x.to(DEV), ops.pack_weight_window(wd, 1), None, rb, ch, addend=add.to(DEV))
     ref = _oracle_fwd(x, w.numpy(), None, idx_np, shape, True) + add.float().numpy()
     _close(dx, ref, "dgrad")
+    dx2, dx32 = ops.subm_window_f32(x.to(DEV), ops.pack_weight_window(wd, 1), None, rb, ch, addend=add.to(DEV))
+    assert torch.equal(dx2, dx) and torch.equal(dx32.to(torch.bfloat16), dx)
+    _close_f32(dx32, ref, "dgrad fp32 sums")
     # ... and the generic kernel on the same operands: identical except for elements on a rounding boundary
     y0 = ops.gather_gemm(x.to(DEV), ops.pack_weight(wd, 0), bias.to(DEV), rb.nbr_out, 27, False, n, ch, torch.bfloat16)
     d = (y0.float() - y.float()).abs()
@@ -261,6 +282,14 @@ def test_window_weight_gradient_against_the_generic_kernel_and_float64(ch, lvl):
         assert dw.shape == ref.shape == (ch, 27, ch)
         scale = float(ref.abs().max())
         assert float((dw - ref).abs().max()) <= 2e-5 * scale * np.sqrt(m / 1000.0 + 1.0), case
+        # the ORACLE's weight gradient (oracle/pcd_oracle.c: dW_k += x[i]^T dy[o] over its own pair lists, fp32) on the same
+        # bf16 operands and the oracle's own rulebook of these coordinates
+        idx_c = (idx if case == "yxz" else idx[perm]).cpu().numpy()
+        rb_o = O.rulebook_subm(idx_c, tuple(shape))
+        _, dw_o, _ = O.conv_bwd(x.float().cpu().numpy(), np.zeros((27, ch, ch), np.float32), dy.float().cpu().numpy(), rb_o,
+                                threads=8)
+        want_o = torch.from_numpy(np.ascontiguousarray(dw_o.transpose(2, 0, 1))).to(DEV)      # [K, ci, co] -> [co, K, ci]
+        assert float((dw - want_o).abs().max()) <= 2e-5 * float(want_o.abs().max()) * np.sqrt(m / 1000.0 + 1.0), (case, "oracle")
         # float64 definition for a few offsets
         x64, dy64 = x.double(), dy.double()
         for k in (0, 4, 13, 22, 26):
