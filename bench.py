@@ -249,6 +249,11 @@ def measure_roofline(step_fn, ms_per_step):
     for kr in out["kernels"]:
         for drop in ("peak", "unit", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "other_frac"):
             kr.pop(drop, None)
+    # which regime these per-launch figures are: NOT the profile's (profiles/*_kernel_stats_graph.txt = kernel durations inside
+    # the replayed graph) and not isolated launches
+    out["kernels_regime"] = ("HIP-event brackets around every launch of ONE eager step, the weight-gradient stream overlapping the "
+                             "data gradients (event overhead subtracted); rocprofv3's in-graph kernel durations are in "
+                             "profiles/, isolated launches in `isolated` / tools/exp_subm_win.py")
     tb, tfl = sum(v["bytes"] for v in groups.values()), sum(v["flops"] for v in groups.values())
     secs = ms_per_step * 1e-3
     out["step"] = {"alg_bytes": int(tb), "alg_flops": int(tfl), "ms_per_step": round(ms_per_step, 4),
@@ -710,7 +715,7 @@ def measure_regime():
 def measure_full_model(args, flags=("--dense-head", "--com"), what=None, extra_env=None):
     """`full_model`: the complete CenterPoint-VoxelNet + COM-head training step (what a user of the reference would
     run), measured by a CHILD process (`bench.py --dense-head --com`, same batch / steps) after this process's own
-    loops have finished; the child is a new process, nothing is exec'ed over this one.  (`fp8_config5` reuses this
+    loops have finished; the child is a new process, nothing is exec'ed over this one.  (`config5_300k` reuses this
     with `--config5`.)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), *flags, "--gpus", "1", "--steps", str(args.steps),
@@ -759,6 +764,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # experiment switches of the sweep scripts (PCD_OPT_*, PCD_RB_*, ...): the product modules read no environment variable
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import env_switches
+    env_switches.apply()
     # (opt-in, PCD_BIND_GPU_NUMA=1: launch thread + pinned staging buffers on the GPU's own NUMA node.  Measured on a
     #  2-socket gpurun box: the HBM-resident loop is unchanged (3.39 ms) and the H2D-inclusive loop gets SLOWER when bound to
     #  the node sysfs reports as local -- 4.8 vs 3.47 ms per step -- so it is off)
@@ -1088,8 +1097,11 @@ def main():
                         bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
                         if "voxel_num_rows" in vox_out:
                             bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
-                        bd_in["after_rulebooks_hook"] = early
-                        train_from_voxels(bd_in)
+                        model.backbone_3d.after_rulebooks = early      # (documented hook of the backbone: backbone3d.py)
+                        try:
+                            train_from_voxels(bd_in)
+                        finally:
+                            model.backbone_3d.after_rulebooks = None
                     else:
                         train_from_voxels(vox_out)
                         voxelize_next()
@@ -1150,6 +1162,46 @@ def main():
                 # the first replay trains on whatever vox_out holds: voxelise batch 0 of THIS loop's source into it (eager
                 # launches into the graph's own buffers), so that every loop -- and every execution form -- sees the
                 # batches in the same order 0, 1, 2, ...
+                pts, offs = source.get(0)
+                s_pts.copy_(pts, non_blocking=True)
+                s_offs.copy_(offs, non_blocking=True)
+                source.release(0)
+                voxelize(s_pts, s_offs, out=vox_out)
+            state["prime"] = prime
+        elif os.environ.get('PCD_N_GT_1_FORM', 'early') != '3graph':
+            # N > 1 (default): ONE graph for forward + backward with the next batch voxelised mid-forward on the rulebook
+            # stream -- exactly the body of the one-graph form -- then the gradient all-reduce (RCCL, a plain call: no
+            # collective is captured) and clip + Adam as plain launches.  Against the three-graph form below: one graph launch
+            # less per step, and the voxelisation sits where the one-graph form has it instead of behind the backward pass.
+            vox_out = voxelize(s_pts, s_offs)
+            torch.cuda.synchronize()
+            g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb):
+                def early():                                 # (called on the rulebook stream, behind its last unit)
+                    vox_next = voxelize(s_pts, s_offs, out=vox_out)
+                    assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
+                bd_in = dict(vox_out)
+                bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)      # (copies by kernels: see the one-graph form)
+                if "voxel_num_rows" in vox_out:
+                    bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
+                model.backbone_3d.after_rulebooks = early
+                try:
+                    train_from_voxels(bd_in)
+                finally:
+                    model.backbone_3d.after_rulebooks = None
+                plan.arm()
+
+            def run_step(i, source=resident):
+                pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
+                schedule()
+                s_pts.copy_(pts, non_blocking=True)          # device -> device
+                s_offs.copy_(offs, non_blocking=True)
+                source.release(i + 1)
+                g_fb.replay()
+                bucket.all_reduce_sum()                      # RCCL over xGMI
+                opt_step()                                   # three plain launches: cheaper than a graph replay
+
+            def prime(source):
                 pts, offs = source.get(0)
                 s_pts.copy_(pts, non_blocking=True)
                 s_offs.copy_(offs, non_blocking=True)
@@ -1418,7 +1470,7 @@ def main():
                    "optimizer": "adam_onecycle (decoupled wd 0.01, betas (OneCycle MOMS, 0.99), clip 10)",
                    "dense_head": bool(args.dense_head), "com_head": bool(args.com),
                    "distinct_batches": n_batches, "recaptures": recaptures[0],
-                   "execution": (("hipGraph replay (one graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream, then clip+Adam)" if os.environ.get('PCD_VOX_EARLY', '1') != '0' else "hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)") if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else "hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam") + ", device-side row counts, sticky overflow guard"
+                   "execution": (("hipGraph replay (one graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream, then clip+Adam)" if os.environ.get('PCD_VOX_EARLY', '1') != '0' else "hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)") if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else ("hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam" if os.environ.get('PCD_N_GT_1_FORM', 'early') == '3graph' else "hipGraph replay (ONE graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream), all-reduce, clip+Adam as plain launches")) + ", device-side row counts, sticky overflow guard"
                                 if use_graph else "eager launches"},
     }
     if h2d is not None:
@@ -1456,26 +1508,35 @@ def main():
         torch.cuda.synchronize()
         result["full_model"] = measure_full_model(args)
     if rank == 0 and world == 1 and not args.no_fp8 and not args.dense_head and not args.config5:
-        result["fp8_config5"] = measure_full_model(
+        # BASELINE config 5's workload (SECOND / VoxelBackBone8x, 300k-point clouds).  Its FAST path on gfx950 is bf16: the
+        # non-scaled fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8) issues at the bf16 rate (MI355X_MICROARCH.md: only the MX-scaled
+        # K = 128 form reaches the 5 PF fp8 peak, and a per-offset contraction over 16..64 channels cannot feed it), so e4m3
+        # features buy bandwidth only -- and the bf16 window kernels already stage every row once.  `config5_300k.value` is
+        # therefore the bf16 step; the fp8-forward step (parity-tested: tests/test_fp8.py, test_gpu_fp8_train.py) is kept
+        # beside it as `fp8_forward_parity_path`, with the ratio -- DESIGN.md section 0 row g.
+        bf = measure_full_model(args, flags=("--config5",),
+                                what="child run `bench.py --config5` with bf16 forward convs: BASELINE config 5's workload as a "
+                                     "TRAINING step -- SECOND's VoxelBackBone8x on 300k-point clouds, window kernels where they "
+                                     "apply, batch-statistics BatchNorm; one hipGraph per step",
+                                extra_env={"PCD_CONFIG5_BF16": "1"})
+        result["config5_300k"] = bf
+        f8 = measure_full_model(
             args, flags=("--config5",),
-            what="child run `bench.py --config5`: BASELINE config 5 as a TRAINING step -- SECOND's VoxelBackBone8x on "
-                 "300k-point clouds, fp8 (e4m3, v_mfma_f32_16x16x32_fp8_fp8) forward convs with static per-tensor scales, "
-                 "batch-statistics BatchNorm, bf16 backward; one hipGraph per step")
-        if isinstance(result["fp8_config5"], dict) and "value" in result["fp8_config5"]:
-            # the SAME workload with bf16 forward convs (window kernels where they apply): what the fp8 forward is worth
-            ref = measure_full_model(args, flags=("--config5",), what="the same child run with bf16 forward convs",
-                                     extra_env={"PCD_CONFIG5_BF16": "1"})
-            if isinstance(ref, dict) and "value" in ref:
-                result["fp8_config5"]["bf16_same_workload"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"]}
-                result["fp8_config5"]["fp8_over_bf16"] = round(result["fp8_config5"]["value"] / ref["value"], 4)
+            what="the same child run with fp8 (e4m3, v_mfma_f32_16x16x32_fp8_fp8) FORWARD convs, static per-tensor scales, "
+                 "bf16 backward")
+        if isinstance(bf, dict) and isinstance(f8, dict) and "value" in f8:
+            bf["fp8_forward_parity_path"] = {k: f8[k] for k in ("value", "unit", "ms_per_step", "config") if k in f8}
+            if "value" in bf:
+                bf["fp8_over_bf16"] = round(f8["value"] / bf["value"], 4)
     if rank == 0 and world == 1 and not args.no_n_gt_1 and not args.dense_head and not args.config5 \
             and not os.environ.get("PCD_FORCE_3GRAPH") and not os.environ.get("PCD_RCCL_WORLD1"):
-        # what N > 1 GPUs run, measured on this one GPU: the three-graph form (voxelise | forward + backward | all-reduce of
-        # the flat gradient bucket, then clip + Adam) with a real RCCL communicator of ONE rank, and the same form without
-        # the collective -- the difference is what the exchange step costs a rank before any byte crosses xGMI
-        a = measure_full_model(args, flags=(), what="three-graph form + dist.all_reduce over a one-rank RCCL communicator",
+        # what N > 1 GPUs run, measured on this one GPU: ONE graph for forward + backward (the next batch voxelised mid-forward),
+        # the all-reduce of the flat gradient bucket, clip + Adam as plain launches -- with a real RCCL communicator of ONE
+        # rank, and the same form without the collective: the difference is what the exchange step costs a rank before any
+        # byte crosses xGMI
+        a = measure_full_model(args, flags=(), what="N > 1 form + dist.all_reduce over a one-rank RCCL communicator",
                                extra_env={"PCD_RCCL_WORLD1": "1"})
-        b = measure_full_model(args, flags=(), what="three-graph form, no collective", extra_env={"PCD_FORCE_3GRAPH": "1"})
+        b = measure_full_model(args, flags=(), what="N > 1 form, no collective", extra_env={"PCD_FORCE_3GRAPH": "1"})
         if "error" in a or "error" in b:
             result["n_gt_1_form"] = {"error": a.get("error") or b.get("error")}
         else:
@@ -1483,8 +1544,9 @@ def main():
                 "ms_per_step": a["ms_per_step"], "ms_per_step_no_collective": b["ms_per_step"],
                 "ms_allreduce_exposed": round(a["ms_per_step"] - b["ms_per_step"], 4),
                 "ms_per_step_one_graph": result["ms_per_step"], "bucket_MB": round(bucket.flat.numel() * 4 / 1e6, 2),
-                "what": "the N > 1 execution form on ONE GPU (child runs): voxelise | forward+backward | all-reduce | clip+Adam "
-                        "as three graphs around the collective; a one-rank RCCL all-reduce moves no bytes, so "
+                "what": "the N > 1 execution form on ONE GPU (child runs): [forward+backward graph incl. the mid-forward "
+                        "voxelisation of the next batch] | all-reduce | clip+Adam as plain launches (until round 4: voxelise-graph | "
+                        "forward+backward-graph, PCD_N_GT_1_FORM=3graph); a one-rank RCCL all-reduce moves no bytes, so "
                         "ms_allreduce_exposed is the launch / synchronisation cost of the exchange step only -- the wire "
                         "time of 2 (N-1)/N x bucket over xGMI comes on top at N > 1 (DESIGN.md section 6)"}
     if rank == 0:

@@ -275,13 +275,8 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        # experiment scripts pass tuning options through the environment: PCD_OPT_<KEY>=<int> -> pcd_set_option (the
-        # library itself reads no environment variable).  Applied BEFORE the handle is published: a mistyped option fails
-        # every call, not just the first.
-        for k, v in os.environ.items():
-            if k.startswith("PCD_OPT_"):
-                if handle.pcd_set_option(k[8:].lower().encode(), int(v)) != 0:
-                    raise PcdError(f"unknown tuning option {k}")
+        # (tuning options are set through set_option -- bench.py / tools/ forward PCD_OPT_<KEY> environment variables with
+        #  tools/env_switches.py; neither this module nor the library reads the environment)
         _lib = handle
     return _lib
 

@@ -70,7 +70,7 @@ class SparseBasicBlock(spconv.SparseModule):
 
 
 class _RulebookPrefetcher:
-    event_per_rulebook = __import__("os").environ.get("PCD_RB_EVENT_EACH", "0") == "1"   # (measured: no difference)
+    event_per_rulebook = False     # (one event per rulebook instead of per unit -- measured: no difference)
 
     def __init__(self, units, x0, side):
         self.units, self.t, self.side, self.next = units, x0, side, 0
@@ -165,10 +165,14 @@ class _BackboneBase(nn.Module):
                 torch._foreach_add_(counters, 1)
 
     prefetch_rulebooks = True
-    first_unit_inline = __import__("os").environ.get("PCD_RB_INLINE0", "0") == "1"   # measured: see _prefetch_rulebooks
-    unit0_own_stream = __import__("os").environ.get("PCD_RB_UNIT0_STREAM", "1") == "1"
+    # Optional callable, run ONCE per forward on the rulebook stream right behind its last unit -- the point from which nothing
+    # issued later reads the voxeliser's outputs (level-1 coordinates, coordinate -> row map): a caller that recycles those
+    # buffers (bench.py voxelises the NEXT batch into them, inside the captured step) continues there.  None: nothing runs.
+    after_rulebooks = None
+    first_unit_inline = False      # measured: see _prefetch_rulebooks
+    unit0_own_stream = True
     # rulebook units issued before the first conv; each unit's first consumer issues one more
-    prefetch_depth = int(__import__("os").environ.get("PCD_RB_DEPTH", "2"))
+    prefetch_depth = 2
 
     def _prefetch_rulebooks(self, x0):
         """All 9 rulebooks depend only on the voxel coordinates, not on features: they are built on a second HIP
@@ -267,8 +271,8 @@ class _BackboneBase(nn.Module):
         ops.stamp("fwd_begin")
         if ops.STAMPS is not None:
             ops.STAMPS["conv_seq"] = 0
-        if batch_dict.get('after_rulebooks_hook', None) is not None:
-            x0.indice_dict["__after_units__"] = batch_dict['after_rulebooks_hook']
+        if self.after_rulebooks is not None:
+            x0.indice_dict["__after_units__"] = self.after_rulebooks
         self._prefetch_rulebooks(x0)
         x = self.conv_input(x0)
         ops.stamp("conv_input")

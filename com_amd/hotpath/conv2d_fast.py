@@ -18,7 +18,7 @@ ENABLED = True
 # statistics, bit 1 = backward reductions on the data-gradient launch.  Measured in the full step
 # (tools/exp_dense_bn_epi.sh, 2 x 80 replays): off 7.84, forward 7.79, backward 7.89, both 7.86 ms -- the backward form
 # re-reads the BatchNorm's input and output tile in the data-gradient epilogue and loses; only the forward one is on.
-DENSE_BN_EPILOGUE = int(os.environ.get('PCD_DENSE_BN_EPI', '1'))
+DENSE_BN_EPILOGUE = 1
 _PAIRS = {}
 
 
@@ -50,7 +50,7 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
-BATCH_BN_COUNTERS = os.environ.get('PCD_BN2D_BUMP', '1') != '0'
+BATCH_BN_COUNTERS = True
 
 
 def _plane_pairs(mode_f, B, hi, wi, device):

@@ -782,7 +782,7 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
 
 
 import os as _os
-BN_FUSED_MID = _os.environ.get("PCD_BN_FUSED_MID", "1") != "0"   # fold the BatchNorm "mid" reduction into the conv launches
+BN_FUSED_MID = True       # fold the BatchNorm "mid" reduction into the conv launches
 _BN_COUNTER_POOL = {}     # device -> [int32 zeros [slots * 16], next slot]     (eager launches)
 _BN_CAPTURE_BLOCK = {}    # (device, stream) -> [capture id, int32 zeros, next slot]   (launches recorded into a hipGraph)
 _BN_SLOTS = 1024
@@ -1368,7 +1368,7 @@ def conv2d_wgrad(x, dy, cout=None, out=None, defer=None):
 # Dense weight-gradient kernels for the plane operators (stride-2 conv, deconvs): built, bit-checked against the pair
 # kernels -- and NOT faster in the step (tools/exp_wgp_blocks.sh: 7.81-7.85 vs 7.79 ms with the pair kernels; isolated the
 # k = stride deconvs gain, 31 / 60 vs 76 us at 512 workgroups, the stride-2 conv loses, 99 vs 80 us): off unless asked for.
-CONV2D_WGRAD_PLANES = _os.environ.get("PCD_CONV2D_WGP", "0") == "1"
+CONV2D_WGRAD_PLANES = False
 
 
 def conv2d_wgrad_planes_splits(mode_f, B, hc, wc, cf, cc):

@@ -11,7 +11,9 @@
  *   - the caller owns every buffer (outputs, workspaces); the library never allocates or frees
  *     device memory and keeps no pointer after returning; all work is enqueued on `stream`
  *     (a hipStream_t, may be NULL for the default stream) and NOT synchronised;
- *   - functions are re-entrant: no global state;
+ *   - functions keep no state between calls and may be called from several host threads; the ONLY process-wide state is the
+ *     tuning-option table (pcd_set_option: set before the first launch, read unsynchronised at launch time) and the two
+ *     profiling pointers that are NULL unless a tool sets them (pcd_subm_window_set_trace);
  *   - index tensors are int32, coordinates are (batch, z, y, x) rows of 4 int32.
  *
  * Device-side row counts: wherever a function takes a row count `n` together with a `const int32_t *n_dev`

@@ -1,8 +1,9 @@
 """GPU: bench.py's execution forms must be the same computation.
 
-  * the N = 1 form (ONE hipGraph per step) and the N > 1 form run on one GPU (PCD_FORCE_3GRAPH=1: voxelise-graph |
-    forward+backward-graph, all-reduce, clip+Adam as plain launches) must leave BIT-IDENTICAL parameters and gradients
-    after the same steps on the same data;
+  * the N = 1 form (ONE hipGraph per step) and the N > 1 form run on one GPU (PCD_FORCE_3GRAPH=1: one graph for
+    forward+backward incl. the mid-forward voxelisation of the next batch, then the all-reduce and clip+Adam as plain
+    launches; PCD_N_GT_1_FORM=3graph: the older voxelise-graph | forward+backward-graph form) must leave BIT-IDENTICAL
+    parameters and gradients after the same steps on the same data;
   * two ranks (PCD_DIST_ONE_GPU=1, gloo, both on cuda:0; bench.py starts them itself from `--gpus 2`) that both
     process rank 0's frames (--same-shard) sum two identical gradients and divide by the world size -- exact in
     binary floating point -- so they too must end bit-identical to the one-rank run: this exercises the launcher,
@@ -22,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(tmp_path, tag, args, env=None):
     e = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCD_FORCE_3GRAPH", "PCD_DIST_ONE_GPU",
-              "PCD_DIST_BACKEND", "PCD_RCCL_WORLD1"):
+              "PCD_DIST_BACKEND", "PCD_RCCL_WORLD1", "PCD_N_GT_1_FORM"):
         e.pop(k, None)
     e.update(env or {})
     dump = tmp_path / f"{tag}.json"
@@ -39,11 +40,15 @@ def _bench(tmp_path, tag, args, env=None):
 @pytest.mark.timeout(1800)
 def test_one_graph_three_graph_and_two_rank_forms_are_bit_identical(tmp_path):
     res1, st1 = _bench(tmp_path, "one_graph", ["--gpus", "1"])
-    res3, st3 = _bench(tmp_path, "three_graph", ["--gpus", "1"], env={"PCD_FORCE_3GRAPH": "1"})
+    res3, st3 = _bench(tmp_path, "n_gt_1", ["--gpus", "1"], env={"PCD_FORCE_3GRAPH": "1"})
     assert res1["n_gpus"] == res3["n_gpus"] == 1
-    assert "one graph" in res1["config"]["execution"] and "voxelise [prefetched" in res3["config"]["execution"]
+    assert "one graph" in res1["config"]["execution"] and "all-reduce, clip+Adam as plain launches" in res3["config"]["execution"]
     assert st1["param_sha256"] == st3["param_sha256"], (st1, st3)
     assert st1["grad_sha256"] == st3["grad_sha256"]
+    # the older N > 1 form (voxelise-graph | forward+backward-graph on two streams), still selectable
+    res3o, st3o = _bench(tmp_path, "three_graph", ["--gpus", "1"], env={"PCD_FORCE_3GRAPH": "1", "PCD_N_GT_1_FORM": "3graph"})
+    assert "voxelise [prefetched" in res3o["config"]["execution"]
+    assert st1["param_sha256"] == st3o["param_sha256"] and st1["grad_sha256"] == st3o["grad_sha256"]
     res2, st2 = _bench(tmp_path, "two_ranks", ["--gpus", "2"], env={"PCD_DIST_ONE_GPU": "1", "PCD_DIST_BACKEND": "gloo"})
     assert res2["n_gpus"] == 2 and res2["rccl_ranks"] == 2 and len(res2["ms_per_step_ranks"]) == 2
     assert res2["config"]["global_batch"] == 4 and res2["config"]["parallelism"] == "dp2"
@@ -59,7 +64,7 @@ def test_rccl_communicator_runs_the_three_graph_form_on_one_gpu(tmp_path):
     replays.  A sum over one rank is the identity, so the parameters must equal the one-graph run bit for bit."""
     res1, st1 = _bench(tmp_path, "one_graph_b", ["--gpus", "1"])
     resr, str_ = _bench(tmp_path, "rccl_world1", ["--gpus", "1"], env={"PCD_RCCL_WORLD1": "1"})
-    assert resr["collective_backend"] == "nccl" and "voxelise [prefetched" in resr["config"]["execution"]
+    assert resr["collective_backend"] == "nccl" and "all-reduce, clip+Adam as plain launches" in resr["config"]["execution"]
     assert str_["param_sha256"] == st1["param_sha256"], (st1, str_)
 
 

@@ -1,0 +1,37 @@
+"""Experiment switches of bench.py and the tools: environment variables -> module attributes / library options.
+
+The product modules (com_amd/**) and the library read NO environment variable; their tunables are plain attributes with the
+measured optimum as default and `pcd_set_option`.  The scripts that sweep them (tools/*.sh, bench.py children) pass values
+through the environment -- this module, imported only by bench.py and tools/, applies them:
+
+  PCD_OPT_<KEY>=<int>       pcd_set_option(<key>, <int>)                  (include/pcd_ops.h lists the keys)
+  PCD_BN_FUSED_MID=0/1      ops.BN_FUSED_MID                              fold the BatchNorm mid reduction into the conv launches
+  PCD_CONV2D_WGP=0/1        ops.CONV2D_WGRAD_PLANES                       dense weight gradient in the planes form
+  PCD_DENSE_BN_EPI=<bits>   hotpath.conv2d_fast.DENSE_BN_EPILOGUE         BatchNorm sums in the dense convs' epilogues
+  PCD_BN2D_BUMP=0/1         hotpath.conv2d_fast.BATCH_BN_COUNTERS
+  PCD_RB_EVENT_EACH=0/1     backbone3d._RulebookPrefetcher.event_per_rulebook
+  PCD_RB_INLINE0=0/1        backbone3d._BackboneBase.first_unit_inline
+  PCD_RB_UNIT0_STREAM=0/1   backbone3d._BackboneBase.unit0_own_stream
+  PCD_RB_DEPTH=<int>        backbone3d._BackboneBase.prefetch_depth
+  PCD_COLMAP=0/1            ops.USE_COLUMN_MAPS                           column-map rulebook builds (0: flat key-space bitmaps)
+"""
+import os
+
+
+def apply(environ=None):
+    env = os.environ if environ is None else environ
+    from com_amd import _lib as L, ops
+    from com_amd.hotpath import backbone3d, conv2d_fast
+    for k, v in env.items():
+        if k.startswith("PCD_OPT_"):
+            L.set_option(k[8:].lower(), int(v))                 # (raises on an unknown key)
+    flag = lambda name, default: env.get(name, "1" if default else "0") != "0"
+    ops.BN_FUSED_MID = flag("PCD_BN_FUSED_MID", ops.BN_FUSED_MID)
+    ops.CONV2D_WGRAD_PLANES = flag("PCD_CONV2D_WGP", ops.CONV2D_WGRAD_PLANES)
+    ops.USE_COLUMN_MAPS = flag("PCD_COLMAP", ops.USE_COLUMN_MAPS)
+    conv2d_fast.DENSE_BN_EPILOGUE = int(env.get("PCD_DENSE_BN_EPI", conv2d_fast.DENSE_BN_EPILOGUE))
+    conv2d_fast.BATCH_BN_COUNTERS = flag("PCD_BN2D_BUMP", conv2d_fast.BATCH_BN_COUNTERS)
+    backbone3d._RulebookPrefetcher.event_per_rulebook = flag("PCD_RB_EVENT_EACH", backbone3d._RulebookPrefetcher.event_per_rulebook)
+    backbone3d._BackboneBase.first_unit_inline = flag("PCD_RB_INLINE0", backbone3d._BackboneBase.first_unit_inline)
+    backbone3d._BackboneBase.unit0_own_stream = flag("PCD_RB_UNIT0_STREAM", backbone3d._BackboneBase.unit0_own_stream)
+    backbone3d._BackboneBase.prefetch_depth = int(env.get("PCD_RB_DEPTH", backbone3d._BackboneBase.prefetch_depth))

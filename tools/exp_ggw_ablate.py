@@ -5,6 +5,9 @@ import numpy as np
 import torch
 sys.path.insert(0, '.')
 from com_amd import ops, hotpath, _lib as L
+sys.path.insert(0, 'tools')
+import env_switches
+env_switches.apply()          # PCD_OPT_* -> pcd_set_option
 from com_amd.utils import synth
 
 dev = torch.device("cuda")

@@ -7,8 +7,9 @@ sys.path.insert(0, '.')
 from com_amd import ops, hotpath
 from com_amd.utils import synth
 dev = 'cuda'
-if os.environ.get('PCD_COLMAP', '1') == '0':      # the flat key-space bitmap builds of rounds 1-4
-    ops.USE_COLUMN_MAPS = False
+sys.path.insert(0, 'tools')
+import env_switches
+env_switches.apply()          # (PCD_COLMAP=0: the flat key-space bitmap builds of rounds 1-4; PCD_OPT_*)
 
 
 def timed_graph(fn, key, n_out, reps=10, inner=8):
