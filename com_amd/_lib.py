@@ -113,6 +113,8 @@ PROTOTYPES = {
     "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
                                          _vp]),
+    "pcd_sparse_conv_gather_gemm_zfast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
+                                         _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_v2": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -988,8 +988,10 @@ class PackPlan:
 
 
 def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None, addend=None,
-                bn_reduce=None):
-    """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o])  (output-stationary; forward and dgrad)."""
+                bn_reduce=None, zfast=False):
+    """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o])  (output-stationary; forward and dgrad).
+    zfast: `nbr` is a SubM 3x3x3 table over rows numbered z-fastest (ROWS_YXZ) -- the 128-channel layers then stage x
+    through row windows (ggwin_kernel) instead of gathering 27 slots per row; same result within one bf16 ulp."""
     _require_cuda(x, packed_w, nbr)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and nbr.is_contiguous()
     y = torch.empty((n_rows_out, c_out), dtype=out_dtype, device=x.device)
@@ -1012,13 +1014,15 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     if PROFILE is not None:
         dg = int(bool(flip_k) or (bn_reduce is not None and bn_reduce.mode == 2))
         variant = L.lib().pcd_sparse_conv_gather_gemm_variant(x.shape[0], x.shape[1], kvol, n_rows_out, c_out, dg)
-        kname = {1: "ggw_kernel", 2: "ggwin_kernel", 3: "ggwave_kernel"}.get(variant, kname)
+        kname = {1: "ggw_kernel"}.get(variant, kname)
+        if variant == 1 and zfast and x.shape[1] == c_out == 128 and kvol == 27 and L.get_option("ggwin") \
+                and n_rows_out <= 256 * 192 * 5 // 4:
+            kname = "ggwin_kernel"
+    entry = L.lib().pcd_sparse_conv_gather_gemm_zfast if zfast else L.lib().pcd_sparse_conv_gather_gemm
     with _Timed(f"{kname}<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
-        L.check(L.lib().pcd_sparse_conv_gather_gemm(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias),
-                                                    L.ptr(nbr), nbr.shape[1], kvol, int(flip_k), n_rows_out,
-                                                    L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y),
-                                                    L.ptr(addend), _byref(bnr), L.stream_ptr()),
-                "pcd_sparse_conv_gather_gemm")
+        L.check(entry(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr), nbr.shape[1], kvol,
+                      int(flip_k), n_rows_out, L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y), L.ptr(addend), _byref(bnr),
+                      L.stream_ptr()), "pcd_sparse_conv_gather_gemm")
     return y
 
 

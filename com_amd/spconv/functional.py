@@ -153,7 +153,8 @@ class SparseConvFunction(Function):
             y = ops.subm_window(x, packed_fwd, b, rb, cout, bn_reduce=stats)
         else:
             y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
-                                n_dev=rb.n_out_dev, bn_reduce=stats)
+                                n_dev=rb.n_out_dev, bn_reduce=stats,
+                                zfast=rb.subm and rb.kvol == 27 and getattr(rb, "order", None) == ops.ROWS_YXZ)
         if stats is not None:
             y._pcd_stats = stats
         # bias gradient = column sum of our dy; when dy comes out of a fused BatchNorm backward that kernel sums it
@@ -228,7 +229,8 @@ class SparseConvFunction(Function):
             elif rb.subm:
                 assert not ctx.window, "window packs cannot feed the generic kernel"
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
-                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red)
+                                      ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red,
+                                      zfast=rb.kvol == 27 and getattr(rb, "order", None) == ops.ROWS_YXZ)
             elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
                     and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
                 # strided conv: rows grouped by parity class run only the 1..8 offsets they can use

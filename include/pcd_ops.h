@@ -87,6 +87,10 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "conv2d_wb" 1, "conv2d_wg_blocks" 128, "conv2d_wgp_mode2" 0, "conv2d_wgp_blocks" 512   dense 3x3 conv variants
  *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
  *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only)
+ *   "ggwin" 0             1: pcd_sparse_conv_gather_gemm_zfast runs 128 -> 128 SubM layers through ggwin_kernel (x through row
+ *                         windows); measured slower than the 27-slot gather kernel (55 vs 46 us), parity-tested, off
+ *   "subm_window_grid" 256   workgroups of a window launch (a multiple of 8, <= 256); fewer leave CUs to other streams --
+ *                         measured: no gain (240 / 224 / 192: 0 / -0.5 / -1 % in the step)
  *   "cm_direct_blocks" 4096   column-map builds: up to this many scan blocks add up the block sums themselves, beyond it a
  *                             spine launch runs (tests lower it to reach the spine path on small inputs) */
 int pcd_set_option(const char *key, int value);
@@ -406,6 +410,15 @@ int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *s
  * residual branch in the dgrad of a SparseBasicBlock's first conv (spconv_backbone.py:56-63) -- replaces the
  * elementwise add autograd would launch. */
 int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
+                                const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
+                                int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
+                                int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
+/* pcd_sparse_conv_gather_gemm for a SubM 3x3x3 neighbour table (spconv_backbone.py:12-13,219-222) whose rows are numbered
+ * z-fastest (PCD_ROWS_YXZ): the nine offsets sharing dy then read one contiguous run of rows, and -- with option "ggwin" --
+ * the 128 -> 128 layers stage those runs in LDS once (ggwin_kernel: half the DMA instructions of the 27-slot gather; offsets
+ * summed run by run, so the result equals pcd_sparse_conv_gather_gemm's within one bf16 ulp, not bit for bit).  Otherwise, and
+ * for any other width: the same kernels as pcd_sparse_conv_gather_gemm.  A table over another row numbering is still computed exactly (further passes), only slowly. */
+int pcd_sparse_conv_gather_gemm_zfast(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
                                 int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);

@@ -111,6 +111,54 @@ def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
     assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(y0.float().abs().max())
 
 
+@pytest.mark.parametrize("order", ["yxz", "shuffled"])
+def test_ggwin_128_channel_windows_against_the_oracle_and_the_generic_kernel(order, pcd_option):
+    """128 -> 128 SubM over z-fastest rows (pcd_sparse_conv_gather_gemm_zfast -> ggwin_kernel: x through row windows, weights
+    streamed): forward (+ bias) and the data gradient (k-flipped view, + addend) against the oracle on the same bf16 operands
+    (one bf16 ulp per element), the fp32-output form at 1e-3 per element, the BatchNorm sums of its epilogue, and against the
+    27-slot gather kernel (option ggwin = 0).  "shuffled": the same table over randomly numbered rows -- runs far longer than
+    the window, i.e. many passes: still exact."""
+    ops = _ops()
+    pcd_option("ggwin", 1)                                  # (off by default: 55 us against ggw_kernel's 46, DESIGN.md section 4.3)
+    idx, rank, shape = _level(1, 4, beams=64, azim=2500)
+    n, ch = idx.shape[0], 128
+    g = torch.Generator().manual_seed(77)
+    if order == "yxz":
+        rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False)
+        assert rb.order == ops.ROWS_YXZ
+    else:
+        perm = torch.randperm(n, generator=g).to(DEV)
+        idx = idx[perm].contiguous()
+        rb = ops.rulebook_subm(idx, 1, shape, want_pairs=False)
+    w = torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))
+    bias = torch.randn(ch, generator=g) * 0.1
+    x = _bf16(torch.randn(n, ch, generator=g).numpy())
+    add = _bf16(torch.randn(n, ch, generator=g).numpy())
+    wd, idx_np = w.to(DEV), idx.cpu().numpy()
+    run = lambda mode, b, a, dt, red=None: ops.gather_gemm(x.to(DEV), ops.pack_weight(wd, mode), b, rb.nbr_out, 27, bool(mode), n, ch, dt,
+                                                           addend=a, bn_reduce=red, zfast=True)
+    y = run(0, bias.to(DEV), None, torch.bfloat16)
+    ref = _oracle_fwd(x, w.numpy(), bias.numpy(), idx_np, shape, False)
+    _close(y, ref, "forward")
+    _close_f32(run(0, bias.to(DEV), None, torch.float32), ref, "forward, fp32 output")
+    dx = run(1, None, add.to(DEV), torch.bfloat16)
+    refd = _oracle_fwd(x, w.numpy(), None, idx_np, shape, True) + add.float().numpy()
+    _close(dx, refd, "dgrad")
+    st = ops.BnReduce(1)
+    y_bn = run(0, bias.to(DEV), None, torch.bfloat16, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y_bn, y)
+    got = st.partial.double().sum(0)
+    want = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)])
+    mag = torch.stack([y.double().abs().sum(0), (y.double() ** 2).sum(0)]).clamp_min(1.0)
+    assert float(((got - want).abs() / mag).max()) < 2e-6
+    pcd_option("ggwin", 0)
+    y0 = run(0, bias.to(DEV), None, torch.bfloat16)
+    d = (y0.float() - y.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(y0.float().abs().max())
+    assert not torch.equal(y0, y) or order == "yxz"       # (another summation order: a few elements land on the other side)
+
+
 @pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1), (128, 4)])
 def test_window_batchnorm_sums_match_the_generic_kernels(ch, lvl):
     """PcdBnReduce in the window kernel's epilogue: mode 1 (sum y, sum y^2 of the rounded outputs) and mode 2 (sum dz, sum
