@@ -2141,7 +2141,18 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
         }
         case 2:
             // (32 channels, staged: <2,2,2,2> / <2,2,2,4> / <2,4,2,2> / <2,2,4,4> / <2,4,1,2> measured 4.20-4.34 vs 4.18)
-            return resident ? launch_gg<2, 2, 1, 0>(GG_ARGS) : launch_gg<2, 2, 1, 2>(GG_ARGS);
+            if (resident) {
+                // (the one resident 32-output-channel layer left on this kernel is the strided 16 -> 32 conv: option "gg2"
+                //  selects look-ahead / rows per wave for it)
+                switch (pcd_opt(PCD_OPT_GG2)) {
+                    case 1: return launch_gg<2, 2, 2, 0>(GG_ARGS);
+                    case 2: return launch_gg<2, 1, 2, 0>(GG_ARGS);
+                    case 3: return launch_gg<2, 4, 1, 0>(GG_ARGS);
+                    case 4: return launch_gg<2, 1, 4, 0>(GG_ARGS);
+                    default: return launch_gg<2, 2, 1, 0>(GG_ARGS);
+                }
+            }
+            return launch_gg<2, 2, 1, 2>(GG_ARGS);
         case 4:
             return resident ? launch_gg<4, 2, 2, 0>(GG_ARGS) : launch_gg<4, 2, 2, 2>(GG_ARGS);
         case 8:

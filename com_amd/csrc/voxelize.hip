@@ -18,7 +18,7 @@
 // Dynamic voxelisation + mean (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72) needs the
 // voxels sorted by key: an occupancy bitmap over the key space + popcount prefix gives every key
 // its rank without sorting.
-#include "common.h"
+#include "colmap_common.h"
 
 namespace {
 
@@ -270,6 +270,89 @@ __global__ __launch_bounds__(256) void vox_flag_down_kernel(int *rank, int n, co
     if (i == n - 1) rank[n] = base + ex + v;
 }
 
+// ---- z-fastest rows: the level's COLUMN MAP instead of a bitmap over the key space ---------------------------------------
+// (b, y, x, z) order: a voxel's row = first row of its BEV column + the set z bits below its own.  Two marks (BEV occupancy
+// bit, then the z bit in the column's 64-bit mask, both order-free ORs), two scans (words -> column ranks, columns -> first
+// rows): 1.1 MB + 16 bytes per column instead of a 46 MB bitmap (zero-filled, scanned and probed at random) + 11.6 MB of
+// prefixes -- and the result IS level 1's coordinate -> row map for the rulebook builds (colmap.hip).
+__global__ __launch_bounds__(256) void vox_cm_mark_kernel(
+    const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
+    VoxGeom G, const int *__restrict__ rank, int max_voxels, int cap, int *frame_rank0, int *frame_base,
+    int32_t *voxel_counts, u32 *cbits, int pitch) {
+    __shared__ int r_s[VOX_FOLD_FRAMES + 1];
+    __shared__ int m_s[VOX_FOLD_FRAMES];
+    for (int b = threadIdx.x; b <= batch; b += 256) r_s[b] = rank[offs[b]];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int base = 0;
+        for (int b = 0; b < batch; ++b) {
+            int m = r_s[b + 1] - r_s[b];
+            if (m > max_voxels) m = max_voxels;
+            if (base + m > cap) m = cap - base;
+            m_s[b] = m;
+            if (blockIdx.x == 0) {
+                frame_rank0[b] = r_s[b];
+                frame_base[b] = base;
+                voxel_counts[b] = m;
+            }
+            base += m;
+        }
+        if (blockIdx.x == 0) voxel_counts[batch] = base;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int rk = rank[i];
+    if (rank[i + 1] == rk) return;                 // not the first point of a voxel
+    const int b = frame_of(offs, batch, i);
+    if (rk - r_s[b] >= m_s[b]) return;
+    const float *p0 = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p0[0], p0[1], p0[2]};
+    int cx, cy, cz;
+    voxel_coord(xyz, G, cx, cy, cz);
+    const u32 key = bev_key(b, cy, cx, G.gy, pitch);
+    atomicOr(cbits + (key >> 5), 1u << (key & 31u));
+}
+
+__global__ __launch_bounds__(256) void vox_cm_zmark_kernel(
+    const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
+    VoxGeom G, const int *__restrict__ rank, const int *__restrict__ frame_rank0, const int32_t *__restrict__ voxel_counts,
+    const uint2 *__restrict__ cw, int ncol_cap, u64 *__restrict__ zm, int pitch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int rk = rank[i];
+    if (rank[i + 1] == rk) return;
+    const int b = frame_of(offs, batch, i);
+    if (rk - frame_rank0[b] >= voxel_counts[b]) return;
+    const float *p0 = pts + (size_t)i * stride + feat_off;
+    float xyz[3] = {p0[0], p0[1], p0[2]};
+    int cx, cy, cz;
+    voxel_coord(xyz, G, cx, cy, cz);
+    const u32 key = bev_key(b, cy, cx, G.gy, pitch);
+    const int col = cm_col(cw[key >> 5], key, ncol_cap);
+    if (col >= 0) atomicOr((unsigned long long *)(zm + col), 1ull << cz);
+}
+
+struct ZmCount {
+    const u64 *zm;
+    __device__ int operator()(int i) const { return __popcll(zm[i]); }
+};
+
+// z masks -> column records {mask, first row, rows}: the down pass of the scan over the columns
+__global__ __launch_bounds__(256) void vox_cm_cols_kernel(const u64 *__restrict__ zm, int ncols_cap, const int *__restrict__ bsums,
+                                                          int spined, uint4 *__restrict__ cr, int *__restrict__ ncols) {
+    __shared__ int lds[4];
+    __shared__ int base_s;
+    const int base = blocks_before(blockIdx.x, bsums, spined, lds, &base_s);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const u64 m = i < ncols_cap ? zm[i] : 0ull;
+    const int v = __popcll(m);
+    int total;
+    const int ex = block_exclusive_scan(v, lds, total);
+    if (i < ncols_cap) cr[i] = make_uint4((u32)m, (u32)(m >> 32), (u32)(base + ex), (u32)v);
+    if (i == ncols_cap - 1 && ncols) ncols[1] = base + ex + v;     // (rows; ncols[0] = columns, written by the word scan)
+}
+
 // Prefix GROUPS of 4 bitmap words (16 bytes, 128 keys): population count of every group.  A block covers 2048 groups
 // in 8 coalesced rounds (whole 4-KiB block loads); also block sums.
 constexpr int VOX_GROUPS_PER_BLOCK = 2048;
@@ -344,8 +427,9 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     const int32_t *__restrict__ offs, int batch, VoxGeom G, int T, int L, const u32 *__restrict__ best,
     const int32_t *__restrict__ pt_slot, const int *__restrict__ rank, const int *frame_rank0,
     const int *frame_base, const int32_t *voxel_counts, float *voxels, int32_t *coords,
-    int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride,
-    const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix) {
+    int32_t *num_points, float *mean_f32, unsigned short *mean_bf16, int bf16_stride, int cap_rows,
+    const u32 *__restrict__ bitmap, const int *__restrict__ chunk_prefix, const uint2 *__restrict__ cw,
+    const uint4 *__restrict__ cr, int ncol_cap, int pitch) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int rk = rank[i];
@@ -359,7 +443,14 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     float xyz[3] = {p0[0], p0[1], p0[2]};
     int cx, cy, cz;
     voxel_coord(xyz, G, cx, cy, cz);
-    if (bitmap)    // key order (frames are the key's major digit: frame b still owns rows frame_base[b] ..)
+    if (cw) {      // z-fastest rows through the column map: first row of the BEV column + the set z bits below
+        const u32 key = bev_key(b, cy, cx, G.gy, pitch);
+        const int col = cm_col(cw[key >> 5], key, ncol_cap);
+        if (col < 0) return;                       // (column beyond the capacity: its rows are dropped like any row beyond it)
+        const uint4 r = cr[col];
+        row = cm_row((u64)r.x | ((u64)r.y << 32), (int)r.z, cz);
+        if (row < 0 || row >= cap_rows) return;
+    } else if (bitmap)    // key order (frames are the key's major digit: frame b still owns rows frame_base[b] ..)
         row = vox_sorted_row(bitmap, chunk_prefix, vox_key_u32(G, b, cz, cy, cx));
     reinterpret_cast<int4 *>(coords)[row] = make_int4(b, cz, cy, cx);
     float sum[16];
@@ -524,11 +615,18 @@ static bool sorted_words(int batch, const VoxGeom &G, size_t *nwords, size_t *nc
     return true;
 }
 
-static size_t hard_workspace_bytes(int n_points, int max_points, int batch, const VoxGeom *G) {
+static size_t hard_workspace_bytes(int n_points, int max_points, int batch, const VoxGeom *G, int cm_cap = 0) {
     if (n_points < 0 || max_points <= 0 || batch <= 0) return 0;
     u32 cap = table_capacity(n_points);
     size_t b = 0;
-    if (G) {
+    if (G && cm_cap > 0) {         // z-fastest rows through the column map (no key-space bitmap)
+        CmBuf B;
+        if (!cm_carve(nullptr, 0, batch, G->gy, G->gx, cm_cap, B, nullptr)) return 0;
+        b += ws_piece(B.nwords + 4, sizeof(u32));                          // BEV occupancy bits
+        b += ws_piece(pcd_div_up((int)B.nwords, 1024) + 2, sizeof(int));   // their block sums
+        b += ws_piece((size_t)B.ncol_cap + 1, sizeof(u64));                // z masks by column
+        b += ws_piece(pcd_div_up(B.ncol_cap, 256) + 2, sizeof(int));       // block sums of the column scan
+    } else if (G) {
         size_t nw, nc;
         if (!sorted_words(batch, *G, &nw, &nc)) return 0;
         b += ws_piece(nw, sizeof(u32));                    // occupancy bitmap of the kept voxels (unless the caller's)
@@ -565,7 +663,8 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
                               int32_t *coords, int32_t *num_points, float *mean_f32,
                               void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts,
                               void *workspace, size_t workspace_bytes, void *stream, bool key_order,
-                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth, int row_order) {
+                              uint32_t *rank_bitmap, int32_t *rank_prefix, int key_depth, int row_order,
+                              void *colmap = nullptr, size_t colmap_bytes = 0) {
     PCD_ENTER();
     if (row_order != PCD_ROWS_ZYX && row_order != PCD_ROWS_YXZ) return PCD_ERR_INVALID_ARG;
     if (n_points < 0 || batch <= 0 || max_points <= 0 || max_voxels < 0 || cap < 0 ||
@@ -584,13 +683,25 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     G.order = row_order;
     if ((double)batch * G.gx * G.gy * G.gz >= 1.8e19) return PCD_ERR_KEYSPACE;
     size_t nw = 0, nc = 0;
-    if (key_order && !sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
-    if (workspace_bytes < hard_workspace_bytes(n_points, max_points, batch, key_order ? &G : nullptr))
+    const bool cm = colmap != nullptr;             // z-fastest rows through the column map, which the caller keeps
+    if (cm && (!key_order || row_order != PCD_ROWS_YXZ || G.kz > 62 || batch > VOX_FOLD_FRAMES)) return PCD_ERR_UNSUPPORTED;
+    if (key_order && !cm && !sorted_words(batch, G, &nw, &nc)) return PCD_ERR_KEYSPACE;
+    if (workspace_bytes < hard_workspace_bytes(n_points, max_points, batch, key_order ? &G : nullptr, cm ? (cap > 0 ? cap : 1) : 0))
         return PCD_ERR_WORKSPACE;
     WsCarver ws(workspace, workspace_bytes);
     u32 *bitmap = nullptr;
     int *chunk_bsums = nullptr, *chunk_prefix = nullptr;
-    if (key_order) {
+    CmBuf CB = {};
+    u32 *cbits = nullptr;
+    int *cbsums = nullptr, *colsums = nullptr;
+    u64 *zm = nullptr;
+    if (cm) {
+        if (!cm_carve(colmap, colmap_bytes, batch, G.gy, G.gx, cap > 0 ? cap : 1, CB, nullptr)) return PCD_ERR_WORKSPACE;
+        cbits = ws.take<u32>(CB.nwords + 4);
+        cbsums = ws.take<int>(pcd_div_up((int)CB.nwords, 1024) + 2);
+        zm = ws.take<u64>((size_t)CB.ncol_cap + 1);
+        colsums = ws.take<int>(pcd_div_up(CB.ncol_cap, 256) + 2);
+    } else if (key_order) {
         bitmap = ws.take<u32>(nw);
         chunk_prefix = ws.take<int>(nc + 8);
         chunk_bsums = ws.take<int>(pcd_div_up((int)nc, VOX_GROUPS_PER_BLOCK) + 2);
@@ -611,8 +722,11 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     int *frame_base = ws.take<int>(batch + 1);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     int nb = pcd_div_up(n_points, 256);
-    const bool fast_sorted = key_order && n_points > 0 && batch <= VOX_FOLD_FRAMES;
-    if (key_order && n_points > 0)
+    const bool fast_sorted = key_order && !cm && n_points > 0 && batch <= VOX_FOLD_FRAMES;
+    if (cm) {
+        // (the bits, their block sums and the z masks lie next to each other in the workspace: one fill)
+        pcd_fill(cbits, 0, (size_t)((char *)(zm + CB.ncol_cap + 1) - (char *)cbits), st);
+    } else if (key_order && n_points > 0)
         pcd_fill(bitmap, 0, nw * sizeof(u32), st);
     // (forking this fill onto a helper stream beside the insert pass -- event fork / join inside the call -- crashed
     //  the HIP runtime when the call was captured into a graph from a stream that had itself joined the capture)
@@ -632,7 +746,36 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(chunk_bsums, ncb, nullptr);
         vox_group_prefix_kernel<<<ncb, 256, 0, st>>>(chunk_prefix, (int)nc, chunk_bsums, spined);
     };
-    if (fast_sorted) {
+    if (cm && n_points > 0) {
+        FirstFlag ff{pt_slot, best, L, rank};
+        const int spined = nb > VOX_DIRECT_BLOCKS;
+        scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
+        if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
+        vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
+        vox_cm_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
+                                               max_voxels, cap, frame_rank0, frame_base, voxel_counts, cbits, CB.pitch);
+        const int nwords = (int)CB.nwords, nwb = pcd_div_up(nwords, 1024);
+        cm_words_count_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, cbsums);
+        const int wsp = cm_spined(nwb);
+        if (wsp) scan_spine_kernel<<<1, 256, 0, st>>>(cbsums, nwb, nullptr);
+        cm_words_prefix_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, nwb, cbsums, wsp, CB.cw, CB.ncols);
+        vox_cm_zmark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
+                                                frame_rank0, voxel_counts, CB.cw, CB.ncol_cap, zm, CB.pitch);
+        const int ncb = pcd_div_up(CB.ncol_cap, 256);
+        const int csp = ncb > VOX_DIRECT_BLOCKS;
+        scan_reduce_kernel<ZmCount><<<ncb, 256, 0, st>>>(ZmCount{zm}, CB.ncol_cap, colsums);
+        if (csp) scan_spine_kernel<<<1, 256, 0, st>>>(colsums, ncb, nullptr);
+        vox_cm_cols_kernel<<<ncb, 256, 0, st>>>(zm, CB.ncol_cap, colsums, csp, CB.cr, CB.ncols);
+        PCD_RETURN_IF_LAUNCH_FAILED();
+    } else if (cm) {
+        // no points: an empty map (all-zero words with zero prefixes), zero frame counts
+        const int nwords = (int)CB.nwords, nwb = pcd_div_up(nwords, 1024);
+        cm_words_count_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, cbsums);
+        cm_words_prefix_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, nwb, cbsums, 0, CB.cw, CB.ncols);
+        rc = scan_exclusive(StoredFlag{rank}, 0, rank, bsums, nullptr, st);
+        if (rc != PCD_OK) return rc;
+        vox_frames_kernel<<<1, 64, 0, st>>>(frame_offsets, batch, rank, max_voxels, cap, frame_rank0, frame_base, voxel_counts);
+    } else if (fast_sorted) {
         // 6 launches behind the insert pass (the generic form below: 10): block sums added up by the consuming blocks
         // instead of scan spines, the per-frame table folded into the mark kernel
         FirstFlag ff{pt_slot, best, L, rank};
@@ -671,7 +814,8 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
                                             num_features, frame_offsets, batch, G, max_points, L, best,
                                             pt_slot, rank, frame_rank0, frame_base, voxel_counts,
                                             voxels, coords, num_points, mean_f32,
-                                            (unsigned short *)mean_bf16, mean_bf16_stride, bitmap, chunk_prefix);
+                                            (unsigned short *)mean_bf16, mean_bf16_stride, cap, bitmap, chunk_prefix,
+                                            cm ? CB.cw : nullptr, cm ? CB.cr : nullptr, cm ? CB.ncol_cap : 0, cm ? CB.pitch : 0);
     }
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -717,6 +861,32 @@ extern "C" int pcd_voxelize_hard_sorted(const float *points, int n_points, int p
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
                               true, rank_bitmap, rank_prefix, key_depth, row_order);
+}
+
+// pcd_voxelize_hard_sorted with row_order PCD_ROWS_YXZ whose coordinate -> row map is the level's COLUMN MAP (colmap: a
+// buffer of pcd_colmap_bytes(batch, (key_depth or gz, gy, gx), cap) bytes the caller keeps for the rulebook builds), built
+// by the voxeliser itself from two order-free marks and two small scans -- no bitmap over the (b, y, x, z) key space.
+extern "C" size_t pcd_voxelize_hard_yxz_workspace_bytes(int n_points, int max_points, int batch, const float *range_host,
+                                                        const float *vsize_host, int key_depth, int cap) {
+    if (!range_host || !vsize_host) return 0;
+    VoxGeom G = make_geom(range_host, vsize_host);
+    if (key_depth > 0 && key_depth < G.gz) return 0;
+    if (key_depth > 0) G.kz = key_depth;
+    if (G.kz > 62 || batch > VOX_FOLD_FRAMES) return 0;
+    return hard_workspace_bytes(n_points, max_points, batch, &G, cap > 0 ? cap : 1);
+}
+
+extern "C" int pcd_voxelize_hard_yxz(const float *points, int n_points, int point_stride, int feat_offset,
+                                     int num_features, const int32_t *frame_offsets, int batch, const float *range_host,
+                                     const float *vsize_host, int max_points, int max_voxels, int cap, float *voxels,
+                                     int32_t *coords, int32_t *num_points, float *mean_f32, void *mean_bf16,
+                                     int mean_bf16_stride, int32_t *voxel_counts, int key_depth, void *colmap,
+                                     size_t colmap_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!colmap || key_depth < 0) return PCD_ERR_INVALID_ARG;
+    return voxelize_hard_impl(points, n_points, point_stride, feat_offset, num_features, frame_offsets, batch,
+                              range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
+                              mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
+                              true, nullptr, nullptr, key_depth, PCD_ROWS_YXZ, colmap, colmap_bytes);
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

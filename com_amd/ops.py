@@ -240,7 +240,18 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     if static:
         cap = min(cap, PLAN.cap("voxels"))
     lib = L.lib()
-    if keyed:
+    gz_, gy_, gx_ = grid_size(point_cloud_range, voxel_size)[::-1]
+    gz_ = max(gz_, int(key_depth))
+    # z-fastest rows: the voxeliser ranks its rows through the level's column map and hands that map out (no key-space bitmap)
+    cm_bytes = 0
+    if row_order == "yxz" and USE_COLUMN_MAPS and n > 0:
+        ws_bytes = lib.pcd_voxelize_hard_yxz_workspace_bytes(n, max_points, batch, L.host_f32(point_cloud_range),
+                                                             L.host_f32(voxel_size), int(key_depth), cap)
+        if ws_bytes:
+            cm_bytes = lib.pcd_colmap_bytes(batch, L.host_i32([gz_, gy_, gx_]), cap)
+    if cm_bytes:
+        entry = lib.pcd_voxelize_hard_yxz
+    elif keyed:
         ws_bytes = lib.pcd_voxelize_hard_sorted_workspace_bytes(n, max_points, batch, L.host_f32(point_cloud_range),
                                                                 L.host_f32(voxel_size), int(key_depth))
         if ws_bytes == 0:
@@ -264,8 +275,12 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     mean = buf("voxel_features", (cap, C), torch.float32, want_mean)
     mean16 = buf("voxel_features_bf16", (cap, mean_bf16_stride), torch.bfloat16, bool(mean_bf16_stride))
     counts = buf("counts", (batch + 1,), torch.int32)
-    rank_bm = rank_px = None
-    if keyed:                     # the coordinate -> row map of the output: kept for the level-1 SubM rulebook
+    rank_bm = rank_px = cm_buf = None
+    if cm_bytes:
+        prev = out.get("rank") if (out is not None and static) else None
+        cm_buf = prev.buf if (isinstance(prev, ColumnMap) and prev.buf.numel() == cm_bytes and prev.cap == cap
+                              and prev.buf.device == dev) else torch.empty((cm_bytes,), dtype=torch.uint8, device=dev)
+    elif keyed:                   # the coordinate -> row map of the output: kept for the level-1 SubM rulebook
         nbw, npw = ctypes.c_size_t(), ctypes.c_size_t()
         L.check(lib.pcd_voxelize_hard_sorted_rank_words(batch, L.host_f32(point_cloud_range), L.host_f32(voxel_size),
                                                         int(key_depth), ctypes.byref(nbw), ctypes.byref(npw)),
@@ -277,7 +292,10 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
         return dict(bytes=24 * n + 36 * m_ + (104 * m_ if want_voxels else 0), flops=0, rows=m_, pairs=0)
 
     with _Timed("voxelize_hard", meta):
-        extra = (int(key_depth), ROW_ORDERS[row_order], L.ptr(rank_bm), L.ptr(rank_px)) if keyed else ()
+        if cm_bytes:
+            extra = (int(key_depth), L.ptr(cm_buf), cm_buf.numel())
+        else:
+            extra = (int(key_depth), ROW_ORDERS[row_order], L.ptr(rank_bm), L.ptr(rank_px)) if keyed else ()
         L.check(entry(L.ptr(points), n, stride, feat_offset, C, L.ptr(offs), batch,
                       L.host_f32(point_cloud_range), L.host_f32(voxel_size), max_points,
                       max_voxels, cap, L.ptr(voxels), L.ptr(coords), L.ptr(nump), L.ptr(mean),
@@ -287,15 +305,16 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     gz = max(gz, int(key_depth))
 
     def rank_of(rows, n_dev):
-        """the coordinate -> row map handed to the level-1 rulebook builds: z-fastest rows get a ColumnMap (O(rows) to
-        build, 2 MB to probe), (b, z, y, x) rows keep the voxeliser's flat bitmap"""
+        """the coordinate -> row map handed to the level-1 rulebook builds: z-fastest rows carry the ColumnMap the voxeliser
+        built (2 MB to probe), (b, z, y, x) rows the voxeliser's flat bitmap"""
+        if cm_buf is not None:
+            return ColumnMap(cm_buf, cap, rows, [gz, gy, gx], batch)
         if rank_bm is None:
             return None
         if row_order == "yxz" and USE_COLUMN_MAPS and gz <= 62 and rows.shape[0] > 0:
+            # (geometries the fused form does not cover: the map from the finished rows)
             prev = out.get("rank") if (out is not None and static) else None
-            cm = colmap_from_rows(rows, batch, [gz, gy, gx], n_dev=n_dev,
-                                  out=prev if isinstance(prev, ColumnMap) else None)
-            return cm
+            return colmap_from_rows(rows, batch, [gz, gy, gx], n_dev=n_dev, out=prev if isinstance(prev, ColumnMap) else None)
         return RankMap(None, rank_bm, rank_px, rows, [gz, gy, gx], 4, ROW_ORDERS[row_order])
 
     if static:

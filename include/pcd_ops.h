@@ -152,6 +152,21 @@ int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride
                              int32_t *num_points, float *mean_f32, void *mean_bf16, int mean_bf16_stride,
                              int32_t *voxel_counts, int key_depth, int row_order, uint32_t *rank_bitmap,
                              int32_t *rank_prefix, void *workspace, size_t workspace_bytes, void *stream);
+/* pcd_voxelize_hard_sorted with row_order PCD_ROWS_YXZ whose coordinate -> row map is the level's COLUMN MAP ("Column maps"
+ * below): `colmap` is a caller-owned buffer of pcd_colmap_bytes(batch, (max(gz, key_depth), gy, gx), cap) bytes that the
+ * rulebook builds of level 1 read (pcd_rulebook_subm_cm, pcd_rulebook_conv_cm_*; pass the same `cap`).  Same voxels, same
+ * rows as pcd_voxelize_hard_sorted(PCD_ROWS_YXZ); the ranks come from two order-free marks (BEV occupancy bit, z bit of the
+ * column's mask) and two small scans instead of a bitmap over the (b, y, x, z) key space (46 MB zero-filled, scanned and
+ * probed per 4-frame Waymo batch) -- and no separate pcd_colmap_from_rows pass.  key depth <= 62, batch <= 256
+ * (PCD_ERR_UNSUPPORTED / 0 bytes otherwise: use pcd_voxelize_hard_sorted + pcd_colmap_from_rows).
+ * Replaces the same call site (pcdet/datasets/processor/data_processor.py:44-60,125-153). */
+size_t pcd_voxelize_hard_yxz_workspace_bytes(int n_points, int max_points, int batch, const float *range_host,
+                                             const float *vsize_host, int key_depth, int cap);
+int pcd_voxelize_hard_yxz(const float *points, int n_points, int point_stride, int feat_offset, int num_features,
+                          const int32_t *frame_offsets, int batch, const float *range_host, const float *vsize_host,
+                          int max_points, int max_voxels, int cap, float *voxels, int32_t *coords, int32_t *num_points,
+                          float *mean_f32, void *mean_bf16, int mean_bf16_stride, int32_t *voxel_counts, int key_depth,
+                          void *colmap, size_t colmap_bytes, void *workspace, size_t workspace_bytes, void *stream);
 /* (a4) MeanVFE on materialised voxels: mean_vfe.py:25-29.  out [m][C] f32. */
 int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,
                  int num_features, float *out, void *stream);
