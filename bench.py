@@ -107,7 +107,7 @@ class HotPath(torch.nn.Module):
         return bd["spatial_features"], bd
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel):
@@ -115,7 +115,7 @@ def _pmc_traffic(kernel):
     (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE) -- PMC counters cannot be read from inside the timed
     process.  Returns (bytes or None, source description incl. the git blob hash of the file that was read)."""
     import hashlib
-    for rel in (TRAFFIC_FILE, os.path.join("profiles", "r03_pmc_traffic.json")):
+    for rel in (TRAFFIC_FILE, os.path.join("profiles", "r04_pmc_traffic.json")):
         path = os.path.join(ROOT, rel)
         try:
             data = open(path, "rb").read()
