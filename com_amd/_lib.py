@@ -86,6 +86,10 @@ PROTOTYPES = {
                                        _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_cm_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
                                         _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_sparse_conv_pairs_seg_bytes": (_sz, [_i, _i]),
+    "pcd_sparse_conv_pairs_seg": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "pcd_sparse_conv_pairs_tiles": (_i, [_i, _i, _i, _i]),
+    "pcd_sparse_conv_pairs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,

@@ -1165,6 +1165,226 @@ static int launch_ggwin(const void *x, const void *wp, const float *bias, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Strided convs of the narrow levels, PAIR-DRIVEN (round 5).  The output-stationary kernels above visit all 27 offsets of
+// every output row although a stride-2 conv pairs an output row with 4.5 inputs on average (level 2): 27 gather slots per
+// row, five of them live.  In z-fastest order the indice pairs of one offset are sorted by input row AND by output row
+// (both follow (b, y, x, z), and for a fixed offset the map input -> output is monotone), so the pairs that end in a tile of
+// 64 consecutive stationary rows -- output rows for the forward, input rows for the data gradient -- are ONE contiguous
+// segment of every offset's list, found once per rulebook (pconv_seg_kernel: K x tiles binary searches).  A wave owns 64
+// stationary rows and their fp32 accumulators in LDS; it walks its segments in chunks of 16 pairs: pair indices (coalesced),
+// the 16 moving rows (one gather per PAIR, not per slot), one MFMA per 16-channel output block with the offset's weight
+// fragment (all 27 resident in LDS: 27 KB at 16 <-> 32 channels), and a read-modify-write of the 16 distinct accumulator rows
+// (rows of a chunk are distinct, chunks are sequential in the wave: no atomics, a fixed summation order).  Groups of four
+// chunks are software-pipelined: indices two groups ahead, gathers one group ahead.  Same epilogue as the gather kernels
+// (bias, addend, one rounding, BatchNorm sums).  Sums in another order than gather_gemm_kernel: equal within one bf16 ulp.
+constexpr int PC_ROWS = 64;            // stationary rows per wave
+constexpr int PC_GROUP = 4;            // chunks of 16 pairs per pipeline stage
+
+// seg[k][t] = first pair of offset k whose stationary row is >= 64 t  (t = 0 .. ntiles: the last column = pair_num[k])
+__global__ __launch_bounds__(256) void pconv_seg_kernel(const int32_t *__restrict__ pairs, int pair_stride,
+                                                        const int32_t *__restrict__ pair_num, int K, int stat_col, int ntiles,
+                                                        int32_t *__restrict__ seg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * (ntiles + 1)) return;
+    const int k = e / (ntiles + 1), t = e - k * (ntiles + 1);
+    const int32_t *col = pairs + ((size_t)k * 2 + stat_col) * pair_stride;
+    const int pn = min(pair_num[k], pair_stride);
+    const int target = t * PC_ROWS;
+    int lo = 0, hi = pn;                                   // first index with col[i] >= target
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    seg[e] = lo;
+}
+
+template <int CK, int NBO, bool OUT_BF16>   // CK: contraction width (moving rows' channels: 16 or 32); NBO: 16-channel output blocks
+__global__ __launch_bounds__(256) void pconv_kernel(
+    const unsigned short *__restrict__ x, unsigned x_bytes, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+    const int32_t *__restrict__ pairs, int pair_stride, const int32_t *__restrict__ seg, int ntiles, int stat_col,
+    int n_stat_cap, const int32_t *__restrict__ n_stat_dev, void *__restrict__ yv, const void *__restrict__ addend, BnRed bn) {
+    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
+    constexpr int K = 27, c_out = NBO * 16;
+    constexpr int FRAGB = CK == 16 ? 8 : 16;               // bytes of an A fragment per lane
+    constexpr int ASTR = c_out * 4 + 16;                   // accumulator row stride (+16: rows spread over the banks)
+    constexpr int NLIST = K * (PC_ROWS / 16) + PC_GROUP;   // chunk descriptors per wave
+    const int n_stat = eff_rows(n_stat_dev, n_stat_cap);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *wlds = smem;                                     // [K][NBO][64] fragments
+    char *accb = wlds + K * NBO * 64 * FRAGB;              // [4 waves][PC_ROWS][ASTR]
+    int2 *list = (int2 *)(accb + 4 * PC_ROWS * ASTR);      // [4 waves][NLIST] {k | n << 8, first pair}
+    float *red_s = (float *)(list + 4 * NLIST);            // [4][2][c_out], only with bn.mode
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rl = lane & 15, g = lane >> 4;
+    const int tile = xcd_tile(n_stat, 4 * PC_ROWS);
+    const int r0wg = tile * 4 * PC_ROWS;
+    if (r0wg >= n_stat) {
+        if (bn.mode) bnred_zero_row(bn, tile, c_out);
+        return;
+    }
+    // weights -> LDS in A-fragment order.  The generic pack (pack_weight modes 0 / 1) holds, per 32-wide contraction step s,
+    // fragments of 8 values per lane: CK = 32 (one offset per step): used as they are; CK = 16 (two offsets per step, lanes
+    // 0-31 the even one): fragment (k, nb, lane (m, g')) = values 4 (g' & 1) .. + 3 of source lane (k & 1) 32 + (g' >> 1) 16 + m
+    if (CK == 32) {
+        for (int e = threadIdx.x; e < K * NBO * 64; e += 256) reinterpret_cast<uint4 *>(wlds)[e] = wp[e];
+    } else {
+        for (int e = threadIdx.x; e < K * NBO * 64; e += 256) {
+            const int ln = e & 63, nb = (e >> 6) % NBO, k = e / (64 * NBO);
+            const int m = ln & 15, gq = ln >> 4;
+            const uint4 v = wp[((size_t)(k >> 1) * NBO + nb) * 64 + (k & 1) * 32 + (gq >> 1) * 16 + m];
+            reinterpret_cast<uint2 *>(wlds)[e] = (gq & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+        }
+    }
+    char *acc = accb + wave * (PC_ROWS * ASTR);
+    for (int e = lane; e < PC_ROWS * ASTR / 16; e += 64) reinterpret_cast<uint4 *>(acc)[e] = make_uint4(0u, 0u, 0u, 0u);
+    // this wave's tile and its chunk list: lane k holds the segment of offset k
+    const int t = tile * 4 + wave;
+    int2 *mylist = list + wave * NLIST;
+    int nch_total = 0;
+    {
+        int s0 = 0, s1 = 0;
+        if (lane < K && t < ntiles) {
+            s0 = seg[(size_t)lane * (ntiles + 1) + t];
+            s1 = seg[(size_t)lane * (ntiles + 1) + t + 1];
+        }
+        const int cnt = s1 - s0, nch = (cnt + 15) >> 4;
+        const int inc = wave_inclusive_scan(nch);
+        nch_total = __shfl(inc, 63);
+        int at = inc - nch;
+        for (int c = 0; c < nch; ++c) mylist[at + c] = make_int2(lane | (min(16, cnt - 16 * c) << 8), s0 + 16 * c);
+        for (int e = lane; e < PC_GROUP; e += 64) mylist[nch_total + e] = make_int2(0, 0);      // (padding chunks: no pairs)
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const int32_t *mov_col = pairs + (size_t)(1 - stat_col) * pair_stride;      // + k * 2 * pair_stride
+    const int32_t *sta_col = pairs + (size_t)stat_col * pair_stride;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    struct Grp {                       // one pipeline stage: PC_GROUP chunks
+        int st[PC_GROUP];              // local stationary row of this lane's pair, -1 = no pair
+        int kk[PC_GROUP];
+        u32x4 op[PC_GROUP];            // the moving row's slice (CK = 16: 8 bytes in .x .y)
+    };
+    int mv_n[PC_GROUP], st_n[PC_GROUP], kk_n[PC_GROUP];
+    auto load_idx = [&](int grp) {     // pair indices of group `grp` (beyond the list: padding chunks)
+#pragma unroll
+        for (int c = 0; c < PC_GROUP; ++c) {
+            const int ci = grp * PC_GROUP + c;
+            const int2 d = mylist[ci < nch_total ? ci : nch_total];
+            const int k = d.x & 255, n = d.x >> 8;
+            kk_n[c] = k;
+            const bool ok = rl < n;
+            const size_t at = (size_t)k * 2 * pair_stride + d.y + rl;
+            mv_n[c] = ok ? mov_col[at] : -1;
+            st_n[c] = ok ? sta_col[at] - (r0wg + wave * PC_ROWS) : -1;
+        }
+    };
+    auto gather = [&](Grp &G) {        // from the indices just loaded
+#pragma unroll
+        for (int c = 0; c < PC_GROUP; ++c) {
+            G.st[c] = st_n[c];
+            G.kk[c] = kk_n[c];
+            const unsigned off = mv_n[c] >= 0 ? (unsigned)mv_n[c] * (unsigned)(CK * 2) + (unsigned)g * (CK == 16 ? 8u : 16u) : 0xFFFFFFF0u;
+            if (CK == 16) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0);
+                G.op[c] = (u32x4){v[0], v[1], 0u, 0u};
+            } else {
+                G.op[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](const Grp &G) {
+#pragma unroll
+        for (int c = 0; c < PC_GROUP; ++c) {
+            const bool any = __builtin_amdgcn_ballot_w64(G.st[c] >= 0) != 0ull;
+            if (!any) continue;
+#pragma unroll
+            for (int nb = 0; nb < NBO; ++nb) {
+                f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const char *wf = wlds + ((size_t)(G.kk[c] * NBO + nb) * 64 + lane) * FRAGB;
+                if (CK == 16) {
+                    const uint2 a = *reinterpret_cast<const uint2 *>(wf);
+                    d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a),
+                                                                  __builtin_bit_cast(s16x4_t, (uint2){G.op[c][0], G.op[c][1]}), d, 0, 0, 0);
+                } else {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(wf);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, G.op[c]), d,
+                                                                0, 0, 0);
+                }
+                if (G.st[c] >= 0) {    // lane (g, rl): channels 4 g .. + 3 of block nb of pair rl's stationary row
+                    f32x4 *p = reinterpret_cast<f32x4 *>(acc + G.st[c] * ASTR + (nb * 16 + 4 * g) * 4);
+                    f32x4 o = *p;
+                    o[0] += d[0]; o[1] += d[1]; o[2] += d[2]; o[3] += d[3];
+                    *p = o;
+                }
+            }
+        }
+    };
+    Grp A, B;
+    const int ngrp = (nch_total + PC_GROUP - 1) / PC_GROUP;
+    load_idx(0);
+    gather(A);
+    load_idx(1);
+    for (int gi = 0; gi < ngrp; gi += 2) {
+        gather(B);                     // group gi + 1 (indices loaded one iteration ago)
+        load_idx(gi + 2);
+        compute(A);
+        gather(A);                     // group gi + 2
+        load_idx(gi + 3);
+        compute(B);
+    }
+
+    // accumulators -> the gather kernels' register layout -> their epilogue
+    f32x4 accr[PC_ROWS / 16][NBO];
+    int rows[PC_ROWS / 16];
+#pragma unroll
+    for (int mi = 0; mi < PC_ROWS / 16; ++mi) {
+        const int lr = mi * 16 + rl, row = r0wg + wave * PC_ROWS + lr;
+        rows[mi] = row < n_stat ? row : -1;
+#pragma unroll
+        for (int nb = 0; nb < NBO; ++nb) accr[mi][nb] = *reinterpret_cast<const f32x4 *>(acc + lr * ASTR + (nb * 16 + 4 * g) * 4);
+    }
+    gg_epilogue<PC_ROWS / 16, NBO, OUT_BF16>(accr, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
+}
+
+template <int CK, int NBO>
+static int launch_pconv(const void *x, int n_mov, const void *wp, const float *bias, const int32_t *pairs, int pair_stride,
+                        const int32_t *seg, int stat_col, int n_stat, const int32_t *n_stat_dev, void *y, int y_dtype,
+                        const void *addend, const PcdBnReduce *bnr, hipStream_t st, int *tiles_only) {
+    const int ntiles = pcd_div_up(n_stat, PC_ROWS);
+    const int grid = pcd_div_up(pcd_div_up(ntiles, 4), 8) * 8;
+    if (tiles_only) {
+        *tiles_only = grid;
+        return PCD_OK;
+    }
+    BnRed bn;
+    if (int rc = make_bnred(bnr, y_dtype, NBO * 16, grid, &bn)) return rc;
+    constexpr int FRAGB = CK == 16 ? 8 : 16, ASTR = NBO * 16 * 4 + 16, NLIST = 27 * (PC_ROWS / 16) + PC_GROUP;
+    const size_t lds = (size_t)27 * NBO * 64 * FRAGB + (size_t)4 * PC_ROWS * ASTR + (size_t)4 * NLIST * sizeof(int2) +
+                       (bn.mode ? (size_t)8 * NBO * 16 * sizeof(float) : 0);
+    auto kb = pconv_kernel<CK, NBO, true>;
+    auto kf = pconv_kernel<CK, NBO, false>;
+    static size_t raised[2] = {0, 0};
+    const int which = y_dtype == PCD_BF16 ? 0 : 1;
+    if (lds > 64 * 1024 && raised[which] < lds) {
+        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return PCD_ERR_LAUNCH;
+        raised[which] = lds;
+    }
+    const unsigned x_bytes = (unsigned)((size_t)n_mov * CK * 2);
+    const int stat = stat_col;
+    if (y_dtype == PCD_BF16)
+        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, x_bytes, (const uint4 *)wp, bias, pairs, pair_stride, seg, ntiles,
+                                   stat, n_stat, n_stat_dev, y, addend, bn);
+    else
+        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, x_bytes, (const uint4 *)wp, bias, pairs, pair_stride, seg, ntiles,
+                                   stat, n_stat, n_stat_dev, y, addend, bn);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
 // rows all share the residues ((c + p) mod s) of the three axes, hence the same 1..8 usable offsets (of 27 for
 // k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
@@ -2183,6 +2403,60 @@ extern "C" int pcd_sparse_conv_gather_gemm_zfast(const void *x, int n_rows_in, i
     PCD_ENTER();
     return gg_dispatch(x, n_rows_in, c_in, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev,
                        c_out, y, y_dtype, addend, bn_reduce, nullptr, stream, -1, 1);
+}
+
+// ---- pair-driven strided convs (pconv_kernel) --------------------------------------------------------------------------
+// dir 0: forward  y[o] += W_k x[i]   (stationary = output rows, pairs[k][1]; moving = input rows; c_mov = C_in, c_sta = C_out)
+// dir 1: data gradient  dx[i] += W_k^T dy[o]   (stationary = input rows, pairs[k][0]; moving = output rows; c_mov = C_out, c_sta = C_in)
+// Supported (c_mov, c_sta): (16, 32) and (32, 16) -- the level-1 -> 2 conv of the backbones -- with K = 27.
+static bool pconv_supported(int c_mov, int c_sta, int kvol) { return kvol == 27 && ((c_mov == 16 && c_sta == 32) || (c_mov == 32 && c_sta == 16)); }
+
+extern "C" size_t pcd_sparse_conv_pairs_seg_bytes(int n_stat_cap, int kvol) {
+    if (n_stat_cap < 0 || kvol <= 0) return 0;
+    return (size_t)kvol * (pcd_div_up(n_stat_cap > 0 ? n_stat_cap : 1, PC_ROWS) + 1) * sizeof(int32_t);
+}
+
+extern "C" int pcd_sparse_conv_pairs_seg(const int32_t *pairs, int pair_stride, const int32_t *pair_num, int kvol, int dir,
+                                         int n_stat_cap, int32_t *seg, void *stream) {
+    PCD_ENTER();
+    if (!pairs || !pair_num || !seg || kvol <= 0 || pair_stride <= 0 || n_stat_cap <= 0 || (dir != 0 && dir != 1))
+        return PCD_ERR_INVALID_ARG;
+    const int ntiles = pcd_div_up(n_stat_cap, PC_ROWS);
+    const int total = kvol * (ntiles + 1);
+    pconv_seg_kernel<<<pcd_div_up(total, 256), 256, 0, (hipStream_t)stream>>>(pairs, pair_stride, pair_num, kvol, dir == 0 ? 1 : 0,
+                                                                             ntiles, seg);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_sparse_conv_pairs_tiles(int n_stat_cap, int c_mov, int c_sta, int kvol) {
+    if (n_stat_cap <= 0 || !pconv_supported(c_mov, c_sta, kvol)) return PCD_ERR_UNSUPPORTED;
+    int tiles = 0;
+    if (c_mov == 16) launch_pconv<16, 2>(nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, n_stat_cap, nullptr, nullptr, PCD_BF16,
+                                         nullptr, nullptr, nullptr, &tiles);
+    else launch_pconv<32, 1>(nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, n_stat_cap, nullptr, nullptr, PCD_BF16, nullptr,
+                             nullptr, nullptr, &tiles);
+    return tiles;
+}
+
+extern "C" int pcd_sparse_conv_pairs(const void *x, int n_mov, int c_mov, const void *packed_w, const float *bias,
+                                     const int32_t *pairs, int pair_stride, const int32_t *seg, int kvol, int dir, int n_stat_cap,
+                                     const int32_t *n_stat_dev, int c_sta, void *y, int y_dtype, const void *addend,
+                                     const PcdBnReduce *bn_reduce, void *stream) {
+    PCD_ENTER();
+    if (!pconv_supported(c_mov, c_sta, kvol)) return PCD_ERR_UNSUPPORTED;
+    if (n_stat_cap < 0 || n_mov < 0 || (dir != 0 && dir != 1)) return PCD_ERR_INVALID_ARG;
+    if (n_stat_cap == 0) return PCD_OK;
+    if (!x || !packed_w || !pairs || !seg || !y || pair_stride <= 0) return PCD_ERR_INVALID_ARG;
+    if ((double)n_mov * c_mov * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
+    if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int stat_col = dir == 0 ? 1 : 0;
+    if (c_mov == 16)
+        return launch_pconv<16, 2>(x, n_mov, packed_w, bias, pairs, pair_stride, seg, stat_col, n_stat_cap, n_stat_dev, y, y_dtype,
+                                   addend, bn_reduce, st, nullptr);
+    return launch_pconv<32, 1>(x, n_mov, packed_w, bias, pairs, pair_stride, seg, stat_col, n_stat_cap, n_stat_dev, y, y_dtype, addend,
+                               bn_reduce, st, nullptr);
 }
 
 extern "C" int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out,

@@ -75,6 +75,7 @@ class _RulebookPrefetcher:
     def __init__(self, units, x0, side):
         self.units, self.t, self.side, self.next = units, x0, side, 0
         self.after_units = x0.indice_dict.pop("__after_units__", None)
+        self.hook_at = x0.indice_dict.pop("__after_units_at__", None)
 
     def advance(self, inline=False, stream=None):
         """inline: build the unit on the CURRENT stream (no event: its consumers are ordered behind it anyway);
@@ -92,6 +93,7 @@ class _RulebookPrefetcher:
                 if getattr(rb, "ready_event", None) is None:
                     built.append(rb)
                     self._window_plan(conv, rb)
+                    self._pair_plan(conv, rb)
                     if not inline and self.event_per_rulebook:
                         # the strided conv that opens a level waits for ITS rulebook only, not for the SubM rulebook (+ window
                         # plan) of the level behind it in the same unit
@@ -112,15 +114,41 @@ class _RulebookPrefetcher:
             if self.next >= len(self.units) and self.after_units is not None:
                 # the last unit is on the stream: nothing issued later reads the voxeliser's outputs (level-1 coordinates, rank
                 # map) -- a caller that recycles those buffers continues HERE, on this stream, idle for the rest of the forward
-                hook, self.after_units = self.after_units, None
-                u0 = getattr(self, "unit0_stream", None)
-                if u0 is not None and u0 is not side:
-                    # unit 0 (the level-1 SubM rulebook) reads the voxeliser's coordinates and rank map on ITS OWN stream: the
-                    # hook may overwrite them, so this stream is ordered behind unit 0's reads first (in a captured graph
-                    # nothing else puts an edge between the two branches)
-                    side.wait_stream(u0)
-                hook()
+                if self.hook_at is None:
+                    self.run_hook()                # (we are on the rulebook stream)
 
+
+    def run_hook(self, after_stream=None):
+        """The caller's after_rulebooks hook, on the rulebook stream behind the last unit -- and, with `after_stream`, behind
+        whatever that stream has been given so far (backbone.after_rulebooks_at: the hook's work then starts when the main
+        chain has finished that level instead of right behind the rulebook chain)."""
+        if self.after_units is None or self.next < len(self.units):
+            return
+        hook, self.after_units = self.after_units, None
+        side = self.side
+        with torch.cuda.stream(side):
+            u0 = getattr(self, "unit0_stream", None)
+            if u0 is not None and u0 is not side:
+                # unit 0 (the level-1 SubM rulebook) reads the voxeliser's coordinates and rank map on ITS OWN stream: the
+                # hook may overwrite them, so this stream is ordered behind unit 0's reads first (in a captured graph
+                # nothing else puts an edge between the two branches)
+                side.wait_stream(u0)
+            if after_stream is not None:
+                side.wait_stream(after_stream)
+            hook()
+
+    @staticmethod
+    def _pair_plan(conv, rb):
+        """The segment tables of the pair-driven strided kernel (ops.pair_conv_plan caches them on the rulebook), here on the
+        rulebook stream instead of in front of the conv that needs them."""
+        from .. import ops
+        if conv.subm or rb._pairs is None:
+            return
+        cin = ops.pow2_ge8(conv.in_channels)
+        if ops.pair_conv_usable(rb, cin, conv.out_channels):
+            ops.pair_conv_plan(rb, 0)
+        if ops.pair_conv_usable(rb, conv.out_channels, cin):
+            ops.pair_conv_plan(rb, 1)
 
     @staticmethod
     def _window_plan(conv, rb):
@@ -169,6 +197,9 @@ class _BackboneBase(nn.Module):
     # issued later reads the voxeliser's outputs (level-1 coordinates, coordinate -> row map): a caller that recycles those
     # buffers (bench.py voxelises the NEXT batch into them, inside the captured step) continues there.  None: nothing runs.
     after_rulebooks = None
+    # None: the hook runs right behind the last rulebook unit; "conv2" / "conv3" / "conv4": additionally not before the main
+    # chain has finished that level (the hook's kernels then run beside the levels after it)
+    after_rulebooks_at = None
     first_unit_inline = False      # measured: see _prefetch_rulebooks
     unit0_own_stream = True
     # rulebook units issued before the first conv; each unit's first consumer issues one more
@@ -273,21 +304,31 @@ class _BackboneBase(nn.Module):
             ops.STAMPS["conv_seq"] = 0
         if self.after_rulebooks is not None:
             x0.indice_dict["__after_units__"] = self.after_rulebooks
+            x0.indice_dict["__after_units_at__"] = self.after_rulebooks_at
         self._prefetch_rulebooks(x0)
         x = self.conv_input(x0)
         ops.stamp("conv_input")
         x_conv1 = self.conv1(x)
         ops.stamp("conv1")
+        pf_ = x0.indice_dict.get("__prefetcher__", None)
+
+        def hook_point(name):
+            if pf_ is not None and pf_.hook_at == name:
+                pf_.run_hook(after_stream=torch.cuda.current_stream())
         x_conv2 = self.conv2(x_conv1)
         ops.stamp("conv2")
+        hook_point("conv2")
         x_conv3 = self.conv3(x_conv2)
         ops.stamp("conv3")
+        hook_point("conv3")
         x_conv4 = self.conv4(x_conv3)
         ops.stamp("conv4")
+        hook_point("conv4")
         out = self.conv_out(x_conv4)
         ops.stamp("conv_out")
         if "__prefetcher__" in x0.indice_dict:                 # every unit was consumed; join the stream(s) anyway
             pf = x0.indice_dict.pop("__prefetcher__")
+            pf.run_hook(after_stream=torch.cuda.current_stream())      # (a hook point that came before the last unit was issued)
             torch.cuda.current_stream().wait_stream(pf.side)
             if getattr(pf, "unit0_stream", None) is not None:
                 torch.cuda.current_stream().wait_stream(pf.unit0_stream)

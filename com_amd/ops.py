@@ -1045,6 +1045,66 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     return y
 
 
+# ---- pair-driven strided convs over z-fastest rows (pconv_kernel) ------------------------------------------------------
+# strided 16 <-> 32-channel convs of z-fastest chains through their indice pairs (one gather per PAIR instead of 27 slots per
+# row).  Parity-green, measured SLOWER: 80 / 42 us (forward / data gradient, isolated) against 34 / 30 for the gather kernels,
+# 1267 against 1296 frames/s in the step -- two dependent memory latencies per group of four 16-pair chunks at two waves per
+# SIMD; off
+PAIR_CONV = False
+
+
+def pair_conv_usable(rb, c_mov, c_sta):
+    """The pair-driven kernel serves this strided rulebook: rows z-fastest (pairs sorted by both rows), pair lists built,
+    widths (16, 32) or (32, 16)."""
+    return (PAIR_CONV and not rb.subm and rb.kvol == 27 and getattr(rb, "order", None) == ROWS_YXZ
+            and rb._pairs is not None and (int(c_mov), int(c_sta)) in ((16, 32), (32, 16)))
+
+
+def pair_conv_plan(rb, direction):
+    """seg[k][tile] of `rb` for the forward (0: tiles of output rows) / data gradient (1: tiles of input rows); cached."""
+    cache = rb.__dict__.setdefault("_pconv_seg", {})
+    if direction not in cache:
+        lib = L.lib()
+        n_stat = rb.n_out if direction == 0 else rb.n_in
+        seg = torch.empty((max(int(lib.pcd_sparse_conv_pairs_seg_bytes(n_stat, rb.kvol)) // 4, 1),), dtype=torch.int32,
+                          device=rb._pairs.device)
+        L.check(lib.pcd_sparse_conv_pairs_seg(L.ptr(rb._pairs), rb._pairs.shape[2], L.ptr(rb._pair_num), rb.kvol, int(direction),
+                                              n_stat, L.ptr(seg), L.stream_ptr()), "pcd_sparse_conv_pairs_seg")
+        cache[direction] = seg
+    return cache[direction]
+
+
+def pair_conv(x, packed_w, bias, rb, direction, c_sta, out_dtype, addend=None, bn_reduce=None):
+    """Strided conv through its indice pairs: direction 0 forward (x = input features, packed_w = pack_weight(w, 0)),
+    1 data gradient (x = dy, packed_w = pack_weight(w, 1)); returns [n_stat, c_sta]."""
+    _require_cuda(x, packed_w)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    n_stat = rb.n_out if direction == 0 else rb.n_in
+    n_stat_dev = rb.n_out_dev if direction == 0 else rb.n_in_dev
+    seg = pair_conv_plan(rb, direction)
+    y = torch.empty((n_stat, c_sta), dtype=out_dtype, device=x.device)
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == y.dtype and addend.is_contiguous() and addend.is_cuda
+    lib = L.lib()
+    c_mov = x.shape[1]
+
+    def meta():
+        pairs = int(rb._pair_num.sum().item())
+        return dict(bytes=(x.shape[0] * c_mov + n_stat * c_sta) * 2 + 8 * pairs + 27 * c_mov * c_sta * 2,
+                    flops=2 * pairs * c_mov * c_sta, rows=n_stat, pairs=pairs)
+
+    bnr = None
+    if bn_reduce is not None:
+        bnr = bn_reduce._struct(_tiles(lib.pcd_sparse_conv_pairs_tiles(n_stat, c_mov, c_sta, rb.kvol), "pcd_sparse_conv_pairs_tiles"),
+                                c_sta, x.device)
+    with _Timed(f"pconv_kernel<{c_mov},{c_sta}> {'dgrad' if direction else 'fwd'} K=27", meta):
+        L.check(lib.pcd_sparse_conv_pairs(L.ptr(x), x.shape[0], c_mov, L.ptr(packed_w), L.ptr(bias), L.ptr(rb._pairs),
+                                          rb._pairs.shape[2], L.ptr(seg), rb.kvol, int(direction), n_stat, L.ptr(n_stat_dev), c_sta,
+                                          L.ptr(y), _dtype_code(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
+                "pcd_sparse_conv_pairs")
+    return y
+
+
 # ---- window gather-GEMM for SubM 3x3x3 layers over z-fastest rows (spconv_win.hip) ----------------------------------
 def subm_window_tile_rows(c_in, c_out):
     """Rows per tile of the window kernel for these widths; 0 = none."""

@@ -151,6 +151,9 @@ class SparseConvFunction(Function):
         elif window:
             assert out_dtype == torch.bfloat16 and rb.subm
             y = ops.subm_window(x, packed_fwd, b, rb, cout, bn_reduce=stats)
+        elif out_dtype == torch.bfloat16 and ops.pair_conv_usable(rb, cin_pad, cout):
+            # strided conv of a z-fastest chain, 16 -> 32 channels: one gather per indice PAIR (ops.pair_conv)
+            y = ops.pair_conv(x, packed_fwd, b, rb, 0, cout, out_dtype, bn_reduce=stats)
         else:
             y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
                                 n_dev=rb.n_out_dev, bn_reduce=stats,
@@ -231,6 +234,9 @@ class SparseConvFunction(Function):
                 dxp = ops.gather_gemm(dy16, packed_d, None, rb.nbr_out, rb.kvol, True, rb.n_in, ctx.cin_pad,
                                       ctx.in_dtype, n_dev=rb.n_in_dev, addend=add, bn_reduce=red,
                                       zfast=rb.kvol == 27 and getattr(rb, "order", None) == ops.ROWS_YXZ)
+            elif ctx.in_dtype == torch.bfloat16 and ops.pair_conv_usable(rb, ctx.cout, ctx.cin_pad):
+                # strided conv of a z-fastest chain, 32 -> 16 channels backwards: one gather per indice pair
+                dxp = ops.pair_conv(dy16, packed_d, None, rb, 1, ctx.cin_pad, ctx.in_dtype, addend=add, bn_reduce=red)
             elif USE_DGRAD_CLASSES and getattr(rb, "classes", None) is not None and ctx.cout >= 32 \
                     and (ctx.cout & (ctx.cout - 1)) == 0 and ctx.cin_pad % 16 == 0:
                 # strided conv: rows grouped by parity class run only the 1..8 offsets they can use

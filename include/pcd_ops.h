@@ -437,6 +437,25 @@ int pcd_sparse_conv_gather_gemm_zfast(const void *x, int n_rows_in, int c_in, co
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
                                 int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
+
+/* ---- Strided convs, PAIR-DRIVEN (spconv.SparseConv3d of the narrow levels, spconv_backbone.py:205-206) ------------------
+ * For rulebooks whose rows are numbered z-fastest the indice pairs of one offset are sorted by input row AND by output row, so
+ * the pairs ending in 64 consecutive stationary rows (output rows: forward, dir 0; input rows: data gradient, dir 1) are one
+ * contiguous segment per offset.  pcd_sparse_conv_pairs_seg finds the segments once per rulebook and direction (seg: K x
+ * (ceil(n_stat_cap / 64) + 1) int32 = pcd_sparse_conv_pairs_seg_bytes); pcd_sparse_conv_pairs then gathers one moving row
+ * per PAIR (the gather kernels: 27 slots per row, 4.5 of them live at level 2) and accumulates per wave in LDS -- no atomics, a
+ * fixed summation order; same epilogue (bias, addend, one rounding, PcdBnReduce with pcd_sparse_conv_pairs_tiles partial
+ * rows); equal to pcd_sparse_conv_gather_gemm / _dgrad_classes within one bf16 ulp.  packed_w: pcd_pack_weight mode `dir`.
+ * Supported (c_mov, c_sta) = (16, 32), (32, 16) with kvol 27 (PCD_ERR_UNSUPPORTED otherwise); pairs must be sorted by the
+ * stationary row inside every offset (true for pcd_rulebook_conv_* builds with row_order PCD_ROWS_YXZ over z-fastest inputs). */
+size_t pcd_sparse_conv_pairs_seg_bytes(int n_stat_cap, int kvol);
+int pcd_sparse_conv_pairs_seg(const int32_t *pairs, int pair_stride, const int32_t *pair_num, int kvol, int dir,
+                              int n_stat_cap, int32_t *seg, void *stream);
+int pcd_sparse_conv_pairs_tiles(int n_stat_cap, int c_mov, int c_sta, int kvol);
+int pcd_sparse_conv_pairs(const void *x, int n_mov, int c_mov, const void *packed_w, const float *bias,
+                          const int32_t *pairs, int pair_stride, const int32_t *seg, int kvol, int dir, int n_stat_cap,
+                          const int32_t *n_stat_dev, int c_sta, void *y, int y_dtype, const void *addend,
+                          const PcdBnReduce *bn_reduce, void *stream);
 /* number of workgroup tiles (= partial rows of bn_reduce) of that launch; < 0: error code */
 int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out);
 /* same for a launch that is a DATA GRADIENT (flip_k != 0 or bn_reduce->mode == 2): the library may pick a different

@@ -230,3 +230,68 @@ def test_unsupported_geometries_fall_back_to_the_flat_builds():
         perm = _yxz_order(rb_o["out_indices"])
         np.testing.assert_array_equal(_cpu(rb.out_indices), rb_o["out_indices"][perm])
         np.testing.assert_array_equal(_cpu(rb.nbr_out), rb_o["nbr_out"][:, perm])
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+def test_pair_driven_strided_conv_against_the_oracle_and_the_gather_kernels(direction):
+    """pcd_sparse_conv_pairs (pconv_kernel) on the level-1 -> 2 conv of a 2-frame Waymo-shaped batch, rows z-fastest: the
+    forward (16 -> 32, + bias) and the data gradient (32 -> 16, + addend) from the rulebook's indice pairs -- first that the
+    pairs of every offset ARE sorted by both rows (what the segment search relies on), then against the oracle's conv on the
+    same bf16 operands (one bf16 ulp per element; the fp32-output form at 1e-3 per element), against the 27-slot gather
+    kernels, the BatchNorm sums of the epilogue, and with padded capacities + device-side row counts."""
+    from com_amd.hotpath import collate_points
+    ops = _ops()
+    pts, offs = collate_points([synth.synth_cloud(f, 32, 2500) for f in (0, 1)], DEV)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
+                            want_voxels=False, row_order="yxz", key_depth=41)
+    idx, shape = res["coords"], [41, 1504, 1504]
+    geo = CHAIN[0]
+    rb = ops.rulebook_conv(idx, 2, shape, geo["k"], geo["s"], geo["p"], order=ops.ROWS_YXZ, in_rank=res["rank"])
+    pn = _cpu(rb.pair_num)
+    pairs = _cpu(rb.pairs)
+    for k in range(27):
+        assert (np.diff(pairs[k, 0, :pn[k]]) > 0).all() and (np.diff(pairs[k, 1, :pn[k]]) > 0).all(), k
+    rb_o = O.rulebook_conv(_cpu(idx), tuple(shape), geo["k"], geo["s"], geo["p"])
+    perm = _yxz_order(rb_o["out_indices"])
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    n_in, n_out = idx.shape[0], rb.n_out
+    g = torch.Generator().manual_seed(123 + direction)
+    w = torch.randn(32, 3, 3, 3, 16, generator=g) * (1.0 / np.sqrt(27 * 16))
+    wk = O.bf16_round(O.weight_from_spconv2(w.numpy()))                                        # [K, 16, 32]
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)
+    if direction == 0:
+        x = bf(torch.randn(n_in, 16, generator=g).numpy())
+        bias = torch.randn(32, generator=g) * 0.1
+        ref = O.conv_fwd(x.float().numpy(), wk, bias.numpy(), rb_o, threads=8)[perm]           # rows in my order
+        packed = ops.pack_weight(w.to(DEV), 0)
+        run = lambda dt, red=None: ops.pair_conv(x.to(DEV), packed, bias.to(DEV), rb, 0, 32, dt, bn_reduce=red)
+        gen = ops.gather_gemm(x.to(DEV), packed, bias.to(DEV), rb.nbr_out, 27, False, n_out, 32, torch.bfloat16)
+    else:
+        dy = bf(torch.randn(n_out, 32, generator=g).numpy())
+        add = bf(torch.randn(n_in, 16, generator=g).numpy())
+        dy_canon = np.zeros((n_out, 32), np.float32)
+        dy_canon[perm] = dy.float().numpy()                                                    # my row r = canonical row perm[r]
+        dxo, _, _ = O.conv_bwd(np.zeros((n_in, 16), np.float32), wk, dy_canon, rb_o, threads=8)
+        ref = dxo + add.float().numpy()
+        packed = ops.pack_weight(w.to(DEV), 1)
+        run = lambda dt, red=None: ops.pair_conv(dy.to(DEV), packed, None, rb, 1, 16, dt,
+                                                 addend=add.to(DEV) if dt == torch.bfloat16 else add.to(DEV).float(), bn_reduce=red)
+        gen = ops.gather_gemm(dy.to(DEV), packed, None, rb.nbr_in, 27, False, n_in, 16, torch.bfloat16, addend=add.to(DEV))
+    y = run(torch.bfloat16)
+    rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    err = np.abs(y.float().cpu().numpy() - ref)
+    assert (err <= 2.0 ** -7 * np.abs(ref) + 2.0 ** -7 * rms).all(), float(err.max())
+    y32 = run(torch.float32).cpu().numpy()
+    assert (np.abs(y32 - ref) <= 1e-3 * (np.abs(ref) + 0.1 * rms)).all()
+    d = (gen.float() - y.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(gen.float().abs().max())
+    if direction == 0:
+        st = ops.BnReduce(1)
+        yb = run(torch.bfloat16, st)
+        torch.cuda.synchronize()
+        assert torch.equal(yb, y)
+        got = st.partial.double().sum(0)
+        want = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)])
+        mag = torch.stack([y.double().abs().sum(0), (y.double() ** 2).sum(0)]).clamp_min(1.0)
+        assert float(((got - want).abs() / mag).max()) < 2e-6

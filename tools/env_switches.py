@@ -13,7 +13,9 @@ through the environment -- this module, imported only by bench.py and tools/, ap
   PCD_RB_INLINE0=0/1        backbone3d._BackboneBase.first_unit_inline
   PCD_RB_UNIT0_STREAM=0/1   backbone3d._BackboneBase.unit0_own_stream
   PCD_RB_DEPTH=<int>        backbone3d._BackboneBase.prefetch_depth
+  PCD_HOOK_AT=conv2|conv3|conv4   backbone3d._BackboneBase.after_rulebooks_at   where the after_rulebooks hook (bench.py: next batch's voxelisation) may start
   PCD_COLMAP=0/1            ops.USE_COLUMN_MAPS                           column-map rulebook builds (0: flat key-space bitmaps)
+  PCD_PAIR_CONV=0/1         ops.PAIR_CONV                                 pair-driven strided 16 <-> 32 convs (0: gather kernels)
 """
 import os
 
@@ -29,9 +31,12 @@ def apply(environ=None):
     ops.BN_FUSED_MID = flag("PCD_BN_FUSED_MID", ops.BN_FUSED_MID)
     ops.CONV2D_WGRAD_PLANES = flag("PCD_CONV2D_WGP", ops.CONV2D_WGRAD_PLANES)
     ops.USE_COLUMN_MAPS = flag("PCD_COLMAP", ops.USE_COLUMN_MAPS)
+    ops.PAIR_CONV = flag("PCD_PAIR_CONV", ops.PAIR_CONV)
     conv2d_fast.DENSE_BN_EPILOGUE = int(env.get("PCD_DENSE_BN_EPI", conv2d_fast.DENSE_BN_EPILOGUE))
     conv2d_fast.BATCH_BN_COUNTERS = flag("PCD_BN2D_BUMP", conv2d_fast.BATCH_BN_COUNTERS)
     backbone3d._RulebookPrefetcher.event_per_rulebook = flag("PCD_RB_EVENT_EACH", backbone3d._RulebookPrefetcher.event_per_rulebook)
     backbone3d._BackboneBase.first_unit_inline = flag("PCD_RB_INLINE0", backbone3d._BackboneBase.first_unit_inline)
     backbone3d._BackboneBase.unit0_own_stream = flag("PCD_RB_UNIT0_STREAM", backbone3d._BackboneBase.unit0_own_stream)
     backbone3d._BackboneBase.prefetch_depth = int(env.get("PCD_RB_DEPTH", backbone3d._BackboneBase.prefetch_depth))
+    if env.get("PCD_HOOK_AT"):
+        backbone3d._BackboneBase.after_rulebooks_at = None if env["PCD_HOOK_AT"] == "units" else env["PCD_HOOK_AT"]
