@@ -706,6 +706,9 @@ def measure_regime():
         for r in rows:
             res[f"B{r['frames']}"] = {"chain_us_graph": r["rulebook_chain_graph_us"], "chain_us_eager": r["rulebook_chain_us"],
                                       "alg_MB": r["alg_MB"], "GBps_graph": r["graph_GBps"], "frac": r["graph_frac_of_8TBps"],
+                                      # (the same chain with pair lists only where the step builds them: levels 3 and 4 + strided)
+                                      "chain_us_graph_as_built": r.get("as_built_chain_graph_us"),
+                                      "frac_as_built": r.get("as_built_frac_of_8TBps"),
                                       "builds_us_graph": {f"{b['kind']}_L{b['level']}": b["graph_us"] for b in r["builds"]}}
         return res
     except Exception as exc:
