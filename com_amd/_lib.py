@@ -38,6 +38,7 @@ PROTOTYPES = {
     "pcd_voxelize_hard_yxz_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp, _i, _i]),
     "pcd_voxelize_hard_yxz": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                    _i, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    "pcd_voxelize_hard_host": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "pcd_mean_vfe": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_workspace_bytes": (_sz, [_i, _i, _i, _vp, _vp]),
     "pcd_voxelize_dynamic_mean": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -30,11 +30,18 @@ struct VoxGeom {
     int order;   // key-ordered form: PCD_ROWS_ZYX = rows by (b, z, y, x); PCD_ROWS_YXZ = rows by (b, y, x, z), z fastest
 };
 
-__device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &G, int &cx, int &cy,
-                                            int &cz) {
+// (__host__ too: pcd_voxelize_hard_host runs the same arithmetic on the CPU -- IEEE float32 subtract and divide, no contraction)
+__host__ __device__ __forceinline__ bool voxel_coord(const float *p, const VoxGeom &G, int &cx, int &cy,
+                                                     int &cz) {
+#if defined(__HIP_DEVICE_COMPILE__)
     float fx = floorf(__fdiv_rn(__fsub_rn(p[0], G.r0), G.v0));
     float fy = floorf(__fdiv_rn(__fsub_rn(p[1], G.r1), G.v1));
     float fz = floorf(__fdiv_rn(__fsub_rn(p[2], G.r2), G.v2));
+#else
+    volatile float dx = p[0] - G.r0, dy = p[1] - G.r1, dz = p[2] - G.r2;      // (volatile: one rounding per operation)
+    volatile float qx = dx / G.v0, qy = dy / G.v1, qz = dz / G.v2;
+    float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+#endif
     bool ok = (fx >= 0.0f) && (fx < (float)G.gx) && (fy >= 0.0f) && (fy < (float)G.gy) &&
               (fz >= 0.0f) && (fz < (float)G.gz);
     cx = (int)fx;
@@ -887,6 +894,53 @@ extern "C" int pcd_voxelize_hard_yxz(const float *points, int n_points, int poin
                               range_host, vsize_host, max_points, max_voxels, cap, voxels, coords, num_points,
                               mean_f32, mean_bf16, mean_bf16_stride, voxel_counts, workspace, workspace_bytes, stream,
                               true, nullptr, nullptr, key_depth, PCD_ROWS_YXZ, colmap, colmap_bytes);
+}
+
+// Host-side hard voxelisation of ONE frame (the loop spconv's CPU voxel generator runs): what the reference
+// calls inside forked DataLoader workers (pcdet/datasets/processor/data_processor.py:44-60,130-141), where no HIP call is
+// possible.  HOST pointers, no stream, no GPU work; the same coordinate arithmetic as the kernels (voxel_coord), the
+// reference's first-appearance ids, per-voxel first `max_points` points and `max_voxels` cut.  voxels [max_voxels][T][C]
+// (zero padded), coords [max_voxels][3] (z, y, x), num_points [max_voxels]; *num_voxels_out = M.
+#include <unordered_map>
+extern "C" int pcd_voxelize_hard_host(const float *points_host, int n_points, int point_stride, int num_features,
+                                      const float *range_host, const float *vsize_host, int max_points, int max_voxels,
+                                      float *voxels_host, int32_t *coords_host, int32_t *num_points_host,
+                                      int32_t *num_voxels_out) {
+    if (n_points < 0 || max_points <= 0 || max_voxels < 0 || !range_host || !vsize_host || !num_voxels_out)
+        return PCD_ERR_INVALID_ARG;
+    if (num_features < 3 || point_stride < num_features) return PCD_ERR_UNSUPPORTED;
+    if (n_points > 0 && (!points_host || !voxels_host || !coords_host || !num_points_host)) return PCD_ERR_INVALID_ARG;
+    const VoxGeom G = make_geom(range_host, vsize_host);
+    std::unordered_map<unsigned long long, int> cell;
+    cell.reserve((size_t)(n_points > 0 ? n_points : 1));
+    int m = 0;
+    for (int i = 0; i < n_points; ++i) {
+        const float *p = points_host + (size_t)i * point_stride;
+        int cx, cy, cz;
+        if (!voxel_coord(p, G, cx, cy, cz)) continue;
+        const unsigned long long key = ((unsigned long long)cz * G.gy + cy) * G.gx + cx;
+        auto it = cell.find(key);
+        int v;
+        if (it == cell.end()) {
+            if (m >= max_voxels) continue;         // never registered: its later points are skipped too
+            v = m++;
+            cell.emplace(key, v);
+            coords_host[(size_t)v * 3 + 0] = cz;
+            coords_host[(size_t)v * 3 + 1] = cy;
+            coords_host[(size_t)v * 3 + 2] = cx;
+            num_points_host[v] = 0;
+            for (size_t e = 0; e < (size_t)max_points * num_features; ++e) voxels_host[(size_t)v * max_points * num_features + e] = 0.0f;
+        } else {
+            v = it->second;
+        }
+        const int np = num_points_host[v];
+        if (np < max_points) {
+            for (int c = 0; c < num_features; ++c) voxels_host[((size_t)v * max_points + np) * num_features + c] = p[c];
+            num_points_host[v] = np + 1;
+        }
+    }
+    *num_voxels_out = m;
+    return PCD_OK;
 }
 
 extern "C" int pcd_mean_vfe(const float *voxels, const int32_t *num_points, int m, int max_points,

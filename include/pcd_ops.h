@@ -160,6 +160,15 @@ int pcd_voxelize_hard_sorted(const float *points, int n_points, int point_stride
  * probed per 4-frame Waymo batch) -- and no separate pcd_colmap_from_rows pass.  key depth <= 62, batch <= 256
  * (PCD_ERR_UNSUPPORTED / 0 bytes otherwise: use pcd_voxelize_hard_sorted + pcd_colmap_from_rows).
  * Replaces the same call site (pcdet/datasets/processor/data_processor.py:44-60,125-153). */
+/* Host-side variant for ONE frame: what the reference calls inside forked DataLoader worker processes
+ * (pcdet/datasets/processor/data_processor.py:44-60,130-141), where a HIP call is impossible.  HOST pointers, no stream, no GPU
+ * work: the sequential algorithm of SURVEY.md A.1 with the kernels' own coordinate arithmetic -- first-appearance voxel ids,
+ * the first max_points points of every voxel, the max_voxels cut.  voxels [max_voxels][max_points][num_features] (rows used
+ * are zero padded), coords [max_voxels][3] (z, y, x), num_points [max_voxels]; *num_voxels_out = M.  Same results as
+ * pcd_voxelize_hard on one frame, bit for bit. */
+int pcd_voxelize_hard_host(const float *points_host, int n_points, int point_stride, int num_features,
+                           const float *range_host, const float *vsize_host, int max_points, int max_voxels,
+                           float *voxels_host, int32_t *coords_host, int32_t *num_points_host, int32_t *num_voxels_out);
 size_t pcd_voxelize_hard_yxz_workspace_bytes(int n_points, int max_points, int batch, const float *range_host,
                                              const float *vsize_host, int key_depth, int cap);
 int pcd_voxelize_hard_yxz(const float *points, int n_points, int point_stride, int feat_offset, int num_features,
