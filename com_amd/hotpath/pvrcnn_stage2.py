@@ -159,6 +159,56 @@ def sectorized_proposal_centric_sampling(roi_boxes, points, num_keypoints, sampl
     return sector_fps(sampled, num_keypoints, num_sectors)
 
 
+def sectorized_proposal_centric_sampling_batch(roi_boxes, points, num_keypoints, sample_radius_with_roi, num_sectors,
+                                               num_points_of_each_sample_part=200000):
+    """SAMPLE_METHOD 'SPC' for a whole batch in ONE stacked farthest point sampling: the reference walks the frames in a Python
+    loop (voxel_set_abstraction.py:236-258) and runs `num_sectors` short dependent chains per frame; the chains of different
+    frames are independent too, so all B x num_sectors of them form one batch of the stacked FPS op -- the same keypoints as
+    sectorized_proposal_centric_sampling frame by frame (tests/test_gpu_stage2.py), B times fewer dependent launches.
+    roi_boxes: list of [M_b, 7+]; points: list of [N_b, 3] -> list of sampled points [N_out_b, 3]."""
+    import math
+    B = len(points)
+    width = math.pi * 2 / num_sectors
+    kept, keys = [], []
+    for b in range(B):
+        k, _ = sample_points_with_roi(roi_boxes[b], points[b], sample_radius_with_roi, num_points_of_each_sample_part)
+        sector = ((torch.atan2(k[:, 1], k[:, 0]) + math.pi) / width).floor().clamp(min=0, max=num_sectors).long()
+        kept.append(k)
+        keys.append(sector + b * (num_sectors + 1))
+    allp, key = torch.cat(kept, 0), torch.cat(keys, 0)
+    order = torch.argsort(key, stable=True)
+    sizes = torch.bincount(key, minlength=B * (num_sectors + 1)).view(B, num_sectors + 1).tolist()      # the one host sync
+    xyz_parts, cnt, quota, frame_of_part, fallback = [], [], [], [], {}
+    at = 0
+    for b in range(B):
+        n_b = kept[b].shape[0]
+        live = [n for n in sizes[b][:num_sectors] if n > 0]
+        if live:
+            for n in sizes[b][:num_sectors]:
+                if n > 0:
+                    xyz_parts.append(order[at:at + n])
+                    cnt.append(n)
+                    quota.append(min(n, math.ceil(n / n_b * num_keypoints)))
+                    frame_of_part.append(b)
+                at += n
+            at += sizes[b][num_sectors]                    # ("sector num_sectors": angle == 2 pi, never visited by the reference)
+        else:                                              # (the reference's fallback: everything as one sector)
+            base = sum(kk.shape[0] for kk in kept[:b])
+            xyz_parts.append(torch.arange(base, base + n_b, device=allp.device))
+            cnt.append(n_b)
+            quota.append(num_keypoints)
+            frame_of_part.append(b)
+            at += sum(sizes[b])
+    sel = torch.cat(xyz_parts, 0)
+    xyz = allp[sel].contiguous()
+    idx = P.stack_farthest_point_sample(xyz, torch.tensor(cnt, device=allp.device, dtype=torch.int32), quota).long()
+    out, at = [[] for _ in range(B)], 0
+    for part, q in zip(frame_of_part, quota):
+        out[part].append(idx[at:at + q])
+        at += q
+    return [xyz[torch.cat(o)] for o in out]
+
+
 def bilinear_interpolate_torch(im, x, y):
     """pcdet/utils/common_utils.py (bilinear_interpolate_torch): im [H, W, C], x / y [N] -> [N, C]."""
     x0 = torch.floor(x).long()

@@ -265,3 +265,10 @@ def test_sectorized_proposal_centric_sampling_against_the_restated_reference():
     # ... and the composed call
     got2 = S2.sectorized_proposal_centric_sampling(tr, tp, nkp, radius, sectors, num_points_of_each_sample_part=7000)
     np.testing.assert_array_equal(got2.cpu().numpy(), want)
+    # ... and the batched form (all frames' sectors in ONE stacked FPS): frame by frame the same keypoints
+    tp2 = torch.from_numpy((pts[::-1] * np.float32(0.9)).copy()).to(DEV)
+    tr2 = torch.from_numpy((rois * np.float32(0.9)).copy()).to(DEV)
+    per = [S2.sectorized_proposal_centric_sampling(r_, p_, nkp, radius, sectors) for r_, p_ in ((tr, tp), (tr2, tp2), (tr, tp2))]
+    bat = S2.sectorized_proposal_centric_sampling_batch([tr, tr2, tr], [tp, tp2, tp2], nkp, radius, sectors)
+    for a_, b_ in zip(per, bat):
+        assert torch.equal(a_, b_)
