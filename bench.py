@@ -681,7 +681,8 @@ def measure_stage2(B, dev):
                 "fps_4096_keypoints_ms": round(e0.elapsed_time(e1), 3),
                 "spc_sampling": {"ms_per_batch": round(ms_spc, 3), "keypoints_per_frame": n_spc,
                                  "what": "SAMPLE_METHOD SPC instead of FPS: RoI-centric point filter (radius 1.6 m) + SectorFPS over 6 "
-                                         "sectors, 4096 keypoints asked per frame (not what the timed stage uses)"},
+                                         "sectors, 4096 keypoints asked per frame, the sectors of ALL frames in one stacked FPS "
+                                         "(frame by frame as the reference loops: 18.4 ms in round 4; not what the timed stage uses)"},
                 "stage2_train": {"ms_per_batch": round(ms_train, 3), "frames_per_s": round(B / ms_train * 1e3, 1),
                                  "what": "the same stage in training mode, forward + backward (eager launches)"},
                 "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points (cooperative kernel: 64 "
