@@ -213,6 +213,39 @@ def test_tiny_border_and_dense_inputs():
                 _check_subm_cm(rb.out_indices, batch, rb.out_shape, rb.rank)
 
 
+def test_random_grids_and_geometries():
+    """Forty random cases: grid sizes whose width is / is not a multiple of 32 (the maps pad the BEV row pitch), 1-3 frames,
+    occupancies from 0.1 % to 60 %, every kernel / stride / padding combination the column-map builds cover -- each strided
+    build and the SubM rulebook of its output level against the oracle, bit for bit."""
+    ops = _ops()
+    rng = np.random.default_rng(2025)
+    ran = 0
+    for case in range(40):
+        D, H, W = int(rng.integers(3, 44)), int(rng.integers(5, 90)), int(rng.choice([31, 32, 33, 47, 64, 65, 96, 100, 127]))
+        batch = int(rng.integers(1, 4))
+        dens = float(rng.choice([0.001, 0.01, 0.05, 0.2, 0.6]))
+        n = max(1, int(batch * D * H * W * dens))
+        idx = np.unique(np.stack([rng.integers(0, batch, n), rng.integers(0, D, n), rng.integers(0, H, n), rng.integers(0, W, n)], 1)
+                        .astype(np.int32), axis=0)
+        idx = _sorted_yxz(idx)
+        idx_t = torch.from_numpy(idx).to(DEV)
+        cmap = ops.colmap_from_rows(idx_t, batch, [D, H, W])
+        _check_subm_cm(idx_t, batch, (D, H, W), cmap)
+        if rng.random() < 0.5:
+            k, s, p = (3, 3, 3), tuple(int(v) for v in rng.integers(1, 3, 3)), tuple(int(v) for v in rng.integers(0, 2, 3))
+        else:
+            k, s, p = (3, 1, 1), (int(rng.integers(1, 3)), 1, 1), (int(rng.integers(0, 2)), 0, 0)
+        out = O.conv_out_shape((D, H, W), k, s, p, (1, 1, 1))
+        if min(out) <= 0:
+            continue
+        geo = dict(k=k, s=s, p=p)
+        rb, rb_o = _check_conv_cm(idx_t, batch, (D, H, W), geo, cmap)
+        ran += 1
+        if rb.out_shape[0] >= 3 and rb.n_out > 0:
+            _check_subm_cm(rb.out_indices, batch, rb.out_shape, rb.rank)
+    assert ran >= 30
+
+
 def test_unsupported_geometries_fall_back_to_the_flat_builds():
     """Dilation, 5-wide kernels and rows that are not z-fastest are outside the column-map builds: the same call still
     returns the oracle's rulebook (through the flat-bitmap build)."""
