@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pcd_subm_window_wgrad_splits": (_i, []),
     "pcd_sparse_conv_subm_window_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_subm_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pcd_sparse_conv_subm_window_bn": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "pcd_sparse_conv_subm_window_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
@@ -258,6 +259,14 @@ class PcdBnReduce(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p),
                 ("partial_rows", ctypes.c_int), ("mid", ctypes.c_void_p), ("counters", ctypes.c_void_p)]
+
+
+class PcdBnFold(ctypes.Structure):
+    """include/pcd_ops.h: struct PcdBnFold (the BatchNorm behind a window conv, applied by the conv launch)."""
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("save_mean", ctypes.c_void_p),
+                ("save_invstd", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("relu", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("sync", ctypes.c_void_p)]
 
 
 def build(force=False):

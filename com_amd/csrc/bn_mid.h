@@ -58,7 +58,8 @@ __device__ __forceinline__ void bn_mid_row(const float *partial, int nblocks, in
         if (j == 0 && col < cols) {
             double s2 = 0.0;
             for (int q = 0; q < tpc; ++q) s2 += lds[q * cw + t];
-            mid[(size_t)r * cols + col] = s2;
+            // (agent scope: a launch that applies the BatchNorm itself -- spconv_win.hip, PcdBnFold -- reads the rows from other XCDs)
+            __hip_atomic_store(mid + (size_t)r * cols + col, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }

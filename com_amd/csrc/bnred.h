@@ -36,12 +36,13 @@ struct BnRed {
 // stores are only visible to other XCDs after an L2 write-back) sums the group's rows, in a fixed order of its own
 // (doubles: it agrees with bn_mid_kernel's order to ~1e-16 relative).  The counter returns to zero for the next launch.
 // partial row `tile` = get(e), e in [0, 2 c_out); all threads of the workgroup, uniformly
+// returns (to every thread): this workgroup delivered the last row of its group and wrote the group's mid row
 template <class F>
-__device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_out, F get, int nrows_arg = -1) {
+__device__ __forceinline__ bool bnred_publish(const BnRed &bn, int tile, int c_out, F get, int nrows_arg = -1) {
     float *dst = bn.partial + (size_t)tile * 2 * c_out;
     if (!bn.mid) {
         for (int e = threadIdx.x; e < 2 * c_out; e += blockDim.x) dst[e] = get(e);
-        return;
+        return false;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_base[];   // the launch's dynamic LDS (>= 8 KiB, free now)
     __shared__ int last_s;
@@ -72,6 +73,7 @@ __device__ __forceinline__ void bnred_publish(const BnRed &bn, int tile, int c_o
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         bn_mid_row(bn.partial, nrows, c_out, r, bn.mid, reinterpret_cast<double *>(smem_base));
     }
+    return last_s != 0;
 }
 
 __device__ __forceinline__ void bnred_zero_row(const BnRed &bn, int tile, int c_out) {

@@ -378,6 +378,27 @@ typedef struct PcdBnReduce {
     double *mid;
     int32_t *counters;
 } PcdBnReduce;
+/* The BatchNorm1d (training mode) (+ residual add) (+ ReLU) behind a conv, applied by the conv launch itself
+ * (pcd_sparse_conv_subm_window_bn): bn_reduce must be mode 1 with `mid` / `counters`; once the launch's statistics are complete
+ * (a launch-wide barrier among its co-resident persistent workgroups) every workgroup normalises the rows it produced --
+ * out = relu?(y * scale + shift + residual?) -- and workgroup 0 writes save_mean / save_invstd and updates the running
+ * statistics exactly as pcd_bn_forward does: `out` and the statistics are bit-identical to conv + pcd_bn_forward(ext_partial =
+ * mid, PCD_BN_EXT_MID).  y (the raw conv output the BatchNorm backward needs) is still written.
+ * Measured on MI355X (B = 4 levels, per layer): slower than the separate pass by 11-12 us -- the barrier is a chain of dependent
+ * agent-scope round trips across the XCDs (~2 us each) that costs more than the kernel boundary it replaces; the host side keeps
+ * it switched off (com_amd.ops.BN_FOLD).
+ *   sync: 64 int32, ZERO before the first use, left consistent by every launch; one buffer per stream that runs such launches
+ *   (two launches sharing a buffer must not overlap).  Reference: spconv_backbone.py:50-66 (conv -> bn -> (+identity) -> relu). */
+typedef struct PcdBnFold {
+    const float *gamma, *beta;   /* NULL = 1 / 0 */
+    float eps, momentum;
+    float *running_mean, *running_var;   /* updated in place; NULL = not tracked */
+    float *save_mean, *save_invstd;      /* out [c_out] */
+    const void *residual;                /* bf16 [n][c_out] or NULL */
+    int relu;
+    void *out;                           /* bf16 [n][c_out] */
+    int32_t *sync;
+} PcdBnFold;
 #define PCD_BN_MID_ROWS 16
 #define PCD_BN_COUNTER_STRIDE 32
 #define PCD_BN_EXT_MID (-1)
@@ -983,6 +1004,10 @@ int pcd_debug_spin(int blocks, unsigned long long ticks, uint32_t *xcc_seen, voi
  *                                  {weight ptr, packed ptr, c_in, mode, first 256-thread block, 0, 0, 0}
  *   pcd_subm_window_partial_rows   rows of PcdBnReduce.partial the launch writes (one per persistent workgroup)
  * ============================================================================================ */
+int pcd_sparse_conv_subm_window_bn(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
+                                   const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev, const void *plan,
+                                   int c_out, void *y, const void *addend, const PcdBnReduce *bn_reduce,
+                                   const PcdBnFold *fold, void *stream);
 int pcd_subm_window_tile_rows(int c_in, int c_out);
 int pcd_subm_window_partial_rows(void);
 /* profiling aid: a device buffer of 1024 x u64 whose first 256 entries receive shader-clock stamps of workgroup 0 at the phase boundaries of its
