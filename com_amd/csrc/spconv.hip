@@ -584,8 +584,12 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char *lds_ds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst_wave_uniform, 16, voffset, 0, 0, 0);
 }
 
-template <int NB, int SOFF, int MI, int R, bool OUT_BF16>   // SOFF = stages per offset = C_in / 64
-__global__ __launch_bounds__(512, 1) void ggw_kernel(
+// CW = 2 (round 5): TWO consumer waves per SIMD, each with half of the output channels of the SIMD's MI x 16 rows -- while one
+// waits for its operand fragments the other issues MFMAs (one consumer per SIMD read all fragments of a stage, then ran its
+// MFMAs: ~1100 clk per stage for 768 clk of matrix work).  Every output element is still accumulated in the same order: the
+// results stay bit-identical.  12 waves: consumers 0-7 (row group w & 3, channel half w >> 2), loaders 8-11.
+template <int NB, int SOFF, int MI, int R, bool OUT_BF16, int CW = 1>   // SOFF = stages per offset = C_in / 64
+__global__ __launch_bounds__(256 * (1 + CW), 1) void ggw_kernel(
     const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
     const int32_t *__restrict__ nbr, int nbr_stride, int K, int flip, int n_out_cap,
     const int32_t *__restrict__ n_out_dev, void *__restrict__ yv, unsigned x_bytes, unsigned w_bytes,
@@ -605,7 +609,9 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
     constexpr int A_STAGE = MI * 2048;                     // bytes per consumer per stage (MI*16 rows x 128 B)
     constexpr int W_STAGE = WFR * 1024;
     constexpr int c_out = NB * 16;
-    constexpr int THREADS = 512;
+    constexpr int THREADS = 256 * (1 + CW);
+    constexpr int NBH = NB / CW;                           // output-channel blocks per consumer
+    static_assert(CW == 1 || (CW == 2 && NB % 2 == 0 && gg_quad(NB) == gg_quad(NB / 2)), "channel split");
     static_assert(R == 2 || R == 3, "ring depth");
     static_assert((R - 2) * (GI + WPW) < 64, "vmcnt field");
     const int n_out = eff_rows(n_out_dev, n_out_cap);
@@ -616,8 +622,9 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
     float *red_s = (float *)(nbr_s + (K + 1) * ROWS);      // [4][2][c_out], only with bn.mode
 
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;                            // consumer index (of the loader: the consumer it feeds)
+    const bool loader = wave8 >= 4 * CW;
+    const int wave = wave8 & 3;                            // row group (of the loader: the one it feeds)
+    const int half = CW == 2 ? (wave8 >> 2) & 1 : 0;       // consumer: its half of the output channels
     const int lane = threadIdx.x & 63;
     const int rl = lane & 15, g = lane >> 4;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD gets a CONTIGUOUS run of row tiles -- of the
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
                 const int row = r0wg + r;
                 const int krow = flip ? (K - 1 - k) : k;
                 const bool ok = idx < total && row < n_out;
-                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
+                const unsigned off = (ok && !(dbg & 16)) ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
                 v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
                 if (!ok) v[u] = -1;
             }
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
     char *const awave = aring + wave * (R * A_STAGE);
     const int wrow0 = wave * (MI * 16);
-    const int T = K * SOFF;                                // stages
+    const int T = (dbg & 8) ? 0 : K * SOFF;                // stages (ablation 8: prologue + epilogue only)
     const int NIT = (T + R - 1) / R * R;                   // iterations (both roles run the same number of barriers)
 
     using S0 = std::integral_constant<int, 0>;
@@ -681,6 +688,7 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
         const unsigned gl_p0 = (unsigned)(lane & 7), gl_p1 = (unsigned)(lane >> 4);
         auto fire = [&](int stage, auto slot_tag) {
             constexpr int SLOT = decltype(slot_tag)::value;
+            if (dbg & 32) return;                              // ablation: no DMA instructions at all
             const unsigned h = SOFF == 2 ? (unsigned)(stage & 1) * 128u : 0u;
             const int *irow = nbr_s + stage_k(stage) * ROWS + wrow0 + gl_row;
             int idx[GI];
@@ -728,20 +736,22 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
         }
 #undef GGW_LOADER_STEP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages beyond T: zeros from beyond num_records
-        f32x4 none[MI][NB];
+        // (the SAME instantiation as the consumers': bnred_publish keeps a __shared__ flag per instantiation -- with
+        //  <MI, NB> here and <MI, NB / 2> there the two halves of the workgroup read different flags)
+        f32x4 none[MI][NBH];
         int norows[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) norows[mi] = -1;
-        gg_epilogue<MI, NB, OUT_BF16>(none, norows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s, true);
+        gg_epilogue<MI, NBH, OUT_BF16>(none, norows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s, true);
         return;
     }
 
     // ----------------------------------------------------------------------------------------------- consumer
-    f32x4 acc[MI][NB];
+    f32x4 acc[MI][NBH];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBH; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned a_lane = (unsigned)rl * 128u;           // + mi * 2048 + (piece ^ swz) * 16
     const unsigned a_swz = (unsigned)((rl >> 1) & 7);
     // does any of this consumer's rows have a neighbour at the stage's offset?  (lane l checks row l of the wave's
@@ -759,20 +769,20 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
         // the LDS returns in issue order, so the MFMAs of step 0 start when its fragments have landed while those
         // of step 1 are still in flight (the compiler's own schedule kept ~3 reads ahead of the MFMAs: with one
         // consumer wave per SIMD that exposed an LDS latency every few MFMAs)
-        bf16x8 xa[2][MI], bw[2][NB];
+        bf16x8 xa[2][MI], bw[2][NBH];
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 xa[cs][mi] = *reinterpret_cast<const bf16x8 *>(ab + mi * 2048 + a_lane + (((unsigned)(cs * 4 + g) ^ a_swz) << 4));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                bw[cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
+            for (int nb = 0; nb < NBH; ++nb)
+                bw[cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + half * NBH + nb) * 64 + lane) * 16);
         }
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)   // (a 16-row tile without neighbours holds zeros: no branch per MFMA)
                     acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[cs][nb], xa[cs][mi], acc[mi][nb], 0, 0, 0);
@@ -807,10 +817,10 @@ __global__ __launch_bounds__(512, 1) void ggw_kernel(
         const int row = r0wg + tile_row + mi * 16;
         rows[mi] = row < n_out ? row : -1;
     }
-    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
+    gg_epilogue<MI, NBH, OUT_BF16>(acc, rows, c_out, half * NBH * 16, g, rl, wave, tile, bias, addend, yv, bn, red_s);
 }
 
-template <int NB, int SOFF, int MI, int R>
+template <int NB, int SOFF, int MI, int R, int CW = 1>
 static int launch_ggw(const void *x, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride, int K,
                       int flip, int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes,
                       unsigned w_bytes, hipStream_t st, const void *addend, const PcdBnReduce *bnr, int *tiles_only) {
@@ -826,8 +836,8 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
                        (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
     if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
     const int dbg = pcd_opt(PCD_OPT_GGW_DBG);   // ablation switches (0 in production)
-    auto kb = ggw_kernel<NB, SOFF, MI, R, true>;
-    auto kf = ggw_kernel<NB, SOFF, MI, R, false>;
+    auto kb = ggw_kernel<NB, SOFF, MI, R, true, CW>;
+    auto kf = ggw_kernel<NB, SOFF, MI, R, false, CW>;
     if (lds > 64 * 1024) {
         static size_t raised[2] = {0, 0};
         const int which = y_dtype == PCD_BF16 ? 0 : 1;
@@ -839,11 +849,11 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
         }
     }
     if (y_dtype == PCD_BF16)
-        kb<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
-                                   n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
+        kb<<<grid, 256 * (1 + CW), lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
+                                              n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
     else
-        kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
-                                   n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
+        kf<<<grid, 256 * (1 + CW), lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, K, flip, n_out,
+                                              n_out_dev, y, x_bytes, w_bytes, addend, bn, dbg);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -2336,12 +2346,21 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
         x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 6)) {
         const unsigned w_bytes = (unsigned)wbytes;
-        const int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
+        int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
         // SubM 3x3x3 over z-fastest rows at 128 -> 128 channels: x through windows (ggwin_kernel; same tiles, same BatchNorm rows)
         if (zfast && !tiles_only && pcd_opt(PCD_OPT_GGWIN) && c_in == 128 && c_out == 128 && kvol == 27 && mi == 3)
             return launch_ggwin<8, 3>(x, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, x_bytes,
                                       w_bytes, st, addend, bnr);
+        // Few rows (one round of 128-row tiles fits the chip): the FORWARD conv takes 128-row tiles -- 36-38 us isolated against
+        // 42-44 at 21-32 k rows (tools/exp_ggw.py) and nothing runs beside levels 3-4 of the forward pass; the data gradient
+        // keeps 192 rows: its workgroups leave ~45 % of the CUs to the weight-gradient kernel running beside it, and with
+        // 128-row tiles everywhere the training step was 7 % SLOWER (3.35 against 3.12 ms).  Option "ggw_mi": 2 / 3 = forced.
+        // (not with option "ggwin": that kernel and its tile count are built on 192 rows)
+        if (mi == 3 && !is_dgrad && c_in == 128 && n_rows_out <= 256 * 128 * 5 / 4 && !pcd_opt(PCD_OPT_GGWIN)) mi = 2;
+        if (pcd_opt(PCD_OPT_GGW_MI) == 2 || pcd_opt(PCD_OPT_GGW_MI) == 3) mi = pcd_opt(PCD_OPT_GGW_MI);
 #define GGW_ARGS x, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, x_bytes, w_bytes, st, addend, bnr, tiles_only
+        // two consumer waves per SIMD (ggw_kernel CW = 2) at 128 -> 128, 192-row tiles: option "ggw_cw" (1 = the one-consumer form)
+        if (c_in == 128 && c_out == 128 && mi == 3 && pcd_opt(PCD_OPT_GGW_CW) == 2) return launch_ggw<8, 2, 3, 3, 2>(GGW_ARGS);
 #define GGW_MI(NBV, SOFFV)                                                         \
         (mi == 3 ? launch_ggw<NBV, SOFFV, 3, 3>(GGW_ARGS) : launch_ggw<NBV, SOFFV, 2, 3>(GGW_ARGS))
         if (c_in == 64) return c_out == 64 ? GGW_MI(4, 1) : GGW_MI(8, 1);

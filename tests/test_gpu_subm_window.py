@@ -462,3 +462,36 @@ def test_batchnorm_folded_into_the_window_launch_is_bit_identical_to_the_separat
         torch.cuda.synchronize()
         same(ra, held, n, ("graph", it))
         assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+
+
+@pytest.mark.parametrize("ch,lvl", [(128, 4), (64, 3)])
+def test_mid_rows_of_the_conv_launch_are_the_sums_of_its_partial_rows(ch, lvl):
+    """BatchNorm sums folded inside the conv launch (PcdBnReduce.mid): the 16 mid rows must be exactly the float64 sums of the
+    launch's partial rows t = r (mod 16), for the generic / wide gather-GEMM kernels (ggw_kernel at 128 channels runs two
+    consumer waves per SIMD: loaders and consumers have to agree on which workgroup folds a group) in both modes -- also
+    while another stream keeps the device busy (the fold is done by whichever workgroup arrives last)."""
+    ops = _ops()
+    idx, rank, shape = _level(2, lvl)
+    n = idx.shape[0]
+    rb = ops.rulebook_subm(idx, 2, shape, rank=rank, want_pairs=False)
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))).to(DEV)
+    x = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
+    bnx = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
+    mean = (torch.randn(ch, generator=g) * 0.3).to(DEV)
+    invstd = (torch.rand(ch, generator=g) + 0.5).to(DEV)
+    side = torch.cuda.Stream()
+    big = torch.randn(200000, 64, device=DEV)
+    assert ops.BN_FUSED_MID
+    for mode in (0, 1):
+        pk = ops.pack_weight(w, mode)
+        for it in range(40):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    big.mul(1.0001).sum()
+            st = ops.BnReduce(1) if mode == 0 else ops.BnReduce(2, False, x=bnx, mean=mean, invstd=invstd)
+            ops.gather_gemm(x, pk, None, rb.nbr_out, 27, bool(mode), n, ch, torch.bfloat16, bn_reduce=st)
+            rows = st.partial_keep.double()
+            want = torch.stack([rows[r::16].sum(0) for r in range(16)])
+            assert st.rows == -1 and torch.equal(st.partial, want), (mode, it, float((st.partial - want).abs().max()))
+        torch.cuda.synchronize()
