@@ -76,7 +76,8 @@ __device__ __forceinline__ int cm_base(const int *__restrict__ bsums, int blk, i
 
 __global__ __launch_bounds__(256) void cm_words_prefix_kernel(const u32 *__restrict__ bits, int nwords, int nblk,
                                                               const int *__restrict__ bsums, int spined,
-                                                              uint2 *__restrict__ cw, int *__restrict__ ncols) {
+                                                              uint2 *__restrict__ cw, int *__restrict__ ncols,
+                                                              u32 *__restrict__ colkey = nullptr, int ncol_cap = 0) {
     __shared__ int lds[4];
     const int base = cm_base(bsums, blockIdx.x, spined, lds);
     if (blockIdx.x == 0 && ncols) {
@@ -98,6 +99,18 @@ __global__ __launch_bounds__(256) void cm_words_prefix_kernel(const u32 *__restr
     const int pre[4] = {ex, ex + c0, ex + c0 + c1, ex + c0 + c1 + c2};
     for (int j = 0; j < 4; ++j)
         if (w0 + j < nwords) cw[w0 + j] = make_uint2(b[j], (u32)pre[j]);
+    if (colkey) {          // the inverse map: column -> BEV key (consecutive columns from consecutive threads)
+        for (int j = 0; j < 4; ++j) {
+            u32 m = b[j];
+            int c = pre[j];
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1u;
+                if (c < ncol_cap) colkey[c] = (u32)(w0 + j) * 32u + (u32)bit;
+                ++c;
+            }
+        }
+    }
 }
 
 }  // namespace

@@ -489,6 +489,99 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(
     }
 }
 
+// z-fastest rows, emitted IN ROW ORDER (round 5): a workgroup takes 256 consecutive columns of the map -- their rows are one
+// contiguous range -- and its threads walk that range: row -> column by a binary search over the 256 first rows in LDS, z =
+// the k-th set bit of the column's mask, the voxel's record by a probe of the key table.  Every output row is written by the
+// thread next to its neighbours' (whole lines instead of 16 / 4 / 32-byte pieces scattered over the arrays: the per-point form
+// above moved 304 MB for ~50 MB of results, most of it lines fetched to be partially overwritten).  Same records, same
+// arithmetic -> the same outputs bit for bit.
+__device__ __forceinline__ int kth_set_bit64(u64 v, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int half = 32; half >= 1; half >>= 1) {
+        const int c = __popcll(v & ((1ull << half) - 1ull));
+        if (k >= c) {
+            k -= c;
+            v >>= half;
+            pos += half;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void vox_emit_rows_kernel(
+    const float *__restrict__ pts, int stride, int feat_off, int C, VoxGeom G, int T, int L, const u64 *__restrict__ keys,
+    const u32 *__restrict__ best, u32 mask, float *voxels, int32_t *coords, int32_t *num_points, float *mean_f32,
+    unsigned short *mean_bf16, int bf16_stride, int cap_rows, const uint4 *__restrict__ cr, const u32 *__restrict__ colkey,
+    const int *__restrict__ ncols, int ncol_cap, int pitch) {
+    __shared__ int start_s[257];
+    __shared__ u32 zlo_s[256], zhi_s[256], key_s[256];
+    const int nc = min(ncols[0], ncol_cap);
+    const int c0 = blockIdx.x * 256;
+    if (c0 >= nc) return;
+    const int c = c0 + threadIdx.x;
+    {
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (c < nc) r = cr[c];
+        start_s[threadIdx.x] = c < nc ? (int)r.z : 0x7fffffff;
+        zlo_s[threadIdx.x] = r.x;
+        zhi_s[threadIdx.x] = r.y;
+        key_s[threadIdx.x] = c < nc ? colkey[c] : 0u;
+        if (threadIdx.x == min(255, nc - 1 - c0)) start_s[256] = (int)(r.z + r.w);    // (end of the last live column)
+    }
+    __syncthreads();
+    const int nlive = min(256, nc - c0);
+    const int r_begin = start_s[0], r_end = min(start_s[256], cap_rows);
+    for (int row = r_begin + threadIdx.x; row < r_end; row += 256) {
+        int lo = 0;                                           // last column with start <= row
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1)
+            if (lo + step < nlive && start_s[lo + step] <= row) lo += step;
+        const u64 zm = (u64)zlo_s[lo] | ((u64)zhi_s[lo] << 32);
+        const int cz = kth_set_bit64(zm, row - start_s[lo]);
+        const u32 bk = key_s[lo];
+        const int cx = (int)(bk % (u32)pitch), by = (int)(bk / (u32)pitch), cy = by % G.gy, b = by / G.gy;
+        const u64 key = (((u64)b * G.gz + cz) * G.gy + cy) * G.gx + cx;
+        u32 h = hash_u64(key) & mask;
+        // (the voxel is in the table -- it was marked from there; the probe count is bounded all the same)
+        int probes = 0;
+        while (keys[(size_t)h * (L / 2)] != key && probes < 4096) {
+            h = (h + 1) & mask;
+            ++probes;
+        }
+        if (probes >= 4096) continue;
+        const u32 *slot = best + (size_t)h * L;
+        reinterpret_cast<int4 *>(coords)[row] = make_int4(b, cz, cy, cx);
+        float sum[16];
+        for (int ch = 0; ch < C; ++ch) sum[ch] = 0.0f;
+        int np = 0;
+        for (int t = 0; t < T; ++t) {
+            const u32 j = slot[t];
+            if (j == IDX_NONE) {
+                if (voxels)
+                    for (int ch = 0; ch < C; ++ch) voxels[((size_t)row * T + t) * C + ch] = 0.0f;
+                continue;
+            }
+            ++np;
+            const float *p = pts + (size_t)j * stride + feat_off;
+            for (int ch = 0; ch < C; ++ch) {
+                const float v = p[ch];
+                sum[ch] += v;  // same order as voxels.sum(dim=1): t ascending
+                if (voxels) voxels[((size_t)row * T + t) * C + ch] = v;
+            }
+        }
+        num_points[row] = np;
+        const float norm = np > 0 ? (float)np : 1.0f;
+        if (mean_f32)
+            for (int ch = 0; ch < C; ++ch) mean_f32[(size_t)row * C + ch] = __fdiv_rn(sum[ch], norm);
+        if (mean_bf16) {
+            for (int ch = 0; ch < bf16_stride; ++ch)
+                mean_bf16[(size_t)row * bf16_stride + ch] =
+                    ch < C ? f32_to_bf16_bits(__fdiv_rn(sum[ch], norm)) : (unsigned short)0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mean_vfe_kernel(const float *__restrict__ voxels,
                                                        const int32_t *__restrict__ nump, int m,
                                                        int T, int C, float *out) {
@@ -633,6 +726,7 @@ static size_t hard_workspace_bytes(int n_points, int max_points, int batch, cons
         b += ws_piece(pcd_div_up((int)B.nwords, 1024) + 2, sizeof(int));   // their block sums
         b += ws_piece((size_t)B.ncol_cap + 1, sizeof(u64));                // z masks by column
         b += ws_piece(pcd_div_up(B.ncol_cap, 256) + 2, sizeof(int));       // block sums of the column scan
+        b += ws_piece((size_t)B.ncol_cap + 1, sizeof(u32));                // column -> BEV key
     } else if (G) {
         size_t nw, nc;
         if (!sorted_words(batch, *G, &nw, &nc)) return 0;
@@ -702,12 +796,14 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     u32 *cbits = nullptr;
     int *cbsums = nullptr, *colsums = nullptr;
     u64 *zm = nullptr;
+    u32 *colkey = nullptr;
     if (cm) {
         if (!cm_carve(colmap, colmap_bytes, batch, G.gy, G.gx, cap > 0 ? cap : 1, CB, nullptr)) return PCD_ERR_WORKSPACE;
         cbits = ws.take<u32>(CB.nwords + 4);
         cbsums = ws.take<int>(pcd_div_up((int)CB.nwords, 1024) + 2);
         zm = ws.take<u64>((size_t)CB.ncol_cap + 1);
         colsums = ws.take<int>(pcd_div_up(CB.ncol_cap, 256) + 2);
+        colkey = ws.take<u32>((size_t)CB.ncol_cap + 1);
     } else if (key_order) {
         bitmap = ws.take<u32>(nw);
         chunk_prefix = ws.take<int>(nc + 8);
@@ -765,7 +861,7 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         cm_words_count_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, cbsums);
         const int wsp = cm_spined(nwb);
         if (wsp) scan_spine_kernel<<<1, 256, 0, st>>>(cbsums, nwb, nullptr);
-        cm_words_prefix_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, nwb, cbsums, wsp, CB.cw, CB.ncols);
+        cm_words_prefix_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, nwb, cbsums, wsp, CB.cw, CB.ncols, colkey, CB.ncol_cap);
         vox_cm_zmark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
                                                 frame_rank0, voxel_counts, CB.cw, CB.ncol_cap, zm, CB.pitch);
         const int ncb = pcd_div_up(CB.ncol_cap, 256);
@@ -816,7 +912,11 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
             PCD_RETURN_IF_LAUNCH_FAILED();
         }
     }
-    if (n_points > 0) {
+    if (n_points > 0 && cm && pcd_opt(PCD_OPT_VOX_EMIT_ROWS)) {
+        vox_emit_rows_kernel<<<pcd_div_up(CB.ncol_cap, 256), 256, 0, st>>>(
+            points, point_stride, feat_offset, num_features, G, max_points, L, keys, best, tcap - 1, voxels, coords, num_points,
+            mean_f32, (unsigned short *)mean_bf16, mean_bf16_stride, cap, CB.cr, colkey, CB.ncols, CB.ncol_cap, CB.pitch);
+    } else if (n_points > 0) {
         vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                             num_features, frame_offsets, batch, G, max_points, L, best,
                                             pt_slot, rank, frame_rank0, frame_base, voxel_counts,
