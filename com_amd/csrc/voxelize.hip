@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict
                                                          const int32_t *__restrict__ offs, int batch,
                                                          VoxGeom G, int T, int L, u64 *keys, u32 *best,
                                                          u32 mask, int32_t *pt_slot) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+  // (a workgroup takes the 256-point chunks blockIdx.x, + gridDim.x, ...: option "vox_grid" sizes the grid)
+  for (int chunk = blockIdx.x; chunk * 256 < n; chunk += gridDim.x) {
+    const int i = chunk * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     u64 key = KEY_EMPTY;
     if (i < n) {
@@ -113,21 +115,22 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict
         }
     }
     h = __shfl(h, head_lane);
-    if (i >= n) return;
+    if (i >= n) continue;
     if (!valid) {
         pt_slot[i] = -1;
-        return;
+        continue;
     }
     pt_slot[i] = (int32_t)h;
     u32 v = (u32)i;
     // T smaller indices are already kept (or precede us in the run): we can never enter
-    if (run_rank >= T || last < v) return;
+    if (run_rank >= T || last < v) continue;
     u32 *slot = best + (size_t)h * L;
     for (int t = run_rank; t < T; ++t) {
         u32 old = atomicMin(&slot[t], v);
         if (old == IDX_NONE) break;
         v = old > v ? old : v;
     }
+  }
 }
 
 // "point i is the first point of its voxel": one random read of the candidate table per point.  The flag is
@@ -307,37 +310,37 @@ __global__ __launch_bounds__(256) void vox_cm_mark_kernel(
         if (blockIdx.x == 0) voxel_counts[batch] = base;
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int rk = rank[i];
-    if (rank[i + 1] == rk) return;                 // not the first point of a voxel
-    const int b = frame_of(offs, batch, i);
-    if (rk - r_s[b] >= m_s[b]) return;
-    const float *p0 = pts + (size_t)i * stride + feat_off;
-    float xyz[3] = {p0[0], p0[1], p0[2]};
-    int cx, cy, cz;
-    voxel_coord(xyz, G, cx, cy, cz);
-    const u32 key = bev_key(b, cy, cx, G.gy, pitch);
-    atomicOr(cbits + (key >> 5), 1u << (key & 31u));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int rk = rank[i];
+        if (rank[i + 1] == rk) continue;               // not the first point of a voxel
+        const int b = frame_of(offs, batch, i);
+        if (rk - r_s[b] >= m_s[b]) continue;
+        const float *p0 = pts + (size_t)i * stride + feat_off;
+        float xyz[3] = {p0[0], p0[1], p0[2]};
+        int cx, cy, cz;
+        voxel_coord(xyz, G, cx, cy, cz);
+        const u32 key = bev_key(b, cy, cx, G.gy, pitch);
+        atomicOr(cbits + (key >> 5), 1u << (key & 31u));
+    }
 }
 
 __global__ __launch_bounds__(256) void vox_cm_zmark_kernel(
     const float *__restrict__ pts, int n, int stride, int feat_off, const int32_t *__restrict__ offs, int batch,
     VoxGeom G, const int *__restrict__ rank, const int *__restrict__ frame_rank0, const int32_t *__restrict__ voxel_counts,
     const uint2 *__restrict__ cw, int ncol_cap, u64 *__restrict__ zm, int pitch) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int rk = rank[i];
-    if (rank[i + 1] == rk) return;
-    const int b = frame_of(offs, batch, i);
-    if (rk - frame_rank0[b] >= voxel_counts[b]) return;
-    const float *p0 = pts + (size_t)i * stride + feat_off;
-    float xyz[3] = {p0[0], p0[1], p0[2]};
-    int cx, cy, cz;
-    voxel_coord(xyz, G, cx, cy, cz);
-    const u32 key = bev_key(b, cy, cx, G.gy, pitch);
-    const int col = cm_col(cw[key >> 5], key, ncol_cap);
-    if (col >= 0) atomicOr((unsigned long long *)(zm + col), 1ull << cz);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int rk = rank[i];
+        if (rank[i + 1] == rk) continue;
+        const int b = frame_of(offs, batch, i);
+        if (rk - frame_rank0[b] >= voxel_counts[b]) continue;
+        const float *p0 = pts + (size_t)i * stride + feat_off;
+        float xyz[3] = {p0[0], p0[1], p0[2]};
+        int cx, cy, cz;
+        voxel_coord(xyz, G, cx, cy, cz);
+        const u32 key = bev_key(b, cy, cx, G.gy, pitch);
+        const int col = cm_col(cw[key >> 5], key, ncol_cap);
+        if (col >= 0) atomicOr((unsigned long long *)(zm + col), 1ull << cz);
+    }
 }
 
 struct ZmCount {
@@ -509,33 +512,34 @@ __device__ __forceinline__ int kth_set_bit64(u64 v, int k) {
     return pos;
 }
 
+template <int COLS>
 __global__ __launch_bounds__(256) void vox_emit_rows_kernel(
     const float *__restrict__ pts, int stride, int feat_off, int C, VoxGeom G, int T, int L, const u64 *__restrict__ keys,
     const u32 *__restrict__ best, u32 mask, float *voxels, int32_t *coords, int32_t *num_points, float *mean_f32,
     unsigned short *mean_bf16, int bf16_stride, int cap_rows, const uint4 *__restrict__ cr, const u32 *__restrict__ colkey,
     const int *__restrict__ ncols, int ncol_cap, int pitch) {
-    __shared__ int start_s[257];
-    __shared__ u32 zlo_s[256], zhi_s[256], key_s[256];
+    __shared__ int start_s[COLS + 1];
+    __shared__ u32 zlo_s[COLS], zhi_s[COLS], key_s[COLS];
     const int nc = min(ncols[0], ncol_cap);
-    const int c0 = blockIdx.x * 256;
+    const int c0 = blockIdx.x * COLS;
     if (c0 >= nc) return;
     const int c = c0 + threadIdx.x;
-    {
+    if (threadIdx.x < COLS) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (c < nc) r = cr[c];
         start_s[threadIdx.x] = c < nc ? (int)r.z : 0x7fffffff;
         zlo_s[threadIdx.x] = r.x;
         zhi_s[threadIdx.x] = r.y;
         key_s[threadIdx.x] = c < nc ? colkey[c] : 0u;
-        if (threadIdx.x == min(255, nc - 1 - c0)) start_s[256] = (int)(r.z + r.w);    // (end of the last live column)
+        if (threadIdx.x == min(COLS - 1, nc - 1 - c0)) start_s[COLS] = (int)(r.z + r.w);    // (end of the last live column)
     }
     __syncthreads();
-    const int nlive = min(256, nc - c0);
-    const int r_begin = start_s[0], r_end = min(start_s[256], cap_rows);
+    const int nlive = min(COLS, nc - c0);
+    const int r_begin = start_s[0], r_end = min(start_s[COLS], cap_rows);
     for (int row = r_begin + threadIdx.x; row < r_end; row += 256) {
         int lo = 0;                                           // last column with start <= row
 #pragma unroll
-        for (int step = 128; step >= 1; step >>= 1)
+        for (int step = COLS / 2; step >= 1; step >>= 1)
             if (lo + step < nlive && start_s[lo + step] <= row) lo += step;
         const u64 zm = (u64)zlo_s[lo] | ((u64)zhi_s[lo] << 32);
         const int cz = kth_set_bit64(zm, row - start_s[lo]);
@@ -836,7 +840,8 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
     // one memset to 0xFF sets both sentinels (empty key, no candidate)
     pcd_fill(tab, 0xFF, (size_t)tcap * L * sizeof(u32), st);
     if (n_points > 0) {
-        vox_insert_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
+        const int vg = pcd_opt(PCD_OPT_VOX_GRID);
+        vox_insert_kernel<<<vg > 0 && vg < nb ? vg : nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                               frame_offsets, batch, G, max_points, L, keys, best,
                                               tcap - 1, pt_slot);
         PCD_RETURN_IF_LAUNCH_FAILED();
@@ -855,14 +860,15 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         scan_reduce_kernel<FirstFlag><<<nb, 256, 0, st>>>(ff, n_points, bsums);
         if (spined) scan_spine_kernel<<<1, 256, 0, st>>>(bsums, nb, nullptr);
         vox_flag_down_kernel<<<nb, 256, 0, st>>>(rank, n_points, bsums, spined);
-        vox_cm_mark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
+        const int vgm = pcd_opt(PCD_OPT_VOX_GRID) > 0 && pcd_opt(PCD_OPT_VOX_GRID) < nb ? pcd_opt(PCD_OPT_VOX_GRID) : nb;
+        vox_cm_mark_kernel<<<vgm, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
                                                max_voxels, cap, frame_rank0, frame_base, voxel_counts, cbits, CB.pitch);
         const int nwords = (int)CB.nwords, nwb = pcd_div_up(nwords, 1024);
         cm_words_count_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, cbsums);
         const int wsp = cm_spined(nwb);
         if (wsp) scan_spine_kernel<<<1, 256, 0, st>>>(cbsums, nwb, nullptr);
         cm_words_prefix_kernel<<<nwb, 256, 0, st>>>(cbits, nwords, nwb, cbsums, wsp, CB.cw, CB.ncols, colkey, CB.ncol_cap);
-        vox_cm_zmark_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
+        vox_cm_zmark_kernel<<<vgm, 256, 0, st>>>(points, n_points, point_stride, feat_offset, frame_offsets, batch, G, rank,
                                                 frame_rank0, voxel_counts, CB.cw, CB.ncol_cap, zm, CB.pitch);
         const int ncb = pcd_div_up(CB.ncol_cap, 256);
         const int csp = ncb > VOX_DIRECT_BLOCKS;
@@ -913,7 +919,12 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         }
     }
     if (n_points > 0 && cm && pcd_opt(PCD_OPT_VOX_EMIT_ROWS)) {
-        vox_emit_rows_kernel<<<pcd_div_up(CB.ncol_cap, 256), 256, 0, st>>>(
+        // (256 columns ~ 800 rows per workgroup, three rows per thread one after the other: 118 us in the graph and a step of
+        //  3.07 ms; 64 columns per workgroup -- one row per thread, four times the workgroups -- 74 us and 3.11 ms: the kernel runs
+        //  beside level 2 of the forward pass, and what it costs the step is the CUs it takes from the window kernels there, not
+        //  its own duration.  The per-point form: 66 us, 3.09 ms.)
+        constexpr int EMIT_COLS = 256;
+        vox_emit_rows_kernel<EMIT_COLS><<<pcd_div_up(CB.ncol_cap, EMIT_COLS), 256, 0, st>>>(
             points, point_stride, feat_offset, num_features, G, max_points, L, keys, best, tcap - 1, voxels, coords, num_points,
             mean_f32, (unsigned short *)mean_bf16, mean_bf16_stride, cap, CB.cr, colkey, CB.ncols, CB.ncol_cap, CB.pitch);
     } else if (n_points > 0) {
