@@ -101,6 +101,7 @@ PROTOTYPES = {
     "pcd_debug_stamp": (_i, [_vp, _vp]),
     "pcd_debug_stream_create_cu_mask": (_i, [_vp, _i, _vp]),
     "pcd_debug_spin": (_i, [_i, ctypes.c_ulonglong, _vp, _vp]),
+    "pcd_debug_spin_shape": (_i, [_i, _i, _i, _i, ctypes.c_ulonglong, _vp]),
     "pcd_pull_from_host": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp]),
     "pcd_counter_add": (_i, [_vp, _i, _vp]),
     "pcd_conv2d_packed_weight_bytes": (_sz, [_i, _i, _i]),

@@ -104,3 +104,36 @@ extern "C" int pcd_debug_spin(int blocks, unsigned long long ticks, uint32_t *xc
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
+// the same with `threads` (a multiple of 64, <= 1024) per workgroup, `lds_bytes` of dynamic LDS and ~`vgprs` live vector
+// registers per lane (24 / 40 / 56 / 72; 0 = minimal): a co-tenant of chosen weight for the residency experiments
+// (tools/exp_coresident.py)
+template <int NV>
+static __global__ __launch_bounds__(1024) void debug_spin_regs_kernel(unsigned long long ticks, float *sink) {
+    const unsigned long long t0 = wall_clock64();
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x + i);
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(v[i]));
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i];
+    if (sink && s == 12345.678f) *sink = s;
+}
+extern "C" int pcd_debug_spin_shape(int blocks, int threads, int lds_bytes, int vgprs, unsigned long long ticks, void *stream) {
+    PCD_ENTER();
+    if (blocks <= 0 || threads <= 0 || threads > 1024 || threads % 64 || lds_bytes < 0 || lds_bytes > 64 * 1024) return PCD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (vgprs) {
+        case 0: debug_spin_kernel<<<blocks, threads, lds_bytes, st>>>(ticks, nullptr); break;
+        case 24: debug_spin_regs_kernel<16><<<blocks, threads, lds_bytes, st>>>(ticks, nullptr); break;
+        case 40: debug_spin_regs_kernel<32><<<blocks, threads, lds_bytes, st>>>(ticks, nullptr); break;
+        case 56: debug_spin_regs_kernel<48><<<blocks, threads, lds_bytes, st>>>(ticks, nullptr); break;
+        case 72: debug_spin_regs_kernel<64><<<blocks, threads, lds_bytes, st>>>(ticks, nullptr); break;
+        default: return PCD_ERR_INVALID_ARG;
+    }
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}

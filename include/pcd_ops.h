@@ -988,6 +988,7 @@ int pcd_debug_stamp(uint64_t *slot, void *stream);
  * launch was given, eagerly and as a replayed hipGraph node.  No reference counterpart. */
 int pcd_debug_stream_create_cu_mask(const uint32_t *cu_mask, int words, void **stream_out);
 int pcd_debug_spin(int blocks, unsigned long long ticks, uint32_t *xcc_seen, void *stream);
+int pcd_debug_spin_shape(int blocks, int threads, int lds_bytes, int vgprs, unsigned long long ticks, void *stream);
 
 /* ============================================================================================
  * (a8) SubMConv3d arithmetic over z-fastest rows: the WINDOW gather-GEMM (spconv_win.hip) -- forward and data gradient of
