@@ -50,35 +50,53 @@ static int pow2_ge8(int c) {
 __host__ __device__ constexpr int gg_quad(int nb) { return nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1); }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pack_one(const float *__restrict__ w, int K, int cin, int cout, int mode,
-                                         int cshift, int NB, size_t e, unsigned short *out) {
-    int j = e & 7;
-    int lane = (e >> 3) & 63;
-    size_t t = e >> 9;
-    int nb = (int)(t % NB);
-    int s = (int)(t / NB);
-    int q = s * 32 + (lane >> 4) * 8 + j;
-    int k = q >> cshift;
-    int c = q & ((1 << cshift) - 1);
-    const int Q = gg_quad(NB), m = lane & 15;   // interleaved channel order, see gg_quad
-    int col = (nb / Q) * 16 * Q + (m >> 2) * 4 * Q + (nb % Q) * 4 + (m & 3);
-    float v = 0.0f;
+// the eight elements e0 .. e0 + 7 (e0 a multiple of 8: one lane's 16 bytes of one fragment = eight consecutive contraction
+// indices of one kernel offset, cshift >= 3): one 16-byte store; forward packs read 32 contiguous bytes of the weight
+__device__ __forceinline__ void pack_eight(const float *__restrict__ w, int K, int cin, int cout, int mode,
+                                           int cshift, int NB, size_t e0, unsigned short *out) {
+    const int lane = (int)(e0 >> 3) & 63;
+    const size_t t = e0 >> 9;
+    const int nb = (int)(t % NB);
+    const int s = (int)(t / NB);
+    const int q0 = s * 32 + (lane >> 4) * 8;
+    const int k = q0 >> cshift;
+    const int c0 = q0 & ((1 << cshift) - 1);
+    const int Q = gg_quad(NB), m = lane & 15;
+    const int col = (nb / Q) * 16 * Q + (m >> 2) * 4 * Q + (nb % Q) * 4 + (m & 3);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < K) {
         if (mode == 0) {
-            if (c < cin && col < cout) v = w[((size_t)col * K + k) * cin + c];
-        } else {
-            if (c < cout && col < cin) v = w[((size_t)c * K + k) * cin + col];
+            if (col < cout) {
+                const float *src = w + ((size_t)col * K + k) * cin + c0;
+                if (c0 + 8 <= cin && (cin & 3) == 0 && (((uintptr_t)src) & 15u) == 0) {
+                    const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (c0 + j < cin) v[j] = src[j];
+                }
+            }
+        } else if (col < cin) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < cout) v[j] = w[((size_t)(c0 + j) * K + k) * cin + col];
         }
     }
-    out[e] = f32_to_bf16_bits(v);
+    u32 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (u32)f32_to_bf16_bits(v[2 * j]) | ((u32)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+    *reinterpret_cast<uint4 *>(out + e0) = make_uint4(o[0], o[1], o[2], o[3]);
 }
+
+constexpr int PACK_PER_BLOCK = 2048;     // elements per 256-thread block (eight per thread)
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int K, int cin,
                                                           int cout, int mode, int cshift, int NB,
                                                           size_t total, unsigned short *out) {
-    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (e >= total) return;
-    pack_one(w, K, cin, cout, mode, cshift, NB, e, out);
+    pack_eight(w, K, cin, cout, mode, cshift, NB, e, out);
 }
 
 // One launch for a whole list of weights.  table[i] = {weight ptr, packed ptr, kvol, cin, cout, mode,
@@ -100,9 +118,9 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long lo
     while ((1 << cshift) < cc) ++cshift;
     const int NB = ((mode == 0 ? cout : cin) + 15) / 16;
     const size_t total = (size_t)((K * cc + 31) / 32) * NB * 512;
-    const size_t e = ((size_t)blockIdx.x - (size_t)row[6]) * 256 + threadIdx.x;
+    const size_t e = (((size_t)blockIdx.x - (size_t)row[6]) * 256 + threadIdx.x) * 8;
     if (e >= total) return;
-    pack_one(w, K, cin, cout, mode, cshift, NB, e, out);
+    pack_eight(w, K, cin, cout, mode, cshift, NB, e, out);
 }
 
 // Tile of workgroup blockIdx.x when the REAL row tiles (ceil(n / rows_per_tile), n known on the device only) are dealt
@@ -2285,7 +2303,7 @@ extern "C" int pcd_pack_weight(const float *weight, int kvol, int cin, int cout,
     int nsteps = (kvol * cc + 31) / 32;
     int NB = (ncol + 15) / 16;
     size_t total = (size_t)nsteps * NB * 64 * 8;
-    pack_weight_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+    pack_weight_kernel<<<(unsigned)((total + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
         weight, kvol, cin, cout, mode, log2_exact(cc), NB, total, (unsigned short *)packed);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;

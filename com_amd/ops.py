@@ -1023,7 +1023,7 @@ class PackPlan:
                 nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
                 buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
                 rows.append([w.data_ptr(), buf.data_ptr(), K, cin, cout, mode, first, 0])
-                first += (nbytes // 2 + 255) // 256
+                first += (nbytes // 2 + 2047) // 2048        # (2048 packed elements per 256-thread block)
             self.packed.append(buf)
         self.total_blocks, self.win_blocks = first, wfirst
         self.n, self.nw = len(rows), len(wrows)

@@ -443,7 +443,7 @@ int pcd_pack_weight(const float *weight, int kvol, int cin, int cout, int mode, 
 /* The same conversion for a whole list of weights in ONE launch (a backbone re-packs ~40 small weights after
  * every optimizer step).  `table` is DEVICE memory, int64 [n][8], row i =
  *   { weight pointer, packed pointer, kvol, cin, cout, mode, first_block_i, 0 },
- * first_block_0 = 0, first_block_{i+1} = first_block_i + ceil(pcd_packed_weight_bytes(..)/2 / 256);
+ * first_block_0 = 0, first_block_{i+1} = first_block_i + ceil(pcd_packed_weight_bytes(..)/2 / 2048)   (2048 packed elements per block);
  * total_blocks = first_block_n.  The table can be built once and reused while the pointers stay valid. */
 int pcd_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);
 
