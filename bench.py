@@ -969,8 +969,9 @@ def main():
         return None
 
     def opt_step():
-        opt.step()       # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 3 launches
-        bucket.zero()    # zero_grad for the NEXT step here, beside the voxelisation, not in front of its backward pass
+        # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 2 launches; the Adam pass clears the gradient
+        # bucket as it consumes it (zero_grad for the NEXT step: no fill launch on the serial tail of the step)
+        opt.step(zero_grad=True)
         if not os.environ.get('PCD_PACK_LATE'):
             model.backbone_3d.pack_after_update()            # the next step's weight packs, off its critical path
             if args.dense_head:

@@ -155,6 +155,9 @@ PROTOTYPES = {
     "pcd_adam_flat_step_v3": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
                                    _vp, _vp, _vp, _sz, _vp]),
+    "pcd_adam_flat_step_v4": (_i, [_vp, _vp, _i, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _i,
+                                   _vp, _vp, _vp, _sz, _vp]),
     "pcd_stream_capture_id": (_i, [_vp, _vp]),
     "pcd_dot_bf16_workspace_bytes": (_sz, []),
     "pcd_dot_bf16": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),

@@ -12,7 +12,7 @@ constexpr int NORM_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float4 *__restrict__ g, size_t n4,
                                                              const float *__restrict__ tail, int ntail,
-                                                             double *__restrict__ partial) {
+                                                             double *__restrict__ partial, float *step_dev = nullptr) {
     __shared__ double lds[4];
     double s = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)NORM_BLOCKS * 256) {
@@ -25,12 +25,16 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float4 *__res
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    // the update counter moves HERE, in the launch in front of the Adam pass (which then finds it already incremented in every
+    // block): no one-thread kernel behind it on the serial tail of the step
+    if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) step_dev[0] += 1.0f;
 }
 
 // step_dev[0] holds the number of updates done so far (a device float, as torch keeps it for capturable
-// optimizers, so the step can be replayed from a hipGraph); the kernel uses step + 1 and a one-thread kernel
-// launched after it stores the increment (every block of this kernel must read the old value).
-__global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, const float4 *__restrict__ g,
+// optimizers, so the step can be replayed from a hipGraph) -- incremented by the norm launch in front of this one: THIS update
+// is number step_dev[0], the schedule row step_dev[0] - 1.  zero_grad: the gradient is cleared as it is consumed (the next
+// step's zero_grad, without a fill launch).
+__global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, float4 *__restrict__ g, int zero_grad,
                                                         float4 *__restrict__ m, float4 *__restrict__ v, size_t n4,
                                                         const double *__restrict__ norm_partial, float max_norm,
                                                         float pre_divisor, const float *__restrict__ step_dev,
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
     const float gscale = coef / pre_divisor;                                  // g_used = g_sum * gscale
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
     if (schedule) {             // the whole OneCycle table on the device: row = number of updates done so far
-        int row = (int)step_dev[0];
+        int row = (int)step_dev[0] - 1;
         row = row < schedule_len - 1 ? row : schedule_len - 1;
         lr = schedule[2 * row];
         beta1 = schedule[2 * row + 1];
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
     }
     const float decay = decoupled ? 1.0f - lr * wd : 1.0f;     // fastai_optim.py:135-150: p *= 1 - wd * lr, then wd = 0
     const float wd_l2 = decoupled ? 0.0f : wd;
-    const float step = step_dev[0] + 1.0f;
+    const float step = step_dev[0];
     const float bc1 = 1.0f - powf(beta1, step);
     const float bc2 = 1.0f - powf(beta2, step);
     const float step_size = lr / bc1;
@@ -87,10 +91,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
         p[i] = make_float4(P[0], P[1], P[2], P[3]);
         m[i] = make_float4(M[0], M[1], M[2], M[3]);
         v[i] = make_float4(V[0], V[1], V[2], V[3]);
+        if (zero_grad) g[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
-
-__global__ void step_inc_kernel(float *step_dev) { step_dev[0] += 1.0f; }
 
 // <a, b> of two bf16 vectors (fp32 products, double partial sums) and y = a * s[0]: the forward / backward of a linear
 // functional of the BEV map (bench.py's stand-in for the dense head's loss when only the sparse hot path is timed) in
@@ -204,6 +207,16 @@ extern "C" int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp
                                      float max_norm, float pre_divisor, int decoupled_wd, float *hyper_dev,
                                      const float *schedule_dev, int schedule_len, float *step_dev, float *norm_out,
                                      void *workspace, size_t workspace_bytes, void *stream) {
+    return pcd_adam_flat_step_v4(param, const_cast<float *>(grad), 0, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                                 max_norm, pre_divisor, decoupled_wd, hyper_dev, schedule_dev, schedule_len, step_dev, norm_out,
+                                 workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_adam_flat_step_v4(float *param, float *grad, int zero_grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     float max_norm, float pre_divisor, int decoupled_wd, float *hyper_dev,
+                                     const float *schedule_dev, int schedule_len, float *step_dev, float *norm_out,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
     PCD_ENTER();
     if (schedule_dev && schedule_len <= 0) return PCD_ERR_INVALID_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || pre_divisor <= 0.0f) return PCD_ERR_INVALID_ARG;
@@ -215,15 +228,14 @@ extern "C" int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)workspace;
     const size_t n4 = n / 4;
-    sumsq_partials_kernel<<<NORM_BLOCKS, 256, 0, st>>>((const float4 *)grad, n4, nullptr, 0, partial);
+    sumsq_partials_kernel<<<NORM_BLOCKS, 256, 0, st>>>((const float4 *)grad, n4, nullptr, 0, partial, step_dev);
     int blocks = (int)((n4 + 1023) / 1024);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    adam_flat_kernel<<<blocks, 256, 0, st>>>((float4 *)param, (const float4 *)grad, (float4 *)exp_avg,
+    adam_flat_kernel<<<blocks, 256, 0, st>>>((float4 *)param, (float4 *)grad, zero_grad ? 1 : 0, (float4 *)exp_avg,
                                              (float4 *)exp_avg_sq, n4, partial, max_norm, pre_divisor, step_dev, lr,
                                              beta1, beta2, eps, weight_decay, norm_out, decoupled_wd, hyper_dev,
                                              schedule_dev, schedule_len);
-    step_inc_kernel<<<1, 1, 0, st>>>(step_dev);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -188,19 +188,22 @@ class FlatAdam:
             ev.record()
             self._hyper_ev[i] = ev
 
-    def step(self):
+    def step(self, zero_grad=False):
+        """zero_grad=True: the gradient bucket is cleared by the Adam pass itself as it consumes it (the next step's zero_grad
+        without a fill launch: do not call bucket.zero() then)."""
         L, b = self.L, self.bucket
         p = b.flat_param.data
         if self._hyper_dirty:                          # `opt.lr = ...` / `opt.betas = ...` since the last step
             self.set_hyper(self._lr, self._betas[0])
         sched = self.schedule                          # (the kernel reads row min(step, T - 1) itself: no lookup launches)
-        L.check(L.lib().pcd_adam_flat_step_v3(L.ptr(p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+        L.check(L.lib().pcd_adam_flat_step_v4(L.ptr(p), L.ptr(b.flat), int(bool(zero_grad)), L.ptr(self.exp_avg),
+                                              L.ptr(self.exp_avg_sq),
                                               p.numel(), self._lr, self._betas[0], self._betas[1], self.eps, self.wd,
                                               self.max_norm, self.world, int(self.decoupled), L.ptr(self.hyper),
                                               L.ptr(sched) if sched is not None else None,
                                               int(sched.shape[0]) if sched is not None else 0,
                                               L.ptr(self.step_dev), L.ptr(self.grad_norm), L.ptr(self.ws),
-                                              self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v3")
+                                              self.ws.numel(), L.stream_ptr()), "pcd_adam_flat_step_v4")
 
 
 def gather_group_confidence(conf_epoch, num_epoch):

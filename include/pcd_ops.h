@@ -657,6 +657,11 @@ int pcd_adam_flat_step_v3(float *param, const float *grad, float *exp_avg, float
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
                           int decoupled_wd, float *hyper_dev, const float *schedule_dev, int schedule_len,
                           float *step_dev, float *norm_out, void *workspace, size_t workspace_bytes, void *stream);
+/* v3 + zero_grad: the gradient buffer is cleared as it is consumed (the next step's zero_grad without a fill launch). */
+int pcd_adam_flat_step_v4(float *param, float *grad, int zero_grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float max_norm, float pre_divisor,
+                          int decoupled_wd, float *hyper_dev, const float *schedule_dev, int schedule_len, float *step_dev,
+                          float *norm_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ============================================================================================
  * (f2) CenterHead target assignment on the device -- replaces the per-object Python / CPU loop of
