@@ -41,8 +41,8 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (centerpoint.yaml:78)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -1255,17 +1255,27 @@ def main():
 
     def timed_loop(run_step, steps, source, graph):
         """(elapsed seconds, host-issue seconds) of `steps` steps bracketed by barrier + synchronize."""
+        import gc
         if graph:
             state["prime"](source)
-        sync()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            run_step(i, source=source)
-            if graph and (i & 7) == 7 and plan.poll():       # sticky device-side flag, read without stalling
-                raise ops.L.PcdError("static capacity overflow during the timed loop")
-        host_issue = time.perf_counter() - t0
-        sync()
-        return time.perf_counter() - t0, host_issue
+        # (the issuing thread must not pause: a collection of the cyclic garbage collector in the middle of the loop -- tens of
+        #  milliseconds with torch's object graphs alive -- starves the device queue; one run in eight was 5-8 % slow at 60 steps)
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                run_step(i, source=source)
+                if graph and (i & 7) == 7 and plan.poll():       # sticky device-side flag, read without stalling
+                    raise ops.L.PcdError("static capacity overflow during the timed loop")
+            host_issue = time.perf_counter() - t0
+            sync()
+            return time.perf_counter() - t0, host_issue
+        finally:
+            if gc_was:
+                gc.enable()
 
     run_step = eager_step
     recaptures = [0]
