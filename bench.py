@@ -977,6 +977,8 @@ def main():
             if args.dense_head:
                 conv_packs.run()
 
+    # where the next batch's voxelisation may start inside the step's forward pass (backbone.after_rulebooks_at)
+    HOOK_AT = {"units": None}.get(os.environ.get('PCD_HOOK_AT', 'conv3'), os.environ.get('PCD_HOOK_AT', 'conv3'))
     DEVICE_SCHEDULE = os.environ.get('PCD_DEVICE_SCHEDULE', '1') != '0'
     if DEVICE_SCHEDULE:
         # OneCycle as a device table indexed by the optimizer's own step counter (looked up inside the replayed graph):
@@ -1108,6 +1110,11 @@ def main():
                         if "voxel_num_rows" in vox_out:
                             bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
                         model.backbone_3d.after_rulebooks = early      # (documented hook of the backbone: backbone3d.py)
+                        # ... and not before the main chain has finished level 3: the voxeliser's kernels then run beside level 4,
+                        # whose 128-channel kernel occupies 137 of the 256 CUs and leaves room on the others, instead of beside
+                        # level 2 / 3, whose window kernels share a CU with almost nothing: 3.025 -> 2.995 ms
+                        # over four alternations ("conv2": 3.033).  PCD_HOOK_AT=units: right behind the rulebook chain.
+                        model.backbone_3d.after_rulebooks_at = HOOK_AT
                         try:
                             train_from_voxels(bd_in)
                         finally:
@@ -1195,6 +1202,7 @@ def main():
                 if "voxel_num_rows" in vox_out:
                     bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
                 model.backbone_3d.after_rulebooks = early
+                model.backbone_3d.after_rulebooks_at = HOOK_AT       # (see the one-graph form)
                 try:
                     train_from_voxels(bd_in)
                 finally:
