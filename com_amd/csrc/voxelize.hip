@@ -923,10 +923,16 @@ static int voxelize_hard_impl(const float *points, int n_points, int point_strid
         //  3.07 ms; 64 columns per workgroup -- one row per thread, four times the workgroups -- 74 us and 3.11 ms: the kernel runs
         //  beside level 2 of the forward pass, and what it costs the step is the CUs it takes from the window kernels there, not
         //  its own duration.  The per-point form: 66 us, 3.09 ms.)
-        constexpr int EMIT_COLS = 256;
-        vox_emit_rows_kernel<EMIT_COLS><<<pcd_div_up(CB.ncol_cap, EMIT_COLS), 256, 0, st>>>(
-            points, point_stride, feat_offset, num_features, G, max_points, L, keys, best, tcap - 1, voxels, coords, num_points,
-            mean_f32, (unsigned short *)mean_bf16, mean_bf16_stride, cap, CB.cr, colkey, CB.ncols, CB.ncol_cap, CB.pitch);
+#define VOX_EMIT_ROWS(COLS)                                                                                                   \
+    vox_emit_rows_kernel<COLS><<<pcd_div_up(CB.ncol_cap, COLS), 256, 0, st>>>(                                                 \
+        points, point_stride, feat_offset, num_features, G, max_points, L, keys, best, tcap - 1, voxels, coords, num_points,   \
+        mean_f32, (unsigned short *)mean_bf16, mean_bf16_stride, cap, CB.cr, colkey, CB.ncols, CB.ncol_cap, CB.pitch)
+        switch (pcd_opt(PCD_OPT_VOX_EMIT_ROWS)) {        // (option value = columns per workgroup; 1 = 256)
+            case 64: VOX_EMIT_ROWS(64); break;
+            case 128: VOX_EMIT_ROWS(128); break;
+            default: VOX_EMIT_ROWS(256); break;
+        }
+#undef VOX_EMIT_ROWS
     } else if (n_points > 0) {
         vox_emit_kernel<<<nb, 256, 0, st>>>(points, n_points, point_stride, feat_offset,
                                             num_features, frame_offsets, batch, G, max_points, L, best,

@@ -85,8 +85,8 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "wg128_chunks" 512    its workgroup count
  *   "wg_rows" 6144        row-range split of the generic weight-gradient kernel
  *   "conv2d_wb" 1, "conv2d_wg_blocks" 128, "conv2d_wgp_mode2" 0, "conv2d_wgp_blocks" 512   dense 3x3 conv variants
- *   "vox_emit_rows" 1     pcd_voxelize_hard_yxz writes its output rows in row order (a workgroup per 256 columns of the map; 0 = one thread
- *                         per point, rows scattered: the round-4 form, same results)
+ *   "vox_emit_rows" 1     pcd_voxelize_hard_yxz writes its output rows in row order (a workgroup per 256 columns of the map; 64 / 128:
+ *                         that many columns per workgroup; 0 = one thread per point, rows scattered: the round-4 form, same results)
  *   "ggw_cw" 2            consumer waves per SIMD of the wide gather-GEMM at 128 -> 128 channels, 192-row tiles (1 = one, the round-4 form)
  *   "ggw_mi" 0            rows per workgroup / 64 of the wide gather-GEMM: 0 = by rule (forward convs of small levels 2, else 3), 2 / 3 forced
  *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
