@@ -1567,12 +1567,17 @@ def main():
         a = measure_full_model(args, flags=(), what="N > 1 form + dist.all_reduce over a one-rank RCCL communicator",
                                extra_env={"PCD_RCCL_WORLD1": "1"})
         b = measure_full_model(args, flags=(), what="N > 1 form, no collective", extra_env={"PCD_FORCE_3GRAPH": "1"})
+        # (... and the one-graph form as a child run of the same kind: the parent's own figure comes from a process that has
+        #  been on the device for a minute, the children's from fresh ones -- the forms are compared child against child)
+        c = measure_full_model(args, flags=(), what="one-graph form, child run", extra_env={"PCD_NO_N_GT_1": "1"})
         if "error" in a or "error" in b:
             result["n_gt_1_form"] = {"error": a.get("error") or b.get("error")}
         else:
             result["n_gt_1_form"] = {
                 "ms_per_step": a["ms_per_step"], "ms_per_step_no_collective": b["ms_per_step"],
                 "ms_allreduce_exposed": round(a["ms_per_step"] - b["ms_per_step"], 4),
+                "ms_per_step_one_graph_child": c.get("ms_per_step"),
+                "ms_over_one_graph_child": (round(a["ms_per_step"] - c["ms_per_step"], 4) if "ms_per_step" in c else None),
                 "ms_per_step_one_graph": result["ms_per_step"], "bucket_MB": round(bucket.flat.numel() * 4 / 1e6, 2),
                 "what": "the N > 1 execution form on ONE GPU (child runs): [forward+backward graph incl. the mid-forward "
                         "voxelisation of the next batch] | all-reduce | clip+Adam as plain launches (until round 4: voxelise-graph | "
