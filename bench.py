@@ -14,6 +14,7 @@ every conv fwd+bwd, rulebook and BatchNorm of ONE whole frame, median of 3 passe
 COM targets / losses -- measured by a child run of `bench.py --dense-head --com`).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -30,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 from com_amd import hotpath, ops  # noqa: E402   (the HIP library is loaded lazily, on the first op)
 from com_amd import dist as cdist  # noqa: E402
+from com_amd import train  # noqa: E402
 from com_amd.utils import synth  # noqa: E402
 
 METRIC = "training frames/sec, CenterPoint-VoxelNet Waymo 160k-pt clouds, 1/2/4/8 MI355X"
@@ -73,13 +75,14 @@ def parse():
     ap.add_argument("--no-stage2", action="store_true", help="skip the PV-RCNN stage-2 (config 4) secondary figure")
     ap.add_argument("--no-full-model", action="store_true", help="skip the child run that measures the full CenterPoint + COM step")
     ap.add_argument("--no-n-gt-1", action="store_true", help="skip the two child runs that measure the N > 1 execution form on one GPU")
+    ap.add_argument("--no-seam-path", action="store_true", help="skip the stock-eager / fused-eager / captured comparison")
     ap.add_argument("--light", action="store_true", help="only the timed loop: every --no-* switch at once (experiment scripts)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU plumbing test of the launcher / result assembly: gloo ranks, no GPU work")
     a = ap.parse_args()
     if a.light:
         a.no_cpu_baseline = a.no_roofline = a.no_h2d = a.no_ragged = a.no_stage2 = a.no_full_model = a.no_fp8 = True
-        a.no_regime = a.no_n_gt_1 = True
+        a.no_regime = a.no_n_gt_1 = a.no_seam_path = True
     return a
 
 
@@ -578,7 +581,12 @@ class PullSource:
                                        L.stream_ptr()), "pcd_pull_from_host")
         L.check(lib.pcd_counter_add(L.ptr(self.counter), 1, L.stream_ptr()), "pcd_counter_add")
 
-    # the ResidentSource / H2DSource protocol, unused by the pull form of run_step
+    def prime(self, s_pts, s_offs8):
+        """batch 0 by the same kernel, eagerly (counter 0 -> 1), into the step's static input buffers"""
+        self.counter.zero_()
+        self.enqueue(s_pts, s_offs8)
+
+    # the ResidentSource / H2DSource protocol, unused by the pull form of the step
     def get(self, j):
         raise RuntimeError("PullSource feeds the graph itself")
 
@@ -697,6 +705,68 @@ def measure_stage2(B, dev):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def measure_seam_path(W, captured_fps, dev, steps=20):
+    """`seam_path`: frames/s of the SAME workload at the three levels of integration INTEGRATION.md describes, measured in
+    this run -- what a user of each seam gets:
+      stock_eager   seams 1-3 only: a backbone written like a stock model file (tools/seam1_model.py: spconv.* names, torch
+                    BatchNorm1d / ReLU / residual add, fp32 features), the reference's loop with torch.optim.Adam +
+                    clip_grad_norm_, eager launches;
+      fused_eager   + seam 3a (com_amd.hotpath backbone) + the flat bucket / FlatAdam, com_amd.train.CapturedStep WITHOUT
+                    capture(): the same loop, one launch per kernel from Python;
+      captured      the same object after capture(): the headline `value`."""
+    import seam1_model as S
+    B, batches = W.B, W.batches
+    out = {"unit": "frames/s", "captured": round(captured_fps, 1), "steps": steps}
+    try:
+        step = W.step
+        step.release()
+        step.prime(batches[0])
+        for i in range(3):
+            step(batches[(i + 1) % len(batches)])
+        torch.cuda.synchronize()
+        gc.collect()
+        t0 = time.perf_counter()
+        train.train_one_epoch(step, batches, steps, accumulated_iter=step.lr_scheduler.last_iter + 1, gc_collect=False)
+        torch.cuda.synchronize()
+        out["fused_eager"] = round(B * steps / (time.perf_counter() - t0), 1)
+    except Exception as exc:
+        out["fused_eager_error"] = f"{type(exc).__name__}: {exc}"
+    try:
+        grid = ops.grid_size(synth.WAYMO_RANGE, synth.WAYMO_VOXEL)
+        torch.manual_seed(666)
+        backbone = S.StockVoxelResBackBone8x(5, grid).to(dev).train()
+        to_bev = hotpath.HeightCompression({"NUM_BEV_FEATURES": 256})
+        optim = torch.optim.Adam(backbone.parameters(), lr=3e-4, betas=(0.9, 0.99))
+        loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3)
+        from com_amd.spconv import functional as Fsp
+
+        def stock_step(batch):
+            pts, offs = batch
+            bd = hotpath.transform_points_to_voxels({"points": pts, "frame_offsets": offs, "batch_size": B}, synth.WAYMO_RANGE,
+                                                    synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS, fuse_mean=True)
+            optim.zero_grad()
+            bd = to_bev(backbone(bd))
+            loss = (bd["spatial_features"].float().reshape(-1) * loss_w).sum()
+            loss.backward()
+            Fsp.join_deferred_wgrad()
+            torch.nn.utils.clip_grad_norm_(backbone.parameters(), 10.0)
+            optim.step()
+        for i in range(3):
+            stock_step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            stock_step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        out["stock_eager"] = round(B * steps / (time.perf_counter() - t0), 1)
+    except Exception as exc:
+        out["stock_eager_error"] = f"{type(exc).__name__}: {exc}"
+    out["what"] = ("same B x 160k-point batches, whole training step (voxelise -> backbone -> BEV -> loss -> backward -> clip -> "
+                   "Adam): stock model file over import seams 1-3 with torch's optimizer, eager | fused backbone + flat "
+                   "optimizer through com_amd.train.CapturedStep without capture, eager | the same object captured (= value)")
+    return out
+
+
 def measure_regime():
     """`roofline.rulebook`: the rulebook chain of one forward pass (9 builds) at B = 4 (reference batch) and B = 32 (the
     bandwidth regime SURVEY 8d asks for), algorithmic bytes 16 N_in + 8 P (+ 16 N_out) over the time of the builds
@@ -730,7 +800,7 @@ def measure_full_model(args, flags=("--dense-head", "--com"), what=None, extra_e
     cmd = [sys.executable, os.path.abspath(__file__), *flags, "--gpus", "1", "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--batch", str(args.batch), "--distinct-batches", str(args.distinct_batches),
            "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-regime",
-           "--no-n-gt-1"]
+           "--no-n-gt-1", "--no-seam-path"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -749,6 +819,193 @@ def measure_full_model(args, flags=("--dense-head", "--com"), what=None, extra_e
                         "COM curriculum targets / FocalLossCenterCurriculum / RegLoss, one hipGraph per step"}
     except Exception as exc:                                  # never lose the headline
         return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+class _SourceFeed:
+    """A ResidentSource / H2DSource as the iterator com_amd.train.train_one_epoch draws from: batch k + 1 while the step
+    trains on batch k (the data side runs one batch ahead); `staged` refills the source's slot once the step has enqueued
+    its copies of the batch."""
+
+    def __init__(self, source):
+        self.source, self.k = source, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self.k += 1
+        return self.source.get(self.k)
+
+    def staged(self):
+        self.source.release(self.k)
+
+
+class _Repeat:
+    """(pull form: the graph fetches its own batches -- the loop has nothing to hand over)"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.value
+
+    def staged(self):
+        pass
+
+
+class Workload:
+    pass
+
+
+def build_workload(args, rank, world, dev, rccl_world1=False):
+    """Model, synthetic batches, optimizer and the com_amd.train.CapturedStep of one rank -- everything main() times, also
+    what tests/test_gpu_train_step.py drives from its own reference-shaped loop."""
+    W = Workload()
+    W.B = B = args.batch
+    torch.manual_seed(666 + (0 if args.same_shard else rank))   # cf. tools/train.py:86-87
+    # frames sharded by rank with DistributedSampler striding (pcdet/datasets/__init__.py:65-72 ->
+    # com_amd.dist.shard_frames); `--distinct-batches` (16) global batches of DISTINCT full 160k-point frames cycle
+    # through the timed loop: voxel / row counts differ from step to step (M = 80..87 k per frame), the static
+    # capacities are sized from the warm-up steps only, and a denser batch would trip the overflow guard
+    W.n_batches = n_batches = max(2, args.distinct_batches)
+    BEAMS = 120 if args.config5 else 64                       # 120 x 2500 = 300 000 points per frame (config 5)
+
+    def make_batches(drop=None):
+        out = []
+        for j in range(n_batches):
+            ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
+            frames = [synth.synth_cloud(f, BEAMS, 2500) for f in ids]
+            if drop is not None:                             # ragged variant: 0-20 % of every frame's rays are lost
+                frames = [f[:int(round(f.shape[0] * (1.0 - drop.uniform(0.0, 0.2))))] for f in frames]
+            pts, offs = hotpath.collate_points(frames, dev)  # resident in HBM before the timed region
+            out.append((pts, torch.tensor(offs, dtype=torch.int32, device=dev)))
+        return out
+
+    def pad_batches(bs, rows):
+        return [(torch.nn.functional.pad(p, (0, 0, 0, rows - p.shape[0])) if p.shape[0] < rows else p, o) for p, o in bs]
+
+    batches = make_batches()
+    # the static graph reads ONE point buffer: batches are padded to a common row count (offsets say what is real)
+    W.nmax = nmax = (max(p.shape[0] for p, _ in batches) + 1) // 2 * 2     # (even: whole 16-byte pieces for the in-graph host pull)
+    W.batches = batches = pad_batches(batches, nmax)
+    W.make_batches, W.pad_batches = make_batches, pad_batches
+    W.resident = ResidentSource(batches)
+
+    ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
+    W.model = model = HotPath(dense_head=args.dense_head, plain=args.config5).to(dev)
+    model.train()
+    if world > 1:                                            # what DDP does at construction (tools/train.py:165-166)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if args.dense_head and os.environ.get('PCD_HEAD_BATCHED', '1') != '0':
+        # the head branches' first-stage parameters back to back in the flat buffers: their batched path (dense2d.py)
+        from com_amd.hotpath import dense2d as _d2
+        params = [p for p in _d2.batched_param_order(model) if p.requires_grad]
+    # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB); so do the
+    # parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step_v4) with the reference's
+    # adam_onecycle rule: decoupled weight decay, betas (MOMS, 0.99), lr / momentum from the OneCycle schedule
+    # (tools/train_utils/optimization/__init__.py:19-32,53-56; centerpoint.yaml:81-96), GRAD_NORM_CLIP 10
+    total_iters = 30 * 1000                                  # schedule length only shapes lr(it) / mom(it)
+    lr0, mom0 = cdist.one_cycle(0, total_iters)
+    W.opt = opt = train.build_optimizer(params, lr=lr0, weight_decay=0.01, moms=(mom0, 0.85), grad_norm_clip=10.0, world=world)
+    W.bucket = bucket = opt.bucket
+    bucket.force_collective = rccl_world1
+    W.flat_param = bucket.flat_param
+    # OneCycle as a device table indexed by the optimizer's own step counter (looked up inside the replayed graph): no
+    # 8-byte host -> device copy in front of every step (PCD_DEVICE_SCHEDULE=0: set_hyper per step)
+    lr_scheduler = train.OneCycle(opt, total_iters, device_table=os.environ.get('PCD_DEVICE_SCHEDULE', '1') != '0')
+    # stand-in for the dense head when only the hot path is timed: loss = <spatial_features, fixed random tensor>
+    # (ops.LinearFunctionalLoss: pcd_dot_bf16 forward, pcd_scale_bf16 backward -- 2 + 1 HIP launches)
+    loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
+
+    CLASS_NAMES = ['Vehicle', 'Pedestrian', 'Cyclist']
+    after_update = [model.backbone_3d.pack_after_update]
+    if args.dense_head:
+        from com_amd.hotpath import center_loss, dense2d, targets
+        # get_loss in four HIP launches per head (centerhead.hip); PCD_LOSS_TORCH=1: the elementwise torch chain
+        loss_cls = center_loss.CenterHeadLoss if os.environ.get('PCD_LOSS_TORCH') else center_loss.FusedCenterHeadLoss
+        head_loss = loss_cls(dense2d.CENTERPOINT_HEAD['SEPARATE_HEAD_CFG']['HEAD_ORDER'],
+                             cls_weight=1.0, loc_weight=2.0).to(dev)                        # centerpoint.yaml:52-58
+        from com_amd.hotpath import conv2d_fast
+        conv_packs = conv2d_fast.Conv3x3Packs(model)       # all dense 3x3 weight packs in one launch per step
+        after_update.append(conv_packs.run)
+        rs = np.random.default_rng(1234 + (0 if args.same_shard else rank))
+        gtb = np.zeros((B, 96, 8), np.float32)             # [x, y, z, dx, dy, dz, heading, class], 0 = padding
+        for b in range(B):
+            n = int(rs.integers(40, 90))
+            cls = rs.integers(1, 4, n)
+            gtb[b, :n, 0:2] = rs.uniform(-74, 74, (n, 2))
+            gtb[b, :n, 2] = rs.uniform(-1, 2, n)
+            gtb[b, :n, 3] = np.where(cls == 1, rs.uniform(3.5, 12, n), rs.uniform(0.5, 2.0, n))
+            gtb[b, :n, 4] = np.where(cls == 1, rs.uniform(1.6, 3.0, n), rs.uniform(0.4, 1.0, n))
+            gtb[b, :n, 5] = rs.uniform(1.0, 3.0, n)
+            gtb[b, :n, 6] = rs.uniform(-np.pi, np.pi, n)
+            gtb[b, :n, 7] = cls
+        gt_boxes = torch.from_numpy(gtb).to(dev)
+        if args.com:
+            # BASELINE config 3: CurriculumCenterHead_x5 (head_zoo.py:145-149) on the voxel backbone's stride-8 map, the
+            # LOSS_CURRICULUM of tools/cfgs/waymo_models/com/centercurriculum_pillar_3cls_b2_com.yaml:168-173 (UCL False,
+            # FIX True) unless --com-ucl; per-object attributes COMAug's dataloader provides, synthetic here
+            from com_amd.hotpath import com_head
+            W.com_cur = com_cur = dict(UCL=bool(args.com_ucl), THRESHOLD=0.2, ELONGATION=-10, HEIGHT=1, FIX=True)
+            head_loss = com_head.CurriculumCenterHeadLoss(dense2d.CENTERPOINT_HEAD['SEPARATE_HEAD_CFG']['HEAD_ORDER'],
+                                                          com_cur, conf_shape=(3, 96), cls_weight=1.0, loc_weight=2.0).to(dev)
+            valid = gtb[..., 7] > 0
+            com_npgt = torch.from_numpy(np.where(valid, rs.integers(1, 400, valid.shape), 0).astype(np.float32)).to(dev)
+            com_true = torch.from_numpy(np.where(valid, rs.choice([1, 1, 1, 2], valid.shape), 0).astype(np.float32)).to(dev)
+            com_occ = torch.from_numpy(np.where(valid, rs.random(valid.shape), 0).astype(np.float32)).to(dev)
+            com_facade = torch.from_numpy(np.where(valid, rs.integers(0, 4, valid.shape), 0).astype(np.float32)).to(dev)
+            com_epoch = 5
+        W.head_loss = head_loss
+
+    def model_func(model, bd):
+        """model_func of the reference's loop (pcdet/models/__init__.py:37-51): batch_dict -> loss.
+        MeanVFE -> VoxelResBackBone8x -> HeightCompression (-> BaseBEVBackbone -> CenterHead / COM head) -> loss"""
+        bd = model.map_to_bev_module(model.backbone_3d(model.vfe(bd)))
+        if ops.STAMPS is not None and bd["spatial_features"].requires_grad:
+            bd["spatial_features"].register_hook(lambda g: ops.stamp("dense_bwd_end"))
+        if args.dense_head:
+            # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, conv2d.hip kernels), then the REAL CenterHead step of the
+            # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
+            # and get_loss = focal(hm) + L1(boxes) (center_head.py:163-262) without its host round trips
+            preds = model.dense_head(model.backbone_2d(bd))["pred_dicts"]
+            ops.stamp("dense_fwd_end")
+            if args.com:
+                # CurriculumCenterHead.forward / get_loss (curriculum_center_head.py:461-487,313-358) on the device
+                group = com_head.cluster(gt_boxes, com_true, com_occ, com_facade)
+                tg = com_head.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
+                                             synth.WAYMO_VOXEL, 8, com_npgt, true_object=group, num_max_objs=500,
+                                             gaussian_overlap=0.1, min_radius=2, epoch=com_epoch, epoch_threshold=100,
+                                             min_points=0)
+                loss, _ = head_loss(preds, tg, epoch=com_epoch)
+            else:
+                tg = targets.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
+                                            synth.WAYMO_VOXEL, 8, num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
+                loss, _ = head_loss(preds, tg)
+        else:
+            # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense gradient)
+            loss = ops.LinearFunctionalLoss.apply(bd["spatial_features"], loss_w)
+        return loss
+
+    # voxel rows numbered by (b, y, x, z) -- z fastest, PCD_ROWS_YXZ: the same voxels as the reference's voxeliser (the caps are
+    # decided by first appearance), every level of the chain numbered the same way, the SubM layers through the window
+    # gather-GEMM; PCD_ROW_ORDER=key = (b, z, y, x) (torch.unique / spconv's sorted order), first = first-appearance ids
+    vox = train.VoxelizeConfig(synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS, synth.WAYMO_MAX_VOXELS,
+                               row_order=os.environ.get('PCD_ROW_ORDER', 'yxz'))
+    if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1:   # (the switches exercise the N > 1 form on one GPU)
+        form = "one_graph"
+    else:
+        form = "three_graph" if os.environ.get('PCD_N_GT_1_FORM', 'early') == '3graph' else "n_gt_1"
+    hook_at = os.environ.get('PCD_HOOK_AT', 'conv3')
+    W.step = train.CapturedStep(model, model_func, opt, vox, B, lr_scheduler=lr_scheduler, world=world, form=form,
+                                hook_at=None if hook_at == "units" else hook_at, after_update=after_update,
+                                options={"WGRAD_JOIN_LAG": int(os.environ.get('PCD_WGRAD_LAG', '32')),
+                                         "FUSE_BN_REDUCTIONS": os.environ.get('PCD_FUSE_BN', '1') != '0'})
+    return W
 
 
 def main():
@@ -798,210 +1055,10 @@ def main():
             port = sk.getsockname()[1]
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
-    B = args.batch
-    torch.manual_seed(666 + (0 if args.same_shard else rank))   # cf. tools/train.py:86-87
-    # frames sharded by rank with DistributedSampler striding (pcdet/datasets/__init__.py:65-72 ->
-    # com_amd.dist.shard_frames); `--distinct-batches` (16) global batches of DISTINCT full 160k-point frames cycle
-    # through the timed loop: voxel / row counts differ from step to step (M = 80..87 k per frame), the static
-    # capacities are sized from the warm-up steps only, and a denser batch would trip the overflow guard
-    n_batches = max(2, args.distinct_batches)
-    BEAMS = 120 if args.config5 else 64                       # 120 x 2500 = 300 000 points per frame (config 5)
-
-    def make_batches(drop=None):
-        out = []
-        for j in range(n_batches):
-            ids = cdist.shard_frames(j, 0, 1, B) if args.same_shard else cdist.shard_frames(j, rank, world, B)
-            frames = [synth.synth_cloud(f, BEAMS, 2500) for f in ids]
-            if drop is not None:                             # ragged variant: 0-20 % of every frame's rays are lost
-                frames = [f[:int(round(f.shape[0] * (1.0 - drop.uniform(0.0, 0.2))))] for f in frames]
-            pts, offs = hotpath.collate_points(frames, dev)  # resident in HBM before the timed region
-            out.append((pts, torch.tensor(offs, dtype=torch.int32, device=dev)))
-        return out
-
-    def pad_batches(bs, rows):
-        return [(torch.nn.functional.pad(p, (0, 0, 0, rows - p.shape[0])) if p.shape[0] < rows else p, o) for p, o in bs]
-
-    batches = make_batches()
-    # the static graph reads ONE point buffer: batches are padded to a common row count (offsets say what is real)
-    nmax = (max(p.shape[0] for p, _ in batches) + 1) // 2 * 2     # (even: whole 16-byte pieces for the in-graph host pull)
-    batches = pad_batches(batches, nmax)
-
-    from com_amd.spconv import functional as Fsp
-    # the side-stream weight-gradient chain is joined once, at the end of the backward pass (a lag >= the number of
-    # convs; lag 1 measured 0.5 % slower: every join is an edge that orders a main-chain kernel behind a weight gradient)
-    Fsp.WGRAD_JOIN_LAG = int(os.environ.get('PCD_WGRAD_LAG', '32'))
-    # voxel rows numbered by (b, y, x, z) -- z fastest, PCD_ROWS_YXZ: the same voxels as the reference's voxeliser (the caps are
-    # decided by first appearance), every level of the chain numbered the same way, the 64-channel SubM layers through the
-    # window gather-GEMM; PCD_ROW_ORDER=key = (b, z, y, x) (torch.unique / spconv's sorted order), first = first-appearance ids
-    ROW_ORDER = os.environ.get('PCD_ROW_ORDER', 'yxz')
-    Fsp.FUSE_BN_REDUCTIONS = os.environ.get('PCD_FUSE_BN', '1') != '0'   # BatchNorm sums taken in the conv epilogues
-    ops.WGRAD_OS = os.environ.get('PCD_WGRAD_OS', '1') != '0'            # output-stationary wgrad at 16 channels
-    Fsp.DIRECT_GRAD = True      # kernels write dW / dbias / dgamma / dbeta straight into the flat gradient bucket
-    model = HotPath(dense_head=args.dense_head, plain=args.config5).to(dev)
-    model.train()
-    if world > 1:                                            # what DDP does at construction (tools/train.py:165-166)
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
-    params = [p for p in model.parameters() if p.requires_grad]
-    if args.dense_head and os.environ.get('PCD_HEAD_BATCHED', '1') != '0':
-        # the head branches' first-stage parameters back to back in the flat buffers: their batched path (dense2d.py)
-        from com_amd.hotpath import dense2d as _d2
-        params = [p for p in _d2.batched_param_order(model) if p.requires_grad]
-    # all gradients live in ONE flat fp32 buffer: the per-step exchange is a single RCCL all-reduce (10.8 MB)
-    bucket = cdist.FlatGradBucket(params)
-    bucket.force_collective = rccl_world1
-    # ... and so do the parameters: clipping + Adam are two passes over the flat buffers (pcd_adam_flat_step_v2) with
-    # the reference's adam_onecycle rule: decoupled weight decay, betas (MOMS, 0.99), lr / momentum from the OneCycle
-    # schedule (tools/train_utils/optimization/__init__.py:19-32,53-56; centerpoint.yaml:81-96), GRAD_NORM_CLIP 10
-    flat_param = bucket.flatten_parameters()
-    total_iters = 30 * 1000                                  # schedule length only shapes lr(it) / mom(it)
-    lr0, mom0 = cdist.one_cycle(0, total_iters)
-    opt = cdist.FlatAdam(bucket, lr=lr0, betas=(mom0, 0.99), eps=1e-8, weight_decay=0.01, max_norm=10.0,
-                         world=world, decoupled=True)
-    it_count = [0]
-    # stand-in for the dense head when only the hot path is timed: loss = <spatial_features, fixed random tensor>
-    # (ops.LinearFunctionalLoss: pcd_dot_bf16 forward, pcd_scale_bf16 backward -- 2 + 1 HIP launches)
-    loss_w = (torch.randn(B * 256 * 188 * 188, device=dev) * 1e-3).to(torch.bfloat16)
-
-    last = {}
-    CLASS_NAMES = ['Vehicle', 'Pedestrian', 'Cyclist']
-    if args.dense_head:
-        from com_amd.hotpath import center_loss, dense2d, targets
-        # get_loss in four HIP launches per head (centerhead.hip); PCD_LOSS_TORCH=1: the elementwise torch chain
-        loss_cls = center_loss.CenterHeadLoss if os.environ.get('PCD_LOSS_TORCH') else center_loss.FusedCenterHeadLoss
-        head_loss = loss_cls(dense2d.CENTERPOINT_HEAD['SEPARATE_HEAD_CFG']['HEAD_ORDER'],
-                             cls_weight=1.0, loc_weight=2.0).to(dev)                        # centerpoint.yaml:52-58
-        from com_amd.hotpath import conv2d_fast
-        conv_packs = conv2d_fast.Conv3x3Packs(model)       # all dense 3x3 weight packs in one launch per step
-        rs = np.random.default_rng(1234 + (0 if args.same_shard else rank))
-        gtb = np.zeros((B, 96, 8), np.float32)             # [x, y, z, dx, dy, dz, heading, class], 0 = padding
-        for b in range(B):
-            n = int(rs.integers(40, 90))
-            cls = rs.integers(1, 4, n)
-            gtb[b, :n, 0:2] = rs.uniform(-74, 74, (n, 2))
-            gtb[b, :n, 2] = rs.uniform(-1, 2, n)
-            gtb[b, :n, 3] = np.where(cls == 1, rs.uniform(3.5, 12, n), rs.uniform(0.5, 2.0, n))
-            gtb[b, :n, 4] = np.where(cls == 1, rs.uniform(1.6, 3.0, n), rs.uniform(0.4, 1.0, n))
-            gtb[b, :n, 5] = rs.uniform(1.0, 3.0, n)
-            gtb[b, :n, 6] = rs.uniform(-np.pi, np.pi, n)
-            gtb[b, :n, 7] = cls
-        gt_boxes = torch.from_numpy(gtb).to(dev)
-        if args.com:
-            # BASELINE config 3: CurriculumCenterHead_x5 (head_zoo.py:145-149) on the voxel backbone's stride-8 map, the
-            # LOSS_CURRICULUM of tools/cfgs/waymo_models/com/centercurriculum_pillar_3cls_b2_com.yaml:168-173 (UCL False,
-            # FIX True) unless --com-ucl; per-object attributes COMAug's dataloader provides, synthetic here
-            from com_amd.hotpath import com_head
-            com_cur = dict(UCL=bool(args.com_ucl), THRESHOLD=0.2, ELONGATION=-10, HEIGHT=1, FIX=True)
-            head_loss = com_head.CurriculumCenterHeadLoss(dense2d.CENTERPOINT_HEAD['SEPARATE_HEAD_CFG']['HEAD_ORDER'],
-                                                          com_cur, conf_shape=(3, 96), cls_weight=1.0, loc_weight=2.0).to(dev)
-            valid = gtb[..., 7] > 0
-            com_npgt = torch.from_numpy(np.where(valid, rs.integers(1, 400, valid.shape), 0).astype(np.float32)).to(dev)
-            com_true = torch.from_numpy(np.where(valid, rs.choice([1, 1, 1, 2], valid.shape), 0).astype(np.float32)).to(dev)
-            com_occ = torch.from_numpy(np.where(valid, rs.random(valid.shape), 0).astype(np.float32)).to(dev)
-            com_facade = torch.from_numpy(np.where(valid, rs.integers(0, 4, valid.shape), 0).astype(np.float32)).to(dev)
-            com_epoch = 5
-
-    def voxelize(pts, offs, out=None):
-        """hard voxelisation + fused MeanVFE of one batch (what the reference's DataLoader workers do on the CPU)"""
-        bd = {"points": pts, "frame_offsets": offs, "batch_size": B}
-        bd = hotpath.transform_points_to_voxels(bd, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, synth.WAYMO_MAX_POINTS,
-                                                synth.WAYMO_MAX_VOXELS, fuse_mean=True, bf16_features=True,
-                                                out=out["_result"] if out is not None else None,
-                                                row_order=ROW_ORDER)
-        bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": B,
-               "_result": bd["voxelize_result"]}
-        if "voxel_num_rows" in bd:
-            bd2["voxel_num_rows"] = bd["voxel_num_rows"]
-        if "voxel_rank" in bd:
-            bd2["voxel_rank"] = bd["voxel_rank"]             # coordinate -> row map: level-1 SubM without a hash table
-        if not (ops.PLAN is not None and ops.PLAN.active):
-            last["voxels"] = sum(bd["voxel_counts"])
-            last["bd2"] = bd2
-        return bd2
-
-    VOX_EARLY = os.environ.get('PCD_VOX_EARLY', '1') != '0'      # one-graph form: see build_graphs
-
-    def train_from_voxels(bd2, ev=None):
-        """MeanVFE -> VoxelResBackBone8x -> HeightCompression -> loss -> backward (grads into the bucket)"""
-        bd = model.map_to_bev_module(model.backbone_3d(model.vfe(dict(bd2))))
-        if ops.STAMPS is not None and bd["spatial_features"].requires_grad:
-            bd["spatial_features"].register_hook(lambda g: ops.stamp("dense_bwd_end"))
-        if bd2.get("at_backward_start") is not None and bd["spatial_features"].requires_grad:
-            # (experiment PCD_VOX_AT=bwd: the next batch is voxelised beside the START of the backward pass)
-            hook_ = bd2["at_backward_start"]
-            bd["spatial_features"].register_hook(lambda g: (hook_(), None)[1])
-        if args.dense_head:
-            # BaseBEVBackbone + CenterHead towers (bf16 / channels_last, conv2d.hip kernels), then the REAL CenterHead step of the
-            # reference: target assignment for this batch's boxes (centerhead.hip, on the device, inside the graph)
-            # and get_loss = focal(hm) + L1(boxes) (center_head.py:163-262) without its host round trips
-            preds = model.dense_head(model.backbone_2d(bd))["pred_dicts"]
-            ops.stamp("dense_fwd_end")
-            if args.com:
-                # CurriculumCenterHead.forward / get_loss (curriculum_center_head.py:461-487,313-358) on the device
-                group = com_head.cluster(gt_boxes, com_true, com_occ, com_facade)
-                tg = com_head.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
-                                             synth.WAYMO_VOXEL, 8, com_npgt, true_object=group, num_max_objs=500,
-                                             gaussian_overlap=0.1, min_radius=2, epoch=com_epoch, epoch_threshold=100,
-                                             min_points=0)
-                loss, _ = head_loss(preds, tg, epoch=com_epoch)
-            else:
-                tg = targets.assign_targets(gt_boxes, (188, 188), CLASS_NAMES, [CLASS_NAMES], synth.WAYMO_RANGE,
-                                            synth.WAYMO_VOXEL, 8, num_max_objs=500, gaussian_overlap=0.1, min_radius=2)
-                loss, _ = head_loss(preds, tg)
-        else:
-            # stand-in for the dense head's loss: a fixed random projection of the BEV map (non-trivial dense gradient)
-            loss = ops.LinearFunctionalLoss.apply(bd["spatial_features"], loss_w)
-        ops.stamp("loss_end")
-        if ev is not None: ev("backward")
-        try:
-            loss.backward()
-        except BaseException:
-            Fsp.reset_deferred()                             # stale jobs hold pointers of the aborted step
-            raise
-        Fsp.join_deferred_wgrad()                            # side-stream wgrad pipeline -> back to this stream
-        ops.stamp("bwd_end")
-
-    def fwd_bwd(pts, offs, ev=None):
-        if ev is not None: ev("voxelize")
-        bd2 = voxelize(pts, offs)
-        if ev is not None: ev("forward")
-        train_from_voxels(bd2, ev)
-        return None
-
-    def opt_step():
-        # mean over the ranks + GRAD_NORM_CLIP 10 (centerpoint.yaml:96) + Adam, 2 launches; the Adam pass clears the gradient
-        # bucket as it consumes it (zero_grad for the NEXT step: no fill launch on the serial tail of the step)
-        opt.step(zero_grad=True)
-        if not os.environ.get('PCD_PACK_LATE'):
-            model.backbone_3d.pack_after_update()            # the next step's weight packs, off its critical path
-            if args.dense_head:
-                conv_packs.run()
-
-    # where the next batch's voxelisation may start inside the step's forward pass (backbone.after_rulebooks_at)
-    HOOK_AT = {"units": None}.get(os.environ.get('PCD_HOOK_AT', 'conv3'), os.environ.get('PCD_HOOK_AT', 'conv3'))
-    DEVICE_SCHEDULE = os.environ.get('PCD_DEVICE_SCHEDULE', '1') != '0'
-    if DEVICE_SCHEDULE:
-        # OneCycle as a device table indexed by the optimizer's own step counter (looked up inside the replayed graph):
-        # no 8-byte host -> device copy in front of every step
-        opt.set_schedule([cdist.one_cycle(i, total_iters) for i in range(total_iters)])
-
-    def schedule():
-        """lr / momentum of this iteration into the device-side pair the (replayed) optimizer kernel reads."""
-        if not DEVICE_SCHEDULE:
-            opt.set_hyper(*cdist.one_cycle(it_count[0], total_iters))
-        it_count[0] += 1
-
-    def eager_step(i, ev=None, source=None):
-        src = source or resident
-        pts, offs = src.get(i)
-        schedule()
-        fwd_bwd(pts, offs, ev)
-        src.release(i)
-        if ev is not None: ev("allreduce")
-        bucket.all_reduce_sum()                              # RCCL over xGMI (no-op at N = 1)
-        if ev is not None: ev("optimizer")
-        opt_step()
-        if ev is not None: ev("end")
+    W = build_workload(args, rank, world, dev, rccl_world1)
+    B, model, step, batches, resident, nmax = W.B, W.model, W.step, W.batches, W.resident, W.nmax
+    bucket, opt, flat_param, n_batches, make_batches, pad_batches = W.bucket, W.opt, W.flat_param, W.n_batches, W.make_batches, W.pad_batches
+    use_graph = args.mode == "graph"
 
     def sync():
         torch.cuda.synchronize()
@@ -1009,307 +1066,45 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    resident = ResidentSource(batches)
-    use_graph = args.mode == "graph"
-    plan = ops.StaticPlan()
-    ops.PLAN = plan
-    for i in range(max(args.warmup, 2)):                     # eager: also observes the data-dependent row counts
-        eager_step(i)
+    # eager warm-up steps: real training steps that also observe the data-dependent row counts for the step's plan
+    for i in range(max(args.warmup, 2)):
+        step.lr_scheduler.step()
+        step.eager(resident.get(i))
         if args.config5 and i == 0 and not os.environ.get('PCD_CONFIG5_BF16'):   # (the switch: same workload, bf16 forward)
             # calibrate on the first batch (amax of every conv input / weight -> static e4m3 scales), then every
             # sparse conv with >= 16 input channels runs its FORWARD in fp8 (backward: bf16, straight-through)
             from com_amd.spconv import fp8 as fp8mod
             with torch.no_grad():
-                scales = fp8mod.enable_fp8_training(model.backbone_3d, model.vfe(dict(last["bd2"])))
-            last["fp8_layers"] = len(scales)
+                bd0 = {k: v for k, v in step.last_voxel_batch.items() if k != "_result"}
+                scales = fp8mod.enable_fp8_training(model.backbone_3d, model.vfe(bd0))
+            W.fp8_layers = len(scales)
 
-    state = {}
-
-    def build_graphs(pull=None):
-        """Capture the step; returns run_step(i, source).  Called again with larger capacities after an overflow.
-        pull (a PullSource, one-graph form only): the graph itself fetches the next batch from pinned host memory."""
-        plan.active = True
-        plan.prepare(dev)                                    # the sticky flag lives outside the graphs' pools
-        s_pts = batches[0][0].clone()
-        s_offs8 = torch.zeros(8, dtype=torch.int32, device=dev)
-        s_offs8[:batches[0][1].numel()] = batches[0][1]
-        s_offs = s_offs8[:batches[0][1].numel()]             # (a view: the pull kernel writes the padded 32 bytes)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                fwd_bwd(s_pts, s_offs)
-                opt_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        plan.recorded.clear()
-        # N > 1: two graphs, voxelisation | forward+backward, then the all-reduce and clip+Adam (3 launches).  The
-        # voxelisation of batch i+1 is replayed on a second stream as soon as forward+backward of batch i has
-        # finished, i.e. beside the gradient all-reduce and the optimizer of step i (the reference voxelises in
-        # DataLoader workers, asynchronously to the training step); it owns its memory pool because it runs
-        # concurrently with the optimizer graph.  Every timed step still contains exactly one voxelisation.
-        vox_stream = torch.cuda.Stream()
-        if world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1:   # (the switches exercise the N > 1 form on one GPU)
-            # no gradient exchange: ONE graph per step -- forward+backward, then clip+Adam beside the
-            # voxelisation of the next batch (a forked branch that writes the very buffers the next replay reads
-            # first).  Two graph boundaries per step less than the N > 1 form.
-            vox_out = voxelize(s_pts, s_offs)
-            torch.cuda.synchronize()
-            shift = int(os.environ.get('PCD_GRAPH_STREAM_SHIFT', '0'))   # (experiment: streams created before the graph's own)
-            state["shift_streams"] = [torch.cuda.Stream() for _ in range(shift)]
-            for st_ in state["shift_streams"]:
-                with torch.cuda.stream(st_):
-                    torch.zeros(1, device=dev)
-            def capture_step():
-                g_all = torch.cuda.CUDAGraph()
-                pull_stream = torch.cuda.Stream() if pull is not None else None
-                # (PCD_GRAPH_PRIO=1, experiment: capture on a high-priority stream -- do the main chain's persistent kernels get
-                #  the CUs ahead of the side streams' workgroups?)
-                cap_stream = torch.cuda.Stream(priority=-1) if os.environ.get('PCD_GRAPH_PRIO') == '1' else None
-                with torch.cuda.graph(g_all, **({"stream": cap_stream} if cap_stream is not None else {})):
-                    cur = torch.cuda.current_stream()
-                    if pull is not None:                         # a branch of its own from the first node of the step
-                        pull_stream.wait_stream(cur)
-                        with torch.cuda.stream(pull_stream):
-                            pull.enqueue(s_pts, s_offs8)
-                    def voxelize_next():
-                        vox_stream.wait_stream(torch.cuda.current_stream())
-                        if pull is not None:
-                            vox_stream.wait_stream(pull_stream)
-                        with torch.cuda.stream(vox_stream):
-                            ops.stamp("vox_begin")
-                            vox_next = voxelize(s_pts, s_offs, out=vox_out)      # writes vox_out's own tensors
-                            assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                            ops.stamp("vox_end")
-
-                    if os.environ.get('PCD_VOX_AT') == 'bwd':
-                        bd_in = dict(vox_out)
-                        bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
-                        if "voxel_num_rows" in vox_out:
-                            bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
-                        bd_in["at_backward_start"] = voxelize_next
-                        train_from_voxels(bd_in)
-                    elif VOX_EARLY:
-                        # The next batch is voxelised in the MIDDLE of this step's forward pass, on the rulebook stream behind its
-                        # last unit (the last reader of the voxeliser's buffers; the stream is idle from there on), instead of after
-                        # the backward pass, where its 245 us were the tail of the step.  (On a stream of its own, forked there, the
-                        # graph executor serialised the conv chain behind the rulebook chain: 3.70 ms against 3.21.)  What the rest of the
-                        # step still needs of this batch is copied first: the row count and the (bf16, 8-channel) features that
-                        # conv_input's weight gradient reads at the very end.
-                        def early():                         # (called on the rulebook stream, behind its last unit)
-                            if pull is not None:
-                                torch.cuda.current_stream().wait_stream(pull_stream)
-                            ops.stamp("vox_begin")
-                            vox_next = voxelize(s_pts, s_offs, out=vox_out)
-                            assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                            ops.stamp("vox_end")
-                        bd_in = dict(vox_out)
-                        # (copies by KERNELS: a clone is a memcpy node, and a memcpy node at the head of the graph held the whole
-                        #  conv chain back behind the second rulebook unit)
-                        bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)
-                        if "voxel_num_rows" in vox_out:
-                            bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
-                        model.backbone_3d.after_rulebooks = early      # (documented hook of the backbone: backbone3d.py)
-                        # ... and not before the main chain has finished level 3: the voxeliser's kernels then run beside level 4,
-                        # whose 128-channel kernel occupies 137 of the 256 CUs and leaves room on the others, instead of beside
-                        # level 2 / 3, whose window kernels share a CU with almost nothing (DESIGN.md section 4.4): 3.025 -> 2.995 ms
-                        # over four alternations ("conv2": 3.033).  PCD_HOOK_AT=units: right behind the rulebook chain.
-                        model.backbone_3d.after_rulebooks_at = HOOK_AT
-                        try:
-                            train_from_voxels(bd_in)
-                        finally:
-                            model.backbone_3d.after_rulebooks = None
-                    else:
-                        train_from_voxels(vox_out)
-                        voxelize_next()
-                    opt_step()
-                    ops.stamp("opt_end")
-                    cur.wait_stream(vox_stream)
-                    plan.arm()                                   # sticky overflow check of every replay, inside the graph
-                    ops.stamp("step_end")
-                return g_all
-
-            # (PCD_GRAPH_TWIN=1, experiment: two instantiations of the same step, replayed alternately -- does the host enqueue
-            #  one while the other runs?)
-            graphs = [capture_step() for _ in range(2 if os.environ.get('PCD_GRAPH_TWIN') == '1' else 1)]
-            g_turn = [0]
-
-            class _Alt:
-                def replay(self_):
-                    graphs[g_turn[0] % len(graphs)].replay()
-                    g_turn[0] += 1
-            g_all = _Alt()
-
-            HT = state.setdefault("host_times", [0.0] * 5) if os.environ.get('PCD_BENCH_DEBUG') else None
-
-            def run_step_pull(i, source=None):
-                schedule()
-                g_all.replay()
-
-            def prime_pull(source):
-                # batch 0 by the same kernel, eagerly (counter 0 -> 1), voxelised into the graph's own buffers
-                source.counter.zero_()
-                source.enqueue(s_pts, s_offs8)
-                voxelize(s_pts, s_offs, out=vox_out)
-            if pull is not None:
-                state["prime"] = prime_pull
-                return run_step_pull
-
-            def run_step(i, source=resident):
-                if HT is not None:                           # where the launching thread's time goes (debug only)
-                    t = [time.perf_counter()]
-                    pts, offs = source.get(i + 1); t.append(time.perf_counter())
-                    schedule()
-                    s_pts.copy_(pts, non_blocking=True)
-                    s_offs.copy_(offs, non_blocking=True); t.append(time.perf_counter())
-                    source.release(i + 1); t.append(time.perf_counter())
-                    g_all.replay(); t.append(time.perf_counter())
-                    for q in range(4):
-                        HT[q] += t[q + 1] - t[q]
-                    HT[4] += 1
-                    return
-                pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
-                schedule()
-                s_pts.copy_(pts, non_blocking=True)          # device -> device
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(i + 1)
-                g_all.replay()
-
-            def prime(source):
-                # the first replay trains on whatever vox_out holds: voxelise batch 0 of THIS loop's source into it (eager
-                # launches into the graph's own buffers), so that every loop -- and every execution form -- sees the
-                # batches in the same order 0, 1, 2, ...
-                pts, offs = source.get(0)
-                s_pts.copy_(pts, non_blocking=True)
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(0)
-                voxelize(s_pts, s_offs, out=vox_out)
-            state["prime"] = prime
-        elif os.environ.get('PCD_N_GT_1_FORM', 'early') != '3graph':
-            # N > 1 (default): ONE graph for forward + backward with the next batch voxelised mid-forward on the rulebook
-            # stream -- exactly the body of the one-graph form -- then the gradient all-reduce (RCCL, a plain call: no
-            # collective is captured) and clip + Adam as plain launches.  Against the three-graph form below: one graph launch
-            # less per step, and the voxelisation sits where the one-graph form has it instead of behind the backward pass.
-            vox_out = voxelize(s_pts, s_offs)
-            torch.cuda.synchronize()
-            g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb):
-                def early():                                 # (called on the rulebook stream, behind its last unit)
-                    vox_next = voxelize(s_pts, s_offs, out=vox_out)
-                    assert vox_next["voxel_features"].data_ptr() == vox_out["voxel_features"].data_ptr()
-                bd_in = dict(vox_out)
-                bd_in["voxel_features"] = torch.mul(vox_out["voxel_features"], 1)      # (copies by kernels: see the one-graph form)
-                if "voxel_num_rows" in vox_out:
-                    bd_in["voxel_num_rows"] = torch.add(vox_out["voxel_num_rows"], 0)
-                model.backbone_3d.after_rulebooks = early
-                model.backbone_3d.after_rulebooks_at = HOOK_AT       # (see the one-graph form)
-                try:
-                    train_from_voxels(bd_in)
-                finally:
-                    model.backbone_3d.after_rulebooks = None
-                plan.arm()
-
-            def run_step(i, source=resident):
-                pts, offs = source.get(i + 1)                # the batch this replay voxelises for the next one
-                schedule()
-                s_pts.copy_(pts, non_blocking=True)          # device -> device
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(i + 1)
-                g_fb.replay()
-                bucket.all_reduce_sum()                      # RCCL over xGMI
-                opt_step()                                   # three plain launches: cheaper than a graph replay
-
-            def prime(source):
-                pts, offs = source.get(0)
-                s_pts.copy_(pts, non_blocking=True)
-                s_offs.copy_(offs, non_blocking=True)
-                source.release(0)
-                voxelize(s_pts, s_offs, out=vox_out)
-            state["prime"] = prime
+    def timed_loop(steps, source, pull=False):
+        """(elapsed seconds, host-issue seconds) of `steps` steps bracketed by barrier + synchronize: the loop is
+        com_amd.train.train_one_epoch -- the reference's loop body (train_utils.py:78-95) over the step object."""
+        if pull:
+            step.prime(None)
+            feed = _Repeat(None)
         else:
-            g_vox, g_fb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_vox):
-                vox_out = voxelize(s_pts, s_offs)
-            with torch.cuda.graph(g_fb):
-                train_from_voxels(vox_out)
-                plan.arm()
-            ev_vox, ev_fb = torch.cuda.Event(), torch.cuda.Event()
+            step.prime(source.get(0), staged=lambda: source.release(0))
+            feed = _SourceFeed(source)
+        gc.collect()                                         # (tens of milliseconds: outside the timed region)
+        sync()
+        t0 = time.perf_counter()
+        train.train_one_epoch(step, feed, steps, accumulated_iter=step.lr_scheduler.last_iter + 1, on_staged=feed.staged,
+                              gc_collect=False)
+        host_issue = time.perf_counter() - t0
+        sync()
+        return time.perf_counter() - t0, host_issue
 
-            def prefetch_voxels(i, source):
-                with torch.cuda.stream(vox_stream):
-                    vox_stream.wait_event(ev_fb)             # the previous forward+backward still reads vox_out
-                    pts, offs = source.get(i)
-                    s_pts.copy_(pts, non_blocking=True)      # device -> device
-                    s_offs.copy_(offs, non_blocking=True)
-                    source.release(i)
-                    g_vox.replay()
-                    ev_vox.record(vox_stream)
-
-            def run_step(i, source=resident):
-                cur = torch.cuda.current_stream()
-                schedule()
-                cur.wait_event(ev_vox)                       # voxels of batch i
-                g_fb.replay()
-                ev_fb.record(cur)
-                prefetch_voxels(i + 1, source)
-                bucket.all_reduce_sum()
-                opt_step()                                   # three plain launches: cheaper than a graph replay
-
-            def prime(source):
-                ev_fb.record(torch.cuda.current_stream())
-                prefetch_voxels(0, source)
-            state["prime"] = prime
-        return run_step
-
-    def timed_loop(run_step, steps, source, graph):
-        """(elapsed seconds, host-issue seconds) of `steps` steps bracketed by barrier + synchronize."""
-        import gc
-        if graph:
-            state["prime"](source)
-        # (the issuing thread must not pause: a collection of the cyclic garbage collector in the middle of the loop -- tens of
-        #  milliseconds with torch's object graphs alive -- starves the device queue; one run in eight was 5-8 % slow at 60 steps)
-        gc.collect()
-        gc_was = gc.isenabled()
-        gc.disable()
-        try:
-            sync()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                run_step(i, source=source)
-                if graph and (i & 7) == 7 and plan.poll():       # sticky device-side flag, read without stalling
-                    raise ops.L.PcdError("static capacity overflow during the timed loop")
-            host_issue = time.perf_counter() - t0
-            sync()
-            return time.perf_counter() - t0, host_issue
-        finally:
-            if gc_was:
-                gc.enable()
-
-    run_step = eager_step
-    recaptures = [0]
     if use_graph:
         try:
-            for attempt in range(3):
-                run_step = build_graphs()
-                state["prime"](resident)
-                for i in range(2):
-                    run_step(i)
-                torch.cuda.synchronize()
-                if not plan.poll(wait=True):
-                    break
-                # a batch denser than the observed ones: larger capacities, capture again (the truncated step's
-                # parameters were never used for a measurement)
-                print("[bench] static capacity overflow: re-capturing with larger buffers", file=sys.stderr)
-                recaptures[0] += 1
-                plan.active = False
-                plan.grow(1.5)
-            plan.check()
+            step.capture(batches[0], validate=batches[:3])
         except Exception as exc:                             # never lose the measurement: fall back to eager
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             use_graph = False
-            plan.active = False
+            step.release()
             torch.cuda.synchronize()
-            run_step = eager_step
 
     if os.environ.get('PCD_STAMPS'):
         # time points inside the replayed graph (device clock, 100 MHz), averaged over the timed steps
@@ -1318,18 +1113,19 @@ def main():
         if os.environ.get('PCD_STAMPS') == 'few':
             ops.STAMPS["only"] = {"fwd_begin", "conv1", "conv2", "conv3", "conv4", "loss_end", "bwd_end", "step_end"}
         if use_graph:
-            run_step = build_graphs()
-            state["prime"](resident)
+            step.release()
+            step.capture(batches[0])                         # (again: the stamp kernels are nodes of the graph)
+        step.prime(resident.get(0))
         acc = None
         for i in range(10):
-            run_step(i)
+            step(resident.get(i + 1))
             torch.cuda.synchronize()
             v = ops.STAMPS["buf"].cpu().numpy().astype(np.float64)[:len(ops.STAMPS["names"])]
             if i >= 2:
                 d = (v - v[0]) / 100.0
                 acc = d if acc is None else acc + d
         print("[stamps us] " + "  ".join(f"{n}={a / 8:.0f}" for n, a in zip(ops.STAMPS["names"], acc)), file=sys.stderr)
-    elapsed, host_issue = timed_loop(run_step, args.steps, resident, use_graph)
+    elapsed, host_issue = timed_loop(args.steps, resident)
     if os.environ.get('PCD_BENCH_DEBUG'):
         print(f"[bench] host issue {1e3 * host_issue / max(args.steps, 1):.3f} ms/step, "
               f"wall {1e3 * elapsed / max(args.steps, 1):.3f} ms/step", file=sys.stderr)
@@ -1337,8 +1133,7 @@ def main():
     elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     fps = world * B * args.steps / elapsed
-    if use_graph:
-        plan.check()                                         # no replay exceeded a capacity (sticky flag + last counts)
+    step.check()                                             # no replay exceeded a capacity (sticky flag + last counts)
     rank_ms = [local_ms]
     if world > 1:
         t = torch.tensor([local_ms], dtype=torch.float64, device=dev)
@@ -1359,16 +1154,17 @@ def main():
     h2d = None
     if not args.no_h2d:
         try:
-            one_graph = use_graph and world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1
+            one_graph = use_graph and step.form == "one_graph"
             h2d_form = "copy stream"
             trial_ms = []
-            if one_graph and os.environ.get('PCD_H2D_PULL'):
+            pulled = bool(one_graph and os.environ.get('PCD_H2D_PULL'))
+            if pulled:
                 # (opt-in) the step's own graph pulls the next batch from pinned host memory (PullSource): no copy stream, no
                 # events, nothing bimodal -- but the hipGraph executor runs the extra branch IN SERIES with the step (it keeps
                 # two branches concurrent, and the step already has two everywhere): + 0.33 ms = the PCIe time of 15.4 MB
                 src = PullSource(batches, dev)
-                keep_prime = state["prime"]
-                run_h2d = build_graphs(pull=src)
+                step.release()
+                step.capture(batches[0], pull=src)
                 h2d_form = "pulled by a kernel of the step's graph"
             else:
                 # Which hardware queue the copy stream shares with the replayed graph's internal streams decides between
@@ -1381,25 +1177,20 @@ def main():
                 for st_ in cands if len(cands) > 1 else []:
                     trial = H2DSource(batches, dev, stream=st_, host=host)
                     host = trial.host
-                    t_el, _ = timed_loop(run_step, 8, trial, use_graph)
+                    t_el, _ = timed_loop(8, trial)
                     trial.close()
                     trial_ms.append(round(1e3 * t_el / 8, 3))
                     if best[0] is None or t_el < best[0]:
                         best = (t_el, st_)
                 src = H2DSource(batches, dev, stream=best[1], host=host)
-                run_h2d = run_step
                 if trial_ms:
                     h2d_form = f"copy stream (best of {len(cands)} candidate streams, 8-step trials: {trial_ms} ms/step)"
-            if state.get("host_times"):
-                state["host_times"][:] = [0.0] * 5               # (debug split: this loop only)
-            el, h2d_host = timed_loop(run_h2d, args.steps, src, use_graph)
-            if isinstance(src, PullSource):
-                state["prime"] = keep_prime
+            el, h2d_host = timed_loop(args.steps, src, pull=pulled)
+            if pulled:
+                step.check()
+                step.release()
+                step.capture(batches[0])                     # the resident form again for the loops below
                 src.close = lambda: None
-            if os.environ.get('PCD_BENCH_DEBUG') and state.get("host_times"):
-                ht = state["host_times"]
-                print("[bench] launching thread in the h2d loop, ms per step: get %.3f  d2d copies %.3f  release %.3f  "
-                      "graph replay %.3f" % tuple(1e3 * v / max(ht[4], 1) for v in ht[:4]), file=sys.stderr)
             if os.environ.get('PCD_BENCH_DEBUG') and src.copy_events:
                 torch.cuda.synchronize()
                 cms = sorted(a.elapsed_time(b) for a, b in src.copy_events)
@@ -1418,8 +1209,7 @@ def main():
                    "what": "same timed loop, points of every batch arriving from PINNED HOST memory inside the step (15.4 MB "
                            "/ step / GPU) on a copy stream two batches ahead, overlapped with compute; `value` above is the "
                            "HBM-resident figure the contract asks for"}
-            if use_graph:
-                plan.check()
+            step.check()
         except Exception as exc:
             print(f"[bench] H2D-inclusive loop failed ({type(exc).__name__}: {exc})", file=sys.stderr)
             torch.cuda.synchronize()
@@ -1434,15 +1224,11 @@ def main():
             el = None
             for attempt in range(3):
                 try:
-                    el, _ = timed_loop(run_step, args.steps, rsrc, use_graph)
-                    if use_graph:
-                        plan.check()
+                    el, _ = timed_loop(args.steps, rsrc)
+                    step.check()
                     break
                 except ops.L.PcdError:
-                    recaptures[0] += 1
-                    plan.active = False
-                    plan.grow(1.5)
-                    run_step = build_graphs()
+                    step.recapture()
             if el is not None:
                 el = cdist.max_over_ranks(el, dev)
                 real = [int(o[-1].item()) for _, o in rb]
@@ -1458,16 +1244,16 @@ def main():
     if args.com:
         # COM's per-epoch exchange (train_utils.py:269-287): all_gather of the (3, 96) epoch sums -> what COMAug's sampler gets
         torch.cuda.synchronize()
-        st_ = head_loss.hm_loss_func
+        st_ = W.head_loss.hm_loss_func
         conf = cdist.gather_group_confidence(st_.epoch_confidence, st_.epoch_num)
-        com_report = {"head": "CurriculumCenterHead_x5 (conf_shape (3, 96)), LOSS_CURRICULUM " + json.dumps(com_cur),
+        com_report = {"head": "CurriculumCenterHead_x5 (conf_shape (3, 96)), LOSS_CURRICULUM " + json.dumps(W.com_cur),
                       "groups_seen": int((st_.epoch_num > 0).sum().item()),
                       "objects_counted": float(st_.epoch_num.sum().item()),
                       "avg_confidence_ema": round(st_.avg_confidence, 6),
                       "confidence_groups_mean": round(float(conf[conf > 0].mean()) if (conf > 0).any() else 0.0, 6),
                       "epoch_gather": "all_gather of 2 x (3, 96) float32 over " + ("RCCL" if world > 1 else "1 rank (no process group)")}
-    if use_graph:
-        plan.active = False                                  # the instrumented steps below run eagerly
+    execution = step.describe()
+    step.release()                                           # the instrumented steps below run eagerly
 
     if args.stage_times:
         marks = []
@@ -1477,7 +1263,7 @@ def main():
             e.record()
             marks.append((name, e, time.perf_counter()))
 
-        eager_step(0, rec)
+        step.eager(resident.get(0), rec)
         torch.cuda.synchronize()
         for (n0, e0, h0), (n1, e1, h1) in zip(marks[:-1], marks[1:]) if rank == 0 else []:
             print(f"[stage] {n0:10s} gpu {e0.elapsed_time(e1):8.3f} ms   host {1e3 * (h1 - h0):8.3f} ms", file=sys.stderr)
@@ -1494,14 +1280,14 @@ def main():
                                "HeightCompression fwd+bwd -> grad all-reduce -> clip -> Adam), Waymo-shaped 160k-pt "
                                "synthetic clouds, 64 beams x 2500 az, grid (41,1504,1504)",
                    "frames_per_gpu": B, "global_batch": B * world, "points_per_frame": 160000,
-                   "voxels_per_frame": int(last.get("voxels", 0) / B), "parallelism": f"dp{world}",
+                   "voxels_per_frame": int(step.last_voxels / B), "parallelism": f"dp{world}",
                    "optimizer": "adam_onecycle (decoupled wd 0.01, betas (OneCycle MOMS, 0.99), clip 10)",
                    "bev_layout": ("channels_last storage of spatial_features [B, C*D, H, W] (MAP_TO_BEV.CHANNELS_LAST)"
                                   if (args.dense_head or os.environ.get("PCD_BEV_NHWC", "1") != "0") else "NCHW-contiguous"),
                    "dense_head": bool(args.dense_head), "com_head": bool(args.com),
-                   "distinct_batches": n_batches, "recaptures": recaptures[0],
-                   "execution": (("hipGraph replay (one graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream, then clip+Adam)" if os.environ.get('PCD_VOX_EARLY', '1') != '0' else "hipGraph replay (one graph: fwd+bwd, then clip+Adam beside the voxelisation of the next batch)") if (world == 1 and not os.environ.get('PCD_FORCE_3GRAPH') and not rccl_world1) else ("hipGraph replay (voxelise [prefetched one batch ahead] | fwd+bwd), all-reduce, clip+Adam" if os.environ.get('PCD_N_GT_1_FORM', 'early') == '3graph' else "hipGraph replay (ONE graph: fwd+bwd with the next batch voxelised mid-forward on the rulebook stream), all-reduce, clip+Adam as plain launches")) + ", device-side row counts, sticky overflow guard"
-                                if use_graph else "eager launches"},
+                   "distinct_batches": n_batches, "recaptures": step.recaptures,
+                   "execution": execution,
+                   "step_object": "com_amd.train.CapturedStep driven by com_amd.train.train_one_epoch"},
     }
     if h2d is not None:
         result["h2d_inclusive"] = h2d
@@ -1512,7 +1298,7 @@ def main():
     if args.config5:
         result["config"]["workload"] = ("SECOND / VoxelNet hot path (hard voxelize+MeanVFE -> VoxelBackBone8x fwd+bwd -> "
                                         "HeightCompression fwd+bwd -> clip -> Adam), fp8 (e4m3) FORWARD convs on "
-                                        f"{last.get('fp8_layers', 0)} layers, bf16 backward, 300k-pt synthetic clouds "
+                                        f"{getattr(W, 'fp8_layers', 0)} layers, bf16 backward, 300k-pt synthetic clouds "
                                         "(120 beams x 2500 az), MAX_NUMBER_OF_VOXELS 150000 per frame")
         result["config"]["points_per_frame"] = 300000
         result["dtype"] = "fp8 forward (e4m3, fp32 accumulate) / bf16 backward"
@@ -1523,13 +1309,15 @@ def main():
                                         + "), Waymo-shaped 160k-pt synthetic clouds")
 
     if not args.no_roofline:
-        roof = measure_roofline(lambda: eager_step(0), ms_per_step)   # every rank runs the extra step (collectives inside)
+        roof = measure_roofline(lambda: step.eager(resident.get(0)), ms_per_step)   # every rank runs the extra step (collectives inside)
         if rank == 0:
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_regime and not args.no_roofline and not args.dense_head and not args.config5 \
             and result.get("roofline"):
         torch.cuda.synchronize()
         result["roofline"]["rulebook"] = measure_regime()
+    if rank == 0 and world == 1 and not args.no_seam_path and use_graph and not args.dense_head and not args.config5:
+        result["seam_path"] = measure_seam_path(W, fps, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = measure_cpu_baseline()
     if rank == 0 and world == 1 and not args.no_stage2 and not args.dense_head and not args.config5:

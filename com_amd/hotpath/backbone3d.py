@@ -196,7 +196,9 @@ class _BackboneBase(nn.Module):
     prefetch_rulebooks = True
     # Optional callable, run ONCE per forward on the rulebook stream right behind its last unit -- the point from which nothing
     # issued later reads the voxeliser's outputs (level-1 coordinates, coordinate -> row map): a caller that recycles those
-    # buffers (bench.py voxelises the NEXT batch into them, inside the captured step) continues there.  None: nothing runs.
+    # buffers (com_amd.train.CapturedStep voxelises the NEXT batch into them, inside the captured step) continues there.
+    # Preferred form: per forward, batch_dict['after_rulebooks_hook'] (+ 'after_rulebooks_at'); this attribute is the
+    # fallback when the batch_dict carries none.  None: nothing runs.
     after_rulebooks = None
     # None: the hook runs right behind the last rulebook unit; "conv2" / "conv3" / "conv4": additionally not before the main
     # chain has finished that level (the hook's kernels then run beside the levels after it)
@@ -303,9 +305,15 @@ class _BackboneBase(nn.Module):
         ops.stamp("fwd_begin")
         if ops.STAMPS is not None:
             ops.STAMPS["conv_seq"] = 0
-        if self.after_rulebooks is not None:
-            x0.indice_dict["__after_units__"] = self.after_rulebooks
-            x0.indice_dict["__after_units_at__"] = self.after_rulebooks_at
+        # the hook of THIS forward: batch_dict['after_rulebooks_hook'] (+ optional 'after_rulebooks_at'), per call -- what
+        # com_amd.train.CapturedStep passes; the module attributes below are the fallback for callers that set them once
+        hook = batch_dict.pop('after_rulebooks_hook', None)
+        hook_at = batch_dict.pop('after_rulebooks_at', self.after_rulebooks_at)
+        if hook is None:
+            hook, hook_at = self.after_rulebooks, self.after_rulebooks_at
+        if hook is not None:
+            x0.indice_dict["__after_units__"] = hook
+            x0.indice_dict["__after_units_at__"] = hook_at
         self._prefetch_rulebooks(x0)
         x = self.conv_input(x0)
         ops.stamp("conv_input")

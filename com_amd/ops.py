@@ -105,6 +105,15 @@ class StaticPlan:
         self._host_flag = None
         self._poll_event = None
 
+    def __enter__(self):
+        _PLAN_SCOPE.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        assert _PLAN_SCOPE and _PLAN_SCOPE[-1] is self, "StaticPlan scopes must nest"
+        _PLAN_SCOPE.pop()
+        return False
+
     def observe(self, key, n):
         self.caps[key] = max(self.caps.get(key, 0), int(n))
 
@@ -187,7 +196,15 @@ class StaticPlan:
         return True
 
 
-PLAN = None  # set by the caller (bench.py / tests) to enable observation / static execution
+# The plan in force is SCOPED, not global: `with plan:` (StaticPlan.__enter__) pushes it for the calls made inside the block --
+# eager observation steps and the capture itself -- and pops it on exit; a replayed graph consults nothing.  The object that
+# captures a step (com_amd.train.CapturedStep) owns its plan; two step objects in one process do not see each other's.
+_PLAN_SCOPE = []
+
+
+def current_plan():
+    """The StaticPlan of the innermost enclosing `with plan:` block, or None."""
+    return _PLAN_SCOPE[-1] if _PLAN_SCOPE else None
 
 
 def pow2_ge8(c):
@@ -223,6 +240,7 @@ def voxelize_hard(points, frame_offsets, point_cloud_range, voxel_size, max_poin
     `rank`, the coordinate -> row map (RankMap) the level-1 SubM rulebook is built from -- laid out for a grid of
     `key_depth` z planes (0 = gz; the 3D backbones' sparse_shape has gz + 1).  "yxz" = the same with the rows numbered
     by ascending (b, y, x, z) -- z fastest, PCD_ROWS_YXZ: the order the window gather-GEMM wants."""
+    PLAN = current_plan()
     assert row_order in ("first", "key", "yxz")
     keyed = row_order in ("key", "yxz")
     _require_cuda(points)
@@ -612,6 +630,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     ascending (b, y, x, z)); the input rows may come in any order.
     `in_rank`: the ColumnMap of the INPUT level (rows in ROWS_YXZ order): the build then derives the output level's map from
     it (pcd_rulebook_conv_cm_*: no map over the output volume, no atomics) -- same outputs; rb.rank is the output's map."""
+    PLAN = current_plan()
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -718,6 +737,7 @@ CLS_TILE = 256
 
 def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank, out_shape):
     """rulebook_conv through the column maps (None: geometry outside what pcd_rulebook_conv_cm_* covers)."""
+    PLAN = current_plan()
     lib = L.lib()
     dev = indices.device
     n = indices.shape[0]

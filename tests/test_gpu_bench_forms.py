@@ -28,7 +28,7 @@ def _bench(tmp_path, tag, args, env=None):
     e.update(env or {})
     dump = tmp_path / f"{tag}.json"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "2",
-           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--distinct-batches", "3",
+           "--no-cpu-baseline", "--no-roofline", "--no-h2d", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-seam-path", "--no-n-gt-1", "--distinct-batches", "3",
            "--same-shard", "--dump-state", str(dump)] + args
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -112,7 +112,7 @@ def test_h2d_inclusive_leg_runs_in_both_forms(tmp_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCD_H2D_PULL"):
         e.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "2", "--no-cpu-baseline",
-           "--no-roofline", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--distinct-batches", "3", "--gpus", "1"]
+           "--no-roofline", "--no-ragged", "--no-full-model", "--no-stage2", "--no-fp8", "--no-seam-path", "--no-n-gt-1", "--distinct-batches", "3", "--gpus", "1"]
     for env, form in (({"PCD_H2D_CANDIDATES": "2"}, "copy stream"), ({"PCD_H2D_PULL": "1"}, "pulled by a kernel")):
         r = subprocess.run(cmd, env={**e, **env}, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]

@@ -11,6 +11,8 @@ import torch
 
 from com_amd.utils import synth
 from oracle import oracle as O
+import contextlib
+_plan_scope = contextlib.ExitStack()      # `with plan:` scopes opened / closed around try blocks (com_amd.ops.current_plan)
 
 pytestmark = pytest.mark.gpu
 
@@ -150,11 +152,11 @@ def test_static_capacities_device_counts_overflow_and_spine(pcd_option):
             plan = ops.StaticPlan()
             plan.observe(("conv", lvl), m)
             plan.active = True
-            ops.PLAN = plan
+            _plan_scope.close(); _plan_scope.enter_context(plan)
             try:
                 rb, _ = _check_conv_cm(idx, 1, shape, geo, cmap, n_dev=n_dev, n_real=n_real, plan_key=("conv", lvl))
             finally:
-                ops.PLAN = None
+                _plan_scope.close()
             assert rb.n_out > m and int(rb.n_out_dev.item()) == m
             (perm, vstart, vcap), (perm_r, vstart_r, vcap_r) = rb.classes, ref.classes
             assert vcap == vcap_r and torch.equal(vstart, vstart_r) and torch.equal(perm, perm_r)
@@ -167,14 +169,14 @@ def test_static_capacities_device_counts_overflow_and_spine(pcd_option):
                 plan = ops.StaticPlan(margin=1.0, round_to=1)
                 plan.observe(("conv", lvl), m // 2)
                 plan.active = True
-                ops.PLAN = plan
+                _plan_scope.close(); _plan_scope.enter_context(plan)
                 try:
                     guard = torch.full((1 << 16,), 0x5A, dtype=torch.uint8, device=DEV)
                     small = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], n_dev=n_dev, order=ops.ROWS_YXZ,
                                               in_rank=cmap, plan_key=("conv", lvl))
                     guard2 = torch.full((1 << 16,), 0x5A, dtype=torch.uint8, device=DEV)
                 finally:
-                    ops.PLAN = None
+                    _plan_scope.close()
                 half = small.n_out
                 assert m // 2 <= half < m and int(small.n_out_dev.item()) == m
                 assert torch.equal(small.out_indices, ref.out_indices[:half])

@@ -28,6 +28,8 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import g7_params as P7  # noqa: E402
+import contextlib
+_plan_scope = contextlib.ExitStack()      # `with plan:` scopes opened / closed around try blocks (com_amd.ops.current_plan)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -281,7 +283,7 @@ def test_g7_static_plan_and_hipgraph_replay(golden):
     pts, offs = _inputs(g)
     proj = torch.from_numpy(P7.loss_projection(P7.BATCH * 256 * 12 * 12)).to(DEV).view(P7.BATCH, 256, 12, 12)
     plan = ops.StaticPlan(margin=1.25, round_to=256)
-    ops.PLAN = plan
+    _plan_scope.close(); _plan_scope.enter_context(plan)
     try:
         _step(net, bev, pts, offs, proj)                   # eager: observes the counts
         plan.active = True
@@ -317,7 +319,7 @@ def test_g7_static_plan_and_hipgraph_replay(golden):
         rep = _check_against_g7(g, net, bd, sf.detach(), loss.detach(), n_real=True)
         print("G7 hipGraph replay: ", rep)
     finally:
-        ops.PLAN = None
+        _plan_scope.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@ import torch
 
 from com_amd.utils import synth
 from oracle import oracle as O
+import contextlib
+_plan_scope = contextlib.ExitStack()      # `with plan:` scopes opened / closed around try blocks (com_amd.ops.current_plan)
 
 pytestmark = pytest.mark.gpu
 
@@ -356,12 +358,12 @@ def test_strided_build_in_one_call_equals_the_two_phase_build():
         plan = ops.StaticPlan()
         plan.observe(("conv", lvl), ref.n_out)
         plan.active = True
-        ops.PLAN = plan
+        _plan_scope.close(); _plan_scope.enter_context(plan)
         try:
             rb = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], pad_pairs=True, n_dev=n_dev,
                                    plan_key=("conv", lvl))
         finally:
-            ops.PLAN = None
+            _plan_scope.close()
         m = ref.n_out
         assert rb.n_out >= m and int(rb.n_out_dev.item()) == m and rb.out_shape == ref.out_shape
         assert torch.equal(rb.out_indices[:m], ref.out_indices)
@@ -379,11 +381,11 @@ def test_strided_build_in_one_call_equals_the_two_phase_build():
         plan = ops.StaticPlan(margin=1.0, round_to=1)
         plan.observe(("conv", lvl), m // 2)
         plan.active = True
-        ops.PLAN = plan
+        _plan_scope.close(); _plan_scope.enter_context(plan)
         try:
             small = ops.rulebook_conv(idx, 1, shape, geo["k"], geo["s"], geo["p"], n_dev=n_dev, plan_key=("conv", lvl))
         finally:
-            ops.PLAN = None
+            _plan_scope.close()
         assert int(small.n_out_dev.item()) == m and small.n_out == m // 2 + 1
         assert torch.equal(small.out_indices, ref.out_indices[:small.n_out])
         keep = ref.nbr_in[:, :n_real].clone()
