@@ -8,15 +8,69 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend="nccl", device=None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run."""
+def init_from_env(backend="nccl", device=None, timeout_s=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run.  `timeout_s`: the process group's
+    collective timeout (torch's RCCL watchdog tears the rank down when a collective exceeds it)."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
+        if timeout_s is not None:
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend, **kw)
     return rank, local_rank, world
+
+
+class Watchdog:
+    """A deadline for a phase of a rank that must not hang a multi-GPU job (rendezvous + communicator set-up + the FIRST
+    all-reduce; the whole run): a daemon thread that, unless `disarm()` came first, prints what timed out and ends THIS
+    process with exit code 124 -- `os._exit`, no clean-up, because a rank stuck inside an RCCL call cannot unwind.  The
+    launcher (launch_local_ranks) sees the non-zero code and stops the other ranks; under torch.distributed.run the agent
+    does.  Nothing is exec'ed and no other process is signalled."""
+
+    def __init__(self, seconds, what, _exit=None):
+        import threading
+        self.what, self.seconds = what, float(seconds)
+        self._done = threading.Event()
+        self._exit = _exit or os._exit
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        import sys
+        if not self._done.wait(self.seconds):
+            print(f"[com_amd.dist] rank {os.environ.get('RANK', '0')}: {self.what} exceeded {self.seconds:.0f} s -- "
+                  f"exiting with code 124", file=sys.stderr, flush=True)
+            self._exit(124)
+
+    def disarm(self):
+        self._done.set()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.disarm()
+        return False
+
+
+def first_all_reduce(device="cpu", timeout_s=120.0):
+    """The first collective of a job under a Watchdog: communicator creation is lazy, so THIS is where a bad fabric /
+    a missing peer shows.  Returns the sum of the ranks' (rank + 1) -- every rank checks it."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 1.0
+    with Watchdog(timeout_s, "the first all-reduce (communicator set-up)"):
+        t = torch.tensor([float(dist.get_rank() + 1)], dtype=torch.float32, device=device)
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        got = float(t.item())
+    world = dist.get_world_size()
+    if got != world * (world + 1) / 2:
+        raise RuntimeError(f"first all-reduce returned {got}, expected {world * (world + 1) / 2}")
+    return got
 
 
 def shard_frames(step, rank, world, frames_per_gpu):

@@ -130,6 +130,62 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert res["slowest"] == 2.0                                   # MAX over ranks
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_plumbing_over_gloo():
+    """The 8-rank job the driver launches, as far as a CPU can take it: 8 ranks started by bench.py itself, rendezvous and the
+    first all-reduce under their watchdogs, DistributedSampler striding over 8 ranks, the REAL exchange of a step (the 10.78 MB
+    flat gradient bucket of VoxelResBackBone8x summed over 8 ranks), max-over-ranks timing, one result line."""
+    rc, res, err = _run_bench(["--gpus", "8", "--selftest-launch", "--batch", "4"], timeout=540)
+    assert rc == 0, err[-3000:]
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["allreduce_sum"] == 36.0
+    assert res["frames"] == [[r + 8 * j for j in range(4)] for r in range(8)]   # rank r: r, r + 8, r + 16, r + 24
+    assert sorted(f for fr in res["frames"] for f in fr) == list(range(32))     # disjoint cover of the global batch
+    assert res["slowest"] == 8.0                                                 # MAX over ranks
+    assert res["bucket_sum_ok"] and 10.7 < res["bucket_MB"] < 10.9
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_that_never_joins_the_first_all_reduce_cannot_hang_the_job():
+    """One of four ranks never arrives at the first collective: the other ranks' watchdogs end them with code 124 after
+    --init-timeout, the launcher stops the straggler, `python bench.py --gpus 4` returns non-zero -- in seconds, not after the
+    driver's whole budget."""
+    import time
+    t0 = time.time()
+    rc, res, err = _run_bench(["--gpus", "4", "--selftest-launch", "--selftest-hang", "2", "--init-timeout", "8",
+                               "--launch-timeout", "120"], timeout=240)
+    took = time.time() - t0
+    assert rc == 1 and res is None, err[-2000:]
+    assert "exceeded 8 s -- exiting with code 124" in err and "ranks failed" in err
+    assert took < 100, took
+
+
+@pytest.mark.timeout(120)
+def test_launcher_deadline_stops_ranks_that_never_finish(tmp_path):
+    import sys
+    import time
+    from com_amd import dist as cdist
+    script = tmp_path / "sleeper.py"
+    script.write_text("import time\ntime.sleep(600)\n")
+    t0 = time.time()
+    codes = cdist.launch_local_ranks(3, [sys.executable, str(script)], timeout=3)
+    assert time.time() - t0 < 30 and all(c != 0 for c in codes)
+
+
+def test_watchdog_fires_once_and_can_be_disarmed():
+    import time
+    from com_amd import dist as cdist
+    fired = []
+    w = cdist.Watchdog(0.2, "unit test phase", _exit=fired.append)
+    time.sleep(0.6)
+    assert fired == [124]
+    fired2 = []
+    with cdist.Watchdog(0.3, "disarmed phase", _exit=fired2.append):
+        pass
+    time.sleep(0.6)
+    assert fired2 == []
+    assert cdist.first_all_reduce() == 1.0                     # no process group: nothing to wait for
+
+
 @pytest.mark.timeout(120)
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     rc, res, err = _run_bench(["--gpus", "2", "--selftest-launch"], env={"WORLD_SIZE": "3", "RANK": "0"})
