@@ -10,6 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpcdops_hip.so")
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "lib_experiments", "libpcdops_hip.so")     # `make -C com_amd/csrc EXPERIMENTS=1`
 CSRC = os.path.join(_HERE, "csrc")
 
 PCD_F32 = 0
@@ -67,7 +68,6 @@ PROTOTYPES = {
     "pcd_subm_window_wgrad_splits": (_i, []),
     "pcd_sparse_conv_subm_window_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_subm_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "pcd_sparse_conv_subm_window_bn": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "pcd_sparse_conv_subm_window_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_rank_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
@@ -88,10 +88,6 @@ PROTOTYPES = {
                                        _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_conv_cm_build": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
                                         _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
-    "pcd_sparse_conv_pairs_seg_bytes": (_sz, [_i, _i]),
-    "pcd_sparse_conv_pairs_seg": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "pcd_sparse_conv_pairs_tiles": (_i, [_i, _i, _i, _i]),
-    "pcd_sparse_conv_pairs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "pcd_conv_out_shape": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_rulebook_conv_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i]),
     "pcd_rulebook_conv_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
@@ -122,8 +118,6 @@ PROTOTYPES = {
     "pcd_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pcd_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "pcd_sparse_conv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
-                                         _vp]),
-    "pcd_sparse_conv_gather_gemm_zfast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
                                          _vp]),
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -255,6 +249,17 @@ class PcdComCurriculum(ctypes.Structure):
                 ("conf_classes", ctypes.c_int), ("conf_groups", ctypes.c_int)]
 
 
+# include/pcd_ops_experiments.h: present only in a library built with `make EXPERIMENTS=1` (measured-slower kernels kept for
+# reproduction); bound when exported, never required
+EXPERIMENT_PROTOTYPES = {
+    "pcd_sparse_conv_pairs_seg_bytes": (_sz, [_i, _i]),
+    "pcd_sparse_conv_pairs_seg": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "pcd_sparse_conv_pairs_tiles": (_i, [_i, _i, _i, _i]),
+    "pcd_sparse_conv_pairs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "pcd_sparse_conv_gather_gemm_zfast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp,
+                                         _vp]),
+}
+
 PCD_COM_CLUSTER_X5 = 0
 
 
@@ -263,14 +268,6 @@ class PcdBnReduce(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("x", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p),
                 ("partial_rows", ctypes.c_int), ("mid", ctypes.c_void_p), ("counters", ctypes.c_void_p)]
-
-
-class PcdBnFold(ctypes.Structure):
-    """include/pcd_ops.h: struct PcdBnFold (the BatchNorm behind a window conv, applied by the conv launch)."""
-    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
-                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("save_mean", ctypes.c_void_p),
-                ("save_invstd", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("relu", ctypes.c_int),
-                ("out", ctypes.c_void_p), ("sync", ctypes.c_void_p)]
 
 
 def build(force=False):
@@ -298,10 +295,37 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in EXPERIMENT_PROTOTYPES.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         # (tuning options are set through set_option -- bench.py / tools/ forward PCD_OPT_<KEY> environment variables with
         #  tools/env_switches.py; neither this module nor the library reads the environment)
         _lib = handle
     return _lib
+
+
+def use_experiments_library():
+    """Tools that reproduce the measured-slower kernels (tools/exp_ggwin.py, tools/exp_pconv.py): load the EXPERIMENTS build
+    instead of the default library -- call it before the first op of the process."""
+    global LIB_PATH
+    if _lib is not None:
+        raise PcdError("use_experiments_library() must come before the first call into the library")
+    if not os.path.exists(EXPERIMENTS_LIB_PATH):
+        raise PcdError(f"{EXPERIMENTS_LIB_PATH} not found: make -C com_amd/csrc EXPERIMENTS=1")
+    LIB_PATH = EXPERIMENTS_LIB_PATH
+
+
+_has_experiments = None
+
+
+def has_experiments():
+    """True if the loaded library exports the entry points of include/pcd_ops_experiments.h."""
+    global _has_experiments
+    if _has_experiments is None:
+        _has_experiments = all(hasattr(lib(), name) for name in EXPERIMENT_PROTOTYPES)
+    return _has_experiments
 
 
 def set_option(key, value):

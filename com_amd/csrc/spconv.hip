@@ -876,541 +876,9 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
     return PCD_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// 128 -> 128 SubM 3x3x3 over z-fastest rows (PCD_ROWS_YXZ): ggw_kernel's weight stream + the WINDOWS of spconv_win.hip for x.
-// ggw_kernel gathers 27 operand slots per output row -- 2160 one-KiB DMA instructions per 192-row workgroup through the
-// CU's one texture-address unit (24 us of a 48-us launch with gathers, weights and MFMAs all switched off) of which 1296 are
-// gather slots, 45 % of them zero fills for missing neighbours.  In (b, y, x, z) order the nine offsets with the same dy read
-// ONE contiguous run of input rows (tools/exp_win_stats.py: 1.1-1.6 x the tile), so here a run's rows reach LDS once, as
-// whole rows by contiguous DMA (RWIN = 320 rows = 40 instructions per (run, channel half)), and the consumers pick their
-// operand rows out of the window by LDS address: row = nbr - run_lo (the rulebook tile is in LDS anyway); offsets are
-// processed run by run, one 64-channel half at a time, so that two 36-KiB window buffers suffice beside the weight ring.
-// Per stage and loader: ~1 window + 4 weight instructions (ggw: 6 + 4): 1100 per workgroup.  A run longer than the window
-// (any row numbering is legal input) takes further passes over ITS nine offsets with the next RWIN rows -- operands outside
-// the current chunk read the zero row -- slower (a third of a tile's time per extra chunk), rare, exact.  fp32 sums in another order than gather_gemm_kernel / ggw_kernel
-// (offsets grouped by run): equal to them within one bf16 ulp, not bit for bit.
-constexpr int GGWIN_RWIN = 320;   // 1.67 x the 192-row tile (level 4 of the Waymo-shaped frames: median 202, p99 272, max 291)
-constexpr int GGWIN_Z0 = 8;       // rows of zeros in front of each window buffer: LDS row 0 = "no operand"
-
-template <int NB, int MI, bool OUT_BF16>
-__global__ __launch_bounds__(512, 1) void ggwin_kernel(
-    const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ nbr, int nbr_stride, int flip, int n_out_cap, const int32_t *__restrict__ n_out_dev,
-    void *__restrict__ yv, unsigned x_bytes, unsigned w_bytes, const void *__restrict__ addend, BnRed bn) {
-    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
-    constexpr int K = 27, ROWS = 64 * MI, ROWB = 256, R = 3;
-    constexpr int WFR = 2 * NB, WPW = WFR / 4, W_STAGE = WFR * 1024;
-    constexpr int RWIN = GGWIN_RWIN, Z0 = GGWIN_Z0, WBUF = (Z0 + RWIN) * 128, NWI = RWIN / 8;   // 36 window instructions
-    constexpr int c_out = NB * 16, THREADS = 512;
-    static_assert(NWI == 40 && WPW == 4, "window instructions per loader: 3 in stage 0, 1 in stages 1-7");
-    const int n_out = eff_rows(n_out_dev, n_out_cap);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *wring = smem;                                    // [R][W_STAGE]
-    char *win = smem + R * W_STAGE;                        // [2][WBUF]
-    int *nbr_s = (int *)(win + 2 * WBUF);                  // [K][ROWS]
-    int *meta = nbr_s + K * ROWS;                          // lo[3], hi[3]; + 64 bytes: 1 KiB of scratch (dummy DMA target)
-    float *red_s = (float *)(meta + 16 + 256);             // [4][2][c_out], only with bn.mode
-
-    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;
-    const int lane = threadIdx.x & 63;
-    const int rl = lane & 15, g4 = lane >> 4;
-    const int tile = xcd_tile(n_out, ROWS);
-    const int r0wg = tile * ROWS;
-    if (r0wg >= n_out) {
-        if (bn.mode) bnred_zero_row(bn, tile, c_out);
-        return;
-    }
-    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)nbr, 0, (int)((unsigned)K * (unsigned)nbr_stride * 4u), 0x00020000);
-    if (threadIdx.x < 6) meta[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -1;
-    for (int e = threadIdx.x; e < 2 * Z0 * 128 / 16; e += THREADS)       // the zero rows of both window buffers
-        *reinterpret_cast<uint4 *>(win + (e / (Z0 * 8)) * WBUF + (e % (Z0 * 8)) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    {   // rulebook tile -> LDS (k-major), and the bounds of the three runs
-        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-        for (int base = threadIdx.x; base < K * ROWS; base += 4 * THREADS) {
-            int v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * THREADS;
-                const int k = idx / ROWS, r = idx - k * ROWS;
-                const int row = r0wg + r;
-                const int krow = flip ? (K - 1 - k) : k;
-                const bool ok = idx < K * ROWS && row < n_out;
-                const unsigned off = ok ? ((unsigned)krow * (unsigned)nbr_stride + (unsigned)row) * 4u : 0xFFFFFFF0u;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
-                if (!ok) v[u] = -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * THREADS;
-                if (idx < K * ROWS) {
-                    nbr_s[idx] = v[u];
-                    const int gq = ((idx / ROWS) / 3) % 3;
-                    if (v[u] >= 0) {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            if (gq == q) {
-                                lo[q] = min(lo[q], v[u]);
-                                hi[q] = max(hi[q], v[u]);
-                            }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                lo[q] = min(lo[q], __shfl_xor(lo[q], d, 64));
-                hi[q] = max(hi[q], __shfl_xor(hi[q], d, 64));
-            }
-            if (lane == 0) {
-                atomicMin(&meta[q], lo[q]);
-                atomicMax(&meta[3 + q], hi[q]);
-            }
-        }
-    }
-    __syncthreads();      // (no DMA in flight yet: a plain barrier)
-    int rlo[3], rcnt[3], cend[3];                          // cend[q]: chunks (of RWIN rows) of runs 0 .. q
-    {
-        int chunks = 0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int l = __builtin_amdgcn_readfirstlane(meta[q]), h = __builtin_amdgcn_readfirstlane(meta[3 + q]);
-            rcnt[q] = h >= 0 ? h - l + 1 : 0;
-            rlo[q] = h >= 0 ? l : 0;
-            chunks += max(1, (rcnt[q] + RWIN - 1) / RWIN);
-            cend[q] = chunks;
-        }
-    }
-    const int NWIN = cend[2] * 2;                          // windows: (run, chunk, channel half), 9 stages each; 6 when every run fits
-    // window wi -> run q, first row of its chunk, rows left in the run from there
-    auto win_of = [&](int wi, int &q, int &first, int &left) {
-        const int ci = wi >> 1;
-        q = ci < cend[0] ? 0 : ci < cend[1] ? 1 : 2;
-        const int pc = ci - (q == 0 ? 0 : q == 1 ? cend[0] : cend[1]);
-        const int lo = q == 0 ? rlo[0] : q == 1 ? rlo[1] : rlo[2], cnt = q == 0 ? rcnt[0] : q == 1 ? rcnt[1] : rcnt[2];
-        first = lo + pc * RWIN;
-        left = cnt - pc * RWIN;
-    };
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)w_bytes, 0x00020000);
-    const int wrow0 = wave * (MI * 16);
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-
-    if (loader) {
-        __builtin_amdgcn_s_setprio(3);
-        // window instruction i of window wi: rows 8 i + (lane >> 3) of the run chunk, whole 128-byte half rows, piece
-        // (lane & 7) ^ swizzle(LDS row) -- the reader looks at piece ^ swizzle (ggw_kernel's source-side swizzle)
-        auto fire_window = [&](int wi, int i) {
-            int q, first, left;
-            win_of(wi, q, first, left);
-            const int h = wi & 1;
-            const int w = 8 * i + (lane >> 3);
-            // (LDS row Z0 + w: the reader's swizzle is ((row >> 1) & 7))
-            const unsigned piece = (unsigned)(lane & 7) ^ (((unsigned)(Z0 + 8 * i) / 2u + (unsigned)(lane >> 4)) & 7u);
-            const unsigned off = (wi < NWIN && w < left)
-                                     ? (unsigned)(first + w) * (unsigned)ROWB + (unsigned)h * 128u + piece * 16u
-                                     : 0xFFFFFFF0u;
-            glds16(xrsrc, win + (wi & 1) * WBUF + (Z0 + 8 * i) * 128, off);
-        };
-        auto fire_weights = [&](int wi, int j, auto slot_tag) {
-            constexpr int SLOT = decltype(slot_tag)::value;
-            int q, first, left;
-            win_of(wi, q, first, left);
-            const int h = wi & 1;
-            const int k = (j / 3) * 9 + q * 3 + (j % 3);
-            const unsigned stage = (unsigned)(k * 2 + h);
-#pragma unroll
-            for (int f = 0; f < WPW; ++f) {
-                const int frag = wave + 4 * f;
-                const unsigned off = wi < NWIN ? stage * (unsigned)W_STAGE + (unsigned)lane * 16u + (unsigned)frag * 1024u : 0xFFFFFFF0u;
-                glds16(wrsrc, wring + SLOT * W_STAGE + frag * 1024, off);
-            }
-        };
-        // Every fire = the four weight instructions of the stage two ahead, THEN window instructions of the NEXT window (two in
-        // the first stage of a window -- three --, one in stages 1-7, a dummy in stage 8: 40 in all); every wait = vmcnt(5): all but the
-        // youngest fire have landed -- the stage about to be published, and every window instruction but the youngest, which
-        // gets two stages of latency.  (The window instruction in FRONT of the weights with vmcnt(4) made every stage wait
-        // for a load issued one stage earlier: 65 us.)  The dummy keeps the count uniform: the last real window instruction
-        // (stage 7) is older than the youngest fire when the next window's first stage is published.
-        auto fire_dummy = [&]() { glds16(xrsrc, (char *)meta + 64, 0xFFFFFFF0u); };      // (zeros into 1 KiB of scratch)
-        for (int i = wave; i < NWI; i += 4) fire_window(0, i);
-        fire_weights(0, 0, S0{});
-        fire_weights(0, 1, S1{});
-        fire_dummy();
-#define GGWIN_LOADER_STEP(J, SLOT_TAG)                                                         \
-    do {                                                                                       \
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                       \
-        __builtin_amdgcn_s_barrier();                                                          \
-        fire_weights((J) + 2 < 9 ? wi : wi + 1, ((J) + 2) % 9, SLOT_TAG);                      \
-        if ((J) == 0) {                                                                        \
-            fire_window(wi + 1, wave);                                                         \
-            fire_window(wi + 1, 4 + wave);                                                     \
-            fire_window(wi + 1, 8 + wave);                                                     \
-        } else if ((J) < 8) {                                                                  \
-            fire_window(wi + 1, 8 + (J) * 4 + wave);                                           \
-        } else {                                                                               \
-            fire_dummy();                                                                      \
-        }                                                                                      \
-    } while (0)
-        for (int wi = 0; wi < NWIN; ++wi) {
-            GGWIN_LOADER_STEP(0, S2{});
-            GGWIN_LOADER_STEP(1, S0{});
-            GGWIN_LOADER_STEP(2, S1{});
-            GGWIN_LOADER_STEP(3, S2{});
-            GGWIN_LOADER_STEP(4, S0{});
-            GGWIN_LOADER_STEP(5, S1{});
-            GGWIN_LOADER_STEP(6, S2{});
-            GGWIN_LOADER_STEP(7, S0{});
-            GGWIN_LOADER_STEP(8, S1{});
-        }
-#undef GGWIN_LOADER_STEP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        f32x4 none[MI][NB];
-        int norows[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) norows[mi] = -1;
-        gg_epilogue<MI, NB, OUT_BF16>(none, norows, c_out, 0, g4, rl, wave, tile, bias, addend, yv, bn, red_s, true);
-        return;
-    }
-
-    // ----------------------------------------------------------------------------------------------- consumer
-    f32x4 acc[MI][NB];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // LDS rows of this lane's MI operand rows at stage (wi, j): Z0 + (nbr - chunk start), 0 = the zero row
-    auto rho_of = [&](int wi, int j, int (&rho)[MI]) -> bool {
-        bool any = false;
-        int q, first, left;
-        win_of(wi, q, first, left);
-        const int k = (j / 3) * 9 + q * 3 + (j % 3);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int i = wi < NWIN ? nbr_s[k * ROWS + wrow0 + mi * 16 + rl] : -1;
-            const unsigned rel = (unsigned)(i - first);
-            const bool ok = i >= 0 && rel < (unsigned)RWIN;
-            rho[mi] = ok ? Z0 + (int)rel : 0;
-            any = any || ok;
-        }
-        return __builtin_amdgcn_ballot_w64(any) != 0ull;
-    };
-    auto compute = [&](auto slot_tag, int wi, const int (&rho)[MI], bool valid) {
-        constexpr int SLOT = decltype(slot_tag)::value;
-        if (!valid) return;
-        const char *wb = wring + SLOT * W_STAGE;
-        const char *ab = win + (wi & 1) * WBUF;
-        bf16x8 xa[2][MI], bw[2][NB];
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                xa[cs][mi] = *reinterpret_cast<const bf16x8 *>(
-                    ab + rho[mi] * 128 + (((unsigned)(cs * 4 + g4) ^ (unsigned)((rho[mi] >> 1) & 7)) << 4));
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                bw[cs][nb] = *reinterpret_cast<const bf16x8 *>(wb + ((cs * NB + nb) * 64 + lane) * 16);
-        }
-#pragma unroll
-        for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[cs][nb], xa[cs][mi], acc[mi][nb], 0, 0, 0);
-    };
-    int rho_c[MI], rho_n[MI];
-    bool vcur = rho_of(0, 0, rho_c);
-#define GGWIN_CONSUMER_STEP(J, SLOT_TAG)                                                                   \
-    do {                                                                                                   \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
-        __builtin_amdgcn_s_barrier();                                                                      \
-        const bool vnext = rho_of((J) + 1 < 9 ? wi : wi + 1, ((J) + 1) % 9, rho_n);                        \
-        compute(SLOT_TAG, wi, rho_c, vcur);                                                                \
-        vcur = vnext;                                                                                      \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) rho_c[mi] = rho_n[mi];                           \
-    } while (0)
-    for (int wi = 0; wi < NWIN; ++wi) {
-        GGWIN_CONSUMER_STEP(0, S0{});
-        GGWIN_CONSUMER_STEP(1, S1{});
-        GGWIN_CONSUMER_STEP(2, S2{});
-        GGWIN_CONSUMER_STEP(3, S0{});
-        GGWIN_CONSUMER_STEP(4, S1{});
-        GGWIN_CONSUMER_STEP(5, S2{});
-        GGWIN_CONSUMER_STEP(6, S0{});
-        GGWIN_CONSUMER_STEP(7, S1{});
-        GGWIN_CONSUMER_STEP(8, S2{});
-    }
-#undef GGWIN_CONSUMER_STEP
-
-    int rows[MI];
-    const int tile_row = wrow0 + rl;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = r0wg + tile_row + mi * 16;
-        rows[mi] = row < n_out ? row : -1;
-    }
-    gg_epilogue<MI, NB, OUT_BF16>(acc, rows, c_out, 0, g4, rl, wave, tile, bias, addend, yv, bn, red_s);
-}
-
-template <int NB, int MI>
-static int launch_ggwin(const void *x, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride, int flip,
-                        int n_out, const int32_t *n_out_dev, void *y, int y_dtype, unsigned x_bytes, unsigned w_bytes,
-                        hipStream_t st, const void *addend, const PcdBnReduce *bnr) {
-    constexpr int ROWS = 64 * MI;
-    const int grid = pcd_div_up(pcd_div_up(n_out, ROWS), 8) * 8;      // (= launch_ggw<NB, 2, MI, 3>'s: same BatchNorm partial rows)
-    BnRed bn;
-    if (int rc = make_bnred(bnr, y_dtype, NB * 16, grid, &bn)) return rc;
-    const size_t lds = (size_t)3 * (2 * NB * 1024) + (size_t)2 * (GGWIN_Z0 + GGWIN_RWIN) * 128 + (size_t)27 * ROWS * sizeof(int) +
-                       (16 + 256) * sizeof(int) + (bn.mode ? (size_t)8 * NB * 16 * sizeof(float) : 0);
-    if (lds > 160 * 1024) return PCD_ERR_UNSUPPORTED;
-    auto kb = ggwin_kernel<NB, MI, true>;
-    auto kf = ggwin_kernel<NB, MI, false>;
-    static size_t raised[2] = {0, 0};
-    const int which = y_dtype == PCD_BF16 ? 0 : 1;
-    if (raised[which] < lds) {
-        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return PCD_ERR_LAUNCH;
-        raised[which] = lds;
-    }
-    if (y_dtype == PCD_BF16)
-        kb<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out, n_out_dev, y,
-                                   x_bytes, w_bytes, addend, bn);
-    else
-        kf<<<grid, 512, lds, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride, flip, n_out, n_out_dev, y,
-                                   x_bytes, w_bytes, addend, bn);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Strided convs of the narrow levels, PAIR-DRIVEN (round 5).  The output-stationary kernels above visit all 27 offsets of
-// every output row although a stride-2 conv pairs an output row with 4.5 inputs on average (level 2): 27 gather slots per
-// row, five of them live.  In z-fastest order the indice pairs of one offset are sorted by input row AND by output row
-// (both follow (b, y, x, z), and for a fixed offset the map input -> output is monotone), so the pairs that end in a tile of
-// 64 consecutive stationary rows -- output rows for the forward, input rows for the data gradient -- are ONE contiguous
-// segment of every offset's list, found once per rulebook (pconv_seg_kernel: K x tiles binary searches).  A wave owns 64
-// stationary rows and their fp32 accumulators in LDS; it walks its segments in chunks of 16 pairs: pair indices (coalesced),
-// the 16 moving rows (one gather per PAIR, not per slot), one MFMA per 16-channel output block with the offset's weight
-// fragment (all 27 resident in LDS: 27 KB at 16 <-> 32 channels), and a read-modify-write of the 16 distinct accumulator rows
-// (rows of a chunk are distinct, chunks are sequential in the wave: no atomics, a fixed summation order).  Groups of four
-// chunks are software-pipelined: indices two groups ahead, gathers one group ahead.  Same epilogue as the gather kernels
-// (bias, addend, one rounding, BatchNorm sums).  Sums in another order than gather_gemm_kernel: equal within one bf16 ulp.
-constexpr int PC_ROWS = 64;            // stationary rows per wave
-constexpr int PC_GROUP = 4;            // chunks of 16 pairs per pipeline stage
-
-// seg[k][t] = first pair of offset k whose stationary row is >= 64 t  (t = 0 .. ntiles: the last column = pair_num[k])
-__global__ __launch_bounds__(256) void pconv_seg_kernel(const int32_t *__restrict__ pairs, int pair_stride,
-                                                        const int32_t *__restrict__ pair_num, int K, int stat_col, int ntiles,
-                                                        int32_t *__restrict__ seg) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= K * (ntiles + 1)) return;
-    const int k = e / (ntiles + 1), t = e - k * (ntiles + 1);
-    const int32_t *col = pairs + ((size_t)k * 2 + stat_col) * pair_stride;
-    const int pn = min(pair_num[k], pair_stride);
-    const int target = t * PC_ROWS;
-    int lo = 0, hi = pn;                                   // first index with col[i] >= target
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (col[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    seg[e] = lo;
-}
-
-template <int CK, int NBO, bool OUT_BF16>   // CK: contraction width (moving rows' channels: 16 or 32); NBO: 16-channel output blocks
-__global__ __launch_bounds__(256) void pconv_kernel(
-    const unsigned short *__restrict__ x, unsigned x_bytes, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-    const int32_t *__restrict__ pairs, int pair_stride, const int32_t *__restrict__ seg, int ntiles, int stat_col,
-    int n_stat_cap, const int32_t *__restrict__ n_stat_dev, void *__restrict__ yv, const void *__restrict__ addend, BnRed bn) {
-    __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);
-    constexpr int K = 27, c_out = NBO * 16;
-    constexpr int FRAGB = CK == 16 ? 8 : 16;               // bytes of an A fragment per lane
-    constexpr int ASTR = c_out * 4 + 16;                   // accumulator row stride (+16: rows spread over the banks)
-    constexpr int NLIST = K * (PC_ROWS / 16) + PC_GROUP;   // chunk descriptors per wave
-    const int n_stat = eff_rows(n_stat_dev, n_stat_cap);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *wlds = smem;                                     // [K][NBO][64] fragments
-    char *accb = wlds + K * NBO * 64 * FRAGB;              // [4 waves][PC_ROWS][ASTR]
-    int2 *list = (int2 *)(accb + 4 * PC_ROWS * ASTR);      // [4 waves][NLIST] {k | n << 8, first pair}
-    float *red_s = (float *)(list + 4 * NLIST);            // [4][2][c_out], only with bn.mode
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rl = lane & 15, g = lane >> 4;
-    const int tile = xcd_tile(n_stat, 4 * PC_ROWS);
-    const int r0wg = tile * 4 * PC_ROWS;
-    if (r0wg >= n_stat) {
-        if (bn.mode) bnred_zero_row(bn, tile, c_out);
-        return;
-    }
-    // weights -> LDS in A-fragment order.  The generic pack (pack_weight modes 0 / 1) holds, per 32-wide contraction step s,
-    // fragments of 8 values per lane: CK = 32 (one offset per step): used as they are; CK = 16 (two offsets per step, lanes
-    // 0-31 the even one): fragment (k, nb, lane (m, g')) = values 4 (g' & 1) .. + 3 of source lane (k & 1) 32 + (g' >> 1) 16 + m
-    if (CK == 32) {
-        for (int e = threadIdx.x; e < K * NBO * 64; e += 256) reinterpret_cast<uint4 *>(wlds)[e] = wp[e];
-    } else {
-        for (int e = threadIdx.x; e < K * NBO * 64; e += 256) {
-            const int ln = e & 63, nb = (e >> 6) % NBO, k = e / (64 * NBO);
-            const int m = ln & 15, gq = ln >> 4;
-            const uint4 v = wp[((size_t)(k >> 1) * NBO + nb) * 64 + (k & 1) * 32 + (gq >> 1) * 16 + m];
-            reinterpret_cast<uint2 *>(wlds)[e] = (gq & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
-        }
-    }
-    char *acc = accb + wave * (PC_ROWS * ASTR);
-    for (int e = lane; e < PC_ROWS * ASTR / 16; e += 64) reinterpret_cast<uint4 *>(acc)[e] = make_uint4(0u, 0u, 0u, 0u);
-    // this wave's tile and its chunk list: lane k holds the segment of offset k
-    const int t = tile * 4 + wave;
-    int2 *mylist = list + wave * NLIST;
-    int nch_total = 0;
-    {
-        int s0 = 0, s1 = 0;
-        if (lane < K && t < ntiles) {
-            s0 = seg[(size_t)lane * (ntiles + 1) + t];
-            s1 = seg[(size_t)lane * (ntiles + 1) + t + 1];
-        }
-        const int cnt = s1 - s0, nch = (cnt + 15) >> 4;
-        const int inc = wave_inclusive_scan(nch);
-        nch_total = __shfl(inc, 63);
-        int at = inc - nch;
-        for (int c = 0; c < nch; ++c) mylist[at + c] = make_int2(lane | (min(16, cnt - 16 * c) << 8), s0 + 16 * c);
-        for (int e = lane; e < PC_GROUP; e += 64) mylist[nch_total + e] = make_int2(0, 0);      // (padding chunks: no pairs)
-    }
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
-    const int32_t *mov_col = pairs + (size_t)(1 - stat_col) * pair_stride;      // + k * 2 * pair_stride
-    const int32_t *sta_col = pairs + (size_t)stat_col * pair_stride;
-    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-    struct Grp {                       // one pipeline stage: PC_GROUP chunks
-        int st[PC_GROUP];              // local stationary row of this lane's pair, -1 = no pair
-        int kk[PC_GROUP];
-        u32x4 op[PC_GROUP];            // the moving row's slice (CK = 16: 8 bytes in .x .y)
-    };
-    int mv_n[PC_GROUP], st_n[PC_GROUP], kk_n[PC_GROUP];
-    auto load_idx = [&](int grp) {     // pair indices of group `grp` (beyond the list: padding chunks)
-#pragma unroll
-        for (int c = 0; c < PC_GROUP; ++c) {
-            const int ci = grp * PC_GROUP + c;
-            const int2 d = mylist[ci < nch_total ? ci : nch_total];
-            const int k = d.x & 255, n = d.x >> 8;
-            kk_n[c] = k;
-            const bool ok = rl < n;
-            const size_t at = (size_t)k * 2 * pair_stride + d.y + rl;
-            mv_n[c] = ok ? mov_col[at] : -1;
-            st_n[c] = ok ? sta_col[at] - (r0wg + wave * PC_ROWS) : -1;
-        }
-    };
-    auto gather = [&](Grp &G) {        // from the indices just loaded
-#pragma unroll
-        for (int c = 0; c < PC_GROUP; ++c) {
-            G.st[c] = st_n[c];
-            G.kk[c] = kk_n[c];
-            const unsigned off = mv_n[c] >= 0 ? (unsigned)mv_n[c] * (unsigned)(CK * 2) + (unsigned)g * (CK == 16 ? 8u : 16u) : 0xFFFFFFF0u;
-            if (CK == 16) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0);
-                G.op[c] = (u32x4){v[0], v[1], 0u, 0u};
-            } else {
-                G.op[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-            }
-        }
-    };
-    auto compute = [&](const Grp &G) {
-#pragma unroll
-        for (int c = 0; c < PC_GROUP; ++c) {
-            const bool any = __builtin_amdgcn_ballot_w64(G.st[c] >= 0) != 0ull;
-            if (!any) continue;
-#pragma unroll
-            for (int nb = 0; nb < NBO; ++nb) {
-                f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const char *wf = wlds + ((size_t)(G.kk[c] * NBO + nb) * 64 + lane) * FRAGB;
-                if (CK == 16) {
-                    const uint2 a = *reinterpret_cast<const uint2 *>(wf);
-                    d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a),
-                                                                  __builtin_bit_cast(s16x4_t, (uint2){G.op[c][0], G.op[c][1]}), d, 0, 0, 0);
-                } else {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(wf);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, G.op[c]), d,
-                                                                0, 0, 0);
-                }
-                if (G.st[c] >= 0) {    // lane (g, rl): channels 4 g .. + 3 of block nb of pair rl's stationary row
-                    f32x4 *p = reinterpret_cast<f32x4 *>(acc + G.st[c] * ASTR + (nb * 16 + 4 * g) * 4);
-                    f32x4 o = *p;
-                    o[0] += d[0]; o[1] += d[1]; o[2] += d[2]; o[3] += d[3];
-                    *p = o;
-                }
-            }
-        }
-    };
-    Grp A, B;
-    const int ngrp = (nch_total + PC_GROUP - 1) / PC_GROUP;
-    load_idx(0);
-    gather(A);
-    load_idx(1);
-    for (int gi = 0; gi < ngrp; gi += 2) {
-        gather(B);                     // group gi + 1 (indices loaded one iteration ago)
-        load_idx(gi + 2);
-        compute(A);
-        gather(A);                     // group gi + 2
-        load_idx(gi + 3);
-        compute(B);
-    }
-
-    // accumulators -> the gather kernels' register layout -> their epilogue
-    f32x4 accr[PC_ROWS / 16][NBO];
-    int rows[PC_ROWS / 16];
-#pragma unroll
-    for (int mi = 0; mi < PC_ROWS / 16; ++mi) {
-        const int lr = mi * 16 + rl, row = r0wg + wave * PC_ROWS + lr;
-        rows[mi] = row < n_stat ? row : -1;
-#pragma unroll
-        for (int nb = 0; nb < NBO; ++nb) accr[mi][nb] = *reinterpret_cast<const f32x4 *>(acc + lr * ASTR + (nb * 16 + 4 * g) * 4);
-    }
-    gg_epilogue<PC_ROWS / 16, NBO, OUT_BF16>(accr, rows, c_out, 0, g, rl, wave, tile, bias, addend, yv, bn, red_s);
-}
-
-template <int CK, int NBO>
-static int launch_pconv(const void *x, int n_mov, const void *wp, const float *bias, const int32_t *pairs, int pair_stride,
-                        const int32_t *seg, int stat_col, int n_stat, const int32_t *n_stat_dev, void *y, int y_dtype,
-                        const void *addend, const PcdBnReduce *bnr, hipStream_t st, int *tiles_only) {
-    const int ntiles = pcd_div_up(n_stat, PC_ROWS);
-    const int grid = pcd_div_up(pcd_div_up(ntiles, 4), 8) * 8;
-    if (tiles_only) {
-        *tiles_only = grid;
-        return PCD_OK;
-    }
-    BnRed bn;
-    if (int rc = make_bnred(bnr, y_dtype, NBO * 16, grid, &bn)) return rc;
-    constexpr int FRAGB = CK == 16 ? 8 : 16, ASTR = NBO * 16 * 4 + 16, NLIST = 27 * (PC_ROWS / 16) + PC_GROUP;
-    const size_t lds = (size_t)27 * NBO * 64 * FRAGB + (size_t)4 * PC_ROWS * ASTR + (size_t)4 * NLIST * sizeof(int2) +
-                       (bn.mode ? (size_t)8 * NBO * 16 * sizeof(float) : 0);
-    auto kb = pconv_kernel<CK, NBO, true>;
-    auto kf = pconv_kernel<CK, NBO, false>;
-    static size_t raised[2] = {0, 0};
-    const int which = y_dtype == PCD_BF16 ? 0 : 1;
-    if (lds > 64 * 1024 && raised[which] < lds) {
-        if (hipFuncSetAttribute((const void *)(which == 0 ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return PCD_ERR_LAUNCH;
-        raised[which] = lds;
-    }
-    const unsigned x_bytes = (unsigned)((size_t)n_mov * CK * 2);
-    const int stat = stat_col;
-    if (y_dtype == PCD_BF16)
-        kb<<<grid, 256, lds, st>>>((const unsigned short *)x, x_bytes, (const uint4 *)wp, bias, pairs, pair_stride, seg, ntiles,
-                                   stat, n_stat, n_stat_dev, y, addend, bn);
-    else
-        kf<<<grid, 256, lds, st>>>((const unsigned short *)x, x_bytes, (const uint4 *)wp, bias, pairs, pair_stride, seg, ntiles,
-                                   stat, n_stat, n_stat_dev, y, addend, bn);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
+#ifdef PCD_EXPERIMENTS
+#include "experiments/spconv_kernels.inc"     // ggwin_kernel (128-channel window/stream hybrid), pconv_kernel (pair-driven strided convs)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Data gradient of a STRIDED conv over rows grouped by parity class (pcd_rulebook_conv_classes): a workgroup's
@@ -2366,9 +1834,11 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
         const unsigned w_bytes = (unsigned)wbytes;
         int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
         // SubM 3x3x3 over z-fastest rows at 128 -> 128 channels: x through windows (ggwin_kernel; same tiles, same BatchNorm rows)
+#ifdef PCD_EXPERIMENTS
         if (zfast && !tiles_only && pcd_opt(PCD_OPT_GGWIN) && c_in == 128 && c_out == 128 && kvol == 27 && mi == 3)
             return launch_ggwin<8, 3>(x, packed_w, bias, nbr, nbr_stride, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, x_bytes,
                                       w_bytes, st, addend, bnr);
+#endif
         // Few rows (one round of 128-row tiles fits the chip): the FORWARD conv takes 128-row tiles -- 36-38 us isolated against
         // 42-44 at 21-32 k rows (tools/exp_ggw.py) and nothing runs beside levels 3-4 of the forward pass; the data gradient
         // keeps 192 rows: its workgroups leave ~45 % of the CUs to the weight-gradient kernel running beside it, and with
@@ -2430,71 +1900,9 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
                        c_out, y, y_dtype, addend, bn_reduce, nullptr, stream);
 }
 
-// pcd_sparse_conv_gather_gemm for a SubM 3x3x3 neighbour table whose rows are numbered z-fastest (PCD_ROWS_YXZ): the nine
-// offsets of a dy then read ONE contiguous run of rows, which the 128-channel kernel (ggwin_kernel) stages in LDS once
-extern "C" int pcd_sparse_conv_gather_gemm_zfast(const void *x, int n_rows_in, int c_in, const void *packed_w,
-                                                 const float *bias, const int32_t *nbr, int nbr_stride, int kvol,
-                                                 int flip_k, int n_rows_out, const int32_t *n_rows_out_dev, int c_out,
-                                                 void *y, int y_dtype, const void *addend, const PcdBnReduce *bn_reduce,
-                                                 void *stream) {
-    PCD_ENTER();
-    return gg_dispatch(x, n_rows_in, c_in, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev,
-                       c_out, y, y_dtype, addend, bn_reduce, nullptr, stream, -1, 1);
-}
-
-// ---- pair-driven strided convs (pconv_kernel) --------------------------------------------------------------------------
-// dir 0: forward  y[o] += W_k x[i]   (stationary = output rows, pairs[k][1]; moving = input rows; c_mov = C_in, c_sta = C_out)
-// dir 1: data gradient  dx[i] += W_k^T dy[o]   (stationary = input rows, pairs[k][0]; moving = output rows; c_mov = C_out, c_sta = C_in)
-// Supported (c_mov, c_sta): (16, 32) and (32, 16) -- the level-1 -> 2 conv of the backbones -- with K = 27.
-static bool pconv_supported(int c_mov, int c_sta, int kvol) { return kvol == 27 && ((c_mov == 16 && c_sta == 32) || (c_mov == 32 && c_sta == 16)); }
-
-extern "C" size_t pcd_sparse_conv_pairs_seg_bytes(int n_stat_cap, int kvol) {
-    if (n_stat_cap < 0 || kvol <= 0) return 0;
-    return (size_t)kvol * (pcd_div_up(n_stat_cap > 0 ? n_stat_cap : 1, PC_ROWS) + 1) * sizeof(int32_t);
-}
-
-extern "C" int pcd_sparse_conv_pairs_seg(const int32_t *pairs, int pair_stride, const int32_t *pair_num, int kvol, int dir,
-                                         int n_stat_cap, int32_t *seg, void *stream) {
-    PCD_ENTER();
-    if (!pairs || !pair_num || !seg || kvol <= 0 || pair_stride <= 0 || n_stat_cap <= 0 || (dir != 0 && dir != 1))
-        return PCD_ERR_INVALID_ARG;
-    const int ntiles = pcd_div_up(n_stat_cap, PC_ROWS);
-    const int total = kvol * (ntiles + 1);
-    pconv_seg_kernel<<<pcd_div_up(total, 256), 256, 0, (hipStream_t)stream>>>(pairs, pair_stride, pair_num, kvol, dir == 0 ? 1 : 0,
-                                                                             ntiles, seg);
-    PCD_RETURN_IF_LAUNCH_FAILED();
-    return PCD_OK;
-}
-
-extern "C" int pcd_sparse_conv_pairs_tiles(int n_stat_cap, int c_mov, int c_sta, int kvol) {
-    if (n_stat_cap <= 0 || !pconv_supported(c_mov, c_sta, kvol)) return PCD_ERR_UNSUPPORTED;
-    int tiles = 0;
-    if (c_mov == 16) launch_pconv<16, 2>(nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, n_stat_cap, nullptr, nullptr, PCD_BF16,
-                                         nullptr, nullptr, nullptr, &tiles);
-    else launch_pconv<32, 1>(nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, n_stat_cap, nullptr, nullptr, PCD_BF16, nullptr,
-                             nullptr, nullptr, &tiles);
-    return tiles;
-}
-
-extern "C" int pcd_sparse_conv_pairs(const void *x, int n_mov, int c_mov, const void *packed_w, const float *bias,
-                                     const int32_t *pairs, int pair_stride, const int32_t *seg, int kvol, int dir, int n_stat_cap,
-                                     const int32_t *n_stat_dev, int c_sta, void *y, int y_dtype, const void *addend,
-                                     const PcdBnReduce *bn_reduce, void *stream) {
-    PCD_ENTER();
-    if (!pconv_supported(c_mov, c_sta, kvol)) return PCD_ERR_UNSUPPORTED;
-    if (n_stat_cap < 0 || n_mov < 0 || (dir != 0 && dir != 1)) return PCD_ERR_INVALID_ARG;
-    if (n_stat_cap == 0) return PCD_OK;
-    if (!x || !packed_w || !pairs || !seg || !y || pair_stride <= 0) return PCD_ERR_INVALID_ARG;
-    if ((double)n_mov * c_mov * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
-    if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int stat_col = dir == 0 ? 1 : 0;
-    if (c_mov == 16)
-        return launch_pconv<16, 2>(x, n_mov, packed_w, bias, pairs, pair_stride, seg, stat_col, n_stat_cap, n_stat_dev, y, y_dtype,
-                                   addend, bn_reduce, st, nullptr);
-    return launch_pconv<32, 1>(x, n_mov, packed_w, bias, pairs, pair_stride, seg, stat_col, n_stat_cap, n_stat_dev, y, y_dtype, addend,
-                               bn_reduce, st, nullptr);
-}
+#ifdef PCD_EXPERIMENTS
+#include "experiments/spconv_entries.inc"     // pcd_sparse_conv_gather_gemm_zfast, pcd_sparse_conv_pairs*
+#endif
 
 extern "C" int pcd_sparse_conv_gather_gemm_tiles_dir(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out,
                                                       int is_dgrad) {

@@ -163,7 +163,9 @@ struct WinCfg {
 using Win64 = WinCfg<64, 2, 1, 4, 64, 128>;      // 64 -> 64: waves = 2 channel blocks x 4 offset slices (7 offsets each)
 using Win32 = WinCfg<32, 1, 4, 2, 128, 320>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
 using Win16 = WinCfg<16, 1, 8, 1, 256, 640>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
+#ifdef PCD_EXPERIMENTS      // (make EXPERIMENTS=1; 61.6 us against ggw_kernel's 49.0 at level 4 -- DESIGN.md 4.1: not in the default library)
 using Win128 = WinCfg<128, 1, 1, 8, 32, 64, 4>;  // 128 -> 128: 4 workgroups x 32 output channels; waves = 8 offset slices (4 each)
+#endif
 
 // c_in -> configuration (square layers): f(Cfg{}) with the matching type, `none` otherwise
 template <class F, class N>
@@ -173,7 +175,9 @@ static inline auto win_dispatch(int c_in, int c_out, F &&f, N none) -> decltype(
         case 64: return f(Win64{});
         case 32: return f(Win32{});
         case 16: return f(Win16{});
+#ifdef PCD_EXPERIMENTS
         case 128: return f(Win128{});
+#endif
         default: return none;
     }
 }
@@ -356,8 +360,10 @@ __device__ __forceinline__ void win_pack_any(const float *__restrict__ w, int ci
         if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out);
     } else if (cin == 32) {
         if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out);
+#ifdef PCD_EXPERIMENTS
     } else if (cin == 128) {
         if (e < win_pack_elems<Win128>()) win_pack_one<Win128>(w, mode, e, out);
+#endif
     } else {
         if (e < win_pack_elems<Win16>()) win_pack_one<Win16>(w, mode, e, out);
     }
@@ -385,17 +391,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 unsigned long long *g_win_trace = nullptr;     // profiling aid, NULL in production (pcd_subm_window_set_trace)
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
-// PcdBnFold as the kernel sees it (on == 0: the launch ends with its BatchNorm row, as before)
-struct BnFoldK {
-    int on, relu;
-    const float *gamma, *beta;
-    float eps, momentum;
-    float *running_mean, *running_var, *save_mean, *save_invstd;
-    const unsigned short *res;
-    unsigned short *out;
-    int *sync;                   // [0] mid rows delivered (returns to zero), [32] generation of the launch-wide barrier
-};
-
 struct WinPlan {                 // scalars only (an array member sent the struct to scratch memory)
     int lo0, lo1, lo2, n0, n1, n2, passes;
     __device__ __forceinline__ int lo(int g) const { return g == 0 ? lo0 : g == 1 ? lo1 : lo2; }
@@ -407,8 +402,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
     const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, const int32_t *__restrict__ n_dev,
     const int4 *__restrict__ plan_g, unsigned short *__restrict__ y, unsigned x_bytes,
-    const unsigned short *__restrict__ addend, BnRed bn, int dbg, unsigned long long *trace, float *__restrict__ y_f32,
-    BnFoldK fold) {
+    const unsigned short *__restrict__ addend, BnRed bn, int dbg, unsigned long long *trace, float *__restrict__ y_f32) {
     __builtin_amdgcn_s_setprio(3);       // main-chain kernel (see spconv.hip: PCD_MAIN_PRIO)
     // profiling aid (pcd_subm_window_set_trace): shader-clock stamps of workgroup 0 / wave 0 at the phase boundaries of its tiles
     int trace_at = 0;
@@ -434,27 +428,8 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const int4 *hdr_g = (const int4 *)((const char *)plan_g + win_hdr_off(ntiles_cap));
 
     float *cols = (float *)(smem + C::COLS);
-    // BatchNorm fold: the generation of the launch-wide barrier, read before this workgroup can have arrived at it (it only
-    // advances once EVERY workgroup has); fold_arrive: a workgroup that wrote a mid row counts it, the 16th opens the barrier
-    const int gen0 = fold.on ? __hip_atomic_load(fold.sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    auto fold_arrive = [&](bool wrote_mid) {
-        if (!wrote_mid) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the mid row has reached the coherence point (agent-scope stores)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(fold.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == BN_MID_ROWS - 1) {
-                __hip_atomic_store(fold.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(fold.sync + 32, gen0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    // (workgroup 0 stays for the fold even without a tile: it publishes the statistics)
-    if (t_begin >= t_end && !(fold.on && blockIdx.x == 0)) {   // no tile: the BatchNorm row of this workgroup is zero
-        if (bn.mode) {
-            const bool wrote = bnred_publish(bn, blockIdx.x, COUT, [](int) { return 0.0f; }, (int)gridDim.x);
-            if (fold.on) fold_arrive(wrote);
-        }
+    if (t_begin >= t_end) {              // no tile: the BatchNorm row of this workgroup is zero
+        if (bn.mode) bnred_publish(bn, blockIdx.x, COUT, [](int) { return 0.0f; }, (int)gridDim.x);
         return;
     }
 
@@ -913,114 +888,10 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         __syncthreads();
         // (CQN > 1: the workgroup's row of the partial matrix carries its COUTW columns, zeros elsewhere -- the column sums over
         //  the rows are the same)
-        const bool wrote_mid = bnred_publish(bn, blockIdx.x, COUT, [&](int e) {
+        bnred_publish(bn, blockIdx.x, COUT, [&](int e) {
             const int which = e / COUT, c = e % COUT - cq * COUTW;
             return (c >= 0 && c < COUTW) ? cols[which * COUTW + c] : 0.0f;
         }, (int)gridDim.x);
-        if constexpr (C::CQN == 1) if (fold.on) {
-            // ---- the BatchNorm (+ residual) (+ ReLU) behind this conv, applied by the launch itself -------------------------------
-            // Every workgroup normalises ITS OWN rows of y (written a moment ago by this CU: L2 hits) once the 16 mid rows of the
-            // launch are complete -- a launch-wide barrier, safe because the grid is co-resident (checked on the host) and nothing
-            // else on the device waits for this kernel while holding CUs.  Arithmetic = bn_apply_kernel's (fused.hip), statement
-            // for statement: the result is bit-identical to the separate pass.
-            fold_arrive(wrote_mid);
-            constexpr int CG8 = COUT / 8, FPF = 4;
-            const int r0 = t_begin * T, r1 = min(t_end * T, n);
-            const int P = max(r1 - r0, 0) * CG8;
-            const unsigned short *yb = y + (size_t)r0 * COUT, *rb = fold.res ? fold.res + (size_t)r0 * COUT : nullptr;
-            // (the bnred_publish above ended with: stores of y awaited, workgroup barrier -- this workgroup's rows are in L2)
-            uint4 py[FPF], pr[FPF];
-            if (P > 0) {
-#pragma unroll
-                for (int u = 0; u < FPF; ++u) {
-                    const int p = tid + u * WIN_THREADS < P ? tid + u * WIN_THREADS : 0;
-                    py[u] = *reinterpret_cast<const uint4 *>(yb + (size_t)p * 8);
-                    if (rb) pr[u] = *reinterpret_cast<const uint4 *>(rb + (size_t)p * 8);
-                }
-            }
-            if (tid == 0)
-                while (__hip_atomic_load(fold.sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) __builtin_amdgcn_s_sleep(1);
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            double *tot = (double *)smem;                    // [2 COUT]
-            float *sc_s = (float *)(tot + 2 * COUT), *sh_s = sc_s + COUT;
-            for (int t = tid; t < 2 * COUT; t += WIN_THREADS) {
-                double v[BN_MID_ROWS];
-#pragma unroll
-                for (int r = 0; r < BN_MID_ROWS; ++r)
-                    v[r] = __hip_atomic_load(bn.mid + (size_t)r * 2 * COUT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                double sum = 0.0;
-#pragma unroll
-                for (int r = 0; r < BN_MID_ROWS; ++r) sum += v[r];
-                tot[t] = sum;
-            }
-            __syncthreads();
-            for (int ch = tid; ch < COUT; ch += WIN_THREADS) {
-                const double su = tot[ch], ss = tot[COUT + ch];
-                double mean = n > 0 ? su / n : 0.0;
-                double var = n > 0 ? ss / n - mean * mean : 0.0;
-                if (var < 0.0) var = 0.0;
-                const float invstd = (float)(1.0 / sqrt(var + (double)fold.eps));
-                const float g = fold.gamma ? fold.gamma[ch] : 1.0f, b = fold.beta ? fold.beta[ch] : 0.0f;
-                sc_s[ch] = g * invstd;
-                sh_s[ch] = b - (float)mean * g * invstd;
-                if (blockIdx.x == 0) {
-                    fold.save_mean[ch] = (float)mean;
-                    fold.save_invstd[ch] = invstd;
-                    if (fold.running_mean)
-                        fold.running_mean[ch] = (1.0f - fold.momentum) * fold.running_mean[ch] + fold.momentum * (float)mean;
-                    if (fold.running_var) {
-                        const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
-                        fold.running_var[ch] = (1.0f - fold.momentum) * fold.running_var[ch] + fold.momentum * (float)unbiased;
-                    }
-                }
-            }
-            __syncthreads();
-            float sc[8], sh[8];
-            {
-                const int cg = tid % CG8;                    // (512 % CG8 == 0: a thread keeps its channel group)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sc[j] = sc_s[cg * 8 + j];
-                    sh[j] = sh_s[cg * 8 + j];
-                }
-            }
-            unsigned short *ob = fold.out + (size_t)r0 * COUT;
-            const bool has_res = rb != nullptr;
-            const int relu = fold.relu;
-            auto finish_piece = [&](const uint4 &xr, const uint4 &rr, int p) {
-                const u32 xw[4] = {xr.x, xr.y, xr.z, xr.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-                float v[8], r[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[2 * j] = __uint_as_float(xw[j] << 16);
-                    v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u);
-                    r[2 * j] = __uint_as_float(rw[j] << 16);
-                    r[2 * j + 1] = __uint_as_float(rw[j] & 0xffff0000u);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float o = v[j] * sc[j] + sh[j];
-                    if (has_res) o += r[j];
-                    if (relu) o = o > 0.0f ? o : 0.0f;
-                    v[j] = o;
-                }
-                u32x4 o4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    o4[j] = __builtin_bit_cast(u32, __builtin_convertvector((f32x2){v[2 * j], v[2 * j + 1]}, bf16x2));
-                *reinterpret_cast<u32x4 *>(ob + (size_t)p * 8) = o4;
-            };
-#pragma unroll
-            for (int u = 0; u < FPF; ++u)
-                if (tid + u * WIN_THREADS < P) finish_piece(py[u], has_res ? pr[u] : py[u], tid + u * WIN_THREADS);
-            for (int p = tid + FPF * WIN_THREADS; p < P; p += WIN_THREADS) {
-                const uint4 xr = *reinterpret_cast<const uint4 *>(yb + (size_t)p * 8);
-                uint4 rr = xr;
-                if (has_res) rr = *reinterpret_cast<const uint4 *>(rb + (size_t)p * 8);
-                finish_piece(xr, rr, p);
-            }
-        }
     }
     stamp();                                 // (last trace slot: kernel exit)
     if (trace && threadIdx.x == 0) trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -1030,7 +901,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
 template <class C>
 static int launch_win(const void *x, int n_rows, const void *wp, const float *bias, const int32_t *nbr, int nbr_stride,
                       const int32_t *n_dev, const void *plan, void *y, const void *addend,
-                      const PcdBnReduce *bnr, hipStream_t st, float *y_f32 = nullptr, const PcdBnFold *fold = nullptr) {
+                      const PcdBnReduce *bnr, hipStream_t st, float *y_f32 = nullptr) {
     BnRed bn;
     const int grid = win_grid();
     if (int rc = make_bnred(bnr, PCD_BF16, C::COUT, grid, &bn)) return rc;
@@ -1039,38 +910,10 @@ static int launch_win(const void *x, int n_rows, const void *wp, const float *bi
     // (set per call: the attribute is per device, the call idempotent)
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
         return PCD_ERR_LAUNCH;
-    BnFoldK fk = {};
-    if (fold) {
-        // the launch-wide barrier needs every workgroup resident at once
-        if (bn.mode != 1 || !bn.mid || y_f32 || C::CQN != 1) return PCD_ERR_INVALID_ARG;
-        if (!fold->save_mean || !fold->save_invstd || !fold->out || !fold->sync) return PCD_ERR_INVALID_ARG;
-        static int resident = -1;            // (per kernel instantiation; one device kind per process)
-        if (resident < 0) {
-            int dev = 0, cus = 0, per_cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, WIN_THREADS, C::LDS_BYTES) != hipSuccess)
-                return PCD_ERR_LAUNCH;
-            resident = cus * per_cu;
-        }
-        if (resident < grid) return PCD_ERR_UNSUPPORTED;
-        fk.on = 1;
-        fk.relu = fold->relu;
-        fk.gamma = fold->gamma;
-        fk.beta = fold->beta;
-        fk.eps = fold->eps;
-        fk.momentum = fold->momentum;
-        fk.running_mean = fold->running_mean;
-        fk.running_var = fold->running_var;
-        fk.save_mean = fold->save_mean;
-        fk.save_invstd = fold->save_invstd;
-        fk.res = (const unsigned short *)fold->residual;
-        fk.out = (unsigned short *)fold->out;
-        fk.sync = fold->sync;
-    }
     k<<<grid, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
                                                     n_rows, n_dev, (const int4 *)plan, (unsigned short *)y,
                                                     (unsigned)((size_t)n_rows * C::ROWB), (const unsigned short *)addend, bn,
-                                                    pcd_opt(PCD_OPT_WIN_DBG), g_win_trace, y_f32, fk);
+                                                    pcd_opt(PCD_OPT_WIN_DBG), g_win_trace, y_f32);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -1503,23 +1346,6 @@ extern "C" int pcd_sparse_conv_subm_window(const void *x, int n_rows, int c_in, 
     return win_dispatch(c_in, c_out, [&](auto c) {
         return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend,
                                        bn_reduce, st);
-    }, (int)PCD_ERR_UNSUPPORTED);
-}
-
-// the same launch + the BatchNorm (training mode) (+ residual) (+ ReLU) behind it: fold->out = relu?(bn(y) + residual?)
-extern "C" int pcd_sparse_conv_subm_window_bn(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
-                                              const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev,
-                                              const void *plan, int c_out, void *y, const void *addend,
-                                              const PcdBnReduce *bn_reduce, const PcdBnFold *fold, void *stream) {
-    PCD_ENTER();
-    if (n_rows < 0 || !win_supported(c_in, c_out)) return PCD_ERR_UNSUPPORTED;
-    if (!fold || !bn_reduce) return PCD_ERR_INVALID_ARG;
-    if (n_rows == 0) return PCD_ERR_UNSUPPORTED;          // (the separate pass handles the empty matrix)
-    if (!x || !packed_w || !nbr || !plan || !y || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    return win_dispatch(c_in, c_out, [&](auto c) {
-        return launch_win<decltype(c)>(x, n_rows, packed_w, bias, nbr, nbr_stride, n_rows_dev, plan, y, addend,
-                                       bn_reduce, st, nullptr, fold);
     }, (int)PCD_ERR_UNSUPPORTED);
 }
 

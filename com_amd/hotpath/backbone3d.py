@@ -57,14 +57,13 @@ class SparseBasicBlock(spconv.SparseModule):
         # the identity branch leaves conv1 as a second output, so its gradient is added in conv1's dgrad epilogue
         fuse_identity = (self.fuse_identity_grad and self.downsample is None and x.features.is_cuda
                          and torch.is_grad_enabled())
-        # (fold_bn announces the BatchNorm call that follows: a window launch applies it to its own rows, see SparseConvolution.forward)
         if fuse_identity:
-            out, identity_features = self.conv1(x, passthrough=True, fold_bn=(self.bn1, None, True))
+            out, identity_features = self.conv1(x, passthrough=True)
         else:
-            out = self.conv1(x, fold_bn=(self.bn1, None, True))
+            out = self.conv1(x)
             identity_features = (self.downsample(x) if self.downsample is not None else x).features
         out = replace_feature(out, Fsp.batch_norm_act(self.bn1, out.features, None, True, out.num_rows))
-        out = self.conv2(out, fold_bn=(self.bn2, identity_features, True))
+        out = self.conv2(out)
         out = replace_feature(out, Fsp.batch_norm_act(self.bn2, out.features, identity_features, True,
                                                       out.num_rows))
         return out

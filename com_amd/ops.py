@@ -922,44 +922,6 @@ class BnReduce:
                              L.ptr(mid), L.ptr(counters))
 
 
-# Window convs can apply the BatchNorm behind them themselves (BnFold) -- OFF: measured slower.  Isolated, B = 4 (tools/exp_bn_fold.py,
-# per layer at 16 / 32 / 64 channels): conv 25.5 / 38.5 / 42.1 us, conv + separate pass 33.1 / 48.7 / 51.6, folded 44.9 / 59.9 /
-# 63.2; the training step 3.27 ms against 3.11.  The launch-wide barrier is a chain of ~6 dependent agent-scope round trips
-# (row -> counter -> mid row -> counter -> flag -> totals), ~2 us each across the XCDs: more than the kernel boundary it replaces.
-BN_FOLD = False
-
-
-class BnFold:
-    """The BatchNorm1d in training mode (+ residual add) (+ ReLU) BEHIND a window conv, applied by the conv launch itself
-    (C ABI: PcdBnFold; spconv_backbone.py:50-66).  After subm_window(..., bn_fold=f): f.out = relu?(bn(y) + residual?),
-    f.save_mean / f.save_invstd the batch statistics, the module's running statistics updated -- bit-identical to
-    bn_forward(y, ..., partials=...) -- or f.out is None (not foldable here: run the separate pass)."""
-
-    def __init__(self, bn, residual, relu):
-        self.bn, self.residual, self.relu = bn, residual, bool(relu)
-        self.out = self.save_mean = self.save_invstd = None
-
-    def usable(self, c_out):
-        bn, r = self.bn, self.residual
-        if not (BN_FOLD and BN_FUSED_MID and bn.training and bn.num_features == c_out):
-            return False
-        for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
-            if t is not None and (t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous()):
-                return False
-        return r is None or (r.dtype == torch.bfloat16 and r.is_cuda and r.is_contiguous() and r.shape[1] == c_out)
-
-    def _struct(self, n, c_out, device):
-        bn = self.bn
-        self.out = torch.empty((n, c_out), dtype=torch.bfloat16, device=device)
-        self.save_mean = torch.empty((c_out,), dtype=torch.float32, device=device)
-        self.save_invstd = torch.empty((c_out,), dtype=torch.float32, device=device)
-        momentum = bn.momentum if bn.momentum is not None else 0.1
-        self._keep = (bn.weight.detach() if bn.weight is not None else None, bn.bias.detach() if bn.bias is not None else None)
-        return L.PcdBnFold(L.ptr(self._keep[0]), L.ptr(self._keep[1]), float(bn.eps), float(momentum), L.ptr(bn.running_mean),
-                           L.ptr(bn.running_var), L.ptr(self.save_mean), L.ptr(self.save_invstd), L.ptr(self.residual),
-                           int(self.relu), L.ptr(self.out), L.ptr(_bn_counters(device)))
-
-
 def _tiles(v, what):
     if v < 0:
         L.check(v, what)
@@ -1095,7 +1057,8 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
         if variant == 1 and zfast and x.shape[1] == c_out == 128 and kvol == 27 and L.get_option("ggwin") \
                 and n_rows_out <= 256 * 192 * 5 // 4:
             kname = "ggwin_kernel"
-    entry = L.lib().pcd_sparse_conv_gather_gemm_zfast if zfast else L.lib().pcd_sparse_conv_gather_gemm
+    # (the z-fastest entry point exists in EXPERIMENTS builds only: pcd_ops_experiments.h)
+    entry = L.lib().pcd_sparse_conv_gather_gemm_zfast if (zfast and L.has_experiments()) else L.lib().pcd_sparse_conv_gather_gemm
     with _Timed(f"{kname}<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
         L.check(entry(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr), nbr.shape[1], kvol,
                       int(flip_k), n_rows_out, L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y), L.ptr(addend), _byref(bnr),
@@ -1114,7 +1077,7 @@ PAIR_CONV = False
 def pair_conv_usable(rb, c_mov, c_sta):
     """The pair-driven kernel serves this strided rulebook: rows z-fastest (pairs sorted by both rows), pair lists built,
     widths (16, 32) or (32, 16)."""
-    return (PAIR_CONV and not rb.subm and rb.kvol == 27 and getattr(rb, "order", None) == ROWS_YXZ
+    return (PAIR_CONV and L.has_experiments() and not rb.subm and rb.kvol == 27 and getattr(rb, "order", None) == ROWS_YXZ
             and rb._pairs is not None and (int(c_mov), int(c_sta)) in ((16, 32), (32, 16)))
 
 
@@ -1217,11 +1180,10 @@ def subm_window_f32(x, packed_w, bias, rb, c_out, addend=None):
     return y, y32
 
 
-def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None, bn_fold=None):
+def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     """gather_gemm over the SubM rulebook `rb` through the window kernel: y[o] = bias + sum_k x[nbr[k][o]] @ W[k] (+ addend[o])
     with packed_w = pack_weight_window(w, 0); the data gradient (k-flipped view, W^T) with pack_weight_window(w, 1) -- the flip
-    is part of that pack.  x, y bf16 [n, c].  bn_fold (a BnFold, with bn_reduce of mode 1): the launch also applies that
-    BatchNorm to its rows (bn_fold.out; None if the launch could not fold it)."""
+    is part of that pack.  x, y bf16 [n, c]."""
     _require_cuda(x, packed_w)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and rb.subm and rb.kvol == 27
     n, c_in = x.shape
@@ -1239,25 +1201,11 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None, bn_fo
     bnr = None
     if bn_reduce is not None:
         bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows()), c_out, x.device)
-    fold = None
-    if bn_fold is not None and bnr is not None and bn_reduce.mode == 1 and bnr.mid and n > 0 and bn_fold.usable(c_out) \
-            and (bn_fold.residual is None or bn_fold.residual.shape[0] == n):
-        fold = bn_fold._struct(n, c_out, x.device)
     with _Timed(f"subm_win_kernel<{c_in}> {c_in}->{c_out} K=27", meta):
-        if fold is not None:
-            rc = L.lib().pcd_sparse_conv_subm_window_bn(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
-                                                        rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan), c_out,
-                                                        L.ptr(y), L.ptr(addend), _byref(bnr), _byref(fold), L.stream_ptr())
-            if rc == -2:                         # PCD_ERR_UNSUPPORTED (the grid is not co-resident on this device: conv alone, separate pass)
-                bn_fold.out = bn_fold.save_mean = bn_fold.save_invstd = None
-                fold = None
-            else:
-                L.check(rc, "pcd_sparse_conv_subm_window_bn")
-        if fold is None:
-            L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
-                                                        rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
-                                                        c_out, L.ptr(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
-                    "pcd_sparse_conv_subm_window")
+        L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
+                                                    rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
+                                                    c_out, L.ptr(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
+                "pcd_sparse_conv_subm_window")
     return y
 
 

@@ -127,11 +127,8 @@ class SparseConvFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False,
-                bn_fold=None):
-        """bn_fold (ops.BnFold): the BatchNorm (+ residual) (+ ReLU) the caller will run on the output next; a window launch
-        applies it itself and leaves the result on the output as `_pcd_bn_folded` for FusedBNFunction to pick up.
-        window=True: `packed_fwd` / `packed_dgrad` are window-kernel packs (ops.pack_weight_window) and `rb` is a SubM
+    def forward(ctx, features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False):
+        """window=True: `packed_fwd` / `packed_dgrad` are window-kernel packs (ops.pack_weight_window) and `rb` is a SubM
         3x3x3 rulebook over z-fastest rows: forward and data gradient run through ops.subm_window.
         passthrough=True also returns `features` itself as a second output (the identity branch of a residual
         block): backward then receives the gradients of BOTH branches in one call and adds the identity gradient
@@ -153,9 +150,7 @@ class SparseConvFunction(Function):
             stats = None
         elif window:
             assert out_dtype == torch.bfloat16 and rb.subm
-            y = ops.subm_window(x, packed_fwd, b, rb, cout, bn_reduce=stats, bn_fold=bn_fold if stats is not None else None)
-            if bn_fold is not None and bn_fold.out is not None:
-                y._pcd_bn_folded = bn_fold
+            y = ops.subm_window(x, packed_fwd, b, rb, cout, bn_reduce=stats)
         elif out_dtype == torch.bfloat16 and ops.pair_conv_usable(rb, cin_pad, cout):
             # strided conv of a z-fastest chain, 16 -> 32 channels: one gather per indice PAIR (ops.pair_conv)
             y = ops.pair_conv(x, packed_fwd, b, rb, 0, cout, out_dtype, bn_reduce=stats)
@@ -406,11 +401,10 @@ class SparseConvExactFunction(Function):
         return (dx, dw, db, None, None)
 
 
-def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False,
-                bn_fold=None):
+def sparse_conv(features, weight, bias, rb, packed_fwd, packed_dgrad=None, passthrough=False, fp8=None, window=False):
     if EXACT_FP32 and features.dtype == torch.float32:
         return SparseConvExactFunction.apply(features, weight, bias, rb, passthrough)
-    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough, fp8, window, bn_fold)
+    return SparseConvFunction.apply(features, weight, bias, rb, packed_fwd, packed_dgrad, passthrough, fp8, window)
 
 
 class _ColsumLink:
@@ -451,17 +445,8 @@ class FusedBNFunction(Function):
         if st is not None and st.partial is not None and xc.data_ptr() == x.data_ptr() \
                 and xc.dtype == torch.bfloat16 and st.partial.shape[2] == xc.shape[1]:
             partials = (st.partial, st.rows)         # the conv that produced x already summed its columns
-        fd = getattr(x, "_pcd_bn_folded", None)
-        if fd is not None:
-            # the conv launch that produced x applied THIS BatchNorm to its rows already (ops.BnFold): running statistics
-            # updated, output and batch statistics waiting -- anything else than the announced call is a caller's bug
-            if not (fd.bn is bn and fd.relu == bool(relu) and out is None and training and xc.data_ptr() == x.data_ptr()
-                    and (fd.residual is None) == (rc is None) and (rc is None or fd.residual.data_ptr() == rc.data_ptr())):
-                raise RuntimeError("BatchNorm folded into the conv launch, but called with other arguments than announced")
-            y, save_mean, save_invstd = fd.out, fd.save_mean, fd.save_invstd
-        else:
-            y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
-                                                       bn.running_var, relu, n_dev=n_dev, partials=partials, out=out)
+        y, save_mean, save_invstd = ops.bn_forward(xc, rc, g, b, bn.eps, momentum, training, bn.running_mean,
+                                                   bn.running_var, relu, n_dev=n_dev, partials=partials, out=out)
         if not training:
             save_mean = bn.running_mean
             save_invstd = torch.rsqrt(bn.running_var + bn.eps)

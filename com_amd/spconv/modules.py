@@ -63,14 +63,7 @@ class SparseSequential(SparseModule):
             i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
-                from .conv import SparseConvolution
-                if isinstance(module, SparseConvolution) and i < len(mods) and isinstance(mods[i], nn.BatchNorm1d) \
-                        and input.indices.shape[0] > 0:
-                    # conv -> BatchNorm1d (-> ReLU): announce the BatchNorm call made below (a window launch applies it itself)
-                    relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                    input = module(input, fold_bn=(mods[i], None, relu))
-                else:
-                    input = module(input)
+                input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] == 0:
                     continue

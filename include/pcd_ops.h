@@ -91,8 +91,7 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "ggw_mi" 0            rows per workgroup / 64 of the wide gather-GEMM: 0 = by rule (forward convs of small levels 2, else 3), 2 / 3 forced
  *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
  *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only)
- *   "ggwin" 0             1: pcd_sparse_conv_gather_gemm_zfast runs 128 -> 128 SubM layers through ggwin_kernel (x through row
- *                         windows); measured slower than the 27-slot gather kernel (55 vs 46 us), parity-tested, off
+ *   "ggwin" 0             (EXPERIMENTS build only, pcd_ops_experiments.h) 1: 128 -> 128 SubM layers through ggwin_kernel
  *   "subm_window_grid" 256   workgroups of a window launch (a multiple of 8, <= 256); fewer leave CUs to other streams --
  *                         measured: no gain (240 / 224 / 192: 0 / -0.5 / -1 % in the step)
  *   "cm_direct_blocks" 4096   column-map builds: up to this many scan blocks add up the block sums themselves, beyond it a
@@ -382,27 +381,6 @@ typedef struct PcdBnReduce {
     double *mid;
     int32_t *counters;
 } PcdBnReduce;
-/* The BatchNorm1d (training mode) (+ residual add) (+ ReLU) behind a conv, applied by the conv launch itself
- * (pcd_sparse_conv_subm_window_bn): bn_reduce must be mode 1 with `mid` / `counters`; once the launch's statistics are complete
- * (a launch-wide barrier among its co-resident persistent workgroups) every workgroup normalises the rows it produced --
- * out = relu?(y * scale + shift + residual?) -- and workgroup 0 writes save_mean / save_invstd and updates the running
- * statistics exactly as pcd_bn_forward does: `out` and the statistics are bit-identical to conv + pcd_bn_forward(ext_partial =
- * mid, PCD_BN_EXT_MID).  y (the raw conv output the BatchNorm backward needs) is still written.
- * Measured on MI355X (B = 4 levels, per layer): slower than the separate pass by 11-12 us -- the barrier is a chain of dependent
- * agent-scope round trips across the XCDs (~2 us each) that costs more than the kernel boundary it replaces; the host side keeps
- * it switched off (com_amd.ops.BN_FOLD).
- *   sync: 64 int32, ZERO before the first use, left consistent by every launch; one buffer per stream that runs such launches
- *   (two launches sharing a buffer must not overlap).  Reference: spconv_backbone.py:50-66 (conv -> bn -> (+identity) -> relu). */
-typedef struct PcdBnFold {
-    const float *gamma, *beta;   /* NULL = 1 / 0 */
-    float eps, momentum;
-    float *running_mean, *running_var;   /* updated in place; NULL = not tracked */
-    float *save_mean, *save_invstd;      /* out [c_out] */
-    const void *residual;                /* bf16 [n][c_out] or NULL */
-    int relu;
-    void *out;                           /* bf16 [n][c_out] */
-    int32_t *sync;
-} PcdBnFold;
 #define PCD_BN_MID_ROWS 16
 #define PCD_BN_COUNTER_STRIDE 32
 #define PCD_BN_EXT_MID (-1)
@@ -462,34 +440,6 @@ int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_in, const vo
                                 const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
                                 int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
                                 int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
-/* pcd_sparse_conv_gather_gemm for a SubM 3x3x3 neighbour table (spconv_backbone.py:12-13,219-222) whose rows are numbered
- * z-fastest (PCD_ROWS_YXZ): the nine offsets sharing dy then read one contiguous run of rows, and -- with option "ggwin" --
- * the 128 -> 128 layers stage those runs in LDS once (ggwin_kernel: half the DMA instructions of the 27-slot gather; offsets
- * summed run by run, so the result equals pcd_sparse_conv_gather_gemm's within one bf16 ulp, not bit for bit).  Otherwise, and
- * for any other width: the same kernels as pcd_sparse_conv_gather_gemm.  A table over another row numbering is still computed exactly (further passes), only slowly. */
-int pcd_sparse_conv_gather_gemm_zfast(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
-                                const int32_t *nbr, int nbr_stride, int kvol, int flip_k,
-                                int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
-                                int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream);
-
-/* ---- Strided convs, PAIR-DRIVEN (spconv.SparseConv3d of the narrow levels, spconv_backbone.py:205-206) ------------------
- * For rulebooks whose rows are numbered z-fastest the indice pairs of one offset are sorted by input row AND by output row, so
- * the pairs ending in 64 consecutive stationary rows (output rows: forward, dir 0; input rows: data gradient, dir 1) are one
- * contiguous segment per offset.  pcd_sparse_conv_pairs_seg finds the segments once per rulebook and direction (seg: K x
- * (ceil(n_stat_cap / 64) + 1) int32 = pcd_sparse_conv_pairs_seg_bytes); pcd_sparse_conv_pairs then gathers one moving row
- * per PAIR (the gather kernels: 27 slots per row, 4.5 of them live at level 2) and accumulates per wave in LDS -- no atomics, a
- * fixed summation order; same epilogue (bias, addend, one rounding, PcdBnReduce with pcd_sparse_conv_pairs_tiles partial
- * rows); equal to pcd_sparse_conv_gather_gemm / _dgrad_classes within one bf16 ulp.  packed_w: pcd_pack_weight mode `dir`.
- * Supported (c_mov, c_sta) = (16, 32), (32, 16) with kvol 27 (PCD_ERR_UNSUPPORTED otherwise); pairs must be sorted by the
- * stationary row inside every offset (true for pcd_rulebook_conv_* builds with row_order PCD_ROWS_YXZ over z-fastest inputs). */
-size_t pcd_sparse_conv_pairs_seg_bytes(int n_stat_cap, int kvol);
-int pcd_sparse_conv_pairs_seg(const int32_t *pairs, int pair_stride, const int32_t *pair_num, int kvol, int dir,
-                              int n_stat_cap, int32_t *seg, void *stream);
-int pcd_sparse_conv_pairs_tiles(int n_stat_cap, int c_mov, int c_sta, int kvol);
-int pcd_sparse_conv_pairs(const void *x, int n_mov, int c_mov, const void *packed_w, const float *bias,
-                          const int32_t *pairs, int pair_stride, const int32_t *seg, int kvol, int dir, int n_stat_cap,
-                          const int32_t *n_stat_dev, int c_sta, void *y, int y_dtype, const void *addend,
-                          const PcdBnReduce *bn_reduce, void *stream);
 /* number of workgroup tiles (= partial rows of bn_reduce) of that launch; < 0: error code */
 int pcd_sparse_conv_gather_gemm_tiles(int n_rows_in, int c_in, int kvol, int n_rows_out, int c_out);
 /* same for a launch that is a DATA GRADIENT (flip_k != 0 or bn_reduce->mode == 2): the library may pick a different
@@ -1014,10 +964,6 @@ int pcd_debug_spin_shape(int blocks, int threads, int lds_bytes, int vgprs, unsi
  *                                  {weight ptr, packed ptr, c_in, mode, first 256-thread block, 0, 0, 0}
  *   pcd_subm_window_partial_rows   rows of PcdBnReduce.partial the launch writes (one per persistent workgroup)
  * ============================================================================================ */
-int pcd_sparse_conv_subm_window_bn(const void *x, int n_rows, int c_in, const void *packed_w, const float *bias,
-                                   const int32_t *nbr, int nbr_stride, const int32_t *n_rows_dev, const void *plan,
-                                   int c_out, void *y, const void *addend, const PcdBnReduce *bn_reduce,
-                                   const PcdBnFold *fold, void *stream);
 int pcd_subm_window_tile_rows(int c_in, int c_out);
 int pcd_subm_window_partial_rows(void);
 /* profiling aid: a device buffer of 1024 x u64 whose first 256 entries receive shader-clock stamps of workgroup 0 at the phase boundaries of its

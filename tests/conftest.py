@@ -12,6 +12,11 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PCD_TEST_EXPERIMENTS=1: run the suite against the EXPERIMENTS build (make -C com_amd/csrc EXPERIMENTS=1), so that the tests
+    # of the measured-slower kernels (ggwin, pconv, the 128-channel window configuration) run instead of skipping
+    if os.environ.get("PCD_TEST_EXPERIMENTS") == "1":
+        from com_amd import _lib
+        _lib.use_experiments_library()
 
 
 @pytest.fixture(scope="session")

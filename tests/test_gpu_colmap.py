@@ -274,6 +274,9 @@ def test_pair_driven_strided_conv_against_the_oracle_and_the_gather_kernels(dire
     pairs of every offset ARE sorted by both rows (what the segment search relies on), then against the oracle's conv on the
     same bf16 operands (one bf16 ulp per element; the fp32-output form at 1e-3 per element), against the 27-slot gather
     kernels, the BatchNorm sums of the epilogue, and with padded capacities + device-side row counts."""
+    from com_amd import _lib as L
+    if not L.has_experiments():
+        pytest.skip("pconv_kernel is an EXPERIMENTS-build kernel (make -C com_amd/csrc EXPERIMENTS=1)")
     from com_amd.hotpath import collate_points
     ops = _ops()
     pts, offs = collate_points([synth.synth_cloud(f, 32, 2500) for f in (0, 1)], DEV)

@@ -74,8 +74,17 @@ def _close_f32(y32, ref, what):
     return rel
 
 
+def _skip_without_experiments(ch=128):
+    """The 128-channel window configuration, ggwin_kernel and pconv_kernel are measured-slower experiments: in the library only
+    when it was built with `make EXPERIMENTS=1` (include/pcd_ops_experiments.h)."""
+    from com_amd import _lib as L
+    if ch == 128 and not L.has_experiments():
+        pytest.skip("EXPERIMENTS build only (make -C com_amd/csrc EXPERIMENTS=1)")
+
+
 @pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1), (128, 4)])
 def test_window_forward_and_dgrad_against_the_oracle(ch, lvl):
+    _skip_without_experiments(ch)
     ops = _ops()
     idx, rank, shape = _level(1, lvl, beams=32 if lvl <= 2 else 64, azim=1250 if lvl <= 2 else 2500)
     n = idx.shape[0]
@@ -119,6 +128,7 @@ def test_ggwin_128_channel_windows_against_the_oracle_and_the_generic_kernel(ord
     27-slot gather kernel (option ggwin = 0).  "shuffled": the same table over randomly numbered rows -- runs far longer than
     the window, i.e. many passes: still exact."""
     ops = _ops()
+    _skip_without_experiments()
     pcd_option("ggwin", 1)                                  # (off by default: 55 us against ggw_kernel's 46, DESIGN.md section 4.3)
     idx, rank, shape = _level(1, 4, beams=64, azim=2500)
     n, ch = idx.shape[0], 128
@@ -163,6 +173,7 @@ def test_ggwin_128_channel_windows_against_the_oracle_and_the_generic_kernel(ord
 def test_window_batchnorm_sums_match_the_generic_kernels(ch, lvl):
     """PcdBnReduce in the window kernel's epilogue: mode 1 (sum y, sum y^2 of the rounded outputs) and mode 2 (sum dz, sum
     dz * xhat with the ReLU mask) against sums taken from the kernel's own output in float64, and against the generic kernel."""
+    _skip_without_experiments(ch)
     ops = _ops()
     idx, rank, shape = _level(1, lvl, beams=32 if lvl <= 2 else 64, azim=1250 if lvl <= 2 else 2500)
     n = idx.shape[0]
@@ -207,6 +218,7 @@ def test_window_multi_pass_tiles_device_row_count_and_tiny_inputs(ch):
     """Rows NOT numbered z-fastest (first-appearance order: every run is far longer than the window) take the multi-pass
     path -- same results as the generic kernel up to rounding ties; a capacity above the real row count with the count in
     device memory; fewer rows than one tile."""
+    _skip_without_experiments(ch)
     ops = _ops()
     from com_amd.hotpath import collate_points
     pts, offs = collate_points([synth.synth_cloud(2, 16, 250)], DEV)
@@ -370,98 +382,6 @@ def test_window_weight_gradient_ignores_the_rows_behind_a_device_side_row_count(
     torch.cuda.synchronize()
     assert bool(torch.isfinite(dw).all())
     assert float((dw - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * np.sqrt(n / 1000.0 + 1.0)
-
-
-@pytest.mark.parametrize("ch,lvl", [(64, 3), (32, 2), (16, 1)])
-def test_batchnorm_folded_into_the_window_launch_is_bit_identical_to_the_separate_pass(ch, lvl, monkeypatch):
-    """PcdBnFold (pcd_sparse_conv_subm_window_bn): the launch applies the training-mode BatchNorm (+ residual) (+ ReLU) behind
-    the conv to the rows each workgroup produced, after a launch-wide barrier on the statistics.  Everything the separate
-    pass leaves -- output, batch statistics, running statistics -- must come out bit for bit: with and without residual /
-    ReLU, with a device-side row count below the capacity, eagerly (the barrier's generation counter advancing from launch
-    to launch) and replayed from a hipGraph."""
-    import torch.nn as nn
-    ops = _ops()
-    monkeypatch.setattr(ops, "BN_FOLD", True)                 # (off by default: correct, but slower than the separate pass)
-    idx, rank, shape = _level(1, lvl, beams=32 if lvl <= 2 else 64, azim=1250 if lvl <= 2 else 2500)
-    n = idx.shape[0]
-    rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False)
-    g = torch.Generator().manual_seed(11)
-    w = (torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))).to(DEV)
-    bias = (torch.randn(ch, generator=g) * 0.1).to(DEV)
-    x = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
-    resid = torch.randn(n, ch, generator=g).to(DEV).to(torch.bfloat16)
-    pw = ops.pack_weight_window(w, 0)
-
-    def make_bn():
-        bn = nn.BatchNorm1d(ch, eps=1e-3, momentum=0.01).to(DEV).train()
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(ch, generator=g) + 0.5)
-            bn.bias.copy_(torch.randn(ch, generator=g) * 0.2)
-            bn.running_mean.copy_(torch.randn(ch, generator=g) * 0.1)
-            bn.running_var.copy_(torch.rand(ch, generator=g) + 0.5)
-        return bn
-
-    def separate(bn, res, relu, rbk, xin):
-        st = ops.BnReduce(1)
-        y = ops.subm_window(xin, pw, bias, rbk, ch, bn_reduce=st)
-        out, m, s = ops.bn_forward(y, res, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, True, bn.running_mean,
-                                   bn.running_var, relu, n_dev=rbk.n_out_dev, partials=(st.partial, st.rows))
-        return y, out, m, s
-
-    def folded(bn, res, relu, rbk, xin):
-        st, fd = ops.BnReduce(1), ops.BnFold(bn, res, relu)
-        y = ops.subm_window(xin, pw, bias, rbk, ch, bn_reduce=st, bn_fold=fd)
-        assert fd.out is not None, "the launch did not fold the BatchNorm"
-        return y, fd.out, fd.save_mean, fd.save_invstd
-
-    def same(a, b, rows, what):
-        for k, (p, q) in enumerate(zip(a, b)):
-            p, q = (p[:rows], q[:rows]) if p.dim() == 2 else (p, q)
-            assert torch.equal(p, q), (what, k, float((p.float() - q.float()).abs().max()))
-
-    for res, relu in ((None, True), (resid, True), (resid, False), (None, False)):
-        bn_a, bn_b = make_bn(), make_bn()
-        bn_b.load_state_dict(bn_a.state_dict())
-        for it in range(3):                                   # (running statistics move from call to call)
-            ra = separate(bn_a, res, relu, rb, x)
-            rf = folded(bn_b, res, relu, rb, x)
-            torch.cuda.synchronize()
-            same(ra, rf, n, (res is not None, relu, it))
-            assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
-        assert float(rf[1].float().abs().max()) > 0.1
-    # capacity above the row count, the count in device memory
-    cap = ((n + 2047) // 1024) * 1024
-    rows = n - 777
-    big = torch.full((cap, 4), 7, dtype=torch.int32, device=DEV)
-    big[:rows] = idx[:rows]
-    n_dev = torch.tensor([rows], dtype=torch.int32, device=DEV)
-    rbc = ops.rulebook_subm(big, 1, shape, want_pairs=False, n_dev=n_dev)
-    xc = torch.randn(cap, ch, generator=g).to(DEV).to(torch.bfloat16)
-    rc = torch.randn(cap, ch, generator=g).to(DEV).to(torch.bfloat16)
-    bn_a, bn_b = make_bn(), make_bn()
-    bn_b.load_state_dict(bn_a.state_dict())
-    ra, rf = separate(bn_a, rc, True, rbc, xc), folded(bn_b, rc, True, rbc, xc)
-    torch.cuda.synchronize()
-    same(ra, rf, rows, "device-side count")
-    assert torch.equal(bn_a.running_var, bn_b.running_var)
-    # replayed from a graph: three replays = three generations of the barrier, statistics moving every time
-    bn_a, bn_b = make_bn(), make_bn()
-    bn_b.load_state_dict(bn_a.state_dict())
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        folded(bn_b, resid, True, rb, x)                      # warm-up (allocations) outside the capture
-        bn_b.load_state_dict(bn_a.state_dict())
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            held = folded(bn_b, resid, True, rb, x)
-    torch.cuda.current_stream().wait_stream(side)
-    for it in range(3):
-        ra = separate(bn_a, resid, True, rb, x)
-        graph.replay()
-        torch.cuda.synchronize()
-        same(ra, held, n, ("graph", it))
-        assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
 
 
 @pytest.mark.parametrize("ch,lvl", [(128, 4), (64, 3)])

@@ -1,9 +1,11 @@
 """ggwin_kernel (128 -> 128 SubM over z-fastest rows: x through windows, weights streamed) against ggw_kernel (27 gather
 slots per row), level 4 of the B = 4 batch, forward and data gradient, isolated launches (HIP events, 50 launches).
-usage: python tools/exp_ggwin.py"""
+usage: make -C com_amd/csrc EXPERIMENTS=1 && python tools/exp_ggwin.py"""
 import sys, torch
 sys.path.insert(0, '.')
 from com_amd import ops, hotpath, _lib as L
+from com_amd import _lib as _L
+_L.use_experiments_library()          # (make -C com_amd/csrc EXPERIMENTS=1)
 sys.path.insert(0, 'tools')
 import env_switches
 env_switches.apply()

@@ -1,9 +1,11 @@
 """pconv_kernel (pair-driven strided conv) against the gather kernels on the level-1 -> 2 conv of the B = 4 batch: forward
 16 -> 32 (gather_gemm_kernel<2,2,1,0>) and data gradient 32 -> 16 (gather_gemm_cls_kernel<2,2>), isolated launches.
-usage: python tools/exp_pconv.py"""
+usage: make -C com_amd/csrc EXPERIMENTS=1 && python tools/exp_pconv.py"""
 import sys, torch
 sys.path.insert(0, '.')
 from com_amd import ops, hotpath
+from com_amd import _lib as _L
+_L.use_experiments_library()          # (make -C com_amd/csrc EXPERIMENTS=1)
 sys.path.insert(0, 'tools')
 import env_switches
 env_switches.apply()
