@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pcd_subm_window_set_trace": (_i, [_vp]),
     "pcd_subm_window_plan_bytes": (_sz, [_i, _i, _i]),
     "pcd_subm_window_plan": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "pcd_subm_window_plan_cm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp, _i, _vp, _vp]),
     "pcd_subm_window_packed_weight_bytes": (_sz, [_i, _i]),
     "pcd_subm_window_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pcd_subm_window_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),

@@ -29,6 +29,7 @@
 #include "common.h"
 #include "bn_mid.h"
 #include "bnred.h"
+#include "colmap_common.h"      // column-map lookups: window plans built straight from a level's map (cm_win_plan_kernel)
 
 namespace {
 
@@ -192,9 +193,12 @@ static inline auto win_dispatch(int c_in, int c_out, F &&f, N none) -> decltype(
 // an over-long run that a later pass covers).  A reader of channels 8 c .. 8 c + 7 takes slot entry ^ c: two instructions
 // between the table and the LDS address.  The kernel DMAs a tile's table straight into LDS.  The data gradient reads the SAME
 // table: its k flip is in the packed weights (win_pack_one).  One wave per tile.
-template <class C>
-__global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict__ nbr, int nbr_stride, int n_cap,
-                                                       const int32_t *__restrict__ n_dev, char *__restrict__ plan_base, int ntiles_cap) {
+// `src(row, live, v)` delivers the 27 neighbour rows of `row` (-1 = none): from the rulebook table (win_plan_kernel) or straight
+// from the level's column map (cm_win_plan_kernel: no table is read -- and none written, except `nbr_out` columns of the tiles
+// that need a second pass, which is where the conv kernels look neighbours up again; nbr_full: the whole table).
+template <class C, class Src>
+__device__ __forceinline__ void win_plan_body(Src src, int n_cap, const int32_t *__restrict__ n_dev, char *__restrict__ plan_base,
+                                              int ntiles_cap, int32_t *__restrict__ nbr_out, int nbr_full) {
     constexpr int T = C::T, R = C::R;
     constexpr int TPW = T >= 64 ? 1 : 64 / T;            // tiles per wave (T < 64: every T lanes one tile)
     constexpr int U = T >= 64 ? T / 64 : 1;              // rows per lane
@@ -209,8 +213,7 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int row = tile * T + u * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) v[u][k] = row < n ? nbr[(size_t)k * nbr_stride + row] : -1;
+        src(row, row < n, v[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -260,6 +263,81 @@ __global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict
         for (int c = 0; c < 4; ++c)
             *reinterpret_cast<uint4 *>(tab + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
     }
+    if (nbr_out && (nbr_full || passes > 1)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = tile * T + u * 64 + lane;
+            if (row < n) {
+#pragma unroll
+                for (int k = 0; k < 27; ++k) nbr_out[(size_t)k * n_cap + row] = v[u][k];
+            }
+        }
+    }
+}
+
+struct WinSrcTable {          // neighbours from the rulebook table nbr[27][stride]
+    const int32_t *__restrict__ nbr;
+    int stride;
+    __device__ __forceinline__ void operator()(int row, bool live, int (&v)[27]) const {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = live ? nbr[(size_t)k * stride + row] : -1;
+    }
+};
+
+struct WinSrcColmap {         // neighbours from the level's column map: nine column lookups serve the 27 offsets (colmap.hip: cm_subm_kernel)
+    const int4 *__restrict__ idx;
+    const uint2 *__restrict__ cw;
+    const uint4 *__restrict__ cr;
+    int D, H, W, P, ncol_cap, n;
+    __device__ __forceinline__ void operator()(int row, bool live, int (&v)[27]) const {
+        const int4 c = live ? idx[row] : make_int4(0, 0, 0, 0);
+        uint2 w[9];
+        u32 key[9];
+        bool in[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int y = c.z + q / 3 - 1, x = c.w + q % 3 - 1;
+            in[q] = live && y >= 0 && y < H && x >= 0 && x < W;
+            key[q] = in[q] ? bev_key(c.x, y, x, H, P) : 0u;
+            w[q] = cw[key[q] >> 5];
+        }
+        uint4 r[9];
+        bool hit[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int col = in[q] ? cm_col(w[q], key[q], ncol_cap) : -1;
+            hit[q] = col >= 0;
+            r[q] = cr[hit[q] ? col : 0];
+        }
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int z = c.y + dz - 1;
+                int rw = -1;
+                if (hit[q] && z >= 0 && z < D) {
+                    rw = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, z);
+                    if (rw >= n) rw = -1;
+                }
+                if (dz * 9 + q == 13 && live) rw = row;
+                v[dz * 9 + q] = rw;
+            }
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void win_plan_kernel(const int32_t *__restrict__ nbr, int nbr_stride, int n_cap,
+                                                       const int32_t *__restrict__ n_dev, char *__restrict__ plan_base, int ntiles_cap) {
+    win_plan_body<C>(WinSrcTable{nbr, nbr_stride}, n_cap, n_dev, plan_base, ntiles_cap, nullptr, 0);
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void cm_win_plan_kernel(const int4 *__restrict__ idx, int n_cap, const int32_t *__restrict__ n_dev,
+                                                          int D, int H, int W, int P, const uint2 *__restrict__ cw,
+                                                          const uint4 *__restrict__ cr, int ncol_cap, char *__restrict__ plan_base,
+                                                          int ntiles_cap, int32_t *__restrict__ nbr_out, int nbr_full) {
+    win_plan_body<C>(WinSrcColmap{idx, cw, cr, D, H, W, P, ncol_cap, eff_rows(n_dev, n_cap)}, n_cap, n_dev, plan_base, ntiles_cap,
+                     nbr_out, nbr_full);
 }
 
 // ---- shares: the tiles dealt to the WIN_GRID persistent workgroups in contiguous runs of EQUAL COST ------------------------
@@ -1304,6 +1382,35 @@ extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_ca
         using C = decltype(c);
         const int nt = pcd_div_up(n_cap, C::T);
         win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
+        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid());
+        return 0;
+    }, 0);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+// The plan of a SubM 3x3x3 level built STRAIGHT from its column map (rows z-fastest): what pcd_rulebook_subm_cm +
+// pcd_subm_window_plan produce together, without the 27 x 4 B per row of the neighbour table in between.  nbr [27][n_cap]:
+// nbr_full != 0 -- the whole table is written as well (for consumers that read it: generic kernels, pair lists); nbr_full == 0 --
+// only the columns of tiles that need a second pass (a run longer than the window), which is all the window kernels ever read.
+extern "C" int pcd_subm_window_plan_cm(const int32_t *indices, int n_cap, const int32_t *n_dev, int batch, const int *shape_host,
+                                       const void *colmap, size_t colmap_bytes, int colmap_cap, int c_in, int c_out,
+                                       int32_t *nbr, int nbr_full, void *plan, void *stream) {
+    PCD_ENTER();
+    if (n_cap < 0 || batch <= 0 || !shape_host || !win_supported(c_in, c_out)) return PCD_ERR_INVALID_ARG;
+    if (shape_host[0] <= 0 || shape_host[0] > 62) return PCD_ERR_UNSUPPORTED;
+    if (n_cap == 0) return PCD_OK;
+    if (!indices || !colmap || !plan || !nbr) return PCD_ERR_INVALID_ARG;
+    CmBuf B;
+    if (!cm_carve(const_cast<void *>(colmap), colmap_bytes, batch, shape_host[1], shape_host[2], colmap_cap, B, nullptr))
+        return PCD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    win_dispatch(c_in, c_out, [&](auto c) {
+        using C = decltype(c);
+        const int nt = pcd_div_up(n_cap, C::T);
+        cm_win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(
+            (const int4 *)indices, n_cap, n_dev, shape_host[0], shape_host[1], shape_host[2], B.pitch, B.cw, B.cr, B.ncol_cap,
+            (char *)plan, nt, nbr, nbr_full);
         win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid());
         return 0;
     }, 0);

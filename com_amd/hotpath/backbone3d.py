@@ -89,7 +89,10 @@ class _RulebookPrefetcher:
             t = self.t
             built = []
             for conv in unit:
+                if conv.subm:
+                    t.indice_dict["__subm_hint__"] = self._subm_hint(conv, unit, t)
                 rb, out_idx, out_shape = conv._rulebook(t)
+                t.indice_dict.pop("__subm_hint__", None)
                 if getattr(rb, "ready_event", None) is None:
                     built.append(rb)
                     self._window_plan(conv, rb)
@@ -136,6 +139,23 @@ class _RulebookPrefetcher:
             if after_stream is not None:
                 side.wait_stream(after_stream)
             hook()
+
+    @staticmethod
+    def _subm_hint(conv, unit, t):
+        """(window width or None, neighbour table needed) for the SubM rulebook `conv` is about to build: all SubM convs of the
+        unit with its kernel share that rulebook (SparseConvolution._rulebook), so the table is only needed if one of them
+        runs outside the window kernels -- forward / data gradient (window_capable) or, when autograd will run, the weight
+        gradient (option "subm_window_wgrad")."""
+        group = [c for c in unit if c.subm and tuple(c.kernel_size) == tuple(conv.kernel_size)
+                 and tuple(c.dilation) == tuple(conv.dilation)]
+        widths = {c.in_channels for c in group if c.window_capable()}
+        if len(widths) != 1:
+            return None, True
+        w = widths.pop()
+        bf16 = t.features.dtype == torch.bfloat16
+        tables = not bf16 or any(not c.window_capable() or getattr(c, "fp8_train", None) is not None
+                                 or (c._needs_backward(t) and not Fsp._window_wgrad(c.in_channels)) for c in group)
+        return w, tables
 
     @staticmethod
     def _pair_plan(conv, rb):

@@ -471,13 +471,37 @@ class Rulebook:
         self.subm, self.kvol, self.n_in, self.n_out = subm, kvol, n_in, n_out
         # device-side row counts (static-shape mode): n_in / n_out are then capacities
         self.n_in_dev, self.n_out_dev = n_in_dev, n_out_dev
-        self.nbr_out, self.nbr_in, self._pairs, self._pair_num = nbr_out, nbr_in, pairs, pair_num
+        self._nbr_out, self._finish_tables = nbr_out, None
+        self.nbr_in, self._pairs, self._pair_num = nbr_in, pairs, pair_num
         self.out_indices = out_indices
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.rank = None          # RankMap of the output level (strided builds only)
         self.order = None         # ROWS_* of the output rows when they are key-numbered (strided / rank-map builds)
         self.classes = None       # (perm, vstart, vcap): input rows grouped by stride-parity class (strided, training)
+
+    # nbr_out is the COMPLETE neighbour table.  A SubM rulebook of a level whose convs all run on window tiles is built without it
+    # (rulebook_subm(..., window=, nbr_tables=False): the plan comes straight from the column map and only the columns of
+    # multi-pass tiles are written): the first reader of `nbr_out` then finishes the table -- one more launch, same values -- so
+    # a consumer outside the window kernels is slower, never wrong.  The window ops read `nbr_buffer` (whatever is there).
+    @property
+    def nbr_out(self):
+        if self._finish_tables is not None:
+            fn, self._finish_tables = self._finish_tables, None
+            fn()
+        return self._nbr_out
+
+    @nbr_out.setter
+    def nbr_out(self, value):
+        self._nbr_out, self._finish_tables = value, None
+
+    @property
+    def nbr_buffer(self):
+        return self._nbr_out
+
+    @property
+    def nbr_complete(self):
+        return self._finish_tables is None
 
     def _lazy_pairs(self):
         # a SubM rulebook built without pairs (only kernels that read nbr have used it so far): derive them now
@@ -578,9 +602,12 @@ def colmap_from_rows(indices, batch_size, spatial_shape, n_dev=None, out=None):
 
 
 def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=True, pad_pairs=False,
-                  n_dev=None, rank=None):
+                  n_dev=None, rank=None, window=None, nbr_tables=True):
     """`rank`: the RankMap of the strided build whose out_indices these `indices` are -- the rulebook is then
-    derived from the bitmap ranks (no hash table); results are identical."""
+    derived from the bitmap ranks (no hash table); results are identical.
+    `window` = (c_in, c_out) (ColumnMap ranks, 3x3x3, no pair lists): the window plan of those widths is built in the SAME pass,
+    straight from the column map (pcd_subm_window_plan_cm), and cached on the rulebook; with `nbr_tables=False` the neighbour
+    table is not materialised at all (Rulebook.nbr_out finishes it on first use)."""
     _require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous() and indices.shape[1] == 4
     dev = indices.device
@@ -595,13 +622,34 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
         p_ = int((nbr >= 0).sum().item())
         return dict(bytes=16 * n + 8 * p_, flops=0, rows=n, pairs=p_)
 
+    win_plan = finish = None
     if isinstance(rank, ColumnMap) and rank.matches(indices, shp, ks) and dl == [1, 1, 1]:
-        ws = _ws(lib.pcd_rulebook_subm_cm_workspace_bytes(n), dev)
-        with _Timed("rulebook_subm_cm", meta):
+        def full_table():
+            ws = _ws(lib.pcd_rulebook_subm_cm_workspace_bytes(n), dev)
             L.check(lib.pcd_rulebook_subm_cm(L.ptr(indices), n, batch_size, L.host_i32(shp), L.ptr(rank.buf),
                                              rank.buf.numel(), rank.cap, L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num),
                                              int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
                     "pcd_rulebook_subm_cm")
+        T = subm_window_tile_rows(*window) if (window is not None and not want_pairs and n > 0) else 0
+        if T > 0:
+            # plan (+ table, or only the multi-pass tiles' columns of it) in one pass over the column map
+            win_plan = (T, torch.empty((max(int(lib.pcd_subm_window_plan_bytes(n, int(window[0]), int(window[1]))), 32),),
+                                       dtype=torch.uint8, device=dev))
+
+            def meta_plan():                     # (the table is not there to be counted: a full build on the side, profiling only)
+                tmp = rulebook_subm(indices, batch_size, spatial_shape, ksize, dilation, want_pairs=False, n_dev=n_dev, rank=rank)
+                p_ = int((tmp.nbr_out >= 0).sum().item())
+                return dict(bytes=16 * n + 8 * p_, flops=0, rows=n, pairs=p_)
+            with _Timed("rulebook_subm_cm", meta_plan):
+                L.check(lib.pcd_subm_window_plan_cm(L.ptr(indices), n, L.ptr(n_dev), batch_size, L.host_i32(shp), L.ptr(rank.buf),
+                                                    rank.buf.numel(), rank.cap, int(window[0]), int(window[1]), L.ptr(nbr),
+                                                    int(bool(nbr_tables)), L.ptr(win_plan[1]), L.stream_ptr()),
+                        "pcd_subm_window_plan_cm")
+            if not nbr_tables:
+                finish = full_table
+        else:
+            with _Timed("rulebook_subm_cm", meta):
+                full_table()
     elif isinstance(rank, RankMap) and rank.matches(indices, shp, ks):
         ws = _ws(lib.pcd_rulebook_subm_ranked_workspace_bytes(n, K), dev)
         with _Timed("rulebook_subm_ranked", meta):
@@ -621,6 +669,9 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     if rank is not None and rank.matches(indices, shp, ks):
         rb.order = rank.order
         rb.rank = rank
+    if win_plan is not None:
+        rb.__dict__.setdefault("_win_plans", {})[win_plan[0]] = win_plan[1]
+    rb._finish_tables = finish
     return rb
 
 
@@ -1140,7 +1191,7 @@ def subm_window_plan(rb, c_in, c_out):
     cache = rb.__dict__.setdefault("_win_plans", {})
     if T not in cache:
         lib = L.lib()
-        n = rb.nbr_out.shape[1]
+        n = rb.nbr_out.shape[1]                  # (a plan of another tile size than the one the build made: from the table)
         plan = torch.empty((max(int(lib.pcd_subm_window_plan_bytes(n, int(c_in), int(c_out))), 32),), dtype=torch.uint8,
                            device=rb.nbr_out.device)
         L.check(lib.pcd_subm_window_plan(L.ptr(rb.nbr_out), n, n, L.ptr(rb.n_out_dev), int(c_in), int(c_out), L.ptr(plan),
@@ -1173,8 +1224,8 @@ def subm_window_f32(x, packed_w, bias, rb, c_out, addend=None):
     plan = subm_window_plan(rb, c_in, c_out)
     y = torch.empty((n, c_out), dtype=torch.bfloat16, device=x.device)
     y32 = torch.zeros((n, c_out), dtype=torch.float32, device=x.device)
-    L.check(L.lib().pcd_sparse_conv_subm_window_f32(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
-                                                    rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan), c_out, L.ptr(y),
+    L.check(L.lib().pcd_sparse_conv_subm_window_f32(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_buffer),
+                                                    rb.nbr_buffer.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan), c_out, L.ptr(y),
                                                     L.ptr(y32), L.ptr(addend), L.stream_ptr()),
             "pcd_sparse_conv_subm_window_f32")
     return y, y32
@@ -1187,7 +1238,7 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     _require_cuda(x, packed_w)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and rb.subm and rb.kvol == 27
     n, c_in = x.shape
-    assert n == rb.nbr_out.shape[1]
+    assert n == rb.nbr_buffer.shape[1]
     plan = subm_window_plan(rb, c_in, c_out)
     y = torch.empty((n, c_out), dtype=torch.bfloat16, device=x.device)
     if addend is not None:
@@ -1202,8 +1253,8 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     if bn_reduce is not None:
         bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows()), c_out, x.device)
     with _Timed(f"subm_win_kernel<{c_in}> {c_in}->{c_out} K=27", meta):
-        L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_out),
-                                                    rb.nbr_out.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
+        L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_buffer),
+                                                    rb.nbr_buffer.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
                                                     c_out, L.ptr(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
                 "pcd_sparse_conv_subm_window")
     return y
@@ -1215,7 +1266,7 @@ def subm_window_wgrad(x, dy, rb, out=None, defer=None):
     (appended to `defer` when given, run here otherwise)."""
     _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
-    assert x.shape == dy.shape and rb.subm and rb.kvol == 27 and x.shape[0] == rb.nbr_out.shape[1]
+    assert x.shape == dy.shape and rb.subm and rb.kvol == 27 and x.shape[0] == rb.nbr_buffer.shape[1]
     n, c = x.shape
     lib = L.lib()
     plan = subm_window_plan(rb, c, c)
@@ -1228,7 +1279,7 @@ def subm_window_wgrad(x, dy, rb, out=None, defer=None):
         return dict(bytes=2 * n * c * 2 + 8 * pairs + 27 * c * c * 4, flops=2 * pairs * c * c, rows=n, pairs=pairs)
 
     with _Timed(f"subm_wgrad_win_kernel<{c}> {c}x{c} K=27", meta):
-        L.check(lib.pcd_sparse_conv_subm_window_wgrad(L.ptr(x), L.ptr(dy), n, c, L.ptr(rb.nbr_out), rb.nbr_out.shape[1],
+        L.check(lib.pcd_sparse_conv_subm_window_wgrad(L.ptr(x), L.ptr(dy), n, c, L.ptr(rb.nbr_buffer), rb.nbr_buffer.shape[1],
                                                       L.ptr(rb.n_out_dev), L.ptr(plan), L.ptr(slab), slab.numel(),
                                                       L.stream_ptr()), "pcd_sparse_conv_subm_window_wgrad")
     job = (slab, dw, 27, c, c, 0, splits)

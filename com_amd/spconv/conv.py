@@ -179,9 +179,19 @@ class SparseConvolution(SparseModule):
                 if not lazy and self.window_capable() and x.indice_dict.get("__row_order__", ops.ROWS_ZYX) == ops.ROWS_YXZ:
                     from .functional import _window_wgrad
                     lazy = _window_wgrad(self.in_channels)
+                # z-fastest rows with a column map: the window plan comes out of the same pass as the rulebook; a caller that
+                # knows ALL consumers of this rulebook (the backbones' prefetcher: indice_dict["__subm_hint__"] = (width,
+                # tables needed)) can drop the neighbour table altogether -- alone, a layer keeps it for the others
+                hint = x.indice_dict.pop("__subm_hint__", None)
+                win_c, tables = (self.in_channels if self.window_capable() else None), True
+                if hint is not None:
+                    win_c, tables = hint
+                if x.indice_dict.get("__row_order__", ops.ROWS_ZYX) != ops.ROWS_YXZ:
+                    win_c, tables = None, True
                 rb = ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
                                        self.dilation, n_dev=x.num_rows, rank=rank,
-                                       want_pairs=self._needs_backward(x) and not lazy)   # (inference never needs them)
+                                       want_pairs=self._needs_backward(x) and not lazy,   # (inference never needs them)
+                                       window=(win_c, win_c) if win_c else None, nbr_tables=tables)
                 x.indice_dict[gkey] = (rb, x.indices, list(x.spatial_shape))
             out_idx, out_shape = x.indices, x.spatial_shape
         else:

@@ -973,6 +973,16 @@ int pcd_subm_window_set_trace(void *buf256_u64);
 size_t pcd_subm_window_plan_bytes(int n_cap, int c_in, int c_out);
 int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_cap, const int32_t *n_dev, int c_in, int c_out,
                          void *plan, void *stream);
+/* The same plan built STRAIGHT from the level's column map (rows numbered PCD_ROWS_YXZ; `indices` [n_cap][4], colmap as handed
+ * out by pcd_voxelize_hard_yxz / pcd_rulebook_conv_cm_* / pcd_colmap_from_rows) -- what pcd_rulebook_subm_cm + pcd_subm_window_plan
+ * produce together, in ONE pass and without the 27 x 4 B per row of neighbour table in between (spconv_backbone.py:38-45,199-218:
+ * the SubM rulebooks of levels whose convs all run on window tiles).  nbr [27][n_cap] must be a buffer of that size:
+ *   nbr_full != 0  the complete table is written too (bit-identical to pcd_rulebook_subm_cm's), for consumers that read it;
+ *   nbr_full == 0  only the columns of tiles whose run exceeds the window (header.passes > 1) are written -- all that
+ *                  pcd_sparse_conv_subm_window / _wgrad ever read of it; the rest of the buffer is left untouched. */
+int pcd_subm_window_plan_cm(const int32_t *indices, int n_cap, const int32_t *n_dev, int batch, const int *shape_host,
+                            const void *colmap, size_t colmap_bytes, int colmap_cap, int c_in, int c_out, int32_t *nbr,
+                            int nbr_full, void *plan, void *stream);
 size_t pcd_subm_window_packed_weight_bytes(int c_in, int c_out);
 int pcd_subm_window_pack_weight(const float *weight, int c_in, int c_out, int mode, void *packed, void *stream);
 int pcd_subm_window_pack_weights_batched(const void *table, int n, int total_blocks, void *stream);

@@ -45,7 +45,8 @@ def test_experiment_kernels_stay_out_of_the_default_library():
         assert not hasattr(default, name), f"{name} is an experiment: it must not be in the default library"
     default.pcd_subm_window_tile_rows.restype = ctypes.c_int
     assert default.pcd_subm_window_tile_rows(128, 128) == 0 and default.pcd_subm_window_tile_rows(64, 64) > 0
-    if os.path.exists(_lib.EXPERIMENTS_LIB_PATH):
+    # (the optional build, when it is there and not older than the default one)
+    if os.path.exists(_lib.EXPERIMENTS_LIB_PATH) and os.path.getmtime(_lib.EXPERIMENTS_LIB_PATH) >= os.path.getmtime(_lib.LIB_PATH):
         exp = ctypes.CDLL(_lib.EXPERIMENTS_LIB_PATH)
         for name in declared + _declared_symbols():
             assert hasattr(exp, name), name

@@ -59,6 +59,7 @@ def timed(fn, reps=10):
     return out, e0.elapsed_time(e1) / reps * 1e-3
 
 
+AS_BUILT_FREE = {int(v) for v in os.environ.get('PCD_REGIME_FREE', '2').split(',') if v}    # levels built without a neighbour table
 for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     frames = [synth.synth_cloud(f) for f in range(B)]
     pts, offs = hotpath.collate_points(frames, dev)
@@ -68,7 +69,7 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     ORDER = ops.ROW_ORDERS[os.environ.get('PCD_ROW_ORDER', 'yxz')]
     idx, shape = res['coords'], [41, 1504, 1504]
     rows = []
-    tot_bytes = tot_t = tot_g = tot_step = 0.0
+    tot_bytes = tot_t = tot_g = tot_step = tot_tables = 0.0
     rank = res.get('rank', None)       # key-ordered rows: the voxeliser's coordinate -> row map serves level 1
     geos = [None, (3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)]
     for lvl, geo in enumerate(geos):
@@ -82,7 +83,7 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
             rows.append(dict(kind="strided" + ("_cm" if isinstance(rbc.rank, ops.ColumnMap) else ""), level=lvl + 1, n_in=n_in, n_out=int(rbc.out_indices.shape[0]), pairs=P,
                              us=round(t * 1e6, 1), graph_us=round(tg * 1e6, 1), alg_MB=round(by / 1e6, 1),
                              GBps=round(by / t / 1e9, 1), graph_GBps=round(by / tg / 1e9, 1)))
-            tot_bytes += by; tot_t += t; tot_g += tg; tot_step += tg
+            tot_bytes += by; tot_t += t; tot_g += tg; tot_step += tg; tot_tables += tg
             idx, shape, rank = rbc.out_indices, rbc.out_shape, rbc.rank
         if lvl < 4:
             n = idx.shape[0]
@@ -92,17 +93,31 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
             tg = timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank), None, 0)
             # as the training step builds it: the 16 / 32-channel levels run their weight gradient over the window tiles and
             # need no pair lists (hotpath/backbone3d.py, spconv/conv.py::_rulebook)
-            tgs = tg if lvl >= 2 else timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=False), None, 0)
+            # ... and their window PLAN comes out of the same pass, straight from the column map (round 6: pcd_subm_window_plan_cm);
+            # where every conv of the level runs on window tiles (AS_BUILT_FREE: level 2, and level 1 once conv_input does) no
+            # neighbour table is written at all.  (Until round 5 the as-built figure was the table build alone, WITHOUT the plan
+            # kernels that followed it: `as_built_tables_us`.)
+            if lvl >= 2 or not isinstance(rank, ops.ColumnMap):
+                tgs = tgt = tg
+            else:
+                ch = 16 << lvl
+                tgt = timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=False), None, 0)
+                free = (lvl + 1) in AS_BUILT_FREE
+                tgs = timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank, want_pairs=False, window=(ch, ch),
+                                                            nbr_tables=not free), None, 0)
             tot_step += tgs
+            tot_tables += tgt
             rows.append(dict(kind="subm" + ("_cm" if isinstance(rank, ops.ColumnMap) else "_ranked" if rank is not None else "_hash"), level=lvl + 1, n_in=n, pairs=P, us=round(t * 1e6, 1),
                              graph_us=round(tg * 1e6, 1), alg_MB=round(by / 1e6, 1), GBps=round(by / t / 1e9, 1),
-                             graph_GBps=round(by / tg / 1e9, 1)))
+                             graph_GBps=round(by / tg / 1e9, 1), as_built_us=round(tgs * 1e6, 1), as_built_tables_us=round(tgt * 1e6, 1)))
             tot_bytes += by; tot_t += t; tot_g += tg
     print(json.dumps(dict(frames=B, rulebook_chain_us=round(tot_t * 1e6, 1), rulebook_chain_graph_us=round(tot_g * 1e6, 1),
                           alg_MB=round(tot_bytes / 1e6, 1),
                           achieved_GBps=round(tot_bytes / tot_t / 1e9, 1), frac_of_8TBps=round(tot_bytes / tot_t / 8e12, 4),
                           graph_GBps=round(tot_bytes / tot_g / 1e9, 1), graph_frac_of_8TBps=round(tot_bytes / tot_g / 8e12, 4),
                           as_built_chain_graph_us=round(tot_step * 1e6, 1), as_built_frac_of_8TBps=round(tot_bytes / tot_step / 8e12, 4),
+                          as_built_free_levels=sorted(AS_BUILT_FREE),
+                          as_built_tables_chain_graph_us=round(tot_tables * 1e6, 1),
                           builds=rows)), flush=True)
     del frames, pts, res, idx
     torch.cuda.empty_cache()
