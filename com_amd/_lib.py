@@ -224,7 +224,7 @@ class PcdWgradReduceJob(ctypes.Structure):
     """include/pcd_ops.h: struct PcdWgradReduceJob."""
     _fields_ = [("workspace", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("kvol", ctypes.c_int),
                 ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("pmax", ctypes.c_int), ("splits", ctypes.c_int),
-                ("layout", ctypes.c_int), ("cout_write", ctypes.c_int)]
+                ("layout", ctypes.c_int), ("cout_write", ctypes.c_int), ("cin_write", ctypes.c_int)]
 
 
 WGRAD_MAX_JOBS = 32

@@ -1592,7 +1592,7 @@ constexpr int WGRAD_OS_ROWS = 1024;     // output rows per workgroup (= per slab
 template <int V>   // V = 4: four consecutive elements per thread (16-byte loads), n % 4 == 0;  V = 1: scalar
 __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int splits, size_t n,
                                                   float *__restrict__ dw, unsigned block, float *lds,
-                                                  int tr_k = 0, int tr_cin = 0, size_t stride = 0) {
+                                                  int tr_k = 0, int tr_cin = 0, size_t stride = 0, int cin_dst = 0) {
     // n = elements to reduce and write (a PREFIX of every slab when only the first output channels are real),
     // stride = elements between two slabs (0: n)
     if (stride == 0) stride = n;
@@ -1641,7 +1641,16 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab
 #pragma unroll
             for (int t = 1; t < 8; ++t) r[j] += part[t][el][j];
         }
-        if (tr_k > 0) {
+        if (cin_dst > 0) {
+            // the slabs carry tr_cin input channels per (co, k), the parameter only the first cin_dst (a layer run on zero-padded
+            // input rows): element e = (co K + k) tr_cin + ci -> (co K + k) cin_dst + ci, ci < cin_dst
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const size_t ej = e + j;
+                const size_t ci = ej % (size_t)tr_cin, t = ej / (size_t)tr_cin;
+                if (ci < (size_t)cin_dst) dw[t * cin_dst + ci] = r[j];
+            }
+        } else if (tr_k > 0) {
             // nn.Conv2d parameter layout [cout][cin][K] instead of [cout][K][cin] (the dense 3x3 convs of the BEV stack
             // write their gradient straight into .grad): element e = (co K + k) cin + ci -> (co cin + ci) K + k
 #pragma unroll
@@ -1675,6 +1684,7 @@ struct RedJobs {
         int splits, vec;
         unsigned first_block;
         int tr_k, tr_cin;        // > 0: write [cout][cin][K]
+        int cin_dst;             // > 0: dw has cin_dst < tr_cin input channels per (co, k)
     } job[PCD_WGRAD_MAX_JOBS];
     int n_jobs;
 };
@@ -1689,10 +1699,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(RedJobs J) {
         wgrad_tiles_reduce_body(J.job[j].slab, (int)J.job[j].n, J.job[j].dw, block, J.job[j].tr_k);
     else if (J.job[j].vec)
         wgrad_reduce_body<4>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
-                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride);
+                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride, J.job[j].cin_dst);
     else
         wgrad_reduce_body<1>(J.job[j].slab, J.job[j].splits, (size_t)J.job[j].n, J.job[j].dw, block, lds,
-                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride);
+                             J.job[j].tr_k, J.job[j].tr_cin, (size_t)J.job[j].stride, J.job[j].cin_dst);
 }
 
 // splits = ranges of INPUT rows (pmax = number of input rows = row stride of `pairs`)
@@ -2081,7 +2091,8 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
     for (int i = 0; i < n_jobs; ++i) {
         const PcdWgradReduceJob &q = jobs_host[i];
         if (q.kvol <= 0 || q.cin <= 0 || q.cout <= 0 || q.pmax < 0 || !q.dweight || (q.layout != 0 && q.layout != 1) ||
-            q.cout_write < 0 || q.cout_write > q.cout)
+            q.cout_write < 0 || q.cout_write > q.cout || q.cin_write < 0 || q.cin_write > q.cin ||
+            (q.cin_write > 0 && q.cin_write < q.cin && (q.layout != 0 || q.splits <= 0)))
             return PCD_ERR_INVALID_ARG;
         if (q.pmax == 0 && q.splits <= 0) continue;   // pcd_sparse_conv_wgrad already zeroed dweight
         if (!q.workspace) return PCD_ERR_WORKSPACE;
@@ -2106,6 +2117,7 @@ extern "C" int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *job
         const size_t n = q.cout_write > 0 ? (size_t)q.cout_write * q.kvol * q.cin : stride;   // real rows = a slab prefix
         const bool vec = (n & 3) == 0 && (stride & 3) == 0 && (((uintptr_t)q.dweight | (uintptr_t)q.workspace) & 15u) == 0;
         auto &d = J.job[J.n_jobs++];
+        d.cin_dst = (q.cin_write > 0 && q.cin_write < q.cin) ? q.cin_write : 0;
         d.slab = (const float *)q.workspace;
         d.dw = q.dweight;
         d.n = n;

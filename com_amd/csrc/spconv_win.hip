@@ -415,8 +415,10 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
 // k = oq * OPW + j (zeros for k >= 27).  mode 0: forward, weight [c_out][K][c_in]; mode 1: data gradient -- the contraction runs
 // over the forward's OUTPUT channels and the k-flipped rulebook view, dx[i] = sum_k dy[nbr[26 - k][i]] W_k^T = sum_k' dy[nbr[k'][i]]
 // W_{26-k'}^T: the flip goes into the pack, W_k[co][ci] := weight[ci][26 - k][co], and the launch reads the table as it is.
+// cin_real < CIN (mode 0 only): the weight has cin_real input channels, the layer runs on rows zero-padded to CIN channels
+// (conv_input of the backbones, 5 -> 16: spconv_backbone.py:191-195) -- the missing channels are packed as zeros.
 template <class C>
-__device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mode, size_t e, unsigned short *out) {
+__device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mode, size_t e, unsigned short *out, int cin_real = C::CIN) {
     const int j8 = (int)(e & 7), lane = (int)((e >> 3) & 63);
     size_t t = e >> 9;
     const int ks = (int)(t % C::KS);
@@ -427,30 +429,32 @@ __device__ __forceinline__ void win_pack_one(const float *__restrict__ w, int mo
     const int k = oq * C::OPW + j;
     const int co = 32 * cb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j8;
     float v = 0.0f;
-    if (k < 27 && co < C::COUT) v = mode == 0 ? w[((size_t)co * 27 + k) * C::CIN + ci] : w[((size_t)ci * 27 + (26 - k)) * C::COUT + co];
+    if (k < 27 && co < C::COUT)
+        v = mode == 0 ? (ci < cin_real ? w[((size_t)co * 27 + k) * cin_real + ci] : 0.0f) : w[((size_t)ci * 27 + (26 - k)) * C::COUT + co];
     out[e] = f32_to_bf16_bits(v);
 }
 template <class C>
 constexpr size_t win_pack_elems() { return (size_t)C::NCBP * C::NOQ * C::OPW * C::KS * 512; }
 
-__device__ __forceinline__ void win_pack_any(const float *__restrict__ w, int cin, int mode, size_t e, unsigned short *out) {
+__device__ __forceinline__ void win_pack_any(const float *__restrict__ w, int cin, int mode, size_t e, unsigned short *out, int cin_real) {
+    if (cin_real <= 0 || cin_real > cin) cin_real = cin;
     if (cin == 64) {
-        if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out);
+        if (e < win_pack_elems<Win64>()) win_pack_one<Win64>(w, mode, e, out, cin_real);
     } else if (cin == 32) {
-        if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out);
+        if (e < win_pack_elems<Win32>()) win_pack_one<Win32>(w, mode, e, out, cin_real);
 #ifdef PCD_EXPERIMENTS
     } else if (cin == 128) {
         if (e < win_pack_elems<Win128>()) win_pack_one<Win128>(w, mode, e, out);
 #endif
     } else {
-        if (e < win_pack_elems<Win16>()) win_pack_one<Win16>(w, mode, e, out);
+        if (e < win_pack_elems<Win16>()) win_pack_one<Win16>(w, mode, e, out, cin_real);
     }
 }
-__global__ __launch_bounds__(256) void win_pack_kernel(const float *__restrict__ w, int cin, int mode, unsigned short *out) {
-    win_pack_any(w, cin, mode, (size_t)blockIdx.x * 256 + threadIdx.x, out);
+__global__ __launch_bounds__(256) void win_pack_kernel(const float *__restrict__ w, int cin, int mode, unsigned short *out, int cin_real) {
+    win_pack_any(w, cin, mode, (size_t)blockIdx.x * 256 + threadIdx.x, out, cin_real);
 }
 
-// table[i] = {weight ptr, packed ptr, c_in, mode, first block, 0, 0, 0}
+// table[i] = {weight ptr, packed ptr, c (= c_out: the kernel configuration), mode, first block, c_in of the weight (0 = c), 0, 0}
 __global__ __launch_bounds__(256) void win_pack_batched_kernel(const long long *__restrict__ table, int n) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void win_pack_batched_kernel(const long long *
     unsigned short *out = (unsigned short *)row[1];
     const int cin = (int)row[2], mode = (int)row[3];
     const size_t e = ((size_t)blockIdx.x - (size_t)row[4]) * 256 + threadIdx.x;
-    win_pack_any(w, cin, mode, e, out);
+    win_pack_any(w, cin, mode, e, out, (int)row[5]);
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -1424,10 +1428,13 @@ extern "C" size_t pcd_subm_window_packed_weight_bytes(int c_in, int c_out) {
 
 extern "C" int pcd_subm_window_pack_weight(const float *weight, int c_in, int c_out, int mode, void *packed, void *stream) {
     PCD_ENTER();
-    if (!weight || !packed || (mode != 0 && mode != 1) || !win_supported(c_in, c_out)) return PCD_ERR_INVALID_ARG;
-    const size_t total = pcd_subm_window_packed_weight_bytes(c_in, c_out) / 2;
-    win_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(weight, c_in, mode,
-                                                                                     (unsigned short *)packed);
+    // c_in < c_out (forward pack only): a layer whose input rows are zero-padded to c_out channels (5 -> 16)
+    if (!weight || !packed || (mode != 0 && mode != 1) || c_in <= 0 || c_in > c_out || (c_in < c_out && mode != 0) ||
+        !win_supported(c_out, c_out))
+        return PCD_ERR_INVALID_ARG;
+    const size_t total = pcd_subm_window_packed_weight_bytes(c_out, c_out) / 2;
+    win_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(weight, c_out, mode,
+                                                                                     (unsigned short *)packed, c_in);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

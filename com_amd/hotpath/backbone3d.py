@@ -148,13 +148,13 @@ class _RulebookPrefetcher:
         gradient (option "subm_window_wgrad")."""
         group = [c for c in unit if c.subm and tuple(c.kernel_size) == tuple(conv.kernel_size)
                  and tuple(c.dilation) == tuple(conv.dilation)]
-        widths = {c.in_channels for c in group if c.window_capable()}
+        widths = {c.out_channels for c in group if c.window_capable()}
         if len(widths) != 1:
             return None, True
         w = widths.pop()
         bf16 = t.features.dtype == torch.bfloat16
         tables = not bf16 or any(not c.window_capable() or getattr(c, "fp8_train", None) is not None
-                                 or (c._needs_backward(t) and not Fsp._window_wgrad(c.in_channels)) for c in group)
+                                 or (c._needs_backward(t) and not Fsp._window_wgrad(c.out_channels)) for c in group)
         return w, tables
 
     @staticmethod

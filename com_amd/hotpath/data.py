@@ -37,7 +37,7 @@ def collate_points(frames, device="cuda"):
 
 def transform_points_to_voxels(batch_dict, point_cloud_range, voxel_size, max_points_per_voxel,
                                max_voxels, fuse_mean=True, keep_voxels=False, bf16_features=False, out=None,
-                               row_order="first", key_depth_extra=1):
+                               row_order="first", key_depth_extra=1, bf16_feature_stride=None):
     """Batched GPU form of data_processor.py:125-153 + collate: consumes batch_dict['points']
     ([sum N, 1+C] with batch index) and batch_dict['frame_offsets'], produces 'voxel_coords' [M,4],
     'voxel_num_points', and either 'voxels' (reference layout) or the fused MeanVFE 'voxel_features'."""
@@ -45,7 +45,10 @@ def transform_points_to_voxels(batch_dict, point_cloud_range, voxel_size, max_po
     res = ops.voxelize_hard(pts, batch_dict['frame_offsets'], point_cloud_range, voxel_size,
                             max_points_per_voxel, max_voxels, feat_offset=1, num_features=pts.shape[1] - 1,
                             want_voxels=keep_voxels or not fuse_mean, want_mean=fuse_mean and not bf16_features,
-                            mean_bf16_stride=ops.pow2_ge8(pts.shape[1] - 1) if (fuse_mean and bf16_features) else 0,
+                            # (bf16_feature_stride: channels of the bf16 MeanVFE rows, zero-padded -- 16 when the first conv runs
+                            #  on the window tiles, which want rows of its OUTPUT width; default: the next power of two >= 8)
+                            mean_bf16_stride=(int(bf16_feature_stride) if bf16_feature_stride else ops.pow2_ge8(pts.shape[1] - 1))
+                            if (fuse_mean and bf16_features) else 0,
                             out=out, row_order=row_order,
                             # (the 3D backbones' sparse_shape = grid_size[::-1] + [1, 0, 0], spconv_backbone.py:87,187)
                             key_depth=(ops.grid_size(point_cloud_range, voxel_size)[2] + key_depth_extra)

@@ -1047,10 +1047,11 @@ class PackPlan:
             cout, cin = w.shape[0], w.shape[-1]
             K = w.numel() // (cout * cin)
             if mode >= 2:
-                nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cin, cout))
-                assert nbytes > 0 and K == 27
+                # (cin < cout: a layer run on input rows zero-padded to cout channels -- forward pack only)
+                nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cout, cout))
+                assert nbytes > 0 and K == 27 and (cin == cout or (cin < cout and mode == 2))
                 buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
-                wrows.append([w.data_ptr(), buf.data_ptr(), cin, mode - 2, wfirst, 0, 0, 0])
+                wrows.append([w.data_ptr(), buf.data_ptr(), cout, mode - 2, wfirst, cin, 0, 0])
                 wfirst += (nbytes // 2 + 255) // 256
             else:
                 nbytes = lib.pcd_packed_weight_bytes(K, cin, cout, mode)
@@ -1202,13 +1203,13 @@ def subm_window_plan(rb, c_in, c_out):
 
 def pack_weight_window(weight, mode, out=None):
     """weight [Cout, 3, 3, 3, Cin] f32 -> the window kernel's register-resident slices (mode 0 forward, 1 dgrad: transposed,
-    kernel offsets reversed)."""
+    kernel offsets reversed).  Cin < Cout (mode 0): the layer runs on input rows zero-padded to Cout channels."""
     _require_cuda(weight)
     w = weight.detach().contiguous().float()
     cout, cin = w.shape[0], w.shape[-1]
     lib = L.lib()
-    nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cin, cout))
-    assert nbytes > 0 and w.numel() == cout * 27 * cin
+    nbytes = int(lib.pcd_subm_window_packed_weight_bytes(cout, cout))
+    assert nbytes > 0 and w.numel() == cout * 27 * cin and (cin == cout or (cin < cout and int(mode) == 0))
     packed = out if (out is not None and out.numel() == nbytes // 2 and out.device == w.device) else \
         torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
     L.check(lib.pcd_subm_window_pack_weight(L.ptr(w), cin, cout, int(mode), L.ptr(packed), L.stream_ptr()),
@@ -1260,10 +1261,10 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
     return y
 
 
-def subm_window_wgrad(x, dy, rb, out=None, defer=None):
+def subm_window_wgrad(x, dy, rb, out=None, defer=None, cin=None):
     """dW [C, 27, C] f32 of a SubM 3x3x3 layer (c_in == c_out == C) over the window kernel's tiles: x, dy bf16 [n, C].  The
     kernel leaves pcd_subm_window_wgrad_splits() partial slabs; their fixed-order sum is a job of wgrad_reduce_batched
-    (appended to `defer` when given, run here otherwise)."""
+    (appended to `defer` when given, run here otherwise).  `cin` < C: x carries zero-padded channels, dW is [C, 27, cin]."""
     _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
     assert x.shape == dy.shape and rb.subm and rb.kvol == 27 and x.shape[0] == rb.nbr_buffer.shape[1]
@@ -1272,7 +1273,9 @@ def subm_window_wgrad(x, dy, rb, out=None, defer=None):
     plan = subm_window_plan(rb, c, c)
     splits = int(lib.pcd_subm_window_wgrad_splits())
     slab = torch.empty((splits * 27 * c * c * 4,), dtype=torch.uint8, device=x.device)
-    dw = out if _usable_out(out, c * 27 * c) else torch.empty((c, 27, c), dtype=torch.float32, device=x.device)
+    cin = c if cin is None else int(cin)
+    assert 0 < cin <= c
+    dw = out if _usable_out(out, c * 27 * cin) else torch.empty((c, 27, cin), dtype=torch.float32, device=x.device)
 
     def meta():
         pairs = int((rb.nbr_out >= 0).sum().item())
@@ -1282,7 +1285,7 @@ def subm_window_wgrad(x, dy, rb, out=None, defer=None):
         L.check(lib.pcd_sparse_conv_subm_window_wgrad(L.ptr(x), L.ptr(dy), n, c, L.ptr(rb.nbr_buffer), rb.nbr_buffer.shape[1],
                                                       L.ptr(rb.n_out_dev), L.ptr(plan), L.ptr(slab), slab.numel(),
                                                       L.stream_ptr()), "pcd_sparse_conv_subm_window_wgrad")
-    job = (slab, dw, 27, c, c, 0, splits)
+    job = (slab, dw, 27, c, c, 0, splits, 0, 0, cin if cin < c else 0)
     if defer is not None:
         defer.append(job)
     else:
@@ -1607,7 +1610,8 @@ def wgrad_f32(x, dy, pairs, pair_num, kvol):
 
 
 def wgrad_reduce_batched(jobs):
-    """jobs = [(slab workspace, dw, kvol, cin, cout, pmax[, splits])] collected by wgrad(defer=...)."""
+    """jobs = [(slab workspace, dw, kvol, cin, cout, pmax[, splits[, layout[, cout_write[, cin_write]]]])] collected by
+    wgrad(defer=...) / subm_window_wgrad(defer=...)."""
     import ctypes
     for i in range(0, len(jobs), L.WGRAD_MAX_JOBS):
         chunk = jobs[i:i + L.WGRAD_MAX_JOBS]
@@ -1615,7 +1619,8 @@ def wgrad_reduce_batched(jobs):
         for j, job in enumerate(chunk):
             ws, dw, kvol, cin, cout, pmax = job[:6]
             arr[j] = L.PcdWgradReduceJob(L.ptr(ws), L.ptr(dw), kvol, cin, cout, pmax, job[6] if len(job) > 6 else 0,
-                                         job[7] if len(job) > 7 else 0, job[8] if len(job) > 8 else 0)
+                                         job[7] if len(job) > 7 else 0, job[8] if len(job) > 8 else 0,
+                                         job[9] if len(job) > 9 else 0)
         L.check(L.lib().pcd_sparse_conv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk),
                                                              L.stream_ptr()), "pcd_sparse_conv_wgrad_reduce_batched")
 

@@ -58,12 +58,15 @@ class SparseConvolution(SparseModule):
     def window_capable(self):
         """A window kernel exists for this layer (and the "subm_window" option admits it: bit 0 = 64 channels, bit 1 = 32, bit 2 = 16, bit 3 = 128)."""
         if not (self.subm and tuple(self.kernel_size) == (3, 3, 3) and tuple(self.dilation) == (1, 1, 1)
-                and self.in_channels == self.out_channels):
+                and self.in_channels <= self.out_channels):
             return False
         from .. import _lib as L
         opt = L.get_option("subm_window")
-        bit = {64: 1, 32: 2, 16: 4, 128: 8}.get(self.in_channels, 0)
-        return bool(opt & bit) and ops.subm_window_tile_rows(self.in_channels, self.out_channels) > 0
+        bit = {64: 1, 32: 2, 16: 4, 128: 8}.get(self.out_channels, 0)
+        if self.in_channels < self.out_channels and not (opt & 16):
+            return False         # (bit 4: fewer input channels than output channels -> rows zero-padded to the kernel's width;
+            #                       forward and weight gradient only: SparseConvolution.forward checks that no data gradient is due)
+        return bool(opt & bit) and ops.subm_window_tile_rows(self.out_channels, self.out_channels) > 0
 
     def set_window(self, on):
         on = bool(on)
@@ -178,12 +181,12 @@ class SparseConvolution(SparseModule):
                 # ... and so are the layers whose weight gradient runs over the window kernel's tiles
                 if not lazy and self.window_capable() and x.indice_dict.get("__row_order__", ops.ROWS_ZYX) == ops.ROWS_YXZ:
                     from .functional import _window_wgrad
-                    lazy = _window_wgrad(self.in_channels)
+                    lazy = _window_wgrad(self.out_channels)
                 # z-fastest rows with a column map: the window plan comes out of the same pass as the rulebook; a caller that
                 # knows ALL consumers of this rulebook (the backbones' prefetcher: indice_dict["__subm_hint__"] = (width,
                 # tables needed)) can drop the neighbour table altogether -- alone, a layer keeps it for the others
                 hint = x.indice_dict.pop("__subm_hint__", None)
-                win_c, tables = (self.in_channels if self.window_capable() else None), True
+                win_c, tables = (self.out_channels if self.window_capable() else None), True
                 if hint is not None:
                     win_c, tables = hint
                 if x.indice_dict.get("__row_order__", ops.ROWS_ZYX) != ops.ROWS_YXZ:
@@ -240,8 +243,12 @@ class SparseConvolution(SparseModule):
         if fp8 is not None and not (self.training and torch.is_grad_enabled()):
             fp8 = None                                  # (the fp8-forward training form; inference has Fp8Backbone)
         # window kernel: SubM rulebook over z-fastest rows, bf16 features (decided here -- the packs follow the decision)
+        padded = self.in_channels < self.out_channels        # (conv_input: 5 -> 16 on rows zero-padded to 16 channels)
         win = (fp8 is None and rb.subm and getattr(rb, "order", None) == ops.ROWS_YXZ and input.features.is_cuda
-               and input.features.dtype == torch.bfloat16 and input.features.shape[1] == self.in_channels
+               and input.features.dtype == torch.bfloat16
+               and (input.features.shape[1] == self.in_channels or
+                    (padded and input.features.shape[1] in (ops.pow2_ge8(self.in_channels), self.out_channels)))
+               and not (padded and input.features.requires_grad and torch.is_grad_enabled())
                and self.window_capable())
         self.set_window(win)
         feats = Fsp.sparse_conv(input.features, self.weight, self.bias, rb, self._packed_fwd(),

@@ -135,7 +135,9 @@ class SparseConvFunction(Function):
         inside the dgrad kernel's epilogue instead of through a separate elementwise kernel."""
         cout, cin = weight.shape[0], weight.shape[-1]
         cin_pad = ops.pow2_ge8(cin)
-        assert features.shape[1] in (cin, cin_pad), (features.shape, weight.shape)
+        if window and cin_pad < cout:
+            cin_pad = cout                       # a window layer with fewer input channels (conv_input, 5 -> 16): rows zero-padded
+        assert features.shape[1] in (cin, ops.pow2_ge8(cin), cin_pad), (features.shape, weight.shape)
         x = _to_bf16_padded(features.detach(), cin_pad)
         out_dtype = features.dtype if features.dtype in (torch.float32, torch.bfloat16) else torch.float32
         b = bias.detach().float().contiguous() if bias is not None else None
@@ -273,9 +275,9 @@ class SparseConvFunction(Function):
             if ops.STAMPS is not None and ops.STAMPS.get("sparse"):
                 ops.stamp(f"wg{_SP_SEQ[0]}s")             # side stream: its weight gradient starts
             if ctx.needs_input_grad[1]:
-                if ctx.window and rb.subm and ctx.cin == ctx.cout == x.shape[1] and _window_wgrad(ctx.cin):
+                if ctx.window and rb.subm and ctx.cin <= ctx.cout == x.shape[1] and _window_wgrad(ctx.cout):
                     dwk = ops.subm_window_wgrad(x, dy16, rb, out=weight_p.grad if direct_w else None,
-                                                defer=_WGRAD_JOBS if (deferred and direct_w) else None)
+                                                defer=_WGRAD_JOBS if (deferred and direct_w) else None, cin=ctx.cin)
                 else:
                     dwk = ops.wgrad(x, ctx.cin, dy16, None, None, rb.kvol,
                                     out=weight_p.grad if direct_w else None,                 # [Cout, K, Cin] f32

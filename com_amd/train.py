@@ -134,6 +134,12 @@ class CapturedStep:
         backbone = getattr(model, "backbone_3d", None)
         self.after_update = list(after_update) if after_update is not None else \
             ([backbone.pack_after_update] if backbone is not None else [])
+        # the voxeliser emits the MeanVFE rows as the bf16 operand of the first conv: zero-padded to that conv's OUTPUT width when
+        # it runs on the window tiles (conv_input 5 -> 16 over z-fastest rows), to the next power of two >= 8 otherwise
+        self.feature_stride = None
+        first = next((m for m in backbone.modules() if hasattr(m, "window_capable")), None) if backbone is not None else None
+        if first is not None and voxelize.row_order == "yxz" and first.in_channels < first.out_channels and first.window_capable():
+            self.feature_stride = first.out_channels
         self.captured = False
         self.recaptures = 0
         self.last_voxels = 0            # voxels of the last eagerly voxelised batch (reporting)
@@ -149,7 +155,8 @@ class CapturedStep:
         bd = {"points": pts, "frame_offsets": offs, "batch_size": self.batch_size}
         bd = hotpath.transform_points_to_voxels(bd, c.point_cloud_range, c.voxel_size, c.max_points_per_voxel, c.max_voxels,
                                                 fuse_mean=True, bf16_features=True,
-                                                out=out["_result"] if out is not None else None, row_order=c.row_order)
+                                                out=out["_result"] if out is not None else None, row_order=c.row_order,
+                                                bf16_feature_stride=self.feature_stride)
         bd2 = {"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": self.batch_size,
                "_result": bd["voxelize_result"]}
         for k in ("voxel_num_rows", "voxel_rank"):

@@ -75,10 +75,11 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "gg_resident_kb" 32   packed weight up to this size stays resident in LDS in gather_gemm_kernel
  *   "ggw" 1               LDS-DMA gather-GEMM for C_in = 128 (0 off, 2..4: rows-per-wave forced also for C_in = 64, 6: forward only)
  *   "gg1" 1               16-channel gather-GEMM variant (1: 32 rows per wave)
- *   "subm_window" 7       window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows: bit 0 = 64 channels, bit 1 = 32,
- *                         bit 2 = 16, bit 3 = 128 (off: its dense 27-offset MFMA work makes it slower than the step-skipping
- *                         generic kernel there, 61.6 vs 49.0 us) (0: generic kernels) -- read by the host-side layer, the C
- *                         entry points take any of these widths
+ *   "subm_window" 23      window gather-GEMM for SubM 3x3x3 layers over PCD_ROWS_YXZ rows: bit 0 = 64 channels, bit 1 = 32,
+ *                         bit 2 = 16, bit 3 = 128 (EXPERIMENTS builds; off: its dense 27-offset MFMA work makes it slower than the
+ *                         step-skipping generic kernel there, 61.6 vs 49.0 us), bit 4 = layers with FEWER input than output
+ *                         channels run on zero-padded rows (conv_input 5 -> 16; forward + weight gradient, no data gradient)
+ *                         (0: generic kernels) -- read by the host-side layer, the C entry points take any of these widths
  *   "subm_window_wgrad" 6 the same bits for the window weight gradient (pcd_sparse_conv_subm_window_wgrad); 64 channels off:
  *                         its 80 partial slabs (35 MB per layer) cost the training step more than the kernel saves
  *   "wg128" 1             equal-pair weight-gradient kernel at 128 x 128 channels
@@ -480,6 +481,9 @@ typedef struct PcdWgradReduceJob {
     int cout_write;          /* 0 = cout; else only the first cout_write output channels are reduced and written (dweight
                               * holds cout_write rows): convs run with zero-padded output channels (the 1-3 channel
                               * final convs of the head towers, padded to 32) */
+    int cin_write;           /* 0 = cin; else (layout 0, splits > 0) the slabs carry cin input channels per (co, k) and dweight
+                              * only the first cin_write: a layer run on zero-padded input rows (conv_input 5 -> 16 on the window
+                              * tiles: pcd_sparse_conv_subm_window_wgrad with c = 16) */
 } PcdWgradReduceJob;
 int pcd_sparse_conv_wgrad_reduce_batched(const PcdWgradReduceJob *jobs_host, int n_jobs, void *stream);
 /* Output-stationary form for layers with 16 output channels (cin_pad 8 or 16, 3x3x3): walks the OUTPUT rows, reads dY in

@@ -521,11 +521,60 @@ def test_backbone_builds_level_2_without_a_neighbour_table_and_matches_the_table
             torch.cuda.synchronize()
             return y.detach().clone(), [p.grad.clone() for p in net.parameters()]
         finally:
-            backbone3d._RulebookPrefetcher._subm_hint = keep
+            backbone3d._RulebookPrefetcher._subm_hint = staticmethod(keep)
 
     y1, g1 = run(True)
     y0, g0 = run(False)
-    assert seen[True]["res2"] is False and seen[True]["res3"] is True and all(seen[False].values()), seen
+    # levels 1 (conv_input 5 -> 16 on zero-padded rows + res1) and 2 (res2) have window kernels for everything; level 3's weight
+    # gradient still reads pair lists
+    assert seen[True]["res1"] is False and seen[True]["res2"] is False and seen[True]["res3"] is True, seen
+    assert all(seen[False].values()), seen
+    assert net.conv_input[0].use_window
     assert torch.equal(y1, y0)
     for a, b in zip(g1, g0):
         assert torch.equal(a, b)
+
+
+def test_input_layer_5_to_16_on_window_tiles_against_the_oracle_and_the_generic_kernels(pcd_option):
+    """conv_input (SubMConv3d 5 -> 16, spconv_backbone.py:191-195) on the 16-channel window tiles: rows zero-padded to 16
+    channels, the weight packed with zeros for the missing input channels (pcd_subm_window_pack_weight, c_in < c_out), the
+    weight gradient reduced into the [16, 27, 5] parameter layout (PcdWgradReduceJob.cin_write).  Forward against the oracle and
+    the generic kernel on 8-channel rows; weight gradient against the output-stationary kernel and float64."""
+    ops = _ops()
+    idx, rank, shape = _level(1, 1, beams=32, azim=1250)
+    n = idx.shape[0]
+    rb = ops.rulebook_subm(idx, 1, shape, rank=rank, want_pairs=False, window=(16, 16), nbr_tables=False)
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(16, 3, 3, 3, 5, generator=g) * (1.0 / np.sqrt(27 * 5))
+    bias = torch.randn(16, generator=g) * 0.1
+    x5 = _bf16(torch.randn(n, 5, generator=g).numpy())
+    x16 = torch.nn.functional.pad(x5, (0, 11)).to(DEV)
+    x8 = torch.nn.functional.pad(x5, (0, 3)).to(DEV)
+    wd = w.to(DEV)
+    y = ops.subm_window(x16, ops.pack_weight_window(wd, 0), bias.to(DEV), rb, 16)
+    assert not rb.nbr_complete
+    ref = _oracle_fwd(torch.nn.functional.pad(x5, (0, 3)), torch.nn.functional.pad(w, (0, 3)).numpy(), bias.numpy(), idx.cpu().numpy(),
+                      shape, False)
+    _close(y, ref, "padded-input forward")
+    yg = ops.gather_gemm(x8, ops.pack_weight(wd, 0), bias.to(DEV), rb.nbr_out, 27, False, n, 16, torch.bfloat16)
+    differ = (y != yg).float().mean().item()
+    assert differ < 2e-3, differ                      # same operands, fp32 sums in another order: rounding ties only
+    dy = torch.randn(n, 16, generator=g).to(DEV).to(torch.bfloat16)
+    dw = ops.subm_window_wgrad(x16, dy, rb, cin=5)
+    assert dw.shape == (16, 27, 5)
+    dwg = ops.wgrad(x8, 5, dy, None, None, 27, rb=rb)
+    nb = rb.nbr_out.cpu().numpy()
+    xd, dyd = x5.double().numpy(), dy.cpu().double().numpy()
+    ref64 = np.zeros((16, 27, 5))
+    for k in range(27):
+        m = nb[k] >= 0
+        ref64[:, k, :] = dyd[m].T @ xd[nb[k][m]]
+    tol = 2e-5 * float(np.abs(ref64).max()) * np.sqrt(n / 1000.0 + 1.0)
+    assert float(np.abs(dw.cpu().numpy() - ref64).max()) <= tol
+    assert float(np.abs(dwg.cpu().numpy().reshape(16, 27, 5) - ref64).max()) <= tol
+    # deferred form writing straight into a parameter-shaped buffer (DIRECT_GRAD's path)
+    out = torch.full((16, 27, 5), 7.0, device=DEV)
+    jobs = []
+    ops.subm_window_wgrad(x16, dy, rb, out=out, defer=jobs, cin=5)
+    ops.wgrad_reduce_batched(jobs)
+    assert torch.equal(out, dw)

@@ -59,7 +59,7 @@ def timed(fn, reps=10):
     return out, e0.elapsed_time(e1) / reps * 1e-3
 
 
-AS_BUILT_FREE = {int(v) for v in os.environ.get('PCD_REGIME_FREE', '2').split(',') if v}    # levels built without a neighbour table
+AS_BUILT_FREE = {int(v) for v in os.environ.get('PCD_REGIME_FREE', '1,2').split(',') if v}    # levels built without a neighbour table
 for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
     frames = [synth.synth_cloud(f) for f in range(B)]
     pts, offs = hotpath.collate_points(frames, dev)
