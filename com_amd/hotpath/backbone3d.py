@@ -349,7 +349,14 @@ class _BackboneBase(nn.Module):
         x_conv3 = self.conv3(x_conv2)
         ops.stamp("conv3")
         hook_point("conv3")
-        x_conv4 = self.conv4(x_conv3)
+        # (level 4 child by child: a hook point behind its strided conv -- "conv4.0" -- lets the hook's kernels start beside the
+        #  128-channel SubM layers instead of beside the strided 64 -> 128 conv, the most contention-sensitive kernel of the chain)
+        x4 = x_conv3
+        for ci, child in enumerate(self.conv4):
+            x4 = child(x4)
+            if ci == 0:
+                hook_point("conv4.0")
+        x_conv4 = x4
         ops.stamp("conv4")
         hook_point("conv4")
         out = self.conv_out(x_conv4)

@@ -578,3 +578,33 @@ def test_input_layer_5_to_16_on_window_tiles_against_the_oracle_and_the_generic_
     ops.subm_window_wgrad(x16, dy, rb, out=out, defer=jobs, cin=5)
     ops.wgrad_reduce_batched(jobs)
     assert torch.equal(out, dw)
+
+
+@pytest.mark.parametrize("ch,lvl", [(16, 1), (32, 2), (64, 3)])
+@pytest.mark.timeout(900)
+def test_window_kernel_at_the_full_batch_of_the_benchmark_against_the_oracle(ch, lvl):
+    """The B = 4 x 160 k-point batch bench.py times (BASELINE config 2), one level per window width: forward (+ bias) and data
+    gradient (+ addend) of the window kernel against the CPU oracle's conv on the same bf16-rounded operands -- every element within
+    one bf16 ulp, the fp32 sums at 1e-3 per element; the rulebook built WITHOUT a neighbour table (plan straight from the
+    column map), as the step builds levels 1-2."""
+    ops = _ops()
+    idx, rank, shape = _level(4, lvl)
+    n = idx.shape[0]
+    assert n > (300000, 250000, 100000)[lvl - 1]
+    rb = ops.rulebook_subm(idx, 4, shape, rank=rank, want_pairs=False, window=(ch, ch), nbr_tables=False)
+    g = torch.Generator().manual_seed(100 + ch)
+    w = torch.randn(ch, 3, 3, 3, ch, generator=g) * (1.0 / np.sqrt(27 * ch))
+    bias = torch.randn(ch, generator=g) * 0.1
+    x = _bf16(torch.randn(n, ch, generator=g).numpy())
+    add = _bf16(torch.randn(n, ch, generator=g).numpy())
+    wd, idx_np = w.to(DEV), idx.cpu().numpy()
+    y, y32 = ops.subm_window_f32(x.to(DEV), ops.pack_weight_window(wd, 0), bias.to(DEV), rb, ch)
+    ref = _oracle_fwd(x, w.numpy(), bias.numpy(), idx_np, shape, False)
+    _close(y, ref, f"full-size forward {ch}")
+    _close_f32(y32, ref, f"full-size forward fp32 sums {ch}")
+    assert torch.equal(y32.to(torch.bfloat16), y)
+    dx, dx32 = ops.subm_window_f32(x.to(DEV), ops.pack_weight_window(wd, 1), None, rb, ch, addend=add.to(DEV))
+    ref = _oracle_fwd(x, w.numpy(), None, idx_np, shape, True) + add.float().numpy()
+    _close(dx, ref, f"full-size dgrad {ch}")
+    _close_f32(dx32, ref, f"full-size dgrad fp32 sums {ch}")
+    assert not rb.nbr_complete
