@@ -294,9 +294,10 @@ def measure_roofline(step_fn, ms_per_step):
 
 def measure_cpu_baseline():
     """CPU baseline ("port"): the C oracle (oracle/pcd_oracle.c, spconv's native gather-GEMM-scatter algorithm,
-    fp32, compiled -O3 -march=native) on the host's cores, timed on ONE WHOLE synthetic frame, unsampled: voxelise,
-    MeanVFE, all 9 rulebooks, all 21 convs of VoxelResBackBone8x (spconv_backbone.py:191-232) forward + backward,
-    21 BatchNorm+ReLU fwd+bwd (torch-CPU), BEV dense + its gradient.  value = 1 / median of 3 whole-frame passes.
+    fp32, compiled -O3 -march=native) on the host's cores, timed on the B = 4 batch of whole synthetic frames the GPU figure
+    is quoted on, unsampled, frame by frame: voxelise, MeanVFE, all 9 rulebooks, all 21 convs of VoxelResBackBone8x
+    (spconv_backbone.py:191-232) forward + backward, 21 BatchNorm+ReLU fwd+bwd (torch-CPU), BEV dense + its gradient.
+    value = 4 / median of 3 batch passes behind one warm-up pass (`protocol` says how that differs from BASELINE.md's).
     The conv arithmetic and BN run on `cores` threads (OpenMP over the pairs of a kernel offset / torch intra-op).  The
     rulebook builders' per-offset loops can run on threads too (orc_set_rulebook_threads): they are timed once sequentially
     and once on min(cores, 27) threads and the faster setting is used and reported (`rulebook_threads`; hash probes bound by
@@ -307,18 +308,30 @@ def measure_cpu_baseline():
     from oracle import oracle as O          # cpu_baseline leg only
     mt = max(1, min(os.cpu_count() or 1, 64))
     RB_THREADS[0] = _pick_rulebook_threads(O, min(mt, 27))
-    passes = [_cpu_frame(O, mt) for _ in range(3)]
+    B = 4                                    # centerpoint.yaml:78 -- the batch of the GPU figure
+    def batch_pass(threads):
+        per = [_cpu_frame(O, threads, f) for f in range(B)]
+        parts = {}
+        for _, p in per:
+            for k, v in p.items():
+                parts[k] = parts.get(k, 0.0) + v
+        return sum(t for t, _ in per), parts
+    batch_pass(mt)                           # warm-up (page faults of the big buffers, OpenMP pool, torch's CPU kernels)
+    passes = [batch_pass(mt) for _ in range(3)]
     passes.sort(key=lambda t: t[0])
-    per_frame, parts = passes[1]
-    st_total = _cpu_frame(O, 1)[0] if mt > 1 else per_frame
-    return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": mt, "kind": "port",
+    per_batch, parts = passes[1]
+    st_total = _cpu_frame(O, 1, 0)[0] if mt > 1 else per_batch / B
+    return {"value": round(B / per_batch, 4), "unit": "frames/s", "cores": mt, "kind": "port",
             "host_cores_available": os.cpu_count(), "single_core_value": round(1.0 / st_total, 4),
             "rulebook_threads": RB_THREADS[0],
             "passes_s": [round(t[0], 3) for t in passes],
-            "sample": "1 whole synthetic 160k-pt frame (unsampled), fp32 C oracle (spconv native gather-GEMM-scatter): "
+            "protocol": f"B = {B} frames per pass (frames 0-{B - 1} of the GPU run's generator), fp32, 1 warm-up pass + median of 3 timed "
+                        "passes -- BASELINE.md section 2 asks for 5 warm-ups + >= 20 iterations; bounded here to ~20 s of CPU work "
+                        "as the bench contract requires (a pass is ~4 s on 64 cores); the single-core figure is ONE frame, one pass",
+            "sample": f"{B} whole synthetic 160k-pt frames (unsampled), fp32 C oracle (spconv native gather-GEMM-scatter): "
                       "voxelize + MeanVFE + 9 rulebooks + all 21 VoxelResBackBone8x convs fwd+bwd + 21 BN/ReLU fwd+bwd "
-                      f"(torch-CPU) + BEV dense fwd+bwd; median of 3 passes; conv and BN on {mt} threads, rulebooks on "
-                      f"{RB_THREADS[0]} (the faster of 1 / {min(mt, 27)}), the rest on 1; " + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
+                      f"(torch-CPU) + BEV dense fwd+bwd per frame; conv and BN on {mt} threads, rulebooks on "
+                      f"{RB_THREADS[0]} (the faster of 1 / {min(mt, 27)}), the rest on 1; per pass: " + ", ".join(f"{k} {v:.2f}s" for k, v in parts.items())
                       + f"; all on one core: {st_total:.2f}s per frame"}
 
 
@@ -347,7 +360,7 @@ def _pick_rulebook_threads(O, cand):
     return best[1]
 
 
-def _cpu_frame(O, threads):
+def _cpu_frame(O, threads, frame=0):
     torch.set_num_threads(threads)
     O.set_rulebook_threads(RB_THREADS[0] if threads > 1 else 1)
     rng = np.random.default_rng(0)
@@ -362,7 +375,7 @@ def _cpu_frame(O, threads):
         t_total[name] = t_total.get(name, 0.0) + (time.perf_counter() - t0)
         return r
 
-    pts = synth.synth_cloud(0)
+    pts = synth.synth_cloud(frame)
     v, c, n = timed("voxelize", lambda: O.voxelize_hard(pts, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000))
     timed("mean_vfe", lambda: O.mean_vfe(v, n))
     idx = np.pad(c, ((0, 0), (1, 0))).astype(np.int32)
@@ -724,9 +737,9 @@ def measure_stage2(B, dev):
                                          "(frame by frame as the reference loops: 18.4 ms in round 4; not what the timed stage uses)"},
                 "stage2_train": {"ms_per_batch": round(ms_train, 3), "frames_per_s": round(B / ms_train * 1e3, 1),
                                  "what": "the same stage in training mode, forward + backward (eager launches)"},
-                "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points (cooperative kernel: 64 "
-                        "workgroups per frame) + set abstraction over raw points, x_conv3, x_conv4 + BEV + RoI-grid pooling "
-                        "128 RoIs x 216 points/frame"}
+                "what": "PV-RCNN stage 2 (eval forward): FPS 4096 keypoints/frame from raw points (bucket-pruned exact kernel: one "
+                        "workgroup per frame, ~13 of 1250 buckets touched per sample) + set abstraction over raw points, x_conv3, "
+                        "x_conv4 + BEV + RoI-grid pooling 128 RoIs x 216 points/frame"}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}
 

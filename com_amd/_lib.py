@@ -181,6 +181,8 @@ PROTOTYPES = {
     "pcd_group_points_stack_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_stack_farthest_point_sampling": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_stack_fps_coop_workspace_bytes": (_sz, [_i]),
+    "pcd_stack_fps_buckets_workspace_bytes": (_sz, [_i, _i]),
+    "pcd_stack_farthest_point_sampling_buckets": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "pcd_stack_farthest_point_sampling_coop": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcd_three_nn_stack": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcd_three_interpolate_stack": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -228,6 +228,368 @@ __global__ __launch_bounds__(1024) void stack_fps_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// BUCKET-PRUNED farthest point sampling for large frames (round 6) -- exact, one workgroup per frame, nothing device-scope
+// inside the loop.  The sequential definition (sampling_gpu.cu:188-348) updates EVERY point's running distance against the new
+// centre in each of the 4095 iterations; here the points of a frame are sorted once along a Z-curve (Morton code of a 128 x 128
+// grid over the frame's x-y extent) and cut into BUCKETS of CH consecutive points (CH = 64 .. 256, <= FPS_NB buckets): equal
+// point counts whatever the density (a LiDAR frame holds thousands of points per square metre near the sensor and a handful far
+// out), compact in space.  Every bucket keeps the tight bounding box of its points and its current farthest point (running
+// distance + the reference's tie key + coordinates).  A new centre c can only change a bucket whose box lies closer to c than
+// the bucket's largest running distance:
+//     dbox(c) >= maxd(bucket)  =>  d(p, c) >= dbox(c) >= maxd >= tmp[p]  for every p in it  =>  fminf(d, tmp[p]) = tmp[p].
+// The inequality d(p, c) >= dbox(c) holds IN FLOAT ARITHMETIC: dbox is computed with the reference's own expression order
+// ((ex ex + ey ey) + ez ez, no contraction) from per-axis gaps with |fl(b - c)| <= |fl(p - c)| -- rounding is monotone.  After
+// the first few dozen samples a new centre touches the handful of buckets around it; the argmax is the reduction of the bucket
+// maxima under the SAME total order as stack_fps_kernel (distance, bit-reversed thread id of the reference's tree, index), so
+// the selected points are the reference's, ties included.  An iteration is one or two global round trips (the touched buckets'
+// points, L2-resident) + LDS; the cooperative kernel below needs two device-scope hops (~5.4 us).
+constexpr int FPS_NB = 2048;             // buckets per frame at most (two per thread of the 1024-thread workgroup)
+constexpr int FPS_FINE = 128;            // Z-curve grid (FPS_FINE^2 = 16384 counters in LDS)
+constexpr int FPS_CHMAX = 256;
+constexpr int FPS_BT = 3;                // touched buckets a wave loads at a time
+
+struct FpsBucketWs {            // per call: sorted point arrays over all frames + per-frame bucket boxes
+    float4 *sp;                 // (x, y, z, running distance) of the sorted points: one 16-byte load / store per point
+    int *sk;                    // original index inside the frame
+    float *bbox;                // [B][6][FPS_NB]
+    long long *stats;           // [B][8] profiling aid: touched buckets, rounds, clocks of the three phases (tools/exp_fps.py)
+};
+
+__host__ __device__ inline int fps_chunk(int n) {          // points per bucket: a multiple of 64, <= FPS_NB buckets
+    int ch = (n + FPS_NB - 1) / FPS_NB;
+    ch = (ch + 63) / 64 * 64;
+    return ch < 64 ? 64 : ch;
+}
+
+__device__ __forceinline__ float block_minmax(float v, bool is_max, float *lds16) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off);
+        v = is_max ? fmaxf(v, o) : fminf(v, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = lds16[0];
+    for (int w = 1; w < 16; ++w) r = is_max ? fmaxf(r, lds16[w]) : fminf(r, lds16[w]);
+    return r;
+}
+
+__device__ __forceinline__ unsigned fps_spread7(unsigned v) {      // 7 bits -> every other bit
+    v = (v | (v << 4)) & 0x070fu;
+    v = (v | (v << 2)) & 0x1333u;
+    v = (v | (v << 1)) & 0x1555u;
+    return v;
+}
+
+// binning: one 1024-thread workgroup per frame; dynamic LDS: FPS_FINE^2 counters
+__global__ __launch_bounds__(1024) void fps_bin_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ xyz_cnt,
+                                                       FpsBucketWs W) {
+    extern __shared__ int fps_hist[];                     // [FPS_FINE * FPS_FINE]: counts, then cursors
+    __shared__ float red[16];
+    __shared__ int wsum[16];
+    constexpr int NC = FPS_FINE * FPS_FINE, PER = NC / 1024;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int start = 0;
+    for (int k = 0; k < b; ++k) start += xyz_cnt[k];
+    const int n = xyz_cnt[b];
+    const float *pts = xyz + (size_t)start * 3;
+    float lox = 3.0e38f, loy = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f;
+    for (int k = tid; k < n; k += 1024) {
+        const float x = pts[(size_t)k * 3], y = pts[(size_t)k * 3 + 1];
+        lox = fminf(lox, x); hix = fmaxf(hix, x);
+        loy = fminf(loy, y); hiy = fmaxf(hiy, y);
+    }
+    lox = block_minmax(lox, false, red);
+    hix = block_minmax(hix, true, red);
+    loy = block_minmax(loy, false, red);
+    hiy = block_minmax(hiy, true, red);
+    const float ivx = hix > lox ? (float)FPS_FINE / (hix - lox) : 0.0f, ivy = hiy > loy ? (float)FPS_FINE / (hiy - loy) : 0.0f;
+    auto cell = [&](float x, float y) {
+        int cx = (int)((x - lox) * ivx), cy = (int)((y - loy) * ivy);
+        cx = cx < 0 ? 0 : cx > FPS_FINE - 1 ? FPS_FINE - 1 : cx;
+        cy = cy < 0 ? 0 : cy > FPS_FINE - 1 ? FPS_FINE - 1 : cy;
+        return (int)(fps_spread7((unsigned)cx) | (fps_spread7((unsigned)cy) << 1));
+    };
+    for (int e = tid; e < NC; e += 1024) fps_hist[e] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) atomicAdd(&fps_hist[cell(pts[(size_t)k * 3], pts[(size_t)k * 3 + 1])], 1);
+    __syncthreads();
+    // exclusive scan of the NC counters: PER consecutive counters per thread
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        loc[i] = fps_hist[tid * PER + i];
+        sum += loc[i];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        fps_hist[tid * PER + i] = run;                    // cursor of the cell
+        run += loc[i];
+    }
+    __syncthreads();
+    // scatter (the order inside a cell does not matter: min-updates are per point, the argmax is a total order)
+    for (int k = tid; k < n; k += 1024) {
+        const float x = pts[(size_t)k * 3], y = pts[(size_t)k * 3 + 1], z = pts[(size_t)k * 3 + 2];
+        const int pos = start + atomicAdd(&fps_hist[cell(x, y)], 1);
+        W.sp[pos] = make_float4(x, y, z, 1e10f);
+        W.sk[pos] = k;
+    }
+    __syncthreads();
+    // tight boxes of the buckets (CH consecutive sorted points each): a wave per bucket
+    const int ch = fps_chunk(n), nb = (n + ch - 1) / ch;
+    float *bb = W.bbox + (size_t)b * 6 * FPS_NB;
+    for (int q = wave; q < nb; q += 16) {
+        const int s0 = start + q * ch, cn = min(ch, n - q * ch);
+        float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
+        for (int p = lane; p < cn; p += 64) {
+            const float4 pt = W.sp[s0 + p];
+            const float x = pt.x, y = pt.y, z = pt.z;
+            mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
+            mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+            mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, off)); mxx = fmaxf(mxx, __shfl_xor(mxx, off));
+            mny = fminf(mny, __shfl_xor(mny, off)); mxy = fmaxf(mxy, __shfl_xor(mxy, off));
+            mnz = fminf(mnz, __shfl_xor(mnz, off)); mxz = fmaxf(mxz, __shfl_xor(mxz, off));
+        }
+        if (lane == 0) {
+            bb[0 * FPS_NB + q] = mnx; bb[1 * FPS_NB + q] = mny; bb[2 * FPS_NB + q] = mnz;
+            bb[3 * FPS_NB + q] = mxx; bb[4 * FPS_NB + q] = mxy; bb[5 * FPS_NB + q] = mxz;
+        }
+    }
+}
+
+// The argmax key of a point in two words, compared lexicographically (larger = better): the running distance itself (a float
+// >= 0; -1 = "no point"), then a 32-bit tie word -- the reference tree's rule (smaller bit-reversed thread id k & 1023 first,
+// then the smaller index): fps_better's total order.
+__device__ __forceinline__ unsigned fps_tie(int k) {
+    const unsigned br = __builtin_bitreverse32((unsigned)(k & 1023)) >> 22;
+    return ((1023u - br) << 22) | (0x3fffffu - (unsigned)k);
+}
+__device__ __forceinline__ int fps_tie_index(unsigned t) { return (int)(0x3fffffu - (t & 0x3fffffu)); }
+
+// wave-wide maxima without the LDS crossbar: four DPP steps inside the rows of 16 lanes (one v_max with a DPP operand each), the
+// four row maxima through scalar registers.  (A __shfl_xor of five values per step cost this kernel 5 k clocks per sample.)
+#define FPS_DPP_ALL(OP, V)                                                                       \
+    V = OP(V, __builtin_bit_cast(decltype(V), __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0xB1, 0xf, 0xf, false)));  \
+    V = OP(V, __builtin_bit_cast(decltype(V), __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x4E, 0xf, 0xf, false)));  \
+    V = OP(V, __builtin_bit_cast(decltype(V), __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x141, 0xf, 0xf, false))); \
+    V = OP(V, __builtin_bit_cast(decltype(V), __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x140, 0xf, 0xf, false)));
+__device__ __forceinline__ float fps_wave_max_f32(float v) {
+    FPS_DPP_ALL(fmaxf, v)
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+#pragma unroll
+    for (int row = 1; row < 4; ++row) r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), row * 16)));
+    return r;
+}
+__device__ __forceinline__ unsigned fps_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned fps_wave_max_u32(unsigned v) {
+    FPS_DPP_ALL(fps_umax, v)
+    unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) r = fps_umax(r, (unsigned)__builtin_amdgcn_readlane((int)v, row * 16));
+    return r;
+}
+// true on the ONE lane that holds the wave's best (d, tie); dmax / tmax: that key (wave-uniform)
+__device__ __forceinline__ bool fps_wave_best(float d, unsigned tie, float &dmax, unsigned &tmax) {
+    dmax = fps_wave_max_f32(d);
+    tmax = fps_wave_max_u32(d == dmax ? tie : 0u);
+    return d == dmax && tie == tmax && dmax >= 0.0f;
+}
+
+// LDS per bucket: box minimum + largest running distance (float4), box maximum + the tie word of its farthest point (float4),
+// that point (float4)
+constexpr int FPS_LDS_BYTES = FPS_NB * (16 + 16 + 16);
+
+struct FpsWaveBest {
+    float d;
+    unsigned tie;
+    float x, y, z;
+    float pad[3];
+};
+
+// Iteration = ONE workgroup barrier.  Bucket q belongs to wave q % 16 (consecutive buckets are neighbours on the Z-curve: the
+// dozen buckets a centre touches spread over the waves), lane (q / 16) % 64, slot q / 1024: a wave tests its own 128 buckets,
+// updates the touched ones itself (nobody else reads or writes them), reduces their keys and publishes its best; after the
+// barrier 16 lanes of every wave reduce the 16 wave results (double-buffered by the parity of the sample).
+__global__ __launch_bounds__(1024) void fps_bucket_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ xyz_cnt,
+                                                          int32_t *__restrict__ idxs, const int32_t *__restrict__ num_sampled,
+                                                          FpsBucketWs W, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char fpsb_lds[];
+    float4 *bmin = (float4 *)fpsb_lds;                                 // (mnx, mny, mnz, maxd)
+    float4 *bmax = bmin + FPS_NB;                                      // (mxx, mxy, mxz, tie word of the farthest point)
+    float4 *bpt = bmax + FPS_NB;                                       // the farthest point of the bucket
+    __shared__ FpsWaveBest wbest[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int start = 0, ostart = 0;
+    for (int k = 0; k < b; ++k) {
+        start += xyz_cnt[k];
+        ostart += num_sampled[k];
+    }
+    const int n = xyz_cnt[b], m = num_sampled[b];
+    int32_t *out = idxs + ostart;
+    if (m <= 0 || n <= 0) return;
+    const int ch = fps_chunk(n), nb = (n + ch - 1) / ch;
+    const float *bb = W.bbox + (size_t)b * 6 * FPS_NB;
+    float4 *__restrict__ sp = W.sp + start;
+    const int *__restrict__ sk = W.sk + start;
+    const int nu = ch / 64;                                            // 64-point pieces of a bucket (1 .. FPS_CHMAX / 64)
+    const int myq[2] = {lane * 16 + wave, (lane + 64) * 16 + wave};    // this thread's buckets
+    // LDS slot of bucket q: the 128 buckets of a wave side by side, a lane's two 64 apart (bucket order itself would put the
+    // float4s of a wave's lanes 256 bytes apart: all on the same four banks)
+    auto slot = [](int q) { return (q & 15) * 128 + (q >> 4); };
+    const int mys[2] = {wave * 128 + lane, wave * 128 + lane + 64};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = myq[h];
+        const bool live = q < nb;
+        bmin[mys[h]] = make_float4(live ? bb[0 * FPS_NB + q] : 0.0f, live ? bb[1 * FPS_NB + q] : 0.0f, live ? bb[2 * FPS_NB + q] : 0.0f,
+                                   live ? 1e10f : -1.0f);                // (a bucket without points never gets touched, never wins)
+        bmax[mys[h]] = make_float4(live ? bb[3 * FPS_NB + q] : 0.0f, live ? bb[4 * FPS_NB + q] : 0.0f, live ? bb[5 * FPS_NB + q] : 0.0f, 0.0f);
+        bpt[mys[h]] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (tid == 0) out[0] = start;
+    float x1 = xyz[(size_t)start * 3], y1 = xyz[(size_t)start * 3 + 1], z1 = xyz[(size_t)start * 3 + 2];
+    long long st_dirty = 0, st_rounds = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+    for (int j = 1; j < m; ++j) {
+        const long long c0 = __builtin_readcyclecounter();
+        // (1) which of this wave's buckets can change?  gap of the box to the centre per axis (max3: the positive one of the two
+        //     differences, or 0 inside), then the reference's expression order
+        bool dt[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 lo = bmin[mys[h]], hi = bmax[mys[h]];
+            const float ex = fmaxf(fmaxf(lo.x - x1, x1 - hi.x), 0.0f);
+            const float ey = fmaxf(fmaxf(lo.y - y1, y1 - hi.y), 0.0f);
+            const float ez = fmaxf(fmaxf(lo.z - z1, z1 - hi.z), 0.0f);
+            const float dbox = ex * ex + ey * ey + ez * ez;
+            dt[h] = dbox < lo.w;                                  // (lo.w = -1 for a bucket without points)
+        }
+        unsigned long long todo[2] = {__ballot(dt[0]), __ballot(dt[1])};
+        const long long c1 = __builtin_readcyclecounter();
+        st_dirty += __popcll(todo[0]) + __popcll(todo[1]);
+        st_rounds += (todo[0] | todo[1]) != 0ull;
+        // (2) the touched buckets of this wave, FPS_BT at a time: ALL their loads are issued before the first use
+        while (todo[0] | todo[1]) {
+            int qs[FPS_BT];
+#pragma unroll
+            for (int i = 0; i < FPS_BT; ++i) {
+                const int h = todo[0] ? 0 : 1;
+                if (todo[h]) {
+                    const int l = __builtin_ctzll(todo[h]);
+                    todo[h] &= todo[h] - 1ull;
+                    qs[i] = (l + 64 * h) * 16 + wave;
+                } else {
+                    qs[i] = -1;
+                }
+            }
+            constexpr int U = FPS_CHMAX / 64;
+            float4 pp[FPS_BT][U];
+            int pk[FPS_BT][U];
+#pragma unroll
+            for (int i = 0; i < FPS_BT; ++i) {
+                const int s0 = qs[i] * ch, cn = qs[i] >= 0 ? min(ch, n - s0) : 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    pp[i][u] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                    pk[i][u] = 0;
+                    if (u < nu && qs[i] >= 0) {                 // (wave-uniform: no instruction for pieces the bucket does not have)
+                        const int p = lane + 64 * u;
+                        if (p < cn && !(dbg & 1)) {
+                            pp[i][u] = sp[s0 + p];
+                            pk[i][u] = sk[s0 + p];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FPS_BT; ++i) {
+                if (qs[i] < 0) continue;                        // (wave-uniform)
+                const int q = qs[i], s0 = q * ch, cn = min(ch, n - s0);
+                float bd = -1.0f, bxv = 0.0f, byv = 0.0f, bzv = 0.0f;
+                unsigned bt = 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = lane + 64 * u;
+                    if (u < nu && p < cn) {
+                        const float px = pp[i][u].x, py = pp[i][u].y, pz = pp[i][u].z;
+                        const float d = (px - x1) * (px - x1) + (py - y1) * (py - y1) + (pz - z1) * (pz - z1);
+                        const float d2 = fminf(d, pp[i][u].w);
+                        if (d2 != pp[i][u].w && !(dbg & 2)) sp[s0 + p].w = d2;
+                        const unsigned t = fps_tie(pk[i][u]);
+                        if (d2 > bd || (d2 == bd && t > bt)) {
+                            bd = d2; bt = t; bxv = px; byv = py; bzv = pz;
+                        }
+                    }
+                }
+                float dmax;
+                unsigned tmax;
+                if (!(dbg & 4) && fps_wave_best(bd, bt, dmax, tmax)) {          // the one lane that holds the bucket's farthest point
+                    bmin[slot(q)].w = dmax;
+                    bmax[slot(q)].w = __uint_as_float(tmax);
+                    bpt[slot(q)] = make_float4(bxv, byv, bzv, 0.0f);
+                }
+            }
+        }
+        const long long c2 = __builtin_readcyclecounter();
+        // (3) this wave's best bucket (its own LDS writes above are ordered before these reads: same wave, in-order LDS)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the LDS stores of the owner lanes have landed
+        const float d0 = bmin[mys[0]].w, d1 = bmin[mys[1]].w;
+        const unsigned t0 = __float_as_uint(bmax[mys[0]].w), t1 = __float_as_uint(bmax[mys[1]].w);
+        const bool second = d1 > d0 || (d1 == d0 && t1 > t0);
+        const float md = second ? d1 : d0;
+        const unsigned mt = second ? t1 : t0;
+        float dmax;
+        unsigned tmax;
+        if (fps_wave_best(md, mt, dmax, tmax)) {
+            const float4 pt = bpt[second ? mys[1] : mys[0]];
+            FpsWaveBest e;
+            e.d = dmax; e.tie = tmax; e.x = pt.x; e.y = pt.y; e.z = pt.z; e.pad[0] = e.pad[1] = e.pad[2] = 0.0f;
+            wbest[j & 1][wave] = e;
+        } else if (dmax < 0.0f && lane == 0) {
+            wbest[j & 1][wave].d = -1.0f;
+            wbest[j & 1][wave].tie = 0u;
+        }
+        __syncthreads();
+        // the best of the 16 waves: lanes 0..15 of every wave take one entry each, reduce inside their row of 16
+        {
+            const FpsWaveBest e = wbest[j & 1][lane & 15];
+            float gd = e.d;
+            FPS_DPP_ALL(fmaxf, gd)
+            unsigned gt = e.d == gd ? e.tie : 0u;
+            FPS_DPP_ALL(fps_umax, gt)
+            const bool win = e.d == gd && e.tie == gt;                      // one lane of every row of 16
+            const unsigned long long wm = __ballot(win);
+            const int wl = __builtin_ctzll(wm);                             // (lanes 0..15 hold the same 16 entries in every row)
+            x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.x), wl));
+            y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.y), wl));
+            z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.z), wl));
+            if (tid == 0) out[j] = fps_tie_index((unsigned)__builtin_amdgcn_readlane((int)e.tie, wl)) + start;
+        }
+        const long long c3 = __builtin_readcyclecounter();
+        st_t1 += c1 - c0; st_t2 += c2 - c1; st_t3 += c3 - c2;
+    }
+    if (tid == 0 && W.stats) {
+        long long *st = W.stats + (size_t)b * 8;
+        st[0] = st_dirty; st[1] = st_rounds; st[2] = st_t1; st[3] = st_t2; st[4] = st_t3; st[5] = nb; st[6] = ch; st[7] = m;
+    }
+}
+#undef FPS_DPP_ALL
+
+// ---------------------------------------------------------------------------------------------
 // COOPERATIVE farthest point sampling for large frames (VoxelSetAbstraction samples 4096 keypoints from ~160 k raw
 // points per frame, voxel_set_abstraction.py:236-263): the reference -- and stack_fps_kernel above -- give ONE
 // workgroup per frame 4095 dependent passes over all of the frame's points (~30 us each at 160 k points: 120 ms).
@@ -594,6 +956,54 @@ extern "C" int pcd_stack_farthest_point_sampling_coop(int B, const float *xyz, c
     pcd_fill(workspace, 0, pcd_stack_fps_coop_workspace_bytes(B), st);   // candidate tags 0 (no iteration has tag 0 before j = 4096), err = 0
     stack_fps_coop_kernel<<<B * G, 256, lds, st>>>(xyz, xyz_batch_cnt, idxs, num_sampled_points, G, slice_cap, cand, counters,
                                                   err);
+    PN2_CHECK_LAUNCH();
+}
+
+static void fps_bucket_carve(void *workspace, int B, size_t total, FpsBucketWs &W, size_t *need) {
+    char *w = (char *)workspace;
+    size_t off = 0;
+    auto take = [&](size_t count, size_t elem) {
+        char *p = w ? w + off : nullptr;
+        off += ws_piece(count, elem);
+        return p;
+    };
+    W.sp = (float4 *)take(total, 16);
+    W.sk = (int *)take(total, 4);
+    W.bbox = (float *)take((size_t)B * 6 * FPS_NB, 4);
+    W.stats = (long long *)take((size_t)B * 8, 8);
+    *need = off;
+}
+
+extern "C" size_t pcd_stack_fps_buckets_workspace_bytes(int B, int total_points) {
+    if (B <= 0 || total_points < 0) return 0;
+    FpsBucketWs W;
+    size_t need = 0;
+    fps_bucket_carve(nullptr, B, (size_t)total_points, W, &need);
+    return need;
+}
+
+// Bucket-pruned exact farthest point sampling (see fps_bucket_kernel): same selected points as
+// pcd_stack_farthest_point_sampling, one workgroup per frame, no inter-workgroup traffic.  total_points = sum of xyz_batch_cnt
+// (the host knows it: the rows of xyz).
+extern "C" int pcd_stack_farthest_point_sampling_buckets(int B, const float *xyz, const int32_t *xyz_batch_cnt, int32_t *idxs,
+                                                         const int32_t *num_sampled_points, int total_points, int max_cnt_host,
+                                                         void *workspace, size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (B <= 0 || !xyz || !xyz_batch_cnt || !idxs || !num_sampled_points || total_points < 0) return PCD_ERR_INVALID_ARG;
+    FpsBucketWs W;
+    size_t need = 0;
+    fps_bucket_carve(workspace, B, (size_t)total_points, W, &need);
+    if (!workspace || workspace_bytes < need) return PCD_ERR_WORKSPACE;
+    // a frame of more than FPS_NB x FPS_CHMAX points does not fit the bucket tables: the caller takes another form
+    if (max_cnt_host <= 0 || max_cnt_host > FPS_NB * FPS_CHMAX) return PCD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int bin_lds = FPS_FINE * FPS_FINE * (int)sizeof(int);
+    if (hipFuncSetAttribute((const void *)fps_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bin_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)fps_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_LDS_BYTES) != hipSuccess)
+        return PCD_ERR_LAUNCH;
+    fps_bin_kernel<<<B, 1024, bin_lds, st>>>(xyz, xyz_batch_cnt, W);
+    const int dbg = pcd_opt(PCD_OPT_FPS_G) >= 1000 ? pcd_opt(PCD_OPT_FPS_G) - 1000 : 0;     // (ablation bits of tools/exp_fps.py; 0 in production)
+    fps_bucket_kernel<<<B, 1024, FPS_LDS_BYTES, st>>>(xyz, xyz_batch_cnt, idxs, num_sampled_points, W, dbg);
     PN2_CHECK_LAUNCH();
 }
 

@@ -773,6 +773,31 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             const WinPlan p = get_plan(t, chunk0);
             // (window + table of tile t were published by the barriers of tile t - 1; B1 = "buffer buf ^ 1 is free" sits inside
             //  compute(), in front of the first prefetch slot)
+            if (dbg & 64) {
+                // COSTING ABLATION (option "win_dbg" bit 6; results are wrong with it): what a BatchNorm applied ON READ would
+                // cost this launch -- one in-LDS pass relu(scale * x + shift) over the tile's three landed runs (scale / shift per
+                // channel out of LDS, one bf16 rounding) + the barrier that publishes it, before the MFMA loop
+                const float *aff = (const float *)(smem + C::COLS);            // [2 COUT] floats: stands in for scale | shift
+                char *wbase = smem + C::ROWBASE + (buf ? C::WIN1ROW : C::Z0) * ROWB;
+                for (int e = fresh(tid); e < C::WINROWS * C::S; e += WIN_THREADS) {
+                    const unsigned row = (unsigned)e / C::S, slot = (unsigned)e % C::S;
+                    const unsigned cg = slot ^ C::swz(row + (buf ? C::WIN1ROW : C::Z0));
+                    uint4 v = *reinterpret_cast<uint4 *>(wbase + (size_t)e * 16);
+                    const float4 s0 = *reinterpret_cast<const float4 *>(aff + cg * 8), s1 = *reinterpret_cast<const float4 *>(aff + cg * 8 + 4);
+                    const float4 h0 = *reinterpret_cast<const float4 *>(aff + COUT + cg * 8), h1 = *reinterpret_cast<const float4 *>(aff + COUT + cg * 8 + 4);
+                    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float a = __uint_as_float(w4[j] << 16), b = __uint_as_float(w4[j] & 0xffff0000u);
+                        a = fmaxf(a * sc[2 * j] + sh[2 * j], 0.0f);
+                        b = fmaxf(b * sc[2 * j + 1] + sh[2 * j + 1], 0.0f);
+                        w4[j] = __builtin_bit_cast(u32, __builtin_convertvector((f32x2){a, b}, bf16x2));
+                    }
+                    *reinterpret_cast<uint4 *>(wbase + (size_t)e * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+                WIN_BARRIER();
+            }
             stamp();
             const bool more = t + 1 < chunk1;
             // (the plan of the last tile is read twice rather than copied conditionally: a struct merged over a branch was

@@ -89,7 +89,10 @@ class QueryAndGroup(nn.Module):
         return new_features, idx
 
 
-COOP_FPS_MIN_POINTS = 16384     # frames at least this large take the cooperative kernel
+COOP_FPS_MIN_POINTS = 16384     # frames at least this large take the large-frame kernels
+# large frames: "buckets" = exact bucket-pruned sampling, one workgroup per frame (round 6: ~4 x the cooperative kernel);
+# "coop" = 256 / B workgroups per frame meeting at a device-scope barrier twice per sample; "single" = the reference's form
+FPS_LARGE = "buckets"
 COOP_FPS_TIMEOUTS = 0           # times the cooperative kernel gave up and the one-workgroup kernel redid the call
 FPS_CHECK_ERR = True            # read the barrier-timeout flag back (one host sync; FPS is an eager op)
 
@@ -109,7 +112,16 @@ class StackFarthestPointSampling(Function):
         cnt = _i32(xyz_batch_cnt)
         lib = L.lib()
         max_cnt = int(cnt.max().item()) if B > 0 else 0
-        if max_cnt >= COOP_FPS_MIN_POINTS:
+        if max_cnt >= COOP_FPS_MIN_POINTS and FPS_LARGE == "buckets":
+            total = int(xyz.shape[0])
+            ws = torch.empty((int(lib.pcd_stack_fps_buckets_workspace_bytes(B, total)),), dtype=torch.uint8, device=xyz.device)
+            rc = lib.pcd_stack_farthest_point_sampling_buckets(B, L.ptr(xyz.float()), L.ptr(cnt), L.ptr(out), L.ptr(npoint), total,
+                                                               max_cnt, L.ptr(ws), ws.numel(), L.stream_ptr())
+            if rc == 0:
+                return out
+            if rc != -2:                                         # PCD_ERR_UNSUPPORTED: a frame beyond the bucket tables
+                L.check(rc, "pcd_stack_farthest_point_sampling_buckets")
+        if max_cnt >= COOP_FPS_MIN_POINTS and FPS_LARGE == "coop":
             # large frames: 256 / B workgroups share a frame (same selected points; see pointnet2.hip)
             ws = torch.empty((int(lib.pcd_stack_fps_coop_workspace_bytes(B)),), dtype=torch.uint8, device=xyz.device)
             rc = lib.pcd_stack_farthest_point_sampling_coop(B, L.ptr(xyz.float()), L.ptr(cnt), L.ptr(out), L.ptr(npoint),
