@@ -123,7 +123,7 @@ class HotPath(torch.nn.Module):
         return bd["spatial_features"], bd
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel):

@@ -30,6 +30,12 @@ def short(name):
     m = re.match(r"(wgrad_kernel<\d+, \d+>)", name)
     if m:
         return m.group(1)
+    m = re.match(r"(subm_win_kernel|subm_wgrad_win_kernel|cm_win_plan_kernel|win_plan_kernel)<WinCfg<(\d+),", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"            # (channels: one entry per instantiation)
+    m = re.match(r"(gather_gemm_cls_kernel|ggw_kernel)<(\d+),", name)
+    if m:
+        return f"{m.group(1)}<NB={m.group(2)}>"
     return re.split(r"[<(]", name)[0]
 
 
