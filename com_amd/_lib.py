@@ -58,7 +58,7 @@ PROTOTYPES = {
     "pcd_sparse_conv_gather_gemm_tiles_dir": (_i, [_i, _i, _i, _i, _i, _i]),
     "pcd_sparse_conv_gather_gemm_variant": (_i, [_i, _i, _i, _i, _i, _i]),
     "pcd_subm_window_tile_rows": (_i, [_i, _i]),
-    "pcd_subm_window_partial_rows": (_i, []),
+    "pcd_subm_window_partial_rows": (_i, [_i, _i]),
     "pcd_subm_window_set_trace": (_i, [_vp]),
     "pcd_subm_window_plan_bytes": (_sz, [_i, _i, _i]),
     "pcd_subm_window_plan": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -66,7 +66,7 @@ PROTOTYPES = {
     "pcd_subm_window_packed_weight_bytes": (_sz, [_i, _i]),
     "pcd_subm_window_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pcd_subm_window_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
-    "pcd_subm_window_wgrad_splits": (_i, []),
+    "pcd_subm_window_wgrad_splits": (_i, [_i]),
     "pcd_sparse_conv_subm_window_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_subm_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pcd_sparse_conv_subm_window_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

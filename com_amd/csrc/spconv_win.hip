@@ -62,40 +62,48 @@ __device__ __forceinline__ u32x4 win_rsrc(const void *base, unsigned bytes) {
         asm volatile("" ::: "memory");                        \
     } while (0)
 
-constexpr int WIN_THREADS = 512;
-constexpr int WIN_GRID = 256;            // (at most) one persistent workgroup per CU; also the number of BatchNorm partial rows
+constexpr int WIN_GRID = 256;            // full configurations (8 waves): (at most) one persistent workgroup per CU
+constexpr int WIN_GRID_MAX = 512;        // half configurations (4 waves, round 6): two per CU; sizes the plan's entry table
 // workgroups of a forward / data-gradient launch = shares of its plan: option "subm_window_grid" (a multiple of 8, <= WIN_GRID;
 // fewer than the CU count leaves CUs to the kernels of the other streams -- a 512-thread, 230-VGPR workgroup starts only on
 // an EMPTY CU)
-static inline int win_grid() {
+static inline int win_grid8() {
     int g = pcd_opt(PCD_OPT_SUBM_WINDOW_GRID);
     g = g / 8 * 8;
     return g < 8 ? 8 : g > WIN_GRID ? WIN_GRID : g;
 }
+// workgroups of a launch of configuration C (= BatchNorm partial rows = shares of its plan)
+template <class C>
+static inline int win_grid() { return win_grid8() * (8 / C::NW); }
 constexpr int WIN_SCRATCH = 0;           // (bnred_publish's 8 KiB of scratch at the head of the dynamic LDS are the zero rows and the
                                          //  first window: dead by then)
 constexpr int WIN_PLAN_CAP = 64;         // tiles whose plans are staged in LDS at a time
 // Plan buffer: [entries: WIN_GRID x 64 B][prefix: ntiles x i32, padded to 32 B][headers: ntiles x 32 B][tables: ntiles x TABB]
 //   entry[w] = {first tile, end tile, 0, 0, header of the first tile (8 ints), 0 ..} of workgroup w (in XCD-major order): one
 //   scalar load at kernel entry gives a workgroup its share AND what it needs to start the first DMAs.
-//   wshare[s] = {first tile, end tile} of share s of the weight-gradient kernel (WIN_WG_SHARES shares, 1 KiB reserved)
+//   wshare[s] = {first tile, end tile} of share s of the weight-gradient kernel (WinCfg::WG_SHARES shares, 2 KiB reserved)
 constexpr int WIN_ENTRY_BYTES = 64;
-constexpr int WIN_WG_SHARES = 80;        // weight gradient: 8 XCDs x 10 shares, three workgroups (one per run) each
-__host__ __device__ constexpr size_t win_wshare_off() { return (size_t)WIN_GRID * WIN_ENTRY_BYTES; }
-__host__ __device__ constexpr size_t win_prefix_off() { return win_wshare_off() + 1024; }
+constexpr int WIN_WG_SHARES = 80;        // weight gradient, 8-wave configurations: 8 XCDs x 10 shares, three workgroups (one per run) each
+constexpr int WIN_WG_SHARES_MAX = 160;   // (4-wave configurations: twice as many, half as long)
+__host__ __device__ constexpr size_t win_wshare_off() { return (size_t)WIN_GRID_MAX * WIN_ENTRY_BYTES; }
+__host__ __device__ constexpr size_t win_prefix_off() { return win_wshare_off() + 2048; }
 __host__ __device__ constexpr size_t win_hdr_off(int ntiles) { return win_prefix_off() + ((size_t)ntiles * 4 + 31) / 32 * 32; }
 __host__ __device__ constexpr size_t win_tab_off(int ntiles) { return win_hdr_off(ntiles) + (size_t)ntiles * 32; }
 
 // Wave roles: wave = (cb, rg, oq) -- output-channel block of 32, group of row blocks, slice of the 27 offsets.
 // CQN > 1: the output channels are dealt to CQN workgroups per share of the tiles (128 channels: the weights of 32 output
 // channels fill the registers of a workgroup) -- each loads the same windows and writes its COUTW columns of y.
-template <int CIN_, int NCB_, int NRG_, int NOQ_, int T_, int R_, int CQN_ = 1>
+// NW_ = waves per workgroup: 8 (one 512-thread workgroup per CU) or 4 (round 6: 256 threads, <= 80 KB of LDS -- TWO per CU, so that
+// a workgroup of another stream that holds part of a CU delays half a CU's worth of this launch instead of all of it).
+template <int CIN_, int NCB_, int NRG_, int NOQ_, int T_, int R_, int CQN_ = 1, int NW_ = 8>
 struct WinCfg {
-    static constexpr int CIN = CIN_, NCB = NCB_, NRG = NRG_, NOQ = NOQ_, T = T_, R = R_, CQN = CQN_;
-    static_assert(NCB * NRG * NOQ == 8, "8 waves");
+    static constexpr int CIN = CIN_, NCB = NCB_, NRG = NRG_, NOQ = NOQ_, T = T_, R = R_, CQN = CQN_, NW = NW_;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int WG_SHARES = WIN_WG_SHARES * 8 / NW;       // weight-gradient shares of the tiles
+    static_assert(NCB * NRG * NOQ == NW && (NW == 8 || NW == 4), "wave roles");
     static constexpr int COUT = CIN;                     // square layers only; a wave's MFMA block spans 32 output channels (the
     static constexpr int COUTW = COUT / CQN;             //  upper 16 are zero weights at 16 channels: LDS reads bound that layer, not MFMAs)
-    static_assert(32 * NCB >= COUTW && WIN_GRID % CQN == 0, "channel blocks");
+    static_assert(32 * NCB >= COUTW && WIN_GRID % CQN == 0 && WG_SHARES <= WIN_WG_SHARES_MAX, "channel blocks");
     static constexpr int NCBP = COUT >= 32 ? COUT / 32 : 1;   // 32-channel blocks of the packed weights
     static constexpr int QN = COUTW >= 32 ? 4 : COUTW / 8;   // live 4-register groups of a lane's 32 x 32 accumulator block
     static constexpr int ROWB = CIN * 2;                 // bytes per feature row
@@ -119,7 +127,7 @@ struct WinCfg {
     static constexpr int TABB = T * 64;                  // bytes per tile
     static_assert(TABB % 1024 == 0, "whole 1-KiB DMA instructions");
     static constexpr int NTABI = TABB / 1024;            // ... of them
-    static constexpr int TSL = (NTABI + 7) / 8;          // table DMA instructions per wave
+    static constexpr int TSL = (NTABI + NW - 1) / NW;    // table DMA instructions per wave
     __host__ __device__ static constexpr unsigned tab_pos(unsigned r, unsigned k) {      // u16 index of (tile row r, offset k)
         const unsigned ei = (k / OPW) * SLICE + k % OPW;
         return r * 32 + (((ei >> 3) ^ ((r >> 2) & 3)) << 3) + (ei & 7);
@@ -128,12 +136,12 @@ struct WinCfg {
     // what a further pass over a tile costs, in quarters of a tile's time (measured per workgroup, tools/exp_subm_win.py
     // WIN_BALANCE: 2.84 / 1.32 / 0.94 tiles at 16 / 32 / 64 channels)
     static constexpr int PASS_COST = CIN <= 16 ? 11 : CIN <= 32 ? 5 : 4;
-    static constexpr int SPR = (R / RPI + 7) / 8;        // window DMA instructions per run and wave
+    static constexpr int SPR = (R / RPI + NW - 1) / NW;  // window DMA instructions per run and wave
     static constexpr int NSLOT = 3 * SPR + TSL;          // prefetch instructions per wave and tile
     static constexpr int REDSTRIDE = COUTW * 4 + 16;     // bytes per (slice, row) of partial sums: +16 keeps b128 stores conflict-free
     static constexpr int REDB = NOQ * T * REDSTRIDE;
     static constexpr int EXTRA = REDB > WINB ? (REDB - WINB + 16 * ROWB - 1) / (16 * ROWB) * (16 * ROWB) : 0;   // whole swizzle periods
-    static_assert(WIN_THREADS * 16 * 4 <= WINB + EXTRA, "BatchNorm column staging fits the reduction area");
+    static_assert(THREADS * 16 * 4 <= WINB + EXTRA, "BatchNorm column staging fits the reduction area");
     // byte offsets into the dynamic LDS
     static constexpr int ROWBASE = WIN_SCRATCH;          // row index 0 lives here
     static constexpr int WIN0 = ROWBASE + Z0 * ROWB;
@@ -151,19 +159,23 @@ struct WinCfg {
     static constexpr int PLAN = TAB0 + 2 * TABB;
     static constexpr int COLS = PLAN + WIN_PLAN_CAP * 32;   // [2 COUT] floats: the workgroup's BatchNorm row
     static constexpr int LDS_BYTES = COLS + 2 * COUT * 4;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static constexpr int NL = (27 * T + WIN_THREADS - 1) / WIN_THREADS;   // rulebook entries per thread and tile (multi-pass tiles only)
+    static_assert(LDS_BYTES <= (NW == 8 ? 160 : 80) * 1024, "LDS (two 4-wave workgroups share a CU)");
+    static constexpr int NL = (27 * T + THREADS - 1) / THREADS;   // rulebook entries per thread and tile (multi-pass tiles only)
     static constexpr size_t plan_bytes(int ntiles) { return win_tab_off(ntiles) + (size_t)ntiles * TABB; }
     static constexpr int CG = COUTW / 8;                 // 8-channel groups per row in the tile epilogue
     static constexpr int NEPI = T * CG;                  // epilogue threads: one (row, 8 channels) each
-    static_assert(NEPI <= WIN_THREADS && NEPI % 64 == 0, "epilogue threads");
+    static_assert(NEPI <= THREADS && NEPI % 64 == 0, "epilogue threads");
     __host__ __device__ static constexpr unsigned swz(unsigned row) { return (row / P) & (S - 1); }
-    static_assert(P * S == 16 && Z0 % 16 == 0 && R % 16 == 0 && (8 * RPI) % 16 == 0, "swizzle period of 16 rows");
+    static_assert(P * S == 16 && Z0 % 16 == 0 && R % 16 == 0 && (NW * RPI) % 16 == 0, "swizzle period of 16 rows");
+    static_assert(R % RPI == 0, "a run is whole DMA instructions (a partial last piece would run into the next run's rows)");
 };
 
 using Win64 = WinCfg<64, 2, 1, 4, 64, 128>;      // 64 -> 64: waves = 2 channel blocks x 4 offset slices (7 offsets each)
 using Win32 = WinCfg<32, 1, 4, 2, 128, 320>;     // 32 -> 32: waves = 4 row blocks x 2 offset slices (14 offsets each)
 using Win16 = WinCfg<16, 1, 8, 1, 256, 640>;     // 16 -> 16: waves = 8 row blocks, all 27 offsets each (no cross-wave sums)
+// 4-wave configurations (option "subm_window_half": bit 1 = 32 channels, bit 2 = 16): the same wave roles on half the rows
+using Win32h = WinCfg<32, 1, 2, 2, 64, 176, 1, 4>;
+using Win16h = WinCfg<16, 1, 4, 1, 128, 320, 1, 4>;
 #ifdef PCD_EXPERIMENTS      // (make EXPERIMENTS=1; 61.6 us against ggw_kernel's 49.0 at level 4 -- DESIGN.md 4.1: not in the default library)
 using Win128 = WinCfg<128, 1, 1, 8, 32, 64, 4>;  // 128 -> 128: 4 workgroups x 32 output channels; waves = 8 offset slices (4 each)
 #endif
@@ -174,8 +186,8 @@ static inline auto win_dispatch(int c_in, int c_out, F &&f, N none) -> decltype(
     if (c_in != c_out) return none;
     switch (c_in) {
         case 64: return f(Win64{});
-        case 32: return f(Win32{});
-        case 16: return f(Win16{});
+        case 32: return (pcd_opt(PCD_OPT_SUBM_WINDOW_HALF) & 2) ? f(Win32h{}) : f(Win32{});
+        case 16: return (pcd_opt(PCD_OPT_SUBM_WINDOW_HALF) & 4) ? f(Win16h{}) : f(Win16{});
 #ifdef PCD_EXPERIMENTS
         case 128: return f(Win128{});
 #endif
@@ -350,8 +362,8 @@ template <class C>
 __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan_base, int n_cap, const int32_t *__restrict__ n_dev,
                                                          int ntiles_cap, int grid) {
     __shared__ int scan[1024];
-    __shared__ int bnd[WIN_GRID + 1];
-    __shared__ int bndw[WIN_WG_SHARES + 1];
+    __shared__ int bnd[WIN_GRID_MAX + 1];
+    __shared__ int bndw[WIN_WG_SHARES_MAX + 1];
     const int tid = threadIdx.x;
     const int n = eff_rows(n_dev, n_cap);
     const int nt = (n + C::T - 1) / C::T;
@@ -387,14 +399,14 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         }
         bnd[j] = j == NSH ? nt : lo;
     }
-    for (int j = tid; j <= WIN_WG_SHARES; j += 1024) {
-        const long long target = total * j / WIN_WG_SHARES;
+    for (int j = tid; j <= C::WG_SHARES; j += 1024) {
+        const long long target = total * j / C::WG_SHARES;
         int lo = 0, hi = nt;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
         }
-        bndw[j] = j == WIN_WG_SHARES ? nt : lo;
+        bndw[j] = j == C::WG_SHARES ? nt : lo;
     }
     __syncthreads();
     for (int w = tid; w < NSH; w += 1024) {
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         e[2] = tb < te ? hdr[(size_t)tb * 2 + 1] : z;
         e[3] = z;
     }
-    for (int w = tid; w < WIN_WG_SHARES; w += 1024)
+    for (int w = tid; w < C::WG_SHARES; w += 1024)
         ((int2 *)(plan_base + win_wshare_off()))[w] = make_int2(bndw[w], bndw[w + 1]);
 }
 
@@ -480,7 +492,7 @@ struct WinPlan {                 // scalars only (an array member sent the struc
 };
 
 template <class C>
-__global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
+__global__ __launch_bounds__(C::THREADS, C::NW == 8 ? 1 : 2) void subm_win_kernel(
     const unsigned short *__restrict__ x, const uint4 *__restrict__ wp, const float *__restrict__ bias,
     const int32_t *__restrict__ nbr, int nbr_stride, int n_cap, const int32_t *__restrict__ n_dev,
     const int4 *__restrict__ plan_g, unsigned short *__restrict__ y, unsigned x_bytes,
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     constexpr int T = C::T, R = C::R, ROWB = C::ROWB, COUT = C::COUT, COUTW = C::COUTW, OPW = C::OPW, KS = C::KS, RBW = C::RBW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stamp();                                 // (trace slot 0: kernel entry)
-    if (trace && threadIdx.x == 0) trace[256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // (per-workgroup entry time, 100 MHz)
+    if (trace && threadIdx.x == 0 && blockIdx.x < 256) trace[256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // (per-workgroup entry time, 100 MHz)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave8 % C::NCB, rg = (wave8 / C::NCB) % C::NRG, oq = wave8 / (C::NCB * C::NRG);
@@ -520,9 +532,10 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     // prefetch) and the waves fill their registers from there: 27 / 56 one-KiB instructions through the CU's texture-address unit
     // instead of 216 / 224 -- a third of a 16-channel launch's DMA work otherwise, all of it ahead of the first tile.
     bf16x8 wreg[OPW][KS];
-    constexpr bool STAGEW = C::NRG > 1;
     constexpr int NWP = C::NCB * C::NOQ * OPW * KS;      // KiB of packed weights
-    static_assert(!STAGEW || NWP * 1024 <= C::WINB, "staged weights fit window buffer 1");
+    // (several waves hold the same slice: the packed weights go to LDS once per workgroup -- where they fit window buffer 1; the
+    //  4-wave 32-channel configuration's 56 KiB do not: its waves load their slices from global memory)
+    constexpr bool STAGEW = C::NRG > 1 && NWP * 1024 <= C::WINB;
     if (!STAGEW) {
         const uint4 *wsrc = wp + (size_t)(((cq * C::NCB + cb) * C::NOQ + oq) * OPW) * KS * 64 + lane;
 #pragma unroll
@@ -531,13 +544,13 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             for (int ks = 0; ks < KS; ++ks) wreg[j][ks] = __builtin_bit_cast(bf16x8, wsrc[(j * KS + ks) * 64]);
     }
     // bias and (BatchNorm mode 2) mean of the epilogue: LDS copies (zeros without a bias) in the area of the final BatchNorm row
-    for (int e = tid; e < 2 * COUTW; e += WIN_THREADS)
+    for (int e = tid; e < 2 * COUTW; e += C::THREADS)
         cols[e] = e < COUTW ? (bias ? bias[cq * COUTW + e] : 0.0f) : (bn.mode == 2 ? bn.mean[cq * COUTW + e - COUTW] : 0.0f);
     // the zero rows in front of both windows
     auto clear_zero1 = [&]() {
-        for (int e = tid; e < C::Z0 * ROWB / 4; e += WIN_THREADS) ((int *)(smem + C::ZERO1))[e] = 0;
+        for (int e = tid; e < C::Z0 * ROWB / 4; e += C::THREADS) ((int *)(smem + C::ZERO1))[e] = 0;
     };
-    for (int e = tid; e < C::Z0 * ROWB / 4; e += WIN_THREADS) ((int *)(smem + C::ROWBASE))[e] = 0;
+    for (int e = tid; e < C::Z0 * ROWB / 4; e += C::THREADS) ((int *)(smem + C::ROWBASE))[e] = 0;
     clear_zero1();
 
     const u32x4 xdma = win_rsrc(x, x_bytes);
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)smem);      // LDS address of smem[0]
     if (STAGEW) {
         const u32x4 wdma = win_rsrc(wp, (unsigned)(NWP * 1024));
-        for (int pc = wave8; pc < NWP; pc += 8)
+        for (int pc = wave8; pc < NWP; pc += C::NW)
             win_glds16(wdma, lds0 + (unsigned)(C::WIN1 + pc * 1024), (unsigned)(pc * 1024) + (unsigned)lane * 16u);
     }
 
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
     auto issue_slot = [&](const WinPlan p, int tile, int buf, int pass, int slot) {
         if (dbg & 1) return;
         if (slot < 3 * SPR) {
-            const int g = slot / SPR, i = wave8 + 8 * (slot % SPR);
+            const int g = slot / SPR, i = wave8 + C::NW * (slot % SPR);
             const int cnt = min(R, p.cnt(g) - pass * R);
             if (i * C::RPI < cnt) {
                 // (whole pieces: the rows past the end of the run are rows of x nobody refers to, or lie beyond the buffer)
@@ -606,8 +619,8 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                 const unsigned sbase = (unsigned)(p.lo(g) + pass * R + i * C::RPI) * (unsigned)ROWB;
                 win_glds16(xdma, lds0 + (unsigned)(C::ROWBASE + wrow * ROWB), sbase + wlane);
             }
-        } else if (wave8 + 8 * (slot - 3 * SPR) < C::NTABI && pass == 0) {
-            const int piece = wave8 + 8 * (slot - 3 * SPR);
+        } else if (wave8 + C::NW * (slot - 3 * SPR) < C::NTABI && pass == 0) {
+            const int piece = wave8 + C::NW * (slot - 3 * SPR);
             win_glds16(tdma, lds0 + (unsigned)(C::TAB0 + buf * C::TABB + piece * 1024),
                        (unsigned)tile * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
         }
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         const int tq = fresh(tid);
 #pragma unroll
         for (int u = 0; u < C::NL; ++u) {
-            const int e = tq + u * WIN_THREADS;
+            const int e = tq + u * C::THREADS;
             const int k = e / T, r = e - k * T;
             const unsigned off = e < 27 * T ? ((unsigned)k * (unsigned)nbr_stride + (unsigned)(t * T + r)) * 4u : 0xFFFFFFF0u;
             nv[u] = __builtin_amdgcn_raw_buffer_load_b32(nrsrc, off, 0, 0);
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         const int tq = fresh(tid);
 #pragma unroll
         for (int u = 0; u < C::NL; ++u) {
-            const int e = tq + u * WIN_THREADS;
+            const int e = tq + u * C::THREADS;
             const int k = e / T, r = e - k * T;
             const int g = (k / 3) % 3;
             const int lo = p.lo(g) + pass * R;
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             const bool first = chunk0 == t_begin;
             const WinPlan p0 = make_plan(first ? ent1 : hdr_g[(size_t)chunk0 * 2], first ? ent2 : hdr_g[(size_t)chunk0 * 2 + 1]);
             for (int q = 0; q < NSLOT; ++q) issue_slot(p0, chunk0, 0, 0, q);
-            for (int e = tid; e < (chunk1 - chunk0) * 2; e += WIN_THREADS) ((int4 *)(smem + C::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
+            for (int e = tid; e < (chunk1 - chunk0) * 2; e += C::THREADS) ((int4 *)(smem + C::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp();                         // (trace slot 1: weights + first window have landed)
             __syncthreads();
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
                 // channel out of LDS, one bf16 rounding) + the barrier that publishes it, before the MFMA loop
                 const float *aff = (const float *)(smem + C::COLS);            // [2 COUT] floats: stands in for scale | shift
                 char *wbase = smem + C::ROWBASE + (buf ? C::WIN1ROW : C::Z0) * ROWB;
-                for (int e = fresh(tid); e < C::WINROWS * C::S; e += WIN_THREADS) {
+                for (int e = fresh(tid); e < C::WINROWS * C::S; e += C::THREADS) {
                     const unsigned row = (unsigned)e / C::S, slot = (unsigned)e % C::S;
                     const unsigned cg = slot ^ C::swz(row + (buf ? C::WIN1ROW : C::Z0));
                     uint4 v = *reinterpret_cast<uint4 *>(wbase + (size_t)e * 16);
@@ -947,7 +960,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             }
             WIN_BARRIER();                               // B3
             stamp();
-            if (!(dbg & 8) && (C::NEPI == WIN_THREADS || fresh(tid) < C::NEPI)) {   // tile epilogue: the slices summed in order
+            if (!(dbg & 8) && (C::NEPI == C::THREADS || fresh(tid) < C::NEPI)) {   // tile epilogue: the slices summed in order
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.0f;
@@ -985,10 +998,10 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < 2 * COUTW; e += WIN_THREADS) {
+        for (int e = tid; e < 2 * COUTW; e += C::THREADS) {
             const int which = e / COUTW, c = e % COUTW;
             float s = 0.0f;
-            for (int w = 0; w < 8; ++w) s += stage[(w * C::CG + c / 8) * 16 + which * 8 + (c & 7)];
+            for (int w = 0; w < C::NW; ++w) s += stage[(w * C::CG + c / 8) * 16 + which * 8 + (c & 7)];
             if (which == 1 && bn.mode == 2) s *= bn.invstd[cq * COUTW + c];
             cols[e] = s;
         }
@@ -1001,7 +1014,7 @@ __global__ __launch_bounds__(WIN_THREADS, 1) void subm_win_kernel(
         }, (int)gridDim.x);
     }
     stamp();                                 // (last trace slot: kernel exit)
-    if (trace && threadIdx.x == 0) trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (trace && threadIdx.x == 0 && blockIdx.x < 256) trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 
 
@@ -1010,14 +1023,14 @@ static int launch_win(const void *x, int n_rows, const void *wp, const float *bi
                       const int32_t *n_dev, const void *plan, void *y, const void *addend,
                       const PcdBnReduce *bnr, hipStream_t st, float *y_f32 = nullptr) {
     BnRed bn;
-    const int grid = win_grid();
+    const int grid = win_grid<C>();
     if (int rc = make_bnred(bnr, PCD_BF16, C::COUT, grid, &bn)) return rc;
     if ((double)n_rows * C::ROWB >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
     auto k = subm_win_kernel<C>;
     // (set per call: the attribute is per device, the call idempotent)
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
         return PCD_ERR_LAUNCH;
-    k<<<grid, WIN_THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
+    k<<<grid, C::THREADS, C::LDS_BYTES, st>>>((const unsigned short *)x, (const uint4 *)wp, bias, nbr, nbr_stride,
                                                     n_rows, n_dev, (const int4 *)plan, (unsigned short *)y,
                                                     (unsigned)((size_t)n_rows * C::ROWB), (const unsigned short *)addend, bn,
                                                     pcd_opt(PCD_OPT_WIN_DBG), g_win_trace, y_f32);
@@ -1050,11 +1063,11 @@ struct WgCfg {
     static constexpr int NOH = MB >= 4 ? 2 : 1;
     static constexpr int NO = (9 + NOH - 1) / NOH;                 // offsets per wave
     static constexpr int NG = MB * NOH;
-    static constexpr int RS = 8 / NG;
+    static constexpr int RS = C::NW / NG;
     static constexpr int NSTEP = T / 32;
-    static_assert(NG * RS == 8 && NSTEP % RS == 0, "wave roles");
-    static constexpr int SPRW = (R / C::RPI + 7) / 8;              // window DMA instructions per wave and tile
-    static_assert(T * ROWB == 8192, "dy tile: one 1-KiB DMA instruction per wave");
+    static_assert(NG * RS == C::NW && NSTEP % RS == 0, "wave roles");
+    static constexpr int SPRW = (R / C::RPI + C::NW - 1) / C::NW;  // window DMA instructions per wave and tile
+    static_assert(T * ROWB == C::NW * 1024, "dy tile: one 1-KiB DMA instruction per wave");
     // A tile's compute is short (~1 k clk) against the latency of its DMAs: a ring of NBUF stages, filled NBUF - 1 tiles ahead.
     // LDS: [Z0 zero rows][NBUF windows of R rows][NBUF dy tiles][NBUF tables][plans]
     static constexpr int NBUF = 3;
@@ -1064,8 +1077,8 @@ struct WgCfg {
     static constexpr int PLAN = TAB0 + NBUF * C::TABB;
     static constexpr int LDS_BYTES = PLAN + WIN_PLAN_CAP * 32;
     static constexpr int REDB = (RS - 1) * NG * NO * NB * 1024;    // final cross-wave sums, over the windows
-    static_assert(REDB <= PLAN && LDS_BYTES <= 160 * 1024, "LDS");
-    static constexpr int NL = (9 * T + WIN_THREADS - 1) / WIN_THREADS;
+    static_assert(REDB <= PLAN && LDS_BYTES <= (C::NW == 8 ? 160 : 80) * 1024, "LDS");
+    static constexpr int NL = (9 * T + C::THREADS - 1) / C::THREADS;
 };
 
 template <class C, int G>
@@ -1128,7 +1141,7 @@ __device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict_
     constexpr int NSL = W::SPRW + 1 + C::TSL;
     auto issue_slot = [&](const Run p, int tile, int buf, int pass, int slot) -> int {
         if (slot < W::SPRW) {
-            const int i = wave8 + 8 * slot;
+            const int i = wave8 + C::NW * slot;
             if (i * C::RPI >= min(R, p.cnt - pass * R)) return 0;
             win_glds16(xdma, lds0 + (unsigned)(W::WIN0 + (buf * R + i * C::RPI) * ROWB),
                        (unsigned)(p.lo + pass * R + i * C::RPI) * (unsigned)ROWB + wlane);
@@ -1140,7 +1153,7 @@ __device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict_
                        (unsigned)(tile * T + wave8 * C::RPI) * (unsigned)ROWB + wlane);
             return 1;
         }
-        const int piece = wave8 + 8 * (slot - W::SPRW - 1);
+        const int piece = wave8 + C::NW * (slot - W::SPRW - 1);
         if (piece >= C::NTABI) return 0;
         win_glds16(tdma, lds0 + (unsigned)(W::TAB0 + buf * C::TABB + piece * 1024),
                    (unsigned)tile * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
@@ -1245,7 +1258,7 @@ __device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict_
                 const Run p1 = run_of(hdr_g[(size_t)chunk0 * 2 + 2], hdr_g[(size_t)chunk0 * 2 + 3]);
                 c_next = issue(p1, chunk0 + 1, 1, 0);
             }
-            for (int e = tid; e < (chunk1 - chunk0) * 2; e += WIN_THREADS) ((int4 *)(smem + W::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
+            for (int e = tid; e < (chunk1 - chunk0) * 2; e += C::THREADS) ((int4 *)(smem + W::PLAN))[e] = hdr_g[(size_t)chunk0 * 2 + e];
             wait_vm(c_next);                 // (the plan loads are older than nothing here: staged below the barrier anyway)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1272,7 +1285,7 @@ __device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict_
                 unsigned short *tabw = (unsigned short *)(smem + W::TAB0 + buf * C::TABB);
 #pragma unroll
                 for (int u = 0; u < W::NL; ++u) {
-                    const int e = tid + u * WIN_THREADS;
+                    const int e = tid + u * C::THREADS;
                     const int o = e / T, r = e - o * T;
                     const int k = 9 * (o / 3) + 3 * G + o % 3;
                     if (e < 9 * T) {
@@ -1338,21 +1351,21 @@ __device__ __forceinline__ void wgrad_win_body(const unsigned short *__restrict_
         }
     }
     stamp();
-    if (trace && threadIdx.x == 0) {         // per-workgroup entry / exit times (trace[256 + b], trace[512 + b])
+    if (trace && threadIdx.x == 0 && blockIdx.x < 256) {         // per-workgroup entry / exit times (trace[256 + b], trace[512 + b])
         trace[256 + blockIdx.x] = t_entry;
         trace[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
 template <class C>
-__global__ __launch_bounds__(WIN_THREADS, 1) void subm_wgrad_win_kernel(
+__global__ __launch_bounds__(C::THREADS, C::NW == 8 ? 1 : 2) void subm_wgrad_win_kernel(
     const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy, const int32_t *__restrict__ nbr, int nbr_stride,
     int n_cap, const int32_t *__restrict__ n_dev, const char *__restrict__ plan_g, float *__restrict__ slab, unsigned x_bytes,
     unsigned dy_bytes, unsigned long long *trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    if (j >= 30) return;
-    const int share = xcd * (WIN_WG_SHARES / 8) + j / 3;
+    if (j >= 3 * (C::WG_SHARES / 8)) return;
+    const int share = xcd * (C::WG_SHARES / 8) + j / 3;
     const int n = eff_rows(n_dev, n_cap);
     switch (j % 3) {
         case 0: wgrad_win_body<C, 0>(x, dy, nbr, nbr_stride, n_cap, n, plan_g, slab, x_bytes, dy_bytes, share, smem, trace); break;
@@ -1370,7 +1383,7 @@ static int launch_wgrad_win(const void *x, const void *dy, int n_rows, const int
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES) != hipSuccess)
         return PCD_ERR_LAUNCH;
     const unsigned bytes = (unsigned)((size_t)n_rows * C::ROWB);
-    k<<<WIN_GRID, WIN_THREADS, W::LDS_BYTES, st>>>((const unsigned short *)x, (const unsigned short *)dy, nbr, nbr_stride, n_rows,
+    k<<<WIN_GRID * (8 / C::NW), C::THREADS, W::LDS_BYTES, st>>>((const unsigned short *)x, (const unsigned short *)dy, nbr, nbr_stride, n_rows,
                                                    n_dev, (const char *)plan, slab, bytes, bytes, g_win_trace);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
@@ -1387,7 +1400,10 @@ extern "C" int pcd_subm_window_tile_rows(int c_in, int c_out) {
     return win_dispatch(c_in, c_out, [](auto c) { return (int)decltype(c)::T; }, 0);
 }
 
-extern "C" int pcd_subm_window_partial_rows(void) { return win_grid(); }
+// rows of PcdBnReduce.partial a forward / data-gradient launch of these widths writes (one per workgroup)
+extern "C" int pcd_subm_window_partial_rows(int c_in, int c_out) {
+    return win_dispatch(c_in, c_out, [](auto c) { return win_grid<decltype(c)>(); }, 0);
+}
 
 extern "C" int pcd_subm_window_set_trace(void *buf256_u64) {
     g_win_trace = (unsigned long long *)buf256_u64;
@@ -1411,7 +1427,7 @@ extern "C" int pcd_subm_window_plan(const int32_t *nbr, int nbr_stride, int n_ca
         using C = decltype(c);
         const int nt = pcd_div_up(n_cap, C::T);
         win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(nbr, nbr_stride, n_cap, n_dev, (char *)plan, nt);
-        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid());
+        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid<C>());
         return 0;
     }, 0);
     PCD_RETURN_IF_LAUNCH_FAILED();
@@ -1440,7 +1456,7 @@ extern "C" int pcd_subm_window_plan_cm(const int32_t *indices, int n_cap, const 
         cm_win_plan_kernel<C><<<pcd_div_up(nt, 4 * (C::T >= 64 ? 1 : 64 / C::T)), 256, 0, st>>>(
             (const int4 *)indices, n_cap, n_dev, shape_host[0], shape_host[1], shape_host[2], B.pitch, B.cw, B.cr, B.ncol_cap,
             (char *)plan, nt, nbr, nbr_full);
-        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid());
+        win_split_kernel<C><<<1, 1024, 0, st>>>((char *)plan, n_cap, n_dev, nt, win_grid<C>());
         return 0;
     }, 0);
     PCD_RETURN_IF_LAUNCH_FAILED();
@@ -1504,24 +1520,26 @@ extern "C" int pcd_sparse_conv_subm_window_f32(const void *x, int n_rows, int c_
     }, (int)PCD_ERR_UNSUPPORTED);
 }
 
-extern "C" int pcd_subm_window_wgrad_splits(void) { return WIN_WG_SHARES; }
+// partial slabs a weight-gradient launch at c channels leaves (= `splits` of its reduction job)
+extern "C" int pcd_subm_window_wgrad_splits(int c) {
+    return win_dispatch(c, c, [](auto cfg) { return (int)decltype(cfg)::WG_SHARES; }, 0);
+}
 
 extern "C" int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, int n_rows, int c, const int32_t *nbr,
                                                  int nbr_stride, const int32_t *n_rows_dev, const void *plan, void *slab,
                                                  size_t slab_bytes, void *stream) {
     PCD_ENTER();
     if (n_rows < 0 || !win_supported(c, c) || c > 64) return PCD_ERR_UNSUPPORTED;
-    if (!slab || slab_bytes < (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float)) return PCD_ERR_WORKSPACE;
+    const size_t need = (size_t)pcd_subm_window_wgrad_splits(c) * 27 * c * c * sizeof(float);
+    if (!slab || slab_bytes < need) return PCD_ERR_WORKSPACE;
     if (n_rows == 0) {
-        if (hipMemsetAsync(slab, 0, (size_t)WIN_WG_SHARES * 27 * c * c * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        if (hipMemsetAsync(slab, 0, need, (hipStream_t)stream) != hipSuccess)
             return PCD_ERR_LAUNCH;
         return PCD_OK;
     }
     if (!x || !dy || !nbr || !plan || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    switch (c) {
-        case 64: return launch_wgrad_win<Win64>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
-        case 32: return launch_wgrad_win<Win32>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
-        default: return launch_wgrad_win<Win16>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
-    }
+    return win_dispatch(c, c, [&](auto cfg) {
+        return launch_wgrad_win<decltype(cfg)>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+    }, (int)PCD_ERR_UNSUPPORTED);
 }

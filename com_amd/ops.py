@@ -1252,7 +1252,7 @@ def subm_window(x, packed_w, bias, rb, c_out, addend=None, bn_reduce=None):
 
     bnr = None
     if bn_reduce is not None:
-        bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows()), c_out, x.device)
+        bnr = bn_reduce._struct(int(L.lib().pcd_subm_window_partial_rows(int(c_in), int(c_out))), c_out, x.device)
     with _Timed(f"subm_win_kernel<{c_in}> {c_in}->{c_out} K=27", meta):
         L.check(L.lib().pcd_sparse_conv_subm_window(L.ptr(x), n, c_in, L.ptr(packed_w), L.ptr(bias), L.ptr(rb.nbr_buffer),
                                                     rb.nbr_buffer.shape[1], L.ptr(rb.n_out_dev), L.ptr(plan),
@@ -1271,7 +1271,7 @@ def subm_window_wgrad(x, dy, rb, out=None, defer=None, cin=None):
     n, c = x.shape
     lib = L.lib()
     plan = subm_window_plan(rb, c, c)
-    splits = int(lib.pcd_subm_window_wgrad_splits())
+    splits = int(lib.pcd_subm_window_wgrad_splits(int(c)))
     slab = torch.empty((splits * 27 * c * c * 4,), dtype=torch.uint8, device=x.device)
     cin = c if cin is None else int(cin)
     assert 0 < cin <= c

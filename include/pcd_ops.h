@@ -93,6 +93,8 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "fps_g" 0             workgroups per frame of the cooperative farthest point sampling (0: from the device's CU count)
  *   "gg_dbg" 0, "ggw_dbg" 0, "win_dbg" 0   ablation bit masks of the gather-GEMM kernels (profiling only)
  *   "ggwin" 0             (EXPERIMENTS build only, pcd_ops_experiments.h) 1: 128 -> 128 SubM layers through ggwin_kernel
+ *   "subm_window_half" 0  4-wave window configurations (256 threads, <= 80 KB of LDS: two workgroups per CU): bit 1 = 32 channels,
+ *                         bit 2 = 16 channels.  Set it before the first plan is built: plans, packs and launches of a width must agree
  *   "subm_window_grid" 256   workgroups of a window launch (a multiple of 8, <= 256); fewer leave CUs to other streams --
  *                         measured: no gain (240 / 224 / 192: 0 / -0.5 / -1 % in the step)
  *   "cm_direct_blocks" 4096   column-map builds: up to this many scan blocks add up the block sums themselves, beyond it a
@@ -976,10 +978,11 @@ int pcd_debug_spin_shape(int blocks, int threads, int lds_bytes, int vgprs, unsi
  *                                  1 data gradient: transposed, offsets reversed), pcd_subm_window_packed_weight_bytes bytes;
  *                                  _batched: table rows of 8 x i64
  *                                  {weight ptr, packed ptr, c_in, mode, first 256-thread block, 0, 0, 0}
- *   pcd_subm_window_partial_rows   rows of PcdBnReduce.partial the launch writes (one per persistent workgroup)
+ *   pcd_subm_window_partial_rows   rows of PcdBnReduce.partial a launch of these widths writes (one per persistent workgroup: 256, or 512
+ *                                  for the 4-wave configurations of option "subm_window_half")
  * ============================================================================================ */
 int pcd_subm_window_tile_rows(int c_in, int c_out);
-int pcd_subm_window_partial_rows(void);
+int pcd_subm_window_partial_rows(int c_in, int c_out);
 /* profiling aid: a device buffer of 1024 x u64 whose first 256 entries receive shader-clock stamps of workgroup 0 at the phase boundaries of its
  * tiles (7 per tile: barrier, prefetch issued, MFMA loop done, prefetch landed, barrier, partial sums written + barrier,
  * epilogue done); NULL (the default) = off.  Process-wide; tools/exp_subm_win.py */
@@ -1003,7 +1006,7 @@ int pcd_subm_window_pack_weights_batched(const void *table, int n, int total_blo
 /* Weight gradient over the same tiles: slab[s][c_out][27][c_in] f32 for s < pcd_subm_window_wgrad_splits() partial sums
  * (slab_bytes >= splits * 27 * c * c * 4), to be summed over s in order -- pcd_sparse_conv_wgrad_reduce_batched with
  * job.splits = that count does it (same job as pcd_sparse_conv_wgrad_os).  x, dy: bf16 [n_rows][c]; nbr / plan as above. */
-int pcd_subm_window_wgrad_splits(void);
+int pcd_subm_window_wgrad_splits(int c);
 int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, int n_rows, int c, const int32_t *nbr, int nbr_stride,
                                       const int32_t *n_rows_dev, const void *plan, void *slab, size_t slab_bytes,
                                       void *stream);

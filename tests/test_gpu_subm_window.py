@@ -419,25 +419,31 @@ def test_mid_rows_of_the_conv_launch_are_the_sums_of_its_partial_rows(ch, lvl):
 
 
 def _plan_headers(plan, n, T):
-    """(passes per tile) out of a window plan buffer: [entries 256 x 64 B][wshares 1 KiB][prefix nt x i32 -> 32 B][headers nt x 32 B]..."""
+    """(passes per tile) out of a window plan buffer: [entries 512 x 64 B][wshares 2 KiB][prefix nt x i32 -> 32 B][headers nt x 32 B]..."""
     nt = (n + T - 1) // T
-    off = 256 * 64 + 1024 + (nt * 4 + 31) // 32 * 32
+    off = 512 * 64 + 2048 + (nt * 4 + 31) // 32 * 32
     hdr = plan[off:off + nt * 32].view(torch.int32).view(nt, 8)
     return hdr[:, 6].cpu().numpy()
 
 
-def _plan_sections(plan, n, T):
+def _half(ch):
+    """The 4-wave configuration of this width is selected (option "subm_window_half": 512 workgroups, 160 weight-gradient shares)."""
+    from com_amd import _lib as L
+    return bool(L.get_option("subm_window_half") & {32: 2, 16: 4}.get(ch, 0))
+
+
+def _plan_sections(plan, n, T, half=False):
     """The bytes of a plan buffer that the build writes (the reserved gaps between its sections are never initialised):
     workgroup entries, weight-gradient shares, cost prefix, tile headers, slot tables (64 B per row, whole tiles)."""
     nt = (n + T - 1) // T
-    o_ws, o_px = 256 * 64, 256 * 64 + 1024
+    o_ws, o_px = 512 * 64, 512 * 64 + 2048
     o_hd = o_px + (nt * 4 + 31) // 32 * 32
     o_tb = o_hd + nt * 32
-    return [plan[:o_ws], plan[o_ws:o_ws + 80 * 8], plan[o_px:o_px + nt * 4], plan[o_hd:o_hd + nt * 32], plan[o_tb:o_tb + nt * T * 64]]
+    return [plan[:(512 if half else 256) * 64], plan[o_ws:o_ws + (160 if half else 80) * 8], plan[o_px:o_px + nt * 4], plan[o_hd:o_hd + nt * 32], plan[o_tb:o_tb + nt * T * 64]]
 
 
-def _plans_equal(a, b, n, T):
-    return all(torch.equal(p, q) for p, q in zip(_plan_sections(a, n, T), _plan_sections(b, n, T)))
+def _plans_equal(a, b, n, T, half=False):
+    return all(torch.equal(p, q) for p, q in zip(_plan_sections(a, n, T, half), _plan_sections(b, n, T, half)))
 
 
 @pytest.mark.parametrize("ch,lvl", [(16, 1), (32, 2), (64, 3)])
@@ -455,9 +461,9 @@ def test_plan_straight_from_the_column_map_equals_the_plan_from_the_table(ch, lv
     plan_ref = ops.subm_window_plan(ref, ch, ch)
     full = ops.rulebook_subm(idx, 2, shape, rank=rank, want_pairs=False, window=(ch, ch), nbr_tables=True)
     assert full.nbr_complete and torch.equal(full.nbr_out, ref.nbr_out)
-    assert _plans_equal(full._win_plans[T], plan_ref, n, T)
+    assert _plans_equal(full._win_plans[T], plan_ref, n, T, _half(ch))
     free = ops.rulebook_subm(idx, 2, shape, rank=rank, want_pairs=False, window=(ch, ch), nbr_tables=False)
-    assert not free.nbr_complete and _plans_equal(free._win_plans[T], plan_ref, n, T)
+    assert not free.nbr_complete and _plans_equal(free._win_plans[T], plan_ref, n, T, _half(ch))
     passes = _plan_headers(plan_ref, n, T)
     assert passes.min() >= 1 and (passes > 1).any(), "the test data must contain multi-pass tiles"
     assert (passes > 1).mean() < 0.1

@@ -63,10 +63,10 @@ for lvl in (1, 2, 3, 4):
     pairs = int((rb.nbr_out >= 0).sum().item())
     T = ops.subm_window_tile_rows(ch, ch)
     nt = (n + T - 1) // T
-    off = 256 * 64 + 1024 + (nt * 4 + 31) // 32 * 32              # (spconv_win.hip: win_hdr_off)
+    off = 512 * 64 + 2048 + (nt * 4 + 31) // 32 * 32              # (spconv_win.hip: win_hdr_off)
     pl = ops.subm_window_plan(rb, ch, ch)
     hdr = pl[off:off + nt * 32].view(torch.int32).view(nt, 8).cpu().numpy()
-    ent = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()
+    ent = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()        # (the 8-wave configurations' 256 entries)
     share = (ent[:, 1] - ent[:, 0])[:256 // (4 if ch == 128 else 1)]
     print(f"level {lvl}: shares of the workgroups: tiles min {share.min()} median {int(np.median(share))} max {share.max()}")
     runs = hdr[:, [1, 3, 5]]
@@ -230,7 +230,7 @@ if os.environ.get("WIN_BALANCE"):
         T = ops.subm_window_tile_rows(ch, ch)
         nt = (n + T - 1) // T
         pl = ops.subm_window_plan(rb, ch, ch)
-        off = 256 * 64 + 1024 + (nt * 4 + 31) // 32 * 32
+        off = 512 * 64 + 2048 + (nt * 4 + 31) // 32 * 32
         hdr = pl[off:off + nt * 32].view(torch.int32).view(nt, 8).cpu().numpy()
         ent_tab = pl[:256 * 64].view(torch.int32).view(256, 16).cpu().numpy()
         tr = torch.zeros(1024, dtype=torch.int64, device=dev)
