@@ -1540,6 +1540,9 @@ extern "C" int pcd_sparse_conv_subm_window_wgrad(const void *x, const void *dy, 
     if (!x || !dy || !nbr || !plan || nbr_stride < n_rows) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     return win_dispatch(c, c, [&](auto cfg) {
-        return launch_wgrad_win<decltype(cfg)>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+        if constexpr (decltype(cfg)::CIN <= 64)         // (the 128-channel configuration of EXPERIMENTS builds has no weight-gradient kernel)
+            return launch_wgrad_win<decltype(cfg)>(x, dy, n_rows, nbr, nbr_stride, n_rows_dev, plan, (float *)slab, st);
+        else
+            return (int)PCD_ERR_UNSUPPORTED;
     }, (int)PCD_ERR_UNSUPPORTED);
 }
