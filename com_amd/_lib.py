@@ -79,6 +79,7 @@ PROTOTYPES = {
     "pcd_rulebook_subm_ranked4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
                                        _vp, _i]),
     "pcd_colmap_bytes": (_sz, [_i, _vp, _i]),
+    "pcd_colmap_counts_offset": (_sz, [_i, _vp, _i, _vp]),
     "pcd_colmap_from_rows_workspace_bytes": (_sz, [_i, _vp]),
     "pcd_colmap_from_rows": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     "pcd_rulebook_subm_cm_workspace_bytes": (_sz, [_i]),

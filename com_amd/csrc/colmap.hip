@@ -635,6 +635,18 @@ extern "C" size_t pcd_colmap_bytes(int batch, const int *shape_host, int n_cap) 
     return need;
 }
 
+// byte offset of the map's two counters {columns, rows} (int32 each, written by the build that produced the map) inside a
+// buffer of pcd_colmap_bytes(batch, shape, n_cap) bytes, and its column capacity: a caller checks columns <= capacity (a
+// strided build whose output z range does not cover every input z numbers columns WITHOUT rows: more columns than rows are
+// then possible, and columns beyond the capacity would be lost)
+extern "C" size_t pcd_colmap_counts_offset(int batch, const int *shape_host, int n_cap, int *ncol_cap_out) {
+    if (!shape_host) return 0;
+    CmBuf B;
+    if (!cm_carve(nullptr, 0, batch, shape_host[1], shape_host[2], n_cap, B, nullptr)) return 0;
+    if (ncol_cap_out) *ncol_cap_out = B.ncol_cap;
+    return ws_piece(B.nwords + 2, sizeof(uint2)) + ws_piece((size_t)B.ncol_cap + 1, sizeof(uint4));      // (cm_carve's order: cw, cr, counts)
+}
+
 extern "C" size_t pcd_colmap_from_rows_workspace_bytes(int batch, const int *shape_host) {
     if (!shape_host) return 0;
     CmBuf B;

@@ -573,6 +573,12 @@ class ColumnMap:
     def __init__(self, buf, cap, indices, shape, batch_size):
         self.buf, self.cap, self.indices, self.shape, self.batch_size = buf, int(cap), indices, list(shape), int(batch_size)
 
+    def counts(self):
+        """(device view of the map's {columns, rows} counters, column capacity)"""
+        capv = ctypes.c_int(0)
+        off = int(L.lib().pcd_colmap_counts_offset(self.batch_size, L.host_i32(self.shape), self.cap, ctypes.byref(capv)))
+        return self.buf[off:off + 8].view(torch.int32), int(capv.value)
+
     def matches(self, indices, shape, ks):
         return indices is self.indices and list(shape) == self.shape and list(ks) == [3, 3, 3]
 
@@ -630,8 +636,8 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
                                              rank.buf.numel(), rank.cap, L.ptr(nbr), L.ptr(pairs), L.ptr(pair_num),
                                              int(pad_pairs), L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
                     "pcd_rulebook_subm_cm")
-        T = subm_window_tile_rows(*window) if (window is not None and not want_pairs and n > 0) else 0
-        if T > 0:
+        T = _plan_key(*window) if (window is not None and not want_pairs and n > 0) else (0, 0)
+        if T[0] > 0:
             # plan (+ table, or only the multi-pass tiles' columns of it) in one pass over the column map
             win_plan = (T, torch.empty((max(int(lib.pcd_subm_window_plan_bytes(n, int(window[0]), int(window[1]))), 32),),
                                        dtype=torch.uint8, device=dev))
@@ -856,6 +862,16 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
                   n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
     rb.rank = ColumnMap(cmap, max(n_out, 1), out_indices, out_shape, batch_size) if n_out > 0 else None
     rb.order = ROWS_YXZ
+    if rb.rank is not None:
+        # columns <= the map's column capacity?  (a geometry whose output z range does not cover every input z -- pad_z 0, k 3, s 2
+        # on an even depth -- numbers output columns that have no rows: more columns than rows are then possible, and the capacity is
+        # sized by rows; columns beyond it would be lost silently)
+        cnts, ncol_cap = rb.rank.counts()
+        if static:
+            PLAN.record(("columns",) + tuple(plan_key if isinstance(plan_key, tuple) else (plan_key,)), cnts[0:1], ncol_cap)
+        elif int(cnts[0].item()) > ncol_cap:
+            raise L.PcdError(f"column map of the output level: {int(cnts[0].item())} columns > capacity {ncol_cap} "
+                             "(output z range does not cover the input: use the flat build, order=ROWS_ZYX, for this geometry)")
     if classes is not None:
         rb.classes = classes
     elif want_pairs and ncls <= 8:
@@ -1184,11 +1200,18 @@ def subm_window_tile_rows(c_in, c_out):
     return int(L.lib().pcd_subm_window_tile_rows(int(c_in), int(c_out)))
 
 
+def _plan_key(c_in, c_out):
+    """What a cached plan depends on beside the rulebook: the tile size of the configuration that serves these widths AND the
+    number of workgroups its shares were cut for (option "subm_window_grid" / "subm_window_half") -- a plan built under one
+    setting must not be launched under another (the launch reads the options again)."""
+    return (subm_window_tile_rows(c_in, c_out), int(L.lib().pcd_subm_window_partial_rows(int(c_in), int(c_out))))
+
+
 def subm_window_plan(rb, c_in, c_out):
     """The three runs of neighbour rows of every tile of `rb` (a SubM 3x3x3 Rulebook), cached on the rulebook per tile
     size: every conv of the indice_key, forward and backward, shares it."""
-    T = subm_window_tile_rows(c_in, c_out)
-    assert T > 0 and rb.subm and rb.kvol == 27
+    T = _plan_key(c_in, c_out)
+    assert T[0] > 0 and rb.subm and rb.kvol == 27
     cache = rb.__dict__.setdefault("_win_plans", {})
     if T not in cache:
         lib = L.lib()

@@ -328,6 +328,11 @@ int pcd_rulebook_subm_ranked(const int32_t *indices, int n, int batch, const int
  *       count (+ class counts) -> emit map + coordinates (+ class offsets) -> both neighbour tables (+ class
  *       permutation) -> pair lists.  _count / _fill share one untouched workspace (the host reads n_out in between). */
 size_t pcd_colmap_bytes(int batch, const int *shape_host, int n_cap);
+/* Byte offset, inside a buffer of pcd_colmap_bytes(batch, shape, n_cap) bytes, of the map's counters {columns, rows} (two int32,
+ * written by the build that produced the map); *ncol_cap_out receives its column capacity.  A strided build whose output z
+ * range does not cover every input z numbers columns WITHOUT rows, so columns > rows is possible: check columns <= capacity
+ * (com_amd.ops does: it rebuilds with a larger map in eager mode and records the count with the static plan's overflow guard). */
+size_t pcd_colmap_counts_offset(int batch, const int *shape_host, int n_cap, int *ncol_cap_out);
 size_t pcd_colmap_from_rows_workspace_bytes(int batch, const int *shape_host);
 int pcd_colmap_from_rows(const int32_t *indices, int n, const int32_t *n_dev, int batch, const int *shape_host,
                          void *colmap, size_t colmap_bytes, void *workspace, size_t workspace_bytes, void *stream);

@@ -333,3 +333,22 @@ def test_pair_driven_strided_conv_against_the_oracle_and_the_gather_kernels(dire
         want = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)])
         mag = torch.stack([y.double().abs().sum(0), (y.double() ** 2).sum(0)]).clamp_min(1.0)
         assert float(((got - want).abs() / mag).max()) < 2e-6
+
+
+def test_columns_without_rows_are_counted_against_the_map_capacity():
+    """pad_z 0, k 3, s 2 on an EVEN depth: input plane D - 1 feeds no output z, so an input column that only holds that plane
+    gives its output BEV cell a column WITHOUT rows -- more columns than rows are possible while the map's column capacity is sized
+    by rows (round-5 advisor finding).  The build reports its column count; the host layer refuses a map that lost columns."""
+    ops = _ops()
+    D, H, W = 4, 24, 40
+    # every second BEV cell holds ONLY z = D - 1 (no output rows), a few cells hold z = 0 (one output row each)
+    rows = [(0, D - 1, y, x) for y in range(0, H, 2) for x in range(0, W, 2)] + [(0, 0, 1, 1), (0, 0, 5, 9)]
+    idx = _sorted_yxz(np.array(rows, np.int32))
+    idx_t = torch.from_numpy(idx).to(DEV)
+    cmap = ops.colmap_from_rows(idx_t, 1, [D, H, W])
+    with pytest.raises(ops.L.PcdError, match="columns > capacity"):
+        ops.rulebook_conv(idx_t, 1, [D, H, W], (3, 3, 3), (2, 2, 2), (0, 1, 1), order=ops.ROWS_YXZ, in_rank=cmap)
+    # the same rows through the flat build: the oracle's rulebook
+    rb = ops.rulebook_conv(idx_t, 1, [D, H, W], (3, 3, 3), (2, 2, 2), (0, 1, 1), pad_pairs=True)
+    rb_o = O.rulebook_conv(idx, (D, H, W), (3, 3, 3), (2, 2, 2), (0, 1, 1))
+    np.testing.assert_array_equal(_cpu(rb.out_indices), rb_o["out_indices"])

@@ -461,9 +461,9 @@ def test_plan_straight_from_the_column_map_equals_the_plan_from_the_table(ch, lv
     plan_ref = ops.subm_window_plan(ref, ch, ch)
     full = ops.rulebook_subm(idx, 2, shape, rank=rank, want_pairs=False, window=(ch, ch), nbr_tables=True)
     assert full.nbr_complete and torch.equal(full.nbr_out, ref.nbr_out)
-    assert _plans_equal(full._win_plans[T], plan_ref, n, T, _half(ch))
+    assert _plans_equal(full._win_plans[ops._plan_key(ch, ch)], plan_ref, n, T, _half(ch))
     free = ops.rulebook_subm(idx, 2, shape, rank=rank, want_pairs=False, window=(ch, ch), nbr_tables=False)
-    assert not free.nbr_complete and _plans_equal(free._win_plans[T], plan_ref, n, T, _half(ch))
+    assert not free.nbr_complete and _plans_equal(free._win_plans[ops._plan_key(ch, ch)], plan_ref, n, T, _half(ch))
     passes = _plan_headers(plan_ref, n, T)
     assert passes.min() >= 1 and (passes > 1).any(), "the test data must contain multi-pass tiles"
     assert (passes > 1).mean() < 0.1
