@@ -74,6 +74,7 @@ PROTOTYPES = {
     "pcd_rulebook_subm_ranked_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_pairs_workspace_bytes": (_sz, [_i, _i]),
     "pcd_rulebook_subm_pairs": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_pairs": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pcd_rulebook_subm_ranked": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
                                       _vp, _i]),
     "pcd_rulebook_subm_ranked4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz,
@@ -124,6 +125,8 @@ PROTOTYPES = {
     "pcd_sparse_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_v2": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "pcd_sparse_conv_wgrad_classes": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                           _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_reduce_batched": (_i, [_vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_os_splits": (_i, [_i, _i, _i, _i]),

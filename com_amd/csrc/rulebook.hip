@@ -891,10 +891,28 @@ extern "C" size_t pcd_rulebook_subm_pairs_workspace_bytes(int n, int kvol) {
 
 // indice_pairs / indice_pair_num of a SubM rulebook from its neighbour table alone (for rulebooks built with
 // pairs == NULL whose pairs turn out to be needed later); same result as pcd_rulebook_subm's.
+static int pairs_from_table(const int32_t *nbr, int n, int kvol, int flip, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int pcd_rulebook_subm_pairs(const int32_t *nbr, int n, int kvol, int32_t *pairs, int32_t *pair_num,
                                        int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
                                        void *stream) {
     PCD_ENTER();
+    return pairs_from_table(nbr, n, kvol, 1, pairs, pair_num, pad_pairs, n_dev, workspace, workspace_bytes, stream);
+}
+
+// The same for a STRIDED rulebook built without pair lists (the training step reads its pairs off the parity classes:
+// pcd_sparse_conv_wgrad_classes): indice_pairs / indice_pair_num from nbr_in [kvol][n] alone, same result as the build's.
+// Workspace: pcd_rulebook_subm_pairs_workspace_bytes(n, kvol).
+extern "C" int pcd_rulebook_conv_pairs(const int32_t *nbr_in, int n, int kvol, int32_t *pairs, int32_t *pair_num,
+                                       int pad_pairs, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    PCD_ENTER();
+    return pairs_from_table(nbr_in, n, kvol, 0, pairs, pair_num, pad_pairs, n_dev, workspace, workspace_bytes, stream);
+}
+
+static int pairs_from_table(const int32_t *nbr, int n, int kvol, int flip, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 0 || kvol <= 0 || !pair_num || (n > 0 && (!nbr || !pairs))) return PCD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
@@ -908,9 +926,9 @@ extern "C" int pcd_rulebook_subm_pairs(const int32_t *nbr, int n, int kvol, int3
     int *totals = ws.take<int>(kvol);
     if (!ws.ok) return PCD_ERR_WORKSPACE;
     nbr_wave_count_kernel<<<pcd_div_up(n, 256), 256, 0, st>>>(nbr, n, n_dev, kvol, nwaves, wave_cnt);
-    scan_rows_kernel<<<kvol, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, 1);
+    scan_rows_kernel<<<kvol, 256, 0, st>>>(wave_cnt, wave_off, nwaves, totals, pair_num, flip);
     if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)kvol * 2 * n * sizeof(int32_t), st);
-    launch_pairs_fill(nbr, n, n_dev, kvol, 1, wave_off, nwaves, pairs, st);
+    launch_pairs_fill(nbr, n, n_dev, kvol, flip, wave_off, nwaves, pairs, st);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }

@@ -1052,12 +1052,24 @@ struct WgradStride {  // elements; C/16 even -> pad by 16 elements (8 dwords)
     static constexpr int value = ((C / 16) % 2 == 0) ? C + 16 : C;
 };
 
+// Pair lists of a STRIDED conv without the lists (pcd_sparse_conv_wgrad_classes): offset k is usable by the rows of exactly one
+// stride-parity class (ClsTable above), and for those rows it almost always has an output (every input row creates the
+// outputs it reaches; only the grid border cuts some).  So the pairs of offset k ARE {(i, nbr_in[k][i]) : i in class(k)}:
+// `pairs` is then the class permutation (ascending rows per class, -1 behind each class's last row), the second index
+// comes from the neighbour table, and a missing output (-1) gathers a zero row.
+struct WgClasses {
+    const int32_t *nbr_in;          // nullptr: explicit pair lists
+    const int32_t *vstart;          // [ncls + 1] first permutation slot of every class
+    int stride;                     // row stride of nbr_in
+    unsigned char cls_of_k[28];
+};
+
 template <int MB, int NBW>
 __global__ __launch_bounds__(256) void wgrad_kernel(
     const unsigned short *__restrict__ x, int cin_pad, int cin, const unsigned short *__restrict__ dy,
     int cout, const int32_t *__restrict__ pairs, const int32_t *__restrict__ pair_num, int K, int pmax,
     int rows_per_split, int n_splits, int n_chunks, int n_cout_chunks, float *__restrict__ slab,
-    unsigned x_bytes, unsigned dy_bytes, int n_x_cap, const int32_t *__restrict__ n_x_dev) {
+    unsigned x_bytes, unsigned dy_bytes, int n_x_cap, const int32_t *__restrict__ n_x_dev, WgClasses I) {
     constexpr int CI = MB * 16, CO = NBW * 16;
     // the row-range splits partition the REAL input rows (static-shape mode: n_x_cap is a capacity, the count lives
     // on the device): with capacity-sized ranges the last splits -- the last XCDs' share -- would be empty
@@ -1086,10 +1098,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     const int cic = chunk / n_cout_chunks;
     const int coc = chunk % n_cout_chunks;
     const int ci0 = cic * CI, co0 = coc * CO;
-    const int P = pair_num[k];
-    const int32_t *pin = pairs + ((size_t)k * 2 + 0) * pmax;
-    const int32_t *pout = pairs + ((size_t)k * 2 + 1) * pmax;
+    const bool implicit = I.nbr_in != nullptr;
+    int P;
+    const int32_t *pin, *pout;
+    if (implicit) {
+        const int c = I.cls_of_k[k];
+        const int v0 = I.vstart[c];
+        P = I.vstart[c + 1] - v0;
+        pin = pairs + v0;                                   // (the class permutation)
+        pout = I.nbr_in + (size_t)k * I.stride;             // indexed by the INPUT ROW
+    } else {
+        P = pair_num[k];
+        pin = pairs + ((size_t)k * 2 + 0) * pmax;
+        pout = pairs + ((size_t)k * 2 + 1) * pmax;
+    }
     // pairs of offset k are ascending in input row: this split owns input rows [row_lo, row_hi)
+    // (unsigned compares: the -1 slots behind a class's last row sort after every row)
     const int row_lo = split * rows_per_split, row_hi = row_lo + rows_per_split;
     // Both lower bounds at once with a 32-ary search: lanes 0-31 look for row_lo, lanes 32-63 for row_hi; every
     // round probes 32 evenly spaced positions per half and a ballot narrows the range 32x, so a 150k-pair list
@@ -1104,7 +1128,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
             const int width = hi - lo;
             const int step = (width + 31) >> 5;
             const int q = lo + l32 * step;
-            const bool pred = width > 0 && q < hi && pin[q] < target;
+            const bool pred = width > 0 && q < hi && (unsigned)pin[q] < (unsigned)target;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
             const int c = __builtin_popcount((unsigned)(half ? (m >> 32) : m));
             if (width > 0) {
@@ -1141,7 +1165,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     // (rows one step ahead, pair indices two steps ahead, so no dependent-load latency is exposed)
     u32x4 xr[MB], yr[NBW];
     int idx_n = -1;   // lanes 0-31: input row of pair p0 + lane; lanes 32-63: output row of pair p0 + lane - 32
+    // implicit lists: the output row is one more dependent load (nbr_in[k][input row]); the input rows are therefore
+    // requested one call EARLIER (calls come with p0 ascending by 128), so that no call waits on a load it issued itself
+    int a_cur = -1;
+    auto fetch_a = [&](int p0) {
+        const int p = p0 + (lane & 31);
+        a_cur = (p < p_end) ? pin[p] : -1;
+    };
     auto load_idx = [&](int p0) {
+        if (implicit) {
+            const int a = a_cur;
+            idx_n = (lane < 32 || a < 0) ? a : pout[a];
+            fetch_a(p0 + 128);
+            return;
+        }
         const int p = p0 + (lane & 31);
         idx_n = -1;
         if (p < p_end) idx_n = (lane < 32) ? pin[p] : pout[p];
@@ -1168,6 +1205,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
         }
     };
     const int p_first = p_begin + wave * 32;
+    if (implicit) fetch_a(p_first);
     load_idx(p_first);
     load_rows(idx_n);
     load_idx(p_first + 128);
@@ -1734,7 +1772,7 @@ static void wgrad_plan(int pmax, int cin, int cout, int *splits, int *rows_per_s
 template <int MB, int NBW>
 static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void *dy, int n_dy, int cout,
                         const int32_t *pairs, const int32_t *pair_num, int K, int pmax, float *slab,
-                        hipStream_t st, const int32_t *n_x_dev) {
+                        hipStream_t st, const int32_t *n_x_dev, const WgClasses &I) {
     constexpr int CI = MB * 16, CO = NBW * 16;
     int splits, per;
     wgrad_plan(pmax, cin, cout, &splits, &per);
@@ -1749,7 +1787,7 @@ static int launch_wgrad(const void *x, int n_x, int cin_pad, int cin, const void
                                                   (const unsigned short *)dy, cout, pairs, pair_num, K,
                                                   pmax, per, splits, ncic * ncoc, ncoc, slab,
                                                   (unsigned)((size_t)n_x * cin_pad * 2),
-                                                  (unsigned)((size_t)n_dy * cout * 2), n_x, n_x_dev);
+                                                  (unsigned)((size_t)n_dy * cout * 2), n_x, n_x_dev, I);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -2019,11 +2057,57 @@ extern "C" int pcd_sparse_conv_wgrad(const void *x, int n_x, int cin_pad, int ci
                                     workspace, workspace_bytes, stream);
 }
 
+static int wgrad_impl(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin, const void *dy, int n_dy, int cout,
+                      const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax, float *dweight, void *workspace,
+                      size_t workspace_bytes, void *stream, const WgClasses &I);
+
 extern "C" int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin,
                                         const void *dy, int n_dy, int cout, const int32_t *pairs,
                                         const int32_t *pair_num, int kvol, int pmax, float *dweight, void *workspace,
                                         size_t workspace_bytes, void *stream) {
     PCD_ENTER();
+    if (pmax > 0 && (!pairs || !pair_num)) return PCD_ERR_INVALID_ARG;
+    WgClasses I = {};
+    return wgrad_impl(x, n_x, n_x_dev, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, dweight, workspace,
+                      workspace_bytes, stream, I);
+}
+
+// The weight gradient of a strided conv WITHOUT pair lists: the pairs of offset k are read off the parity-class permutation of
+// the input rows (pcd_rulebook_conv_cm_build / pcd_rulebook_conv_classes: perm, vstart_dev) and the neighbour table nbr_in
+// [kvol][nbr_stride] (see WgClasses).  Same slabs, same reduction job (pcd_sparse_conv_wgrad_reduce*, pmax = n_x) and -- the
+// pairs being the same pairs in the same order, plus zero rows where an output is missing -- the same values as
+// pcd_sparse_conv_wgrad_v2 over the rulebook's pair lists, to fp32 summation order.  kvol <= 27; not for 128 x 128 channels (PCD_ERR_UNSUPPORTED).
+extern "C" int pcd_sparse_conv_wgrad_classes(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin,
+                                             const void *dy, int n_dy, int cout, const int32_t *nbr_in, int nbr_stride,
+                                             const int *ksize_host, const int *stride_host, const int *dil_host,
+                                             const int32_t *perm, const int32_t *vstart_dev, float *dweight, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+    PCD_ENTER();
+    if (!ksize_host || !stride_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    const int kvol = ksize_host[0] * ksize_host[1] * ksize_host[2];
+    const int ncls = stride_host[0] * stride_host[1] * stride_host[2];
+    if (kvol <= 0 || kvol > 27 || ncls <= 0 || ncls > 8) return PCD_ERR_UNSUPPORTED;
+    if (cin > 0 && cout > 0 && wgrad128_use(cin, cout)) return PCD_ERR_UNSUPPORTED;
+    if (n_x > 0 && (!nbr_in || !perm || !vstart_dev || nbr_stride < n_x)) return PCD_ERR_INVALID_ARG;
+    WgClasses I = {};
+    I.nbr_in = nbr_in;
+    I.vstart = vstart_dev;
+    I.stride = nbr_stride;
+    for (int kz = 0; kz < ksize_host[0]; ++kz)
+        for (int ky = 0; ky < ksize_host[1]; ++ky)
+            for (int kx = 0; kx < ksize_host[2]; ++kx) {
+                const int k = (kz * ksize_host[1] + ky) * ksize_host[2] + kx;
+                const int rz = (kz * dil_host[0]) % stride_host[0], ry = (ky * dil_host[1]) % stride_host[1],
+                          rx = (kx * dil_host[2]) % stride_host[2];       // the class with (r - k d) % s == 0 on every axis
+                I.cls_of_k[k] = (unsigned char)((rz * stride_host[1] + ry) * stride_host[2] + rx);
+            }
+    return wgrad_impl(x, n_x, n_x_dev, cin_pad, cin, dy, n_dy, cout, perm, nullptr, kvol, n_x, dweight, workspace,
+                      workspace_bytes, stream, I);
+}
+
+static int wgrad_impl(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin, const void *dy, int n_dy, int cout,
+                      const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax, float *dweight, void *workspace,
+                      size_t workspace_bytes, void *stream, const WgClasses &I) {
     if (kvol <= 0 || cin <= 0 || cout <= 0 || pmax < 0 || cin_pad < cin || n_x < 0 || n_dy < 0)
         return PCD_ERR_INVALID_ARG;
     if ((double)n_x * cin_pad * 2 >= 4294966000.0 || (double)n_dy * cout * 2 >= 4294966000.0)
@@ -2035,7 +2119,7 @@ extern "C" int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n
         if (dweight) pcd_fill(dweight, 0, n * sizeof(float), st);
         return PCD_OK;
     }
-    if (!x || !dy || !pairs || !pair_num) return PCD_ERR_INVALID_ARG;
+    if (!x || !dy || !pairs) return PCD_ERR_INVALID_ARG;
     if (workspace_bytes < pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, pmax) || !workspace)
         return PCD_ERR_WORKSPACE;
     float *slab = (float *)workspace;
@@ -2053,7 +2137,7 @@ extern "C" int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n
     int rc = PCD_ERR_UNSUPPORTED;
 #define WG(M, N)                                                                                  \
     if (mb == M && nb == N)                                                                       \
-        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, slab, st, n_x_dev);
+        rc = launch_wgrad<M, N>(x, n_x, cin_pad, cin, dy, n_dy, cout, pairs, pair_num, kvol, pmax, slab, st, n_x_dev, I);
     WG(1, 1) WG(1, 2) WG(1, 4) WG(2, 1) WG(2, 2) WG(2, 4) WG(4, 1) WG(4, 2) WG(4, 4)
 #undef WG
     return rc;

@@ -479,6 +479,9 @@ class Rulebook:
         self.rank = None          # RankMap of the output level (strided builds only)
         self.order = None         # ROWS_* of the output rows when they are key-numbered (strided / rank-map builds)
         self.classes = None       # (perm, vstart, vcap): input rows grouped by stride-parity class (strided, training)
+        # strided, training: built WITHOUT pair lists -- the weight gradient reads the pairs of offset k off the parity class
+        # that can use k and nbr_in (pcd_sparse_conv_wgrad_classes); `pairs` / `pair_num` are derived on first access
+        self.implicit_pairs = False
 
     # nbr_out is the COMPLETE neighbour table.  A SubM rulebook of a level whose convs all run on window tiles is built without it
     # (rulebook_subm(..., window=, nbr_tables=False): the plan comes straight from the column map and only the columns of
@@ -514,6 +517,15 @@ class Rulebook:
             L.check(lib.pcd_rulebook_subm_pairs(L.ptr(self.nbr_out), n, self.kvol, L.ptr(self._pairs),
                                                 L.ptr(self._pair_num), 0, L.ptr(self.n_in_dev), L.ptr(ws), ws.numel(),
                                                 L.stream_ptr()), "pcd_rulebook_subm_pairs")
+        elif self._pairs is None and not self.subm and self.implicit_pairs and self.nbr_in is not None and self.n_in > 0:
+            lib = L.lib()
+            n, dev = self.nbr_in.shape[1], self.nbr_in.device
+            self._pairs = torch.empty((self.kvol, 2, n), dtype=torch.int32, device=dev)
+            self._pair_num = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+            ws = _ws(lib.pcd_rulebook_subm_pairs_workspace_bytes(n, self.kvol), dev)
+            L.check(lib.pcd_rulebook_conv_pairs(L.ptr(self.nbr_in), n, self.kvol, L.ptr(self._pairs), L.ptr(self._pair_num), 0,
+                                                L.ptr(self.n_in_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_rulebook_conv_pairs")
 
     @property
     def pairs(self):
@@ -682,8 +694,11 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
 
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
-                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX, in_rank=None):
-    """`order`: how the OUTPUT rows are numbered (ROWS_ZYX: ascending (b, z, y, x), spconv's sorted order; ROWS_YXZ:
+                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX, in_rank=None, pair_lists=True):
+    """`pair_lists=False` (with want_pairs): the parity classes are built, spconv's indice_pairs are not -- the weight gradient
+    reads its pairs off the classes (ops.wgrad(rb=...) -> pcd_sparse_conv_wgrad_classes) and `rb.pairs` / `rb.pair_num` are derived
+    from nbr_in on first access.
+    `order`: how the OUTPUT rows are numbered (ROWS_ZYX: ascending (b, z, y, x), spconv's sorted order; ROWS_YXZ:
     ascending (b, y, x, z)); the input rows may come in any order.
     `in_rank`: the ColumnMap of the INPUT level (rows in ROWS_YXZ order): the build then derives the output level's map from
     it (pcd_rulebook_conv_cm_*: no map over the output volume, no atomics) -- same outputs; rb.rank is the output's map."""
@@ -701,7 +716,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     if isinstance(in_rank, ColumnMap) and order == ROWS_YXZ and n > 0 and dl == [1, 1, 1] \
             and in_rank.serves(indices, shp, batch_size):
         rb = _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank,
-                               out_shape)
+                               out_shape, pair_lists)
         if rb is not None:
             return rb
     wsb = lib.pcd_rulebook_conv_workspace_bytes(n, batch_size, *args)
@@ -712,13 +727,14 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     static = PLAN is not None and PLAN.active
     ncls = st[0] * st[1] * st[2]
     classes = None
+    lists = want_pairs and (pair_lists or ncls > 8 or K > 27)
 
     def outputs(n_out):
         return (torch.empty((n_out, 4), dtype=torch.int32, device=dev),
                 torch.empty((K, n), dtype=torch.int32, device=dev),
                 torch.empty((K, n_out), dtype=torch.int32, device=dev),
-                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None,
-                torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None)
+                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if lists else None,
+                torch.empty((K,), dtype=torch.int32, device=dev) if lists else None)
 
     def meta():                                  # read 16 N_in, write 8 P + 16 N_out
         p_ = int((nbr_in >= 0).sum().item())
@@ -773,6 +789,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     rb.rank = RankMap(ws, ws[boff.value:boff.value + 4 * nw].view(torch.int32),
                       ws[poff.value:poff.value + 4 * nw].view(torch.int32), out_indices, out_shape, 1, order)
     rb.order = order
+    rb.implicit_pairs = want_pairs and not lists
     if classes is not None:
         rb.classes = classes
     elif want_pairs and ncls <= 8:
@@ -790,9 +807,11 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 
 
 CLS_TILE = 256
+IMPLICIT_STRIDED_PAIRS = True     # spconv layers build strided rulebooks without indice_pairs (rulebook_conv(pair_lists=False))
 
 
-def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank, out_shape):
+def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank, out_shape,
+                      pair_lists=True):
     """rulebook_conv through the column maps (None: geometry outside what pcd_rulebook_conv_cm_* covers)."""
     PLAN = current_plan()
     lib = L.lib()
@@ -808,14 +827,15 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
     static = PLAN is not None and PLAN.active
     ncls = st[0] * st[1] * st[2]
     inmap = (L.ptr(in_rank.buf), in_rank.buf.numel(), in_rank.cap)
+    lists = want_pairs and (pair_lists or ncls > 8 or K > 27)
 
     def outputs(n_out):
         cmb = lib.pcd_colmap_bytes(batch_size, L.host_i32(out_shape), max(n_out, 1))
         return (torch.empty((n_out, 4), dtype=torch.int32, device=dev),
                 torch.empty((K, n), dtype=torch.int32, device=dev),
                 torch.empty((K, n_out), dtype=torch.int32, device=dev),
-                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if want_pairs else None,
-                torch.empty((K,), dtype=torch.int32, device=dev) if want_pairs else None,
+                torch.empty((K, 2, n), dtype=torch.int32, device=dev) if lists else None,
+                torch.empty((K,), dtype=torch.int32, device=dev) if lists else None,
                 torch.empty((cmb,), dtype=torch.uint8, device=dev))
 
     def meta():                                  # read 16 N_in, write 8 P + 16 N_out
@@ -862,6 +882,7 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
                   n_in_dev=n_dev, n_out_dev=n_out_dev if static else None)
     rb.rank = ColumnMap(cmap, max(n_out, 1), out_indices, out_shape, batch_size) if n_out > 0 else None
     rb.order = ROWS_YXZ
+    rb.implicit_pairs = want_pairs and not lists
     if rb.rank is not None:
         # columns <= the map's column capacity?  (a geometry whose output z range does not cover every input z -- pad_z 0, k 3, s 2
         # on an even depth -- numbers output columns that have no rows: more columns than rows are then possible, and the capacity is
@@ -1376,6 +1397,31 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
             defer.append(job)
         else:
             wgrad_reduce_batched([job])
+        return dw
+    if rb is not None and not rb.subm and rb.implicit_pairs and rb._pairs is None and rb.classes is not None \
+            and not (cin == 128 and cout == 128 and x.shape[1] == 128) and not x_block:
+        # strided rulebook without pair lists: the pairs of offset k are its parity class's rows and their nbr_in entries
+        n_x = x.shape[0]
+        wsb = lib.pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, n_x)
+        ws = _ws(wsb, x.device) if defer is None else torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
+
+        def meta_c():
+            npairs = int((rb.nbr_in >= 0).sum().item())
+            return dict(bytes=(n_x * x.shape[1] + dy.shape[0] * cout) * 2 + 8 * npairs + kvol * cin * cout * 4,
+                        flops=2 * npairs * x.shape[1] * cout, rows=dy.shape[0], pairs=npairs)
+
+        b = lambda c: 4 if (c + 15) // 16 >= 4 else (2 if (c + 15) // 16 >= 2 else 1)
+        with _Timed(f"wgrad_kernel<{b(cin)}, {b(cout)}> {x.shape[1]}x{cout} K={kvol} classes", meta_c):
+            L.check(lib.pcd_sparse_conv_wgrad_classes(L.ptr(x), n_x, L.ptr(n_in_dev), x.shape[1], cin, L.ptr(dy), dy.shape[0],
+                                                      cout, L.ptr(rb.nbr_in), rb.nbr_in.shape[1], L.host_i32(rb.ksize),
+                                                      L.host_i32(rb.stride), L.host_i32(rb.dilation), L.ptr(rb.classes[0]),
+                                                      L.ptr(rb.classes[1]), L.ptr(dw), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_sparse_conv_wgrad_classes")
+        if defer is not None:
+            defer.append((ws, dw, kvol, cin, cout, n_x, 0, 1 if conv2d_layout else 0, cout_write))
+            return dw
+        L.check(lib.pcd_sparse_conv_wgrad_reduce(kvol, cin, cout, n_x, L.ptr(dw), L.ptr(ws), L.stream_ptr()),
+                "pcd_sparse_conv_wgrad_reduce")
         return dw
     if rb is not None:
         pairs, pair_num = rb.pairs, rb.pair_num

@@ -201,6 +201,9 @@ class SparseConvolution(SparseModule):
             rb = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation, n_dev=x.num_rows,
                                    want_pairs=self._needs_backward(x),   # (pair lists / parity classes: backward only)
+                                   # no indice_pairs where the weight gradient reads its pairs off the parity classes
+                                   # (every width but 128 x 128, whose kernel cuts the concatenated lists into equal chunks)
+                                   pair_lists=not (ops.IMPLICIT_STRIDED_PAIRS and not (self.in_channels == 128 and self.out_channels == 128)),
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)),
                                    # the chain's row order (set by the backbone from the voxeliser's rank map)
                                    order=x.indice_dict.get("__row_order__", ops.ROWS_ZYX),

@@ -281,6 +281,11 @@ int pcd_rulebook_conv_build(const int32_t *indices, int n, int batch, const int 
 size_t pcd_rulebook_subm_pairs_workspace_bytes(int n, int kvol);
 int pcd_rulebook_subm_pairs(const int32_t *nbr, int n, int kvol, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                             const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+/* ... and of a STRIDED rulebook from its nbr_in table [kvol][n] (same workspace size): the training step builds strided
+ * rulebooks without pair lists (pcd_sparse_conv_wgrad_classes reads the pairs off the parity classes); whoever still wants
+ * spconv's indice_pairs (spconv/pytorch/ops.py get_indice_pairs' outputs) derives them here, same values as the build's. */
+int pcd_rulebook_conv_pairs(const int32_t *nbr_in, int n, int kvol, int32_t *pairs, int32_t *pair_num, int pad_pairs,
+                            const int32_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 /* The rank structure the strided build leaves in its workspace is exactly a coordinate -> row map of the OUTPUT
  * level (row id = rank of the linear key): the SubM rulebook of that level (the 'subm2..4' keys that follow
  * every strided conv of spconv_backbone.py:205-229) can use it instead of building and probing a hash table.
@@ -473,6 +478,18 @@ int pcd_sparse_conv_wgrad(const void *x, int n_x_rows, int cin_pad, int cin, con
 int pcd_sparse_conv_wgrad_v2(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin, const void *dy,
                              int n_dy, int cout, const int32_t *pairs, const int32_t *pair_num, int kvol, int pmax,
                              float *dweight, void *workspace, size_t workspace_bytes, void *stream);
+/* The weight gradient of a STRIDED conv without pair lists (replaces the indice_pairs argument of spconv's
+ * indice_conv_backward, spconv/pytorch/ops.py, for SparseConv3d layers spconv_backbone.py:205,212,219): every kernel offset
+ * k is usable by the input rows of exactly one stride-parity class, and for those rows it (almost) always has an output, so
+ * the pairs of offset k are {(i, nbr_in[k][i]) : i in class(k)} -- read off `perm` / `vstart_dev` (pcd_rulebook_conv_cm_build /
+ * pcd_rulebook_conv_classes) and nbr_in [kvol][nbr_stride]; a missing output gathers a zero row.  Same workspace
+ * (pcd_sparse_conv_wgrad_workspace_bytes(kvol, cin, cout, n_x)), same reduction (pmax = n_x); the result equals
+ * pcd_sparse_conv_wgrad_v2's over the rulebook's pair lists to fp32 summation order (a cut output holds a slot with a zero row).  kvol <= 27, at most 8 classes, not 128 x 128 channels. */
+int pcd_sparse_conv_wgrad_classes(const void *x, int n_x, const int32_t *n_x_dev, int cin_pad, int cin, const void *dy,
+                                  int n_dy, int cout, const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
+                                  const int *stride_host, const int *dil_host, const int32_t *perm,
+                                  const int32_t *vstart_dev, float *dweight, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
                                  const void *workspace, void *stream);
 /* The same reduction for up to PCD_WGRAD_MAX_JOBS layers in ONE launch (each layer then needs its own workspace

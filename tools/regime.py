@@ -80,10 +80,16 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
             by = 16 * n_in + 8 * P + 16 * rbc.out_indices.shape[0]
             tg = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER, in_rank=rank),
                              ("conv", lvl), int(rbc.out_indices.shape[0]))
+            # as the training step builds it (round 6): no indice_pairs for the 3 x 3 x 3 strided convs -- their weight gradient
+            # reads the pairs off the parity classes (pcd_sparse_conv_wgrad_classes); conv_out (128 x 128) keeps its lists
+            tgs = tg
+            if ops.IMPLICIT_STRIDED_PAIRS and lvl < 4:
+                tgs = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER,
+                                                            in_rank=rank, pair_lists=False), ("conv", lvl), int(rbc.out_indices.shape[0]))
             rows.append(dict(kind="strided" + ("_cm" if isinstance(rbc.rank, ops.ColumnMap) else ""), level=lvl + 1, n_in=n_in, n_out=int(rbc.out_indices.shape[0]), pairs=P,
                              us=round(t * 1e6, 1), graph_us=round(tg * 1e6, 1), alg_MB=round(by / 1e6, 1),
-                             GBps=round(by / t / 1e9, 1), graph_GBps=round(by / tg / 1e9, 1)))
-            tot_bytes += by; tot_t += t; tot_g += tg; tot_step += tg; tot_tables += tg
+                             GBps=round(by / t / 1e9, 1), graph_GBps=round(by / tg / 1e9, 1), as_built_us=round(tgs * 1e6, 1)))
+            tot_bytes += by; tot_t += t; tot_g += tg; tot_step += tgs; tot_tables += tg
             idx, shape, rank = rbc.out_indices, rbc.out_shape, rbc.rank
         if lvl < 4:
             n = idx.shape[0]
