@@ -126,7 +126,14 @@ PROTOTYPES = {
     "pcd_sparse_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_v2": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "pcd_sparse_conv_wgrad_classes": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
-                                           _vp]),
+                                           _vp, _i]),
+    "pcd_sparse_conv_dgrad_classes_v2": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp,
+                                              _vp, _vp]),
+    "pcd_sparse_conv_gather_gemm_packed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "pcd_rulebook_conv_cm_build_compact": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _i,
+                                                _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pcd_rulebook_conv_expand_nbr_out": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "pcd_rulebook_conv_expand_nbr_in": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "pcd_sparse_conv_wgrad_reduce": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "pcd_sparse_conv_wgrad_reduce_batched": (_i, [_vp, _i, _vp]),
     "pcd_sparse_conv_wgrad_os_splits": (_i, [_i, _i, _i, _i]),

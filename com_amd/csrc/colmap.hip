@@ -19,6 +19,7 @@
 // volume, no scatter: every table entry is written exactly once by the thread that owns its row.
 #include "rulebook_common.h"
 #include "colmap_common.h"
+#include "cls_table.h"
 
 namespace {
 
@@ -453,7 +454,21 @@ struct CmTablesSide {
     int ncls;               // parity classes: permutation of the input rows
     const int *blk_off;
     int32_t *perm;
+    // compact tables (the training step's form; nbr_in / nbr_out may then be nullptr):
+    //  nbr_cls [8][vcap]: entry (j, v) = output row of the input row at permutation slot v through the j-th offset its class can
+    //                     use (ascending k; ClsTable::k[class][j]) -- 27 / 8 entries per row on average instead of 27;
+    //  nbr_out_pk [KH * KW][n_out]: per (ky, kx) the three kz neighbours of an output row, which are CONSECUTIVE rows of one input
+    //                     column: { first present row : 29 bits, presence mask of kz = 0, 1, 2 : 3 bits } (0: none)
+    int32_t *nbr_cls;
+    int vcap;
+    u32 *nbr_out_pk;
 };
+
+// row of kz = a (0..2) from a packed word, or -1
+__device__ __forceinline__ int pk_row(u32 w, int a) {
+    const u32 m = w >> 29;
+    return ((m >> a) & 1u) ? (int)(w & 0x1FFFFFFFu) + __popc(m & ((1u << a) - 1u)) : -1;
+}
 
 // pass 3: both neighbour tables.  Blocks [0, nb_out): one thread per OUTPUT row -> nbr_out[k][o] from the input map;
 // blocks [nb_out, nb_out + nb_in): one thread per INPUT row -> nbr_in[k][i] from the output map (+ pair counts, classes).
@@ -488,6 +503,9 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
             in[q] = col >= 0;
             r[q] = cr[in[q] ? col : 0];
         }
+        u32 pk[KH * KW];
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q) pk[q] = 0;
 #pragma unroll
         for (int a = 0; a < KD; ++a)
 #pragma unroll
@@ -498,8 +516,13 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
                     row = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, z);
                     if (row >= nn_in) row = -1;
                 }
-                nbr_out[(size_t)(a * KH * KW + q) * n_out + o] = row;
+                if (nbr_out) nbr_out[(size_t)(a * KH * KW + q) * n_out + o] = row;
+                if (row >= 0) pk[q] = (pk[q] >> 29) ? (pk[q] | (1u << (29 + a))) : ((u32)row | (1u << (29 + a)));
             }
+        if (S.nbr_out_pk) {
+#pragma unroll
+            for (int q = 0; q < KH * KW; ++q) S.nbr_out_pk[(size_t)q * n_out + o] = pk[q];
+        }
         return;
     }
     __shared__ int wcnt[4][CLS_MAX];
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
         for (int q = threadIdx.x; q < K; q += 256) blk_sum[q] = 0;
         __syncthreads();
     }
+    int vslot = -1;             // permutation slot of this row (parity classes)
     if (S.perm) {
         const int cls = live ? row_class(c, G.pd, G.ph, G.pw, G.sd, G.sh, G.sw) : -1;
         const int wv = threadIdx.x >> 6;
@@ -528,7 +552,8 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
             int before = 0;
             for (int ww = 0; ww < wv; ++ww) before += wcnt[ww][cls];
             const int nclsblk = (int)gridDim.x - nb_out;
-            S.perm[S.blk_off[(size_t)cls * nclsblk + blk] + before + rank] = i;
+            vslot = S.blk_off[(size_t)cls * nclsblk + blk] + before + rank;
+            S.perm[vslot] = i;
         }
     }
     // output columns reached through (ky, kx): oy = (y + ph - ky) / sh where that is a whole, in-range number
@@ -549,9 +574,20 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
         in[q] = col >= 0;
         r[q] = cr_out[in[q] ? col : 0];
     }
+    // class-compact entries: the offsets this row's class can use, numbered in ascending k = (a, q) order
+    bool pq[KH * KW];
+    int jq[KH * KW], nq = 0;
+#pragma unroll
+    for (int q = 0; q < KH * KW; ++q) {
+        pq[q] = ((c.z + G.ph - q / KW) % G.sh + G.sh) % G.sh == 0 && ((c.w + G.pw - q % KW) % G.sw + G.sw) % G.sw == 0;
+        jq[q] = nq;
+        nq += pq[q] ? 1 : 0;
+    }
+    int jz = 0;
 #pragma unroll
     for (int a = 0; a < KD; ++a) {
         const int oz = axis_out(c.y, G.pd, 1, G.sd, a, G.Do);
+        const bool pz = ((c.y + G.pd - a) % G.sd + G.sd) % G.sd == 0;
 #pragma unroll
         for (int q = 0; q < KH * KW; ++q) {
             const int k = a * KH * KW + q;
@@ -560,9 +596,11 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
                 row = cm_row((u64)r[q].x | ((u64)r[q].y << 32), (int)r[q].z, oz);
                 if (row >= nn_out) row = -1;
             }
-            if (live) nbr_in[(size_t)k * n + i] = row;
+            if (live && nbr_in) nbr_in[(size_t)k * n + i] = row;
+            if (S.nbr_cls && vslot >= 0 && pz && pq[q]) S.nbr_cls[(size_t)(jz * nq + jq[q]) * S.vcap + vslot] = row;
             if (S.wave_cnt) publish_wave_count(S.wave_cnt, blk_sum, k, wave, S.nwaves, row >= 0);
         }
+        jz += pz ? 1 : 0;
     }
     if (S.wave_cnt) {
         __syncthreads();
@@ -812,10 +850,15 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
                               int in_cap, int n_out_cap, int32_t *n_out_dev, int32_t *out_indices, void *out_colmap,
                               size_t out_colmap_bytes, int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num,
                               int pad_pairs, int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
-                              void *workspace, size_t workspace_bytes, void *stream, bool counted) {
+                              void *workspace, size_t workspace_bytes, void *stream, bool counted,
+                              int32_t *nbr_cls = nullptr, u32 *nbr_out_pk = nullptr) {
     PCD_ENTER();
     if (n <= 0 || batch <= 0 || n_out_cap <= 0) return PCD_ERR_INVALID_ARG;
-    if (!indices || !out_indices || !nbr_in || !nbr_out || !out_colmap) return PCD_ERR_INVALID_ARG;
+    if (!indices || !out_indices || !out_colmap) return PCD_ERR_INVALID_ARG;
+    if ((!nbr_in && !nbr_cls) || (!nbr_out && !nbr_out_pk)) return PCD_ERR_INVALID_ARG;
+    if (nbr_cls && !perm) return PCD_ERR_INVALID_ARG;                 // (the compact input-side table is indexed by permutation slot)
+    if (pairs && !nbr_in) return PCD_ERR_INVALID_ARG;                 // (the pair lists are cut from the full table)
+    if (n_out_cap >= (1 << 29) || n >= (1 << 29)) return PCD_ERR_UNSUPPORTED;
     if ((pairs != nullptr) != (pair_num != nullptr)) return PCD_ERR_INVALID_ARG;
     CmConvCall X;
     int rc = cm_conv_setup(n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes, in_cap,
@@ -872,6 +915,15 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
         T.blk_off = L.blk_cnt;
         T.perm = perm;
     }
+    T.nbr_cls = nbr_cls;
+    T.vcap = vcap;
+    T.nbr_out_pk = nbr_out_pk;
+    if ((nbr_cls || nbr_out_pk) && X.G.kd != 3) return PCD_ERR_UNSUPPORTED;
+    if (nbr_cls) {                         // 8 table rows: every class must get by with at most 8 usable offsets
+        const int one[3] = {1, 1, 1};
+        ClsTable CT;
+        if (int rc2 = make_cls_table(ksize_host, stride_host, one, CT)) return rc2;
+    }
     cm_tables(X, indices, n, n_dev, out_indices, n_out_cap, n_out_dev, nbr_in, nbr_out, T, st);
     if (pairs) {
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)X.G.K * 2 * n * sizeof(int32_t), st);
@@ -904,4 +956,84 @@ extern "C" int pcd_rulebook_conv_cm_build(const int32_t *indices, int n, int bat
                               in_cap, n_out_cap, n_out_dev, out_indices, out_colmap, out_colmap_bytes, nbr_in, nbr_out, pairs,
                               pair_num, pad_pairs, cls_tile, perm, vcap, vstart_dev, n_dev, workspace, workspace_bytes, stream,
                               false);
+}
+
+// The same build with COMPACT neighbour tables (the training step's form): no 27-wide nbr_in / nbr_out, no pair lists.
+//   nbr_out_packed [kh * kw][n_out_cap] u32: per (ky, kx) { first present input row : 29, presence of kz = 0, 1, 2 : 3 } -- the three
+//       kz neighbours of an output row are consecutive rows of one input column (rows are z-fastest);
+//   nbr_cls [8][vcap] i32: entry (j, v) = output row reached from input row perm[v] through the j-th kernel offset its stride-parity
+//       class can use (ascending k), or -1 -- 27 / 8 entries per row on average.
+// Read by pcd_sparse_conv_gather_gemm_packed, pcd_sparse_conv_dgrad_classes_v2 and pcd_sparse_conv_wgrad_classes (nbr_compact = 1);
+// pcd_rulebook_conv_expand_nbr_out / _nbr_in give the 27-wide tables back.  Kernel depth 3, at most 8 classes.
+extern "C" int pcd_rulebook_conv_cm_build_compact(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                                                  const int *ksize_host, const int *stride_host, const int *pad_host,
+                                                  const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out_cap,
+                                                  int32_t *n_out_dev, int32_t *out_indices, void *out_colmap,
+                                                  size_t out_colmap_bytes, uint32_t *nbr_out_packed, int32_t *nbr_cls, int cls_tile,
+                                                  int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
+                                                  void *workspace, size_t workspace_bytes, void *stream) {
+    if (!n_out_dev || !nbr_out_packed || !nbr_cls || !perm) return PCD_ERR_INVALID_ARG;
+    return cm_conv_build_impl(indices, n, batch, in_shape_host, ksize_host, stride_host, pad_host, in_colmap, in_colmap_bytes,
+                              in_cap, n_out_cap, n_out_dev, out_indices, out_colmap, out_colmap_bytes, nullptr, nullptr, nullptr,
+                              nullptr, 0, cls_tile, perm, vcap, vstart_dev, n_dev, workspace, workspace_bytes, stream, false,
+                              nbr_cls, nbr_out_packed);
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void pk_expand_out_kernel(const u32 *__restrict__ pk, int kq, int n_out,
+                                                            const int32_t *n_out_dev, int32_t *__restrict__ nbr_out) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const bool live = o < eff_rows(n_out_dev, n_out);
+    for (int q = 0; q < kq; ++q) {
+        const u32 w = live ? pk[(size_t)q * n_out + o] : 0u;
+        for (int a = 0; a < 3; ++a) nbr_out[(size_t)(a * kq + q) * n_out + o] = pk_row(w, a);
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_expand_in_kernel(const int32_t *__restrict__ nbr_cls, int vcap,
+                                                            const int32_t *__restrict__ perm, const int32_t *__restrict__ vstart,
+                                                            ClsTable T, int n, int32_t *__restrict__ nbr_in) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vstart[T.ncls] || v >= vcap) return;
+    const int i = perm[v];
+    if (i < 0 || i >= n) return;
+    int cls = 0;
+    for (int q = 1; q < T.ncls; ++q)
+        if (vstart[q] <= v) cls = q;
+    for (int c = 0; c < 8; ++c)            // (compile-time indices into the by-value table)
+        if (c == cls)
+            for (int j = 0; j < 8; ++j)
+                if (j < T.nk[c]) nbr_in[(size_t)T.k[c][j] * n + i] = nbr_cls[(size_t)j * vcap + v];
+}
+
+}  // namespace
+
+extern "C" int pcd_rulebook_conv_expand_nbr_out(const uint32_t *nbr_out_packed, int kq, int n_out, const int32_t *n_out_dev,
+                                                int32_t *nbr_out, void *stream) {
+    PCD_ENTER();
+    if (kq <= 0 || n_out < 0 || (n_out > 0 && (!nbr_out_packed || !nbr_out))) return PCD_ERR_INVALID_ARG;
+    if (n_out == 0) return PCD_OK;
+    pk_expand_out_kernel<<<pcd_div_up(n_out, 256), 256, 0, (hipStream_t)stream>>>(nbr_out_packed, kq, n_out, n_out_dev, nbr_out);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
+}
+
+extern "C" int pcd_rulebook_conv_expand_nbr_in(const int32_t *nbr_cls, int vcap, const int32_t *perm, const int32_t *vstart_dev,
+                                               const int *ksize_host, const int *stride_host, int n, int32_t *nbr_in,
+                                               void *stream) {
+    PCD_ENTER();
+    if (!ksize_host || !stride_host || n < 0 || vcap < 0) return PCD_ERR_INVALID_ARG;
+    if (n == 0) return PCD_OK;
+    if (!nbr_cls || !perm || !vstart_dev || !nbr_in) return PCD_ERR_INVALID_ARG;
+    const int one[3] = {1, 1, 1};
+    ClsTable T;
+    if (int rc = make_cls_table(ksize_host, stride_host, one, T)) return rc;
+    const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
+    hipStream_t st = (hipStream_t)stream;
+    pcd_fill(nbr_in, 0xFF, (size_t)K * n * sizeof(int32_t), st);
+    cls_expand_in_kernel<<<pcd_div_up(vcap > 0 ? vcap : 1, 256), 256, 0, st>>>(nbr_cls, vcap, perm, vstart_dev, T, n, nbr_in);
+    PCD_RETURN_IF_LAUNCH_FAILED();
+    return PCD_OK;
 }

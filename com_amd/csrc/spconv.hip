@@ -23,6 +23,7 @@
 #include "common.h"
 #include "bn_mid.h"
 #include "bnred.h"
+#include "cls_table.h"
 
 // Wave priority of the kernels on the step's critical chain (forward convs, data gradients, BatchNorm passes): the
 // weight-gradient and rulebook kernels that run beside them on other streams keep priority 0, so on a shared SIMD the
@@ -360,7 +361,41 @@ __global__ __launch_bounds__(256 * WN, gg_waves(NB / WN, MI, G)) void gather_gem
     // rulebook tile -> LDS.  With a row stride that is a multiple of 4 (always in static-shape mode, where the
     // capacities are rounded) a lane fetches 4 consecutive rows of one offset with ONE 16-byte load: 4x fewer
     // load instructions in a prologue that is pure latency (27 dword loads per thread otherwise).
-    if ((nbr_stride & 3) == 0) {
+    const bool packed = (flip & 2) != 0;
+    flip &= 1;
+    if (packed) {
+        // strided rulebook in its packed form (pcd_rulebook_conv_cm_build_compact): [K / 3][nbr_stride] words, per (ky, kx)
+        // { first present row : 29, presence of kz = 0, 1, 2 : 3 } -- expanded into the same [K + 1][ROWS] tile
+        const int KQ = K / 3;
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)nbr, 0, (int)((unsigned)KQ * (unsigned)nbr_stride * 4u), 0x00020000);
+        const int total = KQ * ROWS;
+        for (int base = threadIdx.x; base < total; base += 4 * THREADS) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                const int q = idx / ROWS, r = idx - q * ROWS;
+                const int row = r0wg + r;
+                const unsigned off = (idx < total && row < n_out) ? ((unsigned)q * (unsigned)nbr_stride + (unsigned)row) * 4u
+                                                                  : 0xFFFFFFF0u;
+                v[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(prsrc, off, 0, 0);      // beyond the table: 0 = no neighbour
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * THREADS;
+                if (idx < total) {
+                    const int q = idx / ROWS, r = idx - q * ROWS;
+                    const unsigned m = v[u] >> 29;
+                    const int first = (int)(v[u] & 0x1FFFFFFFu);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        nbr_s[(a * KQ + q) * ROWS + r] = ((m >> a) & 1u) ? first + __builtin_popcount(m & ((1u << a) - 1u)) : -1;
+                }
+            }
+        }
+        for (int r = threadIdx.x; r < ROWS; r += THREADS) nbr_s[K * ROWS + r] = -1;   // row K: padded steps
+    } else if ((nbr_stride & 3) == 0) {
         constexpr int QR = ROWS / 4;                       // 16-byte pieces per offset
         const int total = K * QR;
         for (int base = threadIdx.x; base < total; base += 4 * THREADS) {
@@ -886,18 +921,13 @@ static int launch_ggw(const void *x, const void *wp, const float *bias, const in
 // k = 3, s = 2), and only those are executed -- the generic kernel runs all K offsets for every tile although
 // two thirds of its (tile, offset) steps are empty.  Same arithmetic in the same order (skipped steps add exact
 // zeros), so the result is bit-identical to the generic kernel's.
-struct ClsTable {
-    int ncls;
-    int nk[8];
-    int k[8][8];   // usable kernel offsets of class c, ascending
-};
 
 template <int NB, int MI, bool OUT_BF16>
 __global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kernel(
     const unsigned short *__restrict__ x, int c_in, int cshift, const uint4 *__restrict__ wp,
     const int32_t *__restrict__ nbr, int nbr_stride, int K, const int32_t *__restrict__ perm,
     const int32_t *__restrict__ vstart, ClsTable T, void *__restrict__ yv, int nsteps_total, unsigned x_bytes,
-    const void *__restrict__ addend, BnRed bn) {
+    const void *__restrict__ addend, BnRed bn, int compact) {
     __builtin_amdgcn_s_setprio(PCD_MAIN_PRIO);   // main-chain kernel: issue ahead of the weight-gradient waves sharing the SIMD
     constexpr int ROWS = 4 * MI * 16;
     constexpr int VEC = NB * 64;                           // uint4 per weight stage (one contraction step)
@@ -944,7 +974,8 @@ __global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kern
     for (int e = threadIdx.x; e < (nk + 1) * ROWS; e += 256) {
         const int j = e / ROWS, r = e - j * ROWS;
         const int i = row_s[r];
-        nbr_s[e] = (j < nk && i >= 0) ? nbr[(size_t)kk_s[j] * nbr_stride + i] : -1;
+        // (compact: the class-compact table nbr_cls [8][nbr_stride], indexed by permutation slot -- coalesced, no gather)
+        nbr_s[e] = (j < nk && i >= 0) ? (compact ? nbr[(size_t)j * nbr_stride + v0 + r] : nbr[(size_t)kk_s[j] * nbr_stride + i]) : -1;
     }
     u32x4 wreg[WPT];
     auto load_w = [&](int s) {
@@ -1022,7 +1053,7 @@ template <int NB, int MI>
 static int launch_gg_cls(const void *x, int c_in, int cshift, const void *wp, const int32_t *nbr, int nbr_stride,
                          int K, const int32_t *perm, const int32_t *vstart, const ClsTable &T, int vcap, void *y,
                          int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend,
-                         const PcdBnReduce *bnr, int *tiles_only) {
+                         const PcdBnReduce *bnr, int *tiles_only, int compact) {
     constexpr int ROWS = 4 * MI * 16;
     int grid = pcd_div_up(pcd_div_up(vcap, ROWS), 8) * 8;
     if (tiles_only) {
@@ -1036,11 +1067,11 @@ static int launch_gg_cls(const void *x, int c_in, int cshift, const void *wp, co
     if (y_dtype == PCD_BF16)
         gather_gemm_cls_kernel<NB, MI, true><<<grid, 256, lds, st>>>(
             (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
-            nsteps, x_bytes, addend, bn);
+            nsteps, x_bytes, addend, bn, compact);
     else
         gather_gemm_cls_kernel<NB, MI, false><<<grid, 256, lds, st>>>(
             (const unsigned short *)x, c_in, cshift, (const uint4 *)wp, nbr, nbr_stride, K, perm, vstart, T, y,
-            nsteps, x_bytes, addend, bn);
+            nsteps, x_bytes, addend, bn, compact);
     PCD_RETURN_IF_LAUNCH_FAILED();
     return PCD_OK;
 }
@@ -1061,7 +1092,9 @@ struct WgClasses {
     const int32_t *nbr_in;          // nullptr: explicit pair lists
     const int32_t *vstart;          // [ncls + 1] first permutation slot of every class
     int stride;                     // row stride of nbr_in
+    int compact;                    // nbr_in is the class-compact table nbr_cls [8][stride]: entry (j_of_k[k], permutation slot)
     unsigned char cls_of_k[28];
+    unsigned char j_of_k[28];
 };
 
 template <int MB, int NBW>
@@ -1098,7 +1131,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
     const int cic = chunk / n_cout_chunks;
     const int coc = chunk % n_cout_chunks;
     const int ci0 = cic * CI, co0 = coc * CO;
-    const bool implicit = I.nbr_in != nullptr;
+    bool implicit = I.nbr_in != nullptr;
     int P;
     const int32_t *pin, *pout;
     if (implicit) {
@@ -1107,6 +1140,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(
         P = I.vstart[c + 1] - v0;
         pin = pairs + v0;                                   // (the class permutation)
         pout = I.nbr_in + (size_t)k * I.stride;             // indexed by the INPUT ROW
+        if (I.compact) {                                    // indexed by the permutation slot, like a pair list
+            pout = I.nbr_in + (size_t)I.j_of_k[k] * I.stride + v0;
+            implicit = false;
+        }
     } else {
         P = pair_num[k];
         pin = pairs + ((size_t)k * 2 + 0) * pmax;
@@ -1837,8 +1874,10 @@ extern "C" int pcd_pack_weights_batched(const void *table, int n, int total_bloc
 static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
                        const int32_t *nbr, int nbr_stride, int kvol, int flip_k, int n_rows_out,
                        const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype, const void *addend,
-                       const PcdBnReduce *bnr, int *tiles_only, void *stream, int dir_hint = -1, int zfast = 0) {
+                       const PcdBnReduce *bnr, int *tiles_only, void *stream, int dir_hint = -1, int zfast = 0,
+                       int nbr_packed = 0) {
     if (n_rows_out < 0 || kvol <= 0 || c_in <= 0 || c_out <= 0) return PCD_ERR_INVALID_ARG;
+    if (nbr_packed && (flip_k || kvol % 3 != 0)) return PCD_ERR_INVALID_ARG;
     if (y_dtype != PCD_BF16 && y_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
     if (n_rows_out == 0) {
         if (tiles_only) *tiles_only = 0;
@@ -1879,6 +1918,7 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
     // PCD_GGW: 0 = off, 1 = on (default), 2..4 = on with MI rows-per-wave forced (also for C_in = 64), 6 = forward only
     if (ggw_mode && (c_in == 128 || (c_in == 64 && ggw_mode >= 2 && ggw_mode <= 4)) && (c_out == 64 || c_out == 128) &&
         x_bytes <= 0xFFFF0000u && !(is_dgrad && ggw_mode == 6)) {
+        if (nbr_packed) return PCD_ERR_UNSUPPORTED;        // (the LDS-DMA kernel stages full tables only)
         const unsigned w_bytes = (unsigned)wbytes;
         int mi = (ggw_mode >= 2 && ggw_mode <= 4) ? ggw_mode : ((c_in == 128 && n_rows_out <= 256 * 192 * 5 / 4) ? 3 : 2)   /* (capacities are 1.25 x the row counts) */;
         // SubM 3x3x3 over z-fastest rows at 128 -> 128 channels: x through windows (ggwin_kernel; same tiles, same BatchNorm rows)
@@ -1904,7 +1944,8 @@ static int gg_dispatch(const void *x, int n_rows_in, int c_in, const void *packe
 #undef GGW_MI
 #undef GGW_ARGS
     }
-#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_k, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
+    const int flip_arg = (flip_k ? 1 : 0) | (nbr_packed ? 2 : 0);     // (the kernel's `flip` argument: bit 0 = flipped k, bit 1 = packed table)
+#define GG_ARGS x, c_in, cshift, packed_w, bias, nbr, nbr_stride, kvol, flip_arg, n_rows_out, n_rows_out_dev, y, y_dtype, nsteps, x_bytes, st, addend, bnr, tiles_only
     switch (c_out / 16) {
         case 1: {
             // 16 channels (level 1).  With key-ordered voxel rows (pcd_voxelize_hard_sorted) 32 rows per wave and one
@@ -1948,6 +1989,17 @@ extern "C" int pcd_sparse_conv_gather_gemm(const void *x, int n_rows_in, int c_i
                        c_out, y, y_dtype, addend, bn_reduce, nullptr, stream);
 }
 
+// The forward of a strided conv over the PACKED output-side table of pcd_rulebook_conv_cm_build_compact
+// (nbr_out_packed [kvol / 3][nbr_stride]); everything else as pcd_sparse_conv_gather_gemm, same result bit for bit.
+extern "C" int pcd_sparse_conv_gather_gemm_packed(const void *x, int n_rows_in, int c_in, const void *packed_w,
+                                                  const float *bias, const uint32_t *nbr_out_packed, int nbr_stride, int kvol,
+                                                  int n_rows_out, const int32_t *n_rows_out_dev, int c_out, void *y,
+                                                  int y_dtype, const void *addend, const PcdBnReduce *bn_reduce, void *stream) {
+    PCD_ENTER();
+    return gg_dispatch(x, n_rows_in, c_in, packed_w, bias, (const int32_t *)nbr_out_packed, nbr_stride, kvol, 0, n_rows_out,
+                       n_rows_out_dev, c_out, y, y_dtype, addend, bn_reduce, nullptr, stream, 0, 0, 1);
+}
+
 #ifdef PCD_EXPERIMENTS
 #include "experiments/spconv_entries.inc"     // pcd_sparse_conv_gather_gemm_zfast, pcd_sparse_conv_pairs*
 #endif
@@ -1988,37 +2040,33 @@ extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int 
                                              const int32_t *perm, const int32_t *vstart_dev, int vcap,
                                              int n_rows_in, int c_in, void *dx, int dx_dtype, const void *addend,
                                              const PcdBnReduce *bn_reduce, void *stream) {
+    return pcd_sparse_conv_dgrad_classes_v2(dy, n_dy_rows, c_dy, packed_w, nbr_in, nbr_stride, 0, ksize_host, stride_host, pad_host,
+                                            dil_host, perm, vstart_dev, vcap, n_rows_in, c_in, dx, dx_dtype, addend, bn_reduce,
+                                            stream);
+}
+
+// nbr_compact = 1: `nbr_in` is the class-compact table nbr_cls [8][nbr_stride] of pcd_rulebook_conv_cm_build_compact
+// (nbr_stride = the permutation's capacity vcap): the table reads of a tile are coalesced instead of a gather through perm.
+extern "C" int pcd_sparse_conv_dgrad_classes_v2(const void *dy, int n_dy_rows, int c_dy, const void *packed_w,
+                                                const int32_t *nbr_in, int nbr_stride, int nbr_compact, const int *ksize_host,
+                                                const int *stride_host, const int *pad_host, const int *dil_host,
+                                                const int32_t *perm, const int32_t *vstart_dev, int vcap,
+                                                int n_rows_in, int c_in, void *dx, int dx_dtype, const void *addend,
+                                                const PcdBnReduce *bn_reduce, void *stream) {
     PCD_ENTER();
     if (!ksize_host || !stride_host || !pad_host || !dil_host) return PCD_ERR_INVALID_ARG;
+    if (nbr_compact && nbr_stride < vcap) return PCD_ERR_INVALID_ARG;
     if (n_rows_in < 0 || vcap < 0 || c_dy <= 0 || c_in <= 0) return PCD_ERR_INVALID_ARG;
     if (dx_dtype != PCD_BF16 && dx_dtype != PCD_F32) return PCD_ERR_INVALID_ARG;
     if (n_rows_in == 0 || vcap == 0) return PCD_OK;
-    if (!dy || !packed_w || !nbr_in || !perm || !vstart_dev || !dx || nbr_stride < n_rows_in)
+    if (!dy || !packed_w || !nbr_in || !perm || !vstart_dev || !dx || (!nbr_compact && nbr_stride < n_rows_in))
         return PCD_ERR_INVALID_ARG;
     const int cshift = log2_exact(c_dy);
     if (cshift < 5 || (c_in % 16) != 0) return PCD_ERR_UNSUPPORTED;   // a contraction step must stay inside one offset
     if (n_dy_rows < 0 || (double)n_dy_rows * c_dy * 2 >= 4294967040.0) return PCD_ERR_UNSUPPORTED;
     const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
-    ClsTable T = {};
-    T.ncls = stride_host[0] * stride_host[1] * stride_host[2];
-    if (T.ncls > 8 || T.ncls <= 0) return PCD_ERR_UNSUPPORTED;
-    for (int rz = 0; rz < stride_host[0]; ++rz)
-        for (int ry = 0; ry < stride_host[1]; ++ry)
-            for (int rx = 0; rx < stride_host[2]; ++rx) {
-                const int cls = (rz * stride_host[1] + ry) * stride_host[2] + rx;
-                int cnt = 0;
-                for (int kz = 0; kz < ksize_host[0]; ++kz)
-                    for (int ky = 0; ky < ksize_host[1]; ++ky)
-                        for (int kx = 0; kx < ksize_host[2]; ++kx) {
-                            auto ok = [](int r, int k, int d, int st_) { return (((r - k * d) % st_) + st_) % st_ == 0; };
-                            if (ok(rz, kz, dil_host[0], stride_host[0]) && ok(ry, ky, dil_host[1], stride_host[1]) &&
-                                ok(rx, kx, dil_host[2], stride_host[2])) {
-                                if (cnt >= 8) return PCD_ERR_UNSUPPORTED;
-                                T.k[cls][cnt++] = (kz * ksize_host[1] + ky) * ksize_host[2] + kx;
-                            }
-                        }
-                T.nk[cls] = cnt;
-            }
+    ClsTable T;
+    if (int rc = make_cls_table(ksize_host, stride_host, dil_host, T)) return rc;
     const unsigned x_bytes = (unsigned)((size_t)n_dy_rows * c_dy * 2);
     const int nsteps = (K * c_dy + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
@@ -2026,7 +2074,8 @@ extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int 
     // flight) hide its prologue better than the generic kernel's row-count rule
     const int mi = cls_mi(n_rows_in);
     int *tiles_only = nullptr;
-#define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend, bn_reduce, tiles_only
+    const int compact = nbr_compact ? 1 : 0;
+#define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend, bn_reduce, tiles_only, compact
 #define CLS_MI(NBV) (mi == 4 ? launch_gg_cls<NBV, 4>(CLS_ARGS) : mi == 2 ? launch_gg_cls<NBV, 2>(CLS_ARGS) : launch_gg_cls<NBV, 1>(CLS_ARGS))
     switch (c_in / 16) {
         case 1: return CLS_MI(1);
@@ -2081,7 +2130,7 @@ extern "C" int pcd_sparse_conv_wgrad_classes(const void *x, int n_x, const int32
                                              const void *dy, int n_dy, int cout, const int32_t *nbr_in, int nbr_stride,
                                              const int *ksize_host, const int *stride_host, const int *dil_host,
                                              const int32_t *perm, const int32_t *vstart_dev, float *dweight, void *workspace,
-                                             size_t workspace_bytes, void *stream) {
+                                             size_t workspace_bytes, void *stream, int nbr_compact) {
     PCD_ENTER();
     if (!ksize_host || !stride_host || !dil_host) return PCD_ERR_INVALID_ARG;
     const int kvol = ksize_host[0] * ksize_host[1] * ksize_host[2];
@@ -2093,6 +2142,13 @@ extern "C" int pcd_sparse_conv_wgrad_classes(const void *x, int n_x, const int32
     I.nbr_in = nbr_in;
     I.vstart = vstart_dev;
     I.stride = nbr_stride;
+    I.compact = nbr_compact ? 1 : 0;
+    if (nbr_compact) {                 // (the compact table exists only where a class has at most 8 usable offsets)
+        ClsTable T;
+        if (int rc = make_cls_table(ksize_host, stride_host, dil_host, T)) return rc;
+        for (int c = 0; c < T.ncls; ++c)
+            for (int j = 0; j < T.nk[c]; ++j) I.j_of_k[T.k[c][j]] = (unsigned char)j;
+    }
     for (int kz = 0; kz < ksize_host[0]; ++kz)
         for (int ky = 0; ky < ksize_host[1]; ++ky)
             for (int kx = 0; kx < ksize_host[2]; ++kx) {

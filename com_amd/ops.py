@@ -472,7 +472,11 @@ class Rulebook:
         # device-side row counts (static-shape mode): n_in / n_out are then capacities
         self.n_in_dev, self.n_out_dev = n_in_dev, n_out_dev
         self._nbr_out, self._finish_tables = nbr_out, None
-        self.nbr_in, self._pairs, self._pair_num = nbr_in, pairs, pair_num
+        self._nbr_in, self._pairs, self._pair_num = nbr_in, pairs, pair_num
+        # compact tables of a strided rulebook (rulebook_conv(compact=True): pcd_rulebook_conv_cm_build_compact): what the training
+        # step's kernels read; `nbr_out` / `nbr_in` are then expanded from them on first access (same values)
+        self.nbr_out_packed = None    # uint32 [kh * kw, n_out]: {first row : 29, kz presence : 3} per (ky, kx)
+        self.nbr_cls = None           # int32 [8, vcap]: entry (j-th usable offset of the class, permutation slot)
         self.out_indices = out_indices
         self.out_shape = list(out_shape) if out_shape is not None else None
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
@@ -501,6 +505,21 @@ class Rulebook:
     @property
     def nbr_buffer(self):
         return self._nbr_out
+
+    @property
+    def nbr_in(self):
+        if self._nbr_in is None and self.nbr_cls is not None and self.classes is not None:
+            dev = self.nbr_cls.device
+            self._nbr_in = torch.empty((self.kvol, self.n_in), dtype=torch.int32, device=dev)
+            perm, vstart, vcap = self.classes
+            L.check(L.lib().pcd_rulebook_conv_expand_nbr_in(L.ptr(self.nbr_cls), vcap, L.ptr(perm), L.ptr(vstart),
+                                                            L.host_i32(self.ksize), L.host_i32(self.stride), self.n_in,
+                                                            L.ptr(self._nbr_in), L.stream_ptr()), "pcd_rulebook_conv_expand_nbr_in")
+        return self._nbr_in
+
+    @nbr_in.setter
+    def nbr_in(self, value):
+        self._nbr_in = value
 
     @property
     def nbr_complete(self):
@@ -694,8 +713,11 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
 
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=True,
-                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX, in_rank=None, pair_lists=True):
-    """`pair_lists=False` (with want_pairs): the parity classes are built, spconv's indice_pairs are not -- the weight gradient
+                  pad_pairs=False, n_dev=None, plan_key=None, order=ROWS_ZYX, in_rank=None, pair_lists=True, compact=False):
+    """`compact=True` (with pair_lists=False, a static plan, a column-map build of kernel depth 3): the build writes the compact
+    tables only -- nbr_out_packed for the forward, nbr_cls for the data / weight gradients over the parity classes (50 bytes
+    per row instead of 216); `rb.nbr_out` / `rb.nbr_in` are expanded from them on first access.
+    `pair_lists=False` (with want_pairs): the parity classes are built, spconv's indice_pairs are not -- the weight gradient
     reads its pairs off the classes (ops.wgrad(rb=...) -> pcd_sparse_conv_wgrad_classes) and `rb.pairs` / `rb.pair_num` are derived
     from nbr_in on first access.
     `order`: how the OUTPUT rows are numbered (ROWS_ZYX: ascending (b, z, y, x), spconv's sorted order; ROWS_YXZ:
@@ -716,7 +738,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     if isinstance(in_rank, ColumnMap) and order == ROWS_YXZ and n > 0 and dl == [1, 1, 1] \
             and in_rank.serves(indices, shp, batch_size):
         rb = _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank,
-                               out_shape, pair_lists)
+                               out_shape, pair_lists, compact)
         if rb is not None:
             return rb
     wsb = lib.pcd_rulebook_conv_workspace_bytes(n, batch_size, *args)
@@ -808,10 +830,11 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 
 CLS_TILE = 256
 IMPLICIT_STRIDED_PAIRS = True     # spconv layers build strided rulebooks without indice_pairs (rulebook_conv(pair_lists=False))
+COMPACT_STRIDED_TABLES = True     # ... and, under a static plan, with compact neighbour tables only (rulebook_conv(compact=True))
 
 
 def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_pairs, n_dev, plan_key, in_rank, out_shape,
-                      pair_lists=True):
+                      pair_lists=True, compact=False):
     """rulebook_conv through the column maps (None: geometry outside what pcd_rulebook_conv_cm_* covers)."""
     PLAN = current_plan()
     lib = L.lib()
@@ -843,7 +866,34 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
         return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
 
     classes = None
-    if static:
+    packed = cls_tab = None
+    # (compact: 8 table rows -- every parity class must get by with at most 8 usable offsets)
+    if static and compact and want_pairs and not lists and ks[0] == 3 and ncls <= 8 \
+            and math.prod(-(-ks[d] // st[d]) for d in range(3)) <= 8:
+        n_out = PLAN.cap(plan_key)
+        PLAN.record(plan_key, n_out_dev, n_out)
+        cmb = lib.pcd_colmap_bytes(batch_size, L.host_i32(out_shape), max(n_out, 1))
+        out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+        cmap = torch.empty((cmb,), dtype=torch.uint8, device=dev)
+        nbr_in = nbr_out = pairs = pair_num = None
+        vcap = (n + CLS_TILE - 1) // CLS_TILE * CLS_TILE + ncls * CLS_TILE
+        perm = torch.empty((vcap,), dtype=torch.int32, device=dev)
+        vstart = torch.empty((ncls + 1,), dtype=torch.int32, device=dev)
+        classes = (perm, vstart, vcap)
+        packed = torch.empty((ks[1] * ks[2], n_out), dtype=torch.int32, device=dev)
+        cls_tab = torch.empty((8, vcap), dtype=torch.int32, device=dev)
+
+        def meta_c():
+            p_ = int((rb.nbr_in >= 0).sum().item())
+            return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
+
+        with _Timed("rulebook_conv_build", meta_c):
+            L.check(lib.pcd_rulebook_conv_cm_build_compact(L.ptr(indices), n, batch_size, *geo, *inmap, n_out, L.ptr(n_out_dev),
+                                                           L.ptr(out_indices), L.ptr(cmap), cmap.numel(), L.ptr(packed),
+                                                           L.ptr(cls_tab), CLS_TILE, L.ptr(perm), vcap, L.ptr(vstart), L.ptr(n_dev),
+                                                           L.ptr(ws), ws.numel(), L.stream_ptr()),
+                    "pcd_rulebook_conv_cm_build_compact")
+    elif static:
         n_out = PLAN.cap(plan_key)
         PLAN.record(plan_key, n_out_dev, n_out)
         out_indices, nbr_in, nbr_out, pairs, pair_num, cmap = outputs(n_out)
@@ -883,6 +933,15 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
     rb.rank = ColumnMap(cmap, max(n_out, 1), out_indices, out_shape, batch_size) if n_out > 0 else None
     rb.order = ROWS_YXZ
     rb.implicit_pairs = want_pairs and not lists
+    if packed is not None:
+        rb.nbr_out_packed, rb.nbr_cls = packed, cls_tab
+        kq = ks[1] * ks[2]
+
+        def finish():
+            rb._nbr_out = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+            L.check(lib.pcd_rulebook_conv_expand_nbr_out(L.ptr(packed), kq, n_out, L.ptr(n_out_dev), L.ptr(rb._nbr_out),
+                                                         L.stream_ptr()), "pcd_rulebook_conv_expand_nbr_out")
+        rb._finish_tables = finish
     if rb.rank is not None:
         # columns <= the map's column capacity?  (a geometry whose output z range does not cover every input z -- pad_z 0, k 3, s 2
         # on an even depth -- numbers output columns that have no rows: more columns than rows are then possible, and the capacity is
@@ -1040,12 +1099,13 @@ def dgrad_classes(dy, packed_w, rb, c_in, out_dtype, addend=None, bn_reduce=None
         tiles = L.lib().pcd_sparse_conv_dgrad_classes_tiles(vcap, rb.n_in)
         bnr = bn_reduce._struct(_tiles(tiles, "pcd_sparse_conv_dgrad_classes_tiles"), c_in, dy.device)
     with _Timed(f"gather_gemm_cls_kernel<NB={c_in // 16}> {dy.shape[1]}->{c_in} K={rb.kvol}", meta):
-        L.check(L.lib().pcd_sparse_conv_dgrad_classes(
-            L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(rb.nbr_in), rb.nbr_in.shape[1],
+        tab, compact = (rb.nbr_cls, 1) if rb.nbr_cls is not None else (rb.nbr_in, 0)
+        L.check(L.lib().pcd_sparse_conv_dgrad_classes_v2(
+            L.ptr(dy), dy.shape[0], dy.shape[1], L.ptr(packed_w), L.ptr(tab), tab.shape[1], compact,
             L.host_i32(rb.ksize), L.host_i32(rb.stride), L.host_i32(rb.padding), L.host_i32(rb.dilation), L.ptr(perm),
             L.ptr(vstart), vcap, rb.n_in, c_in, L.ptr(dx), _dtype_code(dx), L.ptr(addend), _byref(bnr),
             L.stream_ptr()),
-            "pcd_sparse_conv_dgrad_classes")
+            "pcd_sparse_conv_dgrad_classes_v2")
     return dx
 
 
@@ -1115,9 +1175,15 @@ class PackPlan:
         return self.packed
 
 
+def gather_gemm_is_wide(n_rows_in, c_in, kvol, n_rows_out, c_out, is_dgrad=False):
+    """The LDS-DMA kernel (ggw_kernel) would serve this conv: it stages full neighbour tables only (no packed form)."""
+    return L.lib().pcd_sparse_conv_gather_gemm_variant(n_rows_in, c_in, kvol, max(n_rows_out, 1), c_out, int(is_dgrad)) == 1
+
+
 def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dtype, n_dev=None, addend=None,
-                bn_reduce=None, zfast=False):
+                bn_reduce=None, zfast=False, nbr_packed=False):
     """y[o] = bias + sum_k x[nbr[k'][o]] @ W[k] (+ addend[o])  (output-stationary; forward and dgrad).
+    nbr_packed: `nbr` is a strided rulebook's packed output-side table (Rulebook.nbr_out_packed, [kvol / 3, n_out]).
     zfast: `nbr` is a SubM 3x3x3 table over rows numbered z-fastest (ROWS_YXZ) -- the 128-channel layers then stage x
     through row windows (ggwin_kernel) instead of gathering 27 slots per row; same result within one bf16 ulp."""
     _require_cuda(x, packed_w, nbr)
@@ -1127,7 +1193,11 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
         assert addend.shape == y.shape and addend.dtype == y.dtype and addend.is_contiguous() and addend.is_cuda
 
     def meta():
-        pairs = int((nbr >= 0).sum().item())
+        if nbr_packed:                     # (3 presence bits per word)
+            m = (nbr.view(torch.int32) >> 29) & 7
+            pairs = int(((m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1)).sum().item())
+        else:
+            pairs = int((nbr >= 0).sum().item())
         e = 2
         return dict(bytes=(x.shape[0] * x.shape[1] + n_rows_out * c_out) * e + 8 * pairs
                     + kvol * x.shape[1] * c_out * e, flops=2 * pairs * x.shape[1] * c_out,
@@ -1149,6 +1219,13 @@ def gather_gemm(x, packed_w, bias, nbr, kvol, flip_k, n_rows_out, c_out, out_dty
     # (the z-fastest entry point exists in EXPERIMENTS builds only: pcd_ops_experiments.h)
     entry = L.lib().pcd_sparse_conv_gather_gemm_zfast if (zfast and L.has_experiments()) else L.lib().pcd_sparse_conv_gather_gemm
     with _Timed(f"{kname}<NB={c_out // 16}> {x.shape[1]}->{c_out} K={kvol}", meta):
+        if nbr_packed:
+            assert not flip_k and not zfast and nbr.shape[0] * 3 == kvol
+            L.check(L.lib().pcd_sparse_conv_gather_gemm_packed(
+                L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr), nbr.shape[1], kvol, n_rows_out,
+                L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y), L.ptr(addend), _byref(bnr), L.stream_ptr()),
+                "pcd_sparse_conv_gather_gemm_packed")
+            return y
         L.check(entry(L.ptr(x), x.shape[0], x.shape[1], L.ptr(packed_w), L.ptr(bias), L.ptr(nbr), nbr.shape[1], kvol,
                       int(flip_k), n_rows_out, L.ptr(n_dev), c_out, L.ptr(y), _dtype_code(y), L.ptr(addend), _byref(bnr),
                       L.stream_ptr()), "pcd_sparse_conv_gather_gemm")
@@ -1361,7 +1438,10 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
     assert not conv2d_layout or defer is not None
     n_in_dev = None
     if rb is not None:
-        nbr_out, n_out_dev, n_in_dev = rb.nbr_out, rb.n_out_dev, rb.n_in_dev
+        # (a strided rulebook with compact tables: its 27-wide nbr_out would have to be expanded first, and the output-stationary
+        #  kernel below serves 16-output-channel layers only -- no strided conv of the hot path)
+        nbr_out = rb.nbr_out if rb.nbr_out_packed is None else None
+        n_out_dev, n_in_dev = rb.n_out_dev, rb.n_in_dev
     _require_cuda(x, dy)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     assert dy.is_contiguous()
@@ -1412,10 +1492,12 @@ def wgrad(x, cin, dy, pairs, pair_num, kvol, out=None, defer=None, nbr_out=None,
 
         b = lambda c: 4 if (c + 15) // 16 >= 4 else (2 if (c + 15) // 16 >= 2 else 1)
         with _Timed(f"wgrad_kernel<{b(cin)}, {b(cout)}> {x.shape[1]}x{cout} K={kvol} classes", meta_c):
+            tab, compact = (rb.nbr_cls, 1) if rb.nbr_cls is not None else (rb.nbr_in, 0)
             L.check(lib.pcd_sparse_conv_wgrad_classes(L.ptr(x), n_x, L.ptr(n_in_dev), x.shape[1], cin, L.ptr(dy), dy.shape[0],
-                                                      cout, L.ptr(rb.nbr_in), rb.nbr_in.shape[1], L.host_i32(rb.ksize),
+                                                      cout, L.ptr(tab), tab.shape[1], L.host_i32(rb.ksize),
                                                       L.host_i32(rb.stride), L.host_i32(rb.dilation), L.ptr(rb.classes[0]),
-                                                      L.ptr(rb.classes[1]), L.ptr(dw), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                                      L.ptr(rb.classes[1]), L.ptr(dw), L.ptr(ws), ws.numel(), L.stream_ptr(),
+                                                      compact),
                     "pcd_sparse_conv_wgrad_classes")
         if defer is not None:
             defer.append((ws, dw, kvol, cin, cout, n_x, 0, 1 if conv2d_layout else 0, cout_write))

@@ -204,6 +204,7 @@ class SparseConvolution(SparseModule):
                                    # no indice_pairs where the weight gradient reads its pairs off the parity classes
                                    # (every width but 128 x 128, whose kernel cuts the concatenated lists into equal chunks)
                                    pair_lists=not (ops.IMPLICIT_STRIDED_PAIRS and not (self.in_channels == 128 and self.out_channels == 128)),
+                                   compact=ops.COMPACT_STRIDED_TABLES and self._compact_tables_usable(x),
                                    plan_key=("conv", self.indice_key if self.indice_key is not None else id(self)),
                                    # the chain's row order (set by the backbone from the voxeliser's rank map)
                                    order=x.indice_dict.get("__row_order__", ops.ROWS_ZYX),
@@ -217,6 +218,12 @@ class SparseConvolution(SparseModule):
             # we also remember the INPUT side
             x.indice_dict[self.indice_key] = (rb, x.indices, list(x.spatial_shape))
         return rb, out_idx, out_shape
+
+    def _compact_tables_usable(self, x):
+        """A strided rulebook with compact neighbour tables only (ops.rulebook_conv(compact=True)): worth it where the forward
+        kernel reads the packed table (every width the LDS-DMA kernel does not serve); anything else expands the full tables on
+        first access -- slower, never wrong."""
+        return self.in_channels < 128 and not self.subm and tuple(self.kernel_size)[0] == 3
 
     def _needs_backward(self, x):
         """Pair lists / parity classes are what the weight and strided data gradients read: build them whenever autograd

@@ -157,8 +157,10 @@ class SparseConvFunction(Function):
             # strided conv of a z-fastest chain, 16 -> 32 channels: one gather per indice PAIR (ops.pair_conv)
             y = ops.pair_conv(x, packed_fwd, b, rb, 0, cout, out_dtype, bn_reduce=stats)
         else:
-            y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out, rb.kvol, False, rb.n_out, cout, out_dtype,
-                                n_dev=rb.n_out_dev, bn_reduce=stats,
+            packed = getattr(rb, "nbr_out_packed", None) is not None and out_dtype == torch.bfloat16 \
+                and not ops.gather_gemm_is_wide(x.shape[0], cin_pad, rb.kvol, rb.n_out, cout)
+            y = ops.gather_gemm(x, packed_fwd, b, rb.nbr_out_packed if packed else rb.nbr_out, rb.kvol, False, rb.n_out, cout,
+                                out_dtype, n_dev=rb.n_out_dev, bn_reduce=stats, nbr_packed=packed,
                                 zfast=rb.subm and rb.kvol == 27 and getattr(rb, "order", None) == ops.ROWS_YXZ)
         if stats is not None:
             y._pcd_stats = stats

@@ -364,6 +364,28 @@ int pcd_rulebook_conv_cm_build(const int32_t *indices, int n, int batch, const i
                                int32_t *nbr_in, int32_t *nbr_out, int32_t *pairs, int32_t *pair_num, int pad_pairs,
                                int cls_tile, int32_t *perm, int vcap, int32_t *vstart_dev, const int32_t *n_dev,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* The same one-call build with COMPACT neighbour tables and no pair lists -- what a training step needs of a strided rulebook
+ * (replaces the indice_pairs / indice_pair_num that spconv/pytorch/ops.py get_indice_pairs hands to SparseConv3d,
+ * spconv_backbone.py:205,212,219, for kernel depth 3 and at most 8 stride-parity classes):
+ *   nbr_out_packed [kh * kw][n_out_cap] u32: per (ky, kx) the three kz neighbours of an output row -- consecutive rows of one input
+ *       column, rows being z-fastest -- as { first present row : 29 bits, presence of kz = 0, 1, 2 : 3 bits } (0 = none);
+ *       read by pcd_sparse_conv_gather_gemm_packed;
+ *   nbr_cls [8][vcap] i32: entry (j, v) = output row reached from input row perm[v] through the j-th kernel offset its class can
+ *       use (ascending k), or -1: 27 / 8 entries per row on average; read by pcd_sparse_conv_dgrad_classes_v2 and
+ *       pcd_sparse_conv_wgrad_classes (nbr_compact = 1).
+ * 4 x 9 + 4 x 27 / 8 = 50 bytes per row instead of 2 x 108 (+ 8 per pair).  pcd_rulebook_conv_expand_nbr_out / _nbr_in rebuild
+ * the 27-wide tables (nbr_out [3 kq][n_out], nbr_in [kvol][n]) for whoever wants them: same values as pcd_rulebook_conv_cm_build's. */
+int pcd_rulebook_conv_cm_build_compact(const int32_t *indices, int n, int batch, const int *in_shape_host,
+                                       const int *ksize_host, const int *stride_host, const int *pad_host,
+                                       const void *in_colmap, size_t in_colmap_bytes, int in_cap, int n_out_cap,
+                                       int32_t *n_out_dev, int32_t *out_indices, void *out_colmap, size_t out_colmap_bytes,
+                                       uint32_t *nbr_out_packed, int32_t *nbr_cls, int cls_tile, int32_t *perm, int vcap,
+                                       int32_t *vstart_dev, const int32_t *n_dev, void *workspace, size_t workspace_bytes,
+                                       void *stream);
+int pcd_rulebook_conv_expand_nbr_out(const uint32_t *nbr_out_packed, int kq, int n_out, const int32_t *n_out_dev,
+                                     int32_t *nbr_out, void *stream);
+int pcd_rulebook_conv_expand_nbr_in(const int32_t *nbr_cls, int vcap, const int32_t *perm, const int32_t *vstart_dev,
+                                    const int *ksize_host, const int *stride_host, int n, int32_t *nbr_in, void *stream);
 
 /* Optional per-channel reductions of the OUTPUT tile in the epilogue of pcd_sparse_conv_gather_gemm /
  * pcd_sparse_conv_dgrad_classes (bf16 outputs only; NULL or mode 0 = off).  The BatchNorm1d that follows every conv of
@@ -416,6 +438,19 @@ int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const
                                   const int32_t *perm, const int32_t *vstart_dev, int vcap, int n_rows_in, int c_in,
                                   void *dx, int dx_dtype, const void *addend, const PcdBnReduce *bn_reduce,
                                   void *stream);
+/* v2: nbr_compact = 1 reads the class-compact table nbr_cls [8][nbr_stride] (pcd_rulebook_conv_cm_build_compact; nbr_stride = the
+ * permutation's capacity) instead of nbr_in [kvol][nbr_stride]: coalesced table reads instead of a gather through perm. */
+int pcd_sparse_conv_dgrad_classes_v2(const void *dy, int n_dy_rows, int c_dy, const void *packed_w, const int32_t *nbr_in,
+                                     int nbr_stride, int nbr_compact, const int *ksize_host, const int *stride_host,
+                                     const int *pad_host, const int *dil_host, const int32_t *perm, const int32_t *vstart_dev,
+                                     int vcap, int n_rows_in, int c_in, void *dx, int dx_dtype, const void *addend,
+                                     const PcdBnReduce *bn_reduce, void *stream);
+/* The forward of a strided conv over the PACKED output-side table nbr_out_packed [kvol / 3][nbr_stride] of
+ * pcd_rulebook_conv_cm_build_compact; otherwise pcd_sparse_conv_gather_gemm (bit-identical result). */
+int pcd_sparse_conv_gather_gemm_packed(const void *x, int n_rows_in, int c_in, const void *packed_w, const float *bias,
+                                       const uint32_t *nbr_out_packed, int nbr_stride, int kvol, int n_rows_out,
+                                       const int32_t *n_rows_out_dev, int c_out, void *y, int y_dtype, const void *addend,
+                                       const PcdBnReduce *bn_reduce, void *stream);
 int pcd_sparse_conv_dgrad_classes_tiles(int vcap, int n_rows_in);
 
 /* ============================================================================================
@@ -489,7 +524,9 @@ int pcd_sparse_conv_wgrad_classes(const void *x, int n_x, const int32_t *n_x_dev
                                   int n_dy, int cout, const int32_t *nbr_in, int nbr_stride, const int *ksize_host,
                                   const int *stride_host, const int *dil_host, const int32_t *perm,
                                   const int32_t *vstart_dev, float *dweight, void *workspace, size_t workspace_bytes,
-                                  void *stream);
+                                  void *stream, int nbr_compact);
+/* nbr_compact = 1: `nbr_in` is the class-compact table nbr_cls [8][nbr_stride] of pcd_rulebook_conv_cm_build_compact (entry
+ * (j, v): the j-th usable offset of the class, permutation slot v) -- the pairs of an offset are then two plain arrays. */
 int pcd_sparse_conv_wgrad_reduce(int kvol, int cin, int cout, int pmax, float *dweight,
                                  const void *workspace, void *stream);
 /* The same reduction for up to PCD_WGRAD_MAX_JOBS layers in ONE launch (each layer then needs its own workspace

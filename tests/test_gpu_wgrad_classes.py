@@ -170,3 +170,146 @@ def test_a_layer_builds_no_pair_lists_and_trains_to_the_same_values(monkeypatch)
     assert rb0._pairs is not None and rb1._pairs is None and rb1.implicit_pairs
     assert torch.equal(dx0, dx1)
     torch.testing.assert_close(dw0, dw1, rtol=1e-5, atol=1e-5 * float(dw0.abs().max()))
+
+
+def _compact_pair(ops, idx_t, batch, shape, geo, cmap, n_dev, key, cap_out):
+    """(full tables + pair lists, compact tables only) of the same strided conv under one static plan"""
+    plan = ops.StaticPlan()
+    plan.observe(key, cap_out)
+    plan.active = True
+    with plan:
+        full = ops.rulebook_conv(idx_t, batch, list(shape), geo["k"], geo["s"], geo["p"], order=ops.ROWS_YXZ, in_rank=cmap,
+                                 n_dev=n_dev, plan_key=key)
+        comp = ops.rulebook_conv(idx_t, batch, list(shape), geo["k"], geo["s"], geo["p"], order=ops.ROWS_YXZ, in_rank=cmap,
+                                 n_dev=n_dev, plan_key=key, pair_lists=False, compact=True)
+        plan.check()
+    return full, comp
+
+
+def test_compact_strided_tables_feed_all_three_kernels_and_expand_to_the_full_tables():
+    """pcd_rulebook_conv_cm_build_compact: packed output-side table -> forward, class-compact input-side table -> data and
+    weight gradient, each against the same kernel over the 27-wide tables (bit for bit: the same neighbours in the same
+    slots); the expanded tables equal the full build's (which tests/test_gpu_colmap.py pins to the oracle)."""
+    from com_amd import ops
+    rng = np.random.default_rng(404)
+    ran = 0
+    for case in range(32):
+        D, H, W = int(rng.integers(3, 44)), int(rng.integers(5, 90)), int(rng.choice([31, 32, 33, 47, 64, 65, 96, 100]))
+        batch = int(rng.integers(1, 4))
+        dens = float(rng.choice([0.01, 0.05, 0.2, 0.6]))
+        n = max(1, int(batch * D * H * W * dens))
+        idx = np.unique(np.stack([rng.integers(0, batch, n), rng.integers(0, D, n), rng.integers(0, H, n), rng.integers(0, W, n)], 1)
+                        .astype(np.int32), axis=0)
+        idx = _sorted_yxz(idx)
+        n = idx.shape[0]
+        if case % 2:
+            k, s, p = (3, 3, 3), tuple(int(v) for v in rng.integers(1, 3, 3)), tuple(int(v) for v in rng.integers(0, 2, 3))
+        else:
+            k, s, p = (3, 3, 3), (2, 2, 2), ((1, 1, 1), (0, 1, 1))[case % 4 == 0]
+        out = O.conv_out_shape((D, H, W), k, s, p, (1, 1, 1))
+        if min(out) <= 0 or D + p[0] > 62:
+            continue
+        geo = dict(k=k, s=s, p=p)
+        cap = n + int(rng.integers(0, 300))                                  # capacity >= rows, the count on the device
+        big = torch.zeros((cap, 4), dtype=torch.int32, device=DEV)
+        big[:n] = torch.from_numpy(idx).to(DEV)
+        n_dev = torch.tensor([n], dtype=torch.int32, device=DEV)
+        cmap = ops.colmap_from_rows(big, batch, [D, H, W], n_dev=n_dev)
+        m = O.rulebook_conv(idx, (D, H, W), k, s, p)["n_out"]
+        if m == 0:
+            continue
+        full, comp = _compact_pair(ops, big, batch, (D, H, W), geo, cmap, n_dev, ("conv", case), m + int(rng.integers(0, 200)))
+        if int(np.prod([-(-3 // v) for v in s])) > 8:                       # a class with more than 8 usable offsets: full tables
+            assert comp.nbr_out_packed is None and comp.nbr_cls is None and comp._nbr_out is not None
+            continue
+        assert comp.nbr_out_packed is not None and comp.nbr_cls is not None and comp._nbr_out is None and comp._nbr_in is None
+        assert comp._pairs is None and int(comp.n_out_dev.item()) == m == int(full.n_out_dev.item())
+        cin, cout = [(16, 32), (32, 64), (64, 128), (32, 32)][case % 4]
+        g = torch.Generator(device="cpu").manual_seed(case)
+        x = torch.randn((cap, cin), generator=g).to(DEV).bfloat16()
+        dy = torch.randn((full.n_out, cout), generator=g).to(DEV).bfloat16()
+        x[n:] = float("nan")
+        dy[m:] = float("nan")
+        w = (torch.randn((cout, 27, cin), generator=g) * 0.05).to(DEV)
+        # forward
+        pf = ops.pack_weight(w, 0)
+        y_f = ops.gather_gemm(x, pf, None, full.nbr_out, 27, False, full.n_out, cout, torch.bfloat16, n_dev=full.n_out_dev)
+        y_c = ops.gather_gemm(x, pf, None, comp.nbr_out_packed, 27, False, comp.n_out, cout, torch.bfloat16, n_dev=comp.n_out_dev,
+                              nbr_packed=True)
+        assert comp._nbr_out is None
+        assert torch.equal(y_f[:m].view(torch.int16), y_c[:m].view(torch.int16)) and bool(torch.isfinite(y_c[:m].float()).all())
+        # data gradient over the classes
+        if cout >= 32:
+            pd_ = ops.pack_weight(w, 1)
+            dx_f = ops.dgrad_classes(dy, pd_, full, cin, torch.bfloat16)
+            dx_c = ops.dgrad_classes(dy, pd_, comp, cin, torch.bfloat16)
+            assert comp._nbr_in is None
+            assert torch.equal(dx_f[:n].view(torch.int16), dx_c[:n].view(torch.int16)) and bool(torch.isfinite(dx_c[:n].float()).all())
+        # weight gradient: the class form over nbr_in and over the compact table walk the same slots
+        impl = ops.rulebook_conv  # (a second non-compact, list-free build for the class form over nbr_in)
+        plan = ops.StaticPlan()
+        plan.observe(("conv", case), full.n_out)
+        plan.active = True
+        with plan:
+            mid = impl(big, batch, [D, H, W], k, s, p, order=ops.ROWS_YXZ, in_rank=cmap, n_dev=n_dev, plan_key=("conv", case),
+                       pair_lists=False)
+        dw_l = ops.wgrad(x, cin, dy, None, None, 27, rb=full)
+        dw_m = ops.wgrad(x, cin, dy, None, None, 27, rb=mid)
+        dw_c = ops.wgrad(x, cin, dy, None, None, 27, rb=comp)
+        assert comp._nbr_in is None and comp._pairs is None and bool(torch.isfinite(dw_c).all())
+        assert torch.equal(dw_m, dw_c)
+        scale = float(dw_l.abs().max()) + 1e-6
+        assert float((dw_l - dw_c).abs().max()) <= 2e-5 * scale
+        # the full tables, on demand
+        assert torch.equal(comp.nbr_out[:, :m], full.nbr_out[:, :m]) and bool((comp.nbr_out[:, m:] == -1).all())
+        assert torch.equal(comp.nbr_in[:, :n], full.nbr_in[:, :n])
+        assert torch.equal(comp.out_indices[:m], full.out_indices[:m])
+        np.testing.assert_array_equal(_cpu(comp.pair_num), _cpu(full.pair_num))
+        ran += 1
+    assert ran >= 14
+
+
+def test_layers_with_compact_tables_train_to_the_same_values(monkeypatch):
+    """Two strided layers in a row under a static plan (z-fastest chain with column maps), compact tables on / off."""
+    from com_amd import ops, spconv
+    from com_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(9)
+    shape, batch = [41, 96, 128], 2
+    n = 30000
+    idx = np.unique(np.stack([rng.integers(0, batch, n), rng.integers(0, shape[0], n), rng.integers(0, shape[1], n),
+                              rng.integers(0, shape[2], n)], 1).astype(np.int32), axis=0)
+    idx = _sorted_yxz(idx)
+    idx_t = torch.from_numpy(idx).to(DEV)
+    feats = torch.randn((idx.shape[0], 16), device=DEV).bfloat16()
+    torch.manual_seed(2)
+    c1 = spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="a").to(DEV)
+    c2 = spconv.SparseConv3d(32, 64, 3, stride=2, padding=(0, 1, 1), bias=False, indice_key="b").to(DEV)
+    cmap = ops.colmap_from_rows(idx_t, batch, shape)
+
+    def run(compact, plan):
+        monkeypatch.setattr(ops, "COMPACT_STRIDED_TABLES", compact)
+        for c in (c1, c2):
+            c.zero_grad()
+        x = spconv.SparseConvTensor(feats.clone().requires_grad_(True), idx_t, shape, batch)
+        x.indice_dict["__row_order__"] = ops.ROWS_YXZ
+        x.indice_dict[("__rank__", idx_t.data_ptr())] = cmap
+        with plan:
+            y = c2(c1(x))
+            n_out = int(y.indice_dict["b"][0].n_out_dev.item()) if plan.active else y.features.shape[0]
+            y.features[:n_out].float().square().sum().backward()
+            Fsp.join_deferred_wgrad()
+        return y, n_out, [c.weight.grad.clone() for c in (c1, c2)], x.features.grad.clone()
+
+    plan = ops.StaticPlan()
+    y0, m0, _, _ = run(False, plan)                                     # eager: observes the capacities
+    plan.active = True
+    ya, ma, dwa, dxa = run(False, plan)
+    yb, mb, dwb, dxb = run(True, plan)
+    plan.check()
+    ra, rb_ = ya.indice_dict["a"][0], yb.indice_dict["a"][0]
+    assert ra.nbr_out_packed is None and rb_.nbr_out_packed is not None and rb_._nbr_out is None and rb_._nbr_in is None
+    assert yb.indice_dict["b"][0].nbr_cls is not None
+    assert ma == mb == m0
+    assert torch.equal(ya.features[:ma], yb.features[:mb]) and torch.equal(dxa, dxb)
+    for a, b in zip(dwa, dwb):
+        assert torch.equal(a, b)

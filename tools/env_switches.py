@@ -18,6 +18,7 @@ through the environment -- this module, imported only by bench.py and tools/, ap
   PCD_COLMAP=0/1            ops.USE_COLUMN_MAPS                           column-map rulebook builds (0: flat key-space bitmaps)
   PCD_PAIR_CONV=0/1         ops.PAIR_CONV                                 pair-driven strided 16 <-> 32 convs (0: gather kernels)
   PCD_IMPLICIT_PAIRS=0/1    ops.IMPLICIT_STRIDED_PAIRS                    strided rulebooks without indice_pairs (weight gradient over the parity classes)
+  PCD_COMPACT_TABLES=0/1    ops.COMPACT_STRIDED_TABLES                    ... and with compact neighbour tables only (static plans)
 """
 import os
 
@@ -38,6 +39,7 @@ def apply(environ=None):
     ops.USE_COLUMN_MAPS = flag("PCD_COLMAP", ops.USE_COLUMN_MAPS)
     ops.PAIR_CONV = flag("PCD_PAIR_CONV", ops.PAIR_CONV)
     ops.IMPLICIT_STRIDED_PAIRS = flag("PCD_IMPLICIT_PAIRS", ops.IMPLICIT_STRIDED_PAIRS)
+    ops.COMPACT_STRIDED_TABLES = flag("PCD_COMPACT_TABLES", ops.COMPACT_STRIDED_TABLES)
     conv2d_fast.DENSE_BN_EPILOGUE = int(env.get("PCD_DENSE_BN_EPI", conv2d_fast.DENSE_BN_EPILOGUE))
     conv2d_fast.BATCH_BN_COUNTERS = flag("PCD_BN2D_BUMP", conv2d_fast.BATCH_BN_COUNTERS)
     backbone3d._RulebookPrefetcher.event_per_rulebook = flag("PCD_RB_EVENT_EACH", backbone3d._RulebookPrefetcher.event_per_rulebook)

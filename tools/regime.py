@@ -78,14 +78,17 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
             rbc, t = timed(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], order=ORDER, in_rank=rank))
             P = int(rbc.pair_num.sum())
             by = 16 * n_in + 8 * P + 16 * rbc.out_indices.shape[0]
-            tg = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER, in_rank=rank),
+            SKIP_PLAIN = os.environ.get('PCD_REGIME_SKIP_PLAIN') == '1'      # (profiling runs: only the as-built forms in the graphs)
+            tg = 1e-9 if SKIP_PLAIN else timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER, in_rank=rank),
                              ("conv", lvl), int(rbc.out_indices.shape[0]))
             # as the training step builds it (round 6): no indice_pairs for the 3 x 3 x 3 strided convs -- their weight gradient
-            # reads the pairs off the parity classes (pcd_sparse_conv_wgrad_classes); conv_out (128 x 128) keeps its lists
+            # reads the pairs off the parity classes (pcd_sparse_conv_wgrad_classes) -- and compact neighbour tables only
+            # (pcd_rulebook_conv_cm_build_compact); conv_out (128 x 128) keeps its lists and full tables
             tgs = tg
-            if ops.IMPLICIT_STRIDED_PAIRS and lvl < 4:
+            if (ops.IMPLICIT_STRIDED_PAIRS and lvl < 4) or SKIP_PLAIN:
                 tgs = timed_graph(lambda: ops.rulebook_conv(idx, B, shape, geo[0], geo[1], geo[2], plan_key=("conv", lvl), order=ORDER,
-                                                            in_rank=rank, pair_lists=False), ("conv", lvl), int(rbc.out_indices.shape[0]))
+                                                            in_rank=rank, pair_lists=False, compact=ops.COMPACT_STRIDED_TABLES),
+                                   ("conv", lvl), int(rbc.out_indices.shape[0]))
             rows.append(dict(kind="strided" + ("_cm" if isinstance(rbc.rank, ops.ColumnMap) else ""), level=lvl + 1, n_in=n_in, n_out=int(rbc.out_indices.shape[0]), pairs=P,
                              us=round(t * 1e6, 1), graph_us=round(tg * 1e6, 1), alg_MB=round(by / 1e6, 1),
                              GBps=round(by / t / 1e9, 1), graph_GBps=round(by / tg / 1e9, 1), as_built_us=round(tgs * 1e6, 1)))
@@ -96,7 +99,7 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 32]:
             rb, t = timed(lambda: ops.rulebook_subm(idx, B, shape, rank=rank))
             P = int(rb.pair_num.sum())
             by = 16 * n + 8 * P
-            tg = timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank), None, 0)
+            tg = 1e-9 if os.environ.get('PCD_REGIME_SKIP_PLAIN') == '1' else timed_graph(lambda: ops.rulebook_subm(idx, B, shape, rank=rank), None, 0)
             # as the training step builds it: the 16 / 32-channel levels run their weight gradient over the window tiles and
             # need no pair lists (hotpath/backbone3d.py, spconv/conv.py::_rulebook)
             # ... and their window PLAN comes out of the same pass, straight from the column map (round 6: pcd_subm_window_plan_cm);
