@@ -883,8 +883,9 @@ def _rulebook_conv_cm(indices, batch_size, shp, ks, st, pd, dl, want_pairs, pad_
         packed = torch.empty((ks[1] * ks[2], n_out), dtype=torch.int32, device=dev)
         cls_tab = torch.empty((8, vcap), dtype=torch.int32, device=dev)
 
-        def meta_c():
-            p_ = int((rb.nbr_in >= 0).sum().item())
+        def meta_c():                              # pairs = presence bits of the packed table (rows beyond the count hold 0)
+            m_ = (packed >> 29) & 7
+            p_ = int(((m_ & 1) + ((m_ >> 1) & 1) + ((m_ >> 2) & 1)).sum().item())
             return dict(bytes=16 * n + 8 * p_ + 16 * n_out, flops=0, rows=n_out, pairs=p_)
 
         with _Timed("rulebook_conv_build", meta_c):
