@@ -676,6 +676,53 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
             S.perm[vslot] = i;
         }
     }
+    if (KH == 3 && KW == 3 && !nbr_in && !S.wave_cnt && S.nbr_cls && G.sh == 2 && G.sw == 2) {
+        // compact table only, stride 2 in y and x: a row can use ky = 1 (y + ph odd) or ky in {0, 2} (even), the same in x -- at most
+        // 2 x 2 of the 3 x 3 output columns, and only those are looked up (the class-compact table has no slot for the others)
+        if (vslot < 0) return;
+        const int ey = (c.z + G.ph) & 1, ex = (c.w + G.pw) & 1;
+        const int nky = ey ? 1 : 2, nkx = ex ? 1 : 2;
+        uint2 w4[4];
+        u32 key4[4];
+        bool in4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int jy = s >> 1, jx = s & 1;
+            const int ky = ey ? 1 : 2 * jy, kx = ex ? 1 : 2 * jx;
+            const int oy = axis_out(c.z, G.ph, 1, 2, ky, G.Ho), ox = axis_out(c.w, G.pw, 1, 2, kx, G.Wo);
+            in4[s] = jy < nky && jx < nkx && oy >= 0 && ox >= 0;
+            key4[s] = in4[s] ? bev_key(c.x, oy, ox, G.Ho, G.Po) : 0u;
+            w4[s] = cw_out[key4[s] >> 5];
+        }
+        uint4 r4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = in4[s] ? cm_col(w4[s], key4[s], G.ncol_cap_out) : -1;
+            in4[s] = col >= 0;
+            r4[s] = cr_out[in4[s] ? col : 0];
+        }
+        const int nq4 = nky * nkx;
+        int jz4 = 0;
+#pragma unroll
+        for (int a = 0; a < KD; ++a) {
+            const int oz = axis_out(c.y, G.pd, 1, G.sd, a, G.Do);
+            const bool pz = ((c.y + G.pd - a) % G.sd + G.sd) % G.sd == 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int jy = s >> 1, jx = s & 1;
+                if (pz && jy < nky && jx < nkx) {
+                    int row = -1;
+                    if (in4[s] && oz >= 0) {
+                        row = cm_row((u64)r4[s].x | ((u64)r4[s].y << 32), (int)r4[s].z, oz);
+                        if (row >= nn_out) row = -1;
+                    }
+                    S.nbr_cls[(size_t)(jz4 * nq4 + jy * nkx + jx) * S.vcap + vslot] = row;
+                }
+            }
+            jz4 += pz ? 1 : 0;
+        }
+        return;
+    }
     // output columns reached through (ky, kx): oy = (y + ph - ky) / sh where that is a whole, in-range number
     uint2 w[KH * KW];
     u32 key[KH * KW];
