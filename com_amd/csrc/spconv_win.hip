@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void cm_win_plan_kernel(const int4 *__restrict
 template <class C>
 __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan_base, int n_cap, const int32_t *__restrict__ n_dev,
                                                          int ntiles_cap, int grid) {
-    __shared__ int scan[1024];
+    __shared__ int wtot[2][16];
     __shared__ int bnd[WIN_GRID_MAX + 1];
     __shared__ int bndw[WIN_WG_SHARES_MAX + 1];
     const int tid = threadIdx.x;
@@ -369,24 +369,31 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
     const int nt = (n + C::T - 1) / C::T;
     const int4 *hdr = (const int4 *)(plan_base + win_hdr_off(ntiles_cap));
     int *prefix = (int *)(plan_base + win_prefix_off());
-    const int per = (nt + 1023) / 1024;
-    const int t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
-    int sum = 0;
-    for (int t = t0; t < t1; ++t) sum += 4 + C::PASS_COST * (hdr[(size_t)t * 2 + 1].z - 1);
-    scan[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = tid >= d ? scan[tid - d] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    // inclusive cost prefix in chunks of 1024 consecutive tiles, one tile per thread (a wave reads 64 consecutive headers; the
+    // next chunk's header is requested before this chunk is scanned): wave scans + the 16 wave totals, ONE barrier per chunk.
+    // (Until round 6: a contiguous range of tiles per thread -- 32-byte-strided loads, two serial passes over the range and a
+    //  20-barrier block scan: 43 us at B = 32 for 18 k tiles; integer sums, so the prefix is the same.)
+    const int wv = tid >> 6;
+    int carry = 0;
+    int pz = tid < nt ? hdr[(size_t)tid * 2 + 1].z : 1;
+    for (int c0 = 0, it = 0; c0 < nt; c0 += 1024, ++it) {
+        const int t = c0 + tid;
+        const int cost = t < nt ? 4 + C::PASS_COST * (pz - 1) : 0;
+        if (t + 1024 < nt) pz = hdr[(size_t)(t + 1024) * 2 + 1].z;
+        const int inc = wave_inclusive_scan(cost);
+        if ((tid & 63) == 63) wtot[it & 1][wv] = inc;
+        __syncthreads();                                  // (double-buffered totals: the next chunk writes the other half)
+        int off = carry, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int s = wtot[it & 1][i];
+            off += i < wv ? s : 0;
+            tot += s;
+        }
+        if (t < nt) prefix[t] = off + inc;
+        carry += tot;
     }
-    int run = scan[tid] - sum;
-    for (int t = t0; t < t1; ++t) {
-        run += 4 + C::PASS_COST * (hdr[(size_t)t * 2 + 1].z - 1);
-        prefix[t] = run;
-    }
-    const long long total = scan[1023];
+    const long long total = carry;
     __threadfence_block();
     __syncthreads();
     const int NSH = grid / C::CQN;                    // shares of the forward / data-gradient kernel (CQN workgroups each)
