@@ -351,24 +351,34 @@ __global__ __launch_bounds__(256) void cm_conv_count_kernel(CmGeom G, int ncellb
 }
 
 // exclusive scan of the wave sums (only beyond "cm_direct_blocks" entries): one block, in place, totals -> bsums[nent]
-__global__ __launch_bounds__(256) void cm_spine2_kernel(int2 *bsums, int nent) {
-    __shared__ int lds[4];
-    __shared__ int2 carry_s;
-    if (threadIdx.x == 0) carry_s = make_int2(0, 0);
-    __syncthreads();
-    for (int base = 0; base < nent; base += 256) {
-        const int i = base + threadIdx.x;
-        const int2 v = i < nent ? bsums[i] : make_int2(0, 0);
-        int tc, tr;
-        const int ec = block_exclusive_scan(v.x, lds, tc);
-        const int er = block_exclusive_scan(v.y, lds, tr);
-        const int2 carry = carry_s;
-        if (i < nent) bsums[i] = make_int2(carry.x + ec, carry.y + er);
+__global__ __launch_bounds__(1024) void cm_spine2_kernel(int2 *bsums, int nent) {
+    // chunks of 1024 entries, one per thread, the next chunk requested before this one is scanned; wave scans + the 16 wave
+    // totals (double-buffered): one barrier per chunk (until round 6: 256 threads, five barriers per 256 entries)
+    __shared__ int2 wtot[2][16];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    int2 carry = make_int2(0, 0);
+    int2 nxt = tid < nent ? bsums[tid] : make_int2(0, 0);
+    for (int base = 0, it = 0; base < nent; base += 1024, ++it) {
+        const int i = base + tid;
+        const int2 v = nxt;
+        nxt = i + 1024 < nent ? bsums[i + 1024] : make_int2(0, 0);
+        const int ic = wave_inclusive_scan(v.x), ir = wave_inclusive_scan(v.y);
+        if ((tid & 63) == 63) wtot[it & 1][wv] = make_int2(ic, ir);
         __syncthreads();
-        if (threadIdx.x == 0) carry_s = make_int2(carry.x + tc, carry.y + tr);
-        __syncthreads();
+        int2 off = carry, tot = make_int2(0, 0);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int2 s = wtot[it & 1][w];
+            off.x += w < wv ? s.x : 0;
+            off.y += w < wv ? s.y : 0;
+            tot.x += s.x;
+            tot.y += s.y;
+        }
+        if (i < nent) bsums[i] = make_int2(off.x + ic - v.x, off.y + ir - v.y);
+        carry.x += tot.x;
+        carry.y += tot.y;
     }
-    if (threadIdx.x == 0) bsums[nent] = carry_s;
+    if (tid == 0) bsums[nent] = carry;
 }
 
 // sum of entries [0, ent) (by the block itself, or read from the spine's exclusive prefixes)
@@ -818,7 +828,7 @@ bool cm_conv_ws(void *p, size_t bytes, int n, const ConvGeom &G, const CmGeom &C
 template <int KH, int KW>
 void cm_launch_count(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmConvSide &S, int cls_blocks, hipStream_t st) {
     cm_conv_count_kernel<KH, KW><<<L.ncellblk + cls_blocks, 256, 0, st>>>(C, L.ncellblk, in.cw, in.cr, L.bsums, S);
-    if (cm_spined(L.ncellblk * 4)) cm_spine2_kernel<<<1, 256, 0, st>>>(L.bsums, L.ncellblk * 4);
+    if (cm_spined(L.ncellblk * 4)) cm_spine2_kernel<<<1, 1024, 0, st>>>(L.bsums, L.ncellblk * 4);
 }
 
 template <int KH, int KW>
