@@ -49,7 +49,7 @@ struct OptRow {
 OptRow g_opts[PCD_OPT_COUNT] = {
     {"gg_resident_kb", 32}, {"ggw", 1}, {"gg1", 1}, {"subm_window", 23}, {"subm_window_wgrad", 6}, {"wg128", 1}, {"wg128_chunks", 512},
     {"wg_rows", 6144}, {"conv2d_wb", 1}, {"conv2d_wg_blocks", 128}, {"conv2d_wgp_mode2", 0}, {"conv2d_wgp_blocks", 512},
-    {"fps_g", 0}, {"gg_dbg", 0}, {"ggw_dbg", 0}, {"win_dbg", 0}, {"cm_direct_blocks", 4096}, {"subm_window_grid", 256}, {"ggwin", 0}, {"gg2", 0}, {"ggw_mi", 0}, {"ggw_cw", 2}, {"vox_emit_rows", 1}, {"vox_grid", 0}, {"subm_window_half", 0}, {"cm_emit_coop", 0},
+    {"fps_g", 0}, {"gg_dbg", 0}, {"ggw_dbg", 0}, {"win_dbg", 0}, {"cm_direct_blocks", 4096}, {"subm_window_grid", 256}, {"ggwin", 0}, {"gg2", 0}, {"ggw_mi", 0}, {"ggw_cw", 2}, {"vox_emit_rows", 1}, {"vox_grid", 0}, {"subm_window_half", 0},
 };
 }  // namespace
 int pcd_opt(int which) { return g_opts[which].value; }

@@ -181,36 +181,43 @@ __device__ __forceinline__ u64 in_union(const CmGeom &G, const uint2 *__restrict
     return m;
 }
 
-// in_union that also hands out the columns themselves: zq[q] = z mask of input column q (0: absent), fq[q] = its first row
-template <int KH, int KW>
-__device__ __forceinline__ u64 in_columns(const CmGeom &G, const uint2 *__restrict__ cw, const uint4 *__restrict__ cr, int b,
-                                          int oy, int ox, u64 (&zq)[KH * KW], int (&fq)[KH * KW]) {
-    uint2 w[KH * KW];
-    u32 key[KH * KW];
-    bool in[KH * KW];
+// in_union for NB cells at once: all their word loads, then all their record loads (a wave with more than 64 occupied cells
+// walks them 64 * NB at a time -- its run time is a chain of dependent round trips, one pair per batch otherwise)
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void in_union_n(const CmGeom &G, const uint2 *__restrict__ cw, const uint4 *__restrict__ cr,
+                                           const int (&b)[NB], const int (&oy)[NB], const int (&ox)[NB], const bool (&act)[NB],
+                                           u64 (&m)[NB]) {
+    uint2 w[NB][KH * KW];
+    u32 key[NB][KH * KW];
+    bool in[NB][KH * KW];
 #pragma unroll
-    for (int q = 0; q < KH * KW; ++q) {
-        const int y = oy * G.sh - G.ph + q / KW, x = ox * G.sw - G.pw + q % KW;
-        in[q] = y >= 0 && y < G.H && x >= 0 && x < G.W;
-        key[q] = in[q] ? bev_key(b, y, x, G.H, G.P) : 0u;
-        w[q] = cw[key[q] >> 5];
-    }
-    uint4 r[KH * KW];
+    for (int n = 0; n < NB; ++n)
 #pragma unroll
-    for (int q = 0; q < KH * KW; ++q) {
-        const int col = in[q] ? cm_col(w[q], key[q], G.ncol_cap_in) : -1;
-        in[q] = col >= 0;
-        r[q] = cr[in[q] ? col : 0];
-    }
-    u64 m = 0;
+        for (int q = 0; q < KH * KW; ++q) {
+            const int y = oy[n] * G.sh - G.ph + q / KW, x = ox[n] * G.sw - G.pw + q % KW;
+            in[n][q] = act[n] && y >= 0 && y < G.H && x >= 0 && x < G.W;
+            key[n][q] = in[n][q] ? bev_key(b[n], y, x, G.H, G.P) : 0u;
+            w[n][q] = cw[key[n][q] >> 5];
+        }
+    uint4 r[NB][KH * KW];
 #pragma unroll
-    for (int q = 0; q < KH * KW; ++q) {
-        zq[q] = in[q] ? ((u64)r[q].x | ((u64)r[q].y << 32)) : 0ull;
-        fq[q] = (int)r[q].z;
-        m |= zq[q];
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q) {
+            const int col = in[n][q] ? cm_col(w[n][q], key[n][q], G.ncol_cap_in) : -1;
+            in[n][q] = col >= 0;
+            r[n][q] = cr[in[n][q] ? col : 0];
+        }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        m[n] = 0;
+#pragma unroll
+        for (int q = 0; q < KH * KW; ++q)
+            if (in[n][q]) m[n] |= (u64)r[n][q].x | ((u64)r[n][q].y << 32);
     }
-    return m;
 }
+
+constexpr int CM_NB = 1;    // batches of 64 cells a wave has in flight (count and emit passes); 2 measured: no gain (288 against 279 us, level 2 at B = 32)
 
 struct CmConvSide {         // by-products of the count launch
     int *zero;              // words to zero (wsuper of the pair lists), spread over the cell blocks
@@ -266,12 +273,6 @@ __device__ __forceinline__ int kth_set_bit(u32 v, int k) {
         }
     }
     return pos;
-}
-
-__device__ __forceinline__ int kth_set_bit64(u64 v, int k) {
-    const u32 lo = (u32)v;
-    const int c = __popc(lo);
-    return k < c ? kth_set_bit(lo, k) : 32 + kth_set_bit((u32)(v >> 32), k - c);
 }
 
 // The occupied cells of a wave's 64 words, one per lane and round: lane `idx - base` of round `base` takes the idx-th
@@ -335,15 +336,28 @@ __global__ __launch_bounds__(256) void cm_conv_count_kernel(CmGeom G, int ncellb
     }
     const CmWaveCells Wc = cm_wave_cells(occ, occ_s[wave], excl_s[wave]);
     int rows = 0;
-    for (int base = 0; base < Wc.total; base += 64) {
-        const int idx = base + lane_id();
-        if (idx < Wc.total) {
-            int wl, bit;
-            cm_wave_cell(Wc, idx, wl, bit);
-            const int wd = word0 + wl, t = wd / wpr;
-            const u64 m = in_union<KH, KW>(G, cw, cr, t / G.Ho, t % G.Ho, ((wd % wpr) << 5) + bit);
-            rows += __popcll(squash_z(m, G));
+    for (int base = 0; base < Wc.total; base += 64 * CM_NB) {
+        int cb[CM_NB], coy[CM_NB], cox[CM_NB];
+        bool act[CM_NB];
+        u64 m[CM_NB];
+#pragma unroll
+        for (int n = 0; n < CM_NB; ++n) {
+            const int idx = base + n * 64 + lane_id();
+            act[n] = idx < Wc.total;
+            cb[n] = coy[n] = cox[n] = 0;
+            if (act[n]) {
+                int wl, bit;
+                cm_wave_cell(Wc, idx, wl, bit);
+                const int wd = word0 + wl, t = wd / wpr;
+                cb[n] = t / G.Ho;
+                coy[n] = t % G.Ho;
+                cox[n] = ((wd % wpr) << 5) + bit;
+            }
         }
+        in_union_n<KH, KW, CM_NB>(G, cw, cr, cb, coy, cox, act, m);
+#pragma unroll
+        for (int n = 0; n < CM_NB; ++n)
+            if (act[n]) rows += __popcll(squash_z(m[n], G));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) rows += __shfl_xor(rows, d, 64);
@@ -409,12 +423,6 @@ struct CmEmitSide {
     int *blk_cnt;           // parity classes: one extra block turns the counts into offsets
     int cls_nblk, ncls, cls_tile;
     int *vstart;
-    // row-cooperative emission: one lane per output row writes its coordinates (coalesced) and, with nbr_out_pk, the packed
-    // output-side neighbour table -- from the KH x KW input columns the wave looked up ONCE per output column
-    int coop;
-    u32 *nbr_out_pk;                    // [KH * KW][n_out], or nullptr
-    int n_in_cap;                       // input rows (capacity) and their device-side count
-    const int32_t *nn_in_dev;
 };
 
 // pass 2: the output map (words, column records), the output coordinates, the row count
@@ -428,12 +436,6 @@ __global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellbl
     __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
     __shared__ u32 occ_s[4][64];
     __shared__ int excl_s[4][64];
-    // row-cooperative emission (S.coop): a batch's columns, then one lane per OUTPUT ROW of the batch
-    __shared__ u64 zm_s[4][64];
-    __shared__ int rs_s[4][64 + 1];                       // first row of the column inside the batch (exclusive prefix), total
-    __shared__ int4 cell_s[4][64];                        // (b, oy, ox, -)
-    __shared__ u64 zq_s[4][KH * KW][64];                  // the KH x KW input columns of the output column: z mask ...
-    __shared__ int fq_s[4][KH * KW][64];                  // ... and first row
     if ((int)blockIdx.x >= ncellblk) {
         class_offsets(S.blk_cnt, S.cls_nblk, S.ncls, S.cls_tile, S.vstart, ctot, cstart);
         return;
@@ -471,104 +473,45 @@ __global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellbl
     const CmWaveCells Wc = cm_wave_cells(occ, occ_s[wave], excl_s[wave]);
     if (mine) cw_out[word] = make_uint2(occ, (u32)(base.x + excl_s[wave][lane_id()]));
     int row0 = base.y;
-    if (S.coop) {
-        const int nn_in = S.nn_in_dev ? eff_rows(S.nn_in_dev, S.n_in_cap) : S.n_in_cap;
-        for (int b0 = 0; b0 < Wc.total; b0 += 64) {
-            const int idx = b0 + lane_id();
-            u64 zm = 0;
-            int b = 0, oy = 0, ox = 0;
-            u64 zq[KH * KW];
-            int fq[KH * KW];
+    for (int b0 = 0; b0 < Wc.total; b0 += 64 * CM_NB) {
+        int cb[CM_NB], coy[CM_NB], cox[CM_NB];
+        bool act[CM_NB];
+        u64 mu[CM_NB];
 #pragma unroll
-            for (int q = 0; q < KH * KW; ++q) zq[q] = 0, fq[q] = 0;
-            if (idx < Wc.total) {
+        for (int n = 0; n < CM_NB; ++n) {
+            const int idx = b0 + n * 64 + lane_id();
+            act[n] = idx < Wc.total;
+            cb[n] = coy[n] = cox[n] = 0;
+            if (act[n]) {
                 int wl, bit;
                 cm_wave_cell(Wc, idx, wl, bit);
                 const int wd = word0 + wl, t = wd / wpr;
-                b = t / G.Ho;
-                oy = t % G.Ho;
-                ox = ((wd % wpr) << 5) + bit;
-                zm = squash_z(in_columns<KH, KW>(G, cw, cr, b, oy, ox, zq, fq), G);
+                cb[n] = t / G.Ho;
+                coy[n] = t % G.Ho;
+                cox[n] = ((wd % wpr) << 5) + bit;
             }
+        }
+        in_union_n<KH, KW, CM_NB>(G, cw, cr, cb, coy, cox, act, mu);
+#pragma unroll
+        for (int n = 0; n < CM_NB; ++n) {
+            const int idx = b0 + n * 64 + lane_id();
+            const u64 zm = act[n] ? squash_z(mu[n], G) : 0ull;
             const int cnt = __popcll(zm);
             const int inc = wave_inclusive_scan(cnt);
-            const int T = __shfl(inc, 63);
-            if (idx < Wc.total) {
+            const int start = row0 + inc - cnt;
+            row0 += __shfl(inc, 63);
+            if (act[n]) {
                 const int col = base.x + idx;
-                if (col < G.ncol_cap_out) cr_out[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)(row0 + inc - cnt), (u32)cnt);
-            }
-            zm_s[wave][lane_id()] = zm;
-            rs_s[wave][lane_id()] = inc - cnt;
-            if (lane_id() == 63) rs_s[wave][64] = T;
-            cell_s[wave][lane_id()] = make_int4(b, oy, ox, 0);
-#pragma unroll
-            for (int q = 0; q < KH * KW; ++q) {
-                zq_s[wave][q][lane_id()] = zq[q];
-                fq_s[wave][q][lane_id()] = fq[q];
-            }
-            __builtin_amdgcn_wave_barrier();              // (one wave: LDS accesses are in program order)
-            for (int t = lane_id(); t < T; t += 64) {
-                int lo = 0;                               // the column that owns row t of the batch: largest l with rs[l] <= t
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (rs_s[wave][lo + step] <= t) lo += step;       // (empty columns repeat their successor's prefix: skipped)
-                const u64 zmo = zm_s[wave][lo];
-                const int z = kth_set_bit64(zmo, t - rs_s[wave][lo]);
-                const int4 cell = cell_s[wave][lo];
-                const int r = row0 + t;
-                if (r < n_out) {
-                    if (out_indices) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(cell.x, z, cell.y, cell.z);
-                    if (S.nbr_out_pk) {
-#pragma unroll
-                        for (int q = 0; q < KH * KW; ++q) {
-                            const u64 m = zq_s[wave][q][lo];
-                            u32 pk = 0;
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                const int zi = z * G.sd - G.pd + a;
-                                if (zi >= 0 && zi < G.D && ((m >> zi) & 1ull)) {
-                                    const int row = fq_s[wave][q][lo] + __popcll(m & ((1ull << zi) - 1ull));
-                                    if (row < nn_in) pk = (pk >> 29) ? (pk | (1u << (29 + a))) : ((u32)row | (1u << (29 + a)));
-                                }
-                            }
-                            S.nbr_out_pk[(size_t)q * n_out + r] = pk;
-                        }
+                if (col < G.ncol_cap_out) cr_out[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)start, (u32)cnt);
+                if (out_indices) {
+                    int r = start;
+                    u64 m = zm;
+                    while (m) {
+                        const int z = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        if (r < n_out) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(cb[n], z, coy[n], cox[n]);
+                        ++r;
                     }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            row0 += T;
-        }
-        return;
-    }
-    for (int b0 = 0; b0 < Wc.total; b0 += 64) {
-        const int idx = b0 + lane_id();
-        u64 zm = 0;
-        int b = 0, oy = 0, ox = 0;
-        if (idx < Wc.total) {
-            int wl, bit;
-            cm_wave_cell(Wc, idx, wl, bit);
-            const int wd = word0 + wl, t = wd / wpr;
-            b = t / G.Ho;
-            oy = t % G.Ho;
-            ox = ((wd % wpr) << 5) + bit;
-            zm = squash_z(in_union<KH, KW>(G, cw, cr, b, oy, ox), G);
-        }
-        const int cnt = __popcll(zm);
-        const int inc = wave_inclusive_scan(cnt);
-        const int start = row0 + inc - cnt;
-        row0 += __shfl(inc, 63);
-        if (idx < Wc.total) {
-            const int col = base.x + idx;
-            if (col < G.ncol_cap_out) cr_out[col] = make_uint4((u32)zm, (u32)(zm >> 32), (u32)start, (u32)cnt);
-            if (out_indices) {
-                int r = start;
-                u64 m = zm;
-                while (m) {
-                    const int z = __ffsll((unsigned long long)m) - 1;
-                    m &= m - 1;
-                    if (r < n_out) reinterpret_cast<int4 *>(out_indices)[r] = make_int4(b, z, oy, ox);
-                    ++r;
                 }
             }
         }
@@ -591,7 +534,6 @@ struct CmTablesSide {
     int32_t *nbr_cls;
     int vcap;
     u32 *nbr_out_pk;
-    bool skip_out;          // no output-side blocks at all (the emit pass wrote nbr_out_pk)
 };
 
 // row of kz = a (0..2) from a packed word, or -1
@@ -989,7 +931,7 @@ void cm_emit(const CmConvCall &X, int32_t *out_indices, int n_out, int32_t *n_ou
 
 void cm_tables(const CmConvCall &X, const int32_t *indices, int n, const int32_t *n_dev, const int32_t *out_indices, int n_out,
                const int32_t *n_out_dev, int32_t *nbr_in, int32_t *nbr_out, const CmTablesSide &S, hipStream_t st) {
-    const int nb_out = S.skip_out ? 0 : pcd_div_up(n_out, 256), nb_in = pcd_div_up(n, 256);
+    const int nb_out = pcd_div_up(n_out, 256), nb_in = pcd_div_up(n, 256);
     if (X.G.kh == 3)
         cm_conv_tables_kernel<3, 3, 3><<<nb_out + nb_in, 256, 0, st>>>(X.C, nb_out, (const int4 *)indices, n, n_dev,
                                                                        (const int4 *)out_indices, n_out, n_out_dev, X.in.cw,
@@ -1085,13 +1027,6 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
         E.cls_tile = cls_tile;
         E.vstart = vstart_dev;
     }
-    // option "cm_emit_coop": 1 = one lane per output ROW writes the coordinates; 2 = ... and the packed output-side table, from
-    // the input columns the wave looked up once per output column (the tables launch below then has no output-side half)
-    const bool pk_in_emit = nbr_out_pk && !nbr_out && pcd_opt(PCD_OPT_CM_EMIT_COOP) >= 2;
-    E.coop = pcd_opt(PCD_OPT_CM_EMIT_COOP) >= 1;
-    E.nbr_out_pk = pk_in_emit ? nbr_out_pk : nullptr;
-    E.n_in_cap = n;
-    E.nn_in_dev = n_dev;
     cm_emit(X, out_indices, n_out_cap, n_out_dev, E, st);
     CmTablesSide T = {};
     if (pairs) {
@@ -1107,8 +1042,7 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
     }
     T.nbr_cls = nbr_cls;
     T.vcap = vcap;
-    T.nbr_out_pk = pk_in_emit ? nullptr : nbr_out_pk;
-    T.skip_out = pk_in_emit;
+    T.nbr_out_pk = nbr_out_pk;
     cm_tables(X, indices, n, n_dev, out_indices, n_out_cap, n_out_dev, nbr_in, nbr_out, T, st);
     if (pairs) {
         if (pad_pairs) pcd_fill(pairs, 0xFF, (size_t)X.G.K * 2 * n * sizeof(int32_t), st);

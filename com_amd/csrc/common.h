@@ -25,7 +25,7 @@ extern "C" void pcd_set_last_hip_error(int code);
 enum PcdOpt {
     PCD_OPT_GG_RESIDENT_KB, PCD_OPT_GGW, PCD_OPT_GG1, PCD_OPT_SUBM_WINDOW, PCD_OPT_SUBM_WINDOW_WGRAD, PCD_OPT_WG128, PCD_OPT_WG128_CHUNKS,
     PCD_OPT_WG_ROWS, PCD_OPT_CONV2D_WB, PCD_OPT_CONV2D_WG_BLOCKS, PCD_OPT_CONV2D_WGP_MODE2, PCD_OPT_CONV2D_WGP_BLOCKS,
-    PCD_OPT_FPS_G, PCD_OPT_GG_DBG, PCD_OPT_GGW_DBG, PCD_OPT_WIN_DBG, PCD_OPT_CM_DIRECT_BLOCKS, PCD_OPT_SUBM_WINDOW_GRID, PCD_OPT_GGWIN, PCD_OPT_GG2, PCD_OPT_GGW_MI, PCD_OPT_GGW_CW, PCD_OPT_VOX_EMIT_ROWS, PCD_OPT_VOX_GRID, PCD_OPT_SUBM_WINDOW_HALF, PCD_OPT_CM_EMIT_COOP, PCD_OPT_COUNT
+    PCD_OPT_FPS_G, PCD_OPT_GG_DBG, PCD_OPT_GGW_DBG, PCD_OPT_WIN_DBG, PCD_OPT_CM_DIRECT_BLOCKS, PCD_OPT_SUBM_WINDOW_GRID, PCD_OPT_GGWIN, PCD_OPT_GG2, PCD_OPT_GGW_MI, PCD_OPT_GGW_CW, PCD_OPT_VOX_EMIT_ROWS, PCD_OPT_VOX_GRID, PCD_OPT_SUBM_WINDOW_HALF, PCD_OPT_COUNT
 };
 int pcd_opt(int which);
 

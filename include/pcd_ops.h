@@ -98,11 +98,7 @@ int pcd_stream_capture_id(void *stream, unsigned long long *id_out);
  *   "subm_window_grid" 256   workgroups of a window launch (a multiple of 8, <= 256); fewer leave CUs to other streams --
  *                         measured: no gain (240 / 224 / 192: 0 / -0.5 / -1 % in the step)
  *   "cm_direct_blocks" 4096   column-map builds: up to this many scan blocks add up the block sums themselves, beyond it a
- *                             spine launch runs (tests lower it to reach the spine path on small inputs)
- *   "cm_emit_coop" 0          strided column-map builds, the emit pass: 0 = one lane per output COLUMN loops over its rows;
- *                             1 = one lane per output ROW writes the coordinates (coalesced); 2 = ... and the packed output-side
- *                             table of the compact build too.  Measured (tools/ab_emit.sh): 1 = 0 within noise, 2 costs 0.03 ms
- *                             per step at B = 4 (the pass has one wave per SIMD there) and gains 3 % of the chain at B = 32 */
+ *                             spine launch runs (tests lower it to reach the spine path on small inputs) */
 int pcd_set_option(const char *key, int value);
 int pcd_get_option(const char *key, int *value_out);
 

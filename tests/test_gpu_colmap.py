@@ -215,14 +215,11 @@ def test_tiny_border_and_dense_inputs():
                 _check_subm_cm(rb.out_indices, batch, rb.out_shape, rb.rank)
 
 
-@pytest.mark.parametrize("emit_coop", [0, 1])
-def test_random_grids_and_geometries(pcd_option, emit_coop):
-    """(emit_coop: the emit pass with one lane per output column -- the default -- and with one lane per output row.)
-    Forty random cases: grid sizes whose width is / is not a multiple of 32 (the maps pad the BEV row pitch), 1-3 frames,
+def test_random_grids_and_geometries():
+    """Forty random cases: grid sizes whose width is / is not a multiple of 32 (the maps pad the BEV row pitch), 1-3 frames,
     occupancies from 0.1 % to 60 %, every kernel / stride / padding combination the column-map builds cover -- each strided
     build and the SubM rulebook of its output level against the oracle, bit for bit."""
     ops = _ops()
-    pcd_option("cm_emit_coop", emit_coop)
     rng = np.random.default_rng(2025)
     ran = 0
     for case in range(40):
