@@ -542,7 +542,7 @@ class Rulebook:
             self._pairs = torch.empty((self.kvol, 2, n), dtype=torch.int32, device=dev)
             self._pair_num = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
             ws = _ws(lib.pcd_rulebook_subm_pairs_workspace_bytes(n, self.kvol), dev)
-            L.check(lib.pcd_rulebook_conv_pairs(L.ptr(self.nbr_in), n, self.kvol, L.ptr(self._pairs), L.ptr(self._pair_num), 0,
+            L.check(lib.pcd_rulebook_conv_pairs(L.ptr(self.nbr_in), n, self.kvol, L.ptr(self._pairs), L.ptr(self._pair_num), 1,
                                                 L.ptr(self.n_in_dev), L.ptr(ws), ws.numel(), L.stream_ptr()),
                     "pcd_rulebook_conv_pairs")
 

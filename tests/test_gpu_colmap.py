@@ -106,6 +106,32 @@ def test_waymo_chain_from_column_maps_bit_exact():
         idx_t, cmap, shape = rb.out_indices, rb.rank, tuple(rb.out_shape)
 
 
+def test_waymo_chain_with_compact_tables_against_the_oracle():
+    """The same two full frames with the strided rulebooks built as the training step builds them -- static plan, no pair
+    lists, compact tables only (pcd_rulebook_conv_cm_build_compact) -- and everything the oracle defines checked on the
+    EXPANDED tables and the DERIVED pair lists: out_indices, nbr_out, nbr_in, indice_pairs, indice_pair_num, bit for bit."""
+    from com_amd.hotpath import collate_points
+    ops = _ops()
+    frames = [synth.synth_cloud(f) for f in (0, 1)]
+    pts, offs = collate_points(frames, DEV)
+    shape = (41, 1504, 1504)
+    res = ops.voxelize_hard(pts, offs, synth.WAYMO_RANGE, synth.WAYMO_VOXEL, 5, 150000, feat_offset=1, num_features=5,
+                            want_voxels=False, row_order="yxz", key_depth=41)
+    idx_t, cmap = res["coords"], res["rank"]
+    n_dev, n_real = None, idx_t.shape[0]
+    for lvl, geo in enumerate(CHAIN[:3]):
+        m = O.rulebook_conv(_cpu(idx_t)[:n_real], tuple(shape), geo["k"], geo["s"], geo["p"])["n_out"]
+        plan = ops.StaticPlan()
+        plan.observe(("conv", lvl), m)                    # (capacity = 1.25 x the count, rounded: the levels below run on padded tensors)
+        plan.active = True
+        with plan:
+            rb, _ = _check_conv_cm(idx_t, 2, shape, geo, cmap, n_dev=n_dev, n_real=n_real, pair_lists=False, compact=True,
+                                   plan_key=("conv", lvl))
+            plan.check()
+        assert rb.nbr_out_packed is not None and rb.nbr_cls is not None and rb.implicit_pairs and rb.n_out > m
+        idx_t, cmap, shape, n_dev, n_real = rb.out_indices, rb.rank, tuple(rb.out_shape), rb.n_out_dev, m
+
+
 def test_golden_grid_from_column_maps(golden):
     """Fixture G3 (reduced grid; out_indices pinned by fp64 dense conv3d): level-1 map from the sorted rows, the three
     geometries, and the SubM rulebook of every output level."""
