@@ -420,10 +420,37 @@ __global__ __launch_bounds__(256) void cm_total_kernel(const int2 *__restrict__ 
 struct CmEmitSide {
     void *fill_a;           // 0xFF fill (perm of the parity classes), spread over the cell blocks
     size_t fill_a_bytes;
-    int *blk_cnt;           // parity classes: one extra block turns the counts into offsets
+    int *blk_cnt;           // parity classes: `ncls` extra blocks, one per class, turn the class's counts into exclusive prefixes
     int cls_nblk, ncls, cls_tile;
-    int *vstart;
+    int *cls_tot;           // [CLS_MAX] rows per class (the tables launch turns them into the class starts and writes vstart)
 };
+
+// blk_cnt[cls][0 .. nblk) -> exclusive prefix in place, tot[cls] = the sum: one block of 256 threads per class, 2048 counts per
+// round (8 consecutive per thread).  (Until round 6 ONE extra block did all classes, a wave per class and 512 counts per
+// round: 120 us at B = 32 -- the emit launch lasted exactly as long as that block, whatever its cell blocks did.)
+__device__ void class_prefix_block(int *__restrict__ row, int nblk, int *__restrict__ tot, int *lds /* [4] */) {
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 2048) {
+        const int i0 = base + threadIdx.x * 8;
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = i0 + j < nblk ? row[i0 + j] : 0;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = v[j];
+            v[j] = sum;
+            sum += t;
+        }
+        int total;
+        const int ex = block_exclusive_scan(sum, lds, total);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j < nblk) row[i0 + j] = carry + ex + v[j];
+        carry += total;
+    }
+    if (threadIdx.x == 0) *tot = carry;
+}
 
 // pass 2: the output map (words, column records), the output coordinates, the row count
 template <int KH, int KW>
@@ -433,11 +460,11 @@ __global__ __launch_bounds__(256) void cm_conv_emit_kernel(CmGeom G, int ncellbl
                                                            int *__restrict__ ncols_out, int32_t *__restrict__ out_indices,
                                                            int n_out, int *__restrict__ n_out_dev, CmEmitSide S) {
     __shared__ int lds[4];
-    __shared__ int ctot[CLS_MAX], cstart[CLS_MAX + 1];
     __shared__ u32 occ_s[4][64];
     __shared__ int excl_s[4][64];
     if ((int)blockIdx.x >= ncellblk) {
-        class_offsets(S.blk_cnt, S.cls_nblk, S.ncls, S.cls_tile, S.vstart, ctot, cstart);
+        const int q = (int)blockIdx.x - ncellblk;
+        class_prefix_block(S.blk_cnt + (size_t)q * S.cls_nblk, S.cls_nblk, S.cls_tot + q, lds);
         return;
     }
     if (S.fill_a) fill_ff(S.fill_a, S.fill_a_bytes, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)ncellblk * 256);
@@ -524,7 +551,10 @@ struct CmTablesSide {
     int *wsuper;            // ... and per 64 waves (zeroed by the count launch)
     int nws;
     int ncls;               // parity classes: permutation of the input rows
-    const int *blk_off;
+    const int *blk_off;     // [ncls][nclsblk] exclusive prefixes inside each class (the emit launch's class blocks)
+    const int *cls_tot;     // [ncls] rows per class -> tile-aligned class starts (every block; block nb_out also writes vstart)
+    int cls_tile;
+    int *vstart;
     int32_t *perm;
     // compact tables (the training step's form; nbr_in / nbr_out may then be nullptr):
     //  nbr_cls [8][vcap]: entry (j, v) = output row of the input row at permutation slot v through the j-th offset its class can
@@ -599,7 +629,18 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
     }
     __shared__ int wcnt[4][CLS_MAX];
     __shared__ int blk_sum[K];
+    __shared__ int cstart_s[CLS_MAX + 1];
     const int blk = (int)blockIdx.x - nb_out;
+    if (S.perm && threadIdx.x == 0) {
+        int vb = 0;
+        for (int q = 0; q < S.ncls; ++q) {
+            cstart_s[q] = vb;
+            vb = (vb + S.cls_tot[q] + S.cls_tile - 1) / S.cls_tile * S.cls_tile;
+        }
+        cstart_s[S.ncls] = vb;
+        if (blk == 0)
+            for (int q = 0; q <= S.ncls; ++q) S.vstart[q] = cstart_s[q];
+    }
     const int i = blk * 256 + threadIdx.x;
     const bool live = i < nn_in;
     const int4 c = live ? idx[i] : make_int4(0, 0, 0, 0);
@@ -624,7 +665,7 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
             int before = 0;
             for (int ww = 0; ww < wv; ++ww) before += wcnt[ww][cls];
             const int nclsblk = (int)gridDim.x - nb_out;
-            vslot = S.blk_off[(size_t)cls * nclsblk + blk] + before + rank;
+            vslot = cstart_s[cls] + S.blk_off[(size_t)cls * nclsblk + blk] + before + rank;
             S.perm[vslot] = i;
         }
     }
@@ -731,7 +772,7 @@ __global__ __launch_bounds__(256) void cm_conv_tables_kernel(CmGeom G, int nb_ou
 // ---- host side -------------------------------------------------------------------------------------------------
 struct CmConvWs {
     int2 *bsums;            // per wave of 64 output words: { occupied cells, rows }
-    int *wsuper, *wave_cnt, *blk_cnt;
+    int *wsuper, *wave_cnt, *blk_cnt, *cls_tot;
     int ncellblk, nwaves, nws, nclsblk;
 };
 
@@ -763,6 +804,7 @@ bool cm_conv_ws(void *p, size_t bytes, int n, const ConvGeom &G, const CmGeom &C
     L.wsuper = ws.take<int>((size_t)G.K * L.nws);
     L.wave_cnt = ws.take<int>((size_t)G.K * L.nwaves);
     L.blk_cnt = ws.take<int>((size_t)CLS_MAX * L.nclsblk);
+    L.cls_tot = ws.take<int>(CLS_MAX);
     if (need) *need = ws.off;
     return p == nullptr || ws.ok;
 }
@@ -776,7 +818,7 @@ void cm_launch_count(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const 
 template <int KH, int KW>
 void cm_launch_emit(const CmGeom &C, const CmConvWs &L, const CmBuf &in, const CmBuf &out, int32_t *out_indices, int n_out,
                     int32_t *n_out_dev, const CmEmitSide &S, hipStream_t st) {
-    cm_conv_emit_kernel<KH, KW><<<L.ncellblk + (S.blk_cnt ? 1 : 0), 256, 0, st>>>(
+    cm_conv_emit_kernel<KH, KW><<<L.ncellblk + (S.blk_cnt ? S.ncls : 0), 256, 0, st>>>(
         C, L.ncellblk, in.cw, in.cr, L.bsums, cm_spined(L.ncellblk * 4), out.cw, out.cr, out.ncols, out_indices, n_out,
         n_out_dev, S);
 }
@@ -1025,7 +1067,7 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
         E.cls_nblk = L.nclsblk;
         E.ncls = ncls;
         E.cls_tile = cls_tile;
-        E.vstart = vstart_dev;
+        E.cls_tot = L.cls_tot;
     }
     cm_emit(X, out_indices, n_out_cap, n_out_dev, E, st);
     CmTablesSide T = {};
@@ -1038,6 +1080,9 @@ static int cm_conv_build_impl(const int32_t *indices, int n, int batch, const in
     if (classes) {
         T.ncls = ncls;
         T.blk_off = L.blk_cnt;
+        T.cls_tot = L.cls_tot;
+        T.cls_tile = cls_tile;
+        T.vstart = vstart_dev;
         T.perm = perm;
     }
     T.nbr_cls = nbr_cls;
