@@ -635,6 +635,14 @@ __global__ __launch_bounds__(1024) void col_rows_finalize_kernel(ColJobs jobs) {
     double a = 0.0;
     if (ch < c) {
         int blk = slice;
+        // (a chain of load latencies on the main stream at the end of the backward pass: 16 loads in flight, same order of sums)
+        for (; blk + 15 * slices < nblocks; blk += 16 * slices) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(blk + u * slices) * c + ch];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += (double)v[u];
+        }
         for (; blk + 7 * slices < nblocks; blk += 8 * slices) {
             float v[8];
 #pragma unroll

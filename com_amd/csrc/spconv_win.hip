@@ -362,6 +362,8 @@ template <class C>
 __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan_base, int n_cap, const int32_t *__restrict__ n_dev,
                                                          int ntiles_cap, int grid) {
     __shared__ int wtot[2][16];
+    constexpr int PFX_LDS = 8192;                         // the prefix also stays in LDS when it fits: the share boundaries are
+    __shared__ int pfx_s[PFX_LDS];                        // binary searches -- log2(tiles) DEPENDENT reads each, L2 hits otherwise
     __shared__ int bnd[WIN_GRID_MAX + 1];
     __shared__ int bndw[WIN_WG_SHARES_MAX + 1];
     const int tid = threadIdx.x;
@@ -390,9 +392,13 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
             off += i < wv ? s : 0;
             tot += s;
         }
-        if (t < nt) prefix[t] = off + inc;
+        if (t < nt) {
+            prefix[t] = off + inc;
+            if (t < PFX_LDS) pfx_s[t] = off + inc;
+        }
         carry += tot;
     }
+    const bool in_lds = nt <= PFX_LDS;
     const long long total = carry;
     __threadfence_block();
     __syncthreads();
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         int lo = 0, hi = nt;                          // number of tiles with prefix <= target
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
+            if ((long long)(in_lds ? pfx_s[mid] : prefix[mid]) <= target) lo = mid + 1; else hi = mid;
         }
         bnd[j] = j == NSH ? nt : lo;
     }
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(1024) void win_split_kernel(char *__restrict__ plan
         int lo = 0, hi = nt;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if ((long long)prefix[mid] <= target) lo = mid + 1; else hi = mid;
+            if ((long long)(in_lds ? pfx_s[mid] : prefix[mid]) <= target) lo = mid + 1; else hi = mid;
         }
         bndw[j] = j == C::WG_SHARES ? nt : lo;
     }
