@@ -939,15 +939,38 @@ __global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kern
     int *nbr_s = row_s + ROWS;                             // [8 + 1][ROWS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rl = lane & 15, g = lane >> 4;
-    const int tile = xcd_tile(vstart[T.ncls], ROWS);       // contiguous runs of the REAL tiles per XCD
-    const int v0 = tile * ROWS;
-    if (v0 >= vstart[T.ncls]) {
+    // Workgroup b runs on XCD b % 8.  The classes differ 8 x in work per tile (1 .. 8 usable offsets) and the virtual rows are
+    // ordered by class, so contiguous runs of tiles per XCD -- the generic kernels' rule, used here until round 6 -- gave XCD 0
+    // the 8-offset class and XCD 7 the 1-offset class: the launch lasted 8 / 3.4 = 2.4 x the balanced time.  Now XCD x takes the
+    // x-th EIGHTH of every class's tiles: equal work, and the same spatial eighth of all classes (they gather the same dy
+    // neighbourhood) in one L2.  The BatchNorm partial row of a workgroup is its block index (any bijection onto the grid works).
+    const int tile = blockIdx.x;
+    int v0 = -1, cls_v = 0;
+    if (compact & 2) {                                     // (ablation, option "gg_dbg" bit 8: contiguous runs of tiles per XCD)
+        const int t = xcd_tile(vstart[T.ncls], ROWS);
+        if (t * ROWS < vstart[T.ncls]) {
+            v0 = t * ROWS;
+            for (int q = 1; q < T.ncls; ++q)
+                if (vstart[q] <= v0) cls_v = q;
+        }
+    } else {
+        const int xcd = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        for (int q = 0; q < T.ncls; ++q) {
+            const int t0 = vstart[q] / ROWS, tc = vstart[q + 1] / ROWS - t0;     // (class starts are multiples of the class tile >= ROWS)
+            const int lo = (xcd * tc) >> 3, hi = ((xcd + 1) * tc) >> 3;
+            if (j < hi - lo) {
+                v0 = (t0 + lo + j) * ROWS;
+                cls_v = q;
+                break;
+            }
+            j -= hi - lo;
+        }
+    }
+    if (v0 < 0) {
         if (bn.mode) bnred_zero_row(bn, tile, c_out);
         return;
     }
-    int cls_v = 0;
-    for (int q = 1; q < T.ncls; ++q)
-        if (vstart[q] <= v0) cls_v = q;
     // the class is uniform over the workgroup: keep it in an SGPR so that the by-value table is read with scalar
     // loads (a divergent index would make the compiler copy the whole struct to scratch memory per thread)
     const int cls = __builtin_amdgcn_readfirstlane(cls_v);
@@ -975,7 +998,7 @@ __global__ __launch_bounds__(256, gg_waves(NB, MI, 1)) void gather_gemm_cls_kern
         const int j = e / ROWS, r = e - j * ROWS;
         const int i = row_s[r];
         // (compact: the class-compact table nbr_cls [8][nbr_stride], indexed by permutation slot -- coalesced, no gather)
-        nbr_s[e] = (j < nk && i >= 0) ? (compact ? nbr[(size_t)j * nbr_stride + v0 + r] : nbr[(size_t)kk_s[j] * nbr_stride + i]) : -1;
+        nbr_s[e] = (j < nk && i >= 0) ? ((compact & 1) ? nbr[(size_t)j * nbr_stride + v0 + r] : nbr[(size_t)kk_s[j] * nbr_stride + i]) : -1;
     }
     u32x4 wreg[WPT];
     auto load_w = [&](int s) {
@@ -1055,7 +1078,7 @@ static int launch_gg_cls(const void *x, int c_in, int cshift, const void *wp, co
                          int y_dtype, int nsteps, unsigned x_bytes, hipStream_t st, const void *addend,
                          const PcdBnReduce *bnr, int *tiles_only, int compact) {
     constexpr int ROWS = 4 * MI * 16;
-    int grid = pcd_div_up(pcd_div_up(vcap, ROWS), 8) * 8;
+    int grid = (pcd_div_up(pcd_div_up(vcap, ROWS), 8) + 8) * 8;       // (+ 8 per XCD: its eighths of up to 8 classes round up)
     if (tiles_only) {
         *tiles_only = grid;
         return PCD_OK;
@@ -2031,7 +2054,7 @@ static int cls_mi(int n_rows_in) { return n_rows_in >= 64 * 1024 ? 2 : 1; }
 extern "C" int pcd_sparse_conv_dgrad_classes_tiles(int vcap, int n_rows_in) {
     if (vcap < 0 || n_rows_in < 0) return PCD_ERR_INVALID_ARG;
     if (vcap == 0 || n_rows_in == 0) return 0;
-    return pcd_div_up(pcd_div_up(vcap, 64 * cls_mi(n_rows_in)), 8) * 8;
+    return (pcd_div_up(pcd_div_up(vcap, 64 * cls_mi(n_rows_in)), 8) + 8) * 8;
 }
 
 extern "C" int pcd_sparse_conv_dgrad_classes(const void *dy, int n_dy_rows, int c_dy, const void *packed_w,
@@ -2074,7 +2097,7 @@ extern "C" int pcd_sparse_conv_dgrad_classes_v2(const void *dy, int n_dy_rows, i
     // flight) hide its prologue better than the generic kernel's row-count rule
     const int mi = cls_mi(n_rows_in);
     int *tiles_only = nullptr;
-    const int compact = nbr_compact ? 1 : 0;
+    const int compact = (nbr_compact ? 1 : 0) | ((pcd_opt(PCD_OPT_GG_DBG) & 256) ? 2 : 0);
 #define CLS_ARGS dy, c_dy, cshift, packed_w, nbr_in, nbr_stride, K, perm, vstart_dev, T, vcap, dx, dx_dtype, nsteps, x_bytes, st, addend, bn_reduce, tiles_only, compact
 #define CLS_MI(NBV) (mi == 4 ? launch_gg_cls<NBV, 4>(CLS_ARGS) : mi == 2 ? launch_gg_cls<NBV, 2>(CLS_ARGS) : launch_gg_cls<NBV, 1>(CLS_ARGS))
     switch (c_in / 16) {
