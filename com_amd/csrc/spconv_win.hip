@@ -635,7 +635,8 @@ __global__ __launch_bounds__(C::THREADS, C::NW == 8 ? 1 : 2) void subm_win_kerne
         } else if (wave8 + C::NW * (slot - 3 * SPR) < C::NTABI && pass == 0) {
             const int piece = wave8 + C::NW * (slot - 3 * SPR);
             win_glds16(tdma, lds0 + (unsigned)(C::TAB0 + buf * C::TABB + piece * 1024),
-                       (unsigned)tile * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
+                       (unsigned)((dbg & 16) ? 0 : tile) * (unsigned)C::TABB + (unsigned)(piece * 1024) + (unsigned)lane * 16u);
+            // (dbg & 16, ablation: every tile fetches tile 0's table -- always hot; wrong results, the time of a free table)
         }
     };
 

@@ -46,6 +46,29 @@ def timeit(fn, iters=30):
     return t0.elapsed_time(t1) / iters * 1e3
 
 
+_scratch = None
+
+
+def timeit_cold(fn, iters=12, mb=1024):
+    """One launch at a time behind a `mb`-MB fill (L2 and the 256 MB MALL hold nothing of the conv's inputs, plan or weights):
+    what a conv of the training step sees -- its input was written two launches ago, its plan a millisecond ago."""
+    global _scratch
+    if _scratch is None or _scratch.numel() != mb << 20:
+        _scratch = torch.empty((mb << 20,), dtype=torch.uint8, device=dev)
+    tot = 0.0
+    for i in range(iters + 2):
+        _scratch.fill_(i & 255)
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        fn()
+        t1.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tot += t0.elapsed_time(t1)
+    return tot / iters * 1e3
+
+
 want = sys.argv[1] if len(sys.argv) > 1 else "23"
 for lvl in (1, 2, 3, 4):
     if str(lvl) not in want:
@@ -87,6 +110,10 @@ for lvl in (1, 2, 3, 4):
         scale = y0.float().abs().max().item()
         t_gen = timeit(lambda: ops.gather_gemm(x, pk, b_, rb.nbr_out, 27, flip, n, ch, torch.bfloat16, addend=a_))
         t_win = timeit(lambda: ops.subm_window(x, pw, b_, rb, ch, addend=a_))
+        if os.environ.get("WIN_COLD"):
+            t_cold = timeit_cold(lambda: ops.subm_window(x, pw, b_, rb, ch, addend=a_))
+            t_empty = timeit_cold(lambda: None)
+            print(f"   cold caches (one launch behind a 1 GB fill): window {t_cold:.1f} us (event pair alone: {t_empty:.1f} us); warm loop {t_win:.1f} us")
         fl = 2.0 * pairs * ch * ch
         print(f"level {lvl} {ch}->{ch} rows {n} pairs {pairs} {name}: max|diff| {d.max().item():.4g} (scale {scale:.3g}, "
               f"mismatching elements {(d > 0).float().mean().item():.4f}) generic {t_gen:.1f} us, window {t_win:.1f} us "
